@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the ray -> tetrahedra hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input: trace_rays over one
+800x800 frame (640,000 rays, M = 512) through the 100k-tetrahedra stand-in of BASELINE.json's
+configs[1] ("lego sparse 100k"; dataset unavailable).  Inputs are resident in
+HBM before the timed region.  Multi-GPU: rays are independent units -- every rank traces its
+own frame (camera rotated per rank), no data-path collective; scaling = weak.
+
+Prints ONE JSON line on rank 0 (see the driver contract): metric/value = whole-job ray-tet
+intersections per second, plus `roofline` (dense-output HBM bytes of the dominant kernel over
+its HIP-event duration) and `cpu_baseline` (the CPU oracle's BVH path on a bounded sample of
+the same rays, all host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (6290 GB/s measured copy ceiling), MI355X_MICROARCH.md:35
+
+
+def frame_rays(scenes, rank: int, width: int, height: int):
+    ang = rank * math.pi / 4.0
+    c = np.array([0.5, 0.5, 0.5], np.float32)
+    eye = c + 2.0 * np.array([math.sin(ang), math.cos(ang), 0.0], np.float32)
+    return scenes.pinhole_rays(width, height, eye=tuple(eye), lookat=tuple(c), up=(0.0, 0.0, 1.0), fov_y=45.0)
+
+
+def cpu_baseline(pts, cells, o, d, M, target_s=12.0):
+    """Oracle (BVH all-hits + sort + pairing, OpenMP) on a bounded sample of the bench rays."""
+    from oracle import tn_oracle
+
+    ot = tn_oracle.OracleTracer(use_bvh=True)
+    ot.load_tetrahedra(pts, cells)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(o))
+    probe = perm[:2048]
+    t0 = time.perf_counter()
+    ot.trace_rays(o[probe], d[probe], M)
+    rate = len(probe) / max(time.perf_counter() - t0, 1e-6)
+    n = int(min(len(o), max(4096, rate * target_s)))
+    idx = perm[:n]
+    os_, ds_ = np.ascontiguousarray(o[idx]), np.ascontiguousarray(d[idx])
+    t0 = time.perf_counter()
+    res = ot.trace_rays(os_, ds_, M)
+    dt = time.perf_counter() - t0
+    inter = int(res["num_visited_cells"].astype(np.int64).sum())
+    return {"value": inter / dt, "unit": "ray-tet intersections/s", "cores": tn_oracle.num_threads(),
+            "kind": "port", "rays_per_s": n / dt,
+            "sample": f"{n} random rays of the same frame, M={M}, oracle BVH path, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--max-ray-triangles", type=int, default=512)
+    ap.add_argument("--mesh-points", type=int, default=15000)
+    ap.add_argument("--mesh-seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    tn = importlib.import_module("tetra-nerf_amd")
+    scenes = importlib.import_module("tetra-nerf_amd.scenes")
+
+    pts, cells = scenes.random_mesh(args.mesh_points, args.mesh_seed)
+    o_np, d_np = frame_rays(scenes, rank, args.width, args.height)
+    R, M = len(o_np), args.max_ray_triangles
+
+    tracer = tn.TetrahedraTracer(dev)
+    t0 = time.perf_counter()
+    tracer.load_tetrahedra(torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev))
+    torch.cuda.synchronize()
+    load_s = time.perf_counter() - t0
+    o = torch.from_numpy(o_np).to(dev)
+    d = torch.from_numpy(d_np).to(dev)
+
+    def step():
+        out = tracer.trace_rays(o, d, M)
+        return out["num_visited_cells"]
+
+    inter = 0
+    for _ in range(max(args.warmup, 0)):
+        inter = int(step().sum())
+    if args.warmup <= 0:
+        inter = int(step().sum())
+    stats = tracer.trace_stats()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        step()
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    tot_inter = float(inter)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([tot_inter, float(R)], dtype=torch.float64, device=dev)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        tot_inter, tot_rays = float(s[0].item()), float(s[1].item())
+    else:
+        tot_rays = float(R)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        alg_bytes = R * (28 + 52 * M)  # o,d + count + dense rows, SURVEY.md 8(d)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "ray_tet_intersections_per_s",
+            "value": tot_inter * args.steps / elapsed,
+            "unit": "ray-tet intersections/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "rays_per_s": tot_rays * args.steps / elapsed,
+            "config": {
+                "workload": f"configs[1] stand-in: Delaunay of {args.mesh_points} uniform points seed {args.mesh_seed} "
+                            f"({len(cells)} tets), {args.width}x{args.height} pinhole frame = {R} rays per GPU, "
+                            f"trace_rays M={M}, dense reference outputs",
+                "tets": int(len(cells)), "rays_per_gpu": R, "max_ray_triangles": M,
+                "intersections_per_frame": inter, "sharding": f"rays/{world} ranks, no collective",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "trace_rays launch (walk + general fallback)",
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
+                "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
+            },
+            "trace_path_stats": stats,
+            "load_tetrahedra_s": load_s,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pts, cells, o_np, d_np, M)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

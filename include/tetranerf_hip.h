@@ -1,0 +1,133 @@
+/*
+ * tetranerf_hip.h -- C-ABI of libtetranerf_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the ray -> tetrahedra hot path of jkulhanek/tetra-nerf.
+ * Every entry point replaces one native function the reference's pybind11 module
+ * (`tetranerf_cpp_extension`, /root/reference/src/py_binding.cpp:433-449) binds; the
+ * reference interface each one stands in for is cited at the declaration.
+ *
+ * Conventions
+ *   - plain C, raw DEVICE pointers and sizes, no torch / HIP types in signatures;
+ *     `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - every function returns 0 on success, non-zero on error; the message is available
+ *     from tn_last_error() (thread-local) and mirrors the reference's exception text where
+ *     callers can observe it (src/utils/exception.h:164-181 -> Python RuntimeError);
+ *   - all work is enqueued on `stream`; no call synchronises the device except
+ *     tn_load_tetrahedra (one-off build, like TetrahedraStructure::build's blocking copies,
+ *     src/tetrahedra_tracer.cpp:255-259);
+ *   - the caller owns every input/output buffer.  The tracer owns only what it derives
+ *     from the mesh (face tables, acceleration structures, scratch); the vertex and cell
+ *     buffers are borrowed for the tracer's lifetime (src/tetrahedra_tracer.h:300-303);
+ *   - output buffers need NOT be initialised: each kernel writes every byte of its outputs
+ *     exactly once (the reference memsets them first, py_binding.cpp:53-57,188-191).
+ *   - indices are uint32 with 0xFFFFFFFF = "empty" (int32 -1 on the torch side).
+ */
+#ifndef TETRANERF_HIP_H
+#define TETRANERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tn_tracer *tn_tracer_t;
+
+/* thread-local text of the last error raised on this thread ("" if none) */
+const char *tn_last_error(void);
+
+/* library / build identification: "tetranerf_hip <version> gfx950" */
+const char *tn_version(void);
+
+/* TetrahedraTracer::TetrahedraTracer(int8_t device)   src/tetrahedra_tracer.h:284-378,
+ *                                                       src/tetrahedra_tracer.cpp:90-135
+ * PyTetrahedraTracer ctor                               src/py_binding.cpp:30-36 */
+int tn_tracer_create(int device, tn_tracer_t *out);
+
+/* TetrahedraTracer::~TetrahedraTracer                  src/tetrahedra_tracer.cpp:178-189 */
+int tn_tracer_destroy(tn_tracer_t tracer);
+
+/* TetrahedraTracer::load_tetrahedra -> TetrahedraStructure::build
+ *   src/tetrahedra_tracer.h:304-309, src/tetrahedra_tracer.cpp:244-340;
+ *   face table = convert_tetrahedra_to_triangles, src/tetrahedra_tracer.cpp:45-71
+ * xyz   f32 [V,3] device, cells u32 [T,4] device (borrowed).
+ * Errors: "A triangle is shared by more than two tetrahedra!" */
+int tn_load_tetrahedra(tn_tracer_t tracer, size_t num_vertices, size_t num_cells,
+                       const float *xyz, const uint32_t *cells, void *stream);
+
+/* number of unique faces of the loaded mesh (0 before load) */
+size_t tn_num_faces(tn_tracer_t tracer);
+
+/* copies the face tables to HOST buffers (test/debug aid; faces u32 [F,3] in first-seen
+ * order with the unsorted first-seen triple, face_tets u32 [F,2]) */
+int tn_get_faces(tn_tracer_t tracer, uint32_t *faces_host, uint32_t *face_tets_host);
+
+/* TetrahedraTracer::trace_rays                         src/tetrahedra_tracer.h:311-331,
+ *   TraceRaysPipeline::trace_rays                       src/tetrahedra_tracer.cpp:137-176,
+ *   device programs                                      src/optix/optix_trace_rays.cu:268-331
+ *   launch-parameter block `Params`                     src/optix_types.h:1-14
+ * origins, directions f32 [R,3]; max_ray_triangles = M must be a power of two
+ *   ("max_ray_triangles must be a power of 2.", py_binding.cpp:44-47).
+ * num_visited u32 [R]; visited u32 [R,M]; bary f32 [R,M,2,3]; dist f32 [R,M,2];
+ * verts u32 [R,M,4] (nullable, cf. optix_trace_rays.cu:220).
+ * Slots >= num_visited[r]: visited/verts = 0xFFFFFFFF, bary/dist = 0. */
+int tn_trace_rays(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_triangles,
+                  const float *origins, const float *directions, uint32_t *num_visited,
+                  uint32_t *visited, float *bary, float *dist, uint32_t *verts, void *stream);
+
+/* find_matched_cells                                   src/tetrahedra_tracer.h:380-393,
+ *                                                       src/tetrahedra_tracer.cu:115-193
+ * (PyTetrahedraTracer::find_visited_cells, src/py_binding.cpp:163-216; `cells` of the
+ *  reference signature is unused there and omitted here)
+ * distances f32 [R,S] ascending per ray.  Outputs: cells_out u32 [R,S] (default
+ * 0xFFFFFFFF), verts_out u32 [R,S,4] (0xFFFFFFFF), mask_out u8 [R,S] (0), bary_out
+ * f32 [R,S,3] (0). */
+int tn_find_matched_cells(size_t num_rays, size_t num_samples, size_t max_visited_cells,
+                          const uint32_t *num_visited, const uint32_t *visited,
+                          const float *dist, const float *bary, const float *distances,
+                          const uint32_t *verts, uint32_t *cells_out, uint32_t *verts_out,
+                          uint8_t *mask_out, float *bary_out, void *stream);
+
+/* interpolate_values<D>                                src/tetrahedra_tracer.h:395-402,
+ *                                                       src/tetrahedra_tracer.cu:195-221,250-266
+ * vertex_indices u32 [n,D], barycentric f32 [n,D-1], field f32 [F,V] feature-major,
+ * result f32 [F,n].  D in {2,3,4,6}, else
+ * "Unsupported interpolation dimension with value <D>" (py_binding.cpp:258-276). */
+int tn_interpolate_values(uint32_t interpolation_dim, uint32_t num_vertices,
+                          uint32_t num_values, uint32_t field_dim,
+                          const uint32_t *vertex_indices, const float *barycentric,
+                          const float *field, float *result, void *stream);
+
+/* interpolate_values_backward<D>                       src/tetrahedra_tracer.h:404-411,
+ *                                                       src/tetrahedra_tracer.cu:223-248,268-290
+ * grad_in f32 [F,n] (the transposed contiguous copy py_binding.cpp:369 makes),
+ * field_grad_out f32 [F,V]: fully written (zero + scatter-add). */
+int tn_interpolate_values_backward(uint32_t interpolation_dim, uint32_t num_vertices,
+                                   uint32_t num_values, uint32_t field_dim,
+                                   const uint32_t *vertex_indices, const float *barycentric,
+                                   const float *grad_in, float *field_grad_out, void *stream);
+
+/* Test aid: run only the dedupe / pairing / tail-fill stage
+ * (post_process_tetrahedra, src/optix/optix_trace_rays.cu:110-266) on caller-supplied
+ * sorted hit rows: hit_count u32 [R], hit_ids u32 [R,M], hit_t f32 [R,M], hit_uv f32 [R,M,2]. */
+int tn_postprocess_hits(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_triangles,
+                        const uint32_t *hit_count, const uint32_t *hit_ids, const float *hit_t,
+                        const float *hit_uv, uint32_t *num_visited, uint32_t *visited,
+                        float *bary, float *dist, uint32_t *verts, void *stream);
+
+/* per-call statistics of the last tn_trace_rays on this tracer (host values; forces a
+ * stream sync).  stats[0] = rays served by the adjacency walk, stats[1] = rays re-traced by
+ * the general all-hits path, stats[2] = rays whose post-process ran the serial literal
+ * branch, stats[3] = rays that overflowed M-1 hits. */
+int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]);
+
+/* knobs (also settable through the environment):
+ *   "walk"    1 = adjacency-walk fast path with general-path fallback (default when built),
+ *             0 = general all-hits path for every ray */
+int tn_set_option(tn_tracer_t tracer, const char *name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TETRANERF_HIP_H */

@@ -1,0 +1,74 @@
+"""Generates the committed fixtures under tests/golden/ (run in the build container only;
+/root/reference does not exist on the GPU box).
+
+  bottle_mesh.npz    vertices f32 [2549,3] parsed from the reference's test asset
+                     (tests/assets/bottle.ply, binary little-endian, 8 floats per vertex)
+                     + cells i32 [T,4] = scipy Delaunay of those points (the reference's
+                     fixture runs CGAL Delaunay on the same points,
+                     tests/test_tetrahedra_tracer.py:13-20; CGAL is absent here).
+  bottle_oracle.npz  oracle outputs for config C1 (64x64 rays, M=256): counts, leading
+                     segment cells and a checksum -- regression pins for the oracle itself.
+"""
+import hashlib
+import importlib
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from oracle import tn_oracle  # noqa: E402
+
+scenes = importlib.import_module("tetra-nerf_amd.scenes")
+
+
+def read_ply_vertices(path):
+    raw = Path(path).read_bytes()
+    end = raw.index(b"end_header\n") + len(b"end_header\n")
+    header = raw[:end].decode("ascii").splitlines()
+    assert "format binary_little_endian 1.0" in header
+    nv = next(int(l.split()[-1]) for l in header if l.startswith("element vertex"))
+    props = []
+    in_vertex = False
+    for l in header:
+        if l.startswith("element"):
+            in_vertex = l.startswith("element vertex")
+        elif l.startswith("property") and in_vertex:
+            assert l.split()[1] == "float"
+            props.append(l.split()[2])
+    v = np.frombuffer(raw, dtype="<f4", count=nv * len(props), offset=end).reshape(nv, len(props))
+    return np.ascontiguousarray(v[:, [props.index("x"), props.index("y"), props.index("z")]])
+
+
+def checksum(res):
+    h = hashlib.sha256()
+    for k in ("num_visited_cells", "visited_cells", "vertex_indices", "hit_distances",
+              "barycentric_coordinates"):
+        h.update(np.ascontiguousarray(res[k]).tobytes())
+    return h
+
+
+def main():
+    out = Path(__file__).resolve().parent
+    verts = read_ply_vertices("/root/reference/tests/assets/bottle.ply").astype(np.float32)
+    cells = scenes.delaunay_cells(verts)
+    np.savez_compressed(out / "bottle_mesh.npz", vertices=verts, cells=cells)
+    print("bottle:", verts.shape, cells.shape)
+
+    tr = tn_oracle.OracleTracer()
+    tr.load_tetrahedra(verts, cells)
+    o, d = scenes.pinhole_rays(64, 64)
+    res = tr.trace_rays(o, d, 256)
+    n = res["num_visited_cells"]
+    h = checksum(res)
+    np.savez_compressed(out / "bottle_oracle.npz", num_visited_cells=n,
+                        visited_cells=res["visited_cells"][:, :96].copy(),
+                        num_faces=np.int64(len(tr.faces)),
+                        sha256=np.frombuffer(h.digest(), np.uint8))
+    print("faces", len(tr.faces), "rays hit", int((n > 0).sum()), "max segs", int(n.max()),
+          h.hexdigest()[:16])
+
+
+if __name__ == "__main__":
+    main()

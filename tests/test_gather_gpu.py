@@ -1,0 +1,109 @@
+"""GPU parity tests of interpolate_values forward / backward through the C-ABI.
+
+Forward: bit-exact against the oracle (same summation order), and against the reference's own
+definition -- einsum('jrbi,rbi->rbj') -- within assert_allclose defaults
+(tests/test_tetrahedra_tracer.py:400-416).  Backward: atomics reorder the sum, so it is compared
+with the oracle / autograd of the einsum at rtol 1e-4 (the reference test uses
+assert_allclose defaults on integer-valued fields, :436-453)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(rng, V, shape, D, empty_frac=0.2):
+    vi = rng.integers(0, V, shape + (D,)).astype(np.int32)
+    empty = rng.random(shape) < empty_frac
+    vi[empty] = -1
+    bc = (rng.random(shape + (D - 1,)).astype(np.float32)) / D
+    bc[empty] = 0
+    return vi, bc
+
+
+@pytest.mark.parametrize("D", [2, 3, 4, 6])
+@pytest.mark.parametrize("Fd", [64, 7, 130])
+def test_forward_bit_exact(tn, device, oracle, D, Fd):
+    import torch
+
+    rng = np.random.default_rng(D * 100 + Fd)
+    V = 777
+    vi, bc = _inputs(rng, V, (33, 19), D)
+    field = rng.standard_normal((Fd, V)).astype(np.float32)
+    want = oracle.interpolate_values(vi, bc, field)
+    got = tn.cpp.interpolate_values(torch.from_numpy(vi).to(device), torch.from_numpy(bc).to(device),
+                                    torch.from_numpy(field).to(device))
+    assert tuple(got.shape) == (33, 19, Fd)
+    # same memory layout as the reference: a moveaxis(0,-1) view of a contiguous [Fd, n] buffer
+    assert got.moveaxis(-1, 0).is_contiguous()
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+
+
+def test_forward_backward_reference_definition(tn, device):
+    """Restates test_tetrahedra_interpolate_values (tests/test_tetrahedra_tracer.py:346-456):
+    256 rays x 256 samples, field [64,V].random_()."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    V, R, S = 2549, 256, 256
+    vi_np, bc_np = _inputs(rng, V, (R, S), 4, empty_frac=0.35)
+    vi = torch.from_numpy(vi_np).to(device)
+    bc = torch.from_numpy(bc_np).to(device)
+    torch.manual_seed(0)
+    field = torch.empty((64, V), dtype=torch.float32, device=device).random_(0, 1000)
+
+    def get_field_safe(f):
+        safe_vi = vi.long().clamp_min(0)
+        g = f[:, safe_vi]
+        return torch.where(vi >= 0, g, torch.zeros_like(g))
+
+    w = torch.cat((1 - bc.sum(-1, keepdim=True), bc), -1)
+    val = tn.interpolate_values(vi, bc, field)
+    assert val.shape == (R, S, 64)
+    gt = torch.einsum("jrbi,rbi->rbj", get_field_safe(field), w)
+    torch.testing.assert_close(val, gt, rtol=1.3e-6, atol=1e-2)  # values up to ~1e3: a few fp32 ulps
+
+    field.requires_grad_(True)
+    val = tn.interpolate_values(vi, bc, field)
+    val.sum().backward()
+    grad = field.grad
+    assert grad.shape == (64, V)
+    field2 = field.detach().clone().requires_grad_(True)
+    gt = torch.einsum("jrbi,rbi->rj", get_field_safe(field2), w)
+    gt.sum().backward()
+    torch.testing.assert_close(grad, field2.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("D", [3, 4])
+def test_backward_vs_oracle(tn, device, oracle, D):
+    import torch
+
+    rng = np.random.default_rng(17 + D)
+    V, Fd = 321, 64
+    vi, bc = _inputs(rng, V, (2000,), D)
+    # runs of identical vertex tuples (consecutive samples in one tetrahedron)
+    vi[100:140] = vi[100]
+    bc[100:140] = bc[100]
+    field = rng.standard_normal((Fd, V)).astype(np.float32)
+    g = rng.standard_normal((2000, Fd)).astype(np.float32)
+    want = oracle.interpolate_values_backward(vi, bc, field, g)
+    got = tn.cpp.interpolate_values_backward(torch.from_numpy(vi).to(device), torch.from_numpy(bc).to(device),
+                                             torch.from_numpy(field).to(device), torch.from_numpy(g).to(device))
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
+def test_gather_errors(tn, device):
+    import torch
+
+    vi = torch.zeros((8, 5), dtype=torch.int32, device=device)
+    bc = torch.zeros((8, 4), dtype=torch.float32, device=device)
+    field = torch.zeros((64, 10), dtype=torch.float32, device=device)
+    with pytest.raises(RuntimeError, match="Unsupported interpolation dimension with value 5"):
+        tn.cpp.interpolate_values(vi, bc, field)
+    with pytest.raises(RuntimeError, match="int32"):
+        tn.cpp.interpolate_values(vi.long(), bc, field)
+    with pytest.raises(RuntimeError, match="same last dimension"):
+        tn.cpp.interpolate_values(vi, bc[:, :3].contiguous(), field)
+    # empty batch
+    out = tn.cpp.interpolate_values(torch.zeros((0, 4), dtype=torch.int32, device=device),
+                                    torch.zeros((0, 3), device=device), field)
+    assert tuple(out.shape) == (0, 64)

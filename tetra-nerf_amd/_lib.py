@@ -1,0 +1,65 @@
+"""ctypes binding of libtetranerf_hip.so (the C-ABI declared in include/tetranerf_hip.h).
+
+The library is the product: if it is missing or fails to load, everything here fails
+loudly -- there is no CPU fallback and no route through oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libtetranerf_hip.so"
+
+# every symbol include/tetranerf_hip.h declares
+SYMBOLS = (
+    "tn_last_error", "tn_version", "tn_tracer_create", "tn_tracer_destroy", "tn_load_tetrahedra",
+    "tn_num_faces", "tn_get_faces", "tn_trace_rays", "tn_find_matched_cells",
+    "tn_interpolate_values", "tn_interpolate_values_backward", "tn_postprocess_hits",
+    "tn_trace_stats", "tn_set_option",
+)
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library (once) and declare the signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"ERROR: {LIB_PATH} is missing. Build it first: python __graft_entry__.py "
+            "(or make -C tetra-nerf_amd/csrc). There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+    lib.tn_last_error.restype = C.c_char_p
+    lib.tn_last_error.argtypes = []
+    lib.tn_version.restype = C.c_char_p
+    lib.tn_version.argtypes = []
+    lib.tn_tracer_create.argtypes = [i32, C.POINTER(vp)]
+    lib.tn_tracer_destroy.argtypes = [vp]
+    lib.tn_load_tetrahedra.argtypes = [vp, sz, sz, vp, vp, vp]
+    lib.tn_num_faces.restype = sz
+    lib.tn_num_faces.argtypes = [vp]
+    lib.tn_get_faces.argtypes = [vp, vp, vp]
+    lib.tn_trace_rays.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tn_find_matched_cells.argtypes = [sz, sz, sz] + [vp] * 11
+    lib.tn_interpolate_values.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
+    lib.tn_interpolate_values_backward.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
+    lib.tn_postprocess_hits.argtypes = [vp, sz, u32] + [vp] * 10
+    lib.tn_trace_stats.argtypes = [vp, C.POINTER(C.c_uint64 * 4)]
+    lib.tn_set_option.argtypes = [vp, C.c_char_p, i32]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("tn_last_error", "tn_version", "tn_num_faces"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    """Turn a non-zero return code into the RuntimeError the reference would raise."""
+    if rc != 0:
+        msg = load().tn_last_error().decode("utf-8", "replace")
+        raise RuntimeError(msg or f"libtetranerf_hip call failed (rc={rc})")

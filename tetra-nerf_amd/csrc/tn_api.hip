@@ -1,0 +1,308 @@
+// tn_api.hip -- the C-ABI of libtetranerf_hip.so (see include/tetranerf_hip.h).
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+#include "../../include/tetranerf_hip.h"
+#include "tn_common.h"
+#include "tn_kernels.h"
+
+namespace tn {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        release();
+        if (count) TN_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+    }
+    void upload(const std::vector<T> &h) {
+        alloc(h.size());
+        if (!h.empty()) TN_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+struct DevWideBvh {
+    DevBuf<float> leaf_tri, boxes;
+    DevBuf<uint32_t> leaf_id;
+    WideBvh view{};
+    void upload(const HostWideBvh &h, float scene_max) {
+        leaf_tri.upload(h.leaf_tri);
+        leaf_id.upload(h.leaf_id);
+        boxes.upload(h.boxes);
+        view.leaf_tri = leaf_tri.p; view.leaf_id = leaf_id.p; view.boxes = boxes.p;
+        for (int i = 0; i < MAX_LEVELS; ++i) view.level_off[i] = h.level_off[i];
+        view.top_level = h.top_level;
+        view.scene_max = scene_max;
+    }
+};
+
+}  // namespace tn
+
+struct tn_tracer {
+    int device = 0;
+    tn::DeviceMesh mesh;
+    tn::HostMesh host;  // kept for tn_get_faces
+    tn::DevBuf<uint32_t> faces, face_tets, fallback_list, fallback_count;
+    tn::DevBuf<tn::TetRec> tets;
+    tn::DevWideBvh bvh, hull;
+    tn::DevBuf<unsigned long long> stats;
+    size_t last_num_rays = 0;
+    bool use_walk = true;
+    bool loaded = false;
+    hipStream_t last_stream = nullptr;
+};
+
+namespace {
+
+template <typename Fn>
+int guarded(Fn &&fn) {
+    try {
+        fn();
+        tn::set_error("");
+        return 0;
+    } catch (const std::exception &e) {
+        tn::set_error(e.what());
+        return 1;
+    } catch (...) {
+        tn::set_error("unknown error");
+        return 1;
+    }
+}
+
+struct DeviceGuard {
+    int prev = 0;
+    explicit DeviceGuard(int dev) {
+        TN_HIP(hipGetDevice(&prev));
+        if (prev != dev) TN_HIP(hipSetDevice(dev));
+        cur = dev;
+    }
+    ~DeviceGuard() {
+        if (prev != cur) (void)hipSetDevice(prev);
+    }
+    int cur;
+};
+
+tn_tracer *checked(tn_tracer_t t) {
+    if (!t) throw tn::Error("tracer handle is null");
+    return t;
+}
+
+bool env_flag(const char *name, bool dflt) {
+    const char *v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    return !(v[0] == '0' || v[0] == 'n' || v[0] == 'N' || v[0] == 'f' || v[0] == 'F');
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *tn_last_error(void) { return tn::g_last_error.c_str(); }
+
+const char *tn_version(void) { return "tetranerf_hip 0.1.0 gfx950"; }
+
+int tn_tracer_create(int device, tn_tracer_t *out) {
+    return guarded([&] {
+        if (!out) throw tn::Error("out is null");
+        int count = 0;
+        TN_HIP(hipGetDeviceCount(&count));
+        if (device < 0 || device >= count) throw tn::Error("The device argument must be a CUDA device.");
+        DeviceGuard g(device);
+        auto t = std::make_unique<tn_tracer>();
+        t->device = device;
+        t->use_walk = env_flag("TETRANERF_HIP_WALK", true);
+        t->stats.alloc(4);
+        TN_HIP(hipMemset(t->stats.p, 0, 4 * sizeof(unsigned long long)));
+        t->fallback_count.alloc(1);
+        *out = t.release();
+    });
+}
+
+int tn_tracer_destroy(tn_tracer_t tracer) {
+    return guarded([&] {
+        if (!tracer) return;
+        DeviceGuard g(tracer->device);
+        (void)hipDeviceSynchronize();
+        delete tracer;
+    });
+}
+
+int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz, const uint32_t *cells,
+                       void *stream_) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        DeviceGuard g(t->device);
+        hipStream_t stream = (hipStream_t)stream_;
+        if ((V && !xyz) || (T && !cells)) throw tn::Error("xyz / cells must not be null");
+        if (V >= 0xFFFFFFFFull || T >= 0x0FFFFFFFull) throw tn::Error("mesh too large (uint32 ids)");
+        t->loaded = false;
+        // blocking D2H of the mesh (the reference does the same: tetrahedra_tracer.cpp:255-259)
+        std::vector<float> hxyz(3 * V);
+        std::vector<uint32_t> hcells(4 * T);
+        TN_HIP(hipStreamSynchronize(stream));
+        if (V) TN_HIP(hipMemcpy(hxyz.data(), xyz, hxyz.size() * sizeof(float), hipMemcpyDeviceToHost));
+        if (T) TN_HIP(hipMemcpy(hcells.data(), cells, hcells.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < hcells.size(); ++i)
+            if (hcells[i] >= V) throw tn::Error("cells contains a vertex index that is out of bounds");
+
+        tn::build_face_table(T, hcells.data(), t->host);
+        const size_t F = t->host.face_tets.size() / 2;
+        float smax = 0.f;
+        for (size_t i = 0; i < hcells.size(); ++i)
+            for (int k = 0; k < 3; ++k) smax = std::max(smax, std::fabs(hxyz[3 * (size_t)hcells[i] + k]));
+        t->host.scene_max = smax;
+
+        std::vector<uint32_t> all(F), hull_ids;
+        for (size_t f = 0; f < F; ++f) {
+            all[f] = (uint32_t)f;
+            if (t->host.face_tets[2 * f + 1] == TN_EMPTY) hull_ids.push_back((uint32_t)f);
+        }
+        tn::HostWideBvh hb, hh;
+        tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), all, hb);
+        tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), hull_ids, hh);
+        std::vector<tn::TetRec> recs;
+        tn::build_tet_records(T, hcells.data(), hxyz.data(), t->host, recs);
+
+        t->faces.upload(t->host.faces);
+        t->face_tets.upload(t->host.face_tets);
+        t->bvh.upload(hb, smax);
+        t->hull.upload(hh, smax);
+        t->tets.upload(recs);
+
+        tn::DeviceMesh &m = t->mesh;
+        m.xyz = xyz; m.cells = cells;
+        m.V = (uint32_t)V; m.T = (uint32_t)T; m.F = (uint32_t)F;
+        m.faces = t->faces.p; m.face_tets = t->face_tets.p;
+        m.bvh = t->bvh.view; m.hull = t->hull.view;
+        m.tets = t->tets.p; m.n_hull = (uint32_t)hull_ids.size();
+        t->loaded = true;
+    });
+}
+
+size_t tn_num_faces(tn_tracer_t tracer) { return tracer && tracer->loaded ? tracer->mesh.F : 0; }
+
+int tn_get_faces(tn_tracer_t tracer, uint32_t *faces_host, uint32_t *face_tets_host) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        if (!t->loaded) throw tn::Error("load_tetrahedra must be called first");
+        if (faces_host) std::memcpy(faces_host, t->host.faces.data(), t->host.faces.size() * sizeof(uint32_t));
+        if (face_tets_host)
+            std::memcpy(face_tets_host, t->host.face_tets.data(), t->host.face_tets.size() * sizeof(uint32_t));
+    });
+}
+
+static tn::TraceParams make_params(tn_tracer *t, size_t R, uint32_t M, const float *o, const float *d,
+                                   uint32_t *num, uint32_t *cells, float *bary, float *dist, uint32_t *verts) {
+    tn::TraceParams p{};
+    p.origins = o; p.dirs = d;
+    p.faces = t->mesh.faces; p.face_tets = t->mesh.face_tets;
+    p.bvh = t->mesh.bvh;
+    p.out_num = num; p.out_cells = cells; p.out_bary = bary; p.out_dist = dist; p.out_verts = verts;
+    p.M = M; p.num_items = R; p.ray_list = nullptr;
+    p.stats = t->stats.p;
+    return p;
+}
+
+int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins, const float *directions,
+                  uint32_t *num_visited, uint32_t *visited, float *bary, float *dist, uint32_t *verts,
+                  void *stream_) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        if (M == 0 || (M & (M - 1)) != 0) throw tn::Error("max_ray_triangles must be a power of 2.");
+        if (!t->loaded) throw tn::Error("load_tetrahedra must be called first");
+        if (M > 4096) throw tn::Error("max_ray_triangles larger than 4096 is not supported");
+        if (R >= 0xFFFFFFFFull) throw tn::Error("too many rays for one call");
+        if (R == 0) return;
+        if (!origins || !directions || !num_visited || !visited || !bary || !dist)
+            throw tn::Error("null ray / output pointer");
+        DeviceGuard g(t->device);
+        hipStream_t stream = (hipStream_t)stream_;
+        t->last_stream = stream;
+        t->last_num_rays = R;
+        TN_HIP(hipMemsetAsync(t->stats.p, 0, 4 * sizeof(unsigned long long), stream));
+        tn::TraceParams p = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
+        tn::launch_trace_general(p, stream);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_postprocess_hits(tn_tracer_t tracer, size_t R, uint32_t M, const uint32_t *hit_count,
+                        const uint32_t *hit_ids, const float *hit_t, const float *hit_uv,
+                        uint32_t *num_visited, uint32_t *visited, float *bary, float *dist, uint32_t *verts,
+                        void *stream_) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        if (M == 0 || (M & (M - 1)) != 0) throw tn::Error("max_ray_triangles must be a power of 2.");
+        if (!t->loaded) throw tn::Error("load_tetrahedra must be called first");
+        if (R == 0) return;
+        DeviceGuard g(t->device);
+        hipStream_t stream = (hipStream_t)stream_;
+        tn::TraceParams p = make_params(t, R, M, nullptr, nullptr, num_visited, visited, bary, dist, verts);
+        p.stats = nullptr;
+        tn::launch_postprocess_hits(p, hit_count, hit_ids, hit_t, hit_uv, stream);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        DeviceGuard g(t->device);
+        TN_HIP(hipStreamSynchronize(t->last_stream));
+        unsigned long long h[4];
+        TN_HIP(hipMemcpy(h, t->stats.p, sizeof h, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 4; ++i) stats[i] = h[i];
+    });
+}
+
+int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        if (name && std::strcmp(name, "walk") == 0) t->use_walk = value != 0;
+        else throw tn::Error(std::string("unknown option ") + (name ? name : "(null)"));
+    });
+}
+
+int tn_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited, const uint32_t *visited,
+                          const float *dist, const float *bary, const float *distances, const uint32_t *verts,
+                          uint32_t *cells_out, uint32_t *verts_out, uint8_t *mask_out, float *bary_out,
+                          void *stream_) {
+    return guarded([&] {
+        if (R == 0 || S == 0) return;
+        if (S >= 0xFFFFFFFFull || M >= 0xFFFFFFFFull) throw tn::Error("num_samples / max_visited_cells too large");
+        if (M * 2 * sizeof(float) > 64 * 1024) throw tn::Error("max_visited_cells larger than 8192 is not supported");
+        tn::launch_find_matched_cells(R, S, M, num_visited, visited, dist, bary, distances, verts, cells_out,
+                                      verts_out, mask_out, bary_out, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_interpolate_values(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
+                          const float *field, float *result, void *stream_) {
+    return guarded([&] {
+        tn::launch_interpolate_values(D, V, n, Fd, vi, bc, field, result, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_interpolate_values_backward(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
+                                   const float *bc, const float *grad_in, float *field_grad_out, void *stream_) {
+    return guarded([&] {
+        tn::launch_interpolate_values_backward(D, V, n, Fd, vi, bc, grad_in, field_grad_out, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// tn_common.h -- shared declarations of libtetranerf_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#define TN_EMPTY 0xFFFFFFFFu
+#define TN_EPS 1e-6f  // tie window of the pairing stage (reference: optix_trace_rays.cu:8)
+
+namespace tn {
+
+void set_error(const std::string &msg);
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define TN_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            throw tn::Error(std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" + \
+                            __FILE__ + ":" + std::to_string(__LINE__) + ")");                \
+    } while (0)
+
+constexpr int WIDE = 64;            // BVH branching factor = wavefront width
+constexpr int MAX_LEVELS = 8;       // 64^8 faces is far beyond uint32
+constexpr int STACK_CAP = 64 * 6;   // traversal stack entries per wave
+
+// Wide (64-ary) BVH over the unique faces, complete tree over Morton-ordered faces.
+// Level 0 = leaves (64 triangles each, vertices stored inline SoA so a wave reads a
+// leaf with 10 coalesced 256-B loads); level l>0 node k has children 64k..64k+63 of
+// level l-1, boxes stored SoA [6][64] floats.
+struct WideBvh {
+    const float *leaf_tri;      // [n_leaves][9][64]  v0.xyz v1.xyz v2.xyz
+    const uint32_t *leaf_id;    // [n_leaves][64]     face id or TN_EMPTY
+    const float *boxes;         // [n_internal][6][64] lo.xyz hi.xyz
+    uint32_t level_off[MAX_LEVELS];  // node offset of each internal level into `boxes`
+    int top_level;              // the root is node 0 of this level (>= 1)
+    float scene_max;            // max |coordinate| over the mesh vertices
+};
+
+// Per-tet record of the adjacency walk: one 128-byte line.
+//   vert[k]  vertex ids (cell order);  pos[k] their positions
+//   nbr[k]   tet behind the face opposite local vertex k (TN_EMPTY on the hull)
+//   face[k]  id of that face in the face table
+//   perm     per face k, 3x2 bits: local vertex index (0..3) of the face's 1st/2nd/3rd
+//            STORED vertex (first-seen triple), bits [6k, 6k+6)
+//   back     per face k, 2 bits: the local index of that face in the neighbour tet
+struct alignas(128) TetRec {
+    uint32_t vert[4];
+    uint32_t nbr[4];
+    uint32_t face[4];
+    float pos[4][3];
+    uint32_t perm;
+    uint32_t back;
+    uint32_t pad_[6];
+};
+static_assert(sizeof(TetRec) == 128, "TetRec must be one 128-B line");
+
+struct DeviceMesh {
+    const float *xyz = nullptr;       // borrowed [V,3]
+    const uint32_t *cells = nullptr;  // borrowed [T,4]
+    uint32_t V = 0, T = 0, F = 0;
+    uint32_t *faces = nullptr;      // [F,3] first-seen unsorted triple
+    uint32_t *face_tets = nullptr;  // [F,2]
+    WideBvh bvh{};                  // over all faces
+    // adjacency walk
+    TetRec *tets = nullptr;         // [T]
+    WideBvh hull{};                 // over hull faces only (leaf_id = global face id)
+    uint32_t n_hull = 0;
+};
+
+// host-side build products (tn_mesh.cpp)
+struct HostMesh {
+    std::vector<uint32_t> faces;      // 3F
+    std::vector<uint32_t> face_tets;  // 2F
+    float scene_max = 0.f;
+};
+
+struct HostWideBvh {
+    std::vector<float> leaf_tri;
+    std::vector<uint32_t> leaf_id;
+    std::vector<float> boxes;
+    uint32_t level_off[MAX_LEVELS] = {0};
+    int top_level = 1;
+};
+
+// first-seen face table; throws tn::Error("A triangle is shared by more than two tetrahedra!")
+void build_face_table(size_t T, const uint32_t *cells, HostMesh &out);
+// wide BVH over the faces listed in `ids` (global face ids)
+void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<uint32_t> &ids,
+                    HostWideBvh &out);
+// adjacency records
+void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const HostMesh &hm,
+                       std::vector<TetRec> &out);
+
+}  // namespace tn

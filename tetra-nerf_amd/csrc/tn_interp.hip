@@ -1,0 +1,214 @@
+// tn_interp.hip -- barycentric feature gather (interpolate_values) and its adjoint.
+//
+// Replaces interpolate_values_kernel<D> / interpolate_values_backward_kernel<D>
+// (src/tetrahedra_tracer.cu:195-248): there a thread is one (sample, feature) pair on a
+// (n/1024, field_dim) grid, so indices and weights are re-read field_dim times and every
+// field access is a lone 4-byte gather into a feature-major [Fd, V] table.
+//
+// Here the table is first transposed to vertex-major [V, Fd] (one 256-byte line per vertex
+// at Fd = 64; the table is L2/MALL resident), then ONE WAVEFRONT processes 64 samples with
+// LANE = FEATURE: per sample the D vertex rows are read as coalesced 256-B loads (ids and
+// weights broadcast from the owning lane by v_readlane), results go through a padded LDS
+// tile and leave as 256-B row stores into the reference's [Fd, n] result layout.
+// The per-element summation order of the reference is kept, so the forward result is
+// bit-identical to the CPU oracle:
+//     out = ((b0*f[v1] + b1*f[v2]) + ...) + (1 - ((b0+b1)+...)) * f[v0],  EMPTY ids skipped.
+// Backward: LANE = FEATURE again; 64 lanes add to 64 consecutive floats of a vertex-major
+// gradient (one cache line per atomic instruction), with run-length combining of consecutive
+// samples that hit the same vertex tuple; the result is transposed back to [Fd, V].
+#include "tn_device.h"
+#include "tn_kernels.h"
+
+namespace tn {
+
+namespace {
+
+constexpr int TS = 64;   // samples per tile
+constexpr int TP = 65;   // padded LDS row (floats)
+
+// [rows, cols] -> [cols, rows], 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void k_transpose(const float *__restrict__ in, float *__restrict__ out,
+                                                   uint32_t rows, uint32_t cols) {
+    __shared__ float tile[64][TP];
+    const uint32_t c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4)
+        if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = in[(size_t)(r0 + r) * cols + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4)
+        if (c0 + c < cols && r0 + tx < rows) out[(size_t)(c0 + c) * rows + r0 + tx] = tile[tx][c];
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void k_interp_fwd(uint32_t n, uint32_t Fd, const uint32_t *__restrict__ vi,
+                                                   const float *__restrict__ bc, const float *__restrict__ fieldT,
+                                                   float *__restrict__ result) {
+    __shared__ float tile[TS][TP];
+    const int lane = threadIdx.x;
+    const uint32_t ntiles = (n + TS - 1) / TS;
+    for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+        const uint32_t base = tix * TS;
+        const uint32_t cnt = n - base < TS ? n - base : TS;
+        uint32_t myv[D];
+        float myb[D - 1];
+#pragma unroll
+        for (int k = 0; k < D; ++k) myv[k] = TN_EMPTY;
+#pragma unroll
+        for (int k = 0; k < D - 1; ++k) myb[k] = 0.f;
+        if ((uint32_t)lane < cnt) {
+            const size_t i = base + lane;
+#pragma unroll
+            for (int k = 0; k < D; ++k) myv[k] = vi[i * D + k];
+#pragma unroll
+            for (int k = 0; k < D - 1; ++k) myb[k] = bc[i * (D - 1) + k];
+        }
+        for (uint32_t f0 = 0; f0 < Fd; f0 += 64) {
+            const uint32_t f = f0 + lane;
+            const bool fok = f < Fd;
+            for (uint32_t s = 0; s < cnt; ++s) {
+                float out = 0.f, w = 0.f;
+#pragma unroll
+                for (int k = 0; k < D - 1; ++k) {
+                    const float wk = __shfl(myb[k], s);
+                    const uint32_t v = __shfl(myv[k + 1], s);
+                    if (v != TN_EMPTY) out += wk * (fok ? fieldT[(size_t)v * Fd + f] : 0.f);
+                    w += wk;
+                }
+                const uint32_t v0 = __shfl(myv[0], s);
+                if (v0 != TN_EMPTY) out += (1.0f - w) * (fok ? fieldT[(size_t)v0 * Fd + f] : 0.f);
+                tile[s][lane] = out;
+            }
+            __syncthreads();
+            const uint32_t fcnt = Fd - f0 < 64 ? Fd - f0 : 64;
+            if ((uint32_t)lane < cnt)
+                for (uint32_t j = 0; j < fcnt; ++j) result[(size_t)(f0 + j) * n + base + lane] = tile[lane][j];
+            __syncthreads();
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void k_interp_bwd(uint32_t n, uint32_t Fd, const uint32_t *__restrict__ vi,
+                                                   const float *__restrict__ bc, const float *__restrict__ grad_in,
+                                                   float *__restrict__ gradT) {
+    __shared__ float tile[TS][TP];
+    const int lane = threadIdx.x;
+    const uint32_t ntiles = (n + TS - 1) / TS;
+    for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+        const uint32_t base = tix * TS;
+        const uint32_t cnt = n - base < TS ? n - base : TS;
+        uint32_t myv[D];
+        float myb[D - 1];
+#pragma unroll
+        for (int k = 0; k < D; ++k) myv[k] = TN_EMPTY;
+#pragma unroll
+        for (int k = 0; k < D - 1; ++k) myb[k] = 0.f;
+        if ((uint32_t)lane < cnt) {
+            const size_t i = base + lane;
+#pragma unroll
+            for (int k = 0; k < D; ++k) myv[k] = vi[i * D + k];
+#pragma unroll
+            for (int k = 0; k < D - 1; ++k) myb[k] = bc[i * (D - 1) + k];
+        }
+        for (uint32_t f0 = 0; f0 < Fd; f0 += 64) {
+            const uint32_t fcnt = Fd - f0 < 64 ? Fd - f0 : 64;
+            // grad_in [Fd, n]: rows of 64 consecutive samples -> tile[sample][feature]
+            if ((uint32_t)lane < cnt)
+                for (uint32_t j = 0; j < fcnt; ++j) tile[lane][j] = grad_in[(size_t)(f0 + j) * n + base + lane];
+            __syncthreads();
+            const uint32_t f = f0 + lane;
+            const bool fok = f < Fd;
+            // run-length combine: accumulate while the vertex tuple repeats
+            uint32_t cur[D];
+            float acc[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) { cur[k] = TN_EMPTY; acc[k] = 0.f; }
+            for (uint32_t s = 0; s <= cnt; ++s) {
+                uint32_t v[D];
+                float wgt[D];
+                bool same = s < cnt;
+                if (s < cnt) {
+                    float w = 0.f;
+#pragma unroll
+                    for (int k = 0; k < D - 1; ++k) {
+                        wgt[k + 1] = __shfl(myb[k], s);
+                        w += wgt[k + 1];
+                    }
+                    wgt[0] = 1.0f - w;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { v[k] = __shfl(myv[k], s); same = same && (v[k] == cur[k]); }
+                }
+                if (!same) {
+                    // flush (wave-uniform branch: ids are broadcast values)
+#pragma unroll
+                    for (int k = 0; k < D; ++k)
+                        if (cur[k] != TN_EMPTY && fok) atomicAdd(&gradT[(size_t)cur[k] * Fd + f], acc[k]);
+                    if (s < cnt) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) { cur[k] = v[k]; acc[k] = 0.f; }
+                    }
+                }
+                if (s < cnt) {
+                    const float g = tile[s][lane];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) acc[k] += wgt[k] * g;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int D>
+void run_fwd(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc, const float *field,
+             float *result, hipStream_t stream) {
+    float *fieldT = nullptr;
+    TN_HIP(hipMallocAsync((void **)&fieldT, (size_t)V * Fd * sizeof(float), stream));
+    hipLaunchKernelGGL(k_transpose, dim3((V + 63) / 64, (Fd + 63) / 64), dim3(256), 0, stream, field, fieldT, Fd, V);
+    const uint32_t ntiles = (n + TS - 1) / TS;
+    const unsigned grid = ntiles < 256u * 32u ? ntiles : 256u * 32u;
+    hipLaunchKernelGGL(k_interp_fwd<D>, dim3(grid), dim3(64), 0, stream, n, Fd, vi, bc, fieldT, result);
+    TN_HIP(hipFreeAsync(fieldT, stream));
+}
+
+template <int D>
+void run_bwd(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc, const float *grad_in,
+             float *field_grad, hipStream_t stream) {
+    float *gradT = nullptr;
+    TN_HIP(hipMallocAsync((void **)&gradT, (size_t)V * Fd * sizeof(float), stream));
+    TN_HIP(hipMemsetAsync(gradT, 0, (size_t)V * Fd * sizeof(float), stream));
+    const uint32_t ntiles = (n + TS - 1) / TS;
+    const unsigned grid = ntiles < 256u * 32u ? ntiles : 256u * 32u;
+    if (n) hipLaunchKernelGGL(k_interp_bwd<D>, dim3(grid), dim3(64), 0, stream, n, Fd, vi, bc, grad_in, gradT);
+    hipLaunchKernelGGL(k_transpose, dim3((Fd + 63) / 64, (V + 63) / 64), dim3(256), 0, stream, gradT, field_grad, V, Fd);
+    TN_HIP(hipFreeAsync(gradT, stream));
+}
+
+}  // namespace
+
+void launch_interpolate_values(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
+                               const float *bc, const float *field, float *result, hipStream_t stream) {
+    if (n == 0 || Fd == 0) return;
+    switch (D) {
+        case 2: run_fwd<2>(V, n, Fd, vi, bc, field, result, stream); break;
+        case 3: run_fwd<3>(V, n, Fd, vi, bc, field, result, stream); break;
+        case 4: run_fwd<4>(V, n, Fd, vi, bc, field, result, stream); break;
+        case 6: run_fwd<6>(V, n, Fd, vi, bc, field, result, stream); break;
+        default: throw Error("Unsupported interpolation dimension with value " + std::to_string(D));
+    }
+}
+
+void launch_interpolate_values_backward(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
+                                        const float *bc, const float *grad_in, float *field_grad,
+                                        hipStream_t stream) {
+    if (Fd == 0 || V == 0) return;
+    switch (D) {
+        case 2: run_bwd<2>(V, n, Fd, vi, bc, grad_in, field_grad, stream); break;
+        case 3: run_bwd<3>(V, n, Fd, vi, bc, grad_in, field_grad, stream); break;
+        case 4: run_bwd<4>(V, n, Fd, vi, bc, grad_in, field_grad, stream); break;
+        case 6: run_bwd<6>(V, n, Fd, vi, bc, grad_in, field_grad, stream); break;
+        default: throw Error("Unsupported interpolation dimension with value " + std::to_string(D));
+    }
+}
+
+}  // namespace tn

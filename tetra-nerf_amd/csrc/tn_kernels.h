@@ -1,0 +1,53 @@
+// tn_kernels.h -- host-callable launchers of the HIP kernels.
+#pragma once
+#include "tn_common.h"
+
+namespace tn {
+
+struct TraceParams {
+    const float *origins;      // [R,3]
+    const float *dirs;         // [R,3]
+    const uint32_t *faces;     // [F,3]
+    const uint32_t *face_tets; // [F,2]
+    WideBvh bvh;
+    uint32_t *out_num;         // [R]
+    uint32_t *out_cells;       // [R,M]
+    float *out_bary;           // [R,M,2,3]
+    float *out_dist;           // [R,M,2]
+    uint32_t *out_verts;       // [R,M,4] or null
+    uint32_t M;
+    size_t num_items;          // rays (or entries of ray_list) to process
+    const uint32_t *ray_list;  // optional indirection: item -> ray index
+    unsigned long long *stats; // [4] device counters or null
+};
+
+// general all-hits path, one wavefront per ray (tn_trace_general.hip)
+void launch_trace_general(const TraceParams &p, hipStream_t stream);
+void launch_postprocess_hits(const TraceParams &p, const uint32_t *hit_count, const uint32_t *hit_ids,
+                             const float *hit_t, const float *hit_uv, hipStream_t stream);
+size_t trace_general_smem_bytes(uint32_t M);
+
+// adjacency walk, one lane per ray (tn_trace_walk.hip)
+struct WalkParams {
+    TraceParams t;
+    const TetRec *tets;
+    WideBvh hull;
+    uint32_t *fallback_list;   // [R] rays the walk could not certify
+    uint32_t *fallback_count;  // [1]
+};
+void launch_trace_walk(const WalkParams &p, hipStream_t stream);
+
+// sample -> segment matching (tn_match.hip)
+void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,
+                               const uint32_t *visited, const float *dist, const float *bary,
+                               const float *distances, const uint32_t *verts, uint32_t *cells_out,
+                               uint32_t *verts_out, uint8_t *mask_out, float *bary_out, hipStream_t stream);
+
+// barycentric gather and its adjoint (tn_interp.hip); throws on unsupported D
+void launch_interpolate_values(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
+                               const float *bc, const float *field, float *result, hipStream_t stream);
+void launch_interpolate_values_backward(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
+                                        const float *bc, const float *grad_in, float *field_grad,
+                                        hipStream_t stream);
+
+}  // namespace tn

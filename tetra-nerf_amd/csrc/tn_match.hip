@@ -1,0 +1,140 @@
+// tn_match.hip -- find_visited_cells: match S sorted sample distances of a ray against its
+// <= M sorted segments and lerp the entry/exit barycentrics.
+//
+// Replaces find_matched_cells_kernel (src/tetrahedra_tracer.cu:115-160; 16-thread blocks,
+// one thread per ray, serial over samples).  Here ONE WAVEFRONT owns a ray: the segment
+// bounds are staged in LDS, the per-sample two-pointer merge becomes an independent binary
+// search (valid because the sample distances ascend: the sequential pointer of the reference
+// equals "first segment whose t_out >= d"), and all outputs are written by
+// consecutive lanes (coalesced), including the defaults the reference gets from
+// torch::full/zeros (src/py_binding.cpp:188-191).  Rays whose distances do not ascend take a
+// literal serial branch on lane 0.
+#include "tn_device.h"
+#include "tn_kernels.h"
+
+namespace tn {
+
+__global__ __launch_bounds__(64) void k_find_matched(size_t R, uint32_t S, uint32_t M,
+                                                     const uint32_t *__restrict__ num_visited,
+                                                     const uint32_t *__restrict__ visited,
+                                                     const float *__restrict__ dist,
+                                                     const float *__restrict__ bary,
+                                                     const float *__restrict__ distances,
+                                                     const uint32_t *__restrict__ verts,
+                                                     uint32_t *__restrict__ cells_out,
+                                                     uint32_t *__restrict__ verts_out,
+                                                     uint8_t *__restrict__ mask_out,
+                                                     float *__restrict__ bary_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tin = reinterpret_cast<float *>(smem);  // [M]
+    float *pmax = tin + M;                         // [M] running max of t_out
+    const int lane = threadIdx.x;
+
+    for (size_t ray = blockIdx.x; ray < R; ray += gridDim.x) {
+        uint32_t n = num_visited[ray];
+        if (n > M) n = M;
+        const float2 *drow = reinterpret_cast<const float2 *>(dist) + ray * M;
+        // stage bounds + inclusive running max of t_out (wave scan, chunks of 64)
+        float carry = -INFINITY;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t j = base + lane;
+            float2 d = make_float2(0.f, -INFINITY);
+            if (j < n) d = drow[j];
+            float m = d.y;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float o = __shfl_up(m, off);
+                if (lane >= off) m = fmaxf(m, o);
+            }
+            m = fmaxf(m, carry);
+            if (j < n) { tin[j] = d.x; pmax[j] = m; }
+            carry = __shfl(m, 63);
+        }
+        // do the sample distances ascend?
+        const float *srow = distances + ray * S;
+        bool bad = false;
+        for (uint32_t j = lane; j + 1 < S; j += 64) bad |= !(srow[j] <= srow[j + 1]);
+        const bool ascending = (__ballot(bad) == 0ull);
+        __syncthreads();
+
+        if (ascending) {
+            for (uint32_t base = 0; base < S; base += 64) {
+                const uint32_t j = base + lane;
+                if (j >= S) break;
+                const float cur = srow[j];
+                // first p with pmax[p] >= cur  (== first p with t_out[p] >= cur)
+                uint32_t lo = 0, hi = n;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pmax[mid] < cur) lo = mid + 1; else hi = mid;
+                }
+                const uint32_t p = lo;
+                uint8_t mk = 0;
+                uint32_t cell = TN_EMPTY;
+                uint4 vv = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
+                float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+                if (p < n && tin[p] <= cur) {
+                    const size_t g = ray * M + p;
+                    const float t_in = tin[p], t_out = drow[p].y;
+                    mk = 1;
+                    cell = visited[g];
+                    vv = *reinterpret_cast<const uint4 *>(verts + 4 * g);
+                    const float mult = (cur - t_in) / (t_out - t_in);
+                    const float2 *bp = reinterpret_cast<const float2 *>(bary + 6 * g);
+                    const float2 q0 = bp[0], q1 = bp[1], q2 = bp[2];  // c1.xyz = q0.x q0.y q1.x ; c2.xyz = q1.y q2.x q2.y
+                    b0 = (1 - mult) * q0.x + mult * q1.y;
+                    b1 = (1 - mult) * q0.y + mult * q2.x;
+                    b2 = (1 - mult) * q1.x + mult * q2.y;
+                }
+                const size_t o = ray * S + j;
+                mask_out[o] = mk;
+                cells_out[o] = cell;
+                *reinterpret_cast<uint4 *>(verts_out + 4 * o) = vv;
+                bary_out[3 * o] = b0; bary_out[3 * o + 1] = b1; bary_out[3 * o + 2] = b2;
+            }
+        } else {
+            // defaults everywhere, then the literal pointer walk on lane 0
+            for (uint32_t j = lane; j < S; j += 64) {
+                const size_t o = ray * S + j;
+                mask_out[o] = 0;
+                cells_out[o] = TN_EMPTY;
+                *reinterpret_cast<uint4 *>(verts_out + 4 * o) = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
+                bary_out[3 * o] = 0.f; bary_out[3 * o + 1] = 0.f; bary_out[3 * o + 2] = 0.f;
+            }
+            __syncthreads();
+            if (lane == 0) {
+                uint32_t p = 0;
+                for (uint32_t j = 0; j < S; ++j) {
+                    const float cur = srow[j];
+                    while (p < n && drow[p].y < cur) p++;
+                    if (p >= n) break;
+                    const float2 hd = drow[p];
+                    if (hd.x <= cur) {
+                        const size_t g = ray * M + p, o = ray * S + j;
+                        mask_out[o] = 1;
+                        cells_out[o] = visited[g];
+                        for (int k = 0; k < 4; ++k) verts_out[4 * o + k] = verts[4 * g + k];
+                        const float mult = (cur - hd.x) / (hd.y - hd.x);
+                        for (int k = 0; k < 3; ++k)
+                            bary_out[3 * o + k] = (1 - mult) * bary[6 * g + k] + mult * bary[6 * g + 3 + k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,
+                               const uint32_t *visited, const float *dist, const float *bary,
+                               const float *distances, const uint32_t *verts, uint32_t *cells_out,
+                               uint32_t *verts_out, uint8_t *mask_out, float *bary_out, hipStream_t stream) {
+    if (R == 0 || S == 0) return;
+    const size_t smem = 2 * M * sizeof(float);
+    const size_t max_blocks = 256 * 32;
+    const unsigned grid = (unsigned)(R < max_blocks ? R : max_blocks);
+    hipLaunchKernelGGL(k_find_matched, dim3(grid), dim3(64), smem, stream, R, (uint32_t)S, (uint32_t)M,
+                       num_visited, visited, dist, bary, distances, verts, cells_out, verts_out, mask_out, bary_out);
+}
+
+}  // namespace tn

@@ -1,0 +1,242 @@
+// tn_mesh.cpp -- host-side mesh preprocessing for libtetranerf_hip.
+//
+//  * build_face_table: tetrahedra -> unique faces in FIRST-SEEN order with the unsorted
+//    first-seen vertex triple, plus face -> (tet, tet|EMPTY).  The ordering is observable
+//    through trace_rays' vertex_indices / barycentric ordering, so it reproduces the
+//    enumeration of the reference (src/tetrahedra_tracer.cpp:45-71: tets ascending, local
+//    face j = vertices (j+1)%4,(j+2)%4,(j+3)%4; third sighting is an error).
+//  * build_wide_bvh: 64-ary complete tree over Morton-ordered faces (replaces the OptiX GAS
+//    build, src/tetrahedra_tracer.cpp:285-332).
+//  * build_tet_records: 128-byte per-tet adjacency records for the walk kernel.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+#include "tn_common.h"
+
+namespace tn {
+
+namespace {
+
+inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 31; x *= 0x7fb5d329728ea185ULL;
+    x ^= x >> 27; x *= 0x81dadef4bc2dd44dULL;
+    x ^= x >> 33;
+    return x;
+}
+
+struct Key3 {
+    uint32_t a, b, c;  // ascending
+};
+
+inline Key3 sorted_key(uint32_t a, uint32_t b, uint32_t c) {
+    if (a > b) std::swap(a, b);
+    if (b > c) std::swap(b, c);
+    if (a > b) std::swap(a, b);
+    return {a, b, c};
+}
+
+// spread the low 21 bits of v so that there are two zero bits between each
+inline uint64_t spread21(uint64_t v) {
+    v &= 0x1fffffULL;
+    v = (v | v << 32) & 0x1f00000000ffffULL;
+    v = (v | v << 16) & 0x1f0000ff0000ffULL;
+    v = (v | v << 8) & 0x100f00f00f00f00fULL;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+    v = (v | v << 2) & 0x1249249249249249ULL;
+    return v;
+}
+
+}  // namespace
+
+void build_face_table(size_t T, const uint32_t *cells, HostMesh &out) {
+    size_t cap = 16;
+    while (cap < 8 * T + 16) cap <<= 1;
+    std::vector<uint32_t> slot(cap, TN_EMPTY);  // -> face index
+    std::vector<Key3> keys;
+    keys.reserve(2 * T + 16);
+    out.faces.clear();
+    out.face_tets.clear();
+    out.faces.reserve(3 * (2 * T + 16));
+    out.face_tets.reserve(2 * (2 * T + 16));
+    for (size_t i = 0; i < T; ++i) {
+        const uint32_t *c = cells + 4 * i;
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t v0 = c[(j + 1) & 3], v1 = c[(j + 2) & 3], v2 = c[(j + 3) & 3];
+            const Key3 k = sorted_key(v0, v1, v2);
+            size_t h = mix64((uint64_t(k.a) * 0x9E3779B97F4A7C15ULL) ^ (uint64_t(k.b) << 32 | k.c)) & (cap - 1);
+            for (;;) {
+                const uint32_t f = slot[h];
+                if (f == TN_EMPTY) {
+                    slot[h] = (uint32_t)keys.size();
+                    keys.push_back(k);
+                    out.faces.push_back(v0); out.faces.push_back(v1); out.faces.push_back(v2);
+                    out.face_tets.push_back((uint32_t)i); out.face_tets.push_back(TN_EMPTY);
+                    break;
+                }
+                if (keys[f].a == k.a && keys[f].b == k.b && keys[f].c == k.c) {
+                    if (out.face_tets[2 * (size_t)f + 1] != TN_EMPTY)
+                        throw Error("A triangle is shared by more than two tetrahedra!");
+                    out.face_tets[2 * (size_t)f + 1] = (uint32_t)i;
+                    break;
+                }
+                h = (h + 1) & (cap - 1);
+            }
+        }
+    }
+}
+
+void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<uint32_t> &ids,
+                    HostWideBvh &out) {
+    const size_t n = ids.size();
+    // centroid bounds
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    std::vector<float> cent(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t *f = faces + 3 * (size_t)ids[i];
+        for (int k = 0; k < 3; ++k) {
+            const float c = (xyz[3 * (size_t)f[0] + k] + xyz[3 * (size_t)f[1] + k] + xyz[3 * (size_t)f[2] + k]) * (1.0f / 3.0f);
+            cent[3 * i + k] = c;
+            lo[k] = std::min(lo[k], c); hi[k] = std::max(hi[k], c);
+        }
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> order(n);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t code = 0;
+        for (int k = 0; k < 3; ++k) {
+            const double ext = (double)hi[k] - (double)lo[k];
+            double u = ext > 0 ? ((double)cent[3 * i + k] - lo[k]) / ext : 0.0;
+            uint64_t q = (uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0));
+            code |= spread21(q) << k;
+        }
+        order[i] = {code, (uint32_t)i};
+    }
+    std::sort(order.begin(), order.end());
+
+    const size_t n_leaves = std::max<size_t>(1, (n + WIDE - 1) / WIDE);
+    out.leaf_tri.assign(n_leaves * 9 * WIDE, 0.0f);
+    out.leaf_id.assign(n_leaves * WIDE, TN_EMPTY);
+    // boxes of the current level (flat lo.xyz hi.xyz per node)
+    std::vector<float> cur(6 * n_leaves);
+    for (size_t l = 0; l < n_leaves; ++l) {
+        float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < WIDE; ++i) {
+            const size_t s = l * WIDE + i;
+            if (s >= n) break;
+            const uint32_t fid = ids[order[s].second];
+            const uint32_t *f = faces + 3 * (size_t)fid;
+            out.leaf_id[l * WIDE + i] = fid;
+            for (int v = 0; v < 3; ++v)
+                for (int k = 0; k < 3; ++k) {
+                    const float x = xyz[3 * (size_t)f[v] + k];
+                    out.leaf_tri[(l * 9 + v * 3 + k) * WIDE + i] = x;
+                    blo[k] = std::min(blo[k], x); bhi[k] = std::max(bhi[k], x);
+                }
+        }
+        for (int k = 0; k < 3; ++k) { cur[6 * l + k] = blo[k]; cur[6 * l + 3 + k] = bhi[k]; }
+    }
+    out.boxes.clear();
+    size_t count = n_leaves;
+    int level = 0;
+    size_t node_off = 0;
+    do {
+        ++level;
+        if (level >= MAX_LEVELS) throw Error("mesh too large for the wide BVH");
+        const size_t parents = (count + WIDE - 1) / WIDE;
+        out.level_off[level] = (uint32_t)node_off;
+        out.boxes.resize((node_off + parents) * 6 * WIDE);
+        std::vector<float> next(6 * parents);
+        for (size_t p = 0; p < parents; ++p) {
+            float *b = out.boxes.data() + (node_off + p) * 6 * WIDE;
+            float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int i = 0; i < WIDE; ++i) {
+                const size_t c = p * WIDE + i;
+                for (int k = 0; k < 3; ++k) {
+                    // empty child: lo=+inf, hi=-inf never passes the slab test
+                    b[k * WIDE + i] = c < count ? cur[6 * c + k] : INFINITY;
+                    b[(3 + k) * WIDE + i] = c < count ? cur[6 * c + 3 + k] : -INFINITY;
+                    if (c < count) {
+                        blo[k] = std::min(blo[k], cur[6 * c + k]);
+                        bhi[k] = std::max(bhi[k], cur[6 * c + 3 + k]);
+                    }
+                }
+            }
+            for (int k = 0; k < 3; ++k) { next[6 * p + k] = blo[k]; next[6 * p + 3 + k] = bhi[k]; }
+        }
+        node_off += parents;
+        cur.swap(next);
+        count = parents;
+    } while (count > 1);
+    out.top_level = level;
+}
+
+void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const HostMesh &hm,
+                       std::vector<TetRec> &out) {
+    const size_t F = hm.face_tets.size() / 2;
+    // face id of (tet, local face): re-derive by replaying the first-seen enumeration.
+    // A face's first sighting is (face_tets.x, some j); its second (face_tets.y, some j').
+    // Replaying with a per-face cursor avoids a second hash table.
+    out.assign(T, TetRec{});
+    std::vector<uint32_t> tet_face(4 * T, TN_EMPTY);
+    {
+        // bucket faces by tet
+        std::vector<uint32_t> deg(T + 1, 0);
+        for (size_t f = 0; f < F; ++f) {
+            deg[hm.face_tets[2 * f]]++;
+            if (hm.face_tets[2 * f + 1] != TN_EMPTY) deg[hm.face_tets[2 * f + 1]]++;
+        }
+        std::vector<uint32_t> start(T + 1, 0);
+        for (size_t i = 0; i < T; ++i) start[i + 1] = start[i] + deg[i];
+        std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+        std::vector<uint32_t> bucket(start[T]);
+        for (size_t f = 0; f < F; ++f) {
+            bucket[fill[hm.face_tets[2 * f]]++] = (uint32_t)f;
+            if (hm.face_tets[2 * f + 1] != TN_EMPTY) bucket[fill[hm.face_tets[2 * f + 1]]++] = (uint32_t)f;
+        }
+        for (size_t i = 0; i < T; ++i) {
+            const uint32_t *c = cells + 4 * i;
+            for (int j = 0; j < 4; ++j) {
+                const Key3 k = sorted_key(c[(j + 1) & 3], c[(j + 2) & 3], c[(j + 3) & 3]);
+                for (uint32_t s = start[i]; s < start[i + 1]; ++s) {
+                    const uint32_t f = bucket[s];
+                    const Key3 kf = sorted_key(hm.faces[3 * (size_t)f], hm.faces[3 * (size_t)f + 1], hm.faces[3 * (size_t)f + 2]);
+                    if (kf.a == k.a && kf.b == k.b && kf.c == k.c) { tet_face[4 * i + j] = f; break; }
+                }
+                if (tet_face[4 * i + j] == TN_EMPTY) throw Error("internal: face of a tetrahedron not found");
+            }
+        }
+    }
+    for (size_t i = 0; i < T; ++i) {
+        TetRec &r = out[i];
+        const uint32_t *c = cells + 4 * i;
+        r.perm = 0; r.back = 0;
+        for (int k = 0; k < 4; ++k) {
+            r.vert[k] = c[k];
+            for (int a = 0; a < 3; ++a) r.pos[k][a] = xyz[3 * (size_t)c[k] + a];
+        }
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t f = tet_face[4 * i + k];
+            r.face[k] = f;
+            const uint32_t t0 = hm.face_tets[2 * (size_t)f], t1 = hm.face_tets[2 * (size_t)f + 1];
+            const uint32_t nb = (t0 == (uint32_t)i) ? t1 : t0;
+            r.nbr[k] = nb;
+            if (nb != TN_EMPTY) {
+                uint32_t bk = 0;
+                for (; bk < 4; ++bk) if (tet_face[4 * (size_t)nb + bk] == f) break;
+                if (bk == 4) throw Error("internal: neighbour back-pointer not found");
+                r.back |= bk << (2 * k);
+            }
+            for (int m = 0; m < 3; ++m) {
+                const uint32_t sv = hm.faces[3 * (size_t)f + m];
+                uint32_t li = 0;
+                for (; li < 4; ++li) if (c[li] == sv) break;
+                if (li == 4) throw Error("internal: stored face vertex not in tetrahedron");
+                r.perm |= li << (6 * k + 2 * m);
+            }
+        }
+    }
+}
+
+}  // namespace tn

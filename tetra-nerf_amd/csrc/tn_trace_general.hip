@@ -1,0 +1,354 @@
+// tn_trace_general.hip -- general all-hits trace path: ONE WAVEFRONT PER RAY.
+//
+// Replaces, for one ray per 64-lane wave:
+//   __raygen__rg + optixTrace + __anyhit__ms   (src/optix/optix_trace_rays.cu:268-331)
+//   bitonic_sort                                (:78-108)
+//   post_process_tetrahedra                     (:110-266)
+// of the reference.  Structure (all in LDS, nothing spills to the output rows):
+//   1. wave-cooperative traversal of the 64-ary BVH: one lane per child box / per
+//      triangle, __ballot + prefix popcount to push children / append hits;
+//   2. bitonic sort of the <= M-1 hits on the 64-bit key (t bits << 32 | face id) --
+//      a total order, so the result is independent of traversal order;
+//   3. dedupe + pairing: a wave-parallel fast branch when the sorted list is a clean
+//      chain (every consecutive pair shares a tetrahedron, no two consecutive gaps
+//      below eps -- then the reference's phases reduce to "pair j with j+1, drop pairs
+//      shorter than eps"), else the literal serial algorithm on lane 0;
+//   4. coalesced row writes: segments by consecutive lanes, then the tail fill
+//      (visited/verts = 0xFFFFFFFF, bary/dist = 0) so every output byte is written once.
+#include "tn_device.h"
+#include "tn_kernels.h"
+
+namespace tn {
+
+namespace {
+
+struct WaveSmem {
+    uint64_t *key;   // [M]   t bits << 32 | face id
+    float *hu;       // [M]
+    float *hv;       // [M]
+    uint2 *hft;      // [M]   face -> tets of the sorted hit
+    uint32_t *stack; // [STACK_CAP]
+    uint8_t *mark;   // [M]
+};
+
+__device__ __forceinline__ WaveSmem carve(char *smem, uint32_t M) {
+    WaveSmem s;
+    s.key = reinterpret_cast<uint64_t *>(smem);
+    s.hft = reinterpret_cast<uint2 *>(s.key + M);
+    s.hu = reinterpret_cast<float *>(s.hft + M);
+    s.hv = s.hu + M;
+    s.stack = reinterpret_cast<uint32_t *>(s.hv + M);
+    s.mark = reinterpret_cast<uint8_t *>(s.stack + STACK_CAP);
+    return s;
+}
+
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }  // 1-wave workgroups
+
+// keep-the-nearest insertion once the hit buffer is full (rare): replace the current
+// maximum key if the new key is smaller.  Final content = the M-1 smallest keys.
+__device__ void insert_overflow(WaveSmem &s, uint32_t cap, uint64_t k, float u, float v, int lane) {
+    // wave-parallel argmax over cap entries
+    uint64_t best = 0;
+    uint32_t bidx = 0;
+    for (uint32_t i = lane; i < cap; i += 64) {
+        const uint64_t x = s.key[i];
+        if (x >= best) { best = x; bidx = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t ob = __shfl_xor(best, off);
+        const uint32_t oi = __shfl_xor(bidx, off);
+        if (ob > best || (ob == best && oi > bidx)) { best = ob; bidx = oi; }
+    }
+    if (k < best && lane == 0) { s.key[bidx] = k; s.hu[bidx] = u; s.hv[bidx] = v; }
+    wave_sync();
+}
+
+// ---- stage 3+4: dedupe / pairing / row write for one ray; hits sorted in LDS -------------
+__device__ void postprocess_and_write(const WaveSmem &s, uint32_t nh, uint32_t M, const uint32_t *__restrict__ faces,
+                                      const uint32_t *__restrict__ face_tets, uint32_t *__restrict__ out_num,
+                                      uint32_t *__restrict__ out_cells, float *__restrict__ out_bary,
+                                      float *__restrict__ out_dist, uint32_t *__restrict__ out_verts,
+                                      unsigned long long *stats, int lane) {
+    // face -> tets of each sorted hit
+    for (uint32_t j = lane; j < nh; j += 64) {
+        const uint32_t id = (uint32_t)s.key[j];
+        s.hft[j] = *reinterpret_cast<const uint2 *>(face_tets + 2 * (size_t)id);
+        s.mark[j] = 0;
+    }
+    wave_sync();
+
+    // clean-chain test
+    bool bad = false;
+    for (uint32_t j = lane; j + 1 < nh; j += 64) {
+        uint32_t c;
+        const float t0 = __uint_as_float((uint32_t)(s.key[j] >> 32));
+        const float t1 = __uint_as_float((uint32_t)(s.key[j + 1] >> 32));
+        if (!common_tet(s.hft[j], s.hft[j + 1], c)) bad = true;
+        if (j + 2 < nh) {
+            const float t2 = __uint_as_float((uint32_t)(s.key[j + 2] >> 32));
+            if (fabsf(t1 - t0) < TN_EPS && fabsf(t2 - t1) < TN_EPS) bad = true;
+        }
+    }
+    const bool clean = (__ballot(bad) == 0ull);
+
+    uint32_t nseg = 0;
+    if (clean) {
+        for (uint32_t base = 0; base + 1 < nh; base += 64) {
+            const uint32_t j = base + lane;
+            bool emit = false;
+            float t0 = 0.f, t1 = 0.f;
+            uint32_t cell = TN_EMPTY;
+            if (j + 1 < nh) {
+                t0 = __uint_as_float((uint32_t)(s.key[j] >> 32));
+                t1 = __uint_as_float((uint32_t)(s.key[j + 1] >> 32));
+                common_tet(s.hft[j], s.hft[j + 1], cell);
+                emit = fabsf(t0 - t1) >= TN_EPS;
+            }
+            const uint64_t m = __ballot(emit);
+            if (emit) {
+                const uint32_t slot = nseg + __popcll(m & lanemask_lt());
+                const uint32_t f0 = (uint32_t)s.key[j], f1 = (uint32_t)s.key[j + 1];
+                const uint32_t id1[3] = {faces[3 * (size_t)f0], faces[3 * (size_t)f0 + 1], faces[3 * (size_t)f0 + 2]};
+                const uint32_t id2[3] = {faces[3 * (size_t)f1], faces[3 * (size_t)f1 + 1], faces[3 * (size_t)f1 + 2]};
+                uint32_t vi[4];
+                float b1[3], b2[3];
+                combine_indices(id1, id2, s.hu[j], s.hv[j], s.hu[j + 1], s.hv[j + 1], vi, b1, b2);
+                out_cells[slot] = cell;
+                *reinterpret_cast<float2 *>(out_dist + 2 * (size_t)slot) = make_float2(t0, t1);
+                float2 *bp = reinterpret_cast<float2 *>(out_bary + 6 * (size_t)slot);
+                bp[0] = make_float2(b1[0], b1[1]);
+                bp[1] = make_float2(b1[2], b2[0]);
+                bp[2] = make_float2(b2[1], b2[2]);
+                if (out_verts) *reinterpret_cast<uint4 *>(out_verts + 4 * (size_t)slot) = make_uint4(vi[0], vi[1], vi[2], vi[3]);
+            }
+            nseg += __popcll(m);
+        }
+    } else {
+        // literal serial restatement (optix_trace_rays.cu:124-257) on lane 0.
+        if (lane == 0) {
+            if (stats) atomicAdd(&stats[2], 1ull);
+            auto T = [&](uint32_t j) { return __uint_as_float((uint32_t)(s.key[j] >> 32)); };
+            auto ID = [&](uint32_t j) { return (uint32_t)s.key[j]; };
+            // phase 1
+            for (uint32_t j = 0; j + 1 < nh; ++j) {
+                if (ID(j) == TN_EMPTY) continue;
+                const float dn = T(j);
+                bool clear_self = false;
+                for (uint32_t off = 1; j + off < nh && (ID(j + off) == TN_EMPTY || fabsf(T(j + off) - dn) < TN_EPS); ++off) {
+                    uint32_t c;
+                    if (ID(j + off) != TN_EMPTY && common_tet(s.hft[j], s.hft[j + off], c)) {
+                        if (ID(j) != ID(j + off)) clear_self = true;
+                        if (s.mark[j + off]) s.key[j + off] = (s.key[j + off] & 0xFFFFFFFF00000000ull) | TN_EMPTY;
+                        else s.mark[j + off] = 1;
+                    }
+                }
+                if (clear_self && s.mark[j]) s.key[j] = (s.key[j] & 0xFFFFFFFF00000000ull) | TN_EMPTY;
+                s.mark[j] = 0;
+            }
+            // phase 2
+            uint32_t jc = 0;
+            for (uint32_t j = 0; j < nh; ++j) {
+                if (ID(j) == TN_EMPTY) continue;
+                const uint2 orig = s.hft[j];
+                float dn = T(j);
+                uint32_t real_off = 1;
+                for (uint32_t off = 1; j + off < nh && (real_off < 3 || ID(j + off) == TN_EMPTY || fabsf(T(j + off) - dn) < TN_EPS); ++off) {
+                    if (ID(j + off) == TN_EMPTY) continue;
+                    uint32_t cell;
+                    if (common_tet(orig, s.hft[j + off], cell)) {
+                        if (fabsf(T(j) - T(j + off)) >= TN_EPS) {
+                            const uint32_t f0 = ID(j), f1 = ID(j + off);
+                            const uint32_t id1[3] = {faces[3 * (size_t)f0], faces[3 * (size_t)f0 + 1], faces[3 * (size_t)f0 + 2]};
+                            const uint32_t id2[3] = {faces[3 * (size_t)f1], faces[3 * (size_t)f1 + 1], faces[3 * (size_t)f1 + 2]};
+                            uint32_t vi[4];
+                            float b1[3], b2[3];
+                            combine_indices(id1, id2, s.hu[j], s.hv[j], s.hu[j + off], s.hv[j + off], vi, b1, b2);
+                            out_cells[jc] = cell;
+                            out_dist[2 * (size_t)jc] = T(j); out_dist[2 * (size_t)jc + 1] = T(j + off);
+                            for (int k = 0; k < 3; ++k) { out_bary[6 * (size_t)jc + k] = b1[k]; out_bary[6 * (size_t)jc + 3 + k] = b2[k]; }
+                            if (out_verts) for (int k = 0; k < 4; ++k) out_verts[4 * (size_t)jc + k] = vi[k];
+                            jc++;
+                        }
+                        if (off > 1) {
+                            // swap(dl, first bary record, id) of slots j+off and j+1 (:244-250)
+                            const uint64_t k0 = s.key[j + off]; s.key[j + off] = s.key[j + 1]; s.key[j + 1] = k0;
+                            const float u0 = s.hu[j + off]; s.hu[j + off] = s.hu[j + 1]; s.hu[j + 1] = u0;
+                            const float v0 = s.hv[j + off]; s.hv[j + off] = s.hv[j + 1]; s.hv[j + 1] = v0;
+                            const uint2 f0 = s.hft[j + off]; s.hft[j + off] = s.hft[j + 1]; s.hft[j + 1] = f0;
+                            const uint8_t m0 = s.mark[j + off]; s.mark[j + off] = s.mark[j + 1]; s.mark[j + 1] = m0;
+                        }
+                        break;
+                    }
+                    dn = T(j + off);
+                    real_off++;
+                }
+            }
+            nseg = jc;
+        }
+        nseg = __shfl(nseg, 0);
+    }
+
+    // tail fill: every remaining byte of the rows, coalesced
+    for (uint32_t j = nseg + lane; j < M; j += 64) {
+        out_cells[j] = TN_EMPTY;
+        *reinterpret_cast<float2 *>(out_dist + 2 * (size_t)j) = make_float2(0.f, 0.f);
+        float2 *bp = reinterpret_cast<float2 *>(out_bary + 6 * (size_t)j);
+        bp[0] = make_float2(0.f, 0.f); bp[1] = make_float2(0.f, 0.f); bp[2] = make_float2(0.f, 0.f);
+        if (out_verts) *reinterpret_cast<uint4 *>(out_verts + 4 * (size_t)j) = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
+    }
+    if (lane == 0) *out_num = nseg;
+}
+
+__device__ void sort_hits(const WaveSmem &s, uint32_t nh, int lane) {
+    uint32_t Np = 1;
+    while (Np < nh) Np <<= 1;
+    for (uint32_t i = nh + lane; i < Np; i += 64) s.key[i] = ~0ull;
+    wave_sync();
+    for (uint32_t k = 2; k <= Np; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t tix = lane; tix < (Np >> 1); tix += 64) {
+                // index of the lower element of the tix-th compare-exchange pair
+                const uint32_t i = ((tix & ~(j - 1)) << 1) | (tix & (j - 1));
+                const uint32_t ij = i | j;
+                const uint64_t a = s.key[i], b = s.key[ij];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up && a != b) {
+                    s.key[i] = b; s.key[ij] = a;
+                    const float ua = s.hu[i], ub = s.hu[ij]; s.hu[i] = ub; s.hu[ij] = ua;
+                    const float va = s.hv[i], vb = s.hv[ij]; s.hv[i] = vb; s.hv[ij] = va;
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WaveSmem s = carve(smem, p.M);
+    const int lane = threadIdx.x;
+    const uint32_t M = p.M;
+    const uint32_t cap = M - 1;  // at most M-1 hits are kept (optix_trace_rays.cu:312-315)
+
+    for (size_t it = blockIdx.x; it < p.num_items; it += gridDim.x) {
+        const size_t ray = p.ray_list ? (size_t)p.ray_list[it] : it;
+        const float ox = p.origins[3 * ray], oy = p.origins[3 * ray + 1], oz = p.origins[3 * ray + 2];
+        const float dx = p.dirs[3 * ray], dy = p.dirs[3 * ray + 1], dz = p.dirs[3 * ray + 2];
+        const RayPre rp = ray_pre(ox, oy, oz, dx, dy, dz);
+        const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+        const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.bvh.scene_max);
+
+        uint32_t nh = 0;      // hits stored (wave-uniform)
+        uint32_t sp = 1;      // stack pointer (wave-uniform)
+        bool overflow = false;
+        if (lane == 0) s.stack[0] = ((uint32_t)p.bvh.top_level << 28);
+        wave_sync();
+        while (sp > 0) {
+            const uint32_t e = s.stack[sp - 1];
+            sp--;
+            const uint32_t level = e >> 28, idx = e & 0x0FFFFFFFu;
+            wave_sync();  // everyone has read the top before it can be overwritten
+            if (level > 0) {
+                const float *b = p.bvh.boxes + ((size_t)p.bvh.level_off[level] + idx) * (6 * WIDE);
+                const bool hit = line_box(ox, oy, oz, ix, iy, iz, b[lane], b[WIDE + lane], b[2 * WIDE + lane],
+                                          b[3 * WIDE + lane], b[4 * WIDE + lane], b[5 * WIDE + lane], pad);
+                const uint64_t m = __ballot(hit);
+                if (hit) s.stack[sp + __popcll(m & lanemask_lt())] = ((level - 1) << 28) | (idx * WIDE + lane);
+                sp += __popcll(m);
+            } else {
+                const float *tr = p.bvh.leaf_tri + (size_t)idx * (9 * WIDE);
+                const uint32_t fid = p.bvh.leaf_id[(size_t)idx * WIDE + lane];
+                const SV A = shear(rp, tr[lane], tr[WIDE + lane], tr[2 * WIDE + lane]);
+                const SV B = shear(rp, tr[3 * WIDE + lane], tr[4 * WIDE + lane], tr[5 * WIDE + lane]);
+                const SV C = shear(rp, tr[6 * WIDE + lane], tr[7 * WIDE + lane], tr[8 * WIDE + lane]);
+                float t = 0.f, u = 0.f, v = 0.f;
+                const bool hit = (fid != TN_EMPTY) && tri_hit_sv(A, B, C, t, u, v);
+                const uint64_t m = __ballot(hit);
+                const uint32_t c = __popcll(m);
+                if (c) {
+                    const uint64_t k = ((uint64_t)__float_as_uint(t) << 32) | fid;
+                    if (nh + c <= cap) {
+                        if (hit) {
+                            const uint32_t slot = nh + __popcll(m & lanemask_lt());
+                            s.key[slot] = k; s.hu[slot] = u; s.hv[slot] = v;
+                        }
+                        nh += c;
+                    } else {
+                        overflow = true;
+                        uint64_t mm = m;
+                        while (mm) {
+                            const int src = __ffsll((unsigned long long)mm) - 1;
+                            mm &= mm - 1;
+                            const uint64_t ks = __shfl(k, src);
+                            const float us = __shfl(u, src), vs = __shfl(v, src);
+                            if (nh < cap) {
+                                if (lane == 0) { s.key[nh] = ks; s.hu[nh] = us; s.hv[nh] = vs; }
+                                nh++;
+                                wave_sync();
+                            } else {
+                                insert_overflow(s, cap, ks, us, vs, lane);
+                            }
+                        }
+                    }
+                }
+            }
+            wave_sync();
+        }
+        if (overflow && lane == 0 && p.stats) atomicAdd(&p.stats[3], 1ull);
+
+        sort_hits(s, nh, lane);
+        postprocess_and_write(s, nh, M, p.faces, p.face_tets, p.out_num + ray, p.out_cells + ray * M,
+                              p.out_bary + ray * M * 6, p.out_dist + ray * M * 2,
+                              p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane);
+        wave_sync();
+    }
+}
+
+// post-process only (test aid, tn_postprocess_hits): rows of caller-supplied sorted hits
+__global__ __launch_bounds__(64) void k_postprocess_hits(TraceParams p, const uint32_t *hit_count,
+                                                         const uint32_t *hit_ids, const float *hit_t,
+                                                         const float *hit_uv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WaveSmem s = carve(smem, p.M);
+    const int lane = threadIdx.x;
+    const uint32_t M = p.M;
+    for (size_t ray = blockIdx.x; ray < p.num_items; ray += gridDim.x) {
+        const uint32_t nh = hit_count[ray] < M ? hit_count[ray] : M;
+        for (uint32_t j = lane; j < nh; j += 64) {
+            s.key[j] = ((uint64_t)__float_as_uint(hit_t[ray * M + j]) << 32) | hit_ids[ray * M + j];
+            s.hu[j] = hit_uv[2 * (ray * M + j)];
+            s.hv[j] = hit_uv[2 * (ray * M + j) + 1];
+        }
+        wave_sync();
+        postprocess_and_write(s, nh, M, p.faces, p.face_tets, p.out_num + ray, p.out_cells + ray * M,
+                              p.out_bary + ray * M * 6, p.out_dist + ray * M * 2,
+                              p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane);
+        wave_sync();
+    }
+}
+
+size_t trace_general_smem_bytes(uint32_t M) {
+    return (size_t)M * (8 + 8 + 4 + 4) + STACK_CAP * 4 + M;
+}
+
+void launch_trace_general(const TraceParams &p, hipStream_t stream) {
+    if (p.num_items == 0) return;
+    const size_t smem = trace_general_smem_bytes(p.M);
+    const size_t max_blocks = 256 * 16;
+    const unsigned grid = (unsigned)(p.num_items < max_blocks ? p.num_items : max_blocks);
+    hipLaunchKernelGGL(k_trace_general, dim3(grid), dim3(64), smem, stream, p);
+}
+
+void launch_postprocess_hits(const TraceParams &p, const uint32_t *hit_count, const uint32_t *hit_ids,
+                             const float *hit_t, const float *hit_uv, hipStream_t stream) {
+    if (p.num_items == 0) return;
+    const size_t smem = trace_general_smem_bytes(p.M);
+    const size_t max_blocks = 256 * 16;
+    const unsigned grid = (unsigned)(p.num_items < max_blocks ? p.num_items : max_blocks);
+    hipLaunchKernelGGL(k_postprocess_hits, dim3(grid), dim3(64), smem, stream, p, hit_count, hit_ids, hit_t, hit_uv);
+}
+
+}  // namespace tn

@@ -1,0 +1,284 @@
+"""Drop-in for the reference's pybind11 module `tetranerf_cpp_extension`
+(/root/reference/src/py_binding.cpp:433-449), backed by libtetranerf_hip.so on MI355X.
+
+Same names, argument meaning, result dictionaries, dtypes/shapes and error behaviour:
+
+    TetrahedraTracer(device)                      py_binding.cpp:28-40
+      .device                                     :218-220, 436
+      .load_tetrahedra(xyz, cells)                :144-161
+      .trace_rays(origins, directions, M)         :41-76
+      .find_visited_cells(...)                    :163-216
+    interpolate_values(vi, bc, field)             :298-330
+    interpolate_values_backward(vi, bc, field, g) :341-372
+    triangulate(points), find_average_spacing(points)   :229-256 (CGAL there; scipy here, CPU, offline)
+    gather_uint32 / scatter_ema_uint32            :374-431 (not on the model path)
+
+Host code is PyTorch plumbing only: tensor checks, output allocation (torch.empty -- the
+kernels write every byte, so the reference's torch::zeros memset pass is not needed) and raw
+pointers + the current HIP stream handed to the C-ABI.  Nothing here computes on the CPU and
+nothing imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _check(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_input(x, name):
+    _check(isinstance(x, torch.Tensor), f"{name} must be a tensor")
+    _check(x.device.type == "cuda", f"{name} must be a CUDA tensor")
+    _check(x.is_contiguous(), f"{name} must be contiguous")
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class TetrahedraTracer:
+    """OptiX-free tetrahedra tracer; API of PyTetrahedraTracer (py_binding.cpp:28-227)."""
+
+    def __init__(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("The device argument must be a CUDA device.")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self._device = device
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.tn_tracer_create(int(device.index), C.byref(h)))
+        self._h = h
+        self.tetrahedra_vertices = None
+        self.tetrahedra_cells = None
+
+    # read-only property, compared by the model to decide re-creation (model.py:398-402)
+    @property
+    def device(self):
+        return self._device
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.tn_tracer_destroy(h)
+        self.tetrahedra_vertices = None
+        self.tetrahedra_cells = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check_float_dim3(self, x, name):
+        _check_input(x, name)
+        _check(x.device == self._device, f"{name} must be on the same device")
+        _check(x.dtype == torch.float32, f"{name} must have float32 type")
+        _check(x.dim() >= 1 and x.size(-1) == 3, f"{name} must have last dimension with size 3")
+
+    def load_tetrahedra(self, xyz, cells):
+        self._check_float_dim3(xyz, "xyz")
+        _check_input(cells, "cells")
+        _check(cells.device == self._device, "cells must be on the same device")
+        _check(cells.dim() >= 1 and cells.size(-1) == 4, "indices must have last dimension with size 4")
+        _check(cells.dtype == torch.int32, "indices must have int32 type")
+        # borrowed, not copied (tetrahedra_tracer.h:300-303): keep them alive
+        self.tetrahedra_cells = cells
+        self.tetrahedra_vertices = xyz
+        _lib.check(self._lib.tn_load_tetrahedra(
+            self._h, xyz.numel() // 3, cells.numel() // 4, _ptr(xyz), _ptr(cells), _stream(self._device)))
+
+    def trace_rays(self, ray_origins, ray_directions, max_ray_triangles):
+        M = int(max_ray_triangles)
+        if M <= 0 or (M & (M - 1)) != 0:
+            raise RuntimeError("max_ray_triangles must be a power of 2.")
+        with torch.no_grad():
+            self._check_float_dim3(ray_origins, "ray_origins")
+            self._check_float_dim3(ray_directions, "ray_directions")
+            R = ray_origins.numel() // 3
+            _check(ray_directions.numel() // 3 == R, "ray_origins and ray_directions must have the same number of rays")
+            dev = self._device
+            num_visited_cells = torch.empty((R,), dtype=torch.int32, device=dev)
+            visited_cells = torch.empty((R, M), dtype=torch.int32, device=dev)
+            barycentric_coordinates = torch.empty((R, M, 2, 3), dtype=torch.float32, device=dev)
+            hit_distances = torch.empty((R, M, 2), dtype=torch.float32, device=dev)
+            vertex_indices = torch.empty((R, M, 4), dtype=torch.int32, device=dev)
+            _lib.check(self._lib.tn_trace_rays(
+                self._h, R, M, _ptr(ray_origins), _ptr(ray_directions), _ptr(num_visited_cells),
+                _ptr(visited_cells), _ptr(barycentric_coordinates), _ptr(hit_distances),
+                _ptr(vertex_indices), _stream(dev)))
+        return {
+            "num_visited_cells": num_visited_cells,
+            "visited_cells": visited_cells,
+            "barycentric_coordinates": barycentric_coordinates,
+            "vertex_indices": vertex_indices,
+            "hit_distances": hit_distances,
+        }
+
+    def find_visited_cells(self, num_visited_cells, visited_cells, barycentric_coordinates,
+                           hit_distances, vertex_indices, distances):
+        for x, name in ((num_visited_cells, "num_visited_cells"), (visited_cells, "visited_cells"),
+                        (barycentric_coordinates, "barycentric_coordinates"),
+                        (hit_distances, "hit_distances"), (distances, "distances"),
+                        (vertex_indices, "vertex_indices")):
+            _check_input(x, name)
+            _check(x.device == self._device, f"{name} must be on the same device")
+        _check(distances.dtype == torch.float32, "distances must have float32 type")
+        R = num_visited_cells.size(0)
+        _check(distances.dim() == 2 and distances.size(0) == R,
+               "distances must be of [num_rays, num_samples_per_ray] shape")
+        _check(vertex_indices.size(-1) == 4, "vertex_indices must have last dimension with size 4")
+        _check(self.tetrahedra_vertices is not None, "load_tetrahedra must be called first")
+        _check(num_visited_cells.dtype == torch.int32 and visited_cells.dtype == torch.int32
+               and vertex_indices.dtype == torch.int32, "index tensors must have int32 type")
+        _check(hit_distances.dtype == torch.float32 and barycentric_coordinates.dtype == torch.float32,
+               "hit_distances / barycentric_coordinates must have float32 type")
+        S = distances.size(-1)
+        M = visited_cells.size(1)
+        dev = self._device
+        mask = torch.empty((R, S), dtype=torch.bool, device=dev)
+        matched_cells = torch.empty((R, S), dtype=torch.int32, device=dev)
+        barycentric_coordinates_out = torch.empty((R, S, 3), dtype=torch.float32, device=dev)
+        vertex_indices_out = torch.empty((R, S, 4), dtype=torch.int32, device=dev)
+        _lib.check(self._lib.tn_find_matched_cells(
+            R, S, M, _ptr(num_visited_cells), _ptr(visited_cells), _ptr(hit_distances),
+            _ptr(barycentric_coordinates), _ptr(distances), _ptr(vertex_indices), _ptr(matched_cells),
+            _ptr(vertex_indices_out), _ptr(mask), _ptr(barycentric_coordinates_out), _stream(dev)))
+        return {
+            "cell_indices": matched_cells,
+            "vertex_indices": vertex_indices_out,
+            "mask": mask,
+            "barycentric_coordinates": barycentric_coordinates_out,
+        }
+
+    # -- additions (not in the reference surface) ------------------------------------------
+    def trace_stats(self):
+        """Counters of the last trace_rays call: walk / general / serial-literal / overflow rays."""
+        arr = (C.c_uint64 * 4)()
+        _lib.check(self._lib.tn_trace_stats(self._h, C.byref(arr)))
+        return {"walk": arr[0], "general": arr[1], "serial": arr[2], "overflow": arr[3]}
+
+    def set_option(self, name: str, value: int):
+        _lib.check(self._lib.tn_set_option(self._h, name.encode(), int(value)))
+
+    def face_tables(self):
+        """(faces [F,3], face_tets [F,2]) int64 CPU tensors of the loaded mesh (debug aid)."""
+        F = self._lib.tn_num_faces(self._h)
+        faces = torch.empty((F, 3), dtype=torch.int32)
+        ft = torch.empty((F, 2), dtype=torch.int32)
+        _lib.check(self._lib.tn_get_faces(self._h, _ptr(faces), _ptr(ft)))
+        return faces, ft
+
+    def postprocess_hits(self, hit_count, hit_ids, hit_t, hit_uv):
+        """Run only the dedupe/pairing stage on sorted hit rows (test aid)."""
+        R, M = hit_ids.shape
+        dev = self._device
+        out = {
+            "num_visited_cells": torch.empty((R,), dtype=torch.int32, device=dev),
+            "visited_cells": torch.empty((R, M), dtype=torch.int32, device=dev),
+            "barycentric_coordinates": torch.empty((R, M, 2, 3), dtype=torch.float32, device=dev),
+            "hit_distances": torch.empty((R, M, 2), dtype=torch.float32, device=dev),
+            "vertex_indices": torch.empty((R, M, 4), dtype=torch.int32, device=dev),
+        }
+        _lib.check(self._lib.tn_postprocess_hits(
+            self._h, R, M, _ptr(hit_count), _ptr(hit_ids), _ptr(hit_t), _ptr(hit_uv),
+            _ptr(out["num_visited_cells"]), _ptr(out["visited_cells"]), _ptr(out["barycentric_coordinates"]),
+            _ptr(out["hit_distances"]), _ptr(out["vertex_indices"]), _stream(dev)))
+        return out
+
+
+def interpolate_values(vertex_indices, barycentric_coordinates, field):
+    """py_interpolate_values (py_binding.cpp:298-330): returns [..., field_dim] as a
+    moveaxis(0,-1) view of a contiguous [field_dim, n] buffer."""
+    for x, name in ((vertex_indices, "vertex_indices"), (barycentric_coordinates, "barycentric_coordinates"),
+                    (field, "field")):
+        _check_input(x, name)
+    _check(vertex_indices.dtype == torch.int32, "vertex_indices must be a tensor of type int32")
+    _check(barycentric_coordinates.dtype == torch.float32, "barycentric_coordinates must be a tensor of type float32")
+    _check(barycentric_coordinates.size(-1) + 1 == vertex_indices.size(-1),
+           "barycentric_coordinates must have the same last dimension as vertex_indices - 1")
+    _check(field.dtype == torch.float32, "field must be a tensor of type float32")
+    D = vertex_indices.size(-1)
+    n = vertex_indices.numel() // D
+    Fd, V = field.size(0), field.size(-1)
+    result = torch.empty((Fd,) + tuple(vertex_indices.shape[:-1]), dtype=field.dtype, device=field.device)
+    with torch.cuda.device(field.device):
+        _lib.check(_lib.load().tn_interpolate_values(
+            D, V, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates), _ptr(field), _ptr(result),
+            _stream(field.device)))
+    return result.moveaxis(0, -1)
+
+
+def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, grad_in):
+    """py_interpolate_values_backward (py_binding.cpp:341-372)."""
+    for x, name in ((vertex_indices, "vertex_indices"), (barycentric_coordinates, "barycentric_coordinates"),
+                    (field, "field"), (grad_in, "grad_in")):
+        _check_input(x, name)
+    _check(vertex_indices.dtype == torch.int32, "vertex_indices must be a tensor of type int32")
+    _check(barycentric_coordinates.dtype == torch.float32, "barycentric_coordinates must be a tensor of type float32")
+    _check(field.dtype == torch.float32, "field must be a tensor of type float32")
+    _check(grad_in.dtype == torch.float32, "grad_in must be a tensor of type float32")
+    _check(barycentric_coordinates.size(-1) + 1 == vertex_indices.size(-1),
+           "barycentric_coordinates must have the same last dimension as vertex_indices - 1")
+    D = vertex_indices.size(-1)
+    n = vertex_indices.numel() // D
+    Fd, V = field.size(0), field.size(-1)
+    _check(grad_in.size(-1) == Fd, "grad_in must have shape [..., field_dim]")
+    g = grad_in.moveaxis(-1, 0).contiguous()
+    grad_field_out = torch.empty((Fd, V), dtype=grad_in.dtype, device=grad_in.device)
+    with torch.cuda.device(field.device):
+        _lib.check(_lib.load().tn_interpolate_values_backward(
+            D, V, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates), _ptr(g), _ptr(grad_field_out),
+            _stream(field.device)))
+    return grad_field_out
+
+
+def triangulate(points):
+    """py_triangulate (py_binding.cpp:239-256).  The reference runs CGAL's Delaunay on the CPU
+    (src/triangulation.cpp:34-75); CGAL is not part of this build, Qhull (scipy) stands in.
+    Offline preprocessing, not on the hot path."""
+    _check(points.dim() == 2 and points.size(1) == 3, "points must have shape [num_points, 3]")
+    from .scenes import delaunay_cells
+
+    cells = delaunay_cells(points.detach().cpu().contiguous().numpy())
+    return torch.from_numpy(cells).to(points.device)
+
+
+def find_average_spacing(points):
+    """py_find_average_spacing (py_binding.cpp:229-237): mean distance to the 6 nearest
+    neighbours (CGAL::compute_average_spacing<6>, src/triangulation.cpp:121-134)."""
+    _check(points.is_contiguous(), "points must be contiguous")
+    _check(points.device.type == "cpu", "points must be a CPU tensor")
+    _check(points.dim() == 2 and points.size(1) == 3, "points must have shape [num_points, 3]")
+    from scipy.spatial import cKDTree
+
+    p = points.numpy()
+    d, _ = cKDTree(p).query(p, k=7)
+    return float(d[:, 1:].mean())
+
+
+def gather_uint32(self, dim, index):
+    """py_gather_uint32 (py_binding.cpp:374-399); not called by the model.  PyTorch plumbing."""
+    _check(index.dtype == torch.int32, "index must be a tensor of type int32")
+    _check(self.is_floating_point(), "self must be a tensor of a floating-point type")
+    _check(self.device == index.device, "self and index must be on the same device")
+    _check(self.dim() == 1 and index.dim() == 1, "self and index must have the same number of dimensions")
+    _check(dim == 0, "dim must be 0")
+    return self[index.long() & 0xFFFFFFFF]
+
+
+def scatter_ema_uint32(self, dim, index, decay, values):
+    """py_scatter_ema_uint32 (py_binding.cpp:405-431); dormant occupancy-field op, not on the
+    model path."""
+    raise RuntimeError("scatter_ema_uint32 is not part of the MI355X hot-path build (unused by the model)")
