@@ -42,7 +42,7 @@ struct DevWideBvh {
         leaf_id.upload(h.leaf_id);
         boxes.upload(h.boxes);
         view.leaf_tri = leaf_tri.p; view.leaf_id = leaf_id.p; view.boxes = boxes.p;
-        for (int i = 0; i < MAX_LEVELS; ++i) view.level_off[i] = h.level_off[i];
+        for (int i = 0; i < MAX_LEVELS; ++i) { view.level_off[i] = h.level_off[i]; view.level_cnt[i] = h.level_cnt[i]; }
         view.top_level = h.top_level;
         view.scene_max = scene_max;
     }

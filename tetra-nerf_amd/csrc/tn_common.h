@@ -40,6 +40,7 @@ struct WideBvh {
     const uint32_t *leaf_id;    // [n_leaves][64]     face id or TN_EMPTY
     const float *boxes;         // [n_internal][6][64] lo.xyz hi.xyz
     uint32_t level_off[MAX_LEVELS];  // node offset of each internal level into `boxes`
+    uint32_t level_cnt[MAX_LEVELS];  // number of nodes of each level (level 0 = leaves)
     int top_level;              // the root is node 0 of this level (>= 1)
     float scene_max;            // max |coordinate| over the mesh vertices
 };
@@ -87,6 +88,7 @@ struct HostWideBvh {
     std::vector<uint32_t> leaf_id;
     std::vector<float> boxes;
     uint32_t level_off[MAX_LEVELS] = {0};
+    uint32_t level_cnt[MAX_LEVELS] = {0};
     int top_level = 1;
 };
 

@@ -138,6 +138,7 @@ void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<u
         for (int k = 0; k < 3; ++k) { cur[6 * l + k] = blo[k]; cur[6 * l + 3 + k] = bhi[k]; }
     }
     out.boxes.clear();
+    out.level_cnt[0] = (uint32_t)n_leaves;
     size_t count = n_leaves;
     int level = 0;
     size_t node_off = 0;
@@ -146,6 +147,7 @@ void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<u
         if (level >= MAX_LEVELS) throw Error("mesh too large for the wide BVH");
         const size_t parents = (count + WIDE - 1) / WIDE;
         out.level_off[level] = (uint32_t)node_off;
+        out.level_cnt[level] = (uint32_t)parents;
         out.boxes.resize((node_off + parents) * 6 * WIDE);
         std::vector<float> next(6 * parents);
         for (size_t p = 0; p < parents; ++p) {

@@ -253,8 +253,9 @@ __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
             wave_sync();  // everyone has read the top before it can be overwritten
             if (level > 0) {
                 const float *b = p.bvh.boxes + ((size_t)p.bvh.level_off[level] + idx) * (6 * WIDE);
-                const bool hit = line_box(ox, oy, oz, ix, iy, iz, b[lane], b[WIDE + lane], b[2 * WIDE + lane],
-                                          b[3 * WIDE + lane], b[4 * WIDE + lane], b[5 * WIDE + lane], pad);
+                const bool valid = idx * WIDE + lane < p.bvh.level_cnt[level - 1];
+                const bool hit = valid && line_box(ox, oy, oz, ix, iy, iz, b[lane], b[WIDE + lane], b[2 * WIDE + lane],
+                                                   b[3 * WIDE + lane], b[4 * WIDE + lane], b[5 * WIDE + lane], pad);
                 const uint64_t m = __ballot(hit);
                 if (hit) s.stack[sp + __popcll(m & lanemask_lt())] = ((level - 1) << 28) | (idx * WIDE + lane);
                 sp += __popcll(m);
