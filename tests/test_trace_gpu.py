@@ -18,10 +18,11 @@ def _to_np(out):
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
-def _gpu_tracer(tn, device, pts, cells):
+def _gpu_tracer(tn, device, pts, cells, walk=1):
     import torch
 
     tr = tn.TetrahedraTracer(device)
+    tr.set_option("walk", walk)
     tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
     return tr
 
@@ -50,19 +51,21 @@ def test_face_tables_match_oracle(tn, device, oracle, scenes, bottle):
         np.testing.assert_array_equal(ft.numpy().view(np.uint32), oft)
 
 
-def test_cube_rays(tn, device, oracle, scenes):
+@pytest.mark.parametrize("walk", [0, 1])
+def test_cube_rays(tn, device, oracle, scenes, walk):
     pts, cells = scenes.cube_mesh()
     o = np.array([[-0.05, 0.05, 0.05], [-0.05, 0.07, 0.13], [0.5, 0.5, 0.5], [2, 2, 2], [0.3, 0.2, -1]], np.float32)
     d = np.array([[1, 0, 0], [1.0, 0.11, 0.23], [0.3, -0.2, 0.9], [1, 0, 0], [0, 0, 1]], np.float32)
     d /= np.linalg.norm(d, axis=-1, keepdims=True)
     ot = oracle.OracleTracer()
     ot.load_tetrahedra(pts, cells)
-    tr = _gpu_tracer(tn, device, pts, cells)
+    tr = _gpu_tracer(tn, device, pts, cells, walk)
     for M in (16, 64):
         _assert_same(_trace(tr, device, o, d, M), ot.trace_rays(o, d, M), f"cube M={M}")
 
 
-def test_bottle_c1(tn, device, oracle, scenes, bottle):
+@pytest.mark.parametrize("walk", [0, 1])
+def test_bottle_c1(tn, device, oracle, scenes, bottle, walk):
     """Config C1 of BASELINE.json: bottle mesh, 64x64 rays, M=256, then 300 samples."""
     import torch
 
@@ -71,7 +74,7 @@ def test_bottle_c1(tn, device, oracle, scenes, bottle):
     ot = oracle.OracleTracer()
     ot.load_tetrahedra(pts, cells)
     want = ot.trace_rays(o, d, 256)
-    tr = _gpu_tracer(tn, device, pts, cells)
+    tr = _gpu_tracer(tn, device, pts, cells, walk)
     out = tr.trace_rays(torch.from_numpy(o).to(device), torch.from_numpy(d).to(device), 256)
     got = _to_np(out)
     _assert_same(got, want, "bottle")
@@ -90,12 +93,13 @@ def test_bottle_c1(tn, device, oracle, scenes, bottle):
                                   winter["barycentric_coordinates"].view(np.uint32))
 
 
+@pytest.mark.parametrize("walk", [0, 1])
 @pytest.mark.parametrize("npts,seed,M", [(2000, 3, 256), (15000, 0, 512)])
-def test_random_mesh_parity(tn, device, oracle, scenes, npts, seed, M):
+def test_random_mesh_parity(tn, device, oracle, scenes, npts, seed, M, walk):
     pts, cells = scenes.random_mesh(npts, seed)
     ot = oracle.OracleTracer(use_bvh=True)
     ot.load_tetrahedra(pts, cells)
-    tr = _gpu_tracer(tn, device, pts, cells)
+    tr = _gpu_tracer(tn, device, pts, cells, walk)
     for name, (o, d) in (("outside_in", scenes.outside_in_rays(4096, seed + 10)),
                          ("inside_out", scenes.inside_out_rays(4096, seed + 20))):
         want = ot.trace_rays(o, d, M)
@@ -104,14 +108,21 @@ def test_random_mesh_parity(tn, device, oracle, scenes, npts, seed, M):
         assert want["num_visited_cells"].max() < M - 1
         st = tr.trace_stats()
         assert st["overflow"] == 0
+        assert st["walk"] + st["general"] == len(o)
+        if walk:
+            # the walk certifies the bulk of the rays; the rest is re-traced by the general path
+            assert st["walk"] > 0.8 * len(o), st
+        else:
+            assert st["walk"] == 0
 
 
-def test_overflow_keeps_nearest(tn, device, oracle, scenes):
+@pytest.mark.parametrize("walk", [0, 1])
+def test_overflow_keeps_nearest(tn, device, oracle, scenes, walk):
     """More than M-1 faces on a ray: both sides keep the M-1 nearest hits."""
     pts, cells = scenes.random_mesh(3000, 5)
     ot = oracle.OracleTracer(use_bvh=True)
     ot.load_tetrahedra(pts, cells)
-    tr = _gpu_tracer(tn, device, pts, cells)
+    tr = _gpu_tracer(tn, device, pts, cells, walk)
     o, d = scenes.outside_in_rays(512, 6)
     for M in (32, 64):
         want = ot.trace_rays(o, d, M)
@@ -120,7 +131,8 @@ def test_overflow_keeps_nearest(tn, device, oracle, scenes):
     assert tr.trace_stats()["overflow"] > 0
 
 
-def test_degenerate_rays(tn, device, oracle, scenes):
+@pytest.mark.parametrize("walk", [0, 1])
+def test_degenerate_rays(tn, device, oracle, scenes, walk):
     """Rays through vertices / along edges and faces of the mesh, axis-parallel rays, zero and
     non-normalised directions."""
     pts, cells = scenes.random_mesh(800, 9)
@@ -148,7 +160,7 @@ def test_degenerate_rays(tn, device, oracle, scenes):
     d = np.ascontiguousarray(np.stack(d_list).astype(np.float32))
     ot = oracle.OracleTracer()
     ot.load_tetrahedra(pts, cells)
-    tr = _gpu_tracer(tn, device, pts, cells)
+    tr = _gpu_tracer(tn, device, pts, cells, walk)
     want = ot.trace_rays(o, d, 256)
     got = _trace(tr, device, o, d, 256)
     _assert_same(got, want, "degenerate")

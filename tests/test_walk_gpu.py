@@ -1,0 +1,114 @@
+"""GPU tests specific to the adjacency-walk fast path: large ray sets against the oracle
+(every ray the walk certifies must equal sort + post_process_tetrahedra of the all-hits list),
+the fraction it certifies, size-independent properties at the benchmark size, and the
+equality of the two GPU paths on a full 800x800 frame."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("num_visited_cells", "visited_cells", "vertex_indices", "hit_distances", "barycentric_coordinates")
+
+
+def _tracer(tn, device, pts, cells, walk):
+    import torch
+
+    tr = tn.TetrahedraTracer(device)
+    tr.set_option("walk", walk)
+    tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+    return tr
+
+
+def _trace(tr, device, o, d, M):
+    import torch
+
+    out = tr.trace_rays(torch.from_numpy(o).to(device), torch.from_numpy(d).to(device), M)
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def _bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def test_walk_vs_oracle_many_rays(tn, device, oracle, scenes):
+    pts, cells = scenes.random_mesh(5000, 21)
+    ot = oracle.OracleTracer(use_bvh=True)
+    ot.load_tetrahedra(pts, cells)
+    tr = _tracer(tn, device, pts, cells, 1)
+    c = (0.5, 0.5, 0.5)
+    sets = {
+        "camera_outside": scenes.pinhole_rays(256, 256, eye=(0.5, 2.3, 0.6), lookat=c),
+        "camera_inside": scenes.pinhole_rays(256, 256, eye=(0.45, 0.55, 0.5), lookat=(0.9, 0.1, 0.4), fov_y=90.0),
+        "outside_in": scenes.outside_in_rays(65536, 31),
+        "inside_out": scenes.inside_out_rays(65536, 32),
+    }
+    for name, (o, d) in sets.items():
+        want = ot.trace_rays(o, d, 256)
+        got = _trace(tr, device, o, d, 256)
+        for k in KEYS:
+            assert _bits_equal(got[k], want[k]), f"{name}: {k} differs from the oracle"
+        st = tr.trace_stats()
+        assert st["walk"] + st["general"] == len(o)
+        assert st["walk"] >= 0.85 * len(o), (name, st)
+
+
+def test_walk_equals_general_full_frame(tn, device, scenes):
+    """BASELINE configs[1] size (100k tets, 800x800, M=512 is 17 GB per path -- compared in
+    row blocks at M=256): the two GPU paths must agree bit for bit; plus size-independent
+    properties of the result."""
+    import torch
+
+    pts, cells = scenes.random_mesh(15000, 0)
+    c = np.array([0.5, 0.5, 0.5], np.float32)
+    o, d = scenes.pinhole_rays(800, 800, eye=tuple(c + np.array([0, 2.0, 0], np.float32)), lookat=tuple(c))
+    tw = _tracer(tn, device, pts, cells, 1)
+    tg = _tracer(tn, device, pts, cells, 0)
+    M = 256
+    to, td = torch.from_numpy(o).to(device), torch.from_numpy(d).to(device)
+    total = 0
+    for s in range(0, len(o), 160000):
+        a = tw.trace_rays(to[s:s + 160000].contiguous(), td[s:s + 160000].contiguous(), M)
+        b = tg.trace_rays(to[s:s + 160000].contiguous(), td[s:s + 160000].contiguous(), M)
+        for k in KEYS:
+            assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), k
+        n = a["num_visited_cells"]
+        total += int(n.sum())
+        hd = a["hit_distances"]
+        idx = torch.arange(M, device=device)[None, :]
+        live = idx < n[:, None]
+        # A grazed hull face without a partner is carried along by the reference's swap step and
+        # finally "pairs" with the exit hull face through their common EMPTY tet
+        # (get_common_tetrahedra, optix_trace_rays.cu:22-37): such a closing segment has cell -1.
+        # Everything else: positive length >= eps, ascending, non-overlapping; tails constant.
+        real = live & (a["visited_cells"] != -1)
+        assert int((live & ~real).sum()) < 1e-4 * int(live.sum())
+        assert bool(((hd[..., 1] - hd[..., 0] >= 1e-6 * 0.999) | ~real).all())
+        assert bool(((hd[:, 1:, 0] >= hd[:, :-1, 1]) | ~real[:, 1:]).all())
+        assert bool((a["visited_cells"][~live] == -1).all()) and bool((a["vertex_indices"][~live] == -1).all())
+        assert bool((hd[~live] == 0).all()) and bool((a["barycentric_coordinates"][~live] == 0).all())
+        # live segments name real tets and their own vertices
+        vc = a["visited_cells"][real].long()
+        assert bool((vc >= 0).all()) and bool((vc < len(cells)).all())
+        tc = torch.from_numpy(cells).to(device)[vc].sort(-1).values
+        assert torch.equal(tc, a["vertex_indices"][real].sort(-1).values)
+        # entry/exit barycentrics are convex weights (within rounding)
+        bc = a["barycentric_coordinates"][real]
+        assert bool((bc > -1e-4).all()) and bool((bc.sum(-1) < 1 + 1e-4).all())
+        del a, b
+    assert total > 10_000_000
+    st = tw.trace_stats()
+    assert st["walk"] > 0.9 * (len(o) % 160000 or 160000)
+
+
+def test_walk_handles_small_M_and_misses(tn, device, oracle, scenes):
+    pts, cells = scenes.random_mesh(1200, 8)
+    ot = oracle.OracleTracer(use_bvh=True)
+    ot.load_tetrahedra(pts, cells)
+    tr = _tracer(tn, device, pts, cells, 1)
+    o, d = scenes.outside_in_rays(3000, 14)
+    d[::3] = -d[::3]  # a third of the rays point away from the mesh
+    for M in (2, 4, 8, 128):
+        want = ot.trace_rays(o, d, M)
+        got = _trace(tr, device, o, d, M)
+        for k in KEYS:
+            assert _bits_equal(got[k], want[k]), f"M={M}: {k}"

@@ -60,6 +60,7 @@ struct tn_tracer {
     tn::DevBuf<unsigned long long> stats;
     size_t last_num_rays = 0;
     bool use_walk = true;
+    bool last_walk = false;
     bool loaded = false;
     hipStream_t last_stream = nullptr;
 };
@@ -233,6 +234,22 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
         t->last_num_rays = R;
         TN_HIP(hipMemsetAsync(t->stats.p, 0, 4 * sizeof(unsigned long long), stream));
         tn::TraceParams p = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
+        const bool walk = t->use_walk && M >= 4 && t->mesh.hull.top_level <= 3 && t->mesh.n_hull > 0;
+        t->last_walk = walk;
+        if (walk) {
+            // 1. adjacency walk for every ray; 2. general all-hits path for the rays it could not certify
+            if (t->fallback_list.n < R) t->fallback_list.alloc(R);
+            TN_HIP(hipMemsetAsync(t->fallback_count.p, 0, sizeof(uint32_t), stream));
+            tn::WalkParams w{};
+            w.t = p;
+            w.tets = t->mesh.tets;
+            w.hull = t->mesh.hull;
+            w.fallback_list = t->fallback_list.p;
+            w.fallback_count = t->fallback_count.p;
+            tn::launch_trace_walk(w, stream);
+            p.ray_list = t->fallback_list.p;
+            p.item_count = t->fallback_count.p;
+        }
         tn::launch_trace_general(p, stream);
         TN_HIP(hipGetLastError());
     });
@@ -264,6 +281,15 @@ int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]) {
         unsigned long long h[4];
         TN_HIP(hipMemcpy(h, t->stats.p, sizeof h, hipMemcpyDeviceToHost));
         for (int i = 0; i < 4; ++i) stats[i] = h[i];
+        if (t->last_walk) {
+            uint32_t fb = 0;
+            TN_HIP(hipMemcpy(&fb, t->fallback_count.p, sizeof fb, hipMemcpyDeviceToHost));
+            stats[1] = fb;
+            stats[0] = t->last_num_rays - fb;
+        } else {
+            stats[0] = 0;
+            stats[1] = t->last_num_rays;
+        }
     });
 }
 

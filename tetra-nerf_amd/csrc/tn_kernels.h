@@ -18,6 +18,7 @@ struct TraceParams {
     uint32_t M;
     size_t num_items;          // rays (or entries of ray_list) to process
     const uint32_t *ray_list;  // optional indirection: item -> ray index
+    const uint32_t *item_count; // optional device-side item count (overrides num_items in-kernel)
     unsigned long long *stats; // [4] device counters or null
 };
 

@@ -233,7 +233,8 @@ __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
     const uint32_t M = p.M;
     const uint32_t cap = M - 1;  // at most M-1 hits are kept (optix_trace_rays.cu:312-315)
 
-    for (size_t it = blockIdx.x; it < p.num_items; it += gridDim.x) {
+    const size_t n_items = p.item_count ? (size_t)*p.item_count : p.num_items;
+    for (size_t it = blockIdx.x; it < n_items; it += gridDim.x) {
         const size_t ray = p.ray_list ? (size_t)p.ray_list[it] : it;
         const float ox = p.origins[3 * ray], oy = p.origins[3 * ray + 1], oz = p.origins[3 * ray + 2];
         const float dx = p.dirs[3 * ray], dy = p.dirs[3 * ray + 1], dz = p.dirs[3 * ray + 2];

@@ -1,0 +1,272 @@
+// tn_trace_walk.hip -- adjacency-walk trace path: ONE LANE PER RAY.
+//
+// A Delaunay tetrahedralisation has a convex hull, so a ray's faces form one chain
+// f0 < f1 < ... < fn in which consecutive faces bound the tetrahedron between them.  Instead
+// of collecting all hits through a BVH and sorting them (the reference's structure,
+// src/optix/optix_trace_rays.cu:268-331 + :78-108), a lane walks the chain: find the two hull
+// faces the ray's line crosses, then step tet -> neighbour tet through 128-byte per-tet
+// records, producing the faces already in order.  Per step: one dependent 128-B line, 4 vertex
+// shears, 6 edge functions (shared by the 4 faces: E(P,Q) == -E(Q,P) bitwise), one (t,u,v).
+//
+// Parity by construction: every (t,u,v) is computed by the same expression tree, in the face's
+// STORED vertex order, as the general path / the oracle (tri_finish in tn_device.h); the
+// emitted segment is bit-identical to what sort + post_process_tetrahedra yield whenever the
+// chain is "certified":
+//   (S1) t strictly increases along the chain   (sorted order == chain order, no id tie-breaks)
+//   (S2) no two consecutive gaps below eps      (reference phase 1 is then a no-op and phase 2
+//                                                pairs j with j+1, dropping pairs < eps;
+//                                                DESIGN.md "clean chain")
+//   (S3) exactly two hull faces are crossed, every tet on the way has exactly two crossed
+//        faces, no edge function is exactly 0, every recorded t is in (0, 1e16), < M-1 faces.
+// Any ray that violates a condition is appended to `fallback_list` and re-traced by the
+// general all-hits kernel, which rewrites its rows -- so the union is oracle-identical.
+//
+// Memory behaviour: the per-step segment stores are per-lane (rows are 26 KB apart), the
+// constant tail of every row (about 2/3 of all bytes at M=512) is written wave-cooperatively
+// with 16-byte stores; blockIdx is remapped so each XCD owns a contiguous band of rays and its
+// L2 keeps the tets that band crosses.
+#include "tn_device.h"
+#include "tn_kernels.h"
+
+namespace tn {
+
+namespace {
+
+constexpr int WALK_BLOCK = 256;
+constexpr uint32_t MAX_WALK_STEPS = 1u << 20;
+
+__device__ __forceinline__ SV sel4(const SV &a, const SV &b, const SV &c, const SV &d, uint32_t i) {
+    SV r;
+    r.x = i == 0 ? a.x : (i == 1 ? b.x : (i == 2 ? c.x : d.x));
+    r.y = i == 0 ? a.y : (i == 1 ? b.y : (i == 2 ? c.y : d.y));
+    r.z = i == 0 ? a.z : (i == 1 ? b.z : (i == 2 ? c.z : d.z));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t sel4u(const uint4 &v, uint32_t i) {
+    return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+// fill dwords [start, end) of `base` with `value`; base 16-byte aligned.  Wave-cooperative.
+__device__ __forceinline__ void fill_dwords(uint32_t *__restrict__ base, uint32_t start, uint32_t end, uint32_t value, int lane) {
+    const uint32_t a0 = (start + 3u) & ~3u;  // first 16-B aligned dword
+    const uint32_t head_end = a0 < end ? a0 : end;
+    if (start + lane < head_end) base[start + lane] = value;
+    if (a0 >= end) return;
+    const uint32_t a1 = end & ~3u;
+    uint4 *b4 = reinterpret_cast<uint4 *>(base);
+    const uint4 v4 = make_uint4(value, value, value, value);
+    for (uint32_t i = (a0 >> 2) + lane; i < (a1 >> 2); i += 64) b4[i] = v4;
+    if (a1 + lane < end) base[a1 + lane] = value;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
+    const TraceParams &t = p.t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t M = t.M;
+
+    // XCD-aware block remap: hardware places block b on XCD b % 8; give each XCD a contiguous band
+    const uint32_t nblk = (uint32_t)((t.num_items + WALK_BLOCK - 1) / WALK_BLOCK);
+    const uint32_t per = (nblk + 7) / 8;
+    const uint32_t lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (lb >= nblk) return;
+    const size_t ray = (size_t)lb * WALK_BLOCK + threadIdx.x;
+    const bool active = ray < t.num_items;
+    const size_t rr = active ? ray : 0;
+
+    const float ox = t.origins[3 * rr], oy = t.origins[3 * rr + 1], oz = t.origins[3 * rr + 2];
+    const float dx = t.dirs[3 * rr], dy = t.dirs[3 * rr + 1], dz = t.dirs[3 * rr + 2];
+    const RayPre rp = ray_pre(ox, oy, oz, dx, dy, dz);
+
+    bool flag = false;  // ray must be re-traced by the general path
+
+    // ------------------------------------------------------------------ hull crossing search
+    // Wave-uniform traversal of the (small) hull BVH: a node is visited if ANY lane's line hits
+    // its padded box; box / triangle data are read through uniform (scalar) loads, every lane
+    // tests its own ray.  No stack: the tree has a fixed depth (<= 3 internal levels).
+    uint32_t nhull = 0;
+    uint32_t hf0 = TN_EMPTY, hf1 = TN_EMPTY;
+    float ht0 = 0.f, ht1 = 0.f;
+    {
+        const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+        const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.hull.scene_max);
+        auto any_hit = [&](int level, uint32_t idx, uint32_t c) -> bool {
+            const float *b = p.hull.boxes + ((size_t)p.hull.level_off[level] + idx) * (6 * WIDE);
+            const bool hit = active && line_box(ox, oy, oz, ix, iy, iz, b[c], b[WIDE + c], b[2 * WIDE + c],
+                                                b[3 * WIDE + c], b[4 * WIDE + c], b[5 * WIDE + c], pad);
+            return __ballot(hit) != 0ull;
+        };
+        auto leaf = [&](uint32_t idx) {
+            const float *tr = p.hull.leaf_tri + (size_t)idx * (9 * WIDE);
+            const uint32_t *ids = p.hull.leaf_id + (size_t)idx * WIDE;
+            for (uint32_t c = 0; c < WIDE; ++c) {
+                const uint32_t fid = ids[c];
+                if (fid == TN_EMPTY) break;  // leaves are filled front to back
+                const SV A = shear(rp, tr[c], tr[WIDE + c], tr[2 * WIDE + c]);
+                const SV B = shear(rp, tr[3 * WIDE + c], tr[4 * WIDE + c], tr[5 * WIDE + c]);
+                const SV C = shear(rp, tr[6 * WIDE + c], tr[7 * WIDE + c], tr[8 * WIDE + c]);
+                const float U = edge_f(B, C), V = edge_f(C, A), W = edge_f(A, B);
+                const bool mixed = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
+                if (!mixed) {
+                    // crossed (or degenerate: a zero edge function -> the general path decides)
+                    const float det = (U + V) + W;
+                    if (U == 0.0f || V == 0.0f || W == 0.0f || det == 0.0f) flag = true;
+                    const float T = (U * A.z + V * B.z) + W * C.z;
+                    const float tt = T / det;
+                    if (nhull == 0) { hf0 = fid; ht0 = tt; }
+                    else if (nhull == 1) { hf1 = fid; ht1 = tt; }
+                    nhull++;
+                }
+            }
+        };
+        auto node1 = [&](uint32_t idx) {
+            const uint32_t cnt = p.hull.level_cnt[0];
+            for (uint32_t c = 0; c < WIDE && idx * WIDE + c < cnt; ++c)
+                if (any_hit(1, idx, c)) leaf(idx * WIDE + c);
+        };
+        auto node2 = [&](uint32_t idx) {
+            const uint32_t cnt = p.hull.level_cnt[1];
+            for (uint32_t c = 0; c < WIDE && idx * WIDE + c < cnt; ++c)
+                if (any_hit(2, idx, c)) node1(idx * WIDE + c);
+        };
+        if (p.hull.top_level == 1) node1(0);
+        else if (p.hull.top_level == 2) node2(0);
+        else {
+            const uint32_t cnt = p.hull.level_cnt[2];
+            for (uint32_t c = 0; c < WIDE && c < cnt; ++c)
+                if (any_hit(3, 0, c)) node2(c);
+        }
+    }
+    if (nhull != 0 && nhull != 2) flag = true;
+    if (nhull == 2 && !(ht0 < ht1 || ht1 < ht0)) flag = true;  // equal or NaN
+    if (!active) { flag = false; nhull = 0; }
+
+    // ------------------------------------------------------------------ the walk
+    uint32_t *row_cells = t.out_cells + rr * M;
+    float *row_dist = t.out_dist + rr * M * 2;
+    float *row_bary = t.out_bary + rr * M * 6;
+    uint32_t *row_verts = t.out_verts ? t.out_verts + rr * M * 4 : nullptr;
+
+    uint32_t nseg = 0;
+    if (nhull == 2 && !flag) {
+        const uint32_t f_in = ht0 < ht1 ? hf0 : hf1;
+        const uint32_t f_out = ht0 < ht1 ? hf1 : hf0;
+        uint32_t c = t.face_tets[2 * (size_t)f_in];  // a hull face has exactly one tet
+        uint32_t e = 4;                               // local index of the entry face, found below
+        // state of the previous recorded (valid) hit
+        bool have_prev = false, prev_short = false;
+        float pt = 0.f, pu = 0.f, pv = 0.f;
+        uint32_t nhits = 0;
+        uint32_t steps = 0;
+        bool first = true;
+        for (;;) {
+            const uint4 *rec = reinterpret_cast<const uint4 *>(p.tets + c);
+            const uint4 vert = rec[0], nbr = rec[1], face = rec[2];
+            const uint4 q0 = rec[3], q1 = rec[4], q2 = rec[5], meta = rec[6];
+            if (first) {
+                e = face.x == f_in ? 0u : (face.y == f_in ? 1u : (face.z == f_in ? 2u : (face.w == f_in ? 3u : 4u)));
+                if (e == 4) { flag = true; break; }
+            }
+            const SV P0 = shear(rp, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+            const SV P1 = shear(rp, __uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+            const SV P2 = shear(rp, __uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
+            const SV P3 = shear(rp, __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w));
+            const float e01 = edge_f(P0, P1), e02 = edge_f(P0, P2), e03 = edge_f(P0, P3);
+            const float e12 = edge_f(P1, P2), e13 = edge_f(P1, P3), e23 = edge_f(P2, P3);
+            if (e01 == 0.0f || e02 == 0.0f || e03 == 0.0f || e12 == 0.0f || e13 == 0.0f || e23 == 0.0f) { flag = true; break; }
+            // face k (opposite vertex k) is crossed iff its three cyclic edge functions agree in sign
+            const bool h3 = (e01 > 0.0f) == (e12 > 0.0f) && (e12 > 0.0f) == (e02 < 0.0f);   // 0->1, 1->2, 2->0
+            const bool h2 = (e01 > 0.0f) == (e13 > 0.0f) && (e13 > 0.0f) == (e03 < 0.0f);   // 0->1, 1->3, 3->0
+            const bool h1 = (e02 > 0.0f) == (e23 > 0.0f) && (e23 > 0.0f) == (e03 < 0.0f);   // 0->2, 2->3, 3->0
+            const bool h0 = (e12 > 0.0f) == (e23 > 0.0f) && (e23 > 0.0f) == (e13 < 0.0f);   // 1->2, 2->3, 3->1
+            const uint32_t hmask = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
+            if (__popc(hmask) != 2 || !((hmask >> e) & 1u)) { flag = true; break; }
+            const uint32_t x = __ffs(hmask & ~(1u << e)) - 1;  // exit face
+
+            // (t,u,v) of a face in its STORED vertex order
+            auto face_tuv = [&](uint32_t k, float &tt, float &uu, float &vv) -> bool {
+                const uint32_t pm = meta.x >> (6 * k);
+                const SV A = sel4(P0, P1, P2, P3, pm & 3u), B = sel4(P0, P1, P2, P3, (pm >> 2) & 3u),
+                         C = sel4(P0, P1, P2, P3, (pm >> 4) & 3u);
+                return tri_finish(edge_f(B, C), edge_f(C, A), edge_f(A, B), A.z, B.z, C.z, tt, uu, vv);
+            };
+            if (first) {
+                first = false;
+                float tt, uu, vv;
+                if (face_tuv(e, tt, uu, vv)) { have_prev = true; pt = tt; pu = uu; pv = vv; nhits = 1; }
+            }
+            float ct, cu, cv;
+            const bool valid = face_tuv(x, ct, cu, cv);
+            if (valid) {
+                if (have_prev) {
+                    if (!(ct > pt)) { flag = true; break; }                       // (S1)
+                    const bool is_short = fabsf(pt - ct) < TN_EPS;
+                    if (is_short && prev_short) { flag = true; break; }           // (S2)
+                    prev_short = is_short;
+                    if (!is_short) {
+                        // stored vertex triples of the entry face e and the exit face x
+                        const uint32_t pe = meta.x >> (6 * e), px = meta.x >> (6 * x);
+                        const uint32_t id1[3] = {sel4u(vert, pe & 3u), sel4u(vert, (pe >> 2) & 3u), sel4u(vert, (pe >> 4) & 3u)};
+                        const uint32_t id2[3] = {sel4u(vert, px & 3u), sel4u(vert, (px >> 2) & 3u), sel4u(vert, (px >> 4) & 3u)};
+                        uint32_t vi[4];
+                        float b1[3], b2[3];
+                        combine_indices(id1, id2, pu, pv, cu, cv, vi, b1, b2);
+                        row_cells[nseg] = c;
+                        *reinterpret_cast<float2 *>(row_dist + 2 * (size_t)nseg) = make_float2(pt, ct);
+                        float2 *bp = reinterpret_cast<float2 *>(row_bary + 6 * (size_t)nseg);
+                        bp[0] = make_float2(b1[0], b1[1]);
+                        bp[1] = make_float2(b1[2], b2[0]);
+                        bp[2] = make_float2(b2[1], b2[2]);
+                        if (row_verts) *reinterpret_cast<uint4 *>(row_verts + 4 * (size_t)nseg) = make_uint4(vi[0], vi[1], vi[2], vi[3]);
+                        nseg++;
+                    }
+                }
+                have_prev = true; pt = ct; pu = cu; pv = cv;
+                if (++nhits > M - 1) { flag = true; break; }                      // more than M-1 faces
+            } else if (have_prev) {
+                flag = true; break;                                               // hit list is not a suffix of the chain
+            }
+            const uint32_t nb = sel4u(nbr, x);
+            if (nb == TN_EMPTY) {
+                if (sel4u(face, x) != f_out) flag = true;
+                break;
+            }
+            e = (meta.y >> (2 * x)) & 3u;
+            c = nb;
+            if (++steps > MAX_WALK_STEPS) { flag = true; break; }
+        }
+    }
+
+    // ------------------------------------------------------------------ fallback list + tails
+    if (flag) {
+        const uint32_t slot = atomicAdd(p.fallback_count, 1u);
+        p.fallback_list[slot] = (uint32_t)ray;
+    } else if (active) {
+        t.out_num[ray] = nseg;
+    }
+
+    // wave-cooperative constant tails of the 64 rows this wave owns
+    const size_t wave_ray0 = (size_t)lb * WALK_BLOCK + (size_t)wave * 64;
+    for (int i = 0; i < 64; ++i) {
+        if (wave_ray0 + i >= t.num_items) break;
+        const uint32_t n_i = __shfl(nseg, i);
+        const bool fl_i = __shfl((int)flag, i) != 0;
+        if (fl_i) continue;  // the general kernel rewrites the whole row
+        const size_t r_i = wave_ray0 + i;
+        fill_dwords(t.out_cells + r_i * M, n_i, M, TN_EMPTY, lane);
+        fill_dwords(reinterpret_cast<uint32_t *>(t.out_dist + r_i * M * 2), 2 * n_i, 2 * M, 0u, lane);
+        fill_dwords(reinterpret_cast<uint32_t *>(t.out_bary + r_i * M * 6), 6 * n_i, 6 * M, 0u, lane);
+        if (t.out_verts) fill_dwords(t.out_verts + r_i * M * 4, 4 * n_i, 4 * M, TN_EMPTY, lane);
+    }
+}
+
+void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
+    if (p.t.num_items == 0) return;
+    const uint32_t nblk = (uint32_t)((p.t.num_items + WALK_BLOCK - 1) / WALK_BLOCK);
+    const uint32_t per = (nblk + 7) / 8;
+    hipLaunchKernelGGL(k_trace_walk, dim3(per * 8), dim3(WALK_BLOCK), 0, stream, p);
+}
+
+}  // namespace tn
