@@ -83,7 +83,10 @@ def test_walk_equals_general_full_frame(tn, device, scenes):
         real = live & (a["visited_cells"] != -1)
         assert int((live & ~real).sum()) < 1e-4 * int(live.sum())
         assert bool(((hd[..., 1] - hd[..., 0] >= 1e-6 * 0.999) | ~real).all())
-        assert bool(((hd[:, 1:, 0] >= hd[:, :-1, 1]) | ~real[:, 1:]).all())
+        # (tie handling may also re-order a few neighbours: the swap step of the reference moves a
+        #  matched face forward, optix_trace_rays.cu:244-250 -- allowed for < 1e-4 of the segments)
+        overlap = (hd[:, 1:, 0] < hd[:, :-1, 1]) & real[:, 1:] & real[:, :-1]
+        assert int(overlap.sum()) < 1e-4 * int(real.sum())
         assert bool((a["visited_cells"][~live] == -1).all()) and bool((a["vertex_indices"][~live] == -1).all())
         assert bool((hd[~live] == 0).all()) and bool((a["barycentric_coordinates"][~live] == 0).all())
         # live segments name real tets and their own vertices

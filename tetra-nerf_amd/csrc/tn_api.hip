@@ -54,13 +54,19 @@ struct tn_tracer {
     int device = 0;
     tn::DeviceMesh mesh;
     tn::HostMesh host;  // kept for tn_get_faces
-    tn::DevBuf<uint32_t> faces, face_tets, fallback_list, fallback_count;
+    static constexpr int kEvents = 4;
+    tn::DevBuf<uint32_t> faces, face_tets, fallback_list, fallback_count, walk_n;
+    hipStream_t side = nullptr;          // tail-fill stream (overlaps the walk of the next chunk)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chunk[kEvents] = {};
+    size_t chunk_rays = 65536;           // rays per walk launch when pipelining
+    int mode = 1;                        // launch structure of the walk path (see tn_trace_rays)
     tn::DevBuf<tn::TetRec> tets;
     tn::DevWideBvh bvh, hull;
     tn::DevBuf<unsigned long long> stats;
     size_t last_num_rays = 0;
     bool use_walk = true;
     bool last_walk = false;
+    uint32_t debug = 0;
     bool loaded = false;
     hipStream_t last_stream = nullptr;
 };
@@ -127,6 +133,14 @@ int tn_tracer_create(int device, tn_tracer_t *out) {
         t->stats.alloc(4);
         TN_HIP(hipMemset(t->stats.p, 0, 4 * sizeof(unsigned long long)));
         t->fallback_count.alloc(1);
+        TN_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+        TN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+        TN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+        for (auto &e : t->ev_chunk) TN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (const char *c = std::getenv("TETRANERF_HIP_CHUNK_RAYS")) {
+            const long v = std::atol(c);
+            if (v >= 256) t->chunk_rays = (size_t)v;
+        }
         *out = t.release();
     });
 }
@@ -136,6 +150,10 @@ int tn_tracer_destroy(tn_tracer_t tracer) {
         if (!tracer) return;
         DeviceGuard g(tracer->device);
         (void)hipDeviceSynchronize();
+        if (tracer->side) (void)hipStreamDestroy(tracer->side);
+        if (tracer->ev_fork) (void)hipEventDestroy(tracer->ev_fork);
+        if (tracer->ev_join) (void)hipEventDestroy(tracer->ev_join);
+        for (auto e : tracer->ev_chunk) if (e) (void)hipEventDestroy(e);
         delete tracer;
     });
 }
@@ -237,20 +255,66 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
         const bool walk = t->use_walk && M >= 4 && t->mesh.hull.top_level <= 3 && t->mesh.n_hull > 0;
         t->last_walk = walk;
         if (walk) {
-            // 1. adjacency walk for every ray; 2. general all-hits path for the rays it could not certify
-            if (t->fallback_list.n < R) t->fallback_list.alloc(R);
+            // 1. adjacency walk for every ray (segments + counts), in chunks on `stream`;
+            // 2. constant tails of each finished chunk on the tracer's side stream (pure HBM
+            //    streaming, overlaps the latency-bound walk of the next chunk);
+            // 3. general all-hits path on `stream` for the rays the walk could not certify.
+            if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); }
             TN_HIP(hipMemsetAsync(t->fallback_count.p, 0, sizeof(uint32_t), stream));
-            tn::WalkParams w{};
-            w.t = p;
-            w.tets = t->mesh.tets;
-            w.hull = t->mesh.hull;
-            w.fallback_list = t->fallback_list.p;
-            w.fallback_count = t->fallback_count.p;
-            tn::launch_trace_walk(w, stream);
+            // mode 0: one launch, the walk kernel writes its own tails; mode 1: walk launch, then one
+            // tail launch on the same stream; mode 2: chunked, tails on the side stream
+            const int mode = (t->debug & 1u) ? 0 : (R < 8192 ? 0 : t->mode);
+            const size_t chunk = mode == 2 ? t->chunk_rays : R;
+            const bool pipelined = mode == 2 && R > chunk;
+            if (pipelined) {
+                TN_HIP(hipEventRecord(t->ev_fork, stream));
+                TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
+            }
+            size_t k = 0;
+            for (size_t r0 = 0; r0 < R; r0 += chunk, ++k) {
+                const size_t n = R - r0 < chunk ? R - r0 : chunk;
+                tn::WalkParams w{};
+                w.t = make_params(t, n, M, origins + 3 * r0, directions + 3 * r0, num_visited + r0,
+                                  visited + r0 * M, bary + r0 * M * 6, dist + r0 * M * 2,
+                                  verts ? verts + r0 * M * 4 : nullptr);
+                w.tets = t->mesh.tets;
+                w.hull = t->mesh.hull;
+                w.fallback_list = t->fallback_list.p;
+                w.fallback_count = t->fallback_count.p;
+                w.walk_n = t->walk_n.p + r0;
+                w.ray_base = r0;
+                w.fused_tails = (mode != 0 || (t->debug & 1u)) ? 0u : 1u;
+                w.debug = t->debug;
+                tn::launch_trace_walk(w, stream);
+                if (pipelined) {
+                    hipEvent_t ev = t->ev_chunk[k % tn_tracer::kEvents];
+                    TN_HIP(hipEventRecord(ev, stream));
+                    TN_HIP(hipStreamWaitEvent(t->side, ev, 0));
+                    tn::launch_fill_tails(n, M, w.walk_n, w.t.out_cells, w.t.out_bary, w.t.out_dist, w.t.out_verts,
+                                          t->side);
+                }
+            }
             p.ray_list = t->fallback_list.p;
             p.item_count = t->fallback_count.p;
+            if (mode == 1) {
+                // re-trace of the uncertified rays (latency-bound, few waves) on the side stream,
+                // concurrent with the bandwidth-bound tail fill on `stream`
+                TN_HIP(hipEventRecord(t->ev_fork, stream));
+                TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
+                tn::launch_trace_general(p, t->side);
+                tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream);
+                TN_HIP(hipEventRecord(t->ev_join, t->side));
+                TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
+            } else {
+                tn::launch_trace_general(p, stream);
+                if (pipelined) {
+                    TN_HIP(hipEventRecord(t->ev_join, t->side));
+                    TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
+                }
+            }
+        } else {
+            tn::launch_trace_general(p, stream);
         }
-        tn::launch_trace_general(p, stream);
         TN_HIP(hipGetLastError());
     });
 }
@@ -297,6 +361,9 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);
         if (name && std::strcmp(name, "walk") == 0) t->use_walk = value != 0;
+        else if (name && std::strcmp(name, "debug") == 0) t->debug = (uint32_t)value;
+        else if (name && std::strcmp(name, "mode") == 0) t->mode = value;
+        else if (name && std::strcmp(name, "chunk_rays") == 0) t->chunk_rays = value >= 256 ? (size_t)value : 256;
         else throw tn::Error(std::string("unknown option ") + (name ? name : "(null)"));
     });
 }

@@ -35,8 +35,15 @@ struct WalkParams {
     WideBvh hull;
     uint32_t *fallback_list;   // [R] rays the walk could not certify
     uint32_t *fallback_count;  // [1]
+    uint32_t *walk_n;          // [num_items] segments per certified ray, TN_EMPTY = sent to the fallback
+    size_t ray_base;           // global index of item 0 (rays are traced in chunks)
+    uint32_t fused_tails;      // 1 = the walk kernel writes the constant tails itself
+    uint32_t debug;            // ablation only (bench): 2 = skip segment stores
 };
 void launch_trace_walk(const WalkParams &p, hipStream_t stream);
+// constant tails [n, M) of the rows certified by the walk (n = walk_n[ray] != TN_EMPTY)
+void launch_fill_tails(size_t num_rays, uint32_t M, const uint32_t *walk_n, uint32_t *out_cells, float *out_bary,
+                       float *out_dist, uint32_t *out_verts, hipStream_t stream);
 
 // sample -> segment matching (tn_match.hip)
 void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,

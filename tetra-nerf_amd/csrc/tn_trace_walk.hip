@@ -33,6 +33,7 @@ namespace tn {
 namespace {
 
 constexpr int WALK_BLOCK = 256;
+constexpr uint32_t XCD_GROUP = 16;  // consecutive blocks per XCD run (4096 rays)
 constexpr uint32_t MAX_WALK_STEPS = 1u << 20;
 
 __device__ __forceinline__ SV sel4(const SV &a, const SV &b, const SV &c, const SV &d, uint32_t i) {
@@ -68,9 +69,17 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     const uint32_t M = t.M;
 
     // XCD-aware block remap: hardware places block b on XCD b % 8; give each XCD a contiguous band
+    // Consecutive blocks trace neighbouring rays that cross the same tets, so each XCD gets RUNS
+    // of XCD_GROUP consecutive blocks (its L2 keeps their tets) while the runs still interleave
+    // across the frame (an XCD owning one contiguous band would own all the misses or all the
+    // long rays).
     const uint32_t nblk = (uint32_t)((t.num_items + WALK_BLOCK - 1) / WALK_BLOCK);
-    const uint32_t per = (nblk + 7) / 8;
-    const uint32_t lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    uint32_t lb = blockIdx.x;
+    if (!(p.debug & 4u)) {
+        const uint32_t G = (p.debug & 8u) ? (nblk + 7) / 8 : XCD_GROUP;
+        const uint32_t super = blockIdx.x / (8 * G), rem = blockIdx.x % (8 * G);
+        lb = super * 8 * G + (rem & 7) * G + (rem >> 3);
+    }
     if (lb >= nblk) return;
     const size_t ray = (size_t)lb * WALK_BLOCK + threadIdx.x;
     const bool active = ray < t.num_items;
@@ -161,10 +170,18 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         uint32_t nhits = 0;
         uint32_t steps = 0;
         bool first = true;
-        for (;;) {
+        // record of the current tet; the NEXT record is requested as soon as the exit face is
+        // known and before this step's segment stores are issued: gfx950's vmcnt retires loads
+        // and stores in issue order, so a load issued after the stores would wait for their acks.
+        uint32_t h_cell = 0;  // stashed even-slot segment
+        uint4 h_vi = make_uint4(0, 0, 0, 0);
+        float h_t0 = 0.f, h_t1 = 0.f, h_b0 = 0.f, h_b1 = 0.f, h_b2 = 0.f, h_b3 = 0.f, h_b4 = 0.f, h_b5 = 0.f;
+        uint4 vert, nbr, face, q0, q1, q2, meta;
+        {
             const uint4 *rec = reinterpret_cast<const uint4 *>(p.tets + c);
-            const uint4 vert = rec[0], nbr = rec[1], face = rec[2];
-            const uint4 q0 = rec[3], q1 = rec[4], q2 = rec[5], meta = rec[6];
+            vert = rec[0]; nbr = rec[1]; face = rec[2]; q0 = rec[3]; q1 = rec[4]; q2 = rec[5]; meta = rec[6];
+        }
+        for (;;) {
             if (first) {
                 e = face.x == f_in ? 0u : (face.y == f_in ? 1u : (face.z == f_in ? 2u : (face.w == f_in ? 3u : 4u)));
                 if (e == 4) { flag = true; break; }
@@ -184,6 +201,13 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             const uint32_t hmask = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
             if (__popc(hmask) != 2 || !((hmask >> e) & 1u)) { flag = true; break; }
             const uint32_t x = __ffs(hmask & ~(1u << e)) - 1;  // exit face
+            const uint32_t nb = sel4u(nbr, x);
+            const uint32_t back = (meta.y >> (2 * x)) & 3u;
+            // segment to emit this step (stored only after the next record has been requested)
+            bool do_emit = false;
+            uint32_t s_cell = 0;
+            uint4 s_vi = make_uint4(0, 0, 0, 0);
+            float s_t0 = 0.f, s_t1 = 0.f, s_b0 = 0.f, s_b1 = 0.f, s_b2 = 0.f, s_b3 = 0.f, s_b4 = 0.f, s_b5 = 0.f;
 
             // (t,u,v) of a face in its STORED vertex order
             auto face_tuv = [&](uint32_t k, float &tt, float &uu, float &vv) -> bool {
@@ -213,14 +237,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
                         uint32_t vi[4];
                         float b1[3], b2[3];
                         combine_indices(id1, id2, pu, pv, cu, cv, vi, b1, b2);
-                        row_cells[nseg] = c;
-                        *reinterpret_cast<float2 *>(row_dist + 2 * (size_t)nseg) = make_float2(pt, ct);
-                        float2 *bp = reinterpret_cast<float2 *>(row_bary + 6 * (size_t)nseg);
-                        bp[0] = make_float2(b1[0], b1[1]);
-                        bp[1] = make_float2(b1[2], b2[0]);
-                        bp[2] = make_float2(b2[1], b2[2]);
-                        if (row_verts) *reinterpret_cast<uint4 *>(row_verts + 4 * (size_t)nseg) = make_uint4(vi[0], vi[1], vi[2], vi[3]);
-                        nseg++;
+                        do_emit = true;
+                        s_cell = c; s_t0 = pt; s_t1 = ct;
+                        s_b0 = b1[0]; s_b1 = b1[1]; s_b2 = b1[2]; s_b3 = b2[0]; s_b4 = b2[1]; s_b5 = b2[2];
+                        s_vi = make_uint4(vi[0], vi[1], vi[2], vi[3]);
                     }
                 }
                 have_prev = true; pt = ct; pu = cu; pv = cv;
@@ -228,24 +248,72 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             } else if (have_prev) {
                 flag = true; break;                                               // hit list is not a suffix of the chain
             }
-            const uint32_t nb = sel4u(nbr, x);
-            if (nb == TN_EMPTY) {
-                if (sel4u(face, x) != f_out) flag = true;
+            const bool last = nb == TN_EMPTY;
+            const uint32_t exit_face = sel4u(face, x);
+            if (!last) {
+                // every use of the current record is done: request the next one BEFORE the stores
+                const uint4 *rec = reinterpret_cast<const uint4 *>(p.tets + nb);
+                vert = rec[0]; nbr = rec[1]; face = rec[2]; q0 = rec[3]; q1 = rec[4]; q2 = rec[5]; meta = rec[6];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_emit) {
+                // rows are written two segments at a time (even slot stashed, odd slot flushes the
+                // pair): 7 store transactions per pair instead of 12 -- the per-lane stores are
+                // transaction-bound, not byte-bound
+                if (nseg & 1u) {
+                    if (!(p.debug & 2u)) {
+                        const size_t s0 = nseg - 1;
+                        *reinterpret_cast<uint2 *>(row_cells + s0) = make_uint2(h_cell, s_cell);
+                        *reinterpret_cast<float4 *>(row_dist + 2 * s0) = make_float4(h_t0, h_t1, s_t0, s_t1);
+                        float4 *bp = reinterpret_cast<float4 *>(row_bary + 6 * s0);
+                        bp[0] = make_float4(h_b0, h_b1, h_b2, h_b3);
+                        bp[1] = make_float4(h_b4, h_b5, s_b0, s_b1);
+                        bp[2] = make_float4(s_b2, s_b3, s_b4, s_b5);
+                        if (row_verts) {
+                            uint4 *vp = reinterpret_cast<uint4 *>(row_verts + 4 * s0);
+                            vp[0] = h_vi;
+                            vp[1] = s_vi;
+                        }
+                    }
+                } else {
+                    h_cell = s_cell; h_vi = s_vi; h_t0 = s_t0; h_t1 = s_t1;
+                    h_b0 = s_b0; h_b1 = s_b1; h_b2 = s_b2; h_b3 = s_b3; h_b4 = s_b4; h_b5 = s_b5;
+                }
+                nseg++;
+            }
+            if (last) {
+                if (exit_face != f_out) flag = true;
                 break;
             }
-            e = (meta.y >> (2 * x)) & 3u;
+            e = back;
             c = nb;
             if (++steps > MAX_WALK_STEPS) { flag = true; break; }
+        }
+        if (!flag && (nseg & 1u) && !(p.debug & 2u)) {
+            // odd segment count: the stashed last segment goes out alone
+            const size_t s0 = nseg - 1;
+            row_cells[s0] = h_cell;
+            *reinterpret_cast<float2 *>(row_dist + 2 * s0) = make_float2(h_t0, h_t1);
+            float2 *bp = reinterpret_cast<float2 *>(row_bary + 6 * s0);
+            bp[0] = make_float2(h_b0, h_b1);
+            bp[1] = make_float2(h_b2, h_b3);
+            bp[2] = make_float2(h_b4, h_b5);
+            if (row_verts) *reinterpret_cast<uint4 *>(row_verts + 4 * s0) = h_vi;
         }
     }
 
     // ------------------------------------------------------------------ fallback list + tails
-    if (flag) {
-        const uint32_t slot = atomicAdd(p.fallback_count, 1u);
-        p.fallback_list[slot] = (uint32_t)ray;
-    } else if (active) {
-        t.out_num[ray] = nseg;
+    if (active) {
+        if (flag) {
+            const uint32_t slot = atomicAdd(p.fallback_count, 1u);
+            p.fallback_list[slot] = (uint32_t)(p.ray_base + ray);
+            p.walk_n[ray] = TN_EMPTY;
+        } else {
+            t.out_num[ray] = nseg;
+            p.walk_n[ray] = nseg;
+        }
     }
+    if (!p.fused_tails) return;  // a separate k_fill_tails launch (other stream) writes the tails
 
     // wave-cooperative constant tails of the 64 rows this wave owns
     const size_t wave_ray0 = (size_t)lb * WALK_BLOCK + (size_t)wave * 64;
@@ -262,11 +330,47 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     }
 }
 
+// Constant tails of the rows the walk certified: slots [n, M) of the four row arrays.  Pure
+// streaming stores (16 B per lane), one wave per ray per pass, XCD-banded like the walk so a
+// row's lines are written by the XCD whose L2 already holds the row's segment lines.
+__global__ __launch_bounds__(256) void k_fill_tails(size_t num_rays, uint32_t M, const uint32_t *__restrict__ walk_n,
+                                                    uint32_t *__restrict__ out_cells, float *__restrict__ out_bary,
+                                                    float *__restrict__ out_dist, uint32_t *__restrict__ out_verts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    const uint32_t per = gridDim.x >> 3;  // gridDim.x is a multiple of 8
+    const size_t lb = (size_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    // contiguous span of rays per wave: consecutive rows are consecutive in memory
+    const size_t span = (num_rays + nwaves - 1) / nwaves;
+    const size_t r0 = (lb * 4 + wave) * span;
+    const size_t r1 = r0 + span < num_rays ? r0 + span : num_rays;
+    for (size_t r = r0; r < r1; ++r) {
+        const uint32_t n = walk_n[r];
+        if (n == TN_EMPTY) continue;  // re-traced by the general kernel, which writes the whole row
+        fill_dwords(out_cells + r * M, n, M, TN_EMPTY, lane);
+        fill_dwords(reinterpret_cast<uint32_t *>(out_dist + r * M * 2), 2 * n, 2 * M, 0u, lane);
+        fill_dwords(reinterpret_cast<uint32_t *>(out_bary + r * M * 6), 6 * n, 6 * M, 0u, lane);
+        if (out_verts) fill_dwords(out_verts + r * M * 4, 4 * n, 4 * M, TN_EMPTY, lane);
+    }
+}
+
+void launch_fill_tails(size_t num_rays, uint32_t M, const uint32_t *walk_n, uint32_t *out_cells, float *out_bary,
+                       float *out_dist, uint32_t *out_verts, hipStream_t stream) {
+    if (num_rays == 0) return;
+    size_t blocks = (num_rays + 3) / 4;           // >= one ray per wave
+    if (blocks > 256 * 8) blocks = 256 * 8;       // 8 blocks (32 waves) per CU
+    blocks = (blocks + 7) & ~(size_t)7;
+    hipLaunchKernelGGL(k_fill_tails, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, walk_n, out_cells,
+                       out_bary, out_dist, out_verts);
+}
+
 void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
     if (p.t.num_items == 0) return;
     const uint32_t nblk = (uint32_t)((p.t.num_items + WALK_BLOCK - 1) / WALK_BLOCK);
-    const uint32_t per = (nblk + 7) / 8;
-    hipLaunchKernelGGL(k_trace_walk, dim3(per * 8), dim3(WALK_BLOCK), 0, stream, p);
+    // grid padded so that both remaps (runs of XCD_GROUP blocks / one band per XCD) are bijections
+    const uint32_t unit = 8 * ((p.debug & 8u) ? (nblk + 7) / 8 : XCD_GROUP);
+    const uint32_t grid = (nblk + unit - 1) / unit * unit;
+    hipLaunchKernelGGL(k_trace_walk, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
 }
 
 }  // namespace tn
