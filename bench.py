@@ -43,6 +43,19 @@ def frame_rays(scenes, rank: int, width: int, height: int):
     return scenes.pinhole_rays(width, height, eye=tuple(eye), lookat=tuple(c), up=(0.0, 0.0, 1.0), fov_y=45.0)
 
 
+def pmc_traffic(args, R, M):
+    """HBM bytes per trace_rays launch from the committed rocprofv3 PMC passes of this same
+    command (profiles/traffic.json: WRITE_SIZE + 2 x FETCH_SIZE summed over the kernels of one
+    launch, per MI355X_MICROARCH.md's gfx950 FETCH_SIZE correction).  Counters cannot be read from
+    inside the timed process; null when the workload differs from the profiled one."""
+    f = ROOT / "profiles" / "traffic.json"
+    if not f.exists():
+        return None
+    t = json.loads(f.read_text())
+    key = {"mesh_points": args.mesh_points, "mesh_seed": args.mesh_seed, "rays": R, "M": M}
+    return t.get("hbm_bytes_per_launch") if t.get("workload") == key else None
+
+
 def cpu_baseline(pts, cells, o, d, M, target_s=12.0):
     """Oracle (BVH all-hits + sort + pairing, OpenMP) on a bounded sample of the bench rays."""
     from oracle import tn_oracle
@@ -56,8 +69,8 @@ def cpu_baseline(pts, cells, o, d, M, target_s=12.0):
     t0 = time.perf_counter()
     ot.trace_rays(o[probe], d[probe], M)
     rate = len(probe) / max(time.perf_counter() - t0, 1e-6)
-    # bounded sample: about `target_s` seconds of CPU work, at most 4 passes over the frame
-    n = int(min(4 * len(o), max(8192, rate * target_s)))
+    # bounded sample: about `target_s` seconds of CPU work, at most 12 passes over the frame
+    n = int(min(12 * len(o), max(8192, rate * target_s)))
     idx = np.resize(perm, n)
     os_, ds_ = np.ascontiguousarray(o[idx]), np.ascontiguousarray(d[idx])
     t0 = time.perf_counter()
@@ -141,15 +154,9 @@ def main():
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     tot_inter = float(inter)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        s = torch.tensor([tot_inter, float(R)], dtype=torch.float64, device=dev)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        tot_inter, tot_rays = float(s[0].item()), float(s[1].item())
-    else:
-        tot_rays = float(R)
+    sharding = importlib.import_module("tetra-nerf_amd.sharding")
+    elapsed = sharding.max_over_ranks(elapsed, device=dev)           # MAX over ranks
+    tot_inter, tot_rays = sharding.sum_over_ranks([tot_inter, float(R)], device=dev)  # whole-job units
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -178,7 +185,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, R, M),
                 "kernel": "trace_rays launch (walk + general fallback)",
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,

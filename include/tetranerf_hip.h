@@ -122,6 +122,13 @@ int tn_postprocess_hits(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_tr
  * branch, stats[3] = rays that overflowed M-1 hits. */
 int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]);
 
+/* diagnostic: why the adjacency walk handed rays of the last tn_trace_rays to the general path.
+ * reasons[k], k = 1..12: 1 zero edge function / zero determinant on a hull face, 2 not exactly two
+ * hull crossings, 3 equal hull distances, 4 entry face not in its tet, 5 zero edge function,
+ * 6 not exactly two crossed faces in a tet, 7 non-increasing t, 8 two consecutive gaps < eps,
+ * 9 more than M-1 faces, 10 invalid t after a valid one, 11 exit face mismatch, 12 step limit. */
+int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
+
 /* knobs (also settable through the environment):
  *   "walk"    1 = adjacency-walk fast path with general-path fallback (default when built),
  *             0 = general all-hits path for every ray */

@@ -15,7 +15,7 @@ tr = tn.TetrahedraTracer(dev); tr.load_tetrahedra(torch.from_numpy(pts).to(dev),
 o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
 res = {}
 for rep in range(3):
-    for mode, chunk, dbg in ((1, 0, 0), (1, 0, 4), (1, 0, 8)):
+    for mode, chunk, dbg in ((1, 0, 0), (0, 0, 0)):
         tr.set_option("mode", mode); tr.set_option("debug", dbg)
         if chunk: tr.set_option("chunk_rays", chunk)
         for _ in range(2): out = tr.trace_rays(o, d, M); del out

@@ -14,7 +14,7 @@ def _tracer(tn, device, pts, cells, walk):
     import torch
 
     tr = tn.TetrahedraTracer(device)
-    tr.set_option("walk", walk)
+    tr.set_option("walk", 2 if walk else 0)  # 2 = walk for any batch size (default: >= 16384 rays)
     tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
     return tr
 

@@ -44,6 +44,7 @@ struct DevWideBvh {
         view.leaf_tri = leaf_tri.p; view.leaf_id = leaf_id.p; view.boxes = boxes.p;
         for (int i = 0; i < MAX_LEVELS; ++i) { view.level_off[i] = h.level_off[i]; view.level_cnt[i] = h.level_cnt[i]; }
         view.top_level = h.top_level;
+        view.leaf_size = h.leaf_size;
         view.scene_max = scene_max;
     }
 };
@@ -60,11 +61,14 @@ struct tn_tracer {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chunk[kEvents] = {};
     size_t chunk_rays = 65536;           // rays per walk launch when pipelining
     int mode = 1;                        // launch structure of the walk path (see tn_trace_rays)
+    int hull_leaf = tn::HULL_LEAF;       // triangles per hull-tree leaf (takes effect at load_tetrahedra)
     tn::DevBuf<tn::TetRec> tets;
+    tn::DevBuf<float> hull_nodes, hull_tris;
     tn::DevWideBvh bvh, hull;
     tn::DevBuf<unsigned long long> stats;
     size_t last_num_rays = 0;
-    bool use_walk = true;
+    int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
+    size_t walk_min_rays = 16384;
     bool last_walk = false;
     uint32_t debug = 0;
     bool loaded = false;
@@ -129,9 +133,9 @@ int tn_tracer_create(int device, tn_tracer_t *out) {
         DeviceGuard g(device);
         auto t = std::make_unique<tn_tracer>();
         t->device = device;
-        t->use_walk = env_flag("TETRANERF_HIP_WALK", true);
-        t->stats.alloc(4);
-        TN_HIP(hipMemset(t->stats.p, 0, 4 * sizeof(unsigned long long)));
+        t->use_walk = env_flag("TETRANERF_HIP_WALK", true) ? 1 : 0;
+        t->stats.alloc(20);
+        TN_HIP(hipMemset(t->stats.p, 0, 20 * sizeof(unsigned long long)));
         t->fallback_count.alloc(1);
         TN_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
         TN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
@@ -190,7 +194,9 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         }
         tn::HostWideBvh hb, hh;
         tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), all, hb);
-        tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), hull_ids, hh);
+        tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), hull_ids, hh, t->hull_leaf);
+        tn::HostHullBvh hth;
+        tn::build_hull_threaded(hxyz.data(), t->host.faces.data(), hull_ids, hth);
         std::vector<tn::TetRec> recs;
         tn::build_tet_records(T, hcells.data(), hxyz.data(), t->host, recs);
 
@@ -199,6 +205,8 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         t->bvh.upload(hb, smax);
         t->hull.upload(hh, smax);
         t->tets.upload(recs);
+        t->hull_nodes.upload(hth.nodes);
+        t->hull_tris.upload(hth.tris);
 
         tn::DeviceMesh &m = t->mesh;
         m.xyz = xyz; m.cells = cells;
@@ -206,6 +214,9 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         m.faces = t->faces.p; m.face_tets = t->face_tets.p;
         m.bvh = t->bvh.view; m.hull = t->hull.view;
         m.tets = t->tets.p; m.n_hull = (uint32_t)hull_ids.size();
+        m.hull_nodes = reinterpret_cast<const float4 *>(t->hull_nodes.p);
+        m.hull_tris = reinterpret_cast<const float4 *>(t->hull_tris.p);
+        m.n_hull_nodes = (uint32_t)(hth.nodes.size() / 8);
         t->loaded = true;
     });
 }
@@ -250,9 +261,13 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
         hipStream_t stream = (hipStream_t)stream_;
         t->last_stream = stream;
         t->last_num_rays = R;
-        TN_HIP(hipMemsetAsync(t->stats.p, 0, 4 * sizeof(unsigned long long), stream));
+        TN_HIP(hipMemsetAsync(t->stats.p, 0, 20 * sizeof(unsigned long long), stream));
         tn::TraceParams p = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
-        const bool walk = t->use_walk && M >= 4 && t->mesh.hull.top_level <= 3 && t->mesh.n_hull > 0;
+        // Small batches are latency-bound: a lane walking ~180 dependent steps is slower than one
+        // wavefront per ray through the wide BVH (measured: 4096 rays, 300k tets: 1.5 ms vs 0.75 ms),
+        // so the walk is used from `walk_min_rays` on (use_walk == 2 forces it for any size).
+        const bool walk = t->use_walk && (R >= t->walk_min_rays || t->use_walk == 2) && M >= 4 &&
+                          t->mesh.hull.top_level <= 3 && t->mesh.n_hull > 0;
         t->last_walk = walk;
         if (walk) {
             // 1. adjacency walk for every ray (segments + counts), in chunks on `stream`;
@@ -270,6 +285,12 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
             }
+            if (t->debug & 16u) {  // EXPERIMENT (invalid output): fill every row on the side stream while walking
+                TN_HIP(hipMemsetAsync(t->walk_n.p, 0, R * sizeof(uint32_t), stream));
+                TN_HIP(hipEventRecord(t->ev_fork, stream));
+                TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
+                tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, t->side);
+            }
             size_t k = 0;
             for (size_t r0 = 0; r0 < R; r0 += chunk, ++k) {
                 const size_t n = R - r0 < chunk ? R - r0 : chunk;
@@ -279,6 +300,9 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                                   verts ? verts + r0 * M * 4 : nullptr);
                 w.tets = t->mesh.tets;
                 w.hull = t->mesh.hull;
+                w.hull_nodes = t->mesh.hull_nodes;
+                w.hull_tris = t->mesh.hull_tris;
+                w.n_hull_nodes = t->mesh.n_hull_nodes;
                 w.fallback_list = t->fallback_list.p;
                 w.fallback_count = t->fallback_count.p;
                 w.walk_n = t->walk_n.p + r0;
@@ -302,7 +326,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
                 tn::launch_trace_general(p, t->side);
-                tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream);
+                if (!(t->debug & 16u)) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
             } else {
@@ -357,12 +381,25 @@ int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]) {
     });
 }
 
+int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        DeviceGuard g(t->device);
+        TN_HIP(hipStreamSynchronize(t->last_stream));
+        unsigned long long h[20];
+        TN_HIP(hipMemcpy(h, t->stats.p, sizeof h, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 16; ++i) reasons[i] = h[4 + i];
+    });
+}
+
 int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);
-        if (name && std::strcmp(name, "walk") == 0) t->use_walk = value != 0;
+        if (name && std::strcmp(name, "walk") == 0) t->use_walk = value < 0 ? 0 : (value > 2 ? 2 : value);
+        else if (name && std::strcmp(name, "walk_min_rays") == 0) t->walk_min_rays = value < 0 ? 0 : (size_t)value;
         else if (name && std::strcmp(name, "debug") == 0) t->debug = (uint32_t)value;
         else if (name && std::strcmp(name, "mode") == 0) t->mode = value;
+        else if (name && std::strcmp(name, "hull_leaf") == 0) t->hull_leaf = value < 1 ? 1 : (value > 64 ? 64 : value);
         else if (name && std::strcmp(name, "chunk_rays") == 0) t->chunk_rays = value >= 256 ? (size_t)value : 256;
         else throw tn::Error(std::string("unknown option ") + (name ? name : "(null)"));
     });

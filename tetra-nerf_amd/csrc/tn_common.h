@@ -30,6 +30,7 @@ struct Error : std::runtime_error {
 constexpr int WIDE = 64;            // BVH branching factor = wavefront width
 constexpr int MAX_LEVELS = 8;       // 64^8 faces is far beyond uint32
 constexpr int STACK_CAP = 64 * 6;   // traversal stack entries per wave
+constexpr int HULL_LEAF = 8;        // triangles per leaf of the hull tree (walked wave-uniformly)
 
 // Wide (64-ary) BVH over the unique faces, complete tree over Morton-ordered faces.
 // Level 0 = leaves (64 triangles each, vertices stored inline SoA so a wave reads a
@@ -42,6 +43,7 @@ struct WideBvh {
     uint32_t level_off[MAX_LEVELS];  // node offset of each internal level into `boxes`
     uint32_t level_cnt[MAX_LEVELS];  // number of nodes of each level (level 0 = leaves)
     int top_level;              // the root is node 0 of this level (>= 1)
+    int leaf_size;              // triangles per leaf (64 for the all-faces tree, smaller for the hull)
     float scene_max;            // max |coordinate| over the mesh vertices
 };
 
@@ -73,6 +75,9 @@ struct DeviceMesh {
     // adjacency walk
     TetRec *tets = nullptr;         // [T]
     WideBvh hull{};                 // over hull faces only (leaf_id = global face id)
+    const float4 *hull_nodes = nullptr;  // threaded binary BVH over the hull faces (2 float4 per node)
+    const float4 *hull_tris = nullptr;   // 3 float4 per hull face
+    uint32_t n_hull_nodes = 0;
     uint32_t n_hull = 0;
 };
 
@@ -90,13 +95,21 @@ struct HostWideBvh {
     uint32_t level_off[MAX_LEVELS] = {0};
     uint32_t level_cnt[MAX_LEVELS] = {0};
     int top_level = 1;
+    int leaf_size = WIDE;
 };
+
+struct HostHullBvh {
+    std::vector<float> nodes;  // [n_nodes][8]: lo.xyz, skip | hi.xyz, leaf (first<<3|count, or ~0)
+    std::vector<float> tris;   // [n_hull][12]: v0.xyz, face id | v1.xyz, 0 | v2.xyz, 0  (Morton order)
+};
+void build_hull_threaded(const float *xyz, const uint32_t *faces, const std::vector<uint32_t> &ids,
+                         HostHullBvh &out);
 
 // first-seen face table; throws tn::Error("A triangle is shared by more than two tetrahedra!")
 void build_face_table(size_t T, const uint32_t *cells, HostMesh &out);
 // wide BVH over the faces listed in `ids` (global face ids)
 void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<uint32_t> &ids,
-                    HostWideBvh &out);
+                    HostWideBvh &out, int leaf_size = WIDE);
 // adjacency records
 void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const HostMesh &hm,
                        std::vector<TetRec> &out);

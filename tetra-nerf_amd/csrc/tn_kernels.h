@@ -32,7 +32,10 @@ size_t trace_general_smem_bytes(uint32_t M);
 struct WalkParams {
     TraceParams t;
     const TetRec *tets;
-    WideBvh hull;
+    WideBvh hull;              // wave-uniform hull tree (debug & 128 only)
+    const float4 *hull_nodes;  // threaded per-lane hull tree
+    const float4 *hull_tris;
+    uint32_t n_hull_nodes;
     uint32_t *fallback_list;   // [R] rays the walk could not certify
     uint32_t *fallback_count;  // [1]
     uint32_t *walk_n;          // [num_items] segments per certified ray, TN_EMPTY = sent to the fallback

@@ -9,6 +9,7 @@
 //    build, src/tetrahedra_tracer.cpp:285-332).
 //  * build_tet_records: 128-byte per-tet adjacency records for the walk kernel.
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -89,7 +90,9 @@ void build_face_table(size_t T, const uint32_t *cells, HostMesh &out) {
 }
 
 void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<uint32_t> &ids,
-                    HostWideBvh &out) {
+                    HostWideBvh &out, int leaf_size) {
+    const int LS = leaf_size;
+    out.leaf_size = leaf_size;
     const size_t n = ids.size();
     // centroid bounds
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -115,23 +118,23 @@ void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<u
     }
     std::sort(order.begin(), order.end());
 
-    const size_t n_leaves = std::max<size_t>(1, (n + WIDE - 1) / WIDE);
-    out.leaf_tri.assign(n_leaves * 9 * WIDE, 0.0f);
-    out.leaf_id.assign(n_leaves * WIDE, TN_EMPTY);
+    const size_t n_leaves = std::max<size_t>(1, (n + LS - 1) / LS);
+    out.leaf_tri.assign(n_leaves * 9 * LS, 0.0f);
+    out.leaf_id.assign(n_leaves * LS, TN_EMPTY);
     // boxes of the current level (flat lo.xyz hi.xyz per node)
     std::vector<float> cur(6 * n_leaves);
     for (size_t l = 0; l < n_leaves; ++l) {
         float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int i = 0; i < WIDE; ++i) {
-            const size_t s = l * WIDE + i;
+        for (int i = 0; i < LS; ++i) {
+            const size_t s = l * LS + i;
             if (s >= n) break;
             const uint32_t fid = ids[order[s].second];
             const uint32_t *f = faces + 3 * (size_t)fid;
-            out.leaf_id[l * WIDE + i] = fid;
+            out.leaf_id[l * LS + i] = fid;
             for (int v = 0; v < 3; ++v)
                 for (int k = 0; k < 3; ++k) {
                     const float x = xyz[3 * (size_t)f[v] + k];
-                    out.leaf_tri[(l * 9 + v * 3 + k) * WIDE + i] = x;
+                    out.leaf_tri[(l * 9 + v * 3 + k) * LS + i] = x;
                     blo[k] = std::min(blo[k], x); bhi[k] = std::max(bhi[k], x);
                 }
         }
@@ -239,6 +242,78 @@ void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const 
             }
         }
     }
+}
+
+// Threaded binary BVH over the hull faces, nodes in DFS pre-order: the "hit" successor of a node
+// is the next node, the "miss" successor is `skip`.  A lane can traverse it without a stack and in
+// a ray-independent order (all crossings are wanted, not the nearest).  Leaves hold <= 4 faces.
+void build_hull_threaded(const float *xyz, const uint32_t *faces, const std::vector<uint32_t> &ids,
+                         HostHullBvh &out) {
+    const size_t n = ids.size();
+    out.nodes.clear();
+    out.tris.clear();
+    if (n == 0) return;
+    // Morton order (same code as the wide tree)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    std::vector<float> cent(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t *f = faces + 3 * (size_t)ids[i];
+        for (int k = 0; k < 3; ++k) {
+            const float c = (xyz[3 * (size_t)f[0] + k] + xyz[3 * (size_t)f[1] + k] + xyz[3 * (size_t)f[2] + k]) * (1.0f / 3.0f);
+            cent[3 * i + k] = c;
+            lo[k] = std::min(lo[k], c); hi[k] = std::max(hi[k], c);
+        }
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> order(n);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t code = 0;
+        for (int k = 0; k < 3; ++k) {
+            const double ext = (double)hi[k] - (double)lo[k];
+            const double u = ext > 0 ? ((double)cent[3 * i + k] - lo[k]) / ext : 0.0;
+            const uint64_t q = (uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0));
+            code |= spread21(q) << k;
+        }
+        order[i] = {code, (uint32_t)i};
+    }
+    std::sort(order.begin(), order.end());
+    // triangle slots in Morton order: 3 x float4 (v.xyz, w): w of v0 carries the face id bits
+    out.tris.resize(n * 12);
+    std::vector<float> fb(6 * n);
+    for (size_t s = 0; s < n; ++s) {
+        const uint32_t fid = ids[order[s].second];
+        const uint32_t *f = faces + 3 * (size_t)fid;
+        for (int k = 0; k < 3; ++k) { fb[6 * s + k] = INFINITY; fb[6 * s + 3 + k] = -INFINITY; }
+        for (int v = 0; v < 3; ++v) {
+            for (int k = 0; k < 3; ++k) {
+                const float x = xyz[3 * (size_t)f[v] + k];
+                out.tris[s * 12 + v * 4 + k] = x;
+                fb[6 * s + k] = std::min(fb[6 * s + k], x); fb[6 * s + 3 + k] = std::max(fb[6 * s + 3 + k], x);
+            }
+            out.tris[s * 12 + v * 4 + 3] = 0.0f;
+        }
+        std::memcpy(&out.tris[s * 12 + 3], &fid, 4);
+    }
+    struct Frame { size_t a, b; };
+    // recursive emit in pre-order
+    std::function<void(size_t, size_t)> emit = [&](size_t a, size_t b) {
+        const size_t me = out.nodes.size() / 8;
+        out.nodes.resize(out.nodes.size() + 8);
+        float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t s = a; s < b; ++s)
+            for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], fb[6 * s + k]); bhi[k] = std::max(bhi[k], fb[6 * s + 3 + k]); }
+        uint32_t leaf = 0xFFFFFFFFu;
+        if (b - a <= 4) leaf = (uint32_t)(a << 3) | (uint32_t)(b - a);
+        else {
+            const size_t m = a + (b - a) / 2;
+            emit(a, m);
+            emit(m, b);
+        }
+        const uint32_t skip = (uint32_t)(out.nodes.size() / 8);
+        float *nd = out.nodes.data() + me * 8;
+        nd[0] = blo[0]; nd[1] = blo[1]; nd[2] = blo[2]; std::memcpy(&nd[3], &skip, 4);
+        nd[4] = bhi[0]; nd[5] = bhi[1]; nd[6] = bhi[2]; std::memcpy(&nd[7], &leaf, 4);
+    };
+    emit(0, n);
 }
 
 }  // namespace tn

@@ -61,8 +61,23 @@ __device__ __forceinline__ void fill_dwords(uint32_t *__restrict__ base, uint32_
     if (a1 + lane < end) base[a1 + lane] = value;
 }
 
+// the fields of a TetRec the walk needs every step (face ids are only read at both ends)
+struct WalkRec {
+    uint4 vert, nbr, q0, q1, q2;
+    uint2 meta;
+};
+
+__device__ __forceinline__ WalkRec load_rec(const TetRec *tets, uint32_t c) {
+    const uint4 *r = reinterpret_cast<const uint4 *>(tets + c);
+    WalkRec x;
+    x.vert = r[0]; x.nbr = r[1]; x.q0 = r[3]; x.q1 = r[4]; x.q2 = r[5];
+    x.meta = *reinterpret_cast<const uint2 *>(r + 6);
+    return x;
+}
+
 }  // namespace
 
+template <bool PREFETCH>
 __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     const TraceParams &t = p.t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -90,6 +105,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     const RayPre rp = ray_pre(ox, oy, oz, dx, dy, dz);
 
     bool flag = false;  // ray must be re-traced by the general path
+    uint32_t why = 0;   // first reason (1..12), counted in stats[4 + why]
 
     // ------------------------------------------------------------------ hull crossing search
     // Wave-uniform traversal of the (small) hull BVH: a node is visited if ANY lane's line hits
@@ -98,6 +114,43 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     uint32_t nhull = 0;
     uint32_t hf0 = TN_EMPTY, hf1 = TN_EMPTY;
     float ht0 = 0.f, ht1 = 0.f;
+    auto hull_face = [&](const SV &A, const SV &B, const SV &C, uint32_t fid) {
+        const float U = edge_f(B, C), V = edge_f(C, A), W = edge_f(A, B);
+        const bool mixed = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
+        if (!mixed) {
+            // crossed (or degenerate: a zero edge function -> the general path decides)
+            const float det = (U + V) + W;
+            if (U == 0.0f || V == 0.0f || W == 0.0f || det == 0.0f) { flag = true; why = 1; }
+            const float T = (U * A.z + V * B.z) + W * C.z;
+            const float tt = T / det;
+            if (nhull == 0) { hf0 = fid; ht0 = tt; }
+            else if (nhull == 1) { hf1 = fid; ht1 = tt; }
+            nhull++;
+        }
+    };
+    if (!(p.debug & 128u)) {
+        // Per-lane stackless traversal of the threaded hull tree (DFS pre-order, skip links):
+        // ray-independent visiting order, every crossing of the ray's LINE is found.  Works for
+        // incoherent batches (random training rays) as well as for camera frames.
+        const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+        const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.hull.scene_max);
+        uint32_t i = active ? 0u : p.n_hull_nodes;
+        while (i < p.n_hull_nodes) {
+            const float4 a = p.hull_nodes[2 * (size_t)i], b = p.hull_nodes[2 * (size_t)i + 1];
+            if (!line_box(ox, oy, oz, ix, iy, iz, a.x, a.y, a.z, b.x, b.y, b.z, pad)) { i = __float_as_uint(a.w); continue; }
+            const uint32_t leaf = __float_as_uint(b.w);
+            if (leaf != TN_EMPTY) {
+                const uint32_t first = leaf >> 3, cnt = leaf & 7u;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4 *tp = p.hull_tris + 3 * (size_t)(first + k);
+                    const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                    hull_face(shear(rp, v0.x, v0.y, v0.z), shear(rp, v1.x, v1.y, v1.z), shear(rp, v2.x, v2.y, v2.z),
+                              __float_as_uint(v0.w));
+                }
+            }
+            i = i + 1;
+        }
+    } else
     {
         const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
         const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.hull.scene_max);
@@ -108,26 +161,16 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             return __ballot(hit) != 0ull;
         };
         auto leaf = [&](uint32_t idx) {
-            const float *tr = p.hull.leaf_tri + (size_t)idx * (9 * WIDE);
-            const uint32_t *ids = p.hull.leaf_id + (size_t)idx * WIDE;
-            for (uint32_t c = 0; c < WIDE; ++c) {
+            const uint32_t L = (uint32_t)p.hull.leaf_size;
+            const float *tr = p.hull.leaf_tri + (size_t)idx * (9 * L);
+            const uint32_t *ids = p.hull.leaf_id + (size_t)idx * L;
+            for (uint32_t c = 0; c < L; ++c) {
                 const uint32_t fid = ids[c];
                 if (fid == TN_EMPTY) break;  // leaves are filled front to back
-                const SV A = shear(rp, tr[c], tr[WIDE + c], tr[2 * WIDE + c]);
-                const SV B = shear(rp, tr[3 * WIDE + c], tr[4 * WIDE + c], tr[5 * WIDE + c]);
-                const SV C = shear(rp, tr[6 * WIDE + c], tr[7 * WIDE + c], tr[8 * WIDE + c]);
-                const float U = edge_f(B, C), V = edge_f(C, A), W = edge_f(A, B);
-                const bool mixed = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
-                if (!mixed) {
-                    // crossed (or degenerate: a zero edge function -> the general path decides)
-                    const float det = (U + V) + W;
-                    if (U == 0.0f || V == 0.0f || W == 0.0f || det == 0.0f) flag = true;
-                    const float T = (U * A.z + V * B.z) + W * C.z;
-                    const float tt = T / det;
-                    if (nhull == 0) { hf0 = fid; ht0 = tt; }
-                    else if (nhull == 1) { hf1 = fid; ht1 = tt; }
-                    nhull++;
-                }
+                const SV A = shear(rp, tr[c], tr[L + c], tr[2 * L + c]);
+                const SV B = shear(rp, tr[3 * L + c], tr[4 * L + c], tr[5 * L + c]);
+                const SV C = shear(rp, tr[6 * L + c], tr[7 * L + c], tr[8 * L + c]);
+                hull_face(A, B, C, fid);
             }
         };
         auto node1 = [&](uint32_t idx) {
@@ -148,8 +191,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
                 if (any_hit(3, 0, c)) node2(c);
         }
     }
-    if (nhull != 0 && nhull != 2) flag = true;
-    if (nhull == 2 && !(ht0 < ht1 || ht1 < ht0)) flag = true;  // equal or NaN
+    if (nhull != 0 && nhull != 2) { flag = true; why = 2; }
+    if (nhull == 2 && !(ht0 < ht1 || ht1 < ht0)) { flag = true; why = 3; }  // equal or NaN
     if (!active) { flag = false; nhull = 0; }
 
     // ------------------------------------------------------------------ the walk
@@ -163,55 +206,56 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         const uint32_t f_in = ht0 < ht1 ? hf0 : hf1;
         const uint32_t f_out = ht0 < ht1 ? hf1 : hf0;
         uint32_t c = t.face_tets[2 * (size_t)f_in];  // a hull face has exactly one tet
-        uint32_t e = 4;                               // local index of the entry face, found below
+        uint32_t e = 4;                               // local index of the entry face
+        {
+            const uint4 face = reinterpret_cast<const uint4 *>(p.tets + c)[2];
+            e = face.x == f_in ? 0u : (face.y == f_in ? 1u : (face.z == f_in ? 2u : (face.w == f_in ? 3u : 4u)));
+            if (e == 4) { flag = true; why = 4; }
+        }
         // state of the previous recorded (valid) hit
-        bool have_prev = false, prev_short = false;
-        float pt = 0.f, pu = 0.f, pv = 0.f;
+        bool have_prev = false, have_pp = false, pending_inv = false, had_special = false;
+        float pt = 0.f, pu = 0.f, pv = 0.f, ppt = 0.f;
+        uint32_t run = 0;  // current run of consecutive gaps below eps
         uint32_t nhits = 0;
         uint32_t steps = 0;
         bool first = true;
-        // record of the current tet; the NEXT record is requested as soon as the exit face is
-        // known and before this step's segment stores are issued: gfx950's vmcnt retires loads
-        // and stores in issue order, so a load issued after the stores would wait for their acks.
         uint32_t h_cell = 0;  // stashed even-slot segment
         uint4 h_vi = make_uint4(0, 0, 0, 0);
         float h_t0 = 0.f, h_t1 = 0.f, h_b0 = 0.f, h_b1 = 0.f, h_b2 = 0.f, h_b3 = 0.f, h_b4 = 0.f, h_b5 = 0.f;
-        uint4 vert, nbr, face, q0, q1, q2, meta;
-        {
-            const uint4 *rec = reinterpret_cast<const uint4 *>(p.tets + c);
-            vert = rec[0]; nbr = rec[1]; face = rec[2]; q0 = rec[3]; q1 = rec[4]; q2 = rec[5]; meta = rec[6];
-        }
-        for (;;) {
-            if (first) {
-                e = face.x == f_in ? 0u : (face.y == f_in ? 1u : (face.z == f_in ? 2u : (face.w == f_in ? 3u : 4u)));
-                if (e == 4) { flag = true; break; }
-            }
-            const SV P0 = shear(rp, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
-            const SV P1 = shear(rp, __uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
-            const SV P2 = shear(rp, __uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
-            const SV P3 = shear(rp, __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w));
+        // Record of the current tet.  gfx950's vmcnt retires loads and stores in issue order, so the
+        // NEXT record is always requested BEFORE this step's segment stores.  PREFETCH variant: it is
+        // requested as soon as the exit face is known (shortest dependent chain per step: load ->
+        // 4 shears -> 6 edge functions -> sign logic -> address), and the (t,u,v) / segment
+        // arithmetic of this step runs under the load's latency.
+        WalkRec cur = load_rec(p.tets, c);
+        while (!flag) {
+            const SV P0 = shear(rp, __uint_as_float(cur.q0.x), __uint_as_float(cur.q0.y), __uint_as_float(cur.q0.z));
+            const SV P1 = shear(rp, __uint_as_float(cur.q0.w), __uint_as_float(cur.q1.x), __uint_as_float(cur.q1.y));
+            const SV P2 = shear(rp, __uint_as_float(cur.q1.z), __uint_as_float(cur.q1.w), __uint_as_float(cur.q2.x));
+            const SV P3 = shear(rp, __uint_as_float(cur.q2.y), __uint_as_float(cur.q2.z), __uint_as_float(cur.q2.w));
             const float e01 = edge_f(P0, P1), e02 = edge_f(P0, P2), e03 = edge_f(P0, P3);
             const float e12 = edge_f(P1, P2), e13 = edge_f(P1, P3), e23 = edge_f(P2, P3);
-            if (e01 == 0.0f || e02 == 0.0f || e03 == 0.0f || e12 == 0.0f || e13 == 0.0f || e23 == 0.0f) { flag = true; break; }
+            if (e01 == 0.0f || e02 == 0.0f || e03 == 0.0f || e12 == 0.0f || e13 == 0.0f || e23 == 0.0f) { flag = true; why = 5; break; }
             // face k (opposite vertex k) is crossed iff its three cyclic edge functions agree in sign
             const bool h3 = (e01 > 0.0f) == (e12 > 0.0f) && (e12 > 0.0f) == (e02 < 0.0f);   // 0->1, 1->2, 2->0
             const bool h2 = (e01 > 0.0f) == (e13 > 0.0f) && (e13 > 0.0f) == (e03 < 0.0f);   // 0->1, 1->3, 3->0
             const bool h1 = (e02 > 0.0f) == (e23 > 0.0f) && (e23 > 0.0f) == (e03 < 0.0f);   // 0->2, 2->3, 3->0
             const bool h0 = (e12 > 0.0f) == (e23 > 0.0f) && (e23 > 0.0f) == (e13 < 0.0f);   // 1->2, 2->3, 3->1
             const uint32_t hmask = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
-            if (__popc(hmask) != 2 || !((hmask >> e) & 1u)) { flag = true; break; }
+            if (__popc(hmask) != 2 || !((hmask >> e) & 1u)) { flag = true; why = 6; break; }
             const uint32_t x = __ffs(hmask & ~(1u << e)) - 1;  // exit face
-            const uint32_t nb = sel4u(nbr, x);
-            const uint32_t back = (meta.y >> (2 * x)) & 3u;
-            // segment to emit this step (stored only after the next record has been requested)
-            bool do_emit = false;
-            uint32_t s_cell = 0;
-            uint4 s_vi = make_uint4(0, 0, 0, 0);
-            float s_t0 = 0.f, s_t1 = 0.f, s_b0 = 0.f, s_b1 = 0.f, s_b2 = 0.f, s_b3 = 0.f, s_b4 = 0.f, s_b5 = 0.f;
+            const uint32_t nb = sel4u(cur.nbr, x);
+            const uint32_t back = (cur.meta.y >> (2 * x)) & 3u;
+            const bool last = nb == TN_EMPTY;
+            WalkRec nxt = cur;
+            if constexpr (PREFETCH) {
+                nxt = load_rec(p.tets, last ? c : nb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 
             // (t,u,v) of a face in its STORED vertex order
             auto face_tuv = [&](uint32_t k, float &tt, float &uu, float &vv) -> bool {
-                const uint32_t pm = meta.x >> (6 * k);
+                const uint32_t pm = cur.meta.x >> (6 * k);
                 const SV A = sel4(P0, P1, P2, P3, pm & 3u), B = sel4(P0, P1, P2, P3, (pm >> 2) & 3u),
                          C = sel4(P0, P1, P2, P3, (pm >> 4) & 3u);
                 return tri_finish(edge_f(B, C), edge_f(C, A), edge_f(A, B), A.z, B.z, C.z, tt, uu, vv);
@@ -221,19 +265,41 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
                 float tt, uu, vv;
                 if (face_tuv(e, tt, uu, vv)) { have_prev = true; pt = tt; pu = uu; pv = vv; nhits = 1; }
             }
+            // segment to emit this step
+            bool do_emit = false;
+            uint32_t s_cell = 0;
+            uint4 s_vi = make_uint4(0, 0, 0, 0);
+            float s_t0 = 0.f, s_t1 = 0.f, s_b0 = 0.f, s_b1 = 0.f, s_b2 = 0.f, s_b3 = 0.f, s_b4 = 0.f, s_b5 = 0.f;
             float ct, cu, cv;
             const bool valid = face_tuv(x, ct, cu, cv);
             if (valid) {
                 if (have_prev) {
-                    if (!(ct > pt)) { flag = true; break; }                       // (S1)
                     const bool is_short = fabsf(pt - ct) < TN_EPS;
-                    if (is_short && prev_short) { flag = true; break; }           // (S2)
-                    prev_short = is_short;
+                    bool ascending = ct > pt;
+                    if (ct == pt) {
+                        // exact tie: the sort orders the two faces by id
+                        const uint4 face = reinterpret_cast<const uint4 *>(p.tets + c)[2];
+                        ascending = sel4u(face, x) > sel4u(face, e);
+                    }
+                    if (ascending) {
+                        if (pending_inv) {
+                            // the face after an inverted pair must clear BOTH of its faces by eps
+                            if (!(ct - ppt >= TN_EPS)) { flag = true; why = 7; break; }
+                            pending_inv = false;
+                        }
+                        if (is_short) { if (++run >= 2) had_special = true; } else run = 0;   // (S2)
+                    } else {
+                        // (S1) sorted order != chain order.  Certified only for an isolated pair closer
+                        // than eps whose neighbours are at least eps away on both sides.
+                        if (!is_short || !have_pp || run > 0 || pending_inv || !(ct - ppt >= TN_EPS)) { flag = true; why = 7; break; }
+                        pending_inv = true;
+                        had_special = true;
+                    }
                     if (!is_short) {
                         // stored vertex triples of the entry face e and the exit face x
-                        const uint32_t pe = meta.x >> (6 * e), px = meta.x >> (6 * x);
-                        const uint32_t id1[3] = {sel4u(vert, pe & 3u), sel4u(vert, (pe >> 2) & 3u), sel4u(vert, (pe >> 4) & 3u)};
-                        const uint32_t id2[3] = {sel4u(vert, px & 3u), sel4u(vert, (px >> 2) & 3u), sel4u(vert, (px >> 4) & 3u)};
+                        const uint32_t pe = cur.meta.x >> (6 * e), px = cur.meta.x >> (6 * x);
+                        const uint32_t id1[3] = {sel4u(cur.vert, pe & 3u), sel4u(cur.vert, (pe >> 2) & 3u), sel4u(cur.vert, (pe >> 4) & 3u)};
+                        const uint32_t id2[3] = {sel4u(cur.vert, px & 3u), sel4u(cur.vert, (px >> 2) & 3u), sel4u(cur.vert, (px >> 4) & 3u)};
                         uint32_t vi[4];
                         float b1[3], b2[3];
                         combine_indices(id1, id2, pu, pv, cu, cv, vi, b1, b2);
@@ -243,19 +309,17 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
                         s_vi = make_uint4(vi[0], vi[1], vi[2], vi[3]);
                     }
                 }
+                have_pp = have_prev; ppt = pt;
                 have_prev = true; pt = ct; pu = cu; pv = cv;
-                if (++nhits > M - 1) { flag = true; break; }                      // more than M-1 faces
+                if (++nhits > M - 1) { flag = true; why = 9; break; }                      // more than M-1 faces
             } else if (have_prev) {
-                flag = true; break;                                               // hit list is not a suffix of the chain
+                flag = true; why = 10; break;                                              // hit list is not a suffix of the chain
             }
-            const bool last = nb == TN_EMPTY;
-            const uint32_t exit_face = sel4u(face, x);
-            if (!last) {
+            if constexpr (!PREFETCH) {
                 // every use of the current record is done: request the next one BEFORE the stores
-                const uint4 *rec = reinterpret_cast<const uint4 *>(p.tets + nb);
-                vert = rec[0]; nbr = rec[1]; face = rec[2]; q0 = rec[3]; q1 = rec[4]; q2 = rec[5]; meta = rec[6];
+                if (!last) nxt = load_rec(p.tets, nb);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
             if (do_emit) {
                 // rows are written two segments at a time (even slot stashed, odd slot flushes the
                 // pair): 7 store transactions per pair instead of 12 -- the per-lane stores are
@@ -282,12 +346,19 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
                 nseg++;
             }
             if (last) {
-                if (exit_face != f_out) flag = true;
+                const uint4 face = reinterpret_cast<const uint4 *>(p.tets + c)[2];
+                if (sel4u(face, x) != f_out) { flag = true; why = 11; }
+                // Tie handling is certified away from the chain ends only: in a short chain the
+                // reference's look-ahead can pair the two hull faces through their common EMPTY tet
+                // (get_common_tetrahedra, optix_trace_rays.cu:22-37); a pair inverted at the very end
+                // has no following face to clear it.
+                if ((had_special && nhits <= 8) || pending_inv) { flag = true; why = 8; }
                 break;
             }
             e = back;
             c = nb;
-            if (++steps > MAX_WALK_STEPS) { flag = true; break; }
+            cur = nxt;
+            if (++steps > MAX_WALK_STEPS) { flag = true; why = 12; break; }
         }
         if (!flag && (nseg & 1u) && !(p.debug & 2u)) {
             // odd segment count: the stashed last segment goes out alone
@@ -307,6 +378,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         if (flag) {
             const uint32_t slot = atomicAdd(p.fallback_count, 1u);
             p.fallback_list[slot] = (uint32_t)(p.ray_base + ray);
+            if (t.stats) atomicAdd(&t.stats[4 + why], 1ull);
             p.walk_n[ray] = TN_EMPTY;
         } else {
             t.out_num[ray] = nseg;
@@ -370,7 +442,11 @@ void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
     // grid padded so that both remaps (runs of XCD_GROUP blocks / one band per XCD) are bijections
     const uint32_t unit = 8 * ((p.debug & 8u) ? (nblk + 7) / 8 : XCD_GROUP);
     const uint32_t grid = (nblk + unit - 1) / unit * unit;
-    hipLaunchKernelGGL(k_trace_walk, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
+    // small launches are latency-bound (one wave per SIMD at best): shortest dependent chain;
+    // large launches are throughput-bound: fewer registers, more waves per SIMD
+    const bool prefetch = (p.debug & 32u) ? true : ((p.debug & 64u) ? false : p.t.num_items < 32768);
+    if (prefetch) hipLaunchKernelGGL(k_trace_walk<true>, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
+    else hipLaunchKernelGGL(k_trace_walk<false>, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
 }
 
 }  // namespace tn

@@ -169,6 +169,12 @@ class TetrahedraTracer:
         _lib.check(self._lib.tn_trace_stats(self._h, C.byref(arr)))
         return {"walk": arr[0], "general": arr[1], "serial": arr[2], "overflow": arr[3]}
 
+    def flag_reasons(self):
+        """Why the walk handed rays of the last trace_rays to the general path (reason code -> count)."""
+        arr = (C.c_uint64 * 16)()
+        _lib.check(self._lib.tn_trace_flag_reasons(self._h, C.byref(arr)))
+        return {k: int(arr[k]) for k in range(1, 13) if arr[k]}
+
     def set_option(self, name: str, value: int):
         _lib.check(self._lib.tn_set_option(self._h, name.encode(), int(value)))
 
