@@ -134,6 +134,33 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *             0 = general all-hits path for every ray */
 int tn_set_option(tn_tracer_t tracer, const char *name, int value);
 
+/* ---- shallow MLP + volume render (inference forward) ------------------------------------------
+ * The arithmetic of these two lives in nerfstudio, not in /root/reference; the call sites are
+ * tetranerf/nerfstudio/model.py:414-455 (modules), :602-621 (MLP + heads), :632-638 (weights and
+ * renderers).  Weights use the nn.Linear layout [out, in], row-major fp32, i.e. what a reference
+ * checkpoint holds (mlp_base.layers.{0,1,2}, field_output_density.net, mlp_head.layers.0,
+ * field_output_color.net). */
+typedef struct tn_mlp_weights {
+    const float *w1, *b1; /* [128,64],  [128] */
+    const float *w2, *b2; /* [128,128], [128] */
+    const float *w3, *b3; /* [128,128], [128] */
+    const float *wd, *bd; /* [1,128],   [1]    density head  */
+    const float *wh, *bh; /* [128,155], [128]  mlp_head: columns [direction encoding 27 | base 128] */
+    const float *wr, *br; /* [3,128],   [3]    rgb head      */
+} tn_mlp_weights;
+
+/* feats f32 [64, n] feature-major (the buffer tn_interpolate_values writes), dirs f32 [n/samples_per_ray, 3]
+ * (one direction per ray; samples of a ray are consecutive) -> sigma f32 [n] (softplus), rgb f32 [n,3] (sigmoid) */
+int tn_mlp_forward(size_t n, uint32_t samples_per_ray, const float *feats, const float *dirs,
+                   const tn_mlp_weights *weights, float *sigma, float *rgb, void *stream);
+
+/* RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers.
+ * sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1] (bin edges: starts = edges[:, :-1], ends = edges[:, 1:]);
+ * out_rgb f32 [R,3], out_acc f32 [R], out_depth f32 [R], out_weights f32 [R,S] (nullable). */
+int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, const float *rgb, const float *edges,
+                 float background, float *out_rgb, float *out_acc, float *out_depth, float *out_weights,
+                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,129 @@
+"""GPU tests of the fused fp32-MFMA MLP, the composite kernel and the whole render path
+(config C3 of BASELINE.json: 100k-tet mesh, shallow-MLP forward, fp32, tolerance 1e-5) against the
+plain-PyTorch fp32 statement of the same arithmetic (render.py) evaluated on the CPU with the oracle."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def render():
+    return importlib.import_module("tetra-nerf_amd.render")
+
+
+def _model(render, seed=0, field_scale=1.0):
+    import torch
+
+    torch.manual_seed(seed)
+    return render.TetraMLP()
+
+
+def test_mlp_forward_matches_torch(tn, device, render):
+    import torch
+
+    mlp = _model(render)
+    torch.manual_seed(1)
+    for R, S in ((8, 256), (5, 37), (1, 1), (300, 64)):
+        n = R * S
+        feats = torch.randn(n, 64) * 0.7
+        dirs = torch.nn.functional.normalize(torch.randn(R, 3), dim=-1)
+        with torch.no_grad():
+            ws, wc = mlp(feats.double().float(), dirs[:, None, :].expand(R, S, 3).reshape(n, 3))
+        gm = mlp.to(device)
+        feats_fm = feats.t().contiguous().to(device)
+        sigma, rgb = tn.cpp.mlp_forward(feats_fm, dirs.to(device), render.mlp_weights(gm), S)
+        mlp.cpu()
+        np.testing.assert_allclose(sigma.cpu().numpy(), ws[:, 0].numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(rgb.cpu().numpy(), wc.numpy(), rtol=0, atol=1e-5)
+
+
+def test_mlp_forward_vs_float64(tn, device, render):
+    """fp32 MFMA = exact fp32 fma chain: error vs a float64 evaluation stays at fp32 round-off."""
+    import torch
+
+    mlp = _model(render, 3)
+    torch.manual_seed(4)
+    R, S = 64, 128
+    feats = torch.randn(R * S, 64)
+    dirs = torch.nn.functional.normalize(torch.randn(R, 3), dim=-1)
+    m64 = render.TetraMLP().double()
+    m64.load_state_dict({k: v.double() for k, v in mlp.state_dict().items()})
+    with torch.no_grad():
+        ws, wc = m64(feats.double(), dirs.double()[:, None, :].expand(R, S, 3).reshape(-1, 3))
+    gm = mlp.to(device)
+    sigma, rgb = tn.cpp.mlp_forward(feats.t().contiguous().to(device), dirs.to(device), render.mlp_weights(gm), S)
+    assert float((sigma.cpu().double() - ws[:, 0]).abs().max()) < 5e-6
+    assert float((rgb.cpu().double() - wc).abs().max()) < 2e-6
+
+
+def test_composite_matches_torch(tn, device, render):
+    import torch
+
+    torch.manual_seed(2)
+    for R, S in ((16, 256), (7, 65), (3, 2), (100, 128)):
+        sigma = torch.rand(R, S) * 20
+        sigma[0] = 0            # empty ray: background only, depth = last sample
+        if R > 1:
+            sigma[1] = 1e4      # opaque at the first sample
+        rgb = torch.rand(R, S, 3)
+        near = torch.rand(R, 1) + 0.5
+        edges = near + torch.cumsum(torch.rand(R, S + 1) * 0.02, -1)
+        w_rgb, w_acc, w_depth, w_w = render.composite(sigma[..., None], rgb, edges[:, :-1, None], edges[:, 1:, None])
+        g_rgb, g_acc, g_depth, g_w = tn.cpp.composite(sigma.to(device), rgb.to(device), edges.to(device),
+                                                      return_weights=True)
+        np.testing.assert_allclose(g_w.cpu().numpy(), w_w[..., 0].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(g_rgb.cpu().numpy(), w_rgb.numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(g_acc.cpu().numpy(), w_acc.numpy(), rtol=0, atol=1e-5)
+        # the median sample may flip when a cumulative weight sits within round-off of 0.5
+        same = np.isclose(g_depth.cpu().numpy(), w_depth.numpy(), rtol=0, atol=1e-5)
+        assert same.mean() >= 0.98
+
+
+def test_render_c3(tn, device, oracle, scenes, render):
+    """Config C3: 100k-tet mesh (seed 1), field U(-1e-4,1e-4) with colour rows, default-init MLP
+    (torch.manual_seed(0)), 4096 rays x 256 samples: sigma-weights-RGB within 1e-5 of the CPU fp32
+    statement (oracle tracer + torch MLP)."""
+    import torch
+
+    pts, cells = scenes.random_mesh(15000, 1)
+    torch.manual_seed(0)
+    mlp = render.TetraMLP()
+    field = (torch.rand(64, len(pts)) * 2 - 1) * 1e-4
+    field[1:4] = torch.rand(3, len(pts)) * 2 - 1
+    o, d = scenes.outside_in_rays(4096, 7)
+    S, M = 256, 512
+
+    class CpuTracer:
+        def __init__(self):
+            self.t = oracle.OracleTracer(use_bvh=True)
+            self.t.load_tetrahedra(pts, cells)
+
+        def trace_rays(self, o_, d_, M_):
+            return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in self.t.trace_rays(o_.numpy(), d_.numpy(), M_).items()}
+
+        def find_visited_cells(self, *a):
+            r = self.t.find_visited_cells(*[x.numpy() for x in a])
+            return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in r.items()}
+
+    def cpu_interp(vi, bc, f):
+        return torch.from_numpy(np.ascontiguousarray(oracle.interpolate_values(vi.numpy(), bc.numpy(), f.numpy())))
+
+    with torch.no_grad():
+        want = render.render_reference(CpuTracer(), cpu_interp, field, mlp, torch.from_numpy(o), torch.from_numpy(d), S, M)
+
+    tr = tn.TetrahedraTracer(device)
+    tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+    gm = render.TetraMLP()
+    gm.load_state_dict(mlp.state_dict())
+    gm = gm.to(device)
+    for fused in (True, False):
+        rd = render.TetraRenderer(tr, field.to(device), gm, S, M, fused=fused)
+        got = rd.render(torch.from_numpy(o).to(device), torch.from_numpy(d).to(device))
+        assert torch.equal(got["ray_mask"].cpu(), want["ray_mask"])
+        np.testing.assert_allclose(got["rgb"].cpu().numpy(), want["rgb"].numpy(), rtol=0, atol=1e-5, err_msg=f"fused={fused}")
+        np.testing.assert_allclose(got["accumulation"].cpu().numpy(), want["accumulation"].numpy(), rtol=0, atol=1e-5)
+        dd = np.isclose(got["depth"].cpu().numpy(), want["depth"].numpy(), rtol=0, atol=1e-4)
+        assert dd.mean() > 0.98

@@ -435,4 +435,26 @@ int tn_interpolate_values_backward(uint32_t D, uint32_t V, uint32_t n, uint32_t 
     });
 }
 
+int tn_mlp_forward(size_t n, uint32_t samples_per_ray, const float *feats, const float *dirs,
+                   const tn_mlp_weights *w, float *sigma, float *rgb, void *stream_) {
+    return guarded([&] {
+        if (n == 0) return;
+        if (!w || !feats || !dirs || !sigma || !rgb) throw tn::Error("null pointer");
+        if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
+        tn::MlpWeights m{w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
+        tn::launch_mlp_forward(n, samples_per_ray, n / samples_per_ray, feats, dirs, m, sigma, rgb, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, const float *rgb, const float *edges,
+                 float background, float *out_rgb, float *out_acc, float *out_depth, float *out_weights,
+                 void *stream_) {
+    return guarded([&] {
+        tn::launch_composite(num_rays, num_samples, sigma, rgb, edges, background, out_rgb, out_acc, out_depth,
+                             out_weights, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
 }  // extern "C"

@@ -61,4 +61,18 @@ void launch_interpolate_values_backward(uint32_t D, uint32_t V, uint32_t n, uint
                                         const float *bc, const float *grad_in, float *field_grad,
                                         hipStream_t stream);
 
+// shallow MLP + heads (tn_mlp.hip); all weights in nn.Linear layout [out, in] row-major, fp32
+struct MlpWeights {
+    const float *w1, *b1;  // [128,64],  [128]   mlp_base layer 0
+    const float *w2, *b2;  // [128,128], [128]   mlp_base layer 1
+    const float *w3, *b3;  // [128,128], [128]   mlp_base layer 2 (+ ReLU out)
+    const float *wd, *bd;  // [1,128],   [1]     density head (+ softplus)
+    const float *wh, *bh;  // [128,155], [128]   mlp_head: columns = [dir encoding 27 | base 128]
+    const float *wr, *br;  // [3,128],   [3]     rgb head (+ sigmoid)
+};
+void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const float *dirs,
+                        const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream);
+void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
+                      float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream);
+
 }  // namespace tn

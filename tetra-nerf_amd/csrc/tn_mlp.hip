@@ -1,0 +1,356 @@
+// tn_mlp.hip -- fused shallow MLP + heads of the Tetra-NeRF model on fp32 MFMA, and the per-ray
+// volume-render composite (inference forward).
+//
+// Replaces the PyTorch/cuBLAS chain of the reference's model
+//   mlp_base 64->128->128->128 (ReLU, ReLU out), density head 128->1 + softplus,
+//   NeRFEncoding(dir) ++ base -> mlp_head 155->128 ReLU, rgb head 128->3 + sigmoid
+//   (tetranerf/nerfstudio/model.py:414-455 built, :602-621 run), and
+//   RaySamples.get_weights + RGB/accumulation/depth renderers (:632-638).
+//
+// This part of the path really is a dense GEMM (122,624 FLOP per sample, K in {64,128,155}), so it
+// runs on the matrix cores -- in fp32, because the parity bar is 1e-5: v_mfma_f32_32x32x2_f32 is an
+// exact fp32 fma chain at the fp32 vector rate (157 TFLOP/s peak).
+//
+// Dataflow (the point of the design): one wavefront owns a tile of 32 samples and computes the
+// TRANSPOSED products  Y^T[out][sample] = W[out][k] * X^T[k][sample].  The MFMA C/D layout of a
+// 32x32 tile is  col = lane & 31 (= sample), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (= feature), and
+// the B operand wants lane (h = lane>>5, s = lane&31) to hold X^T[k_h][s] -- so accumulator register r
+// of a tile can be fed STRAIGHT BACK as the B operand of the next layer if that layer consumes its K
+// indices in the order {(r&3)+8*(r>>2), (r&3)+8*(r>>2)+4}.  The weights (A operands) are pre-permuted to
+// exactly that K order once per call (k_mlp_pack), so activations never leave the registers between
+// layers: no LDS round trip, no cross-lane shuffles, no HBM traffic besides the [64,n] input and the
+// 16 B/sample output.  Weights are staged per layer in LDS (<= 80 KB) and shared by the 4 waves of a
+// block; every MFMA reads its A operand as one conflict-free 256-B ds_read_b32.
+#include "tn_device.h"
+#include "tn_kernels.h"
+
+namespace tn {
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int HID = 128;          // hidden width
+constexpr int FD = 64;            // field dim
+constexpr int ENC = 27;           // direction encoding width
+constexpr int ENC_PAD = 28;       // padded to an even K
+constexpr int KS1 = FD / 2;       // k-steps of layer 1
+constexpr int KSH = HID / 2;      // k-steps over 128 features held in accumulators
+constexpr int KSE = ENC_PAD / 2;  // k-steps over the direction encoding
+constexpr int OT = HID / 32;      // output tiles of a hidden layer
+constexpr int MLP_BLOCK = 512;    // 8 waves share one staged layer: 256 samples per group
+
+// One staged layer = [k-steps + 1][tiles][64 lanes] floats; the extra last k-step carries the bias
+// (A = bias for the lower half-wave, 0 for the upper; B = 1.0), so the bias add is part of the GEMM.
+// The head layer has a 5th output tile whose row 0 is the density head (it consumes the same B
+// operands, the mlp_base output); the rgb head is a 1-tile layer (rows 0..2).
+struct LayerGeom { int ksteps, tiles; size_t off; };
+constexpr size_t lfloats(int ksteps, int tiles) { return (size_t)(ksteps + 1) * tiles * 64; }
+constexpr int HEAD_KS = KSE + KSH, HEAD_TILES = OT + 1;
+constexpr size_t OFF_W1 = 0;
+constexpr size_t OFF_W2 = OFF_W1 + lfloats(KS1, OT);
+constexpr size_t OFF_W3 = OFF_W2 + lfloats(KSH, OT);
+constexpr size_t OFF_WHEAD = OFF_W3 + lfloats(KSH, OT);
+constexpr size_t OFF_WRGB = OFF_WHEAD + lfloats(HEAD_KS, HEAD_TILES);
+constexpr size_t PACK_FLOATS = OFF_WRGB + lfloats(KSH, 1);
+constexpr size_t MAX_STAGE_FLOATS = lfloats(HEAD_KS, HEAD_TILES);
+
+__host__ __device__ constexpr int acc_feature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// k index consumed by k-step `ks` (0..63) of a layer whose input lives in accumulators, half h
+__host__ __device__ constexpr int acc_k(int ks, int h) { return 32 * (ks >> 4) + acc_feature(ks & 15, h); }
+
+__global__ void k_mlp_pack(MlpWeights w, float *__restrict__ pk) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= PACK_FLOATS) return;
+    float v = 0.f;
+    auto split = [](size_t j, int tiles, int &ks, int &ot, int &lane) {
+        lane = (int)(j & 63); ot = (int)((j >> 6) % tiles); ks = (int)(j / (64 * (size_t)tiles));
+    };
+    int ks, ot, lane;
+    if (i < OFF_W2) {                       // layer 1: natural K order (input from memory)
+        split(i - OFF_W1, OT, ks, ot, lane);
+        const int o = 32 * ot + (lane & 31), h = lane >> 5;
+        v = ks < KS1 ? w.w1[(size_t)o * FD + 2 * ks + h] : (h == 0 ? w.b1[o] : 0.f);
+    } else if (i < OFF_W3) {
+        split(i - OFF_W2, OT, ks, ot, lane);
+        const int o = 32 * ot + (lane & 31), h = lane >> 5;
+        v = ks < KSH ? w.w2[(size_t)o * HID + acc_k(ks, h)] : (h == 0 ? w.b2[o] : 0.f);
+    } else if (i < OFF_WHEAD) {
+        split(i - OFF_W3, OT, ks, ot, lane);
+        const int o = 32 * ot + (lane & 31), h = lane >> 5;
+        v = ks < KSH ? w.w3[(size_t)o * HID + acc_k(ks, h)] : (h == 0 ? w.b3[o] : 0.f);
+    } else if (i < OFF_WRGB) {              // head [enc(27) | base(128)] -> 128, plus the density tile
+        split(i - OFF_WHEAD, HEAD_TILES, ks, ot, lane);
+        const int row = lane & 31, h = lane >> 5;
+        if (ot < OT) {
+            const int o = 32 * ot + row;
+            const size_t base = (size_t)o * (ENC + HID);
+            if (ks < KSE) { const int k = 2 * ks + h; v = k < ENC ? w.wh[base + k] : 0.f; }
+            else if (ks < HEAD_KS) v = w.wh[base + ENC + acc_k(ks - KSE, h)];
+            else v = h == 0 ? w.bh[o] : 0.f;
+        } else if (row == 0) {              // density head in row 0 of the 5th tile
+            if (ks >= KSE && ks < HEAD_KS) v = w.wd[acc_k(ks - KSE, h)];
+            else if (ks == HEAD_KS) v = h == 0 ? w.bd[0] : 0.f;
+        }
+    } else {                                // rgb head: rows 0..2 of a single tile
+        split(i - OFF_WRGB, 1, ks, ot, lane);
+        const int row = lane & 31, h = lane >> 5;
+        if (row < 3) v = ks < KSH ? w.wr[(size_t)row * HID + acc_k(ks, h)] : (h == 0 ? w.br[row] : 0.f);
+    }
+    pk[i] = v;
+}
+
+// direction encoding per ray (padded to 28): NeRFEncoding(3, 4 freqs 2^linspace(0,4,4), include_input)
+__global__ void k_dir_encoding(size_t R, const float *__restrict__ dirs, float *__restrict__ enc) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float two_pi = 6.283185307179586f, half_pi = 1.5707963267948966f;
+    const float freqs[4] = {1.0f, 2.5198421478271484f, 6.349603652954102f, 16.0f};  // fp32(2**(4*i/3))
+    float *e = enc + r * ENC_PAD;
+    for (int c = 0; c < 3; ++c) {
+        const float x = two_pi * dirs[3 * r + c];
+        for (int f = 0; f < 4; ++f) {
+            const float s = x * freqs[f];
+            e[c * 4 + f] = sinf(s);
+            e[12 + c * 4 + f] = sinf(s + half_pi);
+        }
+        e[24 + c] = dirs[3 * r + c];
+    }
+    e[27] = 0.f;
+}
+
+__device__ __forceinline__ void stage_weights(float *lds, const float *__restrict__ src, size_t n_floats) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(lds);
+    for (size_t i = threadIdx.x; i < n_floats / 4; i += MLP_BLOCK) d4[i] = s4[i];
+}
+
+// acc[t] += W_staged[k-steps KS0 .. KS0+KS) * bin[0..KS)
+template <int KS, int KS0, int TILES>
+__device__ __forceinline__ void gemm_steps(f32x16 (&acc)[TILES], const float (&bin)[KSH], const float *lds, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const float *wrow = lds + (size_t)(KS0 + ks) * TILES * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], bin[ks], acc[t], 0, 0, 0);
+        // keep the scheduler from hoisting hundreds of A-operand reads (register blow-up); the
+        // MFMAs of one k-step (>= 256 cycles) already cover the next step's LDS latency
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int STEP, int TILES>
+__device__ __forceinline__ void bias_step(f32x16 (&acc)[TILES], const float *lds, int lane) {
+    const float *wrow = lds + (size_t)STEP * TILES * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], 1.0f, acc[t], 0, 0, 0);
+}
+
+template <int TILES>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[TILES]) {
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+}
+
+template <int TILES>
+__device__ __forceinline__ void relu_to_bin(const f32x16 (&acc)[TILES], float (&bin)[KSH]) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bin[t * 16 + r] = fmaxf(acc[t][r], 0.f);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t samples_per_ray, const float *__restrict__ feats,
+                                                           const float *__restrict__ enc, const float *__restrict__ pk,
+                                                           float *__restrict__ sigma, float *__restrict__ rgb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lds = reinterpret_cast<float *>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    constexpr size_t GROUP = (MLP_BLOCK / 64) * 32;
+    const size_t ngroups = (n + GROUP - 1) / GROUP;
+
+    for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const size_t s = g * GROUP + (size_t)wave * 32 + (lane & 31);
+        const size_t sc = s < n ? s : n - 1;  // clamped: out-of-range lanes compute a duplicate, store nothing
+        float bin[KSH];
+
+        // ---- layer 1: 64 -> 128, B operands straight from the feature-major input [64, n]
+        __syncthreads();
+        stage_weights(lds, pk + OFF_W1, lfloats(KS1, OT));
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) bin[ks] = feats[(size_t)(2 * ks + h) * n + sc];
+        __syncthreads();
+        {
+            f32x16 acc[OT];
+            zero_acc(acc);
+            gemm_steps<KS1, 0, OT>(acc, bin, lds, lane);
+            bias_step<KS1, OT>(acc, lds, lane);
+            relu_to_bin(acc, bin);
+        }
+        // ---- layers 2, 3: 128 -> 128, accumulators fed back as B operands
+        __syncthreads();
+        stage_weights(lds, pk + OFF_W2, lfloats(KSH, OT));
+        __syncthreads();
+        {
+            f32x16 acc[OT];
+            zero_acc(acc);
+            gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
+            bias_step<KSH, OT>(acc, lds, lane);
+            relu_to_bin(acc, bin);
+        }
+        __syncthreads();
+        stage_weights(lds, pk + OFF_W3, lfloats(KSH, OT));
+        __syncthreads();
+        {
+            f32x16 acc[OT];
+            zero_acc(acc);
+            gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
+            bias_step<KSH, OT>(acc, lds, lane);
+            relu_to_bin(acc, bin);  // mlp_base out_activation = ReLU
+        }
+        // ---- head [enc(27) | base(128)] -> 128 ReLU, with the density head riding as a 5th tile
+        __syncthreads();
+        stage_weights(lds, pk + OFF_WHEAD, lfloats(HEAD_KS, HEAD_TILES));
+        __syncthreads();
+        {
+            f32x16 acc[HEAD_TILES];
+            zero_acc(acc);
+            const float *e = enc + (sc / samples_per_ray) * ENC_PAD;
+#pragma unroll
+            for (int ks = 0; ks < KSE; ++ks) {
+                const float b = e[2 * ks + h];
+                const float *wrow = lds + (size_t)ks * HEAD_TILES * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < OT; ++t)   // the density tile has zero weights for the encoding
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], b, acc[t], 0, 0, 0);
+            }
+            gemm_steps<KSH, KSE, HEAD_TILES>(acc, bin, lds, lane);
+            bias_step<HEAD_KS, HEAD_TILES>(acc, lds, lane);
+            // density = row 0 of tile 4 -> register 0 of the lower half-wave
+            const float raw = acc[OT][0];
+            const float sp = raw > 20.0f ? raw : log1pf(expf(raw));  // torch softplus(beta=1, threshold=20)
+            if (h == 0 && s < n) sigma[s] = sp;
+            relu_to_bin(acc, bin);
+        }
+        // ---- rgb head 128 -> 3 + sigmoid (rows 0..2 of one tile)
+        __syncthreads();
+        stage_weights(lds, pk + OFF_WRGB, lfloats(KSH, 1));
+        __syncthreads();
+        {
+            f32x16 acc[1];
+            zero_acc(acc);
+            gemm_steps<KSH, 0, 1>(acc, bin, lds, lane);
+            bias_step<KSH, 1>(acc, lds, lane);
+            if (h == 0 && s < n) {
+                rgb[3 * s] = 1.0f / (1.0f + expf(-acc[0][0]));
+                rgb[3 * s + 1] = 1.0f / (1.0f + expf(-acc[0][1]));
+                rgb[3 * s + 2] = 1.0f / (1.0f + expf(-acc[0][2]));
+            }
+        }
+    }
+}
+
+// Per-ray composite: one wavefront per ray, lanes stride the samples; exclusive scan of sigma*delta.
+__global__ __launch_bounds__(64) void k_composite(size_t R, uint32_t S, const float *__restrict__ sigma,
+                                                  const float *__restrict__ rgb, const float *__restrict__ edges,
+                                                  float background, float *__restrict__ out_rgb,
+                                                  float *__restrict__ out_acc, float *__restrict__ out_depth,
+                                                  float *__restrict__ out_weights) {
+    const int lane = threadIdx.x;
+    for (size_t ray = blockIdx.x; ray < R; ray += gridDim.x) {
+        const float *e = edges + ray * (S + 1);
+        float carry = 0.f;       // sum of sigma*delta of all previous samples
+        float cw = 0.f;          // running sum of weights (for the median depth)
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f, accw = 0.f;
+        float depth = 0.f;
+        bool found = false;
+        for (uint32_t base = 0; base < S; base += 64) {
+            const uint32_t j = base + lane;
+            const bool ok = j < S;
+            const size_t q = ray * S + (ok ? j : S - 1);
+            const float st = e[ok ? j : S - 1], en = e[(ok ? j : S - 1) + 1];
+            const float dd = ok ? (en - st) * sigma[q] : 0.f;
+            // inclusive scan of dd over the wave
+            float inc = dd;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+            }
+            const float excl = carry + (inc - dd);
+            float w = (1.0f - expf(-dd)) * expf(-excl);
+            if (!(w == w) || !ok) w = 0.f;  // nan_to_num
+            if (out_weights && ok) out_weights[q] = w;
+            r0 += w * rgb[3 * q]; r1 += w * rgb[3 * q + 1]; r2 += w * rgb[3 * q + 2];
+            accw += w;
+            // median depth: first sample whose cumulative weight reaches 0.5
+            float winc = w;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float o = __shfl_up(winc, off);
+                if (lane >= off) winc += o;
+            }
+            const float cum = cw + winc;
+            const uint64_t m = __ballot(ok && cum >= 0.5f);
+            if (!found && m) {
+                const int src = __ffsll((unsigned long long)m) - 1;
+                depth = __shfl(0.5f * (st + en), src);
+                found = true;
+            }
+            carry += __shfl(inc, 63);
+            cw += __shfl(winc, 63);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            r0 += __shfl_xor(r0, off); r1 += __shfl_xor(r1, off); r2 += __shfl_xor(r2, off); accw += __shfl_xor(accw, off);
+        }
+        if (!found) depth = 0.5f * (e[S - 1] + e[S]);  // searchsorted clamps to the last sample
+        if (lane == 0) {
+            out_rgb[3 * ray] = r0 + background * (1.0f - accw);
+            out_rgb[3 * ray + 1] = r1 + background * (1.0f - accw);
+            out_rgb[3 * ray + 2] = r2 + background * (1.0f - accw);
+            out_acc[ray] = accw;
+            out_depth[ray] = depth;
+        }
+    }
+}
+
+size_t mlp_pack_floats() { return PACK_FLOATS; }
+
+void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const float *dirs,
+                        const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream) {
+    if (n == 0) return;
+    float *pk = nullptr, *enc = nullptr;
+    TN_HIP(hipMallocAsync((void **)&pk, PACK_FLOATS * sizeof(float), stream));
+    TN_HIP(hipMallocAsync((void **)&enc, (num_rays ? num_rays : 1) * ENC_PAD * sizeof(float), stream));
+    hipLaunchKernelGGL(k_mlp_pack, dim3((unsigned)((PACK_FLOATS + 255) / 256)), dim3(256), 0, stream, w, pk);
+    if (num_rays)
+        hipLaunchKernelGGL(k_dir_encoding, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, stream, num_rays, dirs, enc);
+    const size_t smem = MAX_STAGE_FLOATS * sizeof(float);  // the largest staged layer (head: 101,120 B)
+    static bool attr_set = false;
+    if (!attr_set) {
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const size_t group = (MLP_BLOCK / 64) * 32;
+    const size_t ngroups = (n + group - 1) / group;
+    const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);  // one 8-wave block per CU
+    hipLaunchKernelGGL(k_mlp_forward, dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, enc, pk, sigma, rgb);
+    TN_HIP(hipFreeAsync(pk, stream));
+    TN_HIP(hipFreeAsync(enc, stream));
+}
+
+void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
+                      float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream) {
+    if (R == 0 || S == 0) return;
+    const unsigned grid = (unsigned)(R < 256u * 32u ? R : 256u * 32u);
+    hipLaunchKernelGGL(k_composite, dim3(grid), dim3(64), 0, stream, R, S, sigma, rgb, edges, background, out_rgb, out_acc,
+                       out_depth, out_weights);
+}
+
+}  // namespace tn

@@ -250,6 +250,61 @@ def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, 
     return grad_field_out
 
 
+class _MlpWeightsStruct(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd", "wh", "bh", "wr", "br")]
+
+
+def mlp_forward(feats_fm, dirs, weights, samples_per_ray):
+    """Fused fp32-MFMA forward of mlp_base + density head + mlp_head + rgb head (addition to the
+    reference surface; the reference runs these through nerfstudio/PyTorch, model.py:602-621).
+    feats_fm f32 [64, n] feature-major (interpolate_values(...).moveaxis(-1, 0) is that buffer),
+    dirs f32 [n // samples_per_ray, 3], weights: 12 contiguous fp32 CUDA tensors in nn.Linear layout
+    (w1,b1,w2,b2,w3,b3,wd,bd,wh,bh,wr,br).  Returns sigma [n], rgb [n,3]."""
+    _check_input(feats_fm, "feats")
+    _check_input(dirs, "dirs")
+    _check(feats_fm.dtype == torch.float32 and feats_fm.dim() == 2 and feats_fm.size(0) == 64, "feats must be f32 [64, n]")
+    n = feats_fm.size(1)
+    S = int(samples_per_ray)
+    _check(S > 0 and n % S == 0, "n must be a multiple of samples_per_ray")
+    _check(dirs.dtype == torch.float32 and tuple(dirs.shape) == (n // S, 3), "dirs must be f32 [n/samples_per_ray, 3]")
+    shapes = [(128, 64), (128,), (128, 128), (128,), (128, 128), (128,), (1, 128), (1,), (128, 155), (128,), (3, 128), (3,)]
+    _check(len(weights) == 12, "weights must hold 12 tensors")
+    st = _MlpWeightsStruct()
+    keep = []
+    for (name, _), w, shp in zip(_MlpWeightsStruct._fields_, weights, shapes):
+        w = w.detach()
+        _check_input(w, name)
+        _check(w.dtype == torch.float32 and tuple(w.shape) == shp, f"{name} must be f32 {shp}")
+        keep.append(w)
+        setattr(st, name, w.data_ptr())
+    dev = feats_fm.device
+    sigma = torch.empty((n,), dtype=torch.float32, device=dev)
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tn_mlp_forward(n, S, _ptr(feats_fm), _ptr(dirs), C.byref(st), _ptr(sigma), _ptr(rgb),
+                                              _stream(dev)))
+    return sigma, rgb
+
+
+def composite(sigma, rgb, edges, background=1.0, return_weights=False):
+    """RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers
+    (model.py:632-638) in one kernel.  sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1]."""
+    for x, name in ((sigma, "sigma"), (rgb, "rgb"), (edges, "edges")):
+        _check_input(x, name)
+        _check(x.dtype == torch.float32, f"{name} must have float32 type")
+    R, S = sigma.shape
+    _check(tuple(rgb.shape) == (R, S, 3) and tuple(edges.shape) == (R, S + 1), "shape mismatch")
+    dev = sigma.device
+    out_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    acc = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    depth = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    weights = torch.empty((R, S), dtype=torch.float32, device=dev) if return_weights else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), _ptr(rgb), _ptr(edges), float(background), _ptr(out_rgb),
+                                            _ptr(acc), _ptr(depth), _ptr(weights), _stream(dev)))
+    return (out_rgb, acc, depth, weights) if return_weights else (out_rgb, acc, depth)
+
+
 def triangulate(points):
     """py_triangulate (py_binding.cpp:239-256).  The reference runs CGAL's Delaunay on the CPU
     (src/triangulation.cpp:34-75); CGAL is not part of this build, Qhull (scipy) stands in.
