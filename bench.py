@@ -56,6 +56,55 @@ def pmc_traffic(args, R, M):
     return t.get("hbm_bytes_per_launch") if t.get("workload") == key else None
 
 
+def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536, reps=2):
+    """Second half of BASELINE.json's metric: rendered rays/s for the 800x800 frame through the whole
+    forward path (trace -> uniform samples -> match -> gather -> fused fp32-MFMA MLP -> composite),
+    coarse pass of the `tetra-nerf-original` evaluation config, nerfstudio-style chunks."""
+    render = importlib.import_module("tetra-nerf_amd.render")
+    torch.manual_seed(0)
+    mlp = render.TetraMLP().to(dev)
+    field = ((torch.rand(64, num_vertices, device=dev) * 2 - 1) * 1e-4)
+    field[1:4] = torch.rand(3, num_vertices, device=dev) * 2 - 1
+    rd = render.TetraRenderer(tracer, field, mlp, samples, M, fused=True)
+    R = o.shape[0]
+
+    def frame():
+        hit = 0
+        for s in range(0, R, chunk):
+            out = rd.render(o[s:s + chunk], d[s:s + chunk])
+            hit += int(out["ray_mask"].sum())
+        return hit
+
+    hit = frame()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        frame()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    # MLP kernel alone on one chunk worth of samples of hitting rays (MFMA roofline)
+    n = min(hit, chunk) * samples
+    feats = torch.randn(64, n, device=dev)
+    dirs = torch.nn.functional.normalize(torch.randn(n // samples, 3, device=dev), dim=-1)
+    w = render.mlp_weights(mlp)
+    for _ in range(2):
+        tn.cpp.mlp_forward(feats, dirs, w, samples)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        tn.cpp.mlp_forward(feats, dirs, w, samples)
+    e1.record()
+    torch.cuda.synchronize()
+    mlp_ms = e0.elapsed_time(e1) / 5
+    flop = 2 * (64 * 128 + 128 * 128 * 2 + 128 + 155 * 128 + 128 * 3)
+    tf = n * flop / (mlp_ms * 1e-3) / 1e12
+    return {"rendered_rays_per_s": R / dt, "ms_per_frame": dt * 1e3, "rays": R, "hitting_rays": hit,
+            "samples_per_ray": samples, "pass": "coarse only (uniform samples), fused MLP + composite",
+            "roofline_mlp": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                             "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "samples": n, "kernel_ms": mlp_ms,
+                             "flop_per_sample": flop}}
+
+
 def cpu_baseline(pts, cells, o, d, M, target_s=12.0):
     """Oracle (BVH all-hits + sort + pairing, OpenMP) on a bounded sample of the bench rays."""
     from oracle import tn_oracle
@@ -93,6 +142,7 @@ def main():
     ap.add_argument("--mesh-points", type=int, default=15000)
     ap.add_argument("--mesh-seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-render", action="store_true", help="skip the rendered-rays/s leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,6 +243,8 @@ def main():
             "trace_path_stats": stats,
             "load_tetrahedra_s": load_s,
         }
+        if not args.no_render:
+            line["render"] = render_leg(tn, tracer, len(pts), o, d, M, dev)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pts, cells, o_np, d_np, M)
         print(json.dumps(line), flush=True)

@@ -154,6 +154,12 @@ typedef struct tn_mlp_weights {
 int tn_mlp_forward(size_t n, uint32_t samples_per_ray, const float *feats, const float *dirs,
                    const tn_mlp_weights *weights, float *sigma, float *rgb, void *stream);
 
+/* the same with the barycentric gather fused in (tn_interpolate_values<4> + tn_mlp_forward without the
+ * [64,n] intermediate): vertex_indices u32 [n,4], barycentric f32 [n,3], field f32 [64,V] feature-major */
+int tn_mlp_forward_gather(size_t n, uint32_t samples_per_ray, uint32_t num_vertices,
+                          const uint32_t *vertex_indices, const float *barycentric, const float *field,
+                          const float *dirs, const tn_mlp_weights *weights, float *sigma, float *rgb, void *stream);
+
 /* RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers.
  * sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1] (bin edges: starts = edges[:, :-1], ends = edges[:, 1:]);
  * out_rgb f32 [R,3], out_acc f32 [R], out_depth f32 [R], out_weights f32 [R,S] (nullable). */

@@ -40,6 +40,33 @@ def test_mlp_forward_matches_torch(tn, device, render):
         np.testing.assert_allclose(rgb.cpu().numpy(), wc.numpy(), rtol=0, atol=1e-5)
 
 
+def test_mlp_forward_gather_equals_two_step(tn, device, render):
+    """Fused gather+MLP must produce exactly the bits of interpolate_values followed by mlp_forward up to
+    the K order of layer 1 (different, so compare at fp32 round-off) and match the torch statement."""
+    import torch
+
+    mlp = _model(render, 5).to(device)
+    rng = np.random.default_rng(6)
+    V, R, S = 3000, 40, 96
+    vi = rng.integers(0, V, (R, S, 4)).astype(np.int32)
+    vi[rng.random((R, S)) < 0.25] = -1
+    bc = (rng.random((R, S, 3)).astype(np.float32)) / 4
+    bc[vi[..., 0] < 0] = 0
+    field = torch.randn(64, V, device=device)
+    dirs = torch.nn.functional.normalize(torch.randn(R, 3, device=device), dim=-1)
+    tvi, tbc = torch.from_numpy(vi).to(device), torch.from_numpy(bc).to(device)
+    w = render.mlp_weights(mlp)
+    feats = tn.cpp.interpolate_values(tvi, tbc, field)
+    s2, c2 = tn.cpp.mlp_forward(feats.moveaxis(-1, 0).reshape(64, -1), dirs, w, S)
+    s1, c1 = tn.cpp.mlp_forward_gather(tvi, tbc, field, dirs, w, S)
+    np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c1.cpu().numpy(), c2.cpu().numpy(), rtol=0, atol=2e-6)
+    with torch.no_grad():
+        ws, wc = mlp(feats, dirs[:, None, :].expand(R, S, 3))
+    np.testing.assert_allclose(s1.cpu().numpy(), ws.reshape(-1).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c1.cpu().numpy(), wc.reshape(-1, 3).cpu().numpy(), rtol=0, atol=1e-5)
+
+
 def test_mlp_forward_vs_float64(tn, device, render):
     """fp32 MFMA = exact fp32 fma chain: error vs a float64 evaluation stays at fp32 round-off."""
     import torch

@@ -16,7 +16,7 @@ SYMBOLS = (
     "tn_last_error", "tn_version", "tn_tracer_create", "tn_tracer_destroy", "tn_load_tetrahedra",
     "tn_num_faces", "tn_get_faces", "tn_trace_rays", "tn_find_matched_cells",
     "tn_interpolate_values", "tn_interpolate_values_backward", "tn_postprocess_hits",
-    "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_forward", "tn_composite",
+    "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite",
 )
 
 _lib = None
@@ -52,6 +52,7 @@ def load():
     lib.tn_trace_flag_reasons.argtypes = [vp, C.POINTER(C.c_uint64 * 16)]
     lib.tn_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.tn_mlp_forward.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp]
+    lib.tn_mlp_forward_gather.argtypes = [sz, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_composite.argtypes = [sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)

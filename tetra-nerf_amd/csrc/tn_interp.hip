@@ -39,50 +39,61 @@ __global__ __launch_bounds__(256) void k_transpose(const float *__restrict__ in,
         if (c0 + c < cols && r0 + tx < rows) out[(size_t)(c0 + c) * rows + r0 + tx] = tile[tx][c];
 }
 
+// Forward: one wavefront = 32 samples; lane (h = lane >> 5, s = lane & 31) produces the 32 features
+// 32h .. 32h+31 (of each 64-feature block) of sample s.  Every vertex row is read as 8 contiguous
+// 16-B loads per lane (128 B), every result store of the wave is two fully used 128-B segments of the
+// reference's [Fd, n] layout -- no LDS, no transposition, ~50 VGPRs.
 template <int D>
-__global__ __launch_bounds__(64) void k_interp_fwd(uint32_t n, uint32_t Fd, const uint32_t *__restrict__ vi,
-                                                   const float *__restrict__ bc, const float *__restrict__ fieldT,
-                                                   float *__restrict__ result) {
-    __shared__ float tile[TS][TP];
-    const int lane = threadIdx.x;
-    const uint32_t ntiles = (n + TS - 1) / TS;
-    for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
-        const uint32_t base = tix * TS;
-        const uint32_t cnt = n - base < TS ? n - base : TS;
-        uint32_t myv[D];
-        float myb[D - 1];
+__global__ __launch_bounds__(256) void k_interp_fwd(uint32_t n, uint32_t Fd, const uint32_t *__restrict__ vi,
+                                                    const float *__restrict__ bc, const float *__restrict__ fieldT,
+                                                    float *__restrict__ result) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const uint32_t ntiles = (n + 31) / 32;
+    const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t tix = wave0; tix < ntiles; tix += nwaves) {
+        const uint32_t s = tix * 32 + (lane & 31);
+        const bool ok = s < n;
+        uint32_t v[D];
+        float b[D - 1];
 #pragma unroll
-        for (int k = 0; k < D; ++k) myv[k] = TN_EMPTY;
+        for (int k = 0; k < D; ++k) v[k] = ok ? vi[(size_t)s * D + k] : TN_EMPTY;
 #pragma unroll
-        for (int k = 0; k < D - 1; ++k) myb[k] = 0.f;
-        if ((uint32_t)lane < cnt) {
-            const size_t i = base + lane;
+        for (int k = 0; k < D - 1; ++k) b[k] = ok ? bc[(size_t)s * (D - 1) + k] : 0.f;
+        float w = 0.f;
 #pragma unroll
-            for (int k = 0; k < D; ++k) myv[k] = vi[i * D + k];
+        for (int k = 0; k < D - 1; ++k) w += b[k];
+        const float w0 = 1.0f - w;
+        for (uint32_t f0 = 32 * h; f0 < Fd; f0 += 64) {
+            float out[32];
 #pragma unroll
-            for (int k = 0; k < D - 1; ++k) myb[k] = bc[i * (D - 1) + k];
-        }
-        for (uint32_t f0 = 0; f0 < Fd; f0 += 64) {
-            const uint32_t f = f0 + lane;
-            const bool fok = f < Fd;
-            for (uint32_t s = 0; s < cnt; ++s) {
-                float out = 0.f, w = 0.f;
+            for (int j = 0; j < 32; ++j) out[j] = 0.f;
+            // reference order: the D-1 weighted vertices first, the implicit-weight vertex last
 #pragma unroll
-                for (int k = 0; k < D - 1; ++k) {
-                    const float wk = __shfl(myb[k], s);
-                    const uint32_t v = __shfl(myv[k + 1], s);
-                    if (v != TN_EMPTY) out += wk * (fok ? fieldT[(size_t)v * Fd + f] : 0.f);
-                    w += wk;
+            for (int k = 0; k < D; ++k) {
+                const int kk = k < D - 1 ? k + 1 : 0;
+                const float wk = k < D - 1 ? b[k < D - 1 ? k : 0] : w0;
+                if (v[kk] != TN_EMPTY) {
+                    const float *row = fieldT + (size_t)v[kk] * Fd + f0;
+                    if (f0 + 32 <= Fd && (Fd & 3) == 0) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float4 x = reinterpret_cast<const float4 *>(row)[q];
+                            out[4 * q] += wk * x.x; out[4 * q + 1] += wk * x.y;
+                            out[4 * q + 2] += wk * x.z; out[4 * q + 3] += wk * x.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 32; ++j)
+                            if (f0 + j < Fd) out[j] += wk * row[j];
+                    }
                 }
-                const uint32_t v0 = __shfl(myv[0], s);
-                if (v0 != TN_EMPTY) out += (1.0f - w) * (fok ? fieldT[(size_t)v0 * Fd + f] : 0.f);
-                tile[s][lane] = out;
             }
-            __syncthreads();
-            const uint32_t fcnt = Fd - f0 < 64 ? Fd - f0 : 64;
-            if ((uint32_t)lane < cnt)
-                for (uint32_t j = 0; j < fcnt; ++j) result[(size_t)(f0 + j) * n + base + lane] = tile[lane][j];
-            __syncthreads();
+            if (ok) {
+#pragma unroll
+                for (int j = 0; j < 32; ++j)
+                    if (f0 + j < Fd) result[(size_t)(f0 + j) * n + s] = out[j];
+            }
         }
     }
 }
@@ -165,9 +176,9 @@ void run_fwd(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const floa
     float *fieldT = nullptr;
     TN_HIP(hipMallocAsync((void **)&fieldT, (size_t)V * Fd * sizeof(float), stream));
     hipLaunchKernelGGL(k_transpose, dim3((V + 63) / 64, (Fd + 63) / 64), dim3(256), 0, stream, field, fieldT, Fd, V);
-    const uint32_t ntiles = (n + TS - 1) / TS;
-    const unsigned grid = ntiles < 256u * 32u ? ntiles : 256u * 32u;
-    hipLaunchKernelGGL(k_interp_fwd<D>, dim3(grid), dim3(64), 0, stream, n, Fd, vi, bc, fieldT, result);
+    const uint32_t nblocks = ((n + 31) / 32 + 3) / 4;  // 4 waves (128 samples) per block
+    const unsigned grid = nblocks < 256u * 16u ? nblocks : 256u * 16u;
+    hipLaunchKernelGGL(k_interp_fwd<D>, dim3(grid), dim3(256), 0, stream, n, Fd, vi, bc, fieldT, result);
     TN_HIP(hipFreeAsync(fieldT, stream));
 }
 
@@ -185,6 +196,11 @@ void run_bwd(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const floa
 }
 
 }  // namespace
+
+void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols, hipStream_t stream) {
+    if (rows == 0 || cols == 0) return;
+    hipLaunchKernelGGL(k_transpose, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, stream, in, out, rows, cols);
+}
 
 void launch_interpolate_values(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
                                const float *bc, const float *field, float *result, hipStream_t stream) {

@@ -70,8 +70,12 @@ struct MlpWeights {
     const float *wh, *bh;  // [128,155], [128]   mlp_head: columns = [dir encoding 27 | base 128]
     const float *wr, *br;  // [3,128],   [3]     rgb head (+ sigmoid)
 };
-void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const float *dirs,
+// feats != null: input is the [64, n] feature buffer; feats == null: the kernel gathers the features
+// itself from (vi [n,4], bc [n,3], field [64, V] feature-major)
+void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
+                        const float *bc, const float *field, uint32_t num_vertices, const float *dirs,
                         const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream);
+void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols, hipStream_t stream);
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
                       float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream);
 

@@ -59,7 +59,7 @@ __host__ __device__ constexpr int acc_feature(int r, int h) { return (r & 3) + 8
 // k index consumed by k-step `ks` (0..63) of a layer whose input lives in accumulators, half h
 __host__ __device__ constexpr int acc_k(int ks, int h) { return 32 * (ks >> 4) + acc_feature(ks & 15, h); }
 
-__global__ void k_mlp_pack(MlpWeights w, float *__restrict__ pk) {
+__global__ void k_mlp_pack(MlpWeights w, float *__restrict__ pk, int gather_l1) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= PACK_FLOATS) return;
     float v = 0.f;
@@ -70,7 +70,9 @@ __global__ void k_mlp_pack(MlpWeights w, float *__restrict__ pk) {
     if (i < OFF_W2) {                       // layer 1: natural K order (input from memory)
         split(i - OFF_W1, OT, ks, ot, lane);
         const int o = 32 * ot + (lane & 31), h = lane >> 5;
-        v = ks < KS1 ? w.w1[(size_t)o * FD + 2 * ks + h] : (h == 0 ? w.b1[o] : 0.f);
+        // k-step ks consumes features (2ks, 2ks+1) when the input is read from the [64,n] buffer, and
+        // (ks, 32+ks) when the wave gathers it itself (each half-wave owns 32 contiguous features)
+        v = ks < KS1 ? w.w1[(size_t)o * FD + (gather_l1 ? 32 * h + ks : 2 * ks + h)] : (h == 0 ? w.b1[o] : 0.f);
     } else if (i < OFF_W3) {
         split(i - OFF_W2, OT, ks, ot, lane);
         const int o = 32 * ot + (lane & 31), h = lane >> 5;
@@ -165,7 +167,10 @@ __device__ __forceinline__ void relu_to_bin(const f32x16 (&acc)[TILES], float (&
 
 }  // namespace
 
+template <bool GATHER>
 __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t samples_per_ray, const float *__restrict__ feats,
+                                                           const uint32_t *__restrict__ vi, const float *__restrict__ bc,
+                                                           const float *__restrict__ fieldT,
                                                            const float *__restrict__ enc, const float *__restrict__ pk,
                                                            float *__restrict__ sigma, float *__restrict__ rgb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -182,8 +187,33 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t sa
         // ---- layer 1: 64 -> 128, B operands straight from the feature-major input [64, n]
         __syncthreads();
         stage_weights(lds, pk + OFF_W1, lfloats(KS1, OT));
+        if constexpr (!GATHER) {
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) bin[ks] = feats[(size_t)(2 * ks + h) * n + sc];
+            for (int ks = 0; ks < KS1; ++ks) bin[ks] = feats[(size_t)(2 * ks + h) * n + sc];
+        } else {
+            // fused barycentric gather (interpolate_values<4>, same summation order => same bits as the
+            // stand-alone op): this lane produces features 32h .. 32h+31 of its sample straight into the
+            // B-operand registers; the [64, n] feature buffer never exists.
+            const uint4 v4 = *reinterpret_cast<const uint4 *>(vi + 4 * sc);
+            const float b0 = bc[3 * sc], b1 = bc[3 * sc + 1], b2 = bc[3 * sc + 2];
+            const float w0 = 1.0f - ((b0 + b1) + b2);
+            const uint32_t vv[4] = {v4.y, v4.z, v4.w, v4.x};
+            const float ww[4] = {b0, b1, b2, w0};
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) bin[ks] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (vv[k] != TN_EMPTY) {
+                    const float4 *row = reinterpret_cast<const float4 *>(fieldT + (size_t)vv[k] * FD + 32 * h);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float4 x = row[q];
+                        bin[4 * q] += ww[k] * x.x; bin[4 * q + 1] += ww[k] * x.y;
+                        bin[4 * q + 2] += ww[k] * x.z; bin[4 * q + 3] += ww[k] * x.w;
+                    }
+                }
+            }
+        }
         __syncthreads();
         {
             f32x16 acc[OT];
@@ -322,27 +352,40 @@ __global__ __launch_bounds__(64) void k_composite(size_t R, uint32_t S, const fl
 
 size_t mlp_pack_floats() { return PACK_FLOATS; }
 
-void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const float *dirs,
+void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
+                        const float *bc, const float *field, uint32_t num_vertices, const float *dirs,
                         const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream) {
     if (n == 0) return;
-    float *pk = nullptr, *enc = nullptr;
+    const bool gather = feats == nullptr;
+    float *pk = nullptr, *enc = nullptr, *fieldT = nullptr;
     TN_HIP(hipMallocAsync((void **)&pk, PACK_FLOATS * sizeof(float), stream));
     TN_HIP(hipMallocAsync((void **)&enc, (num_rays ? num_rays : 1) * ENC_PAD * sizeof(float), stream));
-    hipLaunchKernelGGL(k_mlp_pack, dim3((unsigned)((PACK_FLOATS + 255) / 256)), dim3(256), 0, stream, w, pk);
+    hipLaunchKernelGGL(k_mlp_pack, dim3((unsigned)((PACK_FLOATS + 255) / 256)), dim3(256), 0, stream, w, pk, gather ? 1 : 0);
     if (num_rays)
         hipLaunchKernelGGL(k_dir_encoding, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, stream, num_rays, dirs, enc);
+    if (gather) {
+        TN_HIP(hipMallocAsync((void **)&fieldT, (size_t)num_vertices * FD * sizeof(float), stream));
+        launch_transpose(field, fieldT, FD, num_vertices, stream);  // [64, V] -> [V, 64]
+    }
     const size_t smem = MAX_STAGE_FLOATS * sizeof(float);  // the largest staged layer (head: 101,120 B)
     static bool attr_set = false;
     if (!attr_set) {
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     const size_t group = (MLP_BLOCK / 64) * 32;
     const size_t ngroups = (n + group - 1) / group;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);  // one 8-wave block per CU
-    hipLaunchKernelGGL(k_mlp_forward, dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, enc, pk, sigma, rgb);
+    if (gather)
+        hipLaunchKernelGGL(k_mlp_forward<true>, dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc,
+                           fieldT, enc, pk, sigma, rgb);
+    else
+        hipLaunchKernelGGL(k_mlp_forward<false>, dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc,
+                           fieldT, enc, pk, sigma, rgb);
     TN_HIP(hipFreeAsync(pk, stream));
     TN_HIP(hipFreeAsync(enc, stream));
+    if (fieldT) TN_HIP(hipFreeAsync(fieldT, stream));
 }
 
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,

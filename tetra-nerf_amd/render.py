@@ -161,9 +161,9 @@ class TetraRenderer:
                                                     out["barycentric_coordinates"][idx].contiguous(),
                                                     out["hit_distances"][idx].contiguous(),
                                                     out["vertex_indices"][idx].contiguous(), dist)
-            feats = cpp.interpolate_values(traced["vertex_indices"], traced["barycentric_coordinates"], self.field)
-            feats_fm = feats.moveaxis(-1, 0).reshape(FIELD_DIM, -1)   # the contiguous [64, n] buffer itself
-            sigma, col = cpp.mlp_forward(feats_fm, directions[idx].contiguous(), mlp_weights(self.mlp), S)
+            # gather + MLP + heads in one kernel (no [64, n] feature buffer)
+            sigma, col = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
+                                                directions[idx].contiguous(), mlp_weights(self.mlp), S)
             rgb_r, acc_r, depth_r = cpp.composite(sigma.view(-1, S), col.view(-1, S, 3), edges)
             rgb[idx] = rgb_r
             acc[idx] = acc_r

@@ -286,6 +286,45 @@ def mlp_forward(feats_fm, dirs, weights, samples_per_ray):
     return sigma, rgb
 
 
+def _weights_struct(weights):
+    shapes = [(128, 64), (128,), (128, 128), (128,), (128, 128), (128,), (1, 128), (1,), (128, 155), (128,), (3, 128), (3,)]
+    _check(len(weights) == 12, "weights must hold 12 tensors")
+    st = _MlpWeightsStruct()
+    keep = []
+    for (name, _), w, shp in zip(_MlpWeightsStruct._fields_, weights, shapes):
+        w = w.detach()
+        _check_input(w, name)
+        _check(w.dtype == torch.float32 and tuple(w.shape) == shp, f"{name} must be f32 {shp}")
+        keep.append(w)
+        setattr(st, name, w.data_ptr())
+    return st, keep
+
+
+def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray):
+    """interpolate_values + mlp_forward in ONE kernel: the wave gathers its samples' features from the
+    field straight into MFMA operand registers; the [64, n] feature buffer is never written.
+    vertex_indices i32 [..., 4], barycentric_coordinates f32 [..., 3], field f32 [64, V]."""
+    for x, name in ((vertex_indices, "vertex_indices"), (barycentric_coordinates, "barycentric_coordinates"),
+                    (field, "field"), (dirs, "dirs")):
+        _check_input(x, name)
+    _check(vertex_indices.dtype == torch.int32 and vertex_indices.size(-1) == 4, "vertex_indices must be i32 [...,4]")
+    _check(barycentric_coordinates.dtype == torch.float32 and barycentric_coordinates.size(-1) == 3,
+           "barycentric_coordinates must be f32 [...,3]")
+    _check(field.dtype == torch.float32 and field.dim() == 2 and field.size(0) == 64, "field must be f32 [64, V]")
+    n = vertex_indices.numel() // 4
+    S = int(samples_per_ray)
+    _check(S > 0 and n % S == 0, "n must be a multiple of samples_per_ray")
+    _check(dirs.dtype == torch.float32 and tuple(dirs.shape) == (n // S, 3), "dirs must be f32 [n/samples_per_ray, 3]")
+    st, keep = _weights_struct(weights)
+    dev = field.device
+    sigma = torch.empty((n,), dtype=torch.float32, device=dev)
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tn_mlp_forward_gather(n, S, field.size(1), _ptr(vertex_indices), _ptr(barycentric_coordinates),
+                                                     _ptr(field), _ptr(dirs), C.byref(st), _ptr(sigma), _ptr(rgb), _stream(dev)))
+    return sigma, rgb
+
+
 def composite(sigma, rgb, edges, background=1.0, return_weights=False):
     """RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers
     (model.py:632-638) in one kernel.  sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1]."""
