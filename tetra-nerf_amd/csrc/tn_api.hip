@@ -195,10 +195,11 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         tn::HostWideBvh hb, hh;
         tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), all, hb);
         tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), hull_ids, hh, t->hull_leaf);
-        tn::HostHullBvh hth;
-        tn::build_hull_threaded(hxyz.data(), t->host.faces.data(), hull_ids, hth);
         std::vector<tn::TetRec> recs;
-        tn::build_tet_records(T, hcells.data(), hxyz.data(), t->host, recs);
+        std::vector<uint32_t> rec_of_tet;
+        tn::build_tet_records(T, hcells.data(), hxyz.data(), t->host, recs, rec_of_tet);
+        tn::HostHullBvh hth;
+        tn::build_hull_threaded(hxyz.data(), t->host.faces.data(), t->host.face_tets.data(), hull_ids, recs, rec_of_tet, hth);
 
         t->faces.upload(t->host.faces);
         t->face_tets.upload(t->host.face_tets);

@@ -54,6 +54,8 @@ struct WideBvh {
 //   perm     per face k, 3x2 bits: local vertex index (0..3) of the face's 1st/2nd/3rd
 //            STORED vertex (first-seen triple), bits [6k, 6k+6)
 //   back     per face k, 2 bits: the local index of that face in the neighbour tet
+// Records are stored in Morton order of the tet centroids (consecutive steps of a walk and neighbouring
+// rays touch neighbouring lines); nbr[] are record indices, `orig` is the caller's tet id.
 struct alignas(128) TetRec {
     uint32_t vert[4];
     uint32_t nbr[4];
@@ -61,7 +63,11 @@ struct alignas(128) TetRec {
     float pos[4][3];
     uint32_t perm;
     uint32_t back;
-    uint32_t pad_[6];
+    uint32_t orig;     // index of this tet in the caller's `cells` (records are stored in Morton order)
+    uint32_t euv[2];   // per face k, 12 bits at [12*(k&1)] of euv[k>>1]: three 4-bit codes (U,V,W of the
+                       // face in stored order): bits 0-2 = edge pair index (01,02,03,12,13,23), bit 3 = negate
+    uint32_t cmb[3];   // per ordered face pair (entry e, exit x), 6 bits at 6*(3e + x - (x>e)): for each entry-face
+                       // slot j the position (0..2) of that vertex in the exit face's stored order, 3 = absent
 };
 static_assert(sizeof(TetRec) == 128, "TetRec must be one 128-B line");
 
@@ -100,10 +106,13 @@ struct HostWideBvh {
 
 struct HostHullBvh {
     std::vector<float> nodes;  // [n_nodes][8]: lo.xyz, skip | hi.xyz, leaf (first<<3|count, or ~0)
-    std::vector<float> tris;   // [n_hull][12]: v0.xyz, face id | v1.xyz, 0 | v2.xyz, 0  (Morton order)
+    std::vector<float> tris;   // [n_hull][12]: v0.xyz, face id | v1.xyz, tet record | v2.xyz, local face  (Morton order)
 };
-void build_hull_threaded(const float *xyz, const uint32_t *faces, const std::vector<uint32_t> &ids,
-                         HostHullBvh &out);
+// `recs` / `rec_of_tet` (record index of each original tet) from build_tet_records: every hull face carries
+// the record index of its tet and its local face index, so the walk starts without further lookups
+void build_hull_threaded(const float *xyz, const uint32_t *faces, const uint32_t *face_tets,
+                         const std::vector<uint32_t> &ids, const std::vector<TetRec> &recs,
+                         const std::vector<uint32_t> &rec_of_tet, HostHullBvh &out);
 
 // first-seen face table; throws tn::Error("A triangle is shared by more than two tetrahedra!")
 void build_face_table(size_t T, const uint32_t *cells, HostMesh &out);
@@ -112,6 +121,6 @@ void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<u
                     HostWideBvh &out, int leaf_size = WIDE);
 // adjacency records
 void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const HostMesh &hm,
-                       std::vector<TetRec> &out);
+                       std::vector<TetRec> &out, std::vector<uint32_t> &rec_of_tet);
 
 }  // namespace tn

@@ -20,8 +20,12 @@ struct RayPre {
     float ox, oy, oz;
 };
 
+// component k of (x,y,z) as two v_cndmask on the index bits (a `k == 0 ? .. : k == 1 ? ..` chain is
+// turned into a switch and lowered to exec-masked branches)
 __device__ __forceinline__ float pick(float x, float y, float z, int k) {
-    return k == 0 ? x : (k == 1 ? y : z);
+    const bool b0 = (k & 1) != 0, b1 = (k & 2) != 0;
+    const float lo = b0 ? y : x;
+    return b1 ? z : lo;
 }
 
 __device__ __forceinline__ RayPre ray_pre(float ox, float oy, float oz, float dx, float dy, float dz) {

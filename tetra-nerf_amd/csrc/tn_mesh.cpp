@@ -178,7 +178,7 @@ void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<u
 }
 
 void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const HostMesh &hm,
-                       std::vector<TetRec> &out) {
+                       std::vector<TetRec> &out, std::vector<uint32_t> &rec_of_tet) {
     const size_t F = hm.face_tets.size() / 2;
     // face id of (tet, local face): re-derive by replaying the first-seen enumeration.
     // A face's first sighting is (face_tets.x, some j); its second (face_tets.y, some j').
@@ -241,14 +241,79 @@ void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const 
                 r.perm |= li << (6 * k + 2 * m);
             }
         }
+        // derived selection codes (see TetRec): edge-function reuse and combine_indices by local ids
+        auto pair_code = [](uint32_t a, uint32_t b) -> uint32_t {
+            static const int idx[4][4] = {{-1, 0, 1, 2}, {0, -1, 3, 4}, {1, 3, -1, 5}, {2, 4, 5, -1}};
+            if (a == b) return 0;  // degenerate tet (repeated vertex): any code, the walk flags zero edge functions
+            return a < b ? (uint32_t)idx[a][b] : ((uint32_t)idx[b][a] | 8u);
+        };
+        r.euv[0] = r.euv[1] = 0;
+        r.cmb[0] = r.cmb[1] = r.cmb[2] = 0;
+        uint32_t loc[4][3];
+        for (int k = 0; k < 4; ++k)
+            for (int m = 0; m < 3; ++m) loc[k][m] = (r.perm >> (6 * k + 2 * m)) & 3u;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t a = loc[k][0], b = loc[k][1], c2 = loc[k][2];
+            const uint32_t code = pair_code(b, c2) | (pair_code(c2, a) << 4) | (pair_code(a, b) << 8);  // U, V, W
+            r.euv[k >> 1] |= code << (12 * (k & 1));
+        }
+        for (int e = 0; e < 4; ++e)
+            for (int x = 0; x < 4; ++x) {
+                if (x == e) continue;
+                uint32_t code = 0;
+                for (int j = 0; j < 3; ++j) {
+                    uint32_t pos = 3;
+                    for (int i2 = 0; i2 < 3; ++i2) if (loc[x][i2] == loc[e][j]) { pos = (uint32_t)i2; break; }
+                    code |= pos << (2 * j);
+                }
+                const int pid = 3 * e + x - (x > e ? 1 : 0);
+                const int bit = 6 * pid;
+                r.cmb[bit >> 5] |= code << (bit & 31);
+                if ((bit & 31) > 26) r.cmb[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+            }
+    }
+    // Morton order of the tet centroids: consecutive walk steps and neighbouring rays then touch
+    // neighbouring 128-B lines (L2 / TLB locality); nbr[] become record indices.
+    {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        std::vector<float> cen(3 * T);
+        for (size_t i = 0; i < T; ++i)
+            for (int a = 0; a < 3; ++a) {
+                const float c = 0.25f * (out[i].pos[0][a] + out[i].pos[1][a] + out[i].pos[2][a] + out[i].pos[3][a]);
+                cen[3 * i + a] = c;
+                lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c);
+            }
+        std::vector<std::pair<uint64_t, uint32_t>> order(T);
+        for (size_t i = 0; i < T; ++i) {
+            uint64_t code = 0;
+            for (int a = 0; a < 3; ++a) {
+                const double ext = (double)hi[a] - (double)lo[a];
+                const double u = ext > 0 ? ((double)cen[3 * i + a] - lo[a]) / ext : 0.0;
+                code |= spread21((uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0))) << a;
+            }
+            order[i] = {code, (uint32_t)i};
+        }
+        std::sort(order.begin(), order.end());
+        rec_of_tet.assign(T, 0);
+        for (size_t r = 0; r < T; ++r) rec_of_tet[order[r].second] = (uint32_t)r;
+        std::vector<TetRec> sorted(T);
+        for (size_t r = 0; r < T; ++r) {
+            TetRec rec = out[order[r].second];
+            rec.orig = order[r].second;
+            for (int k = 0; k < 4; ++k)
+                if (rec.nbr[k] != TN_EMPTY) rec.nbr[k] = rec_of_tet[rec.nbr[k]];
+            sorted[r] = rec;
+        }
+        out.swap(sorted);
     }
 }
 
 // Threaded binary BVH over the hull faces, nodes in DFS pre-order: the "hit" successor of a node
 // is the next node, the "miss" successor is `skip`.  A lane can traverse it without a stack and in
 // a ray-independent order (all crossings are wanted, not the nearest).  Leaves hold <= 4 faces.
-void build_hull_threaded(const float *xyz, const uint32_t *faces, const std::vector<uint32_t> &ids,
-                         HostHullBvh &out) {
+void build_hull_threaded(const float *xyz, const uint32_t *faces, const uint32_t *face_tets,
+                         const std::vector<uint32_t> &ids, const std::vector<TetRec> &recs,
+                         const std::vector<uint32_t> &rec_of_tet, HostHullBvh &out) {
     const size_t n = ids.size();
     out.nodes.clear();
     out.tris.clear();
@@ -292,6 +357,13 @@ void build_hull_threaded(const float *xyz, const uint32_t *faces, const std::vec
             out.tris[s * 12 + v * 4 + 3] = 0.0f;
         }
         std::memcpy(&out.tris[s * 12 + 3], &fid, 4);
+        // the hull face's only tet (as a record index) and the face's local index in it
+        const uint32_t rec = rec_of_tet[face_tets[2 * (size_t)fid]];
+        uint32_t loc = 0;
+        for (; loc < 4; ++loc) if (recs[rec].face[loc] == fid) break;
+        if (loc == 4) throw Error("internal: hull face not found in its tetrahedron");
+        std::memcpy(&out.tris[s * 12 + 7], &rec, 4);
+        std::memcpy(&out.tris[s * 12 + 11], &loc, 4);
     }
     struct Frame { size_t a, b; };
     // recursive emit in pre-order

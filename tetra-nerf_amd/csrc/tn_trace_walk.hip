@@ -36,16 +36,13 @@ constexpr int WALK_BLOCK = 256;
 constexpr uint32_t XCD_GROUP = 16;  // consecutive blocks per XCD run (4096 rays)
 constexpr uint32_t MAX_WALK_STEPS = 1u << 20;
 
-__device__ __forceinline__ SV sel4(const SV &a, const SV &b, const SV &c, const SV &d, uint32_t i) {
-    SV r;
-    r.x = i == 0 ? a.x : (i == 1 ? b.x : (i == 2 ? c.x : d.x));
-    r.y = i == 0 ? a.y : (i == 1 ? b.y : (i == 2 ? c.y : d.y));
-    r.z = i == 0 ? a.z : (i == 1 ? b.z : (i == 2 ? c.z : d.z));
-    return r;
-}
-
+// Branch-free 4-way selects on the two index bits (three v_cndmask).  Written as bit tests on
+// purpose: an `i == 0 ? a : i == 1 ? b : ...` chain is turned into a switch by the optimiser and then
+// lowered to exec-masked branches -- a dozen of those per step cost more than the arithmetic.
 __device__ __forceinline__ uint32_t sel4u(const uint4 &v, uint32_t i) {
-    return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+    const bool b0 = (i & 1u) != 0, b1 = (i & 2u) != 0;
+    const uint32_t lo = b0 ? v.y : v.x, hi = b0 ? v.w : v.z;
+    return b1 ? hi : lo;
 }
 
 // fill dwords [start, end) of `base` with `value`; base 16-byte aligned.  Wave-cooperative.
@@ -64,14 +61,30 @@ __device__ __forceinline__ void fill_dwords(uint32_t *__restrict__ base, uint32_
 // the fields of a TetRec the walk needs every step (face ids are only read at both ends)
 struct WalkRec {
     uint4 vert, nbr, q0, q1, q2;
-    uint2 meta;
+    uint4 m0;  // perm, back, orig, euv[0]
+    uint4 m1;  // euv[1], cmb[0..2]
 };
+
+// one of the six shared edge functions, by 4-bit code (bits 0-2 pair index, bit 3 negate)
+__device__ __forceinline__ float sel_edge(float e01, float e02, float e03, float e12, float e13, float e23, uint32_t c) {
+    const bool b0 = (c & 1u) != 0, b1 = (c & 2u) != 0, b2 = (c & 4u) != 0;
+    const float p0 = b0 ? e02 : e01, p1 = b0 ? e12 : e03, p2 = b0 ? e23 : e13;  // indices {0,1} {2,3} {4,5}
+    const float q = b1 ? p1 : p0;
+    const float v = b2 ? p2 : q;
+    return __uint_as_float(__float_as_uint(v) ^ ((c & 8u) << 28));
+}
+
+__device__ __forceinline__ float sel4f(float a, float b, float c, float d, uint32_t i) {
+    const bool b0 = (i & 1u) != 0, b1 = (i & 2u) != 0;
+    const float lo = b0 ? b : a, hi = b0 ? d : c;
+    return b1 ? hi : lo;
+}
 
 __device__ __forceinline__ WalkRec load_rec(const TetRec *tets, uint32_t c) {
     const uint4 *r = reinterpret_cast<const uint4 *>(tets + c);
     WalkRec x;
     x.vert = r[0]; x.nbr = r[1]; x.q0 = r[3]; x.q1 = r[4]; x.q2 = r[5];
-    x.meta = *reinterpret_cast<const uint2 *>(r + 6);
+    x.m0 = r[6]; x.m1 = r[7];
     return x;
 }
 
@@ -112,9 +125,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     // its padded box; box / triangle data are read through uniform (scalar) loads, every lane
     // tests its own ray.  No stack: the tree has a fixed depth (<= 3 internal levels).
     uint32_t nhull = 0;
-    uint32_t hf0 = TN_EMPTY, hf1 = TN_EMPTY;
+    uint32_t hf0 = TN_EMPTY, hf1 = TN_EMPTY, hc0 = 0, hc1 = 0, he0 = 0, he1 = 0;
     float ht0 = 0.f, ht1 = 0.f;
-    auto hull_face = [&](const SV &A, const SV &B, const SV &C, uint32_t fid) {
+    auto hull_face = [&](const SV &A, const SV &B, const SV &C, uint32_t fid, uint32_t rec, uint32_t loc) {
         const float U = edge_f(B, C), V = edge_f(C, A), W = edge_f(A, B);
         const bool mixed = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
         if (!mixed) {
@@ -123,12 +136,12 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             if (U == 0.0f || V == 0.0f || W == 0.0f || det == 0.0f) { flag = true; why = 1; }
             const float T = (U * A.z + V * B.z) + W * C.z;
             const float tt = T / det;
-            if (nhull == 0) { hf0 = fid; ht0 = tt; }
-            else if (nhull == 1) { hf1 = fid; ht1 = tt; }
+            if (nhull == 0) { hf0 = fid; ht0 = tt; hc0 = rec; he0 = loc; }
+            else if (nhull == 1) { hf1 = fid; ht1 = tt; hc1 = rec; he1 = loc; }
             nhull++;
         }
     };
-    if (!(p.debug & 128u)) {
+    {
         // Per-lane stackless traversal of the threaded hull tree (DFS pre-order, skip links):
         // ray-independent visiting order, every crossing of the ray's LINE is found.  Works for
         // incoherent batches (random training rays) as well as for camera frames.
@@ -145,50 +158,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
                     const float4 *tp = p.hull_tris + 3 * (size_t)(first + k);
                     const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
                     hull_face(shear(rp, v0.x, v0.y, v0.z), shear(rp, v1.x, v1.y, v1.z), shear(rp, v2.x, v2.y, v2.z),
-                              __float_as_uint(v0.w));
+                              __float_as_uint(v0.w), __float_as_uint(v1.w), __float_as_uint(v2.w));
                 }
             }
             i = i + 1;
-        }
-    } else
-    {
-        const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
-        const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.hull.scene_max);
-        auto any_hit = [&](int level, uint32_t idx, uint32_t c) -> bool {
-            const float *b = p.hull.boxes + ((size_t)p.hull.level_off[level] + idx) * (6 * WIDE);
-            const bool hit = active && line_box(ox, oy, oz, ix, iy, iz, b[c], b[WIDE + c], b[2 * WIDE + c],
-                                                b[3 * WIDE + c], b[4 * WIDE + c], b[5 * WIDE + c], pad);
-            return __ballot(hit) != 0ull;
-        };
-        auto leaf = [&](uint32_t idx) {
-            const uint32_t L = (uint32_t)p.hull.leaf_size;
-            const float *tr = p.hull.leaf_tri + (size_t)idx * (9 * L);
-            const uint32_t *ids = p.hull.leaf_id + (size_t)idx * L;
-            for (uint32_t c = 0; c < L; ++c) {
-                const uint32_t fid = ids[c];
-                if (fid == TN_EMPTY) break;  // leaves are filled front to back
-                const SV A = shear(rp, tr[c], tr[L + c], tr[2 * L + c]);
-                const SV B = shear(rp, tr[3 * L + c], tr[4 * L + c], tr[5 * L + c]);
-                const SV C = shear(rp, tr[6 * L + c], tr[7 * L + c], tr[8 * L + c]);
-                hull_face(A, B, C, fid);
-            }
-        };
-        auto node1 = [&](uint32_t idx) {
-            const uint32_t cnt = p.hull.level_cnt[0];
-            for (uint32_t c = 0; c < WIDE && idx * WIDE + c < cnt; ++c)
-                if (any_hit(1, idx, c)) leaf(idx * WIDE + c);
-        };
-        auto node2 = [&](uint32_t idx) {
-            const uint32_t cnt = p.hull.level_cnt[1];
-            for (uint32_t c = 0; c < WIDE && idx * WIDE + c < cnt; ++c)
-                if (any_hit(2, idx, c)) node1(idx * WIDE + c);
-        };
-        if (p.hull.top_level == 1) node1(0);
-        else if (p.hull.top_level == 2) node2(0);
-        else {
-            const uint32_t cnt = p.hull.level_cnt[2];
-            for (uint32_t c = 0; c < WIDE && c < cnt; ++c)
-                if (any_hit(3, 0, c)) node2(c);
         }
     }
     if (nhull != 0 && nhull != 2) { flag = true; why = 2; }
@@ -203,22 +176,15 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
 
     uint32_t nseg = 0;
     if (nhull == 2 && !flag) {
-        const uint32_t f_in = ht0 < ht1 ? hf0 : hf1;
         const uint32_t f_out = ht0 < ht1 ? hf1 : hf0;
-        uint32_t c = t.face_tets[2 * (size_t)f_in];  // a hull face has exactly one tet
-        uint32_t e = 4;                               // local index of the entry face
-        {
-            const uint4 face = reinterpret_cast<const uint4 *>(p.tets + c)[2];
-            e = face.x == f_in ? 0u : (face.y == f_in ? 1u : (face.z == f_in ? 2u : (face.w == f_in ? 3u : 4u)));
-            if (e == 4) { flag = true; why = 4; }
-        }
+        uint32_t c = ht0 < ht1 ? hc0 : hc1;  // record of the entry face's tet (a hull face has exactly one)
+        uint32_t e = ht0 < ht1 ? he0 : he1;  // local index of the entry face in it
         // state of the previous recorded (valid) hit
         bool have_prev = false, have_pp = false, pending_inv = false, had_special = false;
         float pt = 0.f, pu = 0.f, pv = 0.f, ppt = 0.f;
         uint32_t run = 0;  // current run of consecutive gaps below eps
         uint32_t nhits = 0;
         uint32_t steps = 0;
-        bool first = true;
         uint32_t h_cell = 0;  // stashed even-slot segment
         uint4 h_vi = make_uint4(0, 0, 0, 0);
         float h_t0 = 0.f, h_t1 = 0.f, h_b0 = 0.f, h_b1 = 0.f, h_b2 = 0.f, h_b3 = 0.f, h_b4 = 0.f, h_b5 = 0.f;
@@ -228,99 +194,121 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         // 4 shears -> 6 edge functions -> sign logic -> address), and the (t,u,v) / segment
         // arithmetic of this step runs under the load's latency.
         WalkRec cur = load_rec(p.tets, c);
-        while (!flag) {
+
+        // (t,u,v) of face k of the current tet in the face's STORED vertex order: U,V,W are picked (with
+        // sign) from the six shared edge functions -- E(Q,P) == -E(P,Q) bitwise -- by the record's codes.
+        auto face_tuv = [&](const WalkRec &rc, const SV &P0, const SV &P1, const SV &P2, const SV &P3, float e01, float e02,
+                            float e03, float e12, float e13, float e23, uint32_t k, float &tt, float &uu, float &vv) -> bool {
+            const uint32_t word = (k & 2u) ? rc.m1.x : rc.m0.w;
+            const uint32_t code = (word >> (12u * (k & 1u))) & 0xFFFu;
+            const uint32_t pm = rc.m0.x >> (6u * k);
+            const float U = sel_edge(e01, e02, e03, e12, e13, e23, code);
+            const float V = sel_edge(e01, e02, e03, e12, e13, e23, code >> 4);
+            const float W = sel_edge(e01, e02, e03, e12, e13, e23, code >> 8);
+            return tri_finish(U, V, W, sel4f(P0.z, P1.z, P2.z, P3.z, pm & 3u), sel4f(P0.z, P1.z, P2.z, P3.z, (pm >> 2) & 3u),
+                              sel4f(P0.z, P1.z, P2.z, P3.z, (pm >> 4) & 3u), tt, uu, vv);
+        };
+        // vertex ids of the entry face in its stored order (carried: the exit face of one step is the
+        // entry face of the next, same face table entry => same triple)
+        uint32_t in0, in1, in2;
+        {
+            const uint32_t pe = cur.m0.x >> (6u * e);
+            in0 = sel4u(cur.vert, pe & 3u); in1 = sel4u(cur.vert, (pe >> 2) & 3u); in2 = sel4u(cur.vert, (pe >> 4) & 3u);
+            // the entry hull face itself may be the first recorded hit
+            const SV P0 = shear(rp, __uint_as_float(cur.q0.x), __uint_as_float(cur.q0.y), __uint_as_float(cur.q0.z));
+            const SV P1 = shear(rp, __uint_as_float(cur.q0.w), __uint_as_float(cur.q1.x), __uint_as_float(cur.q1.y));
+            const SV P2 = shear(rp, __uint_as_float(cur.q1.z), __uint_as_float(cur.q1.w), __uint_as_float(cur.q2.x));
+            const SV P3 = shear(rp, __uint_as_float(cur.q2.y), __uint_as_float(cur.q2.z), __uint_as_float(cur.q2.w));
+            float tt, uu, vv;
+            if (face_tuv(cur, P0, P1, P2, P3, edge_f(P0, P1), edge_f(P0, P2), edge_f(P0, P3), edge_f(P1, P2), edge_f(P1, P3),
+                         edge_f(P2, P3), e, tt, uu, vv)) {
+                have_prev = true; pt = tt; pu = uu; pv = vv; nhits = 1;
+            }
+        }
+
+        for (;;) {
+            // All checks of a step accumulate into `bad` (first reason kept) and are acted on ONCE at the
+            // end of the step: one divergence point per step instead of a dozen.
+            uint32_t bad = 0;
             const SV P0 = shear(rp, __uint_as_float(cur.q0.x), __uint_as_float(cur.q0.y), __uint_as_float(cur.q0.z));
             const SV P1 = shear(rp, __uint_as_float(cur.q0.w), __uint_as_float(cur.q1.x), __uint_as_float(cur.q1.y));
             const SV P2 = shear(rp, __uint_as_float(cur.q1.z), __uint_as_float(cur.q1.w), __uint_as_float(cur.q2.x));
             const SV P3 = shear(rp, __uint_as_float(cur.q2.y), __uint_as_float(cur.q2.z), __uint_as_float(cur.q2.w));
             const float e01 = edge_f(P0, P1), e02 = edge_f(P0, P2), e03 = edge_f(P0, P3);
             const float e12 = edge_f(P1, P2), e13 = edge_f(P1, P3), e23 = edge_f(P2, P3);
-            if (e01 == 0.0f || e02 == 0.0f || e03 == 0.0f || e12 == 0.0f || e13 == 0.0f || e23 == 0.0f) { flag = true; why = 5; break; }
+            if (e01 == 0.0f || e02 == 0.0f || e03 == 0.0f || e12 == 0.0f || e13 == 0.0f || e23 == 0.0f) bad = 5;
             // face k (opposite vertex k) is crossed iff its three cyclic edge functions agree in sign
             const bool h3 = (e01 > 0.0f) == (e12 > 0.0f) && (e12 > 0.0f) == (e02 < 0.0f);   // 0->1, 1->2, 2->0
             const bool h2 = (e01 > 0.0f) == (e13 > 0.0f) && (e13 > 0.0f) == (e03 < 0.0f);   // 0->1, 1->3, 3->0
             const bool h1 = (e02 > 0.0f) == (e23 > 0.0f) && (e23 > 0.0f) == (e03 < 0.0f);   // 0->2, 2->3, 3->0
             const bool h0 = (e12 > 0.0f) == (e23 > 0.0f) && (e23 > 0.0f) == (e13 < 0.0f);   // 1->2, 2->3, 3->1
             const uint32_t hmask = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
-            if (__popc(hmask) != 2 || !((hmask >> e) & 1u)) { flag = true; why = 6; break; }
-            const uint32_t x = __ffs(hmask & ~(1u << e)) - 1;  // exit face
+            if (!bad && (__popc(hmask) != 2 || !((hmask >> e) & 1u))) bad = 6;
+            const uint32_t x = (__ffs(hmask & ~(1u << e)) - 1) & 3u;  // exit face
             const uint32_t nb = sel4u(cur.nbr, x);
-            const uint32_t back = (cur.meta.y >> (2 * x)) & 3u;
+            const uint32_t back = (cur.m0.y >> (2 * x)) & 3u;
             const bool last = nb == TN_EMPTY;
             WalkRec nxt = cur;
             if constexpr (PREFETCH) {
-                nxt = load_rec(p.tets, last ? c : nb);
+                nxt = load_rec(p.tets, (last || bad) ? c : nb);
                 __builtin_amdgcn_sched_barrier(0);
             }
 
-            // (t,u,v) of a face in its STORED vertex order
-            auto face_tuv = [&](uint32_t k, float &tt, float &uu, float &vv) -> bool {
-                const uint32_t pm = cur.meta.x >> (6 * k);
-                const SV A = sel4(P0, P1, P2, P3, pm & 3u), B = sel4(P0, P1, P2, P3, (pm >> 2) & 3u),
-                         C = sel4(P0, P1, P2, P3, (pm >> 4) & 3u);
-                return tri_finish(edge_f(B, C), edge_f(C, A), edge_f(A, B), A.z, B.z, C.z, tt, uu, vv);
-            };
-            if (first) {
-                first = false;
-                float tt, uu, vv;
-                if (face_tuv(e, tt, uu, vv)) { have_prev = true; pt = tt; pu = uu; pv = vv; nhits = 1; }
-            }
-            // segment to emit this step
+            float ct = 0.f, cu = 0.f, cv = 0.f;
+            bool valid;
+            if (p.debug & 256u) { ct = pt + 0.01f; cu = 0.25f; cv = 0.25f; valid = true; }  // ablation: no (t,u,v) arithmetic
+            else valid = face_tuv(cur, P0, P1, P2, P3, e01, e02, e03, e12, e13, e23, x, ct, cu, cv);
+
+            // exit face's stored vertex triple (next step's entry triple)
+            const uint32_t px = cur.m0.x >> (6u * x);
+            const uint32_t ex0 = sel4u(cur.vert, px & 3u), ex1 = sel4u(cur.vert, (px >> 2) & 3u), ex2 = sel4u(cur.vert, (px >> 4) & 3u);
+
             bool do_emit = false;
-            uint32_t s_cell = 0;
-            uint4 s_vi = make_uint4(0, 0, 0, 0);
-            float s_t0 = 0.f, s_t1 = 0.f, s_b0 = 0.f, s_b1 = 0.f, s_b2 = 0.f, s_b3 = 0.f, s_b4 = 0.f, s_b5 = 0.f;
-            float ct, cu, cv;
-            const bool valid = face_tuv(x, ct, cu, cv);
-            if (valid) {
-                if (have_prev) {
-                    const bool is_short = fabsf(pt - ct) < TN_EPS;
-                    bool ascending = ct > pt;
-                    if (ct == pt) {
-                        // exact tie: the sort orders the two faces by id
-                        const uint4 face = reinterpret_cast<const uint4 *>(p.tets + c)[2];
-                        ascending = sel4u(face, x) > sel4u(face, e);
-                    }
-                    if (ascending) {
-                        if (pending_inv) {
-                            // the face after an inverted pair must clear BOTH of its faces by eps
-                            if (!(ct - ppt >= TN_EPS)) { flag = true; why = 7; break; }
-                            pending_inv = false;
-                        }
-                        if (is_short) { if (++run >= 2) had_special = true; } else run = 0;   // (S2)
-                    } else {
-                        // (S1) sorted order != chain order.  Certified only for an isolated pair closer
-                        // than eps whose neighbours are at least eps away on both sides.
-                        if (!is_short || !have_pp || run > 0 || pending_inv || !(ct - ppt >= TN_EPS)) { flag = true; why = 7; break; }
-                        pending_inv = true;
-                        had_special = true;
-                    }
-                    if (!is_short) {
-                        // stored vertex triples of the entry face e and the exit face x
-                        const uint32_t pe = cur.meta.x >> (6 * e), px = cur.meta.x >> (6 * x);
-                        const uint32_t id1[3] = {sel4u(cur.vert, pe & 3u), sel4u(cur.vert, (pe >> 2) & 3u), sel4u(cur.vert, (pe >> 4) & 3u)};
-                        const uint32_t id2[3] = {sel4u(cur.vert, px & 3u), sel4u(cur.vert, (px >> 2) & 3u), sel4u(cur.vert, (px >> 4) & 3u)};
-                        uint32_t vi[4];
-                        float b1[3], b2[3];
-                        combine_indices(id1, id2, pu, pv, cu, cv, vi, b1, b2);
-                        do_emit = true;
-                        s_cell = c; s_t0 = pt; s_t1 = ct;
-                        s_b0 = b1[0]; s_b1 = b1[1]; s_b2 = b1[2]; s_b3 = b2[0]; s_b4 = b2[1]; s_b5 = b2[2];
-                        s_vi = make_uint4(vi[0], vi[1], vi[2], vi[3]);
-                    }
+            if (valid && have_prev) {
+                const bool is_short = fabsf(pt - ct) < TN_EPS;
+                bool ascending = ct > pt;
+                if (ct == pt) {
+                    // exact tie: the sort orders the two faces by id
+                    const uint4 face = reinterpret_cast<const uint4 *>(p.tets + c)[2];
+                    ascending = sel4u(face, x) > sel4u(face, e);
                 }
-                have_pp = have_prev; ppt = pt;
-                have_prev = true; pt = ct; pu = cu; pv = cv;
-                if (++nhits > M - 1) { flag = true; why = 9; break; }                      // more than M-1 faces
-            } else if (have_prev) {
-                flag = true; why = 10; break;                                              // hit list is not a suffix of the chain
+                if (ascending) {
+                    // the face after an inverted pair must clear BOTH of its faces by eps
+                    if (pending_inv && !(ct - ppt >= TN_EPS) && !bad) bad = 7;
+                    pending_inv = false;
+                    if (is_short) { if (++run >= 2) had_special = true; } else run = 0;   // (S2)
+                } else {
+                    // (S1) sorted order != chain order.  Certified only for an isolated pair closer
+                    // than eps whose neighbours are at least eps away on both sides.
+                    if ((!is_short || !have_pp || run > 0 || pending_inv || !(ct - ppt >= TN_EPS)) && !bad) bad = 7;
+                    pending_inv = true;
+                    had_special = true;
+                }
+                do_emit = !is_short;
+            } else if (!valid && have_prev && !bad) {
+                bad = 10;  // hit list is not a suffix of the chain
             }
+            if (valid && ++nhits > M - 1 && !bad) bad = 9;  // more than M-1 faces
+
             if constexpr (!PREFETCH) {
-                // every use of the current record is done: request the next one BEFORE the stores
-                if (!last) nxt = load_rec(p.tets, nb);
+                // every use of the current record's geometry is done: request the next one BEFORE the stores
+                if (!last && !bad) nxt = load_rec(p.tets, nb);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (do_emit) {
+            if (do_emit && !bad) {
+                // combine_indices by local indices: entry slot j <- position of its vertex in the exit face
+                const uint32_t bit = 6u * (3u * e + x - (x > e ? 1u : 0u));
+                const uint32_t w = bit >> 5;
+                const bool w0 = (w & 1u) != 0, w1 = (w & 2u) != 0;
+                const uint32_t lo = w1 ? cur.m1.w : (w0 ? cur.m1.z : cur.m1.y);
+                const uint32_t hi = w1 ? 0u : (w0 ? cur.m1.w : cur.m1.z);
+                const uint32_t cc = __builtin_amdgcn_alignbit(hi, lo, bit & 31u);
+                const float r0 = 1.0f - cu - cv;
+                const uint32_t c0 = cc & 3u, c1 = (cc >> 2) & 3u, c2 = (cc >> 4) & 3u;
+                const float s_b0 = 1.0f - pu - pv, s_b1 = pu, s_b2 = pv;
+                const float s_b3 = sel4f(r0, cu, cv, 0.f, c0), s_b4 = sel4f(r0, cu, cv, 0.f, c1), s_b5 = sel4f(r0, cu, cv, 0.f, c2);
+                const uint32_t s_cell = cur.m0.z;  // the caller's tet id
+                const uint4 s_vi = make_uint4(sel4u(cur.vert, e), in0, in1, in2);
                 // rows are written two segments at a time (even slot stashed, odd slot flushes the
                 // pair): 7 store transactions per pair instead of 12 -- the per-lane stores are
                 // transaction-bound, not byte-bound
@@ -328,7 +316,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
                     if (!(p.debug & 2u)) {
                         const size_t s0 = nseg - 1;
                         *reinterpret_cast<uint2 *>(row_cells + s0) = make_uint2(h_cell, s_cell);
-                        *reinterpret_cast<float4 *>(row_dist + 2 * s0) = make_float4(h_t0, h_t1, s_t0, s_t1);
+                        *reinterpret_cast<float4 *>(row_dist + 2 * s0) = make_float4(h_t0, h_t1, pt, ct);
                         float4 *bp = reinterpret_cast<float4 *>(row_bary + 6 * s0);
                         bp[0] = make_float4(h_b0, h_b1, h_b2, h_b3);
                         bp[1] = make_float4(h_b4, h_b5, s_b0, s_b1);
@@ -340,25 +328,31 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
                         }
                     }
                 } else {
-                    h_cell = s_cell; h_vi = s_vi; h_t0 = s_t0; h_t1 = s_t1;
+                    h_cell = s_cell; h_vi = s_vi; h_t0 = pt; h_t1 = ct;
                     h_b0 = s_b0; h_b1 = s_b1; h_b2 = s_b2; h_b3 = s_b3; h_b4 = s_b4; h_b5 = s_b5;
                 }
                 nseg++;
             }
-            if (last) {
+            if (valid) {
+                have_pp = have_prev; ppt = pt;
+                have_prev = true; pt = ct; pu = cu; pv = cv;
+            }
+            if (last && !bad) {
                 const uint4 face = reinterpret_cast<const uint4 *>(p.tets + c)[2];
-                if (sel4u(face, x) != f_out) { flag = true; why = 11; }
+                if (sel4u(face, x) != f_out) bad = 11;
                 // Tie handling is certified away from the chain ends only: in a short chain the
                 // reference's look-ahead can pair the two hull faces through their common EMPTY tet
                 // (get_common_tetrahedra, optix_trace_rays.cu:22-37); a pair inverted at the very end
                 // has no following face to clear it.
-                if ((had_special && nhits <= 8) || pending_inv) { flag = true; why = 8; }
-                break;
+                else if ((had_special && nhits <= 8) || pending_inv) bad = 8;
             }
+            if (!bad && !last && ++steps > MAX_WALK_STEPS) bad = 12;
+            if (bad) { flag = true; why = bad; break; }
+            if (last) break;
             e = back;
             c = nb;
             cur = nxt;
-            if (++steps > MAX_WALK_STEPS) { flag = true; why = 12; break; }
+            in0 = ex0; in1 = ex1; in2 = ex2;
         }
         if (!flag && (nseg & 1u) && !(p.debug & 2u)) {
             // odd segment count: the stashed last segment goes out alone
