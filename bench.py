@@ -105,7 +105,7 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
                              "flop_per_sample": flop}}
 
 
-def cpu_baseline(pts, cells, o, d, M, target_s=12.0):
+def cpu_baseline(pts, cells, o, d, M, target_s=30.0):
     """Oracle (BVH all-hits + sort + pairing, OpenMP) on a bounded sample of the bench rays."""
     from oracle import tn_oracle
 
@@ -113,7 +113,7 @@ def cpu_baseline(pts, cells, o, d, M, target_s=12.0):
     ot.load_tetrahedra(pts, cells)
     rng = np.random.default_rng(0)
     perm = rng.permutation(len(o))
-    probe = perm[:8192]
+    probe = perm[:65536]
     ot.trace_rays(o[probe[:256]], d[probe[:256]], M)  # thread pool warm-up
     t0 = time.perf_counter()
     ot.trace_rays(o[probe], d[probe], M)

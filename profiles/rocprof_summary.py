@@ -31,7 +31,7 @@ def stats(db):
             "min(scratch_size), min(workgroup_size), max(grid_size) from kernels group by kernel_name").fetchall()
         print("\n# resources per kernel (vgpr, agpr, sgpr, lds bytes, scratch bytes, workgroup, max grid)")
         for r in rows:
-            if r[0].startswith("tn::"):
+            if "tn::" in r[0]:
                 print(f"{short(r[0], 80):<82} " + " ".join(str(x) for x in r[1:]))
     except sqlite3.Error:
         pass
@@ -45,7 +45,7 @@ def pmc(db):
     print(f"# rocprofv3 --pmc summary of {db} (FETCH_SIZE / WRITE_SIZE are in KiB per dispatch)")
     print(f"{'kernel':<82} {'counter':<28} {'avg':>16} {'min':>16} {'max':>16} {'n':>4}")
     for name, ctr, avg, mn, mx, n in rows:
-        if name.startswith("tn::"):
+        if "tn::" in name:
             print(f"{short(name, 80):<82} {ctr:<28} {avg:>16.1f} {mn:>16.1f} {mx:>16.1f} {n:>4}")
 
 
