@@ -327,7 +327,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
                 tn::launch_trace_general(p, t->side);
-                if (!(t->debug & 16u)) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream);
+                if (!(t->debug & 16u)) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream, (t->debug & 512u) != 0);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
             } else {

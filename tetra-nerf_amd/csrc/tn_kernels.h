@@ -46,7 +46,7 @@ struct WalkParams {
 void launch_trace_walk(const WalkParams &p, hipStream_t stream);
 // constant tails [n, M) of the rows certified by the walk (n = walk_n[ray] != TN_EMPTY)
 void launch_fill_tails(size_t num_rays, uint32_t M, const uint32_t *walk_n, uint32_t *out_cells, float *out_bary,
-                       float *out_dist, uint32_t *out_verts, hipStream_t stream);
+                       float *out_dist, uint32_t *out_verts, hipStream_t stream, bool nontemporal = false);
 
 // sample -> segment matching (tn_match.hip)
 void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,

@@ -46,15 +46,21 @@ __device__ __forceinline__ uint32_t sel4u(const uint4 &v, uint32_t i) {
 }
 
 // fill dwords [start, end) of `base` with `value`; base 16-byte aligned.  Wave-cooperative.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT = false>
 __device__ __forceinline__ void fill_dwords(uint32_t *__restrict__ base, uint32_t start, uint32_t end, uint32_t value, int lane) {
     const uint32_t a0 = (start + 3u) & ~3u;  // first 16-B aligned dword
     const uint32_t head_end = a0 < end ? a0 : end;
     if (start + lane < head_end) base[start + lane] = value;
     if (a0 >= end) return;
     const uint32_t a1 = end & ~3u;
-    uint4 *b4 = reinterpret_cast<uint4 *>(base);
-    const uint4 v4 = make_uint4(value, value, value, value);
-    for (uint32_t i = (a0 >> 2) + lane; i < (a1 >> 2); i += 64) b4[i] = v4;
+    u32x4 *b4 = reinterpret_cast<u32x4 *>(base);
+    const u32x4 v4 = {value, value, value, value};
+    for (uint32_t i = (a0 >> 2) + lane; i < (a1 >> 2); i += 64) {
+        if constexpr (NT) __builtin_nontemporal_store(v4, &b4[i]);  // streamed once, never re-read on chip
+        else b4[i] = v4;
+    }
     if (a1 + lane < end) base[a1 + lane] = value;
 }
 
@@ -399,6 +405,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
 // Constant tails of the rows the walk certified: slots [n, M) of the four row arrays.  Pure
 // streaming stores (16 B per lane), one wave per ray per pass, XCD-banded like the walk so a
 // row's lines are written by the XCD whose L2 already holds the row's segment lines.
+template <bool NT>
 __global__ __launch_bounds__(256) void k_fill_tails(size_t num_rays, uint32_t M, const uint32_t *__restrict__ walk_n,
                                                     uint32_t *__restrict__ out_cells, float *__restrict__ out_bary,
                                                     float *__restrict__ out_dist, uint32_t *__restrict__ out_verts) {
@@ -413,21 +420,25 @@ __global__ __launch_bounds__(256) void k_fill_tails(size_t num_rays, uint32_t M,
     for (size_t r = r0; r < r1; ++r) {
         const uint32_t n = walk_n[r];
         if (n == TN_EMPTY) continue;  // re-traced by the general kernel, which writes the whole row
-        fill_dwords(out_cells + r * M, n, M, TN_EMPTY, lane);
-        fill_dwords(reinterpret_cast<uint32_t *>(out_dist + r * M * 2), 2 * n, 2 * M, 0u, lane);
-        fill_dwords(reinterpret_cast<uint32_t *>(out_bary + r * M * 6), 6 * n, 6 * M, 0u, lane);
-        if (out_verts) fill_dwords(out_verts + r * M * 4, 4 * n, 4 * M, TN_EMPTY, lane);
+        fill_dwords<NT>(out_cells + r * M, n, M, TN_EMPTY, lane);
+        fill_dwords<NT>(reinterpret_cast<uint32_t *>(out_dist + r * M * 2), 2 * n, 2 * M, 0u, lane);
+        fill_dwords<NT>(reinterpret_cast<uint32_t *>(out_bary + r * M * 6), 6 * n, 6 * M, 0u, lane);
+        if (out_verts) fill_dwords<NT>(out_verts + r * M * 4, 4 * n, 4 * M, TN_EMPTY, lane);
     }
 }
 
 void launch_fill_tails(size_t num_rays, uint32_t M, const uint32_t *walk_n, uint32_t *out_cells, float *out_bary,
-                       float *out_dist, uint32_t *out_verts, hipStream_t stream) {
+                       float *out_dist, uint32_t *out_verts, hipStream_t stream, bool nontemporal) {
     if (num_rays == 0) return;
     size_t blocks = (num_rays + 3) / 4;           // >= one ray per wave
     if (blocks > 256 * 8) blocks = 256 * 8;       // 8 blocks (32 waves) per CU
     blocks = (blocks + 7) & ~(size_t)7;
-    hipLaunchKernelGGL(k_fill_tails, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, walk_n, out_cells,
-                       out_bary, out_dist, out_verts);
+    if (nontemporal)
+        hipLaunchKernelGGL(k_fill_tails<true>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, walk_n, out_cells,
+                           out_bary, out_dist, out_verts);
+    else
+        hipLaunchKernelGGL(k_fill_tails<false>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, walk_n, out_cells,
+                           out_bary, out_dist, out_verts);
 }
 
 void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
@@ -436,9 +447,9 @@ void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
     // grid padded so that both remaps (runs of XCD_GROUP blocks / one band per XCD) are bijections
     const uint32_t unit = 8 * ((p.debug & 8u) ? (nblk + 7) / 8 : XCD_GROUP);
     const uint32_t grid = (nblk + unit - 1) / unit * unit;
-    // small launches are latency-bound (one wave per SIMD at best): shortest dependent chain;
-    // large launches are throughput-bound: fewer registers, more waves per SIMD
-    const bool prefetch = (p.debug & 32u) ? true : ((p.debug & 64u) ? false : p.t.num_items < 32768);
+    // the early-prefetch variant (shortest dependent chain per step) measured faster at every size
+    // (4096 rays: -5 %, 640k rays: -2 %); debug bit 64 selects the late-load variant for A/B runs
+    const bool prefetch = !(p.debug & 64u);
     if (prefetch) hipLaunchKernelGGL(k_trace_walk<true>, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
     else hipLaunchKernelGGL(k_trace_walk<false>, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
 }
