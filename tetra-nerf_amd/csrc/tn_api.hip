@@ -35,16 +35,15 @@ struct DevBuf {
 
 struct DevWideBvh {
     DevBuf<float> leaf_tri, boxes;
-    DevBuf<uint32_t> leaf_id;
+    DevBuf<uint32_t> leaf_id, child;
     WideBvh view{};
     void upload(const HostWideBvh &h, float scene_max) {
         leaf_tri.upload(h.leaf_tri);
         leaf_id.upload(h.leaf_id);
         boxes.upload(h.boxes);
-        view.leaf_tri = leaf_tri.p; view.leaf_id = leaf_id.p; view.boxes = boxes.p;
-        for (int i = 0; i < MAX_LEVELS; ++i) { view.level_off[i] = h.level_off[i]; view.level_cnt[i] = h.level_cnt[i]; }
-        view.top_level = h.top_level;
-        view.leaf_size = h.leaf_size;
+        child.upload(h.child);
+        view.leaf_tri = leaf_tri.p; view.leaf_id = leaf_id.p; view.boxes = boxes.p; view.child = child.p;
+        view.n_nodes = (uint32_t)(h.child.size() / WIDE);
         view.scene_max = scene_max;
     }
 };
@@ -61,16 +60,16 @@ struct tn_tracer {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chunk[kEvents] = {};
     size_t chunk_rays = 65536;           // rays per walk launch when pipelining
     int mode = 1;                        // launch structure of the walk path (see tn_trace_rays)
-    int hull_leaf = tn::HULL_LEAF;       // triangles per hull-tree leaf (takes effect at load_tetrahedra)
     tn::DevBuf<tn::TetRec> tets;
     tn::DevBuf<float> hull_nodes, hull_tris;
-    tn::DevWideBvh bvh, hull;
+    tn::DevWideBvh bvh;
     tn::DevBuf<unsigned long long> stats;
     size_t last_num_rays = 0;
     int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
     size_t walk_min_rays = 16384;
     bool last_walk = false;
     uint32_t debug = 0;
+    uint32_t gdebug = 0;
     bool loaded = false;
     hipStream_t last_stream = nullptr;
 };
@@ -192,9 +191,8 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
             all[f] = (uint32_t)f;
             if (t->host.face_tets[2 * f + 1] == TN_EMPTY) hull_ids.push_back((uint32_t)f);
         }
-        tn::HostWideBvh hb, hh;
+        tn::HostWideBvh hb;
         tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), all, hb);
-        tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), hull_ids, hh, t->hull_leaf);
         std::vector<tn::TetRec> recs;
         std::vector<uint32_t> rec_of_tet;
         tn::build_tet_records(T, hcells.data(), hxyz.data(), t->host, recs, rec_of_tet);
@@ -204,7 +202,6 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         t->faces.upload(t->host.faces);
         t->face_tets.upload(t->host.face_tets);
         t->bvh.upload(hb, smax);
-        t->hull.upload(hh, smax);
         t->tets.upload(recs);
         t->hull_nodes.upload(hth.nodes);
         t->hull_tris.upload(hth.tris);
@@ -213,7 +210,7 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         m.xyz = xyz; m.cells = cells;
         m.V = (uint32_t)V; m.T = (uint32_t)T; m.F = (uint32_t)F;
         m.faces = t->faces.p; m.face_tets = t->face_tets.p;
-        m.bvh = t->bvh.view; m.hull = t->hull.view;
+        m.bvh = t->bvh.view;
         m.tets = t->tets.p; m.n_hull = (uint32_t)hull_ids.size();
         m.hull_nodes = reinterpret_cast<const float4 *>(t->hull_nodes.p);
         m.hull_tris = reinterpret_cast<const float4 *>(t->hull_tris.p);
@@ -243,6 +240,7 @@ static tn::TraceParams make_params(tn_tracer *t, size_t R, uint32_t M, const flo
     p.out_num = num; p.out_cells = cells; p.out_bary = bary; p.out_dist = dist; p.out_verts = verts;
     p.M = M; p.num_items = R; p.ray_list = nullptr;
     p.stats = t->stats.p;
+    p.gdebug = t->gdebug;
     return p;
 }
 
@@ -268,7 +266,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
         // wavefront per ray through the wide BVH (measured: 4096 rays, 300k tets: 1.5 ms vs 0.75 ms),
         // so the walk is used from `walk_min_rays` on (use_walk == 2 forces it for any size).
         const bool walk = t->use_walk && (R >= t->walk_min_rays || t->use_walk == 2) && M >= 4 &&
-                          t->mesh.hull.top_level <= 3 && t->mesh.n_hull > 0;
+                          t->mesh.n_hull > 0;
         t->last_walk = walk;
         if (walk) {
             // 1. adjacency walk for every ray (segments + counts), in chunks on `stream`;
@@ -300,7 +298,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                                   visited + r0 * M, bary + r0 * M * 6, dist + r0 * M * 2,
                                   verts ? verts + r0 * M * 4 : nullptr);
                 w.tets = t->mesh.tets;
-                w.hull = t->mesh.hull;
+                w.scene_max = t->mesh.bvh.scene_max;
                 w.hull_nodes = t->mesh.hull_nodes;
                 w.hull_tris = t->mesh.hull_tris;
                 w.n_hull_nodes = t->mesh.n_hull_nodes;
@@ -399,8 +397,8 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         if (name && std::strcmp(name, "walk") == 0) t->use_walk = value < 0 ? 0 : (value > 2 ? 2 : value);
         else if (name && std::strcmp(name, "walk_min_rays") == 0) t->walk_min_rays = value < 0 ? 0 : (size_t)value;
         else if (name && std::strcmp(name, "debug") == 0) t->debug = (uint32_t)value;
+        else if (name && std::strcmp(name, "gdebug") == 0) t->gdebug = (uint32_t)value;
         else if (name && std::strcmp(name, "mode") == 0) t->mode = value;
-        else if (name && std::strcmp(name, "hull_leaf") == 0) t->hull_leaf = value < 1 ? 1 : (value > 64 ? 64 : value);
         else if (name && std::strcmp(name, "chunk_rays") == 0) t->chunk_rays = value >= 256 ? (size_t)value : 256;
         else throw tn::Error(std::string("unknown option ") + (name ? name : "(null)"));
     });

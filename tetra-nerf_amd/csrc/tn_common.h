@@ -28,22 +28,18 @@ struct Error : std::runtime_error {
     } while (0)
 
 constexpr int WIDE = 64;            // BVH branching factor = wavefront width
-constexpr int MAX_LEVELS = 8;       // 64^8 faces is far beyond uint32
 constexpr int STACK_CAP = 64 * 6;   // traversal stack entries per wave
-constexpr int HULL_LEAF = 8;        // triangles per leaf of the hull tree (walked wave-uniformly)
 
-// Wide (64-ary) BVH over the unique faces, complete tree over Morton-ordered faces.
-// Level 0 = leaves (64 triangles each, vertices stored inline SoA so a wave reads a
-// leaf with 10 coalesced 256-B loads); level l>0 node k has children 64k..64k+63 of
-// level l-1, boxes stored SoA [6][64] floats.
+// Wide (64-ary) BVH over the unique faces.  Built by recursive median splits of the face centroids
+// (compact leaves of 33..64 triangles) and collapsed to 64-wide internal nodes.  Leaves store the
+// triangle vertices inline, SoA, so a wave reads a leaf with 10 coalesced 256-B loads; an internal node
+// is 6 SoA box rows + 1 row of child references (bit 31 = leaf index, TN_EMPTY = no child).
 struct WideBvh {
     const float *leaf_tri;      // [n_leaves][9][64]  v0.xyz v1.xyz v2.xyz
     const uint32_t *leaf_id;    // [n_leaves][64]     face id or TN_EMPTY
-    const float *boxes;         // [n_internal][6][64] lo.xyz hi.xyz
-    uint32_t level_off[MAX_LEVELS];  // node offset of each internal level into `boxes`
-    uint32_t level_cnt[MAX_LEVELS];  // number of nodes of each level (level 0 = leaves)
-    int top_level;              // the root is node 0 of this level (>= 1)
-    int leaf_size;              // triangles per leaf (64 for the all-faces tree, smaller for the hull)
+    const float *boxes;         // [n_nodes][6][64]   lo.xyz hi.xyz of the children
+    const uint32_t *child;      // [n_nodes][64]      child reference
+    uint32_t n_nodes;           // node 0 is the root
     float scene_max;            // max |coordinate| over the mesh vertices
 };
 
@@ -80,7 +76,6 @@ struct DeviceMesh {
     WideBvh bvh{};                  // over all faces
     // adjacency walk
     TetRec *tets = nullptr;         // [T]
-    WideBvh hull{};                 // over hull faces only (leaf_id = global face id)
     const float4 *hull_nodes = nullptr;  // threaded binary BVH over the hull faces (2 float4 per node)
     const float4 *hull_tris = nullptr;   // 3 float4 per hull face
     uint32_t n_hull_nodes = 0;
@@ -98,10 +93,7 @@ struct HostWideBvh {
     std::vector<float> leaf_tri;
     std::vector<uint32_t> leaf_id;
     std::vector<float> boxes;
-    uint32_t level_off[MAX_LEVELS] = {0};
-    uint32_t level_cnt[MAX_LEVELS] = {0};
-    int top_level = 1;
-    int leaf_size = WIDE;
+    std::vector<uint32_t> child;
 };
 
 struct HostHullBvh {
@@ -118,7 +110,7 @@ void build_hull_threaded(const float *xyz, const uint32_t *faces, const uint32_t
 void build_face_table(size_t T, const uint32_t *cells, HostMesh &out);
 // wide BVH over the faces listed in `ids` (global face ids)
 void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<uint32_t> &ids,
-                    HostWideBvh &out, int leaf_size = WIDE);
+                    HostWideBvh &out);
 // adjacency records
 void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const HostMesh &hm,
                        std::vector<TetRec> &out, std::vector<uint32_t> &rec_of_tet);

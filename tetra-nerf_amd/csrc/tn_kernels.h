@@ -20,6 +20,7 @@ struct TraceParams {
     const uint32_t *ray_list;  // optional indirection: item -> ray index
     const uint32_t *item_count; // optional device-side item count (overrides num_items in-kernel)
     unsigned long long *stats; // [4] device counters or null
+    uint32_t gdebug;           // ablation of the general kernel (bench only): 1 stop after traversal, 2 skip sort
 };
 
 // general all-hits path, one wavefront per ray (tn_trace_general.hip)
@@ -32,7 +33,7 @@ size_t trace_general_smem_bytes(uint32_t M);
 struct WalkParams {
     TraceParams t;
     const TetRec *tets;
-    WideBvh hull;              // wave-uniform hull tree (debug & 128 only)
+    float scene_max;           // max |coordinate| of the mesh (box padding)
     const float4 *hull_nodes;  // threaded per-lane hull tree
     const float4 *hull_tris;
     uint32_t n_hull_nodes;

@@ -90,91 +90,120 @@ void build_face_table(size_t T, const uint32_t *cells, HostMesh &out) {
 }
 
 void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<uint32_t> &ids,
-                    HostWideBvh &out, int leaf_size) {
-    const int LS = leaf_size;
-    out.leaf_size = leaf_size;
+                    HostWideBvh &out) {
     const size_t n = ids.size();
-    // centroid bounds
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    std::vector<float> cent(3 * n);
+    out.leaf_tri.clear(); out.leaf_id.clear(); out.boxes.clear(); out.child.clear();
+    // per-face boxes and centroids
+    std::vector<float> fb(6 * n), cen(3 * n);
     for (size_t i = 0; i < n; ++i) {
         const uint32_t *f = faces + 3 * (size_t)ids[i];
         for (int k = 0; k < 3; ++k) {
-            const float c = (xyz[3 * (size_t)f[0] + k] + xyz[3 * (size_t)f[1] + k] + xyz[3 * (size_t)f[2] + k]) * (1.0f / 3.0f);
-            cent[3 * i + k] = c;
-            lo[k] = std::min(lo[k], c); hi[k] = std::max(hi[k], c);
+            const float a = xyz[3 * (size_t)f[0] + k], b = xyz[3 * (size_t)f[1] + k], c = xyz[3 * (size_t)f[2] + k];
+            fb[6 * i + k] = std::min(a, std::min(b, c));
+            fb[6 * i + 3 + k] = std::max(a, std::max(b, c));
+            cen[3 * i + k] = (a + b + c) * (1.0f / 3.0f);
         }
     }
-    std::vector<std::pair<uint64_t, uint32_t>> order(n);
-    for (size_t i = 0; i < n; ++i) {
-        uint64_t code = 0;
-        for (int k = 0; k < 3; ++k) {
-            const double ext = (double)hi[k] - (double)lo[k];
-            double u = ext > 0 ? ((double)cent[3 * i + k] - lo[k]) / ext : 0.0;
-            uint64_t q = (uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0));
-            code |= spread21(q) << k;
-        }
-        order[i] = {code, (uint32_t)i};
-    }
-    std::sort(order.begin(), order.end());
-
-    const size_t n_leaves = std::max<size_t>(1, (n + LS - 1) / LS);
-    out.leaf_tri.assign(n_leaves * 9 * LS, 0.0f);
-    out.leaf_id.assign(n_leaves * LS, TN_EMPTY);
-    // boxes of the current level (flat lo.xyz hi.xyz per node)
-    std::vector<float> cur(6 * n_leaves);
-    for (size_t l = 0; l < n_leaves; ++l) {
-        float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int i = 0; i < LS; ++i) {
-            const size_t s = l * LS + i;
-            if (s >= n) break;
-            const uint32_t fid = ids[order[s].second];
-            const uint32_t *f = faces + 3 * (size_t)fid;
-            out.leaf_id[l * LS + i] = fid;
-            for (int v = 0; v < 3; ++v)
-                for (int k = 0; k < 3; ++k) {
-                    const float x = xyz[3 * (size_t)f[v] + k];
-                    out.leaf_tri[(l * 9 + v * 3 + k) * LS + i] = x;
-                    blo[k] = std::min(blo[k], x); bhi[k] = std::max(bhi[k], x);
-                }
-        }
-        for (int k = 0; k < 3; ++k) { cur[6 * l + k] = blo[k]; cur[6 * l + 3 + k] = bhi[k]; }
-    }
-    out.boxes.clear();
-    out.level_cnt[0] = (uint32_t)n_leaves;
-    size_t count = n_leaves;
-    int level = 0;
-    size_t node_off = 0;
-    do {
-        ++level;
-        if (level >= MAX_LEVELS) throw Error("mesh too large for the wide BVH");
-        const size_t parents = (count + WIDE - 1) / WIDE;
-        out.level_off[level] = (uint32_t)node_off;
-        out.level_cnt[level] = (uint32_t)parents;
-        out.boxes.resize((node_off + parents) * 6 * WIDE);
-        std::vector<float> next(6 * parents);
-        for (size_t p = 0; p < parents; ++p) {
-            float *b = out.boxes.data() + (node_off + p) * 6 * WIDE;
-            float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (int i = 0; i < WIDE; ++i) {
-                const size_t c = p * WIDE + i;
-                for (int k = 0; k < 3; ++k) {
-                    // empty child: lo=+inf, hi=-inf never passes the slab test
-                    b[k * WIDE + i] = c < count ? cur[6 * c + k] : INFINITY;
-                    b[(3 + k) * WIDE + i] = c < count ? cur[6 * c + 3 + k] : -INFINITY;
-                    if (c < count) {
-                        blo[k] = std::min(blo[k], cur[6 * c + k]);
-                        bhi[k] = std::max(bhi[k], cur[6 * c + 3 + k]);
-                    }
-                }
+    // 1. binary tree by median splits along the widest centroid axis, leaves of <= 64 faces
+    struct BNode { float lo[3], hi[3]; uint32_t first, count; int left, right; };
+    std::vector<BNode> bn;
+    bn.reserve(n / 16 + 16);
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::function<int(uint32_t, uint32_t)> build = [&](uint32_t first, uint32_t count) -> int {
+        BNode nd;
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < 3; ++k) { nd.lo[k] = INFINITY; nd.hi[k] = -INFINITY; }
+        for (uint32_t i = first; i < first + count; ++i) {
+            const uint32_t f = order[i];
+            for (int k = 0; k < 3; ++k) {
+                nd.lo[k] = std::min(nd.lo[k], fb[6 * (size_t)f + k]); nd.hi[k] = std::max(nd.hi[k], fb[6 * (size_t)f + 3 + k]);
+                clo[k] = std::min(clo[k], cen[3 * (size_t)f + k]); chi[k] = std::max(chi[k], cen[3 * (size_t)f + k]);
             }
-            for (int k = 0; k < 3; ++k) { next[6 * p + k] = blo[k]; next[6 * p + 3 + k] = bhi[k]; }
         }
-        node_off += parents;
-        cur.swap(next);
-        count = parents;
-    } while (count > 1);
-    out.top_level = level;
+        nd.first = first; nd.count = count; nd.left = nd.right = -1;
+        const int me = (int)bn.size();
+        bn.push_back(nd);
+        if (count > (uint32_t)WIDE) {
+            int ax = 0;
+            if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
+            if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+            const uint32_t half = count / 2;
+            std::nth_element(order.begin() + first, order.begin() + first + half, order.begin() + first + count,
+                             [&](uint32_t a, uint32_t b) { return cen[3 * (size_t)a + ax] < cen[3 * (size_t)b + ax]; });
+            const int l = build(first, half);
+            const int r = build(first + half, count - half);
+            bn[me].left = l; bn[me].right = r;
+        }
+        return me;
+    };
+    const int root = n ? build(0, (uint32_t)n) : -1;
+
+    // 2. leaves -> SoA triangle blocks
+    std::vector<int> leaf_of(bn.size(), -1);
+    for (size_t b = 0; b < bn.size(); ++b) {
+        if (bn[b].left >= 0) continue;
+        const size_t l = out.leaf_id.size() / WIDE;
+        leaf_of[b] = (int)l;
+        out.leaf_tri.resize((l + 1) * 9 * WIDE, 0.0f);
+        out.leaf_id.resize((l + 1) * WIDE, TN_EMPTY);
+        for (uint32_t i = 0; i < bn[b].count; ++i) {
+            const uint32_t fid = ids[order[bn[b].first + i]];
+            const uint32_t *f = faces + 3 * (size_t)fid;
+            out.leaf_id[l * WIDE + i] = fid;
+            for (int v = 0; v < 3; ++v)
+                for (int k = 0; k < 3; ++k) out.leaf_tri[(l * 9 + v * 3 + k) * WIDE + i] = xyz[3 * (size_t)f[v] + k];
+        }
+    }
+    if (out.leaf_id.empty()) { out.leaf_tri.assign(9 * WIDE, 0.0f); out.leaf_id.assign(WIDE, TN_EMPTY); }
+
+    // 3. collapse to 64-wide nodes: open the child with the largest box until 64 children (or only leaves)
+    auto area = [&](int b) {
+        const float dx = bn[b].hi[0] - bn[b].lo[0], dy = bn[b].hi[1] - bn[b].lo[1], dz = bn[b].hi[2] - bn[b].lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<std::pair<int, uint32_t>> todo;  // (binary subtree root, wide node index)
+    auto new_node = [&]() -> uint32_t {
+        const uint32_t id = (uint32_t)(out.child.size() / WIDE);
+        out.child.resize((size_t)(id + 1) * WIDE, TN_EMPTY);
+        out.boxes.resize((size_t)(id + 1) * 6 * WIDE, 0.0f);
+        for (int k = 0; k < 3; ++k)
+            for (int i = 0; i < WIDE; ++i) { out.boxes[((size_t)id * 6 + k) * WIDE + i] = INFINITY; out.boxes[((size_t)id * 6 + 3 + k) * WIDE + i] = -INFINITY; }
+        return id;
+    };
+    const uint32_t root_wide = new_node();
+    (void)root_wide;
+    if (root >= 0) todo.push_back({root, 0u});
+    while (!todo.empty()) {
+        const auto [sub, wid] = todo.back();
+        todo.pop_back();
+        std::vector<int> kids;
+        if (bn[sub].left < 0) kids.push_back(sub);
+        else { kids.push_back(bn[sub].left); kids.push_back(bn[sub].right); }
+        for (;;) {
+            int best = -1;
+            float best_a = -1.f;
+            for (size_t i = 0; i < kids.size(); ++i)
+                if (bn[kids[i]].left >= 0 && area(kids[i]) > best_a) { best_a = area(kids[i]); best = (int)i; }
+            if (best < 0 || kids.size() >= (size_t)WIDE) break;
+            const int k = kids[best];
+            kids[best] = bn[k].left;
+            kids.push_back(bn[k].right);
+        }
+        for (size_t i = 0; i < kids.size(); ++i) {
+            const int k = kids[i];
+            for (int a = 0; a < 3; ++a) {
+                out.boxes[((size_t)wid * 6 + a) * WIDE + i] = bn[k].lo[a];
+                out.boxes[((size_t)wid * 6 + 3 + a) * WIDE + i] = bn[k].hi[a];
+            }
+            if (bn[k].left < 0) out.child[(size_t)wid * WIDE + i] = 0x80000000u | (uint32_t)leaf_of[k];
+            else {
+                const uint32_t cw = new_node();
+                out.child[(size_t)wid * WIDE + i] = cw;
+                todo.push_back({k, cw});
+            }
+        }
+    }
 }
 
 void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const HostMesh &hm,

@@ -29,16 +29,18 @@ struct WaveSmem {
     uint2 *hft;      // [M]   face -> tets of the sorted hit
     uint32_t *stack; // [STACK_CAP]
     uint8_t *mark;   // [M]
+    uint8_t *emitf;  // [M]   slot j emits the segment (slot j, slot j+1)
 };
 
 __device__ __forceinline__ WaveSmem carve(char *smem, uint32_t M) {
     WaveSmem s;
     s.key = reinterpret_cast<uint64_t *>(smem);
     s.hft = reinterpret_cast<uint2 *>(s.key + M);
-    s.hu = reinterpret_cast<float *>(s.hft + M);
+    s.hu = reinterpret_cast<float *>(s.hft + (M < 32 ? 32 : M));  // hft doubles as the leaf list (>= 64 entries)
     s.hv = s.hu + M;
     s.stack = reinterpret_cast<uint32_t *>(s.hv + M);
     s.mark = reinterpret_cast<uint8_t *>(s.stack + STACK_CAP);
+    s.emitf = s.mark + M;
     return s;
 }
 
@@ -92,45 +94,29 @@ __device__ void postprocess_and_write(const WaveSmem &s, uint32_t nh, uint32_t M
     }
     const bool clean = (__ballot(bad) == 0ull);
 
-    uint32_t nseg = 0;
+    // Decide which slots j emit the segment (slot j, slot j+1): in parallel for a clean chain, else by
+    // the literal serial algorithm on lane 0.  The serial pass touches LDS only: the reference's swap
+    // step moves a matched face to slot j+1 and never touches slots <= j again, so once the pass is over
+    // every emitted segment is exactly (final slot j, final slot j+1) and the row data can be produced by
+    // all lanes in parallel below.
     if (clean) {
-        for (uint32_t base = 0; base + 1 < nh; base += 64) {
-            const uint32_t j = base + lane;
-            bool emit = false;
-            float t0 = 0.f, t1 = 0.f;
-            uint32_t cell = TN_EMPTY;
+        for (uint32_t j = lane; j < nh; j += 64) {
+            bool em = false;
             if (j + 1 < nh) {
-                t0 = __uint_as_float((uint32_t)(s.key[j] >> 32));
-                t1 = __uint_as_float((uint32_t)(s.key[j + 1] >> 32));
-                common_tet(s.hft[j], s.hft[j + 1], cell);
-                emit = fabsf(t0 - t1) >= TN_EPS;
+                const float t0 = __uint_as_float((uint32_t)(s.key[j] >> 32));
+                const float t1 = __uint_as_float((uint32_t)(s.key[j + 1] >> 32));
+                em = fabsf(t0 - t1) >= TN_EPS;
             }
-            const uint64_t m = __ballot(emit);
-            if (emit) {
-                const uint32_t slot = nseg + __popcll(m & lanemask_lt());
-                const uint32_t f0 = (uint32_t)s.key[j], f1 = (uint32_t)s.key[j + 1];
-                const uint32_t id1[3] = {faces[3 * (size_t)f0], faces[3 * (size_t)f0 + 1], faces[3 * (size_t)f0 + 2]};
-                const uint32_t id2[3] = {faces[3 * (size_t)f1], faces[3 * (size_t)f1 + 1], faces[3 * (size_t)f1 + 2]};
-                uint32_t vi[4];
-                float b1[3], b2[3];
-                combine_indices(id1, id2, s.hu[j], s.hv[j], s.hu[j + 1], s.hv[j + 1], vi, b1, b2);
-                out_cells[slot] = cell;
-                *reinterpret_cast<float2 *>(out_dist + 2 * (size_t)slot) = make_float2(t0, t1);
-                float2 *bp = reinterpret_cast<float2 *>(out_bary + 6 * (size_t)slot);
-                bp[0] = make_float2(b1[0], b1[1]);
-                bp[1] = make_float2(b1[2], b2[0]);
-                bp[2] = make_float2(b2[1], b2[2]);
-                if (out_verts) *reinterpret_cast<uint4 *>(out_verts + 4 * (size_t)slot) = make_uint4(vi[0], vi[1], vi[2], vi[3]);
-            }
-            nseg += __popcll(m);
+            s.emitf[j] = em ? 1 : 0;
         }
     } else {
-        // literal serial restatement (optix_trace_rays.cu:124-257) on lane 0.
+        for (uint32_t j = lane; j < nh; j += 64) s.emitf[j] = 0;
+        wave_sync();
         if (lane == 0) {
             if (stats) atomicAdd(&stats[2], 1ull);
             auto T = [&](uint32_t j) { return __uint_as_float((uint32_t)(s.key[j] >> 32)); };
             auto ID = [&](uint32_t j) { return (uint32_t)s.key[j]; };
-            // phase 1
+            // phase 1 (optix_trace_rays.cu:124-159)
             for (uint32_t j = 0; j + 1 < nh; ++j) {
                 if (ID(j) == TN_EMPTY) continue;
                 const float dn = T(j);
@@ -146,8 +132,7 @@ __device__ void postprocess_and_write(const WaveSmem &s, uint32_t nh, uint32_t M
                 if (clear_self && s.mark[j]) s.key[j] = (s.key[j] & 0xFFFFFFFF00000000ull) | TN_EMPTY;
                 s.mark[j] = 0;
             }
-            // phase 2
-            uint32_t jc = 0;
+            // phase 2 (optix_trace_rays.cu:188-257): pairing decisions + swaps only
             for (uint32_t j = 0; j < nh; ++j) {
                 if (ID(j) == TN_EMPTY) continue;
                 const uint2 orig = s.hft[j];
@@ -157,19 +142,7 @@ __device__ void postprocess_and_write(const WaveSmem &s, uint32_t nh, uint32_t M
                     if (ID(j + off) == TN_EMPTY) continue;
                     uint32_t cell;
                     if (common_tet(orig, s.hft[j + off], cell)) {
-                        if (fabsf(T(j) - T(j + off)) >= TN_EPS) {
-                            const uint32_t f0 = ID(j), f1 = ID(j + off);
-                            const uint32_t id1[3] = {faces[3 * (size_t)f0], faces[3 * (size_t)f0 + 1], faces[3 * (size_t)f0 + 2]};
-                            const uint32_t id2[3] = {faces[3 * (size_t)f1], faces[3 * (size_t)f1 + 1], faces[3 * (size_t)f1 + 2]};
-                            uint32_t vi[4];
-                            float b1[3], b2[3];
-                            combine_indices(id1, id2, s.hu[j], s.hv[j], s.hu[j + off], s.hv[j + off], vi, b1, b2);
-                            out_cells[jc] = cell;
-                            out_dist[2 * (size_t)jc] = T(j); out_dist[2 * (size_t)jc + 1] = T(j + off);
-                            for (int k = 0; k < 3; ++k) { out_bary[6 * (size_t)jc + k] = b1[k]; out_bary[6 * (size_t)jc + 3 + k] = b2[k]; }
-                            if (out_verts) for (int k = 0; k < 4; ++k) out_verts[4 * (size_t)jc + k] = vi[k];
-                            jc++;
-                        }
+                        if (fabsf(T(j) - T(j + off)) >= TN_EPS) s.emitf[j] = 1;
                         if (off > 1) {
                             // swap(dl, first bary record, id) of slots j+off and j+1 (:244-250)
                             const uint64_t k0 = s.key[j + off]; s.key[j + off] = s.key[j + 1]; s.key[j + 1] = k0;
@@ -184,9 +157,37 @@ __device__ void postprocess_and_write(const WaveSmem &s, uint32_t nh, uint32_t M
                     real_off++;
                 }
             }
-            nseg = jc;
         }
-        nseg = __shfl(nseg, 0);
+    }
+    wave_sync();
+
+    // parallel emission of the flagged pairs (slot j, slot j+1), in slot order
+    uint32_t nseg = 0;
+    for (uint32_t base = 0; base + 1 < nh; base += 64) {
+        const uint32_t j = base + lane;
+        const bool emit = j + 1 < nh && s.emitf[j] != 0;
+        const uint64_t m = __ballot(emit);
+        if (emit) {
+            const uint32_t slot = nseg + __popcll(m & lanemask_lt());
+            const float t0 = __uint_as_float((uint32_t)(s.key[j] >> 32));
+            const float t1 = __uint_as_float((uint32_t)(s.key[j + 1] >> 32));
+            uint32_t cell = TN_EMPTY;
+            common_tet(s.hft[j], s.hft[j + 1], cell);
+            const uint32_t f0 = (uint32_t)s.key[j], f1 = (uint32_t)s.key[j + 1];
+            const uint32_t id1[3] = {faces[3 * (size_t)f0], faces[3 * (size_t)f0 + 1], faces[3 * (size_t)f0 + 2]};
+            const uint32_t id2[3] = {faces[3 * (size_t)f1], faces[3 * (size_t)f1 + 1], faces[3 * (size_t)f1 + 2]};
+            uint32_t vi[4];
+            float b1[3], b2[3];
+            combine_indices(id1, id2, s.hu[j], s.hv[j], s.hu[j + 1], s.hv[j + 1], vi, b1, b2);
+            out_cells[slot] = cell;
+            *reinterpret_cast<float2 *>(out_dist + 2 * (size_t)slot) = make_float2(t0, t1);
+            float2 *bp = reinterpret_cast<float2 *>(out_bary + 6 * (size_t)slot);
+            bp[0] = make_float2(b1[0], b1[1]);
+            bp[1] = make_float2(b1[2], b2[0]);
+            bp[2] = make_float2(b2[1], b2[2]);
+            if (out_verts) *reinterpret_cast<uint4 *>(out_verts + 4 * (size_t)slot) = make_uint4(vi[0], vi[1], vi[2], vi[3]);
+        }
+        nseg += __popcll(m);
     }
 
     // tail fill: every remaining byte of the rows, coalesced
@@ -243,65 +244,102 @@ __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
         const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.bvh.scene_max);
 
         uint32_t nh = 0;      // hits stored (wave-uniform)
-        uint32_t sp = 1;      // stack pointer (wave-uniform)
         bool overflow = false;
-        if (lane == 0) s.stack[0] = ((uint32_t)p.bvh.top_level << 28);
-        wave_sync();
-        while (sp > 0) {
-            const uint32_t e = s.stack[sp - 1];
-            sp--;
-            const uint32_t level = e >> 28, idx = e & 0x0FFFFFFFu;
-            wave_sync();  // everyone has read the top before it can be overwritten
-            if (level > 0) {
-                const float *b = p.bvh.boxes + ((size_t)p.bvh.level_off[level] + idx) * (6 * WIDE);
-                const bool valid = idx * WIDE + lane < p.bvh.level_cnt[level - 1];
-                const bool hit = valid && line_box(ox, oy, oz, ix, iy, iz, b[lane], b[WIDE + lane], b[2 * WIDE + lane],
-                                                   b[3 * WIDE + lane], b[4 * WIDE + lane], b[5 * WIDE + lane], pad);
-                const uint64_t m = __ballot(hit);
-                if (hit) s.stack[sp + __popcll(m & lanemask_lt())] = ((level - 1) << 28) | (idx * WIDE + lane);
-                sp += __popcll(m);
-            } else {
-                const float *tr = p.bvh.leaf_tri + (size_t)idx * (9 * WIDE);
-                const uint32_t fid = p.bvh.leaf_id[(size_t)idx * WIDE + lane];
-                const SV A = shear(rp, tr[lane], tr[WIDE + lane], tr[2 * WIDE + lane]);
-                const SV B = shear(rp, tr[3 * WIDE + lane], tr[4 * WIDE + lane], tr[5 * WIDE + lane]);
-                const SV C = shear(rp, tr[6 * WIDE + lane], tr[7 * WIDE + lane], tr[8 * WIDE + lane]);
-                float t = 0.f, u = 0.f, v = 0.f;
-                const bool hit = (fid != TN_EMPTY) && tri_hit_sv(A, B, C, t, u, v);
-                const uint64_t m = __ballot(hit);
-                const uint32_t c = __popcll(m);
-                if (c) {
-                    const uint64_t k = ((uint64_t)__float_as_uint(t) << 32) | fid;
-                    if (nh + c <= cap) {
-                        if (hit) {
-                            const uint32_t slot = nh + __popcll(m & lanemask_lt());
-                            s.key[slot] = k; s.hu[slot] = u; s.hv[slot] = v;
-                        }
-                        nh += c;
-                    } else {
-                        overflow = true;
-                        uint64_t mm = m;
-                        while (mm) {
-                            const int src = __ffsll((unsigned long long)mm) - 1;
-                            mm &= mm - 1;
-                            const uint64_t ks = __shfl(k, src);
-                            const float us = __shfl(u, src), vs = __shfl(v, src);
-                            if (nh < cap) {
-                                if (lane == 0) { s.key[nh] = ks; s.hu[nh] = us; s.hv[nh] = vs; }
-                                nh++;
-                                wave_sync();
-                            } else {
-                                insert_overflow(s, cap, ks, us, vs, lane);
-                            }
+
+        // One leaf: 64 triangles against the ray, hits appended to the LDS hit arrays.
+        auto test_leaf = [&](float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2,
+                             uint32_t fid) {
+            const SV A = shear(rp, a0, a1, a2), B = shear(rp, b0, b1, b2), C = shear(rp, c0, c1, c2);
+            float t = 0.f, u = 0.f, v = 0.f;
+            const bool hit = (fid != TN_EMPTY) && tri_hit_sv(A, B, C, t, u, v);
+            const uint64_t m = __ballot(hit);
+            const uint32_t c = __popcll(m);
+            if (c) {
+                const uint64_t k = ((uint64_t)__float_as_uint(t) << 32) | fid;
+                if (nh + c <= cap) {
+                    if (hit) {
+                        const uint32_t slot = nh + __popcll(m & lanemask_lt());
+                        s.key[slot] = k; s.hu[slot] = u; s.hv[slot] = v;
+                    }
+                    nh += c;
+                } else {
+                    overflow = true;
+                    wave_sync();
+                    uint64_t mm = m;
+                    while (mm) {
+                        const int src = __ffsll((unsigned long long)mm) - 1;
+                        mm &= mm - 1;
+                        const uint64_t ks = __shfl(k, src);
+                        const float us = __shfl(u, src), vs = __shfl(v, src);
+                        if (nh < cap) {
+                            if (lane == 0) { s.key[nh] = ks; s.hu[nh] = us; s.hv[nh] = vs; }
+                            nh++;
+                            wave_sync();
+                        } else {
+                            insert_overflow(s, cap, ks, us, vs, lane);
                         }
                     }
                 }
             }
+        };
+        // Leaves whose box the line crosses are first collected (their order is irrelevant: the hits are
+        // sorted afterwards), then tested in a loop that requests leaf i+1's triangles before testing leaf
+        // i -- the dependent pop -> load -> test chain of a stack traversal becomes one load latency per
+        // ray instead of one per leaf.  The list lives in the LDS area of `hft` (unused until the sort).
+        uint32_t *leaf_list = reinterpret_cast<uint32_t *>(s.hft);
+        const uint32_t leaf_cap = 2 * (M < 32 ? 32 : M);  // >= 64: one node's children always fit after a flush
+        uint32_t nleaf = 0;
+        auto run_leaves = [&]() {
+            wave_sync();
+            if (nleaf == 0) return;
+            if (lane == 0 && p.stats) atomicAdd(&p.stats[19], (unsigned long long)nleaf);
+            auto fetch = [&](uint32_t li, float (&d)[9], uint32_t &fid) {
+                const float *tr = p.bvh.leaf_tri + (size_t)li * (9 * WIDE) + lane;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) d[k] = tr[k * WIDE];
+                fid = p.bvh.leaf_id[(size_t)li * WIDE + lane];
+            };
+            float cur[9], nxt[9];
+            uint32_t cfid, nfid = TN_EMPTY;
+            fetch(leaf_list[0], cur, cfid);
+            for (uint32_t i = 0; i < nleaf; ++i) {
+                if (i + 1 < nleaf) fetch(leaf_list[i + 1], nxt, nfid);
+                test_leaf(cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7], cur[8], cfid);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) cur[k] = nxt[k];
+                cfid = nfid;
+            }
+            nleaf = 0;
+            wave_sync();
+        };
+
+        uint32_t sp = 1;      // stack of internal nodes (wave-uniform)
+        if (lane == 0) s.stack[0] = 0u;  // root = internal node 0
+        wave_sync();
+        while (sp > 0) {
+            const uint32_t idx = s.stack[sp - 1];
+            sp--;
+            wave_sync();  // everyone has read the top before it can be overwritten
+            if (lane == 0 && p.stats) atomicAdd(&p.stats[18], 1ull);
+            const float *b = p.bvh.boxes + (size_t)idx * (6 * WIDE);
+            const uint32_t ch = p.bvh.child[(size_t)idx * WIDE + lane];
+            const bool hit = ch != TN_EMPTY &&
+                             line_box(ox, oy, oz, ix, iy, iz, b[lane], b[WIDE + lane], b[2 * WIDE + lane],
+                                      b[3 * WIDE + lane], b[4 * WIDE + lane], b[5 * WIDE + lane], pad);
+            const bool to_leaf = hit && (ch >> 31) != 0, to_node = hit && (ch >> 31) == 0;
+            const uint64_t ml = __ballot(to_leaf), mn = __ballot(to_node);
+            if (nleaf + __popcll(ml) > leaf_cap) run_leaves();  // flush a full list (tiny M only)
+            if (to_leaf) leaf_list[nleaf + __popcll(ml & lanemask_lt())] = ch & 0x7FFFFFFFu;
+            nleaf += __popcll(ml);
+            if (to_node) s.stack[sp + __popcll(mn & lanemask_lt())] = ch;
+            sp += __popcll(mn);
             wave_sync();
         }
+        run_leaves();
         if (overflow && lane == 0 && p.stats) atomicAdd(&p.stats[3], 1ull);
 
-        sort_hits(s, nh, lane);
+        if (p.gdebug & 1u) nh = 0;
+        if (!(p.gdebug & 2u)) sort_hits(s, nh, lane);
         postprocess_and_write(s, nh, M, p.faces, p.face_tets, p.out_num + ray, p.out_cells + ray * M,
                               p.out_bary + ray * M * 6, p.out_dist + ray * M * 2,
                               p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane);
@@ -333,7 +371,7 @@ __global__ __launch_bounds__(64) void k_postprocess_hits(TraceParams p, const ui
 }
 
 size_t trace_general_smem_bytes(uint32_t M) {
-    return (size_t)M * (8 + 8 + 4 + 4) + STACK_CAP * 4 + M;
+    return (size_t)M * (8 + 4 + 4) + (size_t)(M < 32 ? 32 : M) * 8 + STACK_CAP * 4 + 2 * (size_t)M;
 }
 
 void launch_trace_general(const TraceParams &p, hipStream_t stream) {

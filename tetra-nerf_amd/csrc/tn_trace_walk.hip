@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         // ray-independent visiting order, every crossing of the ray's LINE is found.  Works for
         // incoherent batches (random training rays) as well as for camera frames.
         const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
-        const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.hull.scene_max);
+        const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.scene_max);
         uint32_t i = active ? 0u : p.n_hull_nodes;
         while (i < p.n_hull_nodes) {
             const float4 a = p.hull_nodes[2 * (size_t)i], b = p.hull_nodes[2 * (size_t)i + 1];
