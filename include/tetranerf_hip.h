@@ -76,6 +76,22 @@ int tn_trace_rays(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_triangle
                   const float *origins, const float *directions, uint32_t *num_visited,
                   uint32_t *visited, float *bary, float *dist, uint32_t *verts, void *stream);
 
+/* TetrahedraTracer::trace_rays_triangles                src/tetrahedra_tracer.h:333-352,
+ *   device programs                                      src/optix/optix_trace_rays_triangles.cu:50-115
+ * the sorted all-hits list of each ray, without the pairing stage (not called by the model).
+ * visited u32 [R,M] face ids; bary f32 [R,M,2] = (u,v); dist f32 [R,M] = t; verts u32 [R,M,3] = the face's
+ * stored vertex triple.  Slots >= num_visited[r]: ids 0xFFFFFFFF, floats 0. */
+int tn_trace_rays_triangles(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_triangles,
+                            const float *origins, const float *directions, uint32_t *num_visited,
+                            uint32_t *visited, float *bary, float *dist, uint32_t *verts, void *stream);
+
+/* TetrahedraTracer::find_tetrahedra                      src/tetrahedra_tracer.h:354-366,
+ *   device programs                                      src/optix/optix_find_tetrahedra.cu:84-212
+ * point location by two closest-hit rays (+x, -x): tetrahedra u32 [N] (0xFFFFFFFF = outside),
+ * bary f32 [N,3] (weights of verts[1..3]; verts[0] has 1 - sum), verts u32 [N,4]; not found: bary/verts = 0. */
+int tn_find_tetrahedra(tn_tracer_t tracer, size_t num_points, const float *positions, uint32_t *tetrahedra,
+                       float *bary, uint32_t *verts, void *stream);
+
 /* find_matched_cells                                   src/tetrahedra_tracer.h:380-393,
  *                                                       src/tetrahedra_tracer.cu:115-193
  * (PyTetrahedraTracer::find_visited_cells, src/py_binding.cpp:163-216; `cells` of the

@@ -518,6 +518,45 @@ int tno_trace_rays(uint64_t V, const float *xyz, uint64_t F, const uint32_t *fac
     return 0;
 }
 
+/* find_tetrahedra: optix_find_tetrahedra.cu:84-212 (two closest-hit rays +x / -x, common
+ * tetrahedron, blended barycentrics).  Closest = smallest (t, face id).  Defaults (not found):
+ * tetrahedron 0xFFFFFFFF, barycentrics and vertex ids 0 (torch::zeros, py_binding.cpp:121-129). */
+int tno_find_tetrahedra(const float *xyz, uint64_t F, const uint32_t *faces, const uint32_t *face_tets,
+                        uint64_t N, const float *points, uint32_t *tets, float *bary, uint32_t *verts) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)N; ++i) {
+        uint32_t fid[2] = {TNO_EMPTY, TNO_EMPTY};
+        float ht[2] = {0, 0}, hu[2] = {0, 0}, hv[2] = {0, 0};
+        for (int side = 0; side < 2; ++side) {
+            const float d[3] = {side == 0 ? 1.0f : -1.0f, 0.0f, 0.0f};
+            RayPre rp;
+            ray_pre(points + 3 * i, d, &rp);
+            for (uint64_t f = 0; f < F; ++f) {
+                const uint32_t *fv = faces + 3 * f;
+                float t, u, v;
+                if (tri_hit(&rp, xyz + 3 * (size_t)fv[0], xyz + 3 * (size_t)fv[1], xyz + 3 * (size_t)fv[2], &t, &u, &v)) {
+                    if (fid[side] == TNO_EMPTY || t < ht[side]) { fid[side] = (uint32_t)f; ht[side] = t; hu[side] = u; hv[side] = v; }
+                }
+            }
+        }
+        uint32_t cell = TNO_EMPTY, vi[4] = {0, 0, 0, 0};
+        float c[3] = {0, 0, 0};
+        if (fid[0] != TNO_EMPTY && fid[1] != TNO_EMPTY &&
+            get_common_tetrahedra(face_tets + 2 * (size_t)fid[0], face_tets + 2 * (size_t)fid[1], &cell)) {
+            float c0[3], c1[3];
+            combine_indices(faces + 3 * (size_t)fid[0], faces + 3 * (size_t)fid[1], hu[0], hv[0], hu[1], hv[1], vi, c0, c1);
+            const float m = ht[1] / (ht[0] + ht[1]);
+            for (int k = 0; k < 3; ++k) c[k] = c0[k] * m + c1[k] * (1 - m);
+        } else {
+            cell = TNO_EMPTY;
+        }
+        tets[i] = cell;
+        memcpy(bary + 3 * i, c, sizeof c);
+        memcpy(verts + 4 * i, vi, sizeof vi);
+    }
+    return 0;
+}
+
 /* post-process caller-supplied sorted hit lists (crafted tie / duplicate cases) */
 int tno_postprocess(const uint32_t *faces, const uint32_t *face_tets, uint64_t R, uint32_t M,
                     const uint32_t *hit_count, const uint32_t *hit_ids, const float *hit_t,

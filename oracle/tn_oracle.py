@@ -130,6 +130,28 @@ class OracleTracer:
             res["raw"] = raw
         return res
 
+    def trace_rays_triangles(self, origins, directions, max_ray_triangles):
+        """Sorted all-hits list (reference: trace_rays_triangles, py_binding.cpp:78-113)."""
+        raw = self.trace_rays(origins, directions, max_ray_triangles, with_raw=True)["raw"]
+        ids = raw["ids"]
+        v3 = np.where((ids != 0xFFFFFFFF)[..., None], self.faces[np.minimum(ids, len(self.faces) - 1).astype(np.int64)], 0xFFFFFFFF)
+        return {"num_visited_triangles": raw["count"].view(np.int32), "visited_triangles": ids.view(np.int32),
+                "barycentric_coordinates": raw["uv"], "hit_distances": raw["t"],
+                "vertex_indices": np.ascontiguousarray(v3.astype(np.uint32)).view(np.int32)}
+
+    def find_tetrahedra(self, positions):
+        pts = _f32(positions).reshape(-1, 3)
+        N = len(pts)
+        tets = np.empty(N, np.uint32)
+        bary = np.empty((N, 3), np.float32)
+        verts = np.empty((N, 4), np.uint32)
+        rc = lib().tno_find_tetrahedra(_p(self.xyz), C.c_uint64(len(self.faces)), _p(self.faces), _p(self.face_tets),
+                                       C.c_uint64(N), _p(pts), _p(tets), _p(bary), _p(verts))
+        if rc:
+            raise RuntimeError(f"tno_find_tetrahedra failed rc={rc}")
+        t = tets.view(np.int32)
+        return {"tetrahedra": t, "barycentric_coordinates": bary, "vertex_indices": verts.view(np.int32), "valid_mask": t != -1}
+
     def find_visited_cells(self, num_visited_cells, visited_cells, barycentric_coordinates,
                            hit_distances, vertex_indices, distances):
         return find_visited_cells(num_visited_cells, visited_cells, barycentric_coordinates,

@@ -14,7 +14,8 @@ LIB_PATH = _HERE / "libtetranerf_hip.so"
 # every symbol include/tetranerf_hip.h declares
 SYMBOLS = (
     "tn_last_error", "tn_version", "tn_tracer_create", "tn_tracer_destroy", "tn_load_tetrahedra",
-    "tn_num_faces", "tn_get_faces", "tn_trace_rays", "tn_find_matched_cells",
+    "tn_num_faces", "tn_get_faces", "tn_trace_rays", "tn_trace_rays_triangles", "tn_find_tetrahedra",
+    "tn_find_matched_cells",
     "tn_interpolate_values", "tn_interpolate_values_backward", "tn_postprocess_hits",
     "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite",
 )
@@ -44,6 +45,8 @@ def load():
     lib.tn_num_faces.argtypes = [vp]
     lib.tn_get_faces.argtypes = [vp, vp, vp]
     lib.tn_trace_rays.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tn_trace_rays_triangles.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tn_find_tetrahedra.argtypes = [vp, sz, vp, vp, vp, vp, vp]
     lib.tn_find_matched_cells.argtypes = [sz, sz, sz] + [vp] * 11
     lib.tn_interpolate_values.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
     lib.tn_interpolate_values_backward.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]

@@ -360,6 +360,37 @@ int tn_postprocess_hits(tn_tracer_t tracer, size_t R, uint32_t M, const uint32_t
     });
 }
 
+int tn_trace_rays_triangles(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins, const float *directions,
+                            uint32_t *num_visited, uint32_t *visited, float *bary, float *dist, uint32_t *verts,
+                            void *stream_) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        if (M == 0 || (M & (M - 1)) != 0) throw tn::Error("max_ray_triangles must be a power of 2.");
+        if (!t->loaded) throw tn::Error("load_tetrahedra must be called first");
+        if (M > 4096) throw tn::Error("max_ray_triangles larger than 4096 is not supported");
+        if (R == 0) return;
+        DeviceGuard g(t->device);
+        tn::TraceParams p = make_params(t, R, M, origins, directions, num_visited, nullptr, nullptr, nullptr, nullptr);
+        p.stats = nullptr;
+        tn::launch_trace_triangles(p, visited, dist, bary, verts, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_find_tetrahedra(tn_tracer_t tracer, size_t N, const float *positions, uint32_t *tetrahedra, float *bary,
+                       uint32_t *verts, void *stream_) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        if (!t->loaded) throw tn::Error("load_tetrahedra must be called first");
+        if (N == 0) return;
+        DeviceGuard g(t->device);
+        tn::TraceParams p = make_params(t, N, 512, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        p.stats = nullptr;
+        tn::launch_find_tetrahedra(p, positions, tetrahedra, bary, verts, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
 int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);

@@ -28,6 +28,10 @@ void launch_trace_general(const TraceParams &p, hipStream_t stream);
 void launch_postprocess_hits(const TraceParams &p, const uint32_t *hit_count, const uint32_t *hit_ids,
                              const float *hit_t, const float *hit_uv, hipStream_t stream);
 size_t trace_general_smem_bytes(uint32_t M);
+void launch_trace_triangles(const TraceParams &p, uint32_t *out_ids, float *out_t, float *out_uv, uint32_t *out_v3,
+                            hipStream_t stream);
+void launch_find_tetrahedra(const TraceParams &p, const float *points, uint32_t *out_tet, float *out_bary,
+                            uint32_t *out_verts, hipStream_t stream);
 
 // adjacency walk, one lane per ray (tn_trace_walk.hip)
 struct WalkParams {

@@ -227,24 +227,15 @@ __device__ void sort_hits(const WaveSmem &s, uint32_t nh, int lane) {
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    WaveSmem s = carve(smem, p.M);
-    const int lane = threadIdx.x;
-    const uint32_t M = p.M;
-    const uint32_t cap = M - 1;  // at most M-1 hits are kept (optix_trace_rays.cu:312-315)
-
-    const size_t n_items = p.item_count ? (size_t)*p.item_count : p.num_items;
-    for (size_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const size_t ray = p.ray_list ? (size_t)p.ray_list[it] : it;
-        const float ox = p.origins[3 * ray], oy = p.origins[3 * ray + 1], oz = p.origins[3 * ray + 2];
-        const float dx = p.dirs[3 * ray], dy = p.dirs[3 * ray + 1], dz = p.dirs[3 * ray + 2];
-        const RayPre rp = ray_pre(ox, oy, oz, dx, dy, dz);
-        const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
-        const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.bvh.scene_max);
-
+// All faces of the mesh the ray (o, d) hits with 0 < t < 1e16, into the LDS hit arrays (unsorted).
+// Returns the number kept (<= cap; beyond cap the nearest are kept).
+__device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, uint32_t cap, float ox, float oy, float oz,
+                                 float dx, float dy, float dz, unsigned long long *stats, int lane, bool &overflow) {
+    const RayPre rp = ray_pre(ox, oy, oz, dx, dy, dz);
+    const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+    const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + bvh.scene_max);
         uint32_t nh = 0;      // hits stored (wave-uniform)
-        bool overflow = false;
+        overflow = false;
 
         // One leaf: 64 triangles against the ray, hits appended to the LDS hit arrays.
         auto test_leaf = [&](float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2,
@@ -292,12 +283,12 @@ __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
         auto run_leaves = [&]() {
             wave_sync();
             if (nleaf == 0) return;
-            if (lane == 0 && p.stats) atomicAdd(&p.stats[19], (unsigned long long)nleaf);
+            if (lane == 0 && stats) atomicAdd(&stats[19], (unsigned long long)nleaf);
             auto fetch = [&](uint32_t li, float (&d)[9], uint32_t &fid) {
-                const float *tr = p.bvh.leaf_tri + (size_t)li * (9 * WIDE) + lane;
+                const float *tr = bvh.leaf_tri + (size_t)li * (9 * WIDE) + lane;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) d[k] = tr[k * WIDE];
-                fid = p.bvh.leaf_id[(size_t)li * WIDE + lane];
+                fid = bvh.leaf_id[(size_t)li * WIDE + lane];
             };
             float cur[9], nxt[9];
             uint32_t cfid, nfid = TN_EMPTY;
@@ -320,9 +311,9 @@ __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
             const uint32_t idx = s.stack[sp - 1];
             sp--;
             wave_sync();  // everyone has read the top before it can be overwritten
-            if (lane == 0 && p.stats) atomicAdd(&p.stats[18], 1ull);
-            const float *b = p.bvh.boxes + (size_t)idx * (6 * WIDE);
-            const uint32_t ch = p.bvh.child[(size_t)idx * WIDE + lane];
+            if (lane == 0 && stats) atomicAdd(&stats[18], 1ull);
+            const float *b = bvh.boxes + (size_t)idx * (6 * WIDE);
+            const uint32_t ch = bvh.child[(size_t)idx * WIDE + lane];
             const bool hit = ch != TN_EMPTY &&
                              line_box(ox, oy, oz, ix, iy, iz, b[lane], b[WIDE + lane], b[2 * WIDE + lane],
                                       b[3 * WIDE + lane], b[4 * WIDE + lane], b[5 * WIDE + lane], pad);
@@ -336,6 +327,22 @@ __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
             wave_sync();
         }
         run_leaves();
+        return nh;
+}
+
+__global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WaveSmem s = carve(smem, p.M);
+    const int lane = threadIdx.x;
+    const uint32_t M = p.M;
+    const uint32_t cap = M - 1;  // at most M-1 hits are kept (optix_trace_rays.cu:312-315)
+
+    const size_t n_items = p.item_count ? (size_t)*p.item_count : p.num_items;
+    for (size_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const size_t ray = p.ray_list ? (size_t)p.ray_list[it] : it;
+        bool overflow = false;
+        uint32_t nh = collect_hits(p.bvh, s, M, cap, p.origins[3 * ray], p.origins[3 * ray + 1], p.origins[3 * ray + 2],
+                                   p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2], p.stats, lane, overflow);
         if (overflow && lane == 0 && p.stats) atomicAdd(&p.stats[3], 1ull);
 
         if (p.gdebug & 1u) nh = 0;
@@ -368,6 +375,109 @@ __global__ __launch_bounds__(64) void k_postprocess_hits(TraceParams p, const ui
                               p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane);
         wave_sync();
     }
+}
+
+size_t trace_general_smem_bytes(uint32_t M);
+
+// trace_rays_triangles: the sorted all-hits list itself, no pairing
+// (src/optix/optix_trace_rays_triangles.cu:50-87).  Slots >= count: ids -1, floats 0.
+__global__ __launch_bounds__(64) void k_trace_triangles(TraceParams p, uint32_t *out_ids, float *out_t, float *out_uv,
+                                                        uint32_t *out_v3) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WaveSmem s = carve(smem, p.M);
+    const int lane = threadIdx.x;
+    const uint32_t M = p.M;
+    for (size_t ray = blockIdx.x; ray < p.num_items; ray += gridDim.x) {
+        bool overflow = false;
+        const uint32_t nh = collect_hits(p.bvh, s, M, M - 1, p.origins[3 * ray], p.origins[3 * ray + 1], p.origins[3 * ray + 2],
+                                         p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2], nullptr, lane, overflow);
+        sort_hits(s, nh, lane);
+        for (uint32_t j = lane; j < M; j += 64) {
+            const bool ok = j < nh;
+            const uint32_t id = ok ? (uint32_t)s.key[j] : TN_EMPTY;
+            const size_t q = ray * M + j;
+            out_ids[q] = id;
+            out_t[q] = ok ? __uint_as_float((uint32_t)(s.key[j] >> 32)) : 0.f;
+            out_uv[2 * q] = ok ? s.hu[j] : 0.f;
+            out_uv[2 * q + 1] = ok ? s.hv[j] : 0.f;
+            for (int k = 0; k < 3; ++k) out_v3[3 * q + k] = ok ? p.faces[3 * (size_t)id + k] : TN_EMPTY;
+        }
+        if (lane == 0) p.out_num[ray] = nh;
+        wave_sync();
+    }
+}
+
+// find_tetrahedra: closest face hit along +x and -x, common tetrahedron, blended barycentrics
+// (src/optix/optix_find_tetrahedra.cu:84-212).  Closest = smallest (t, face id).
+__global__ __launch_bounds__(64) void k_find_tetrahedra(TraceParams p, const float *__restrict__ points, uint32_t *out_tet,
+                                                        float *out_bary, uint32_t *out_verts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WaveSmem s = carve(smem, p.M);
+    const int lane = threadIdx.x;
+    const uint32_t M = p.M;
+    for (size_t pt = blockIdx.x; pt < p.num_items; pt += gridDim.x) {
+        const float ox = points[3 * pt], oy = points[3 * pt + 1], oz = points[3 * pt + 2];
+        uint32_t fid[2] = {TN_EMPTY, TN_EMPTY};
+        float ht[2] = {0.f, 0.f}, hu[2] = {0.f, 0.f}, hv[2] = {0.f, 0.f};
+        for (int side = 0; side < 2; ++side) {
+            bool overflow = false;
+            const uint32_t nh = collect_hits(p.bvh, s, M, M - 1, ox, oy, oz, side == 0 ? 1.0f : -1.0f, 0.0f, 0.0f, nullptr, lane, overflow);
+            wave_sync();
+            uint64_t best = ~0ull;
+            uint32_t bidx = 0;
+            for (uint32_t j = lane; j < nh; j += 64) if (s.key[j] < best) { best = s.key[j]; bidx = j; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint64_t ob = __shfl_xor(best, off);
+                const uint32_t oi = __shfl_xor(bidx, off);
+                if (ob < best) { best = ob; bidx = oi; }
+            }
+            if (nh) {
+                fid[side] = (uint32_t)best; ht[side] = __uint_as_float((uint32_t)(best >> 32));
+                hu[side] = s.hu[bidx]; hv[side] = s.hv[bidx];
+            }
+            wave_sync();
+        }
+        if (lane == 0) {
+            uint32_t cell = TN_EMPTY;
+            uint32_t vi[4] = {0, 0, 0, 0};
+            float c[3] = {0.f, 0.f, 0.f};
+            if (fid[0] != TN_EMPTY && fid[1] != TN_EMPTY) {
+                const uint2 t0 = *reinterpret_cast<const uint2 *>(p.face_tets + 2 * (size_t)fid[0]);
+                const uint2 t1 = *reinterpret_cast<const uint2 *>(p.face_tets + 2 * (size_t)fid[1]);
+                if (common_tet(t0, t1, cell)) {
+                    const uint32_t id1[3] = {p.faces[3 * (size_t)fid[0]], p.faces[3 * (size_t)fid[0] + 1], p.faces[3 * (size_t)fid[0] + 2]};
+                    const uint32_t id2[3] = {p.faces[3 * (size_t)fid[1]], p.faces[3 * (size_t)fid[1] + 1], p.faces[3 * (size_t)fid[1] + 2]};
+                    float c0[3], c1[3];
+                    combine_indices(id1, id2, hu[0], hv[0], hu[1], hv[1], vi, c0, c1);
+                    const float m = ht[1] / (ht[0] + ht[1]);
+                    for (int k = 0; k < 3; ++k) c[k] = c0[k] * m + c1[k] * (1 - m);
+                } else {
+                    cell = TN_EMPTY;
+                }
+            }
+            out_tet[pt] = cell;
+            for (int k = 0; k < 3; ++k) out_bary[3 * pt + k] = c[k];
+            for (int k = 0; k < 4; ++k) out_verts[4 * pt + k] = vi[k];
+        }
+        wave_sync();
+    }
+}
+
+void launch_trace_triangles(const TraceParams &p, uint32_t *out_ids, float *out_t, float *out_uv, uint32_t *out_v3,
+                            hipStream_t stream) {
+    if (p.num_items == 0) return;
+    const size_t max_blocks = 256 * 16;
+    const unsigned grid = (unsigned)(p.num_items < max_blocks ? p.num_items : max_blocks);
+    hipLaunchKernelGGL(k_trace_triangles, dim3(grid), dim3(64), trace_general_smem_bytes(p.M), stream, p, out_ids, out_t, out_uv, out_v3);
+}
+
+void launch_find_tetrahedra(const TraceParams &p, const float *points, uint32_t *out_tet, float *out_bary,
+                            uint32_t *out_verts, hipStream_t stream) {
+    if (p.num_items == 0) return;
+    const size_t max_blocks = 256 * 16;
+    const unsigned grid = (unsigned)(p.num_items < max_blocks ? p.num_items : max_blocks);
+    hipLaunchKernelGGL(k_find_tetrahedra, dim3(grid), dim3(64), trace_general_smem_bytes(p.M), stream, p, points, out_tet, out_bary, out_verts);
 }
 
 size_t trace_general_smem_bytes(uint32_t M) {

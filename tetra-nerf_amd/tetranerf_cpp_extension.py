@@ -126,6 +126,40 @@ class TetrahedraTracer:
             "hit_distances": hit_distances,
         }
 
+    def trace_rays_triangles(self, ray_origins, ray_directions, max_ray_triangles):
+        """PyTetrahedraTracer::trace_rays_triangles (py_binding.cpp:78-113): the sorted all-hits list."""
+        M = int(max_ray_triangles)
+        if M <= 0 or (M & (M - 1)) != 0:
+            raise RuntimeError("max_ray_triangles must be a power of 2.")
+        with torch.no_grad():
+            self._check_float_dim3(ray_origins, "ray_origins")
+            self._check_float_dim3(ray_directions, "ray_directions")
+            R = ray_origins.numel() // 3
+            dev = self._device
+            num = torch.empty((R,), dtype=torch.int32, device=dev)
+            vis = torch.empty((R, M), dtype=torch.int32, device=dev)
+            bary = torch.empty((R, M, 2), dtype=torch.float32, device=dev)
+            dist = torch.empty((R, M), dtype=torch.float32, device=dev)
+            verts = torch.empty((R, M, 3), dtype=torch.int32, device=dev)
+            _lib.check(self._lib.tn_trace_rays_triangles(self._h, R, M, _ptr(ray_origins), _ptr(ray_directions), _ptr(num),
+                                                         _ptr(vis), _ptr(bary), _ptr(dist), _ptr(verts), _stream(dev)))
+        return {"num_visited_triangles": num, "visited_triangles": vis, "barycentric_coordinates": bary,
+                "vertex_indices": verts, "hit_distances": dist}
+
+    def find_tetrahedra(self, positions):
+        """PyTetrahedraTracer::find_tetrahedra (py_binding.cpp:115-142): point location."""
+        with torch.no_grad():
+            self._check_float_dim3(positions, "positions")
+            shape = tuple(positions.shape[:-1])
+            N = positions.numel() // 3
+            dev = self._device
+            bary = torch.empty(shape + (3,), dtype=torch.float32, device=dev)
+            verts = torch.empty(shape + (4,), dtype=torch.int32, device=dev)
+            tets = torch.empty(shape, dtype=torch.int32, device=dev)
+            _lib.check(self._lib.tn_find_tetrahedra(self._h, N, _ptr(positions), _ptr(tets), _ptr(bary), _ptr(verts),
+                                                    _stream(dev)))
+        return {"tetrahedra": tets, "barycentric_coordinates": bary, "vertex_indices": verts, "valid_mask": tets != -1}
+
     def find_visited_cells(self, num_visited_cells, visited_cells, barycentric_coordinates,
                            hit_distances, vertex_indices, distances):
         for x, name in ((num_visited_cells, "num_visited_cells"), (visited_cells, "visited_cells"),
