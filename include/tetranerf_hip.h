@@ -150,6 +150,16 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *             0 = general all-hits path for every ray */
 int tn_set_option(tn_tracer_t tracer, const char *name, int value);
 
+/* gather_uint32<T> / scatter_ema_uint32<T>              src/tetrahedra_tracer.cu:30-113,
+ *                                                       src/py_binding.cpp:374-431
+ * (exported by the reference, not called by its model).  elem_size 4 = float32, 8 = float64.
+ * gather: result[i] = values[indices[i]];  scatter: result[k] = result[k]*decay + (1-decay)*values[i], k = indices[i],
+ * applied atomically per element (compare-and-swap).  Out-of-range indices are skipped. */
+int tn_gather_uint32(int elem_size, uint32_t num_values, uint32_t num_indices, const uint32_t *indices,
+                     const void *values, void *result, void *stream);
+int tn_scatter_ema_uint32(int elem_size, uint32_t num_result, uint32_t num_indices, const uint32_t *indices,
+                          double decay, const void *values, void *result, void *stream);
+
 /* ---- shallow MLP + volume render (inference forward) ------------------------------------------
  * The arithmetic of these two lives in nerfstudio, not in /root/reference; the call sites are
  * tetranerf/nerfstudio/model.py:414-455 (modules), :602-621 (MLP + heads), :632-638 (weights and

@@ -107,3 +107,41 @@ def test_gather_errors(tn, device):
     out = tn.cpp.interpolate_values(torch.zeros((0, 4), dtype=torch.int32, device=device),
                                     torch.zeros((0, 3), device=device), field)
     assert tuple(out.shape) == (0, 64)
+
+
+def test_gather_uint32(tn, device):
+    """Mirrors tests/test_uint32.py::test_gather_uint32 of the reference."""
+    import torch
+
+    torch.manual_seed(0)
+    for dt in (torch.float32, torch.float64):
+        vals = torch.rand((5,), dtype=dt, device=device)
+        indices = torch.randint(0, 5, (12,), dtype=torch.int32, device=device)
+        res = tn.gather_uint32(vals, 0, indices)
+        torch.testing.assert_close(res, vals[indices.long()], rtol=0, atol=0)
+    with pytest.raises(Exception):
+        tn.gather_uint32(torch.rand((5, 3), device=device), 0, torch.randint(0, 3, (5, 8), device=device))
+
+
+def test_scatter_ema_uint32(tn, device):
+    """Mirrors tests/test_uint32.py::test_scatter_ema_uint32 of the reference."""
+    import torch
+
+    torch.manual_seed(0)
+    for dt in (torch.float32, torch.float64):
+        tensor = torch.rand((10,), dtype=dt, device=device)
+        indices = torch.tensor([4, 3, 5, 8, 2, 1, 0], dtype=torch.int32, device=device)
+        vals = torch.rand((7,), dtype=dt, device=device)
+        res = tensor.clone()
+        decay = 0.5
+        tn.scatter_ema_uint32_(res, 0, indices, decay, vals)
+        gt = torch.scatter(tensor, 0, indices.long(), tensor[indices.long()] * decay + (1 - decay) * vals)
+        torch.testing.assert_close(res, gt)
+    # repeated index: the updates are applied one after the other (atomic), in some order
+    x = torch.zeros((1,), device=device)
+    tn.scatter_ema_uint32_(x, 0, torch.zeros((3,), dtype=torch.int32, device=device), 0.5, torch.ones((3,), device=device))
+    torch.testing.assert_close(x, torch.tensor([0.875], device=device))
+    with pytest.raises(Exception):
+        t2 = torch.rand((5, 3), device=device)
+        tn.scatter_ema_uint32_(t2, 0, torch.randint(0, 3, (5, 8), dtype=torch.int32, device=device), 0.5,
+                               torch.rand((5, 8), device=device))

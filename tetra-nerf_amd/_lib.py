@@ -17,7 +17,7 @@ SYMBOLS = (
     "tn_num_faces", "tn_get_faces", "tn_trace_rays", "tn_trace_rays_triangles", "tn_find_tetrahedra",
     "tn_find_matched_cells",
     "tn_interpolate_values", "tn_interpolate_values_backward", "tn_postprocess_hits",
-    "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite",
+    "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
 )
 
 _lib = None
@@ -56,6 +56,8 @@ def load():
     lib.tn_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.tn_mlp_forward.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp]
     lib.tn_mlp_forward_gather.argtypes = [sz, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tn_gather_uint32.argtypes = [i32, u32, u32, vp, vp, vp, vp]
+    lib.tn_scatter_ema_uint32.argtypes = [i32, u32, u32, vp, C.c_double, vp, vp, vp]
     lib.tn_composite.argtypes = [sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)

@@ -502,4 +502,20 @@ int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, cons
     });
 }
 
+int tn_gather_uint32(int elem_size, uint32_t num_values, uint32_t num_indices, const uint32_t *indices,
+                     const void *values, void *result, void *stream_) {
+    return guarded([&] {
+        tn::launch_gather_uint32(elem_size, num_values, num_indices, indices, values, result, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_scatter_ema_uint32(int elem_size, uint32_t num_result, uint32_t num_indices, const uint32_t *indices,
+                          double decay, const void *values, void *result, void *stream_) {
+    return guarded([&] {
+        tn::launch_scatter_ema_uint32(elem_size, num_result, num_indices, indices, decay, values, result, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
 }  // extern "C"

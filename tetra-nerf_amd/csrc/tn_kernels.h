@@ -84,4 +84,10 @@ void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols,
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
                       float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream);
 
+// uint32-indexed gather / EMA scatter (tn_uint32.hip); elem_size 4 = f32, 8 = f64
+void launch_gather_uint32(int elem_size, uint32_t num_values, uint32_t num_indices, const uint32_t *indices,
+                          const void *values, void *result, hipStream_t stream);
+void launch_scatter_ema_uint32(int elem_size, uint32_t num_result, uint32_t num_indices, const uint32_t *indices,
+                               double decay, const void *values, void *result, hipStream_t stream);
+
 }  // namespace tn

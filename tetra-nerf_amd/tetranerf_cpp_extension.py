@@ -403,16 +403,42 @@ def find_average_spacing(points):
 
 
 def gather_uint32(self, dim, index):
-    """py_gather_uint32 (py_binding.cpp:374-399); not called by the model.  PyTorch plumbing."""
+    """py_gather_uint32 (py_binding.cpp:374-399); not called by the model."""
     _check(index.dtype == torch.int32, "index must be a tensor of type int32")
     _check(self.is_floating_point(), "self must be a tensor of a floating-point type")
     _check(self.device == index.device, "self and index must be on the same device")
-    _check(self.dim() == 1 and index.dim() == 1, "self and index must have the same number of dimensions")
+    _check(self.is_contiguous(), "self must be contiguous")
+    _check(index.is_contiguous(), "index must be contiguous")
+    _check(self.device.type == "cuda", "self must be on CUDA")
+    _check(index.device.type == "cuda", "index must be on CUDA")
+    _check(self.dim() == 1, "self must be 1-dimensional")
+    _check(index.dim() == self.dim(), "self and index must have the same number of dimensions")
     _check(dim == 0, "dim must be 0")
-    return self[index.long() & 0xFFFFFFFF]
+    _check(self.dtype in (torch.float32, torch.float64), "self must be float32 or float64")
+    result = torch.empty(index.shape, dtype=self.dtype, device=self.device)
+    with torch.cuda.device(self.device):
+        _lib.check(_lib.load().tn_gather_uint32(self.element_size(), self.numel(), index.numel(), _ptr(index), _ptr(self),
+                                                _ptr(result), _stream(self.device)))
+    return result
 
 
 def scatter_ema_uint32(self, dim, index, decay, values):
-    """py_scatter_ema_uint32 (py_binding.cpp:405-431); dormant occupancy-field op, not on the
-    model path."""
-    raise RuntimeError("scatter_ema_uint32 is not part of the MI355X hot-path build (unused by the model)")
+    """py_scatter_ema_uint32 (py_binding.cpp:405-431): in-place x[idx] = x[idx]*decay + (1-decay)*v."""
+    _check(dim == 0, "dim must be 0")
+    _check(self.is_floating_point(), "self must be a tensor of a floating-point type")
+    _check(self.is_contiguous(), "self must be contiguous")
+    _check(self.dim() == 1, "self must be 1-dimensional")
+    _check(self.device.type == "cuda", "self must be on CUDA")
+    _check(index.dtype == torch.int32, "index must be a tensor of type int32")
+    _check(index.is_contiguous(), "index must be contiguous")
+    _check(index.device.type == "cuda", "index must be on CUDA")
+    _check(values.is_contiguous(), "values must be contiguous")
+    _check(self.device == index.device, "self and index must be on the same device")
+    _check(values.device == index.device, "values and index must be on the same device")
+    _check(values.dtype == self.dtype, "values and self must have the same dtype")
+    _check(index.dim() == self.dim(), "self and index must have the same number of dimensions")
+    _check(values.shape == index.shape, "values and index must have the same shape")
+    _check(self.dtype in (torch.float32, torch.float64), "self must be float32 or float64")
+    with torch.cuda.device(self.device):
+        _lib.check(_lib.load().tn_scatter_ema_uint32(self.element_size(), self.numel(), index.numel(), _ptr(index),
+                                                     float(decay), _ptr(values), _ptr(self), _stream(self.device)))
