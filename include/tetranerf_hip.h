@@ -176,7 +176,8 @@ typedef struct tn_mlp_weights {
 } tn_mlp_weights;
 
 /* feats f32 [64, n] feature-major (the buffer tn_interpolate_values writes), dirs f32 [n/samples_per_ray, 3]
- * (one direction per ray; samples of a ray are consecutive) -> sigma f32 [n] (softplus), rgb f32 [n,3] (sigmoid) */
+ * (one direction per ray; samples of a ray are consecutive) -> sigma f32 [n] (softplus), rgb f32 [n,3] (sigmoid).
+ * rgb == NULL: density only (mlp_base + density head: the coarse pass of the model, model.py:577-581); dirs unused. */
 int tn_mlp_forward(size_t n, uint32_t samples_per_ray, const float *feats, const float *dirs,
                    const tn_mlp_weights *weights, float *sigma, float *rgb, void *stream);
 
@@ -188,7 +189,8 @@ int tn_mlp_forward_gather(size_t n, uint32_t samples_per_ray, uint32_t num_verti
 
 /* RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers.
  * sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1] (bin edges: starts = edges[:, :-1], ends = edges[:, 1:]);
- * out_rgb f32 [R,3], out_acc f32 [R], out_depth f32 [R], out_weights f32 [R,S] (nullable). */
+ * out_rgb f32 [R,3], out_acc f32 [R], out_depth f32 [R], out_weights f32 [R,S] (nullable).
+ * rgb == NULL and out_rgb == NULL: only out_weights is written (get_weights of the coarse pass, model.py:582). */
 int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, const float *rgb, const float *edges,
                  float background, float *out_rgb, float *out_acc, float *out_depth, float *out_weights,
                  void *stream);

@@ -8,7 +8,12 @@
                      tests/test_tetrahedra_tracer.py:13-20; CGAL is absent here).
   bottle_oracle.npz  oracle outputs for config C1 (64x64 rays, M=256): counts, leading
                      segment cells and a checksum -- regression pins for the oracle itself.
+  biased_sampler.npz inputs/outputs of the REFERENCE's own map_from_real_distances_to_biased_with_bounds
+                     (tetranerf/nerfstudio/model.py:111-122; the function is extracted from the file
+                     with ast and executed -- the module itself needs nerfstudio, absent here) on the
+                     bottle's hit lists: pins render.biased_sample_bins.
 """
+import ast
 import hashlib
 import importlib
 import sys
@@ -70,5 +75,41 @@ def main():
           h.hexdigest()[:16])
 
 
+def reference_function(path, name):
+    """Execute one top-level function of a reference source file without importing the module."""
+    import torch
+
+    tree = ast.parse(Path(path).read_text())
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), str(path), "exec"), ns)
+    return ns[name]
+
+
+def biased_sampler_golden():
+    import torch
+
+    out = Path(__file__).resolve().parent
+    mesh = np.load(out / "bottle_mesh.npz")
+    tr = tn_oracle.OracleTracer()
+    tr.load_tetrahedra(mesh["vertices"], mesh["cells"])
+    o, d = scenes.pinhole_rays(64, 64)
+    res = tr.trace_rays(o, d, 256)
+    hit = res["num_visited_cells"] > 0
+    nv = res["num_visited_cells"][hit]
+    width = int(nv.max())
+    hd = np.ascontiguousarray(res["hit_distances"][hit][:, :width])
+    S = 48
+    near = hd[:, 0, 0][:, None]
+    far = np.take_along_axis(hd[:, :, 1], (nv[:, None].astype(np.int64) - 1).clip(0), 1)
+    bins = torch.linspace(0.0, 1.0, S + 1)[None].numpy()   # model.py:166,177-178
+    samples = (bins * far + (1 - bins) * near).astype(np.float32)
+    fn = reference_function("/root/reference/tetranerf/nerfstudio/model.py", "map_from_real_distances_to_biased_with_bounds")
+    mapped = fn(torch.from_numpy(nv).long(), torch.from_numpy(hd.copy()), torch.from_numpy(samples.copy())).numpy()
+    np.savez_compressed(out / "biased_sampler.npz", num_visited_cells=nv, hit_distances=hd, samples=samples, mapped=mapped)
+    print("biased sampler:", mapped.shape, float(mapped.min()), float(mapped.max()))
+
+
 if __name__ == "__main__":
     main()
+    biased_sampler_golden()

@@ -67,6 +67,30 @@ def test_mlp_forward_gather_equals_two_step(tn, device, render):
     np.testing.assert_allclose(c1.cpu().numpy(), wc.reshape(-1, 3).cpu().numpy(), rtol=0, atol=1e-5)
 
 
+def test_density_only_and_weights_only(tn, device, render):
+    """Coarse pass of the model (model.py:577-582): mlp_base + density head only, then get_weights."""
+    import torch
+
+    mlp = _model(render, 8).to(device)
+    rng = np.random.default_rng(9)
+    V, R, S = 2000, 33, 128
+    vi = rng.integers(0, V, (R, S, 4)).astype(np.int32)
+    vi[rng.random((R, S)) < 0.3] = -1
+    bc = (rng.random((R, S, 3)).astype(np.float32)) / 4
+    field = torch.randn(64, V, device=device)
+    dirs = torch.nn.functional.normalize(torch.randn(R, 3, device=device), dim=-1)
+    tvi, tbc = torch.from_numpy(vi).to(device), torch.from_numpy(bc).to(device)
+    w = render.mlp_weights(mlp)
+    s_full, _ = tn.cpp.mlp_forward_gather(tvi, tbc, field, dirs, w, S)
+    s_only = tn.cpp.mlp_forward_gather(tvi, tbc, field, None, w, S)
+    # the density head alone accumulates the same products in the same order as the 5th tile of the head layer
+    np.testing.assert_allclose(s_only.cpu().numpy(), s_full.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    edges = (1 + torch.cumsum(torch.rand(R, S + 1, device=device) * 0.02, -1)).contiguous()
+    w_only = tn.cpp.composite(s_only.view(R, S), None, edges)
+    want = render.ray_weights(s_only.view(R, S), edges)
+    np.testing.assert_allclose(w_only.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-6)
+
+
 def test_mlp_forward_vs_float64(tn, device, render):
     """fp32 MFMA = exact fp32 fma chain: error vs a float64 evaluation stays at fp32 round-off."""
     import torch
@@ -109,19 +133,26 @@ def test_composite_matches_torch(tn, device, render):
         assert same.mean() >= 0.98
 
 
-def test_render_c3(tn, device, oracle, scenes, render):
+@pytest.mark.parametrize("cfg", ["coarse", "tetra-nerf-original", "tetra-nerf"])
+def test_render_c3(tn, device, oracle, scenes, render, cfg):
     """Config C3: 100k-tet mesh (seed 1), field U(-1e-4,1e-4) with colour rows, default-init MLP
-    (torch.manual_seed(0)), 4096 rays x 256 samples: sigma-weights-RGB within 1e-5 of the CPU fp32
-    statement (oracle tracer + torch MLP)."""
+    (torch.manual_seed(0)), 4096 rays: sigma-weights-RGB within 1e-5 of the CPU fp32 statement (oracle
+    tracer + torch MLP).  coarse: 256 uniform samples; tetra-nerf-original: 256 uniform + 256 PDF
+    (513 fine samples); tetra-nerf: biased 128 + 128 PDF (registration.py:55-57)."""
     import torch
+
+    S, S_fine, biased = {"coarse": (256, 0, False), "tetra-nerf-original": (256, 256, False),
+                         "tetra-nerf": (128, 128, True)}[cfg]
 
     pts, cells = scenes.random_mesh(15000, 1)
     torch.manual_seed(0)
     mlp = render.TetraMLP()
     field = (torch.rand(64, len(pts)) * 2 - 1) * 1e-4
     field[1:4] = torch.rand(3, len(pts)) * 2 - 1
-    o, d = scenes.outside_in_rays(4096, 7)
-    S, M = 256, 512
+    if cfg != "coarse":
+        field[0] = torch.rand(len(pts)) * 6 - 3    # a density-driving row so that the PDF pass has structure
+    o, d = scenes.outside_in_rays(4096 if cfg == "coarse" else 1024, 7)
+    M = 512
 
     class CpuTracer:
         def __init__(self):
@@ -139,7 +170,8 @@ def test_render_c3(tn, device, oracle, scenes, render):
         return torch.from_numpy(np.ascontiguousarray(oracle.interpolate_values(vi.numpy(), bc.numpy(), f.numpy())))
 
     with torch.no_grad():
-        want = render.render_reference(CpuTracer(), cpu_interp, field, mlp, torch.from_numpy(o), torch.from_numpy(d), S, M)
+        want = render.render_reference(CpuTracer(), cpu_interp, field, mlp, torch.from_numpy(o), torch.from_numpy(d), S, M,
+                                       num_fine_samples=S_fine, biased=biased)
 
     tr = tn.TetrahedraTracer(device)
     tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
@@ -147,7 +179,7 @@ def test_render_c3(tn, device, oracle, scenes, render):
     gm.load_state_dict(mlp.state_dict())
     gm = gm.to(device)
     for fused in (True, False):
-        rd = render.TetraRenderer(tr, field.to(device), gm, S, M, fused=fused)
+        rd = render.TetraRenderer(tr, field.to(device), gm, S, M, fused=fused, num_fine_samples=S_fine, biased=biased)
         got = rd.render(torch.from_numpy(o).to(device), torch.from_numpy(d).to(device))
         assert torch.equal(got["ray_mask"].cpu(), want["ray_mask"])
         np.testing.assert_allclose(got["rgb"].cpu().numpy(), want["rgb"].numpy(), rtol=0, atol=1e-5, err_msg=f"fused={fused}")

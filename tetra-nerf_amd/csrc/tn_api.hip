@@ -469,7 +469,7 @@ int tn_mlp_forward(size_t n, uint32_t samples_per_ray, const float *feats, const
                    const tn_mlp_weights *w, float *sigma, float *rgb, void *stream_) {
     return guarded([&] {
         if (n == 0) return;
-        if (!w || !feats || !dirs || !sigma || !rgb) throw tn::Error("null pointer");
+        if (!w || !feats || !sigma || (rgb && !dirs)) throw tn::Error("null pointer");
         if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
         tn::MlpWeights m{w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
         tn::launch_mlp_forward(n, samples_per_ray, n / samples_per_ray, feats, nullptr, nullptr, nullptr, 0, dirs, m, sigma, rgb,
@@ -483,7 +483,7 @@ int tn_mlp_forward_gather(size_t n, uint32_t samples_per_ray, uint32_t num_verti
                           float *sigma, float *rgb, void *stream_) {
     return guarded([&] {
         if (n == 0) return;
-        if (!w || !vertex_indices || !barycentric || !field || !dirs || !sigma || !rgb) throw tn::Error("null pointer");
+        if (!w || !vertex_indices || !barycentric || !field || !sigma || (rgb && !dirs)) throw tn::Error("null pointer");
         if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
         tn::MlpWeights m{w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
         tn::launch_mlp_forward(n, samples_per_ray, n / samples_per_ray, nullptr, vertex_indices, barycentric, field,

@@ -52,7 +52,8 @@ constexpr size_t OFF_W2 = OFF_W1 + lfloats(KS1, OT);
 constexpr size_t OFF_W3 = OFF_W2 + lfloats(KSH, OT);
 constexpr size_t OFF_WHEAD = OFF_W3 + lfloats(KSH, OT);
 constexpr size_t OFF_WRGB = OFF_WHEAD + lfloats(HEAD_KS, HEAD_TILES);
-constexpr size_t PACK_FLOATS = OFF_WRGB + lfloats(KSH, 1);
+constexpr size_t OFF_WDENS = OFF_WRGB + lfloats(KSH, 1);   // density head alone (coarse pass: no colour)
+constexpr size_t PACK_FLOATS = OFF_WDENS + lfloats(KSH, 1);
 constexpr size_t MAX_STAGE_FLOATS = lfloats(HEAD_KS, HEAD_TILES);
 
 __host__ __device__ constexpr int acc_feature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -94,10 +95,14 @@ __global__ void k_mlp_pack(MlpWeights w, float *__restrict__ pk, int gather_l1) 
             if (ks >= KSE && ks < HEAD_KS) v = w.wd[acc_k(ks - KSE, h)];
             else if (ks == HEAD_KS) v = h == 0 ? w.bd[0] : 0.f;
         }
-    } else {                                // rgb head: rows 0..2 of a single tile
+    } else if (i < OFF_WDENS) {             // rgb head: rows 0..2 of a single tile
         split(i - OFF_WRGB, 1, ks, ot, lane);
         const int row = lane & 31, h = lane >> 5;
         if (row < 3) v = ks < KSH ? w.wr[(size_t)row * HID + acc_k(ks, h)] : (h == 0 ? w.br[row] : 0.f);
+    } else {                                // density head alone: row 0 of a single tile
+        split(i - OFF_WDENS, 1, ks, ot, lane);
+        const int row = lane & 31, h = lane >> 5;
+        if (row == 0) v = ks < KSH ? w.wd[acc_k(ks, h)] : (h == 0 ? w.bd[0] : 0.f);
     }
     pk[i] = v;
 }
@@ -167,7 +172,7 @@ __device__ __forceinline__ void relu_to_bin(const f32x16 (&acc)[TILES], float (&
 
 }  // namespace
 
-template <bool GATHER>
+template <bool GATHER, bool DENSITY_ONLY>
 __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t samples_per_ray, const float *__restrict__ feats,
                                                            const uint32_t *__restrict__ vi, const float *__restrict__ bc,
                                                            const float *__restrict__ fieldT,
@@ -243,6 +248,20 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t sa
             bias_step<KSH, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);  // mlp_base out_activation = ReLU
         }
+        if constexpr (DENSITY_ONLY) {
+            // coarse pass of the model (model.py:577-581): mlp_base + density head only
+            __syncthreads();
+            stage_weights(lds, pk + OFF_WDENS, lfloats(KSH, 1));
+            __syncthreads();
+            f32x16 acc[1];
+            zero_acc(acc);
+            gemm_steps<KSH, 0, 1>(acc, bin, lds, lane);
+            bias_step<KSH, 1>(acc, lds, lane);
+            const float raw = acc[0][0];
+            const float sp = raw > 20.0f ? raw : log1pf(expf(raw));
+            if (h == 0 && s < n) sigma[s] = sp;
+            continue;
+        }
         // ---- head [enc(27) | base(128)] -> 128 ReLU, with the density head riding as a 5th tile
         __syncthreads();
         stage_weights(lds, pk + OFF_WHEAD, lfloats(HEAD_KS, HEAD_TILES));
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(64) void k_composite(size_t R, uint32_t S, const fl
             float w = (1.0f - expf(-dd)) * expf(-excl);
             if (!(w == w) || !ok) w = 0.f;  // nan_to_num
             if (out_weights && ok) out_weights[q] = w;
-            r0 += w * rgb[3 * q]; r1 += w * rgb[3 * q + 1]; r2 += w * rgb[3 * q + 2];
+            if (rgb) { r0 += w * rgb[3 * q]; r1 += w * rgb[3 * q + 1]; r2 += w * rgb[3 * q + 2]; }
             accw += w;
             // median depth: first sample whose cumulative weight reaches 0.5
             float winc = w;
@@ -340,7 +359,7 @@ __global__ __launch_bounds__(64) void k_composite(size_t R, uint32_t S, const fl
             r0 += __shfl_xor(r0, off); r1 += __shfl_xor(r1, off); r2 += __shfl_xor(r2, off); accw += __shfl_xor(accw, off);
         }
         if (!found) depth = 0.5f * (e[S - 1] + e[S]);  // searchsorted clamps to the last sample
-        if (lane == 0) {
+        if (lane == 0 && out_rgb) {
             out_rgb[3 * ray] = r0 + background * (1.0f - accw);
             out_rgb[3 * ray + 1] = r1 + background * (1.0f - accw);
             out_rgb[3 * ray + 2] = r2 + background * (1.0f - accw);
@@ -357,6 +376,8 @@ void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, con
                         const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream) {
     if (n == 0) return;
     const bool gather = feats == nullptr;
+    const bool density_only = rgb == nullptr;  // coarse pass: no colour head, no direction encoding
+    if (density_only) num_rays = 0;
     float *pk = nullptr, *enc = nullptr, *fieldT = nullptr;
     TN_HIP(hipMallocAsync((void **)&pk, PACK_FLOATS * sizeof(float), stream));
     TN_HIP(hipMallocAsync((void **)&enc, (num_rays ? num_rays : 1) * ENC_PAD * sizeof(float), stream));
@@ -370,19 +391,23 @@ void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, con
     const size_t smem = MAX_STAGE_FLOATS * sizeof(float);  // the largest staged layer (head: 101,120 B)
     static bool attr_set = false;
     if (!attr_set) {
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     const size_t group = (MLP_BLOCK / 64) * 32;
     const size_t ngroups = (n + group - 1) / group;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);  // one 8-wave block per CU
-    if (gather)
-        hipLaunchKernelGGL(k_mlp_forward<true>, dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc,
-                           fieldT, enc, pk, sigma, rgb);
-    else
-        hipLaunchKernelGGL(k_mlp_forward<false>, dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc,
-                           fieldT, enc, pk, sigma, rgb);
+#define TN_MLP_LAUNCH(G, D)                                                                                         \
+    hipLaunchKernelGGL((k_mlp_forward<G, D>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc, \
+                       fieldT, enc, pk, sigma, rgb)
+    if (gather && density_only) TN_MLP_LAUNCH(true, true);
+    else if (gather) TN_MLP_LAUNCH(true, false);
+    else if (density_only) TN_MLP_LAUNCH(false, true);
+    else TN_MLP_LAUNCH(false, false);
+#undef TN_MLP_LAUNCH
     TN_HIP(hipFreeAsync(pk, stream));
     TN_HIP(hipFreeAsync(enc, stream));
     if (fieldT) TN_HIP(hipFreeAsync(fieldT, stream));

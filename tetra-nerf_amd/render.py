@@ -1,11 +1,15 @@
 """Forward render path of the Tetra-NeRF model on top of the HIP ops (inference / evaluation).
 
-Mirrors TetrahedraNerf.get_outputs (/root/reference/tetranerf/nerfstudio/model.py:520-662) for
-the `tetra-nerf-original` evaluation configuration restricted to the coarse pass:
+Mirrors TetrahedraNerf.get_outputs (/root/reference/tetranerf/nerfstudio/model.py:520-662) in
+evaluation mode for both shipped configurations (`tetra-nerf-original`: uniform 256 + PDF 256;
+`tetra-nerf`: biased TetrahedraSampler 128 + PDF 128, registration.py:55-57):
 
-    trace_rays -> nears/fars (:531-544) -> uniform samples (nerfstudio UniformSampler, eval mode:
-    bins = linspace(0,1,S+1), euclidean = near + bins*(far-near)) -> find_visited_cells (:560-567)
-    -> interpolate_values (:569-573) -> mlp_base 64->128->128->128 ReLU (+ReLU out) (:414-455, 602-603)
+    trace_rays -> nears/fars (:531-544) -> coarse samples: nerfstudio UniformSampler (eval:
+    bins = linspace(0,1,S+1), euclidean = near + bins*(far-near)) or the biased TetrahedraSampler
+    (:111-192) -> find_visited_cells (:560-567) -> interpolate_values (:569-573)
+    [num_fine_samples > 0 (:575-600): mlp_base + density head -> get_weights -> PDFSampler
+     (include_original: S + S_fine + 1 samples) -> find_visited_cells -> interpolate_values]
+    -> mlp_base 64->128->128->128 ReLU (+ReLU out) (:414-455, 602-603)
     -> density head 128->1 + softplus, direction encoding (NeRFEncoding 3->27) ++ base -> mlp_head
     155->128 ReLU -> rgb head 128->3 + sigmoid (:605-621) -> weights = alpha * transmittance
     (RaySamples.get_weights) -> rgb over white background, accumulation, median depth (:632-662).
@@ -67,6 +71,65 @@ def uniform_sample_bins(nears: torch.Tensor, fars: torch.Tensor, num_samples: in
     return bins * fars + (1.0 - bins) * nears
 
 
+def biased_sample_bins(nears: torch.Tensor, fars: torch.Tensor, num_samples: int, num_visited_cells: torch.Tensor,
+                       hit_distances: torch.Tensor) -> torch.Tensor:
+    """[R,S+1] euclidean bin edges of the biased TetrahedraSampler in eval mode (model.py:111-192):
+    the uniform edges are re-mapped so that every visited tetrahedron receives the same share of the
+    samples, placed proportionally inside its [t_in, t_out] segment (the mapping stacks the segment
+    lengths from the first entry point; negative lengths -- the cell -1 closing segments -- count 0)."""
+    return map_to_biased(num_visited_cells, hit_distances, uniform_sample_bins(nears, fars, num_samples))
+
+
+def map_to_biased(num_visited_cells: torch.Tensor, hit_distances: torch.Tensor, uni: torch.Tensor) -> torch.Tensor:
+    """map_from_real_distances_to_biased_with_bounds (model.py:111-122) without the in-place clamps."""
+    nb = num_visited_cells.long()
+    lengths = (hit_distances[..., 1] - hit_distances[..., 0]).clamp_min(0)
+    start = hit_distances[..., 0, 0]
+    end = torch.gather(hit_distances[..., 1], 1, (nb[:, None] - 1).clamp_min(0)).squeeze(-1)
+    rest = (uni - start[:, None]) / (end - start)[:, None] * nb[:, None]
+    intervals = rest.floor().clamp_max(nb[:, None] - 1).clamp_min(0)
+    rest = rest - intervals
+    intervals = intervals.long()
+    cum = torch.cumsum(torch.cat((start[:, None], lengths), 1), 1)
+    return torch.gather(cum, 1, intervals) + torch.gather(lengths, 1, intervals) * rest
+
+
+def pdf_sample_bins(spacing_edges: torch.Tensor, weights: torch.Tensor, num_fine: int, nears: torch.Tensor,
+                    fars: torch.Tensor, histogram_padding: float = 0.01, eps: float = 1e-5) -> torch.Tensor:
+    """[R, S + num_fine + 2] euclidean bin edges of nerfstudio's PDFSampler in eval mode with
+    include_original=True (model.py:463,584): inverse-CDF samples of the padded coarse weights at the
+    num_fine+1 bin-centred quantiles, merged with the coarse edges and sorted, then mapped back with
+    spacing_to_euclidean (x*far + (1-x)*near, model.py:177).  spacing_edges [R,S+1] in [0,1], weights [R,S]."""
+    num_bins = num_fine + 1
+    w = weights + histogram_padding
+    wsum = w.sum(-1, keepdim=True)
+    padding = torch.relu(eps - wsum)
+    w = w + padding / w.shape[-1]
+    wsum = wsum + padding
+    pdf = w / wsum
+    cdf = torch.min(torch.ones_like(pdf), torch.cumsum(pdf, dim=-1))
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
+    u = torch.linspace(0.0, 1.0 - (1.0 / num_bins), steps=num_bins, dtype=cdf.dtype, device=cdf.device)
+    u = (u + 1.0 / (2 * num_bins)).expand(*cdf.shape[:-1], num_bins).contiguous()
+    inds = torch.searchsorted(cdf.contiguous(), u, side="right")
+    last = spacing_edges.shape[-1] - 1
+    below, above = (inds - 1).clamp(0, last), inds.clamp(0, last)
+    cdf0, cdf1 = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)
+    b0, b1 = torch.gather(spacing_edges, -1, below), torch.gather(spacing_edges, -1, above)
+    t = torch.clip(torch.nan_to_num((u - cdf0) / (cdf1 - cdf0), 0), 0, 1)
+    bins = b0 + t * (b1 - b0)
+    bins, _ = torch.sort(torch.cat([spacing_edges, bins], -1), -1)
+    return bins * fars + (1.0 - bins) * nears
+
+
+def ray_weights(sigma: torch.Tensor, edges: torch.Tensor) -> torch.Tensor:
+    """RaySamples.get_weights on [R,S] densities and [R,S+1] edges."""
+    dd = (edges[:, 1:] - edges[:, :-1]) * sigma
+    trans = torch.cumsum(dd[:, :-1], dim=-1)
+    trans = torch.cat([torch.zeros_like(trans[:, :1]), trans], dim=-1)
+    return torch.nan_to_num((1.0 - torch.exp(-dd)) * torch.exp(-trans))
+
+
 def composite(sigma: torch.Tensor, rgb: torch.Tensor, starts: torch.Tensor, ends: torch.Tensor,
               background: float = 1.0):
     """RaySamples.get_weights + RGBRenderer(white) + AccumulationRenderer + DepthRenderer(median).
@@ -89,8 +152,8 @@ def composite(sigma: torch.Tensor, rgb: torch.Tensor, starts: torch.Tensor, ends
 
 def render_reference(tracer, interpolate_values, field: torch.Tensor, mlp: TetraMLP, origins: torch.Tensor,
                      directions: torch.Tensor, num_samples: int = 256, max_ray_triangles: int = 512,
-                     far_plane: float = 1000.0) -> Dict[str, torch.Tensor]:
-    """Plain-PyTorch statement of the coarse render path; `tracer` needs trace_rays /
+                     far_plane: float = 1000.0, num_fine_samples: int = 0, biased: bool = False) -> Dict[str, torch.Tensor]:
+    """Plain-PyTorch statement of the render path; `tracer` needs trace_rays /
     find_visited_cells returning tensors, `interpolate_values(vi, bc, field)` the gather."""
     out = tracer.trace_rays(origins.contiguous(), directions.contiguous(), max_ray_triangles)
     nv = out["num_visited_cells"]
@@ -102,15 +165,30 @@ def render_reference(tracer, interpolate_values, field: torch.Tensor, mlp: Tetra
     acc = torch.zeros((R, 1), dtype=torch.float32, device=origins.device)
     depth = torch.full((R, 1), far_plane, dtype=torch.float32, device=origins.device)
     if bool(ray_mask.any()):
-        edges = uniform_sample_bins(nears[ray_mask], fars[ray_mask], num_samples)
+        lists = [out[k][ray_mask].contiguous() for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates",
+                                                         "hit_distances", "vertex_indices")]
+        near_r, far_r = nears[ray_mask], fars[ray_mask]
+
+        def features(edges):
+            dist = ((edges[:, 1:] + edges[:, :-1]) / 2).contiguous()
+            traced = tracer.find_visited_cells(*lists, dist)
+            return interpolate_values(traced["vertex_indices"], traced["barycentric_coordinates"], field)
+
+        if biased:
+            edges = biased_sample_bins(near_r, far_r, num_samples, lists[0], lists[3])
+        else:
+            edges = uniform_sample_bins(near_r, far_r, num_samples)
+        feats = features(edges)
+        if num_fine_samples > 0:
+            x = feats
+            for lin in mlp.base:
+                x = torch.relu(lin(x))
+            sigma_c = torch.nn.functional.softplus(mlp.density(x))[..., 0]
+            spacing = (edges - near_r) / (far_r - near_r)
+            edges = pdf_sample_bins(spacing, ray_weights(sigma_c, edges), num_fine_samples, near_r, far_r)
+            feats = features(edges)
         starts, ends = edges[:, :-1, None], edges[:, 1:, None]
-        dist = ((ends + starts) / 2).squeeze(-1).contiguous()
-        traced = tracer.find_visited_cells(nv[ray_mask].contiguous(), out["visited_cells"][ray_mask].contiguous(),
-                                           out["barycentric_coordinates"][ray_mask].contiguous(),
-                                           out["hit_distances"][ray_mask].contiguous(),
-                                           out["vertex_indices"][ray_mask].contiguous(), dist)
-        feats = interpolate_values(traced["vertex_indices"], traced["barycentric_coordinates"], field)
-        dirs = directions[ray_mask][:, None, :].expand(-1, num_samples, -1)
+        dirs = directions[ray_mask][:, None, :].expand(-1, edges.shape[1] - 1, -1)
         sigma, col = mlp(feats, dirs)
         rgb_r, acc_r, depth_r, _ = composite(sigma, col, starts, ends)
         rgb[ray_mask] = rgb_r
@@ -131,19 +209,21 @@ class TetraRenderer:
     composite kernel).  With `fused=False` the MLP and the composite run in PyTorch on the GPU."""
 
     def __init__(self, tracer, field: torch.Tensor, mlp: TetraMLP, num_samples: int = 256,
-                 max_ray_triangles: int = 512, fused: bool = True, far_plane: float = 1000.0):
+                 max_ray_triangles: int = 512, fused: bool = True, far_plane: float = 1000.0,
+                 num_fine_samples: int = 0, biased: bool = False):
         from . import tetranerf_cpp_extension as cpp
 
         self.cpp = cpp
         self.tracer, self.field, self.mlp = tracer, field, mlp
         self.S, self.M, self.fused, self.far_plane = int(num_samples), int(max_ray_triangles), fused, far_plane
+        self.S_fine, self.biased = int(num_fine_samples), bool(biased)
 
     @torch.no_grad()
     def render(self, origins: torch.Tensor, directions: torch.Tensor) -> Dict[str, torch.Tensor]:
         cpp, S = self.cpp, self.S
         if not self.fused:
             return render_reference(self.tracer, cpp.interpolate_values, self.field, self.mlp, origins, directions,
-                                    S, self.M, self.far_plane)
+                                    S, self.M, self.far_plane, self.S_fine, self.biased)
         out = self.tracer.trace_rays(origins.contiguous(), directions.contiguous(), self.M)
         nv = out["num_visited_cells"]
         nears = out["hit_distances"][:, 0, 0][:, None]
@@ -155,15 +235,34 @@ class TetraRenderer:
         depth = torch.full((R, 1), self.far_plane, dtype=torch.float32, device=dev)
         idx = torch.nonzero(ray_mask)[:, 0]
         if idx.numel():
-            edges = uniform_sample_bins(nears[idx], fars[idx], S).contiguous()
-            dist = ((edges[:, 1:] + edges[:, :-1]) / 2).contiguous()
-            traced = self.tracer.find_visited_cells(nv[idx].contiguous(), out["visited_cells"][idx].contiguous(),
-                                                    out["barycentric_coordinates"][idx].contiguous(),
-                                                    out["hit_distances"][idx].contiguous(),
-                                                    out["vertex_indices"][idx].contiguous(), dist)
+            all_rays = idx.numel() == R
+            lists = [out[k] if all_rays else out[k][idx].contiguous()
+                     for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates", "hit_distances",
+                               "vertex_indices")]
+            near_r, far_r = nears[idx], fars[idx]
+            w = mlp_weights(self.mlp)
+
+            def locate(edges):
+                dist = ((edges[:, 1:] + edges[:, :-1]) / 2).contiguous()
+                return self.tracer.find_visited_cells(*lists, dist)
+
+            if self.biased:
+                edges = biased_sample_bins(near_r, far_r, S, lists[0], lists[3]).contiguous()
+            else:
+                edges = uniform_sample_bins(near_r, far_r, S).contiguous()
+            traced = locate(edges)
+            if self.S_fine > 0:
+                # coarse pass: gather + mlp_base + density head in one kernel, weights in one more
+                sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
+                                                 None, w, S)
+                weights_c = cpp.composite(sigma_c.view(-1, S), None, edges)
+                spacing = (edges - near_r) / (far_r - near_r)
+                edges = pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r).contiguous()
+                traced = locate(edges)
+                S = edges.shape[1] - 1
             # gather + MLP + heads in one kernel (no [64, n] feature buffer)
             sigma, col = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
-                                                directions[idx].contiguous(), mlp_weights(self.mlp), S)
+                                                directions[idx].contiguous(), w, S)
             rgb_r, acc_r, depth_r = cpp.composite(sigma.view(-1, S), col.view(-1, S, 3), edges)
             rgb[idx] = rgb_r
             acc[idx] = acc_r

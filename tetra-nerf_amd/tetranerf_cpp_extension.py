@@ -337,9 +337,11 @@ def _weights_struct(weights):
 def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray):
     """interpolate_values + mlp_forward in ONE kernel: the wave gathers its samples' features from the
     field straight into MFMA operand registers; the [64, n] feature buffer is never written.
-    vertex_indices i32 [..., 4], barycentric_coordinates f32 [..., 3], field f32 [64, V]."""
+    vertex_indices i32 [..., 4], barycentric_coordinates f32 [..., 3], field f32 [64, V].
+    dirs=None: density only (the coarse pass of the model, model.py:577-581) -> sigma [n]."""
+    density_only = dirs is None
     for x, name in ((vertex_indices, "vertex_indices"), (barycentric_coordinates, "barycentric_coordinates"),
-                    (field, "field"), (dirs, "dirs")):
+                    (field, "field")) + (() if density_only else ((dirs, "dirs"),)):
         _check_input(x, name)
     _check(vertex_indices.dtype == torch.int32 and vertex_indices.size(-1) == 4, "vertex_indices must be i32 [...,4]")
     _check(barycentric_coordinates.dtype == torch.float32 and barycentric_coordinates.size(-1) == 3,
@@ -348,26 +350,34 @@ def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, wei
     n = vertex_indices.numel() // 4
     S = int(samples_per_ray)
     _check(S > 0 and n % S == 0, "n must be a multiple of samples_per_ray")
-    _check(dirs.dtype == torch.float32 and tuple(dirs.shape) == (n // S, 3), "dirs must be f32 [n/samples_per_ray, 3]")
+    _check(density_only or (dirs.dtype == torch.float32 and tuple(dirs.shape) == (n // S, 3)),
+           "dirs must be f32 [n/samples_per_ray, 3]")
     st, keep = _weights_struct(weights)
     dev = field.device
     sigma = torch.empty((n,), dtype=torch.float32, device=dev)
-    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    rgb = None if density_only else torch.empty((n, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.load().tn_mlp_forward_gather(n, S, field.size(1), _ptr(vertex_indices), _ptr(barycentric_coordinates),
                                                      _ptr(field), _ptr(dirs), C.byref(st), _ptr(sigma), _ptr(rgb), _stream(dev)))
-    return sigma, rgb
+    return sigma if density_only else (sigma, rgb)
 
 
 def composite(sigma, rgb, edges, background=1.0, return_weights=False):
     """RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers
-    (model.py:632-638) in one kernel.  sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1]."""
-    for x, name in ((sigma, "sigma"), (rgb, "rgb"), (edges, "edges")):
+    (model.py:632-638) in one kernel.  sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1].
+    rgb=None: only the weights [R,S] are computed and returned (get_weights of the coarse pass, model.py:582)."""
+    for x, name in ((sigma, "sigma"), (edges, "edges")) + (() if rgb is None else ((rgb, "rgb"),)):
         _check_input(x, name)
         _check(x.dtype == torch.float32, f"{name} must have float32 type")
     R, S = sigma.shape
-    _check(tuple(rgb.shape) == (R, S, 3) and tuple(edges.shape) == (R, S + 1), "shape mismatch")
+    _check((rgb is None or tuple(rgb.shape) == (R, S, 3)) and tuple(edges.shape) == (R, S + 1), "shape mismatch")
     dev = sigma.device
+    if rgb is None:
+        weights = torch.empty((R, S), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), None, _ptr(edges), float(background), None, None, None,
+                                                _ptr(weights), _stream(dev)))
+        return weights
     out_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
     acc = torch.empty((R, 1), dtype=torch.float32, device=dev)
     depth = torch.empty((R, 1), dtype=torch.float32, device=dev)
