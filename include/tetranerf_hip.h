@@ -124,6 +124,13 @@ int tn_interpolate_values_backward(uint32_t interpolation_dim, uint32_t num_vert
                                    const uint32_t *vertex_indices, const float *barycentric,
                                    const float *grad_in, float *field_grad_out, void *stream);
 
+/* The same with the gradient in the layout autograd hands over, grad_rows f32 [n,F] (sample-major):
+ * saves the transposed copy of py_binding.cpp:369 (addition to the reference surface). */
+int tn_interpolate_values_backward_rows(uint32_t interpolation_dim, uint32_t num_vertices,
+                                        uint32_t num_values, uint32_t field_dim,
+                                        const uint32_t *vertex_indices, const float *barycentric,
+                                        const float *grad_rows, float *field_grad_out, void *stream);
+
 /* Test aid: run only the dedupe / pairing / tail-fill stage
  * (post_process_tetrahedra, src/optix/optix_trace_rays.cu:110-266) on caller-supplied
  * sorted hit rows: hit_count u32 [R], hit_ids u32 [R,M], hit_t f32 [R,M], hit_uv f32 [R,M,2]. */

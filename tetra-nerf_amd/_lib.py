@@ -16,7 +16,8 @@ SYMBOLS = (
     "tn_last_error", "tn_version", "tn_tracer_create", "tn_tracer_destroy", "tn_load_tetrahedra",
     "tn_num_faces", "tn_get_faces", "tn_trace_rays", "tn_trace_rays_triangles", "tn_find_tetrahedra",
     "tn_find_matched_cells",
-    "tn_interpolate_values", "tn_interpolate_values_backward", "tn_postprocess_hits",
+    "tn_interpolate_values", "tn_interpolate_values_backward", "tn_interpolate_values_backward_rows",
+    "tn_postprocess_hits",
     "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
 )
 
@@ -50,6 +51,7 @@ def load():
     lib.tn_find_matched_cells.argtypes = [sz, sz, sz] + [vp] * 11
     lib.tn_interpolate_values.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
     lib.tn_interpolate_values_backward.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
+    lib.tn_interpolate_values_backward_rows.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
     lib.tn_postprocess_hits.argtypes = [vp, sz, u32] + [vp] * 10
     lib.tn_trace_stats.argtypes = [vp, C.POINTER(C.c_uint64 * 4)]
     lib.tn_trace_flag_reasons.argtypes = [vp, C.POINTER(C.c_uint64 * 16)]

@@ -59,6 +59,7 @@ struct tn_tracer {
     hipStream_t side = nullptr;          // tail-fill stream (overlaps the walk of the next chunk)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chunk[kEvents] = {};
     size_t chunk_rays = 65536;           // rays per walk launch when pipelining
+    unsigned fill_blocks = 0;            // cap of the tail-fill grid (0 = default); throttle knob of mode 2
     int mode = 1;                        // launch structure of the walk path (see tn_trace_rays)
     tn::DevBuf<tn::TetRec> tets;
     tn::DevBuf<float> hull_nodes, hull_tris;
@@ -314,7 +315,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                     TN_HIP(hipEventRecord(ev, stream));
                     TN_HIP(hipStreamWaitEvent(t->side, ev, 0));
                     tn::launch_fill_tails(n, M, w.walk_n, w.t.out_cells, w.t.out_bary, w.t.out_dist, w.t.out_verts,
-                                          t->side);
+                                          t->side, false, t->fill_blocks);
                 }
             }
             p.ray_list = t->fallback_list.p;
@@ -430,6 +431,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && std::strcmp(name, "debug") == 0) t->debug = (uint32_t)value;
         else if (name && std::strcmp(name, "gdebug") == 0) t->gdebug = (uint32_t)value;
         else if (name && std::strcmp(name, "mode") == 0) t->mode = value;
+        else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
         else if (name && std::strcmp(name, "chunk_rays") == 0) t->chunk_rays = value >= 256 ? (size_t)value : 256;
         else throw tn::Error(std::string("unknown option ") + (name ? name : "(null)"));
     });
@@ -460,7 +462,15 @@ int tn_interpolate_values(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const
 int tn_interpolate_values_backward(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
                                    const float *bc, const float *grad_in, float *field_grad_out, void *stream_) {
     return guarded([&] {
-        tn::launch_interpolate_values_backward(D, V, n, Fd, vi, bc, grad_in, field_grad_out, (hipStream_t)stream_);
+        tn::launch_interpolate_values_backward(D, V, n, Fd, vi, bc, grad_in, false, field_grad_out, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_interpolate_values_backward_rows(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
+                                        const float *bc, const float *grad_rows, float *field_grad_out, void *stream_) {
+    return guarded([&] {
+        tn::launch_interpolate_values_backward(D, V, n, Fd, vi, bc, grad_rows, true, field_grad_out, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }

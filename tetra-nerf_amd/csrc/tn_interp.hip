@@ -13,9 +13,9 @@
 // The per-element summation order of the reference is kept, so the forward result is
 // bit-identical to the CPU oracle:
 //     out = ((b0*f[v1] + b1*f[v2]) + ...) + (1 - ((b0+b1)+...)) * f[v0],  EMPTY ids skipped.
-// Backward: LANE = FEATURE again; 64 lanes add to 64 consecutive floats of a vertex-major
-// gradient (one cache line per atomic instruction), with run-length combining of consecutive
-// samples that hit the same vertex tuple; the result is transposed back to [Fd, V].
+// Backward: LANE = FEATURE; 64 lanes add to 64 consecutive floats of a vertex-major gradient (one
+// cache line per atomic instruction), with run-length combining of consecutive samples that hit the
+// same vertex tuple; the result is transposed back to [Fd, V].
 #include "tn_device.h"
 #include "tn_kernels.h"
 
@@ -98,74 +98,63 @@ __global__ __launch_bounds__(256) void k_interp_fwd(uint32_t n, uint32_t Fd, con
     }
 }
 
+// Backward: one wavefront = 64 consecutive samples, LANE = FEATURE.  The incoming gradient is read
+// sample-major ([n, Fd] rows: one coalesced 256-B load per sample at Fd = 64); vertex ids and weights
+// are wave-uniform and come through scalar loads; consecutive samples with the same vertex tuple
+// (same tetrahedron along the ray) are combined in registers, and each flush is D atomic instructions
+// whose 64 lanes hit 64 consecutive floats of the vertex-major gradient (one or two cache lines).
 template <int D>
-__global__ __launch_bounds__(64) void k_interp_bwd(uint32_t n, uint32_t Fd, const uint32_t *__restrict__ vi,
-                                                   const float *__restrict__ bc, const float *__restrict__ grad_in,
-                                                   float *__restrict__ gradT) {
-    __shared__ float tile[TS][TP];
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_interp_bwd(uint32_t n, uint32_t Fd, const uint32_t *__restrict__ vi,
+                                                    const float *__restrict__ bc,
+                                                    const float *__restrict__ grad_rows, float *__restrict__ gradT) {
+    constexpr int B = 8;  // samples whose gradient rows are in flight together
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     const uint32_t ntiles = (n + TS - 1) / TS;
-    for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    for (uint32_t tix = wave; tix < ntiles; tix += nwaves) {
         const uint32_t base = tix * TS;
         const uint32_t cnt = n - base < TS ? n - base : TS;
-        uint32_t myv[D];
-        float myb[D - 1];
-#pragma unroll
-        for (int k = 0; k < D; ++k) myv[k] = TN_EMPTY;
-#pragma unroll
-        for (int k = 0; k < D - 1; ++k) myb[k] = 0.f;
-        if ((uint32_t)lane < cnt) {
-            const size_t i = base + lane;
-#pragma unroll
-            for (int k = 0; k < D; ++k) myv[k] = vi[i * D + k];
-#pragma unroll
-            for (int k = 0; k < D - 1; ++k) myb[k] = bc[i * (D - 1) + k];
-        }
         for (uint32_t f0 = 0; f0 < Fd; f0 += 64) {
-            const uint32_t fcnt = Fd - f0 < 64 ? Fd - f0 : 64;
-            // grad_in [Fd, n]: rows of 64 consecutive samples -> tile[sample][feature]
-            if ((uint32_t)lane < cnt)
-                for (uint32_t j = 0; j < fcnt; ++j) tile[lane][j] = grad_in[(size_t)(f0 + j) * n + base + lane];
-            __syncthreads();
             const uint32_t f = f0 + lane;
             const bool fok = f < Fd;
-            // run-length combine: accumulate while the vertex tuple repeats
             uint32_t cur[D];
             float acc[D];
 #pragma unroll
             for (int k = 0; k < D; ++k) { cur[k] = TN_EMPTY; acc[k] = 0.f; }
-            for (uint32_t s = 0; s <= cnt; ++s) {
-                uint32_t v[D];
-                float wgt[D];
-                bool same = s < cnt;
-                if (s < cnt) {
+            for (uint32_t s0 = 0; s0 < cnt; s0 += B) {
+                float g[B];
+#pragma unroll
+                for (int j = 0; j < B; ++j)
+                    g[j] = (s0 + j < cnt && fok) ? grad_rows[(size_t)(base + s0 + j) * Fd + f] : 0.f;
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    if (s0 + j >= cnt) break;
+                    const size_t i = base + s0 + j;
+                    uint32_t v[D];
+                    float wgt[D];
                     float w = 0.f;
+                    bool same = true;
 #pragma unroll
-                    for (int k = 0; k < D - 1; ++k) {
-                        wgt[k + 1] = __shfl(myb[k], s);
-                        w += wgt[k + 1];
-                    }
+                    for (int k = 0; k < D; ++k) { v[k] = vi[i * D + k]; same = same && (v[k] == cur[k]); }
+#pragma unroll
+                    for (int k = 0; k < D - 1; ++k) { wgt[k + 1] = bc[i * (D - 1) + k]; w += wgt[k + 1]; }
                     wgt[0] = 1.0f - w;
+                    if (!same) {  // wave-uniform
 #pragma unroll
-                    for (int k = 0; k < D; ++k) { v[k] = __shfl(myv[k], s); same = same && (v[k] == cur[k]); }
-                }
-                if (!same) {
-                    // flush (wave-uniform branch: ids are broadcast values)
-#pragma unroll
-                    for (int k = 0; k < D; ++k)
-                        if (cur[k] != TN_EMPTY && fok) atomicAdd(&gradT[(size_t)cur[k] * Fd + f], acc[k]);
-                    if (s < cnt) {
-#pragma unroll
-                        for (int k = 0; k < D; ++k) { cur[k] = v[k]; acc[k] = 0.f; }
+                        for (int k = 0; k < D; ++k) {
+                            if (cur[k] != TN_EMPTY && fok) atomicAdd(&gradT[(size_t)cur[k] * Fd + f], acc[k]);
+                            cur[k] = v[k];
+                            acc[k] = 0.f;
+                        }
                     }
-                }
-                if (s < cnt) {
-                    const float g = tile[s][lane];
 #pragma unroll
-                    for (int k = 0; k < D; ++k) acc[k] += wgt[k] * g;
+                    for (int k = 0; k < D; ++k) acc[k] += wgt[k] * g[j];
                 }
             }
-            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                if (cur[k] != TN_EMPTY && fok) atomicAdd(&gradT[(size_t)cur[k] * Fd + f], acc[k]);
         }
     }
 }
@@ -182,15 +171,25 @@ void run_fwd(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const floa
     TN_HIP(hipFreeAsync(fieldT, stream));
 }
 
+// rows_major: grad_in is [n, Fd] (what autograd hands over for a contiguous [..., Fd] gradient);
+// otherwise the reference's native layout [Fd, n] (tetrahedra_tracer.h:404-411), transposed first.
 template <int D>
 void run_bwd(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc, const float *grad_in,
-             float *field_grad, hipStream_t stream) {
-    float *gradT = nullptr;
+             bool rows_major, float *field_grad, hipStream_t stream) {
+    float *gradT = nullptr, *rows = nullptr;
     TN_HIP(hipMallocAsync((void **)&gradT, (size_t)V * Fd * sizeof(float), stream));
     TN_HIP(hipMemsetAsync(gradT, 0, (size_t)V * Fd * sizeof(float), stream));
-    const uint32_t ntiles = (n + TS - 1) / TS;
-    const unsigned grid = ntiles < 256u * 32u ? ntiles : 256u * 32u;
-    if (n) hipLaunchKernelGGL(k_interp_bwd<D>, dim3(grid), dim3(64), 0, stream, n, Fd, vi, bc, grad_in, gradT);
+    if (n) {
+        if (!rows_major) {
+            TN_HIP(hipMallocAsync((void **)&rows, (size_t)n * Fd * sizeof(float), stream));
+            hipLaunchKernelGGL(k_transpose, dim3((n + 63) / 64, (Fd + 63) / 64), dim3(256), 0, stream, grad_in, rows, Fd, n);
+            grad_in = rows;
+        }
+        const uint32_t nblocks = ((n + TS - 1) / TS + 3) / 4;  // 4 waves per block
+        const unsigned grid = nblocks < 256u * 32u ? nblocks : 256u * 32u;
+        hipLaunchKernelGGL(k_interp_bwd<D>, dim3(grid), dim3(256), 0, stream, n, Fd, vi, bc, grad_in, gradT);
+        if (rows) TN_HIP(hipFreeAsync(rows, stream));
+    }
     hipLaunchKernelGGL(k_transpose, dim3((Fd + 63) / 64, (V + 63) / 64), dim3(256), 0, stream, gradT, field_grad, V, Fd);
     TN_HIP(hipFreeAsync(gradT, stream));
 }
@@ -215,14 +214,14 @@ void launch_interpolate_values(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, 
 }
 
 void launch_interpolate_values_backward(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
-                                        const float *bc, const float *grad_in, float *field_grad,
+                                        const float *bc, const float *grad_in, bool rows_major, float *field_grad,
                                         hipStream_t stream) {
     if (Fd == 0 || V == 0) return;
     switch (D) {
-        case 2: run_bwd<2>(V, n, Fd, vi, bc, grad_in, field_grad, stream); break;
-        case 3: run_bwd<3>(V, n, Fd, vi, bc, grad_in, field_grad, stream); break;
-        case 4: run_bwd<4>(V, n, Fd, vi, bc, grad_in, field_grad, stream); break;
-        case 6: run_bwd<6>(V, n, Fd, vi, bc, grad_in, field_grad, stream); break;
+        case 2: run_bwd<2>(V, n, Fd, vi, bc, grad_in, rows_major, field_grad, stream); break;
+        case 3: run_bwd<3>(V, n, Fd, vi, bc, grad_in, rows_major, field_grad, stream); break;
+        case 4: run_bwd<4>(V, n, Fd, vi, bc, grad_in, rows_major, field_grad, stream); break;
+        case 6: run_bwd<6>(V, n, Fd, vi, bc, grad_in, rows_major, field_grad, stream); break;
         default: throw Error("Unsupported interpolation dimension with value " + std::to_string(D));
     }
 }

@@ -20,7 +20,7 @@ struct TraceParams {
     const uint32_t *ray_list;  // optional indirection: item -> ray index
     const uint32_t *item_count; // optional device-side item count (overrides num_items in-kernel)
     unsigned long long *stats; // [4] device counters or null
-    uint32_t gdebug;           // ablation of the general kernel (bench only): 1 stop after traversal, 2 skip sort
+    uint32_t gdebug;           // ablation of the general kernel (bench only): 1 stop after traversal, 2 skip sort, 8 count node/leaf visits in stats[18]/[19]
 };
 
 // general all-hits path, one wavefront per ray (tn_trace_general.hip)
@@ -51,7 +51,7 @@ struct WalkParams {
 void launch_trace_walk(const WalkParams &p, hipStream_t stream);
 // constant tails [n, M) of the rows certified by the walk (n = walk_n[ray] != TN_EMPTY)
 void launch_fill_tails(size_t num_rays, uint32_t M, const uint32_t *walk_n, uint32_t *out_cells, float *out_bary,
-                       float *out_dist, uint32_t *out_verts, hipStream_t stream, bool nontemporal = false);
+                       float *out_dist, uint32_t *out_verts, hipStream_t stream, bool nontemporal = false, unsigned max_blocks = 0);
 
 // sample -> segment matching (tn_match.hip)
 void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,
@@ -63,7 +63,7 @@ void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num
 void launch_interpolate_values(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
                                const float *bc, const float *field, float *result, hipStream_t stream);
 void launch_interpolate_values_backward(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
-                                        const float *bc, const float *grad_in, float *field_grad,
+                                        const float *bc, const float *grad_in, bool rows_major, float *field_grad,
                                         hipStream_t stream);
 
 // shallow MLP + heads (tn_mlp.hip); all weights in nn.Linear layout [out, in] row-major, fp32

@@ -342,7 +342,9 @@ __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
         const size_t ray = p.ray_list ? (size_t)p.ray_list[it] : it;
         bool overflow = false;
         uint32_t nh = collect_hits(p.bvh, s, M, cap, p.origins[3 * ray], p.origins[3 * ray + 1], p.origins[3 * ray + 2],
-                                   p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2], p.stats, lane, overflow);
+                                   p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2],
+                                   (p.gdebug & 8u) ? p.stats : nullptr /* visit counters: same-address atomics, debug only */,
+                                   lane, overflow);
         if (overflow && lane == 0 && p.stats) atomicAdd(&p.stats[3], 1ull);
 
         if (p.gdebug & 1u) nh = 0;

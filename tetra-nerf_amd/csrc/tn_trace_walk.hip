@@ -428,10 +428,11 @@ __global__ __launch_bounds__(256) void k_fill_tails(size_t num_rays, uint32_t M,
 }
 
 void launch_fill_tails(size_t num_rays, uint32_t M, const uint32_t *walk_n, uint32_t *out_cells, float *out_bary,
-                       float *out_dist, uint32_t *out_verts, hipStream_t stream, bool nontemporal) {
+                       float *out_dist, uint32_t *out_verts, hipStream_t stream, bool nontemporal, unsigned max_blocks) {
     if (num_rays == 0) return;
     size_t blocks = (num_rays + 3) / 4;           // >= one ray per wave
-    if (blocks > 256 * 8) blocks = 256 * 8;       // 8 blocks (32 waves) per CU
+    const size_t cap = max_blocks ? max_blocks : 256 * 8;  // default: 8 blocks (32 waves) per CU
+    if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) & ~(size_t)7;
     if (nontemporal)
         hipLaunchKernelGGL(k_fill_tails<true>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, walk_n, out_cells,

@@ -275,12 +275,17 @@ def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, 
     n = vertex_indices.numel() // D
     Fd, V = field.size(0), field.size(-1)
     _check(grad_in.size(-1) == Fd, "grad_in must have shape [..., field_dim]")
-    g = grad_in.moveaxis(-1, 0).contiguous()
     grad_field_out = torch.empty((Fd, V), dtype=grad_in.dtype, device=grad_in.device)
+    lib = _lib.load()
+    if grad_in.moveaxis(-1, 0).is_contiguous():
+        # the reference's layout: a [Fd, n] buffer viewed as [..., Fd] (what py_binding.cpp:369 produces)
+        fn, g = lib.tn_interpolate_values_backward, grad_in.moveaxis(-1, 0)
+    else:
+        # sample-major rows, the usual autograd gradient: consumed as is (no transposed copy)
+        fn, g = lib.tn_interpolate_values_backward_rows, grad_in.contiguous()
     with torch.cuda.device(field.device):
-        _lib.check(_lib.load().tn_interpolate_values_backward(
-            D, V, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates), _ptr(g), _ptr(grad_field_out),
-            _stream(field.device)))
+        _lib.check(fn(D, V, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates), _ptr(g), _ptr(grad_field_out),
+                      _stream(field.device)))
     return grad_field_out
 
 
