@@ -250,10 +250,31 @@ def main():
                 "kernel": "trace_rays launch (walk + general fallback)",
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
+                "frac_of_measured_write_ceiling_5500": achieved / 5500.0,  # torch fill_ of 15 GB, profiles/r01_overlap_sweep.txt
             },
             "trace_path_stats": stats,
             "load_tetrahedra_s": load_s,
         }
+        # secondary figure of SURVEY.md 8(d): the same launch without the constant tails of the dense
+        # reference layout ("dense_tails" = 0; rows valid through num_visited only) -- what a
+        # non-materialising consumer (find_visited_cells, the render path) needs
+        tracer.set_option("dense_tails", 0)
+        step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        tracer.set_option("dense_tails", 1)
+        seg_ms = e0.elapsed_time(e1) / args.steps
+        seg_bytes = 28 * R + 52 * inter
+        line["segments_only"] = {"ms_per_step": seg_ms, "rays_per_s": R / (seg_ms * 1e-3),
+                                 "intersections_per_s": inter / (seg_ms * 1e-3),
+                                 "algorithmic_bytes_per_launch": seg_bytes,
+                                 "achieved_GBps": seg_bytes / (seg_ms * 1e-3) / 1e9,
+                                 "note": "non-reference option dense_tails=0: 28 B/ray + 52 B/segment; latency-bound walk"}
         if not args.no_render:
             line["render"] = render_leg(tn, tracer, len(pts), o, d, M, dev)
         if not args.no_cpu_baseline:

@@ -154,7 +154,13 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
 
 /* knobs (also settable through the environment):
  *   "walk"    1 = adjacency-walk fast path with general-path fallback (default when built),
- *             0 = general all-hits path for every ray */
+ *             0 = general all-hits path for every ray, 2 = walk for any batch size
+ *   "walk_min_rays"  smallest batch the walk is used for (default 16384; below it one wavefront per
+ *             ray through the wide BVH has the lower latency)
+ *   "dense_tails"  1 (default) = every slot of the [R,M] rows is written, as the reference does;
+ *             0 = slots >= num_visited[r] of walked rows are left UNWRITTEN (non-reference: for callers
+ *             that only read rows through num_visited, e.g. tn_find_matched_cells; saves ~88 % of the bytes)
+ *   "mode", "chunk_rays", "fill_blocks", "debug", "gdebug": launch-structure / ablation knobs (profiles/) */
 int tn_set_option(tn_tracer_t tracer, const char *name, int value);
 
 /* gather_uint32<T> / scatter_ema_uint32<T>              src/tetrahedra_tracer.cu:30-113,

@@ -115,3 +115,38 @@ def test_walk_handles_small_M_and_misses(tn, device, oracle, scenes):
         got = _trace(tr, device, o, d, M)
         for k in KEYS:
             assert _bits_equal(got[k], want[k]), f"M={M}: {k}"
+
+
+def test_dense_tails_off_keeps_the_valid_prefix(tn, device, scenes):
+    """Non-reference option dense_tails=0: slots < num_visited are bit-identical to the dense result,
+    slots beyond stay untouched on walked rows (here: the sentinel the test pre-fills... torch.empty
+    is not controllable, so only the prefix is compared), and find_visited_cells -- which reads rows
+    through num_visited only -- returns identical matches."""
+    import torch
+
+    pts, cells = scenes.random_mesh(4000, 5)
+    tr = _tracer(tn, device, pts, cells, 1)
+    o, d = scenes.outside_in_rays(40000, 3)
+    to, td = torch.from_numpy(o).to(device), torch.from_numpy(d).to(device)
+    M = 128
+    dense = tr.trace_rays(to, td, M)
+    tr.set_option("dense_tails", 0)
+    lean = tr.trace_rays(to, td, M)
+    tr.set_option("dense_tails", 1)
+    n = dense["num_visited_cells"]
+    assert torch.equal(n, lean["num_visited_cells"])
+    valid = torch.arange(M, device=device)[None] < n[:, None]
+    for k in KEYS[1:]:
+        a, b = dense[k], lean[k]
+        m = valid.reshape(valid.shape + (1,) * (a.dim() - 2)).expand_as(a)
+        assert torch.equal(a[m].view(torch.int32), b[m].view(torch.int32)), k
+    hit = n > 0
+    near = dense["hit_distances"][:, 0, 0]
+    far = torch.gather(dense["hit_distances"][:, :, 1], 1, (n[:, None].long() - 1).clamp_min(0))[:, 0]
+    ts = torch.linspace(0, 1, 64, device=device)[None]
+    dist = torch.where(hit[:, None], near[:, None] * (1 - ts) + far[:, None] * ts, ts).contiguous()
+    args = lambda r: (r["num_visited_cells"], r["visited_cells"], r["barycentric_coordinates"], r["hit_distances"],
+                      r["vertex_indices"], dist)
+    m1, m2 = tr.find_visited_cells(*args(dense)), tr.find_visited_cells(*args(lean))
+    for k in m1:
+        assert torch.equal(m1[k], m2[k]), k

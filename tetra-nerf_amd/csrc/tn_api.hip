@@ -59,6 +59,7 @@ struct tn_tracer {
     hipStream_t side = nullptr;          // tail-fill stream (overlaps the walk of the next chunk)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chunk[kEvents] = {};
     size_t chunk_rays = 65536;           // rays per walk launch when pipelining
+    bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
     unsigned fill_blocks = 0;            // cap of the tail-fill grid (0 = default); throttle knob of mode 2
     int mode = 1;                        // launch structure of the walk path (see tn_trace_rays)
     tn::DevBuf<tn::TetRec> tets;
@@ -278,7 +279,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             TN_HIP(hipMemsetAsync(t->fallback_count.p, 0, sizeof(uint32_t), stream));
             // mode 0: one launch, the walk kernel writes its own tails; mode 1: walk launch, then one
             // tail launch on the same stream; mode 2: chunked, tails on the side stream
-            const int mode = (t->debug & 1u) ? 0 : (R < 8192 ? 0 : t->mode);
+            const int mode = (t->debug & 1u) ? 0 : (R < 8192 && t->dense_tails ? 0 : (t->dense_tails ? t->mode : 1));
             const size_t chunk = mode == 2 ? t->chunk_rays : R;
             const bool pipelined = mode == 2 && R > chunk;
             if (pipelined) {
@@ -326,7 +327,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
                 tn::launch_trace_general(p, t->side);
-                if (!(t->debug & 16u)) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream, (t->debug & 512u) != 0);
+                if (!(t->debug & 16u) && t->dense_tails) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream, (t->debug & 512u) != 0);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
             } else {
@@ -431,6 +432,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && std::strcmp(name, "debug") == 0) t->debug = (uint32_t)value;
         else if (name && std::strcmp(name, "gdebug") == 0) t->gdebug = (uint32_t)value;
         else if (name && std::strcmp(name, "mode") == 0) t->mode = value;
+        else if (name && std::strcmp(name, "dense_tails") == 0) t->dense_tails = value != 0;
         else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
         else if (name && std::strcmp(name, "chunk_rays") == 0) t->chunk_rays = value >= 256 ? (size_t)value : 256;
         else throw tn::Error(std::string("unknown option ") + (name ? name : "(null)"));

@@ -210,13 +210,16 @@ class TetraRenderer:
 
     def __init__(self, tracer, field: torch.Tensor, mlp: TetraMLP, num_samples: int = 256,
                  max_ray_triangles: int = 512, fused: bool = True, far_plane: float = 1000.0,
-                 num_fine_samples: int = 0, biased: bool = False):
+                 num_fine_samples: int = 0, biased: bool = False, dense_tails: bool = False):
         from . import tetranerf_cpp_extension as cpp
 
         self.cpp = cpp
         self.tracer, self.field, self.mlp = tracer, field, mlp
         self.S, self.M, self.fused, self.far_plane = int(num_samples), int(max_ray_triangles), fused, far_plane
         self.S_fine, self.biased = int(num_fine_samples), bool(biased)
+        # the render path only reads the trace rows through num_visited_cells, so the constant tails of the
+        # dense reference layout need not be written (non-materialising trace: 52 B per segment, not 52*M per ray)
+        self.dense_tails = bool(dense_tails)
 
     @torch.no_grad()
     def render(self, origins: torch.Tensor, directions: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -224,11 +227,19 @@ class TetraRenderer:
         if not self.fused:
             return render_reference(self.tracer, cpp.interpolate_values, self.field, self.mlp, origins, directions,
                                     S, self.M, self.far_plane, self.S_fine, self.biased)
-        out = self.tracer.trace_rays(origins.contiguous(), directions.contiguous(), self.M)
+        if not self.dense_tails:
+            self.tracer.set_option("dense_tails", 0)
+        try:
+            out = self.tracer.trace_rays(origins.contiguous(), directions.contiguous(), self.M)
+        finally:
+            if not self.dense_tails:
+                self.tracer.set_option("dense_tails", 1)
         nv = out["num_visited_cells"]
-        nears = out["hit_distances"][:, 0, 0][:, None]
-        fars = torch.gather(out["hit_distances"][:, :, 1], 1, (nv[:, None].long() - 1).clamp_min(0))
         ray_mask = nv > 0
+        # rows of empty rays are unwritten without dense tails: read nears/fars under the mask
+        nears = torch.where(ray_mask, out["hit_distances"][:, 0, 0], 0.0)[:, None]
+        fars = torch.where(ray_mask[:, None], torch.gather(out["hit_distances"][:, :, 1], 1,
+                                                          (nv[:, None].long() - 1).clamp_min(0)), 0.0)
         R, dev = origins.shape[0], origins.device
         rgb = torch.ones((R, 3), dtype=torch.float32, device=dev)
         acc = torch.zeros((R, 1), dtype=torch.float32, device=dev)
