@@ -149,7 +149,10 @@ int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]);
  * reasons[k], k = 1..12: 1 zero edge function / zero determinant on a hull face, 2 not exactly two
  * hull crossings, 3 equal hull distances, 4 entry face not in its tet, 5 zero edge function,
  * 6 not exactly two crossed faces in a tet, 7 non-increasing t, 8 two consecutive gaps < eps,
- * 9 more than M-1 faces, 10 invalid t after a valid one, 11 exit face mismatch, 12 step limit. */
+ * 9 more than M-1 faces, 10 invalid t after a valid one, 11 exit face mismatch, 12 step limit.
+ * Reasons 7 / 8 / 10 concern only the ORDER of a sound chain: those rays are re-walked (raw hit list -> literal
+ * sort + pairing) instead of re-traced through the BVH; reasons[13] = rays handled that way, reasons[14] =
+ * re-walked chains that went to the BVH path after all. */
 int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
 
 /* knobs (also settable through the environment):
@@ -160,6 +163,9 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *   "dense_tails"  1 (default) = every slot of the [R,M] rows is written, as the reference does;
  *             0 = slots >= num_visited[r] of walked rows are left UNWRITTEN (non-reference: for callers
  *             that only read rows through num_visited, e.g. tn_find_matched_cells; saves ~88 % of the bytes)
+ *   "rewalk"  1 (default) = chains whose order the walk cannot certify are re-walked and paired literally,
+ *             0 = every uncertified ray is re-traced through the BVH all-hits path;
+ *             "rewalk_min" (default 4096): fewer such chains in a call also take the BVH path (decided on the device)
  *   "mode", "chunk_rays", "fill_blocks", "debug", "gdebug": launch-structure / ablation knobs (profiles/) */
 int tn_set_option(tn_tracer_t tracer, const char *name, int value);
 
@@ -199,6 +205,14 @@ int tn_mlp_forward(size_t n, uint32_t samples_per_ray, const float *feats, const
 int tn_mlp_forward_gather(size_t n, uint32_t samples_per_ray, uint32_t num_vertices,
                           const uint32_t *vertex_indices, const float *barycentric, const float *field,
                           const float *dirs, const tn_mlp_weights *weights, float *sigma, float *rgb, void *stream);
+
+/* Arithmetic of tn_mlp_forward / tn_mlp_forward_gather (process-wide):
+ *   0 (default)  v_mfma_f32_32x32x2_f32: an exact fp32 fma chain (157 TFLOP/s peak);
+ *   1 "bf16x3"   v_mfma_f32_32x32x16_bf16 on operands split into three bf16 pieces, six partial products per
+ *                multiply, fp32 accumulation: fp32-grade accuracy (dropped terms < 2^-24 of a product; the 1e-5
+ *                parity tests run in both modes) at 2.67x fewer matrix-core cycles. */
+int tn_mlp_set_mode(int mode);
+int tn_mlp_get_mode(void);
 
 /* RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers.
  * sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1] (bin edges: starts = edges[:, :-1], ends = edges[:, 1:]);

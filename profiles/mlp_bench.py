@@ -23,11 +23,17 @@ for R, S in ((4096, 256), (4096, 513), (16384, 256)):
     dirs = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
     w = render.mlp_weights(mlp)
     ms = timeit(lambda: tn.cpp.mlp_forward(feats_fm, dirs, w, S))
+    tn.cpp.mlp_set_mode("bf16x3")
+    ms3 = timeit(lambda: tn.cpp.mlp_forward(feats_fm, dirs, w, S))
+    s3, c3 = tn.cpp.mlp_forward(feats_fm, dirs, w, S)
+    tn.cpp.mlp_set_mode("fp32")
     feats = feats_fm.t().contiguous(); dd = dirs[:, None, :].expand(R, S, 3).reshape(n, 3)
     with torch.no_grad():
         ms_t = timeit(lambda: mlp(feats, dd), 5)
     sigma, rgb = tn.cpp.mlp_forward(feats_fm, dirs, w, S)
     edges = (torch.rand(R, 1, device=dev) + torch.cumsum(torch.rand(R, S + 1, device=dev) * 0.01, -1)).contiguous()
     ms_c = timeit(lambda: tn.cpp.composite(sigma.view(R, S), rgb.view(R, S, 3), edges))
+    print(f"MLP n={n} bf16x3 mode: {ms3:.3f} ms = {n*FLOP/ms3/1e9:.1f} fp32-equivalent TFLOP/s ({ms/ms3:.2f}x the fp32 MFMA kernel); "
+          f"max |sigma diff| {float((s3 - sigma).abs().max()):.2e}, max |rgb diff| {float((c3 - rgb).abs().max()):.2e} vs the fp32 kernel")
     print(f"MLP n={n} ({R}x{S}): fused {ms:.3f} ms = {n*FLOP/ms/1e9:.1f} TFLOP/s ({n*FLOP/ms/1e9/157.3*100:.1f}% of 157.3 fp32 MFMA peak); "
           f"torch {ms_t:.3f} ms = {n*FLOP/ms_t/1e9:.1f} TFLOP/s; composite {ms_c*1e3:.1f} us ({n*20/ms_c/1e6:.0f} GB/s of 20 B/sample)")

@@ -49,5 +49,22 @@ def pmc(db):
             print(f"{short(name, 80):<82} {ctr:<28} {avg:>16.1f} {mn:>16.1f} {mx:>16.1f} {n:>4}")
 
 
+def dispatches(db):
+    """every tn:: kernel dispatch in launch order: name, grid, duration (us)"""
+    con = sqlite3.connect(db)
+    cols = [r[1] for r in con.execute("pragma table_info(kernels)").fetchall()]
+    namecol = "kernel_name" if "kernel_name" in cols else ("name" if "name" in cols else None)
+    gridcol = "grid_size" if "grid_size" in cols else ("grid" if "grid" in cols else "0")
+    if not {"start", "end"} <= set(cols) or namecol is None:
+        print("kernels view columns:", cols)
+        print("views:", [r[0] for r in con.execute("select name from sqlite_master where type in ('view','table')").fetchall()][:60])
+        return
+    rows = con.execute(f"select {namecol}, {gridcol}, start, end from kernels order by start").fetchall()
+    t0 = rows[0][2] if rows else 0
+    for name, grid, st, en in rows:
+        if "tn::" in name:
+            print(f"{(st - t0) / 1e3:>12.1f} us  +{(en - st) / 1e3:>10.1f} us  grid {grid:>9}  {short(name, 70)}")
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "dispatches": dispatches}[sys.argv[1]](sys.argv[2])

@@ -14,6 +14,15 @@ def render():
     return importlib.import_module("tetra-nerf_amd.render")
 
 
+@pytest.fixture(params=["fp32", "bf16x3"])
+def mlp_mode(request, tn):
+    """Both arithmetic modes of the fused MLP kernel (tn_mlp_set_mode) against the same 1e-5 bar."""
+    tn.cpp.mlp_set_mode(request.param)
+    assert tn.cpp.mlp_get_mode() == request.param
+    yield request.param
+    tn.cpp.mlp_set_mode("fp32")
+
+
 def _model(render, seed=0, field_scale=1.0):
     import torch
 
@@ -21,7 +30,7 @@ def _model(render, seed=0, field_scale=1.0):
     return render.TetraMLP()
 
 
-def test_mlp_forward_matches_torch(tn, device, render):
+def test_mlp_forward_matches_torch(tn, device, render, mlp_mode):
     import torch
 
     mlp = _model(render)
@@ -40,7 +49,7 @@ def test_mlp_forward_matches_torch(tn, device, render):
         np.testing.assert_allclose(rgb.cpu().numpy(), wc.numpy(), rtol=0, atol=1e-5)
 
 
-def test_mlp_forward_gather_equals_two_step(tn, device, render):
+def test_mlp_forward_gather_equals_two_step(tn, device, render, mlp_mode):
     """Fused gather+MLP must produce exactly the bits of interpolate_values followed by mlp_forward up to
     the K order of layer 1 (different, so compare at fp32 round-off) and match the torch statement."""
     import torch
@@ -67,7 +76,7 @@ def test_mlp_forward_gather_equals_two_step(tn, device, render):
     np.testing.assert_allclose(c1.cpu().numpy(), wc.reshape(-1, 3).cpu().numpy(), rtol=0, atol=1e-5)
 
 
-def test_density_only_and_weights_only(tn, device, render):
+def test_density_only_and_weights_only(tn, device, render, mlp_mode):
     """Coarse pass of the model (model.py:577-582): mlp_base + density head only, then get_weights."""
     import torch
 
@@ -91,8 +100,9 @@ def test_density_only_and_weights_only(tn, device, render):
     np.testing.assert_allclose(w_only.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-6)
 
 
-def test_mlp_forward_vs_float64(tn, device, render):
-    """fp32 MFMA = exact fp32 fma chain: error vs a float64 evaluation stays at fp32 round-off."""
+def test_mlp_forward_vs_float64(tn, device, render, mlp_mode):
+    """fp32 MFMA = exact fp32 fma chain; bf16x3 = six exact partial products per multiply with the dropped
+    terms below 2^-24: in both modes the error vs a float64 evaluation stays at fp32 round-off."""
     import torch
 
     mlp = _model(render, 3)
@@ -134,7 +144,7 @@ def test_composite_matches_torch(tn, device, render):
 
 
 @pytest.mark.parametrize("cfg", ["coarse", "tetra-nerf-original", "tetra-nerf"])
-def test_render_c3(tn, device, oracle, scenes, render, cfg):
+def test_render_c3(tn, device, oracle, scenes, render, cfg, mlp_mode):
     """Config C3: 100k-tet mesh (seed 1), field U(-1e-4,1e-4) with colour rows, default-init MLP
     (torch.manual_seed(0)), 4096 rays: sigma-weights-RGB within 1e-5 of the CPU fp32 statement (oracle
     tracer + torch MLP).  coarse: 256 uniform samples; tetra-nerf-original: 256 uniform + 256 PDF

@@ -150,3 +150,31 @@ def test_dense_tails_off_keeps_the_valid_prefix(tn, device, scenes):
     m1, m2 = tr.find_visited_cells(*args(dense)), tr.find_visited_cells(*args(lean))
     for k in m1:
         assert torch.equal(m1[k], m2[k]), k
+
+
+def test_rewalk_equals_bvh_fallback(tn, device, oracle, scenes):
+    """Chains whose ORDER the walk cannot certify are re-walked (raw hit list -> literal sort + pairing) instead
+    of re-traced through the BVH: both fallbacks, and the oracle, must agree bit for bit -- on a mesh / ray set
+    dense enough that hundreds of rays take that route."""
+    import torch
+
+    pts, cells = scenes.random_mesh(20000, 11)
+    o, d = scenes.outside_in_rays(120000, 12)
+    tr = _tracer(tn, device, pts, cells, 1)
+    tr.set_option("rewalk_min", 0)   # default: fewer than 4096 such chains per call take the BVH path
+    a = _trace(tr, device, o, d, 512)
+    reasons = tr.flag_reasons()
+    assert reasons.get(13, 0) > 100, reasons
+    st = tr.trace_stats()
+    assert st["walk"] + st["general"] == len(o)
+    tr.set_option("rewalk", 0)
+    b = _trace(tr, device, o, d, 512)
+    assert 13 not in tr.flag_reasons()
+    for k in KEYS:
+        assert _bits_equal(a[k], b[k]), k
+    # and against the oracle on a slice that contains re-walked rays
+    ot = oracle.OracleTracer(use_bvh=True)
+    ot.load_tetrahedra(pts, cells)
+    want = ot.trace_rays(o[:30000], d[:30000], 512)
+    for k in KEYS:
+        assert _bits_equal(a[k][:30000], want[k]), k

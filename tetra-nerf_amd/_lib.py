@@ -18,7 +18,8 @@ SYMBOLS = (
     "tn_find_matched_cells",
     "tn_interpolate_values", "tn_interpolate_values_backward", "tn_interpolate_values_backward_rows",
     "tn_postprocess_hits",
-    "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
+    "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_set_mode", "tn_mlp_get_mode",
+    "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
 )
 
 _lib = None
@@ -56,6 +57,8 @@ def load():
     lib.tn_trace_stats.argtypes = [vp, C.POINTER(C.c_uint64 * 4)]
     lib.tn_trace_flag_reasons.argtypes = [vp, C.POINTER(C.c_uint64 * 16)]
     lib.tn_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.tn_mlp_set_mode.argtypes = [i32]
+    lib.tn_mlp_get_mode.argtypes = []
     lib.tn_mlp_forward.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp]
     lib.tn_mlp_forward_gather.argtypes = [sz, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_gather_uint32.argtypes = [i32, u32, u32, vp, vp, vp, vp]

@@ -1,4 +1,5 @@
 // tn_api.hip -- the C-ABI of libtetranerf_hip.so (see include/tetranerf_hip.h).
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -55,7 +56,10 @@ struct tn_tracer {
     tn::DeviceMesh mesh;
     tn::HostMesh host;  // kept for tn_get_faces
     static constexpr int kEvents = 4;
-    tn::DevBuf<uint32_t> faces, face_tets, fallback_list, fallback_count, walk_n;
+    tn::DevBuf<uint32_t> faces, face_tets, fallback_list, fallback_count, walk_n, rewalk_count;
+    tn::DevBuf<uint4> rewalk_list;
+    uint32_t rewalk_min = 4096;          // fewer uncertified chains than this per call: BVH re-trace instead
+    bool rewalk = true;                  // re-walk chains with uncertified order instead of the BVH re-trace
     hipStream_t side = nullptr;          // tail-fill stream (overlaps the walk of the next chunk)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chunk[kEvents] = {};
     size_t chunk_rays = 65536;           // rays per walk launch when pipelining
@@ -135,9 +139,10 @@ int tn_tracer_create(int device, tn_tracer_t *out) {
         auto t = std::make_unique<tn_tracer>();
         t->device = device;
         t->use_walk = env_flag("TETRANERF_HIP_WALK", true) ? 1 : 0;
-        t->stats.alloc(20);
-        TN_HIP(hipMemset(t->stats.p, 0, 20 * sizeof(unsigned long long)));
+        t->stats.alloc(24);
+        TN_HIP(hipMemset(t->stats.p, 0, 24 * sizeof(unsigned long long)));
         t->fallback_count.alloc(1);
+        t->rewalk_count.alloc(1);
         TN_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
         TN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
         TN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
@@ -262,7 +267,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
         hipStream_t stream = (hipStream_t)stream_;
         t->last_stream = stream;
         t->last_num_rays = R;
-        TN_HIP(hipMemsetAsync(t->stats.p, 0, 20 * sizeof(unsigned long long), stream));
+        TN_HIP(hipMemsetAsync(t->stats.p, 0, 24 * sizeof(unsigned long long), stream));
         tn::TraceParams p = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
         // Small batches are latency-bound: a lane walking ~180 dependent steps is slower than one
         // wavefront per ray through the wide BVH (measured: 4096 rays, 300k tets: 1.5 ms vs 0.75 ms),
@@ -275,8 +280,9 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             // 2. constant tails of each finished chunk on the tracer's side stream (pure HBM
             //    streaming, overlaps the latency-bound walk of the next chunk);
             // 3. general all-hits path on `stream` for the rays the walk could not certify.
-            if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); }
+            if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->rewalk_list.alloc(R); }
             TN_HIP(hipMemsetAsync(t->fallback_count.p, 0, sizeof(uint32_t), stream));
+            TN_HIP(hipMemsetAsync(t->rewalk_count.p, 0, sizeof(uint32_t), stream));
             // mode 0: one launch, the walk kernel writes its own tails; mode 1: walk launch, then one
             // tail launch on the same stream; mode 2: chunked, tails on the side stream
             const int mode = (t->debug & 1u) ? 0 : (R < 8192 && t->dense_tails ? 0 : (t->dense_tails ? t->mode : 1));
@@ -306,6 +312,8 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 w.n_hull_nodes = t->mesh.n_hull_nodes;
                 w.fallback_list = t->fallback_list.p;
                 w.fallback_count = t->fallback_count.p;
+                w.rewalk_list = t->rewalk ? t->rewalk_list.p : nullptr;
+                w.rewalk_count = t->rewalk_count.p;
                 w.walk_n = t->walk_n.p + r0;
                 w.ray_base = r0;
                 w.fused_tails = (mode != 0 || (t->debug & 1u)) ? 0u : 1u;
@@ -321,17 +329,41 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             }
             p.ray_list = t->fallback_list.p;
             p.item_count = t->fallback_count.p;
+            // the rays the walk did not certify: re-walk + literal pairing of the sound chains, then the BVH
+            // all-hits kernel for the rest (the re-walk may still append to its list)
+            // The re-walk is a latency-bound pointer chase: it runs ALONE on `stream` right after the walk
+            // (measured under the saturating tail fill: 12 us per step instead of ~1).  The wave-parallel parts
+            // (literal pairing of the collected lists, BVH re-trace) overlap the fill on the side stream.
+            auto launch_collect = [&](hipStream_t st) {
+                if (!t->rewalk) return;
+                tn::WalkParams w{};
+                w.t = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
+                w.tets = t->mesh.tets;
+                w.fallback_list = t->fallback_list.p;
+                w.fallback_count = t->fallback_count.p;
+                w.rewalk_list = t->rewalk_list.p;
+                w.rewalk_count = t->rewalk_count.p;
+                w.rewalk_min = t->rewalk_min;
+                tn::launch_walk_collect(w, R, st);
+            };
+            auto launch_pairing = [&](hipStream_t st) {
+                if (t->rewalk) {
+                    const tn::TraceParams q = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
+                    tn::launch_postprocess_rows(q, t->rewalk_list.p, t->rewalk_count.p, R, st);
+                }
+                tn::launch_trace_general(p, st);
+            };
             if (mode == 1) {
-                // re-trace of the uncertified rays (latency-bound, few waves) on the side stream,
-                // concurrent with the bandwidth-bound tail fill on `stream`
+                launch_collect(stream);
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
-                tn::launch_trace_general(p, t->side);
+                launch_pairing(t->side);
                 if (!(t->debug & 16u) && t->dense_tails) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream, (t->debug & 512u) != 0);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
             } else {
-                tn::launch_trace_general(p, stream);
+                launch_collect(stream);
+                launch_pairing(stream);
                 if (pipelined) {
                     TN_HIP(hipEventRecord(t->ev_join, t->side));
                     TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
@@ -398,12 +430,14 @@ int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]) {
         tn_tracer *t = checked(tracer);
         DeviceGuard g(t->device);
         TN_HIP(hipStreamSynchronize(t->last_stream));
-        unsigned long long h[4];
+        unsigned long long h[24];
         TN_HIP(hipMemcpy(h, t->stats.p, sizeof h, hipMemcpyDeviceToHost));
         for (int i = 0; i < 4; ++i) stats[i] = h[i];
         if (t->last_walk) {
-            uint32_t fb = 0;
+            uint32_t fb = 0, rw = 0;  // not certified by the walk: BVH re-trace + re-walked chains
             TN_HIP(hipMemcpy(&fb, t->fallback_count.p, sizeof fb, hipMemcpyDeviceToHost));
+            TN_HIP(hipMemcpy(&rw, t->rewalk_count.p, sizeof rw, hipMemcpyDeviceToHost));
+            fb += rw - (uint32_t)h[4 + 14];  // chains the re-walk handed on are in both counts
             stats[1] = fb;
             stats[0] = t->last_num_rays - fb;
         } else {
@@ -433,6 +467,8 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && std::strcmp(name, "gdebug") == 0) t->gdebug = (uint32_t)value;
         else if (name && std::strcmp(name, "mode") == 0) t->mode = value;
         else if (name && std::strcmp(name, "dense_tails") == 0) t->dense_tails = value != 0;
+        else if (name && std::strcmp(name, "rewalk") == 0) t->rewalk = value != 0;
+        else if (name && std::strcmp(name, "rewalk_min") == 0) t->rewalk_min = value < 0 ? 0u : (uint32_t)value;
         else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
         else if (name && std::strcmp(name, "chunk_rays") == 0) t->chunk_rays = value >= 256 ? (size_t)value : 256;
         else throw tn::Error(std::string("unknown option ") + (name ? name : "(null)"));
@@ -477,6 +513,17 @@ int tn_interpolate_values_backward_rows(uint32_t D, uint32_t V, uint32_t n, uint
     });
 }
 
+static std::atomic<int> g_mlp_mode{0};
+
+int tn_mlp_set_mode(int mode) {
+    return guarded([&] {
+        if (mode != 0 && mode != 1) throw tn::Error("mlp mode must be 0 (fp32 MFMA) or 1 (bf16x3 MFMA)");
+        g_mlp_mode.store(mode);
+    });
+}
+
+int tn_mlp_get_mode(void) { return g_mlp_mode.load(); }
+
 int tn_mlp_forward(size_t n, uint32_t samples_per_ray, const float *feats, const float *dirs,
                    const tn_mlp_weights *w, float *sigma, float *rgb, void *stream_) {
     return guarded([&] {
@@ -484,8 +531,8 @@ int tn_mlp_forward(size_t n, uint32_t samples_per_ray, const float *feats, const
         if (!w || !feats || !sigma || (rgb && !dirs)) throw tn::Error("null pointer");
         if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
         tn::MlpWeights m{w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
-        tn::launch_mlp_forward(n, samples_per_ray, n / samples_per_ray, feats, nullptr, nullptr, nullptr, 0, dirs, m, sigma, rgb,
-                               (hipStream_t)stream_);
+        (g_mlp_mode.load() ? tn::launch_mlp_forward_x3 : tn::launch_mlp_forward)(
+            n, samples_per_ray, n / samples_per_ray, feats, nullptr, nullptr, nullptr, 0, dirs, m, sigma, rgb, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }
@@ -498,8 +545,9 @@ int tn_mlp_forward_gather(size_t n, uint32_t samples_per_ray, uint32_t num_verti
         if (!w || !vertex_indices || !barycentric || !field || !sigma || (rgb && !dirs)) throw tn::Error("null pointer");
         if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
         tn::MlpWeights m{w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
-        tn::launch_mlp_forward(n, samples_per_ray, n / samples_per_ray, nullptr, vertex_indices, barycentric, field,
-                               num_vertices, dirs, m, sigma, rgb, (hipStream_t)stream_);
+        (g_mlp_mode.load() ? tn::launch_mlp_forward_x3 : tn::launch_mlp_forward)(
+            n, samples_per_ray, n / samples_per_ray, nullptr, vertex_indices, barycentric, field, num_vertices, dirs, m, sigma, rgb,
+            (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }

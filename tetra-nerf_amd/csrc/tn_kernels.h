@@ -43,12 +43,19 @@ struct WalkParams {
     uint32_t n_hull_nodes;
     uint32_t *fallback_list;   // [R] rays the walk could not certify
     uint32_t *fallback_count;  // [1]
+    uint4 *rewalk_list;        // [R] {ray, first tet record, entry face, hull exit face}: sound chains whose ORDER
+    uint32_t *rewalk_count;    // [1]  is not certified (re-collected by k_walk_collect); nullptr = all to the fallback
+    uint32_t rewalk_min;       // fewer chains than this: k_walk_collect hands them to the BVH list instead
     uint32_t *walk_n;          // [num_items] segments per certified ray, TN_EMPTY = sent to the fallback
     size_t ray_base;           // global index of item 0 (rays are traced in chunks)
     uint32_t fused_tails;      // 1 = the walk kernel writes the constant tails itself
     uint32_t debug;            // ablation only (bench): 2 = skip segment stores
 };
 void launch_trace_walk(const WalkParams &p, hipStream_t stream);
+// re-walk of the chains in rewalk_list (raw hits into the rays' own rows) and their literal sort + pairing
+void launch_walk_collect(const WalkParams &p, size_t max_items, hipStream_t stream);
+void launch_postprocess_rows(const TraceParams &p, const uint4 *rewalk_list, const uint32_t *rewalk_count, size_t max_items,
+                             hipStream_t stream);
 // constant tails [n, M) of the rows certified by the walk (n = walk_n[ray] != TN_EMPTY)
 void launch_fill_tails(size_t num_rays, uint32_t M, const uint32_t *walk_n, uint32_t *out_cells, float *out_bary,
                        float *out_dist, uint32_t *out_verts, hipStream_t stream, bool nontemporal = false, unsigned max_blocks = 0);
@@ -78,6 +85,10 @@ struct MlpWeights {
 // feats != null: input is the [64, n] feature buffer; feats == null: the kernel gathers the features
 // itself from (vi [n,4], bc [n,3], field [64, V] feature-major)
 void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
+                        const float *bc, const float *field, uint32_t num_vertices, const float *dirs,
+                        const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream);
+// the same on the bf16 matrix cores with 3-way operand splitting (tn_mlp_x3.hip)
+void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
                         const float *bc, const float *field, uint32_t num_vertices, const float *dirs,
                         const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream);
 void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols, hipStream_t stream);

@@ -46,15 +46,21 @@ constexpr int MLP_BLOCK = 512;    // 8 waves share one staged layer: 256 samples
 // operands, the mlp_base output); the rgb head is a 1-tile layer (rows 0..2).
 struct LayerGeom { int ksteps, tiles; size_t off; };
 constexpr size_t lfloats(int ksteps, int tiles) { return (size_t)(ksteps + 1) * tiles * 64; }
-constexpr int HEAD_KS = KSE + KSH, HEAD_TILES = OT + 1;
+constexpr int HEAD_KS = KSE + KSH;
+// The two narrow heads (density 128 -> 1 on the mlp_base output, rgb 128 -> 3 on the head output) are NOT
+// MFMA layers: as 32-row tiles they would spend 130 of 1098 MFMAs per 32 samples on 4 useful rows.  Their
+// weights ride behind the layer that produces their input ([half][64] floats in the lane's K order + bias)
+// and each lane does its half of the dot products on the otherwise idle VALU (64 fma per output).
+constexpr size_t DVEC = 2 * 64 + 4;        // density: wd in K order per half, bd, pad
+constexpr size_t CVEC = 3 * 2 * 64 + 4;    // rgb: wr rows in K order per half, br, pad
 constexpr size_t OFF_W1 = 0;
 constexpr size_t OFF_W2 = OFF_W1 + lfloats(KS1, OT);
 constexpr size_t OFF_W3 = OFF_W2 + lfloats(KSH, OT);
-constexpr size_t OFF_WHEAD = OFF_W3 + lfloats(KSH, OT);
-constexpr size_t OFF_WRGB = OFF_WHEAD + lfloats(HEAD_KS, HEAD_TILES);
-constexpr size_t OFF_WDENS = OFF_WRGB + lfloats(KSH, 1);   // density head alone (coarse pass: no colour)
-constexpr size_t PACK_FLOATS = OFF_WDENS + lfloats(KSH, 1);
-constexpr size_t MAX_STAGE_FLOATS = lfloats(HEAD_KS, HEAD_TILES);
+constexpr size_t N_W3 = lfloats(KSH, OT) + DVEC;
+constexpr size_t OFF_WHEAD = OFF_W3 + N_W3;
+constexpr size_t N_WHEAD = lfloats(HEAD_KS, OT) + CVEC;
+constexpr size_t PACK_FLOATS = OFF_WHEAD + N_WHEAD;
+constexpr size_t MAX_STAGE_FLOATS = N_WHEAD;
 
 __host__ __device__ constexpr int acc_feature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 // k index consumed by k-step `ks` (0..63) of a layer whose input lives in accumulators, half h
@@ -78,31 +84,26 @@ __global__ void k_mlp_pack(MlpWeights w, float *__restrict__ pk, int gather_l1) 
         split(i - OFF_W2, OT, ks, ot, lane);
         const int o = 32 * ot + (lane & 31), h = lane >> 5;
         v = ks < KSH ? w.w2[(size_t)o * HID + acc_k(ks, h)] : (h == 0 ? w.b2[o] : 0.f);
-    } else if (i < OFF_WHEAD) {
+    } else if (i < OFF_W3 + lfloats(KSH, OT)) {
         split(i - OFF_W3, OT, ks, ot, lane);
         const int o = 32 * ot + (lane & 31), h = lane >> 5;
         v = ks < KSH ? w.w3[(size_t)o * HID + acc_k(ks, h)] : (h == 0 ? w.b3[o] : 0.f);
-    } else if (i < OFF_WRGB) {              // head [enc(27) | base(128)] -> 128, plus the density tile
-        split(i - OFF_WHEAD, HEAD_TILES, ks, ot, lane);
+    } else if (i < OFF_WHEAD) {             // density head vector behind layer 3
+        const int j = (int)(i - OFF_W3 - lfloats(KSH, OT));
+        if (j < 128) v = w.wd[acc_k(j & 63, j >> 6)];
+        else if (j == 128) v = w.bd[0];
+    } else if (i < OFF_WHEAD + lfloats(HEAD_KS, OT)) {  // head [enc(27) | base(128)] -> 128
+        split(i - OFF_WHEAD, OT, ks, ot, lane);
         const int row = lane & 31, h = lane >> 5;
-        if (ot < OT) {
-            const int o = 32 * ot + row;
-            const size_t base = (size_t)o * (ENC + HID);
-            if (ks < KSE) { const int k = 2 * ks + h; v = k < ENC ? w.wh[base + k] : 0.f; }
-            else if (ks < HEAD_KS) v = w.wh[base + ENC + acc_k(ks - KSE, h)];
-            else v = h == 0 ? w.bh[o] : 0.f;
-        } else if (row == 0) {              // density head in row 0 of the 5th tile
-            if (ks >= KSE && ks < HEAD_KS) v = w.wd[acc_k(ks - KSE, h)];
-            else if (ks == HEAD_KS) v = h == 0 ? w.bd[0] : 0.f;
-        }
-    } else if (i < OFF_WDENS) {             // rgb head: rows 0..2 of a single tile
-        split(i - OFF_WRGB, 1, ks, ot, lane);
-        const int row = lane & 31, h = lane >> 5;
-        if (row < 3) v = ks < KSH ? w.wr[(size_t)row * HID + acc_k(ks, h)] : (h == 0 ? w.br[row] : 0.f);
-    } else {                                // density head alone: row 0 of a single tile
-        split(i - OFF_WDENS, 1, ks, ot, lane);
-        const int row = lane & 31, h = lane >> 5;
-        if (row == 0) v = ks < KSH ? w.wd[acc_k(ks, h)] : (h == 0 ? w.bd[0] : 0.f);
+        const int o = 32 * ot + row;
+        const size_t base = (size_t)o * (ENC + HID);
+        if (ks < KSE) { const int k = 2 * ks + h; v = k < ENC ? w.wh[base + k] : 0.f; }
+        else if (ks < HEAD_KS) v = w.wh[base + ENC + acc_k(ks - KSE, h)];
+        else v = h == 0 ? w.bh[o] : 0.f;
+    } else {                                // rgb head vectors behind the head layer
+        const int j = (int)(i - OFF_WHEAD - lfloats(HEAD_KS, OT));
+        if (j < 384) v = w.wr[(size_t)(j >> 7) * HID + acc_k(j & 63, (j >> 6) & 1)];
+        else if (j < 387) v = w.br[j - 384];
     }
     pk[i] = v;
 }
@@ -126,10 +127,24 @@ __global__ void k_dir_encoding(size_t R, const float *__restrict__ dirs, float *
     e[27] = 0.f;
 }
 
+// Packed layer -> LDS with the async global->LDS path (global_load_lds_dwordx4: no staging registers, all
+// of a thread's loads in flight at once; a load-wait-write loop exposes one L2 latency per 8 KB).  The LDS
+// destination of a wave is uniform base + lane * 16, which is exactly a linear copy.
 __device__ __forceinline__ void stage_weights(float *lds, const float *__restrict__ src, size_t n_floats) {
     const float4 *s4 = reinterpret_cast<const float4 *>(src);
     float4 *d4 = reinterpret_cast<float4 *>(lds);
-    for (size_t i = threadIdx.x; i < n_floats / 4; i += MLP_BLOCK) d4[i] = s4[i];
+    const uint32_t n16 = (uint32_t)(n_floats / 4), lane = threadIdx.x & 63;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+    for (uint32_t base = wave0; base < n16; base += MLP_BLOCK) {
+        const uint32_t i = base + lane;
+        if (i < n16)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s4 + i),
+                                             (__attribute__((address_space(3))) void *)(d4 + base), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void stage_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
 // acc[t] += W_staged[k-steps KS0 .. KS0+KS) * bin[0..KS)
@@ -160,6 +175,22 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TILES]) {
     for (int t = 0; t < TILES; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+}
+
+// This lane's half of a 128-long dot product with the activations it holds (wl: 64 floats in the lane's K
+// order, broadcast LDS reads), plus the other half-wave's half.
+__device__ __forceinline__ float head_dot(const float *wl, const float (&bin)[KSH]) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float4 w4 = reinterpret_cast<const float4 *>(wl)[i];
+        a0 = __builtin_fmaf(w4.x, bin[4 * i], a0);
+        a1 = __builtin_fmaf(w4.y, bin[4 * i + 1], a1);
+        a2 = __builtin_fmaf(w4.z, bin[4 * i + 2], a2);
+        a3 = __builtin_fmaf(w4.w, bin[4 * i + 3], a3);
+    }
+    const float part = (a0 + a1) + (a2 + a3);
+    return part + __shfl_xor(part, 32);
 }
 
 template <int TILES>
@@ -219,7 +250,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t sa
                 }
             }
         }
-        __syncthreads();
+        stage_wait();
         {
             f32x16 acc[OT];
             zero_acc(acc);
@@ -230,7 +261,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t sa
         // ---- layers 2, 3: 128 -> 128, accumulators fed back as B operands
         __syncthreads();
         stage_weights(lds, pk + OFF_W2, lfloats(KSH, OT));
-        __syncthreads();
+        stage_wait();
         {
             f32x16 acc[OT];
             zero_acc(acc);
@@ -239,8 +270,8 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t sa
             relu_to_bin(acc, bin);
         }
         __syncthreads();
-        stage_weights(lds, pk + OFF_W3, lfloats(KSH, OT));
-        __syncthreads();
+        stage_weights(lds, pk + OFF_W3, N_W3);
+        stage_wait();
         {
             f32x16 acc[OT];
             zero_acc(acc);
@@ -248,57 +279,44 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t sa
             bias_step<KSH, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);  // mlp_base out_activation = ReLU
         }
-        if constexpr (DENSITY_ONLY) {
-            // coarse pass of the model (model.py:577-581): mlp_base + density head only
-            __syncthreads();
-            stage_weights(lds, pk + OFF_WDENS, lfloats(KSH, 1));
-            __syncthreads();
-            f32x16 acc[1];
-            zero_acc(acc);
-            gemm_steps<KSH, 0, 1>(acc, bin, lds, lane);
-            bias_step<KSH, 1>(acc, lds, lane);
-            const float raw = acc[0][0];
-            const float sp = raw > 20.0f ? raw : log1pf(expf(raw));
-            if (h == 0 && s < n) sigma[s] = sp;
-            continue;
-        }
-        // ---- head [enc(27) | base(128)] -> 128 ReLU, with the density head riding as a 5th tile
-        __syncthreads();
-        stage_weights(lds, pk + OFF_WHEAD, lfloats(HEAD_KS, HEAD_TILES));
-        __syncthreads();
         {
-            f32x16 acc[HEAD_TILES];
+            // density head 128 -> 1 + softplus on the VALU (the vector rides behind layer 3's weights)
+            const float *dv = lds + lfloats(KSH, OT);
+            const float raw = head_dot(dv + 64 * h, bin) + dv[128];
+            const float sp = raw > 20.0f ? raw : log1pf(expf(raw));  // torch softplus(beta=1, threshold=20)
+            if (h == 0 && s < n) sigma[s] = sp;
+        }
+        if constexpr (DENSITY_ONLY) continue;  // coarse pass of the model (model.py:577-581)
+        // ---- head [enc(27) | base(128)] -> 128 ReLU
+        __syncthreads();
+        stage_weights(lds, pk + OFF_WHEAD, N_WHEAD);
+        stage_wait();
+        {
+            f32x16 acc[OT];
             zero_acc(acc);
             const float *e = enc + (sc / samples_per_ray) * ENC_PAD;
 #pragma unroll
             for (int ks = 0; ks < KSE; ++ks) {
                 const float b = e[2 * ks + h];
-                const float *wrow = lds + (size_t)ks * HEAD_TILES * 64 + lane;
+                const float *wrow = lds + (size_t)ks * OT * 64 + lane;
 #pragma unroll
-                for (int t = 0; t < OT; ++t)   // the density tile has zero weights for the encoding
+                for (int t = 0; t < OT; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], b, acc[t], 0, 0, 0);
             }
-            gemm_steps<KSH, KSE, HEAD_TILES>(acc, bin, lds, lane);
-            bias_step<HEAD_KS, HEAD_TILES>(acc, lds, lane);
-            // density = row 0 of tile 4 -> register 0 of the lower half-wave
-            const float raw = acc[OT][0];
-            const float sp = raw > 20.0f ? raw : log1pf(expf(raw));  // torch softplus(beta=1, threshold=20)
-            if (h == 0 && s < n) sigma[s] = sp;
+            gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
+            bias_step<HEAD_KS, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);
         }
-        // ---- rgb head 128 -> 3 + sigmoid (rows 0..2 of one tile)
-        __syncthreads();
-        stage_weights(lds, pk + OFF_WRGB, lfloats(KSH, 1));
-        __syncthreads();
         {
-            f32x16 acc[1];
-            zero_acc(acc);
-            gemm_steps<KSH, 0, 1>(acc, bin, lds, lane);
-            bias_step<KSH, 1>(acc, lds, lane);
+            // rgb head 128 -> 3 + sigmoid on the VALU
+            const float *cv = lds + lfloats(HEAD_KS, OT);
+            const float c0 = head_dot(cv + 64 * h, bin) + cv[384];
+            const float c1 = head_dot(cv + 128 + 64 * h, bin) + cv[385];
+            const float c2 = head_dot(cv + 256 + 64 * h, bin) + cv[386];
             if (h == 0 && s < n) {
-                rgb[3 * s] = 1.0f / (1.0f + expf(-acc[0][0]));
-                rgb[3 * s + 1] = 1.0f / (1.0f + expf(-acc[0][1]));
-                rgb[3 * s + 2] = 1.0f / (1.0f + expf(-acc[0][2]));
+                rgb[3 * s] = 1.0f / (1.0f + expf(-c0));
+                rgb[3 * s + 1] = 1.0f / (1.0f + expf(-c1));
+                rgb[3 * s + 2] = 1.0f / (1.0f + expf(-c2));
             }
         }
     }
@@ -388,7 +406,7 @@ void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, con
         TN_HIP(hipMallocAsync((void **)&fieldT, (size_t)num_vertices * FD * sizeof(float), stream));
         launch_transpose(field, fieldT, FD, num_vertices, stream);  // [64, V] -> [V, 64]
     }
-    const size_t smem = MAX_STAGE_FLOATS * sizeof(float);  // the largest staged layer (head: 101,120 B)
+    const size_t smem = MAX_STAGE_FLOATS * sizeof(float);  // the largest staged layer (head)
     static bool attr_set = false;
     if (!attr_set) {
         TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

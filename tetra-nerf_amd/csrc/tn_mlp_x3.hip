@@ -1,0 +1,420 @@
+// tn_mlp_x3.hip -- the shallow MLP + heads on the bf16 matrix cores at fp32 accuracy ("bf16x3").
+//
+// Optional mode of tn_mlp_forward / tn_mlp_forward_gather (tn_mlp_set_mode(1)); the default stays the
+// exact fp32 MFMA kernel of tn_mlp.hip.  fp32 MFMA runs at the vector rate (157 TFLOP/s); the bf16
+// MFMA (v_mfma_f32_32x32x16_bf16) is 16x faster.  Every fp32 operand is split into three bf16 pieces
+//     x = x_hi + x_mid + x_lo,   x_hi = bf16(x), x_mid = bf16(x - x_hi), x_lo = bf16(x - x_hi - x_mid)
+// (both subtractions are exact in fp32; the three pieces carry 24+ significant bits), and a product is
+// evaluated as the six partial products of order <= 2^-16
+//     w*x ~= w_lo*x_hi + w_hi*x_lo + w_mid*x_mid + w_mid*x_hi + w_hi*x_mid + w_hi*x_hi
+// each exact in the MFMA's fp32 accumulator; the dropped terms are below 2^-24 |w x|, i.e. under one
+// fp32 rounding of the product.  6 bf16 MFMAs (K = 16) replace 8 fp32 MFMAs (K = 2): 2.67x fewer
+// matrix-core cycles for the same 1e-5 parity bar (tests/test_render_gpu.py checks it against float64).
+//
+// Dataflow as in tn_mlp.hip: a wavefront owns 32 samples, computes Y^T = W * X^T, and feeds the
+// accumulators of one layer straight back as the B operand of the next.  With K = 16 per instruction
+// lane (h, s) supplies 8 K-values per step: registers (tile q>>1, r = 8(q&1) .. +7) of its accumulators
+// at step q -- the weights are packed to that K order (k_mlp_pack_x3).  A and B operands use the same
+// (half-wave, element) -> k assignment, so the packing only has to agree with itself.  The bias is the
+// accumulators' initial value.  Per layer the three weight pieces are staged in LDS
+// ([step][tile][piece][lane] x 16 B, <= 120 KB for the head layer) and shared by the 8 waves of a block.
+#include "tn_device.h"
+#include "tn_kernels.h"
+
+namespace tn {
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HID = 128, FD = 64, ENC = 27, ENC32 = 32;
+constexpr int X3_BLOCK = 512;
+
+// sizes in 16-byte units
+constexpr size_t wu4(int steps, int tiles) { return (size_t)steps * tiles * 3 * 64; }
+constexpr size_t bu4(int tiles) { return (size_t)tiles * 8; }  // bias: [tile][half][16] floats
+// The narrow heads (density 128 -> 1, rgb 128 -> 3) run on the VALU as in tn_mlp.hip: their fp32 vectors
+// ([half][64] floats in the lane's K order + bias) ride behind the layer that produces their input.
+constexpr size_t DVEC_U4 = (2 * 64 + 4) / 4, CVEC_U4 = (3 * 2 * 64 + 4) / 4;
+constexpr size_t N_L1 = wu4(4, 4) + bu4(4);
+constexpr size_t N_L2 = wu4(8, 4) + bu4(4);
+constexpr size_t N_L3 = N_L2 + DVEC_U4;
+constexpr size_t N_HEAD = wu4(2, 4) + wu4(8, 4) + bu4(4) + CVEC_U4;
+constexpr size_t O_L1 = 0, O_L2 = O_L1 + N_L1, O_L3 = O_L2 + N_L2, O_HEAD = O_L3 + N_L3, N_BLOB = O_HEAD + N_HEAD;
+constexpr size_t MAX_STAGE_U4 = N_HEAD > N_L3 ? N_HEAD : N_L3;
+
+__host__ __device__ constexpr int acc_feature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// input feature consumed by K slot (step q, half h, element j) of a layer fed from accumulators
+__host__ __device__ constexpr int acc_k(int q, int h, int j) { return 32 * (q >> 1) + acc_feature(8 * (q & 1) + j, h); }
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // a -> low half, round to nearest even
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// 8 fp32 values -> three packed-bf16 operand registers quadruples (hi, mid, lo)
+__device__ __forceinline__ void split8(const float *v, uint4 &hi, uint4 &mid, uint4 &lo) {
+    uint32_t H[4], Mi[4], L[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float a = v[2 * p], b = v[2 * p + 1];
+        const uint32_t ph = pk_bf16(a, b);
+        const float ra = a - __uint_as_float(ph << 16), rb = b - __uint_as_float(ph & 0xFFFF0000u);
+        const uint32_t pm = pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(pm << 16), sb = rb - __uint_as_float(pm & 0xFFFF0000u);
+        H[p] = ph; Mi[p] = pm; L[p] = pk_bf16(sa, sb);
+    }
+    hi = make_uint4(H[0], H[1], H[2], H[3]);
+    mid = make_uint4(Mi[0], Mi[1], Mi[2], Mi[3]);
+    lo = make_uint4(L[0], L[1], L[2], L[3]);
+}
+
+__device__ __forceinline__ f32x16 mma(const uint4 &a, const uint4 &b, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+struct B3 { uint4 h, m, l; };  // the three bf16 pieces of 8 K-values of a lane
+
+// one K = 16 step of NT output tiles: acc[t] += W[t](hi,mid,lo) x B(hi,mid,lo), six partial products,
+// small terms first; two tiles are interleaved so that consecutive MFMAs never share an accumulator
+template <int NT, int TILES>
+__device__ __forceinline__ void x3_mma(f32x16 (&acc)[TILES], const uint4 *wl, const B3 &b, int lane) {
+#pragma unroll
+    for (int t = 0; t + 1 < NT; t += 2) {
+        const uint4 *w0 = wl + (size_t)t * 192 + lane, *w1 = w0 + 192;
+        const uint4 ah0 = w0[0], am0 = w0[64], al0 = w0[128];
+        const uint4 ah1 = w1[0], am1 = w1[64], al1 = w1[128];
+        acc[t] = mma(al0, b.h, acc[t]);     acc[t + 1] = mma(al1, b.h, acc[t + 1]);
+        acc[t] = mma(ah0, b.l, acc[t]);     acc[t + 1] = mma(ah1, b.l, acc[t + 1]);
+        acc[t] = mma(am0, b.m, acc[t]);     acc[t + 1] = mma(am1, b.m, acc[t + 1]);
+        acc[t] = mma(am0, b.h, acc[t]);     acc[t + 1] = mma(am1, b.h, acc[t + 1]);
+        acc[t] = mma(ah0, b.m, acc[t]);     acc[t + 1] = mma(ah1, b.m, acc[t + 1]);
+        acc[t] = mma(ah0, b.h, acc[t]);     acc[t + 1] = mma(ah1, b.h, acc[t + 1]);
+    }
+    if constexpr (NT & 1) {
+        constexpr int t = NT - 1;
+        const uint4 *w0 = wl + (size_t)t * 192 + lane;
+        const uint4 ah0 = w0[0], am0 = w0[64], al0 = w0[128];
+        acc[t] = mma(al0, b.h, acc[t]);
+        acc[t] = mma(ah0, b.l, acc[t]);
+        acc[t] = mma(am0, b.m, acc[t]);
+        acc[t] = mma(am0, b.h, acc[t]);
+        acc[t] = mma(ah0, b.m, acc[t]);
+        acc[t] = mma(ah0, b.h, acc[t]);
+    }
+}
+
+// STEPS consecutive K = 16 steps over bin[0 .. 8*STEPS): the operand split of step q+1 (VALU) is issued
+// in the same scheduling region as the MFMAs of step q, so it runs in their shadow; the sched_barrier
+// between regions keeps the A-operand reads of later steps from being hoisted (registers).
+template <int STEPS, int NT, int TILES>
+__device__ __forceinline__ void x3_steps(f32x16 (&acc)[TILES], const uint4 *wl, const float *bin, int lane) {
+    B3 cur, nxt;
+    split8(bin, cur.h, cur.m, cur.l);
+#pragma unroll
+    for (int q = 0; q < STEPS; ++q) {
+        if (q + 1 < STEPS) split8(bin + 8 * (q + 1), nxt.h, nxt.m, nxt.l);
+        x3_mma<NT>(acc, wl + (size_t)q * NT * 192, cur, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+}
+
+template <int TILES>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[TILES], const uint4 *bias, int h) {
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        const float4 *b = reinterpret_cast<const float4 *>(bias) + (t * 2 + h) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 x = b[q];
+            acc[t][4 * q] = x.x; acc[t][4 * q + 1] = x.y; acc[t][4 * q + 2] = x.z; acc[t][4 * q + 3] = x.w;
+        }
+    }
+}
+
+__device__ __forceinline__ float head_dot(const float *wl, const float (&bin)[64]) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float4 w4 = reinterpret_cast<const float4 *>(wl)[i];
+        a0 = __builtin_fmaf(w4.x, bin[4 * i], a0);
+        a1 = __builtin_fmaf(w4.y, bin[4 * i + 1], a1);
+        a2 = __builtin_fmaf(w4.z, bin[4 * i + 2], a2);
+        a3 = __builtin_fmaf(w4.w, bin[4 * i + 3], a3);
+    }
+    const float part = (a0 + a1) + (a2 + a3);
+    return part + __shfl_xor(part, 32);
+}
+
+template <int TILES>
+__device__ __forceinline__ void relu_to_bin(const f32x16 (&acc)[TILES], float (&bin)[64]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bin[t * 16 + r] = fmaxf(acc[t][r], 0.f);
+}
+
+// Layer blob -> LDS with the async global->LDS path (global_load_lds_dwordx4: no staging registers, all
+// of a thread's loads in flight at once; a load-wait-write loop exposes one L2 latency per 8 KB).  The LDS
+// destination of a wave is uniform base + lane * 16, which is exactly a linear copy.
+__device__ __forceinline__ void stage(uint4 *lds, const uint4 *__restrict__ src, uint32_t n16) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+    for (uint32_t base = wave0; base < n16; base += X3_BLOCK) {
+        const uint32_t i = base + lane;
+        if (i < n16)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i),
+                                             (__attribute__((address_space(3))) void *)(lds + base), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void stage_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// ---- weight packing -------------------------------------------------------------------------------
+
+// weight of (segment, output tile, row, K slot); segments: 0 L1, 1 L2, 2 L3, 3 head/encoding steps,
+// 4 head/base steps
+__device__ float x3_weight(const MlpWeights &w, int seg, int tile, int row, int q, int h, int j) {
+    const int o = 32 * tile + row;
+    switch (seg) {
+        case 0: return w.w1[(size_t)o * FD + 32 * h + 8 * q + j];
+        case 1: return w.w2[(size_t)o * HID + acc_k(q, h, j)];
+        case 2: return w.w3[(size_t)o * HID + acc_k(q, h, j)];
+        case 3: { const int e = 16 * q + 8 * h + j; return e < ENC ? w.wh[(size_t)o * (ENC + HID) + e] : 0.f; }
+        default: return w.wh[(size_t)o * (ENC + HID) + ENC + acc_k(q, h, j)];
+    }
+}
+
+__device__ float x3_bias(const MlpWeights &w, int layer, int tile, int h, int r) {
+    const int o = 32 * tile + acc_feature(r, h);
+    switch (layer) {
+        case 0: return w.b1[o];
+        case 1: return w.b2[o];
+        case 2: return w.b3[o];
+        default: return w.bh[o];
+    }
+}
+
+struct Seg { int seg, steps, tiles; size_t off; };
+
+__global__ void k_mlp_pack_x3(MlpWeights w, uint4 *__restrict__ blob) {
+    const Seg segs[5] = {{0, 4, 4, O_L1}, {1, 8, 4, O_L2}, {2, 8, 4, O_L3}, {3, 2, 4, O_HEAD}, {4, 8, 4, O_HEAD + wu4(2, 4)}};
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int s = 0; s < 5; ++s) {
+        const size_t cnt = (size_t)segs[s].steps * segs[s].tiles * 64;
+        if (i < cnt) {
+            const int lane = (int)(i & 63), st = (int)(i >> 6), tile = st % segs[s].tiles, q = st / segs[s].tiles;
+            float v[8];
+            for (int j = 0; j < 8; ++j) v[j] = x3_weight(w, segs[s].seg, tile, lane & 31, q, lane >> 5, j);
+            uint4 hi, mid, lo;
+            split8(v, hi, mid, lo);
+            uint4 *dst = blob + segs[s].off + (size_t)st * 192 + lane;
+            dst[0] = hi; dst[64] = mid; dst[128] = lo;
+            return;
+        }
+        i -= cnt;
+    }
+    // biases: [tile][half][16] floats behind each layer's weights
+    const size_t boff[4] = {O_L1 + wu4(4, 4), O_L2 + wu4(8, 4), O_L3 + wu4(8, 4), O_HEAD + wu4(2, 4) + wu4(8, 4)};
+    for (int l = 0; l < 4; ++l) {
+        if (i < 128) {
+            const int r = (int)(i & 15), h = (int)((i >> 4) & 1), tile = (int)(i >> 5);
+            reinterpret_cast<float *>(blob + boff[l])[i] = x3_bias(w, l, tile, h, r);
+            return;
+        }
+        i -= 128;
+    }
+    // head vectors (fp32): density behind layer 3, rgb behind the head layer; K order of bin[]: feature
+    // 32*(i>>4) + acc_feature(i&15, h) for element i of half h
+    float *dv = reinterpret_cast<float *>(blob + O_L3 + N_L2);
+    float *cv = reinterpret_cast<float *>(blob + O_HEAD + wu4(2, 4) + wu4(8, 4) + bu4(4));
+    if (i < 132) {
+        const int j = (int)i;
+        dv[j] = j < 128 ? w.wd[32 * ((j & 63) >> 4) + acc_feature(j & 15, j >> 6)] : (j == 128 ? w.bd[0] : 0.f);
+        return;
+    }
+    i -= 132;
+    if (i < 388) {
+        const int j = (int)i;
+        cv[j] = j < 384 ? w.wr[(size_t)(j >> 7) * HID + 32 * ((j & 63) >> 4) + acc_feature(j & 15, (j >> 6) & 1)]
+                        : (j < 387 ? w.br[j - 384] : 0.f);
+    }
+}
+constexpr size_t PACK_THREADS = (4 * 4 + 8 * 4 + 8 * 4 + 2 * 4 + 8 * 4) * 64 + 4 * 128 + 132 + 388;
+
+// direction encoding per ray, padded to 32 (same arithmetic as k_dir_encoding of tn_mlp.hip)
+__global__ void k_dir_encoding32(size_t R, const float *__restrict__ dirs, float *__restrict__ enc) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float two_pi = 6.283185307179586f, half_pi = 1.5707963267948966f;
+    const float freqs[4] = {1.0f, 2.5198421478271484f, 6.349603652954102f, 16.0f};
+    float *e = enc + r * ENC32;
+    for (int c = 0; c < 3; ++c) {
+        const float x = two_pi * dirs[3 * r + c];
+        for (int f = 0; f < 4; ++f) {
+            const float s = x * freqs[f];
+            e[c * 4 + f] = sinf(s);
+            e[12 + c * 4 + f] = sinf(s + half_pi);
+        }
+        e[24 + c] = dirs[3 * r + c];
+    }
+    for (int k = ENC; k < ENC32; ++k) e[k] = 0.f;
+}
+
+}  // namespace
+
+template <bool GATHER, bool DENSITY_ONLY>
+__global__ __launch_bounds__(X3_BLOCK) void k_mlp_forward_x3(size_t n, uint32_t samples_per_ray, const float *__restrict__ feats,
+                                                             const uint32_t *__restrict__ vi, const float *__restrict__ bc,
+                                                             const float *__restrict__ fieldT, const float *__restrict__ enc,
+                                                             const uint4 *__restrict__ blob, float *__restrict__ sigma,
+                                                             float *__restrict__ rgb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4 *lds = reinterpret_cast<uint4 *>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    constexpr size_t GROUP = (X3_BLOCK / 64) * 32;
+    const size_t ngroups = (n + GROUP - 1) / GROUP;
+
+    for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const size_t s = g * GROUP + (size_t)wave * 32 + (lane & 31);
+        const size_t sc = s < n ? s : n - 1;
+        float bin[64];
+
+        // ---- layer 1: this lane supplies features 32h .. 32h+31 of its sample
+        __syncthreads();
+        stage(lds, blob + O_L1, N_L1);
+        if constexpr (!GATHER) {  // B operands straight from the feature-major input [64, n]
+#pragma unroll
+            for (int i = 0; i < 32; ++i) bin[i] = feats[(size_t)(32 * h + i) * n + sc];
+        } else {
+            const uint4 v4 = *reinterpret_cast<const uint4 *>(vi + 4 * sc);
+            const float b0 = bc[3 * sc], b1 = bc[3 * sc + 1], b2 = bc[3 * sc + 2];
+            const float w0 = 1.0f - ((b0 + b1) + b2);
+            const uint32_t vv[4] = {v4.y, v4.z, v4.w, v4.x};
+            const float ww[4] = {b0, b1, b2, w0};
+#pragma unroll
+            for (int i = 0; i < 32; ++i) bin[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (vv[k] != TN_EMPTY) {
+                    const float4 *row = reinterpret_cast<const float4 *>(fieldT + (size_t)vv[k] * FD + 32 * h);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float4 x = row[q];
+                        bin[4 * q] += ww[k] * x.x; bin[4 * q + 1] += ww[k] * x.y;
+                        bin[4 * q + 2] += ww[k] * x.z; bin[4 * q + 3] += ww[k] * x.w;
+                    }
+                }
+            }
+        }
+        stage_wait();
+        {
+            f32x16 acc[4];
+            init_bias(acc, lds + wu4(4, 4), h);
+            x3_steps<4, 4>(acc, lds, bin, lane);
+            relu_to_bin(acc, bin);
+        }
+        // ---- layers 2, 3
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            __syncthreads();
+            stage(lds, blob + (l == 0 ? O_L2 : O_L3), l == 0 ? N_L2 : N_L3);
+            stage_wait();
+            f32x16 acc[4];
+            init_bias(acc, lds + wu4(8, 4), h);
+            x3_steps<8, 4>(acc, lds, bin, lane);
+            relu_to_bin(acc, bin);
+        }
+        {
+            // density head 128 -> 1 + softplus on the VALU, fp32 (vector behind layer 3's blob)
+            const float *dv = reinterpret_cast<const float *>(lds + N_L2);
+            const float raw = head_dot(dv + 64 * h, bin) + dv[128];
+            const float sp = raw > 20.0f ? raw : log1pf(expf(raw));
+            if (h == 0 && s < n) sigma[s] = sp;
+        }
+        if constexpr (DENSITY_ONLY) continue;
+        // ---- head [enc(27) | base(128)] -> 128 ReLU
+        __syncthreads();
+        stage(lds, blob + O_HEAD, N_HEAD);
+        stage_wait();
+        {
+            f32x16 acc[4];
+            init_bias(acc, lds + wu4(2, 4) + wu4(8, 4), h);
+            const float *e = enc + (sc / samples_per_ray) * ENC32;
+            float ev[16];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 e0 = *reinterpret_cast<const float4 *>(e + 16 * q + 8 * h);
+                const float4 e1 = *reinterpret_cast<const float4 *>(e + 16 * q + 8 * h + 4);
+                ev[8 * q] = e0.x; ev[8 * q + 1] = e0.y; ev[8 * q + 2] = e0.z; ev[8 * q + 3] = e0.w;
+                ev[8 * q + 4] = e1.x; ev[8 * q + 5] = e1.y; ev[8 * q + 6] = e1.z; ev[8 * q + 7] = e1.w;
+            }
+            x3_steps<2, 4>(acc, lds, ev, lane);
+            x3_steps<8, 4>(acc, lds + wu4(2, 4), bin, lane);
+            relu_to_bin(acc, bin);
+        }
+        {
+            // rgb head 128 -> 3 + sigmoid on the VALU, fp32
+            const float *cv = reinterpret_cast<const float *>(lds + wu4(2, 4) + wu4(8, 4) + bu4(4));
+            const float c0 = head_dot(cv + 64 * h, bin) + cv[384];
+            const float c1 = head_dot(cv + 128 + 64 * h, bin) + cv[385];
+            const float c2 = head_dot(cv + 256 + 64 * h, bin) + cv[386];
+            if (h == 0 && s < n) {
+                rgb[3 * s] = 1.0f / (1.0f + expf(-c0));
+                rgb[3 * s + 1] = 1.0f / (1.0f + expf(-c1));
+                rgb[3 * s + 2] = 1.0f / (1.0f + expf(-c2));
+            }
+        }
+    }
+}
+
+void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
+                           const float *bc, const float *field, uint32_t num_vertices, const float *dirs,
+                           const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream) {
+    if (n == 0) return;
+    const bool gather = feats == nullptr;
+    const bool density_only = rgb == nullptr;
+    if (density_only) num_rays = 0;
+    uint4 *blob = nullptr;
+    float *enc = nullptr, *fieldT = nullptr;
+    TN_HIP(hipMallocAsync((void **)&blob, N_BLOB * sizeof(uint4), stream));
+    TN_HIP(hipMallocAsync((void **)&enc, (num_rays ? num_rays : 1) * ENC32 * sizeof(float), stream));
+    hipLaunchKernelGGL(k_mlp_pack_x3, dim3((unsigned)((PACK_THREADS + 255) / 256)), dim3(256), 0, stream, w, blob);
+    if (num_rays)
+        hipLaunchKernelGGL(k_dir_encoding32, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, stream, num_rays, dirs, enc);
+    if (gather) {
+        TN_HIP(hipMallocAsync((void **)&fieldT, (size_t)num_vertices * FD * sizeof(float), stream));
+        launch_transpose(field, fieldT, FD, num_vertices, stream);
+    }
+    const size_t smem = MAX_STAGE_U4 * sizeof(uint4);  // head layer: 120 KB of weight pieces + bias + rgb vectors
+    static bool attr_set = false;
+    if (!attr_set) {
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward_x3<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward_x3<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward_x3<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward_x3<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const size_t group = (X3_BLOCK / 64) * 32;
+    const size_t ngroups = (n + group - 1) / group;
+    const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
+#define TN_X3_LAUNCH(G, D)                                                                                            \
+    hipLaunchKernelGGL((k_mlp_forward_x3<G, D>), dim3(grid), dim3(X3_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc, \
+                       fieldT, enc, blob, sigma, rgb)
+    if (gather && density_only) TN_X3_LAUNCH(true, true);
+    else if (gather) TN_X3_LAUNCH(true, false);
+    else if (density_only) TN_X3_LAUNCH(false, true);
+    else TN_X3_LAUNCH(false, false);
+#undef TN_X3_LAUNCH
+    TN_HIP(hipFreeAsync(blob, stream));
+    TN_HIP(hipFreeAsync(enc, stream));
+    if (fieldT) TN_HIP(hipFreeAsync(fieldT, stream));
+}
+
+}  // namespace tn

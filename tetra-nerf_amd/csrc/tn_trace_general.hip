@@ -283,7 +283,7 @@ __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, ui
         auto run_leaves = [&]() {
             wave_sync();
             if (nleaf == 0) return;
-            if (lane == 0 && stats) atomicAdd(&stats[19], (unsigned long long)nleaf);
+            if (lane == 0 && stats) atomicAdd(&stats[23], (unsigned long long)nleaf);
             auto fetch = [&](uint32_t li, float (&d)[9], uint32_t &fid) {
                 const float *tr = bvh.leaf_tri + (size_t)li * (9 * WIDE) + lane;
 #pragma unroll
@@ -311,7 +311,7 @@ __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, ui
             const uint32_t idx = s.stack[sp - 1];
             sp--;
             wave_sync();  // everyone has read the top before it can be overwritten
-            if (lane == 0 && stats) atomicAdd(&stats[18], 1ull);
+            if (lane == 0 && stats) atomicAdd(&stats[22], 1ull);
             const float *b = bvh.boxes + (size_t)idx * (6 * WIDE);
             const uint32_t ch = bvh.child[(size_t)idx * WIDE + lane];
             const bool hit = ch != TN_EMPTY &&
@@ -372,6 +372,38 @@ __global__ __launch_bounds__(64) void k_postprocess_hits(TraceParams p, const ui
             s.hv[j] = hit_uv[2 * (ray * M + j) + 1];
         }
         wave_sync();
+        postprocess_and_write(s, nh, M, p.faces, p.face_tets, p.out_num + ray, p.out_cells + ray * M,
+                              p.out_bary + ray * M * 6, p.out_dist + ray * M * 2,
+                              p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane);
+        wave_sync();
+    }
+}
+
+// Sort + literal pairing of the raw hit lists k_walk_collect left in the rays' own output rows
+// (ids in the visited row, t in the first M floats of the distance row, (u,v) in the first 2M floats of the
+// barycentric row, count in num_visited; TN_EMPTY = handed to the BVH path).  All hits are in LDS before
+// the first output byte is written.
+__global__ __launch_bounds__(64) void k_postprocess_rows(TraceParams p, const uint4 *__restrict__ rewalk_list,
+                                                         const uint32_t *__restrict__ rewalk_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WaveSmem s = carve(smem, p.M);
+    const int lane = threadIdx.x;
+    const uint32_t M = p.M;
+    const size_t n_items = *rewalk_count;
+    for (size_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const size_t ray = rewalk_list[it].x;
+        const uint32_t cnt = p.out_num[ray];
+        if (cnt == TN_EMPTY) continue;  // wave-uniform
+        const uint32_t nh = cnt < M ? cnt : M;
+        const uint32_t *ids = p.out_cells + ray * M;
+        const float *ts = p.out_dist + ray * M * 2, *uv = p.out_bary + ray * M * 6;
+        for (uint32_t j = lane; j < nh; j += 64) {
+            s.key[j] = ((uint64_t)__float_as_uint(ts[j]) << 32) | ids[j];
+            s.hu[j] = uv[2 * j];
+            s.hv[j] = uv[2 * j + 1];
+        }
+        wave_sync();
+        sort_hits(s, nh, lane);
         postprocess_and_write(s, nh, M, p.faces, p.face_tets, p.out_num + ray, p.out_cells + ray * M,
                               p.out_bary + ray * M * 6, p.out_dist + ray * M * 2,
                               p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane);
@@ -492,6 +524,14 @@ void launch_trace_general(const TraceParams &p, hipStream_t stream) {
     const size_t max_blocks = 256 * 16;
     const unsigned grid = (unsigned)(p.num_items < max_blocks ? p.num_items : max_blocks);
     hipLaunchKernelGGL(k_trace_general, dim3(grid), dim3(64), smem, stream, p);
+}
+
+void launch_postprocess_rows(const TraceParams &p, const uint4 *rewalk_list, const uint32_t *rewalk_count, size_t max_items,
+                             hipStream_t stream) {
+    if (max_items == 0) return;
+    const size_t max_blocks = 256 * 16;
+    const unsigned grid = (unsigned)(max_items < max_blocks ? max_items : max_blocks);
+    hipLaunchKernelGGL(k_postprocess_rows, dim3(grid), dim3(64), trace_general_smem_bytes(p.M), stream, p, rewalk_list, rewalk_count);
 }
 
 void launch_postprocess_hits(const TraceParams &p, const uint32_t *hit_count, const uint32_t *hit_ids,

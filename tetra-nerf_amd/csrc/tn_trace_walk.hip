@@ -94,6 +94,21 @@ __device__ __forceinline__ WalkRec load_rec(const TetRec *tets, uint32_t c) {
     return x;
 }
 
+// (t,u,v) of face k of the current tet in the face's STORED vertex order: U,V,W are picked (with sign) from
+// the six shared edge functions -- E(Q,P) == -E(P,Q) bitwise -- by the record's codes.
+__device__ __forceinline__ bool face_tuv(const WalkRec &rc, const SV &P0, const SV &P1, const SV &P2, const SV &P3, float e01,
+                                         float e02, float e03, float e12, float e13, float e23, uint32_t k, float &tt,
+                                         float &uu, float &vv) {
+    const uint32_t word = (k & 2u) ? rc.m1.x : rc.m0.w;
+    const uint32_t code = (word >> (12u * (k & 1u))) & 0xFFFu;
+    const uint32_t pm = rc.m0.x >> (6u * k);
+    const float U = sel_edge(e01, e02, e03, e12, e13, e23, code);
+    const float V = sel_edge(e01, e02, e03, e12, e13, e23, code >> 4);
+    const float W = sel_edge(e01, e02, e03, e12, e13, e23, code >> 8);
+    return tri_finish(U, V, W, sel4f(P0.z, P1.z, P2.z, P3.z, pm & 3u), sel4f(P0.z, P1.z, P2.z, P3.z, (pm >> 2) & 3u),
+                      sel4f(P0.z, P1.z, P2.z, P3.z, (pm >> 4) & 3u), tt, uu, vv);
+}
+
 }  // namespace
 
 template <bool PREFETCH>
@@ -181,10 +196,12 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     uint32_t *row_verts = t.out_verts ? t.out_verts + rr * M * 4 : nullptr;
 
     uint32_t nseg = 0;
+    uint32_t c_start = 0, e_start = 0, f_end = 0;  // chain start / hull exit face, for the re-walk of an uncertified chain
     if (nhull == 2 && !flag) {
         const uint32_t f_out = ht0 < ht1 ? hf1 : hf0;
         uint32_t c = ht0 < ht1 ? hc0 : hc1;  // record of the entry face's tet (a hull face has exactly one)
         uint32_t e = ht0 < ht1 ? he0 : he1;  // local index of the entry face in it
+        c_start = c; e_start = e; f_end = f_out;
         // state of the previous recorded (valid) hit
         bool have_prev = false, have_pp = false, pending_inv = false, had_special = false;
         float pt = 0.f, pu = 0.f, pv = 0.f, ppt = 0.f;
@@ -201,19 +218,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         // arithmetic of this step runs under the load's latency.
         WalkRec cur = load_rec(p.tets, c);
 
-        // (t,u,v) of face k of the current tet in the face's STORED vertex order: U,V,W are picked (with
-        // sign) from the six shared edge functions -- E(Q,P) == -E(P,Q) bitwise -- by the record's codes.
-        auto face_tuv = [&](const WalkRec &rc, const SV &P0, const SV &P1, const SV &P2, const SV &P3, float e01, float e02,
-                            float e03, float e12, float e13, float e23, uint32_t k, float &tt, float &uu, float &vv) -> bool {
-            const uint32_t word = (k & 2u) ? rc.m1.x : rc.m0.w;
-            const uint32_t code = (word >> (12u * (k & 1u))) & 0xFFFu;
-            const uint32_t pm = rc.m0.x >> (6u * k);
-            const float U = sel_edge(e01, e02, e03, e12, e13, e23, code);
-            const float V = sel_edge(e01, e02, e03, e12, e13, e23, code >> 4);
-            const float W = sel_edge(e01, e02, e03, e12, e13, e23, code >> 8);
-            return tri_finish(U, V, W, sel4f(P0.z, P1.z, P2.z, P3.z, pm & 3u), sel4f(P0.z, P1.z, P2.z, P3.z, (pm >> 2) & 3u),
-                              sel4f(P0.z, P1.z, P2.z, P3.z, (pm >> 4) & 3u), tt, uu, vv);
-        };
         // vertex ids of the entry face in its stored order (carried: the exit face of one step is the
         // entry face of the next, same face table entry => same triple)
         uint32_t in0, in1, in2;
@@ -376,8 +380,16 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     // ------------------------------------------------------------------ fallback list + tails
     if (active) {
         if (flag) {
-            const uint32_t slot = atomicAdd(p.fallback_count, 1u);
-            p.fallback_list[slot] = (uint32_t)(p.ray_base + ray);
+            // ordering problems only (7 / 8: the chain itself is sound, its sorted order is not certified;
+            // 10: an invalid t inside the chain): the hit list is re-collected by walking the chain again
+            // (k_walk_collect) and goes through the literal sort + pairing; anything else -> BVH all-hits path
+            if (p.rewalk_list && (why == 7 || why == 8 || why == 10)) {
+                const uint32_t slot = atomicAdd(p.rewalk_count, 1u);
+                p.rewalk_list[slot] = make_uint4((uint32_t)(p.ray_base + ray), c_start, e_start, f_end);
+            } else {
+                const uint32_t slot = atomicAdd(p.fallback_count, 1u);
+                p.fallback_list[slot] = (uint32_t)(p.ray_base + ray);
+            }
             if (t.stats) atomicAdd(&t.stats[4 + why], 1ull);
             p.walk_n[ray] = TN_EMPTY;
         } else {
@@ -400,6 +412,107 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         fill_dwords(reinterpret_cast<uint32_t *>(t.out_bary + r_i * M * 6), 6 * n_i, 6 * M, 0u, lane);
         if (t.out_verts) fill_dwords(t.out_verts + r_i * M * 4, 4 * n_i, 4 * M, TN_EMPTY, lane);
     }
+}
+
+// Re-walk of the chains whose ORDER the walk could not certify (reasons 7 / 8 / 10): lane per ray, same
+// chain, same per-face arithmetic, but every valid hit (face id, t, u, v) is only RECORDED -- into the ray's
+// own output rows, used as scratch exactly like the reference's any-hit program does
+// (optix_trace_rays.cu:310-326): ids -> visited row, t -> first M floats of the distance row, (u,v) -> first
+// 2M floats of the barycentric row, count -> num_visited.  k_postprocess_rows then sorts and pairs them
+// literally.  With two hull crossings, two crossed faces per tet and no zero edge function, the faces of the
+// chain ARE the ray's all-hits set, so this equals the BVH path at a fraction of its cost; a chain that fails
+// those checks here goes to the BVH list after all.
+__global__ __launch_bounds__(WALK_BLOCK) void k_walk_collect(WalkParams p) {
+    const TraceParams &t = p.t;
+    const uint32_t M = t.M;
+    const uint32_t n_items = *p.rewalk_count;
+    // A lane walking ~200 dependent steps only pays off with enough lanes: below `rewalk_min` chains one
+    // wavefront per ray through the BVH finishes sooner (measured: 1021 chains 0.39 ms vs 0.25 ms), so the
+    // entries are handed to that list unchanged (decided on the device: no host round trip).
+    const bool hand_over = n_items < p.rewalk_min;
+    for (uint32_t it = blockIdx.x * WALK_BLOCK + threadIdx.x; it < n_items; it += gridDim.x * WALK_BLOCK) {
+        const uint4 ent = p.rewalk_list[it];
+        if (hand_over) {
+            const uint32_t slot = atomicAdd(p.fallback_count, 1u);
+            p.fallback_list[slot] = ent.x;
+            t.out_num[ent.x] = TN_EMPTY;
+            if (t.stats) atomicAdd(&t.stats[4 + 14], 1ull);
+            continue;
+        }
+        const size_t ray = ent.x;
+        uint32_t c = ent.y, e = ent.z;
+        const uint32_t f_out = ent.w;
+        const RayPre rp = ray_pre(t.origins[3 * ray], t.origins[3 * ray + 1], t.origins[3 * ray + 2], t.dirs[3 * ray],
+                                  t.dirs[3 * ray + 1], t.dirs[3 * ray + 2]);
+        uint32_t *row_id = t.out_cells + ray * M;
+        float *row_t = t.out_dist + ray * M * 2;
+        float *row_uv = t.out_bary + ray * M * 6;
+        uint32_t nhits = 0, steps = 0, bad = 0;
+        auto record = [&](uint32_t fid, float tt, float uu, float vv) {
+            if (nhits < M - 1) {
+                row_id[nhits] = fid;
+                row_t[nhits] = tt;
+                *reinterpret_cast<float2 *>(row_uv + 2 * nhits) = make_float2(uu, vv);
+            }
+            nhits++;
+        };
+        WalkRec cur = load_rec(p.tets, c);
+        bool first = true;
+        for (;;) {
+            const SV P0 = shear(rp, __uint_as_float(cur.q0.x), __uint_as_float(cur.q0.y), __uint_as_float(cur.q0.z));
+            const SV P1 = shear(rp, __uint_as_float(cur.q0.w), __uint_as_float(cur.q1.x), __uint_as_float(cur.q1.y));
+            const SV P2 = shear(rp, __uint_as_float(cur.q1.z), __uint_as_float(cur.q1.w), __uint_as_float(cur.q2.x));
+            const SV P3 = shear(rp, __uint_as_float(cur.q2.y), __uint_as_float(cur.q2.z), __uint_as_float(cur.q2.w));
+            const float e01 = edge_f(P0, P1), e02 = edge_f(P0, P2), e03 = edge_f(P0, P3);
+            const float e12 = edge_f(P1, P2), e13 = edge_f(P1, P3), e23 = edge_f(P2, P3);
+            if (e01 == 0.0f || e02 == 0.0f || e03 == 0.0f || e12 == 0.0f || e13 == 0.0f || e23 == 0.0f) bad = 5;
+            const bool h3 = (e01 > 0.0f) == (e12 > 0.0f) && (e12 > 0.0f) == (e02 < 0.0f);
+            const bool h2 = (e01 > 0.0f) == (e13 > 0.0f) && (e13 > 0.0f) == (e03 < 0.0f);
+            const bool h1 = (e02 > 0.0f) == (e23 > 0.0f) && (e23 > 0.0f) == (e03 < 0.0f);
+            const bool h0 = (e12 > 0.0f) == (e23 > 0.0f) && (e23 > 0.0f) == (e13 < 0.0f);
+            const uint32_t hmask = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
+            if (!bad && (__popc(hmask) != 2 || !((hmask >> e) & 1u))) bad = 6;
+            const uint32_t x = (__ffs(hmask & ~(1u << e)) - 1) & 3u;  // exit face
+            const uint32_t nb = sel4u(cur.nbr, x);
+            const uint32_t back = (cur.m0.y >> (2 * x)) & 3u;
+            const bool last = nb == TN_EMPTY;
+            const WalkRec nxt = load_rec(p.tets, (last || bad) ? c : nb);  // requested before this step's stores
+            __builtin_amdgcn_sched_barrier(0);
+            if (bad) break;
+            const uint4 face = reinterpret_cast<const uint4 *>(p.tets + c)[2];
+            float tt, uu, vv;
+            if (first) {  // the hull entry face itself
+                first = false;
+                if (face_tuv(cur, P0, P1, P2, P3, e01, e02, e03, e12, e13, e23, e, tt, uu, vv)) record(sel4u(face, e), tt, uu, vv);
+            }
+            if (face_tuv(cur, P0, P1, P2, P3, e01, e02, e03, e12, e13, e23, x, tt, uu, vv)) record(sel4u(face, x), tt, uu, vv);
+            if (last) {
+                if (sel4u(face, x) != f_out) bad = 11;
+                break;
+            }
+            if (++steps > MAX_WALK_STEPS) { bad = 12; break; }
+            e = back;
+            c = nb;
+            cur = nxt;
+        }
+        if (!bad && nhits > M - 1) bad = 9;  // overflow: the BVH path keeps the M-1 nearest
+        if (bad) {
+            const uint32_t slot = atomicAdd(p.fallback_count, 1u);
+            p.fallback_list[slot] = (uint32_t)ray;
+            t.out_num[ray] = TN_EMPTY;  // k_postprocess_rows skips it; the BVH kernel rewrites the row
+            if (t.stats) atomicAdd(&t.stats[4 + 14], 1ull);
+        } else {
+            t.out_num[ray] = nhits;
+            if (t.stats) atomicAdd(&t.stats[4 + 13], 1ull);
+        }
+    }
+}
+
+void launch_walk_collect(const WalkParams &p, size_t max_items, hipStream_t stream) {
+    if (max_items == 0) return;
+    size_t blocks = (max_items + WALK_BLOCK - 1) / WALK_BLOCK;
+    if (blocks > 256 * 4) blocks = 256 * 4;
+    hipLaunchKernelGGL(k_walk_collect, dim3((unsigned)blocks), dim3(WALK_BLOCK), 0, stream, p);
 }
 
 // Constant tails of the rows the walk certified: slots [n, M) of the four row arrays.  Pure

@@ -204,10 +204,11 @@ class TetrahedraTracer:
         return {"walk": arr[0], "general": arr[1], "serial": arr[2], "overflow": arr[3]}
 
     def flag_reasons(self):
-        """Why the walk handed rays of the last trace_rays to the general path (reason code -> count)."""
+        """Why the walk handed rays of the last trace_rays over (reason code 1..12 -> count); 13 = chains
+        re-walked and paired literally (order not certified), 14 = re-walked chains sent on to the BVH path."""
         arr = (C.c_uint64 * 16)()
         _lib.check(self._lib.tn_trace_flag_reasons(self._h, C.byref(arr)))
-        return {k: int(arr[k]) for k in range(1, 13) if arr[k]}
+        return {k: int(arr[k]) for k in range(1, 15) if arr[k]}
 
     def set_option(self, name: str, value: int):
         _lib.check(self._lib.tn_set_option(self._h, name.encode(), int(value)))
@@ -291,6 +292,18 @@ def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, 
 
 class _MlpWeightsStruct(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd", "wh", "bh", "wr", "br")]
+
+
+def mlp_set_mode(mode):
+    """Arithmetic of mlp_forward / mlp_forward_gather (process-wide): "fp32" (default; exact fp32 MFMA
+    chain) or "bf16x3" (bf16 MFMA on 3-way split operands, fp32-grade accuracy, ~2x faster)."""
+    m = {"fp32": 0, "bf16x3": 1, 0: 0, 1: 1}.get(mode)
+    _check(m is not None, 'mlp mode must be "fp32" or "bf16x3"')
+    _lib.check(_lib.load().tn_mlp_set_mode(m))
+
+
+def mlp_get_mode():
+    return ("fp32", "bf16x3")[_lib.load().tn_mlp_get_mode()]
 
 
 def mlp_forward(feats_fm, dirs, weights, samples_per_ray):
