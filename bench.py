@@ -86,12 +86,19 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
 
     hit = frame()
     dt = timed(rd)
-    # the two shipped evaluation configs with the PDF fine pass (registration.py:55-57, model.py:78-80)
+    # the two shipped evaluation configs with the PDF fine pass (registration.py:55-57, model.py:78-80), in both
+    # arithmetic modes of the fused MLP kernel (fp32 MFMA = exact fp32 chain; bf16x3 = split-operand bf16 MFMA)
     full = {}
-    for name, (s_c, s_f, biased) in (("tetra-nerf-original", (256, 256, False)), ("tetra-nerf", (128, 128, True))):
-        dtf = timed(render.TetraRenderer(tracer, field, mlp, s_c, M, fused=True, num_fine_samples=s_f, biased=biased))
-        full[name] = {"rendered_rays_per_s": R / dtf, "ms_per_frame": dtf * 1e3,
-                      "samples_per_ray": f"{s_c} coarse (density only) + {s_c + s_f + 1} fine"}
+    configs = (("coarse-256", (samples, 0, False)), ("tetra-nerf-original", (256, 256, False)), ("tetra-nerf", (128, 128, True)))
+    for mode in ("fp32", "bf16x3"):
+        tn.cpp.mlp_set_mode(mode)
+        for name, (s_c, s_f, biased) in configs:
+            if mode == "fp32" and s_f == 0:
+                continue  # that is `dt` above
+            dtf = timed(render.TetraRenderer(tracer, field, mlp, s_c, M, fused=True, num_fine_samples=s_f, biased=biased))
+            full.setdefault(name, {"samples_per_ray": f"{s_c} coarse" + (f" (density only) + {s_c + s_f + 1} fine" if s_f else "")})
+            full[name][mode] = {"rendered_rays_per_s": R / dtf, "ms_per_frame": dtf * 1e3}
+    tn.cpp.mlp_set_mode("fp32")
     # MLP kernel alone on one chunk worth of samples of hitting rays (MFMA roofline)
     n = min(hit, chunk) * samples
     feats = torch.randn(64, n, device=dev)
@@ -108,12 +115,25 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
     mlp_ms = e0.elapsed_time(e1) / 5
     flop = 2 * (64 * 128 + 128 * 128 * 2 + 128 + 155 * 128 + 128 * 3)
     tf = n * flop / (mlp_ms * 1e-3) / 1e12
+    tn.cpp.mlp_set_mode("bf16x3")
+    for _ in range(2):
+        tn.cpp.mlp_forward(feats, dirs, w, samples)
+    e0.record()
+    for _ in range(5):
+        tn.cpp.mlp_forward(feats, dirs, w, samples)
+    e1.record()
+    torch.cuda.synchronize()
+    tn.cpp.mlp_set_mode("fp32")
+    x3_ms = e0.elapsed_time(e1) / 5
     return {"rendered_rays_per_s": R / dt, "ms_per_frame": dt * 1e3, "rays": R, "hitting_rays": hit,
             "samples_per_ray": samples, "pass": "coarse only (uniform samples), fused MLP + composite",
             "eval_configs": full,
             "roofline_mlp": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
                              "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "samples": n, "kernel_ms": mlp_ms,
-                             "flop_per_sample": flop}}
+                             "flop_per_sample": flop},
+            "mlp_bf16x3": {"kernel_ms": x3_ms, "fp32_equivalent_TFLOPs": n * flop / (x3_ms * 1e-3) / 1e12,
+                           "note": "optional mode: operands split into 3 bf16 pieces, 6 bf16 MFMAs per fp32 product, "
+                                   "fp32 accumulate; same 1e-5 parity tests; not the default"}}
 
 
 def cpu_baseline(pts, cells, o, d, M, target_s=30.0):

@@ -331,9 +331,11 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             p.item_count = t->fallback_count.p;
             // the rays the walk did not certify: re-walk + literal pairing of the sound chains, then the BVH
             // all-hits kernel for the rest (the re-walk may still append to its list)
-            // The re-walk is a latency-bound pointer chase: it runs ALONE on `stream` right after the walk
-            // (measured under the saturating tail fill: 12 us per step instead of ~1).  The wave-parallel parts
-            // (literal pairing of the collected lists, BVH re-trace) overlap the fill on the side stream.
+            // Everything that runs beside the saturating tail fill crawls (measured: re-walk 12 us per step
+            // instead of ~1; literal pairing of 10.7k lists 3.6 ms instead of 0.7), so the re-walk and the pairing
+            // of its lists run ALONE on `stream` between the walk and the fill.  Only the BVH re-trace of the
+            // (few) remaining rays overlaps the fill on the side stream: it is short next to the fill, and when
+            // there are many uncertified chains (>= rewalk_min) they have gone through the re-walk instead.
             auto launch_collect = [&](hipStream_t st) {
                 if (!t->rewalk) return;
                 tn::WalkParams w{};
@@ -347,23 +349,23 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 tn::launch_walk_collect(w, R, st);
             };
             auto launch_pairing = [&](hipStream_t st) {
-                if (t->rewalk) {
-                    const tn::TraceParams q = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
-                    tn::launch_postprocess_rows(q, t->rewalk_list.p, t->rewalk_count.p, R, st);
-                }
-                tn::launch_trace_general(p, st);
+                if (!t->rewalk) return;
+                const tn::TraceParams q = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
+                tn::launch_postprocess_rows(q, t->rewalk_list.p, t->rewalk_count.p, R, st);
             };
             if (mode == 1) {
                 launch_collect(stream);
+                launch_pairing(stream);
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
-                launch_pairing(t->side);
+                tn::launch_trace_general(p, t->side);
                 if (!(t->debug & 16u) && t->dense_tails) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream, (t->debug & 512u) != 0);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
             } else {
                 launch_collect(stream);
                 launch_pairing(stream);
+                tn::launch_trace_general(p, stream);
                 if (pipelined) {
                     TN_HIP(hipEventRecord(t->ev_join, t->side));
                     TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));

@@ -114,47 +114,83 @@ __device__ void postprocess_and_write(const WaveSmem &s, uint32_t nh, uint32_t M
         wave_sync();
         if (lane == 0) {
             if (stats) atomicAdd(&stats[2], 1ull);
-            auto T = [&](uint32_t j) { return __uint_as_float((uint32_t)(s.key[j] >> 32)); };
+            // The literal algorithm, one lane, LDS only.  Its common step looks at slots j and j+1 only, so
+            // slot j+1 (key + face->tets) is carried in registers into the next iteration and slot j+2 is
+            // requested a full iteration early: one LDS round trip per hit instead of five to seven dependent
+            // ones.  Any store to the arrays (clear / swap, rare) drops the carried copies.
+            auto Tk = [](uint64_t k) { return __uint_as_float((uint32_t)(k >> 32)); };
+            auto T = [&](uint32_t j) { return Tk(s.key[j]); };
             auto ID = [&](uint32_t j) { return (uint32_t)s.key[j]; };
             // phase 1 (optix_trace_rays.cu:124-159)
-            for (uint32_t j = 0; j + 1 < nh; ++j) {
-                if (ID(j) == TN_EMPTY) continue;
-                const float dn = T(j);
-                bool clear_self = false;
-                for (uint32_t off = 1; j + off < nh && (ID(j + off) == TN_EMPTY || fabsf(T(j + off) - dn) < TN_EPS); ++off) {
-                    uint32_t c;
-                    if (ID(j + off) != TN_EMPTY && common_tet(s.hft[j], s.hft[j + off], c)) {
-                        if (ID(j) != ID(j + off)) clear_self = true;
-                        if (s.mark[j + off]) s.key[j + off] = (s.key[j + off] & 0xFFFFFFFF00000000ull) | TN_EMPTY;
-                        else s.mark[j + off] = 1;
+            {
+                uint64_t kj = nh ? s.key[0] : 0, kn = nh > 1 ? s.key[1] : 0;  // slots j, j+1
+                for (uint32_t j = 0; j + 1 < nh; ++j) {
+                    const uint64_t kn2 = j + 2 < nh ? s.key[j + 2] : 0;  // early request of slot j+2
+                    bool dirty = false;
+                    if ((uint32_t)kj != TN_EMPTY) {
+                        const float dn = Tk(kj);
+                        // fast exit: the next slot is a real face at least eps away -> the window is empty
+                        if ((uint32_t)kn == TN_EMPTY || fabsf(Tk(kn) - dn) < TN_EPS) {
+                            bool clear_self = false;
+                            for (uint32_t off = 1; j + off < nh && (ID(j + off) == TN_EMPTY || fabsf(T(j + off) - dn) < TN_EPS); ++off) {
+                                uint32_t c;
+                                if (ID(j + off) != TN_EMPTY && common_tet(s.hft[j], s.hft[j + off], c)) {
+                                    if (ID(j) != ID(j + off)) clear_self = true;
+                                    if (s.mark[j + off]) { s.key[j + off] = (s.key[j + off] & 0xFFFFFFFF00000000ull) | TN_EMPTY; dirty = true; }
+                                    else s.mark[j + off] = 1;
+                                }
+                            }
+                            if (clear_self && s.mark[j]) s.key[j] = (s.key[j] & 0xFFFFFFFF00000000ull) | TN_EMPTY;
+                        }
+                        s.mark[j] = 0;
                     }
+                    kj = dirty ? s.key[j + 1] : kn;
+                    kn = dirty ? (j + 2 < nh ? s.key[j + 2] : 0) : kn2;
                 }
-                if (clear_self && s.mark[j]) s.key[j] = (s.key[j] & 0xFFFFFFFF00000000ull) | TN_EMPTY;
-                s.mark[j] = 0;
             }
             // phase 2 (optix_trace_rays.cu:188-257): pairing decisions + swaps only
-            for (uint32_t j = 0; j < nh; ++j) {
-                if (ID(j) == TN_EMPTY) continue;
-                const uint2 orig = s.hft[j];
-                float dn = T(j);
-                uint32_t real_off = 1;
-                for (uint32_t off = 1; j + off < nh && (real_off < 3 || ID(j + off) == TN_EMPTY || fabsf(T(j + off) - dn) < TN_EPS); ++off) {
-                    if (ID(j + off) == TN_EMPTY) continue;
-                    uint32_t cell;
-                    if (common_tet(orig, s.hft[j + off], cell)) {
-                        if (fabsf(T(j) - T(j + off)) >= TN_EPS) s.emitf[j] = 1;
-                        if (off > 1) {
-                            // swap(dl, first bary record, id) of slots j+off and j+1 (:244-250)
-                            const uint64_t k0 = s.key[j + off]; s.key[j + off] = s.key[j + 1]; s.key[j + 1] = k0;
-                            const float u0 = s.hu[j + off]; s.hu[j + off] = s.hu[j + 1]; s.hu[j + 1] = u0;
-                            const float v0 = s.hv[j + off]; s.hv[j + off] = s.hv[j + 1]; s.hv[j + 1] = v0;
-                            const uint2 f0 = s.hft[j + off]; s.hft[j + off] = s.hft[j + 1]; s.hft[j + 1] = f0;
-                            const uint8_t m0 = s.mark[j + off]; s.mark[j + off] = s.mark[j + 1]; s.mark[j + 1] = m0;
+            {
+                uint64_t kj = nh ? s.key[0] : 0, kn = nh > 1 ? s.key[1] : 0;
+                uint2 fj = nh ? s.hft[0] : make_uint2(0, 0), fn = nh > 1 ? s.hft[1] : make_uint2(0, 0);
+                for (uint32_t j = 0; j < nh; ++j) {
+                    const uint64_t kn2 = j + 2 < nh ? s.key[j + 2] : 0;
+                    const uint2 fn2 = j + 2 < nh ? s.hft[j + 2] : make_uint2(0, 0);
+                    bool dirty = false;
+                    if ((uint32_t)kj != TN_EMPTY) {
+                        uint32_t cell;
+                        if (j + 1 < nh && (uint32_t)kn != TN_EMPTY && common_tet(fj, fn, cell)) {
+                            // common step: the next slot is a real face sharing a tetrahedron (off = 1, no swap)
+                            if (fabsf(Tk(kj) - Tk(kn)) >= TN_EPS) s.emitf[j] = 1;
+                        } else {
+                            const uint2 orig = fj;
+                            float dn = Tk(kj);
+                            uint32_t real_off = 1;
+                            for (uint32_t off = 1; j + off < nh && (real_off < 3 || ID(j + off) == TN_EMPTY || fabsf(T(j + off) - dn) < TN_EPS); ++off) {
+                                if (ID(j + off) == TN_EMPTY) continue;
+                                if (common_tet(orig, s.hft[j + off], cell)) {
+                                    if (fabsf(T(j) - T(j + off)) >= TN_EPS) s.emitf[j] = 1;
+                                    if (off > 1) {
+                                        // swap(dl, first bary record, id) of slots j+off and j+1 (:244-250)
+                                        const uint64_t k0 = s.key[j + off]; s.key[j + off] = s.key[j + 1]; s.key[j + 1] = k0;
+                                        const float u0 = s.hu[j + off]; s.hu[j + off] = s.hu[j + 1]; s.hu[j + 1] = u0;
+                                        const float v0 = s.hv[j + off]; s.hv[j + off] = s.hv[j + 1]; s.hv[j + 1] = v0;
+                                        const uint2 f0 = s.hft[j + off]; s.hft[j + off] = s.hft[j + 1]; s.hft[j + 1] = f0;
+                                        const uint8_t m0 = s.mark[j + off]; s.mark[j + off] = s.mark[j + 1]; s.mark[j + 1] = m0;
+                                        dirty = true;
+                                    }
+                                    break;
+                                }
+                                dn = T(j + off);
+                                real_off++;
+                            }
                         }
-                        break;
                     }
-                    dn = T(j + off);
-                    real_off++;
+                    if (dirty) {
+                        kj = j + 1 < nh ? s.key[j + 1] : 0; fj = j + 1 < nh ? s.hft[j + 1] : make_uint2(0, 0);
+                        kn = j + 2 < nh ? s.key[j + 2] : 0; fn = j + 2 < nh ? s.hft[j + 2] : make_uint2(0, 0);
+                    } else {
+                        kj = kn; fj = fn; kn = kn2; fn = fn2;
+                    }
                 }
             }
         }
