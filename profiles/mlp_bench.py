@@ -26,7 +26,15 @@ for R, S in ((4096, 256), (4096, 513), (16384, 256)):
     tn.cpp.mlp_set_mode("bf16x3")
     ms3 = timeit(lambda: tn.cpp.mlp_forward(feats_fm, dirs, w, S))
     s3, c3 = tn.cpp.mlp_forward(feats_fm, dirs, w, S)
+    # the production variant: barycentric gather fused in (no [64,n] buffer)
+    V = 45000
+    vi = torch.randint(0, V, (n, 4), dtype=torch.int32, device=dev); bcw = torch.rand(n, 3, device=dev) / 4
+    field = torch.randn(64, V, device=dev)
+    msg3 = timeit(lambda: tn.cpp.mlp_forward_gather(vi, bcw, field, dirs, w, S))
     tn.cpp.mlp_set_mode("fp32")
+    msg = timeit(lambda: tn.cpp.mlp_forward_gather(vi, bcw, field, dirs, w, S))
+    print(f"MLP n={n} gather-fused: fp32 {msg:.3f} ms = {n*FLOP/msg/1e9:.1f} TFLOP/s, bf16x3 {msg3:.3f} ms = {n*FLOP/msg3/1e9:.1f} fp32-equivalent TFLOP/s")
+    del vi, bcw, field
     feats = feats_fm.t().contiguous(); dd = dirs[:, None, :].expand(R, S, 3).reshape(n, 3)
     with torch.no_grad():
         ms_t = timeit(lambda: mlp(feats, dd), 5)
