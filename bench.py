@@ -294,10 +294,10 @@ def main():
                                  "intersections_per_s": inter / (seg_ms * 1e-3),
                                  "algorithmic_bytes_per_launch": seg_bytes,
                                  "achieved_GBps": seg_bytes / (seg_ms * 1e-3) / 1e9,
-                                 "note": "non-reference option dense_tails=0: 28 B/ray + 52 B/segment; latency-bound walk"}
-        if not args.no_render:
+                                 "note": "non-reference option dense_tails=0: 28 B/ray + 52 B/segment; instruction-issue-bound walk"}
+        if not args.no_render and world == 1:   # secondary legs: single-GPU runs only (rank 0 alone would hold the job)
             line["render"] = render_leg(tn, tracer, len(pts), o, d, M, dev)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(pts, cells, o_np, d_np, M)
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -285,18 +285,12 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             TN_HIP(hipMemsetAsync(t->rewalk_count.p, 0, sizeof(uint32_t), stream));
             // mode 0: one launch, the walk kernel writes its own tails; mode 1: walk launch, then one
             // tail launch on the same stream; mode 2: chunked, tails on the side stream
-            const int mode = (t->debug & 1u) ? 0 : (R < 8192 && t->dense_tails ? 0 : (t->dense_tails ? t->mode : 1));
+            const int mode = !t->dense_tails ? 1 : (R < 8192 ? 0 : t->mode);
             const size_t chunk = mode == 2 ? t->chunk_rays : R;
             const bool pipelined = mode == 2 && R > chunk;
             if (pipelined) {
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
-            }
-            if (t->debug & 16u) {  // EXPERIMENT (invalid output): fill every row on the side stream while walking
-                TN_HIP(hipMemsetAsync(t->walk_n.p, 0, R * sizeof(uint32_t), stream));
-                TN_HIP(hipEventRecord(t->ev_fork, stream));
-                TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
-                tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, t->side);
             }
             size_t k = 0;
             for (size_t r0 = 0; r0 < R; r0 += chunk, ++k) {
@@ -316,7 +310,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 w.rewalk_count = t->rewalk_count.p;
                 w.walk_n = t->walk_n.p + r0;
                 w.ray_base = r0;
-                w.fused_tails = (mode != 0 || (t->debug & 1u)) ? 0u : 1u;
+                w.fused_tails = mode == 0 ? 1u : 0u;
                 w.debug = t->debug;
                 tn::launch_trace_walk(w, stream);
                 if (pipelined) {
@@ -324,7 +318,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                     TN_HIP(hipEventRecord(ev, stream));
                     TN_HIP(hipStreamWaitEvent(t->side, ev, 0));
                     tn::launch_fill_tails(n, M, w.walk_n, w.t.out_cells, w.t.out_bary, w.t.out_dist, w.t.out_verts,
-                                          t->side, false, t->fill_blocks);
+                                          t->side, t->fill_blocks);
                 }
             }
             p.ray_list = t->fallback_list.p;
@@ -359,7 +353,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
                 tn::launch_trace_general(p, t->side);
-                if (!(t->debug & 16u) && t->dense_tails) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream, (t->debug & 512u) != 0);
+                if (t->dense_tails) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
             } else {

@@ -49,7 +49,7 @@ struct WalkParams {
     uint32_t *walk_n;          // [num_items] segments per certified ray, TN_EMPTY = sent to the fallback
     size_t ray_base;           // global index of item 0 (rays are traced in chunks)
     uint32_t fused_tails;      // 1 = the walk kernel writes the constant tails itself
-    uint32_t debug;            // ablation only (bench): 2 = skip segment stores
+    uint32_t debug;            // block->XCD mapping ablation (profiles/): 4 = no remap, 8 = one contiguous band per XCD
 };
 void launch_trace_walk(const WalkParams &p, hipStream_t stream);
 // re-walk of the chains in rewalk_list (raw hits into the rays' own rows) and their literal sort + pairing
@@ -58,7 +58,7 @@ void launch_postprocess_rows(const TraceParams &p, const uint4 *rewalk_list, con
                              hipStream_t stream);
 // constant tails [n, M) of the rows certified by the walk (n = walk_n[ray] != TN_EMPTY)
 void launch_fill_tails(size_t num_rays, uint32_t M, const uint32_t *walk_n, uint32_t *out_cells, float *out_bary,
-                       float *out_dist, uint32_t *out_verts, hipStream_t stream, bool nontemporal = false, unsigned max_blocks = 0);
+                       float *out_dist, uint32_t *out_verts, hipStream_t stream, unsigned max_blocks = 0);
 
 // sample -> segment matching (tn_match.hip)
 void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,

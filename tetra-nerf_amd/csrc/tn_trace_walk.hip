@@ -18,13 +18,16 @@
 //                                                DESIGN.md "clean chain")
 //   (S3) exactly two hull faces are crossed, every tet on the way has exactly two crossed
 //        faces, no edge function is exactly 0, every recorded t is in (0, 1e16), < M-1 faces.
-// Any ray that violates a condition is appended to `fallback_list` and re-traced by the
-// general all-hits kernel, which rewrites its rows -- so the union is oracle-identical.
+// A ray that violates a condition is handed over: when only the ORDER of a sound chain is uncertified (S1 /
+// S2; 97 % of the hand-overs) it goes to `rewalk_list` -- k_walk_collect walks the chain again recording raw
+// hits into the ray's own rows and k_postprocess_rows (tn_trace_general.hip) sorts and pairs them literally --
+// otherwise to `fallback_list`, re-traced by the BVH all-hits kernel.  Both rewrite the ray's rows, so the
+// union is oracle-identical.
 //
-// Memory behaviour: the per-step segment stores are per-lane (rows are 26 KB apart), the
-// constant tail of every row (about 2/3 of all bytes at M=512) is written wave-cooperatively
-// with 16-byte stores; blockIdx is remapped so each XCD owns a contiguous band of rays and its
-// L2 keeps the tets that band crosses.
+// Memory behaviour: the per-step segment stores are per-lane (rows are 26 KB apart, written two segments at a
+// time with 16-B stores); the constant tail of every row (about 88 % of all bytes at M=512) is streamed by
+// k_fill_tails with 16-byte stores, one wave per row span; blockIdx is remapped so each XCD owns runs of 16
+// consecutive blocks (4096 neighbouring rays) and its L2 keeps the tets they cross.
 #include "tn_device.h"
 #include "tn_kernels.h"
 
@@ -48,7 +51,6 @@ __device__ __forceinline__ uint32_t sel4u(const uint4 &v, uint32_t i) {
 // fill dwords [start, end) of `base` with `value`; base 16-byte aligned.  Wave-cooperative.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool NT = false>
 __device__ __forceinline__ void fill_dwords(uint32_t *__restrict__ base, uint32_t start, uint32_t end, uint32_t value, int lane) {
     const uint32_t a0 = (start + 3u) & ~3u;  // first 16-B aligned dword
     const uint32_t head_end = a0 < end ? a0 : end;
@@ -58,8 +60,7 @@ __device__ __forceinline__ void fill_dwords(uint32_t *__restrict__ base, uint32_
     u32x4 *b4 = reinterpret_cast<u32x4 *>(base);
     const u32x4 v4 = {value, value, value, value};
     for (uint32_t i = (a0 >> 2) + lane; i < (a1 >> 2); i += 64) {
-        if constexpr (NT) __builtin_nontemporal_store(v4, &b4[i]);  // streamed once, never re-read on chip
-        else b4[i] = v4;
+        b4[i] = v4;  // plain stores: nontemporal ones measured slower for this pure write stream
     }
     if (a1 + lane < end) base[a1 + lane] = value;
 }
@@ -111,7 +112,6 @@ __device__ __forceinline__ bool face_tuv(const WalkRec &rc, const SV &P0, const 
 
 }  // namespace
 
-template <bool PREFETCH>
 __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     const TraceParams &t = p.t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -258,16 +258,13 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             const uint32_t nb = sel4u(cur.nbr, x);
             const uint32_t back = (cur.m0.y >> (2 * x)) & 3u;
             const bool last = nb == TN_EMPTY;
-            WalkRec nxt = cur;
-            if constexpr (PREFETCH) {
-                nxt = load_rec(p.tets, (last || bad) ? c : nb);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            // the next record is requested as soon as the exit face is known (shortest dependent chain per
+            // step) and before this step's stores (vmcnt retires loads and stores in issue order)
+            const WalkRec nxt = load_rec(p.tets, (last || bad) ? c : nb);
+            __builtin_amdgcn_sched_barrier(0);
 
             float ct = 0.f, cu = 0.f, cv = 0.f;
-            bool valid;
-            if (p.debug & 256u) { ct = pt + 0.01f; cu = 0.25f; cv = 0.25f; valid = true; }  // ablation: no (t,u,v) arithmetic
-            else valid = face_tuv(cur, P0, P1, P2, P3, e01, e02, e03, e12, e13, e23, x, ct, cu, cv);
+            const bool valid = face_tuv(cur, P0, P1, P2, P3, e01, e02, e03, e12, e13, e23, x, ct, cu, cv);
 
             // exit face's stored vertex triple (next step's entry triple)
             const uint32_t px = cur.m0.x >> (6u * x);
@@ -300,11 +297,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             }
             if (valid && ++nhits > M - 1 && !bad) bad = 9;  // more than M-1 faces
 
-            if constexpr (!PREFETCH) {
-                // every use of the current record's geometry is done: request the next one BEFORE the stores
-                if (!last && !bad) nxt = load_rec(p.tets, nb);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             if (do_emit && !bad) {
                 // combine_indices by local indices: entry slot j <- position of its vertex in the exit face
                 const uint32_t bit = 6u * (3u * e + x - (x > e ? 1u : 0u));
@@ -323,7 +315,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
                 // pair): 7 store transactions per pair instead of 12 -- the per-lane stores are
                 // transaction-bound, not byte-bound
                 if (nseg & 1u) {
-                    if (!(p.debug & 2u)) {
+                    {
                         const size_t s0 = nseg - 1;
                         *reinterpret_cast<uint2 *>(row_cells + s0) = make_uint2(h_cell, s_cell);
                         *reinterpret_cast<float4 *>(row_dist + 2 * s0) = make_float4(h_t0, h_t1, pt, ct);
@@ -364,7 +356,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             cur = nxt;
             in0 = ex0; in1 = ex1; in2 = ex2;
         }
-        if (!flag && (nseg & 1u) && !(p.debug & 2u)) {
+        if (!flag && (nseg & 1u)) {
             // odd segment count: the stashed last segment goes out alone
             const size_t s0 = nseg - 1;
             row_cells[s0] = h_cell;
@@ -518,7 +510,6 @@ void launch_walk_collect(const WalkParams &p, size_t max_items, hipStream_t stre
 // Constant tails of the rows the walk certified: slots [n, M) of the four row arrays.  Pure
 // streaming stores (16 B per lane), one wave per ray per pass, XCD-banded like the walk so a
 // row's lines are written by the XCD whose L2 already holds the row's segment lines.
-template <bool NT>
 __global__ __launch_bounds__(256) void k_fill_tails(size_t num_rays, uint32_t M, const uint32_t *__restrict__ walk_n,
                                                     uint32_t *__restrict__ out_cells, float *__restrict__ out_bary,
                                                     float *__restrict__ out_dist, uint32_t *__restrict__ out_verts) {
@@ -533,26 +524,22 @@ __global__ __launch_bounds__(256) void k_fill_tails(size_t num_rays, uint32_t M,
     for (size_t r = r0; r < r1; ++r) {
         const uint32_t n = walk_n[r];
         if (n == TN_EMPTY) continue;  // re-traced by the general kernel, which writes the whole row
-        fill_dwords<NT>(out_cells + r * M, n, M, TN_EMPTY, lane);
-        fill_dwords<NT>(reinterpret_cast<uint32_t *>(out_dist + r * M * 2), 2 * n, 2 * M, 0u, lane);
-        fill_dwords<NT>(reinterpret_cast<uint32_t *>(out_bary + r * M * 6), 6 * n, 6 * M, 0u, lane);
-        if (out_verts) fill_dwords<NT>(out_verts + r * M * 4, 4 * n, 4 * M, TN_EMPTY, lane);
+        fill_dwords(out_cells + r * M, n, M, TN_EMPTY, lane);
+        fill_dwords(reinterpret_cast<uint32_t *>(out_dist + r * M * 2), 2 * n, 2 * M, 0u, lane);
+        fill_dwords(reinterpret_cast<uint32_t *>(out_bary + r * M * 6), 6 * n, 6 * M, 0u, lane);
+        if (out_verts) fill_dwords(out_verts + r * M * 4, 4 * n, 4 * M, TN_EMPTY, lane);
     }
 }
 
 void launch_fill_tails(size_t num_rays, uint32_t M, const uint32_t *walk_n, uint32_t *out_cells, float *out_bary,
-                       float *out_dist, uint32_t *out_verts, hipStream_t stream, bool nontemporal, unsigned max_blocks) {
+                       float *out_dist, uint32_t *out_verts, hipStream_t stream, unsigned max_blocks) {
     if (num_rays == 0) return;
     size_t blocks = (num_rays + 3) / 4;           // >= one ray per wave
     const size_t cap = max_blocks ? max_blocks : 256 * 8;  // default: 8 blocks (32 waves) per CU
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) & ~(size_t)7;
-    if (nontemporal)
-        hipLaunchKernelGGL(k_fill_tails<true>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, walk_n, out_cells,
-                           out_bary, out_dist, out_verts);
-    else
-        hipLaunchKernelGGL(k_fill_tails<false>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, walk_n, out_cells,
-                           out_bary, out_dist, out_verts);
+    hipLaunchKernelGGL(k_fill_tails, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, walk_n, out_cells, out_bary,
+                       out_dist, out_verts);
 }
 
 void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
@@ -561,11 +548,7 @@ void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
     // grid padded so that both remaps (runs of XCD_GROUP blocks / one band per XCD) are bijections
     const uint32_t unit = 8 * ((p.debug & 8u) ? (nblk + 7) / 8 : XCD_GROUP);
     const uint32_t grid = (nblk + unit - 1) / unit * unit;
-    // the early-prefetch variant (shortest dependent chain per step) measured faster at every size
-    // (4096 rays: -5 %, 640k rays: -2 %); debug bit 64 selects the late-load variant for A/B runs
-    const bool prefetch = !(p.debug & 64u);
-    if (prefetch) hipLaunchKernelGGL(k_trace_walk<true>, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
-    else hipLaunchKernelGGL(k_trace_walk<false>, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL(k_trace_walk, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
 }
 
 }  // namespace tn
