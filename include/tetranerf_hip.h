@@ -105,6 +105,15 @@ int tn_find_matched_cells(size_t num_rays, size_t num_samples, size_t max_visite
                           const uint32_t *verts, uint32_t *cells_out, uint32_t *verts_out,
                           uint8_t *mask_out, float *bary_out, void *stream);
 
+/* The same for a SUBSET of the traced rays without compacting their rows first (addition): sample row r of
+ * distances / outputs ([R,S...]) is matched against trace row ray_index[r] of the [*,M] arrays.  The model
+ * compacts the 26 KB rows of the hitting rays with boolean indexing (model.py:560-567); this reads them in place. */
+int tn_find_matched_cells_indexed(size_t num_rays, size_t num_samples, size_t max_visited_cells,
+                                  const uint32_t *ray_index, const uint32_t *num_visited, const uint32_t *visited,
+                                  const float *dist, const float *bary, const float *distances,
+                                  const uint32_t *verts, uint32_t *cells_out, uint32_t *verts_out,
+                                  uint8_t *mask_out, float *bary_out, void *stream);
+
 /* interpolate_values<D>                                src/tetrahedra_tracer.h:395-402,
  *                                                       src/tetrahedra_tracer.cu:195-221,250-266
  * vertex_indices u32 [n,D], barycentric f32 [n,D-1], field f32 [F,V] feature-major,

@@ -178,3 +178,26 @@ def test_rewalk_equals_bvh_fallback(tn, device, oracle, scenes):
     want = ot.trace_rays(o[:30000], d[:30000], 512)
     for k in KEYS:
         assert _bits_equal(a[k][:30000], want[k]), k
+
+
+def test_find_visited_cells_ray_index(tn, device, scenes):
+    """Addition to the reference surface: matching a subset of the traced rays in place (ray_index) equals
+    matching their compacted rows."""
+    import torch
+
+    pts, cells = scenes.random_mesh(3000, 8)
+    tr = _tracer(tn, device, pts, cells, 1)
+    o, d = scenes.outside_in_rays(20000, 9)
+    out = tr.trace_rays(torch.from_numpy(o).to(device), torch.from_numpy(d).to(device), 128)
+    n = out["num_visited_cells"]
+    idx = torch.nonzero(n > 0)[:, 0][::3].contiguous()
+    near = out["hit_distances"][idx, 0, 0]
+    far = torch.gather(out["hit_distances"][idx][:, :, 1], 1, (n[idx, None].long() - 1).clamp_min(0))[:, 0]
+    ts = torch.linspace(0, 1, 96, device=device)[None]
+    dist = (near[:, None] * (1 - ts) + far[:, None] * ts).contiguous()
+    keys = ("num_visited_cells", "visited_cells", "barycentric_coordinates", "hit_distances", "vertex_indices")
+    a = tr.find_visited_cells(*[out[k] for k in keys], dist, ray_index=idx.to(torch.int32))
+    b = tr.find_visited_cells(*[out[k][idx].contiguous() for k in keys], dist)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert bool(a["mask"].any())

@@ -15,7 +15,7 @@ LIB_PATH = _HERE / "libtetranerf_hip.so"
 SYMBOLS = (
     "tn_last_error", "tn_version", "tn_tracer_create", "tn_tracer_destroy", "tn_load_tetrahedra",
     "tn_num_faces", "tn_get_faces", "tn_trace_rays", "tn_trace_rays_triangles", "tn_find_tetrahedra",
-    "tn_find_matched_cells",
+    "tn_find_matched_cells", "tn_find_matched_cells_indexed",
     "tn_interpolate_values", "tn_interpolate_values_backward", "tn_interpolate_values_backward_rows",
     "tn_postprocess_hits",
     "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_set_mode", "tn_mlp_get_mode",
@@ -50,6 +50,7 @@ def load():
     lib.tn_trace_rays_triangles.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_find_tetrahedra.argtypes = [vp, sz, vp, vp, vp, vp, vp]
     lib.tn_find_matched_cells.argtypes = [sz, sz, sz] + [vp] * 11
+    lib.tn_find_matched_cells_indexed.argtypes = [sz, sz, sz] + [vp] * 12
     lib.tn_interpolate_values.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
     lib.tn_interpolate_values_backward.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
     lib.tn_interpolate_values_backward_rows.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]

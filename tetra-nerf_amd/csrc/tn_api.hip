@@ -372,6 +372,21 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
     });
 }
 
+int tn_find_matched_cells_indexed(size_t R, size_t S, size_t M, const uint32_t *ray_index, const uint32_t *num_visited,
+                                  const uint32_t *visited, const float *dist, const float *bary, const float *distances,
+                                  const uint32_t *verts, uint32_t *cells_out, uint32_t *verts_out, uint8_t *mask_out,
+                                  float *bary_out, void *stream_) {
+    return guarded([&] {
+        if (R == 0 || S == 0) return;
+        if (!ray_index) throw tn::Error("ray_index is null");
+        if (S >= 0xFFFFFFFFull || M >= 0xFFFFFFFFull) throw tn::Error("num_samples / max_visited_cells too large");
+        if (M * 2 * sizeof(float) > 64 * 1024) throw tn::Error("max_visited_cells larger than 8192 is not supported");
+        tn::launch_find_matched_cells(R, S, M, num_visited, visited, dist, bary, distances, verts, cells_out,
+                                      verts_out, mask_out, bary_out, (hipStream_t)stream_, ray_index);
+        TN_HIP(hipGetLastError());
+    });
+}
+
 int tn_postprocess_hits(tn_tracer_t tracer, size_t R, uint32_t M, const uint32_t *hit_count,
                         const uint32_t *hit_ids, const float *hit_t, const float *hit_uv,
                         uint32_t *num_visited, uint32_t *visited, float *bary, float *dist, uint32_t *verts,

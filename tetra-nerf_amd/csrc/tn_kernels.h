@@ -64,7 +64,8 @@ void launch_fill_tails(size_t num_rays, uint32_t M, const uint32_t *walk_n, uint
 void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,
                                const uint32_t *visited, const float *dist, const float *bary,
                                const float *distances, const uint32_t *verts, uint32_t *cells_out,
-                               uint32_t *verts_out, uint8_t *mask_out, float *bary_out, hipStream_t stream);
+                               uint32_t *verts_out, uint8_t *mask_out, float *bary_out, hipStream_t stream,
+                               const uint32_t *ray_index = nullptr);
 
 // barycentric gather and its adjoint (tn_interp.hip); throws on unsupported D
 void launch_interpolate_values(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,

@@ -24,16 +24,20 @@ __global__ __launch_bounds__(64) void k_find_matched(size_t R, uint32_t S, uint3
                                                      uint32_t *__restrict__ cells_out,
                                                      uint32_t *__restrict__ verts_out,
                                                      uint8_t *__restrict__ mask_out,
-                                                     float *__restrict__ bary_out) {
+                                                     float *__restrict__ bary_out,
+                                                     const uint32_t *__restrict__ ray_index) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *tin = reinterpret_cast<float *>(smem);  // [M]
     float *pmax = tin + M;                         // [M] running max of t_out
     const int lane = threadIdx.x;
 
     for (size_t ray = blockIdx.x; ray < R; ray += gridDim.x) {
-        uint32_t n = num_visited[ray];
+        // row of the trace outputs this sample row belongs to (ray_index: the caller kept the trace rows of ALL
+        // rays and matches a subset -- no compacted copy of the 26 KB rows)
+        const size_t src = ray_index ? (size_t)ray_index[ray] : ray;
+        uint32_t n = num_visited[src];
         if (n > M) n = M;
-        const float2 *drow = reinterpret_cast<const float2 *>(dist) + ray * M;
+        const float2 *drow = reinterpret_cast<const float2 *>(dist) + src * M;
         // stage bounds + inclusive running max of t_out (wave scan, chunks of 64)
         float carry = -INFINITY;
         for (uint32_t base = 0; base < n; base += 64) {
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(64) void k_find_matched(size_t R, uint32_t S, uint3
                 uint4 vv = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
                 float b0 = 0.f, b1 = 0.f, b2 = 0.f;
                 if (p < n && tin[p] <= cur) {
-                    const size_t g = ray * M + p;
+                    const size_t g = src * M + p;
                     const float t_in = tin[p], t_out = drow[p].y;
                     mk = 1;
                     cell = visited[g];
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(64) void k_find_matched(size_t R, uint32_t S, uint3
                     if (p >= n) break;
                     const float2 hd = drow[p];
                     if (hd.x <= cur) {
-                        const size_t g = ray * M + p, o = ray * S + j;
+                        const size_t g = src * M + p, o = ray * S + j;
                         mask_out[o] = 1;
                         cells_out[o] = visited[g];
                         for (int k = 0; k < 4; ++k) verts_out[4 * o + k] = verts[4 * g + k];
@@ -128,13 +132,14 @@ __global__ __launch_bounds__(64) void k_find_matched(size_t R, uint32_t S, uint3
 void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,
                                const uint32_t *visited, const float *dist, const float *bary,
                                const float *distances, const uint32_t *verts, uint32_t *cells_out,
-                               uint32_t *verts_out, uint8_t *mask_out, float *bary_out, hipStream_t stream) {
+                               uint32_t *verts_out, uint8_t *mask_out, float *bary_out, hipStream_t stream,
+                               const uint32_t *ray_index) {
     if (R == 0 || S == 0) return;
     const size_t smem = 2 * M * sizeof(float);
     const size_t max_blocks = 256 * 32;
     const unsigned grid = (unsigned)(R < max_blocks ? R : max_blocks);
     hipLaunchKernelGGL(k_find_matched, dim3(grid), dim3(64), smem, stream, R, (uint32_t)S, (uint32_t)M,
-                       num_visited, visited, dist, bary, distances, verts, cells_out, verts_out, mask_out, bary_out);
+                       num_visited, visited, dist, bary, distances, verts, cells_out, verts_out, mask_out, bary_out, ray_index);
 }
 
 }  // namespace tn

@@ -246,19 +246,20 @@ class TetraRenderer:
         depth = torch.full((R, 1), self.far_plane, dtype=torch.float32, device=dev)
         idx = torch.nonzero(ray_mask)[:, 0]
         if idx.numel():
-            all_rays = idx.numel() == R
-            lists = [out[k] if all_rays else out[k][idx].contiguous()
-                     for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates", "hit_distances",
-                               "vertex_indices")]
+            # the 26 KB trace rows of the hitting rays are NOT compacted (model.py:546-567 copies them with boolean
+            # indexing): find_visited_cells reads them in place through the ray index
+            lists = [out[k] for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates", "hit_distances",
+                                      "vertex_indices")]
+            ridx = idx.to(torch.int32)
             near_r, far_r = nears[idx], fars[idx]
             w = mlp_weights(self.mlp)
 
             def locate(edges):
                 dist = ((edges[:, 1:] + edges[:, :-1]) / 2).contiguous()
-                return self.tracer.find_visited_cells(*lists, dist)
+                return self.tracer.find_visited_cells(*lists, dist, ray_index=ridx)
 
             if self.biased:
-                edges = biased_sample_bins(near_r, far_r, S, lists[0], lists[3]).contiguous()
+                edges = biased_sample_bins(near_r, far_r, S, lists[0][idx], lists[3][idx]).contiguous()
             else:
                 edges = uniform_sample_bins(near_r, far_r, S).contiguous()
             traced = locate(edges)

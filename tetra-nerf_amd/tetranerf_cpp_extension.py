@@ -161,7 +161,9 @@ class TetrahedraTracer:
         return {"tetrahedra": tets, "barycentric_coordinates": bary, "vertex_indices": verts, "valid_mask": tets != -1}
 
     def find_visited_cells(self, num_visited_cells, visited_cells, barycentric_coordinates,
-                           hit_distances, vertex_indices, distances):
+                           hit_distances, vertex_indices, distances, ray_index=None):
+        """py_binding.cpp:163-216.  Addition: `ray_index` (int32 [r]) matches a SUBSET of the traced rays without
+        compacting their rows first -- `distances` and the results are [r, S...], the trace tensors stay [R, M...]."""
         for x, name in ((num_visited_cells, "num_visited_cells"), (visited_cells, "visited_cells"),
                         (barycentric_coordinates, "barycentric_coordinates"),
                         (hit_distances, "hit_distances"), (distances, "distances"),
@@ -170,6 +172,10 @@ class TetrahedraTracer:
             _check(x.device == self._device, f"{name} must be on the same device")
         _check(distances.dtype == torch.float32, "distances must have float32 type")
         R = num_visited_cells.size(0)
+        if ray_index is not None:
+            _check_input(ray_index, "ray_index")
+            _check(ray_index.dtype == torch.int32 and ray_index.dim() == 1, "ray_index must be int32 [r]")
+            R = ray_index.size(0)
         _check(distances.dim() == 2 and distances.size(0) == R,
                "distances must be of [num_rays, num_samples_per_ray] shape")
         _check(vertex_indices.size(-1) == 4, "vertex_indices must have last dimension with size 4")
@@ -185,10 +191,16 @@ class TetrahedraTracer:
         matched_cells = torch.empty((R, S), dtype=torch.int32, device=dev)
         barycentric_coordinates_out = torch.empty((R, S, 3), dtype=torch.float32, device=dev)
         vertex_indices_out = torch.empty((R, S, 4), dtype=torch.int32, device=dev)
-        _lib.check(self._lib.tn_find_matched_cells(
-            R, S, M, _ptr(num_visited_cells), _ptr(visited_cells), _ptr(hit_distances),
-            _ptr(barycentric_coordinates), _ptr(distances), _ptr(vertex_indices), _ptr(matched_cells),
-            _ptr(vertex_indices_out), _ptr(mask), _ptr(barycentric_coordinates_out), _stream(dev)))
+        if ray_index is None:
+            _lib.check(self._lib.tn_find_matched_cells(
+                R, S, M, _ptr(num_visited_cells), _ptr(visited_cells), _ptr(hit_distances),
+                _ptr(barycentric_coordinates), _ptr(distances), _ptr(vertex_indices), _ptr(matched_cells),
+                _ptr(vertex_indices_out), _ptr(mask), _ptr(barycentric_coordinates_out), _stream(dev)))
+        else:
+            _lib.check(self._lib.tn_find_matched_cells_indexed(
+                R, S, M, _ptr(ray_index), _ptr(num_visited_cells), _ptr(visited_cells), _ptr(hit_distances),
+                _ptr(barycentric_coordinates), _ptr(distances), _ptr(vertex_indices), _ptr(matched_cells),
+                _ptr(vertex_indices_out), _ptr(mask), _ptr(barycentric_coordinates_out), _stream(dev)))
         return {
             "cell_indices": matched_cells,
             "vertex_indices": vertex_indices_out,
