@@ -148,6 +148,13 @@ int tn_postprocess_hits(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_tr
                         const float *hit_uv, uint32_t *num_visited, uint32_t *visited,
                         float *bary, float *dist, uint32_t *verts, void *stream);
 
+/* the same on caller-supplied face tables (faces u32 [F,3], face_tets u32 [F,2]) instead of a loaded mesh's:
+ * lets hit lists that do not come from a mesh at hand -- the reference's tests/test_sort.py vectors -- be paired */
+int tn_postprocess_hits_tables(int device, size_t num_rays, uint32_t max_ray_triangles, const uint32_t *faces,
+                               const uint32_t *face_tets, const uint32_t *hit_count, const uint32_t *hit_ids,
+                               const float *hit_t, const float *hit_uv, uint32_t *num_visited, uint32_t *visited,
+                               float *bary, float *dist, uint32_t *verts, void *stream);
+
 /* per-call statistics of the last tn_trace_rays on this tracer (host values; forces a
  * stream sync).  stats[0] = rays served by the adjacency walk, stats[1] = rays re-traced by
  * the general all-hits path, stats[2] = rays whose post-process ran the serial literal

@@ -8,6 +8,10 @@
                      tests/test_tetrahedra_tracer.py:13-20; CGAL is absent here).
   bottle_oracle.npz  oracle outputs for config C1 (64x64 rays, M=256): counts, leading
                      segment cells and a checksum -- regression pins for the oracle itself.
+  sort_vectors.npz   the hit-list vectors t0..t4 of the reference's tests/test_sort.py:3-687 (real OptiX hit lists
+                     of an earlier per-tet-face design: (t, tet, local face) per side of a crossed face) together
+                     with the tetrahedra its pairing prototype (test_sort, :690-760, executed from the file) pairs,
+                     in order.
   biased_sampler.npz inputs/outputs of the REFERENCE's own map_from_real_distances_to_biased_with_bounds
                      (tetranerf/nerfstudio/model.py:111-122; the function is extracted from the file
                      with ast and executed -- the module itself needs nerfstudio, absent here) on the
@@ -86,6 +90,31 @@ def reference_function(path, name):
     return ns[name]
 
 
+def sort_vectors_golden():
+    """tests/test_sort.py of the reference: vectors + the result of its own pairing prototype."""
+    import copy
+
+    out = Path(__file__).resolve().parent
+    tree = ast.parse(Path("/root/reference/tests/test_sort.py").read_text())
+    vecs = {n.targets[0].id: ast.literal_eval(n.value) for n in tree.body
+            if isinstance(n, ast.Assign) and n.targets[0].id.startswith("t")}
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "test_sort")
+    fn.decorator_list = []
+    fn.body.append(ast.Return(value=ast.Name(id="o", ctx=ast.Load())))   # hand the paired list back
+    ast.fix_missing_locations(fn)
+    ns = {"print": lambda *a, **k: None}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "test_sort.py", "exec"), ns)
+    data = {}
+    for name in ("t0", "t1", "t2", "t3", "t4"):   # the vectors the reference's test is parametrised over (:690)
+        v = vecs[name]
+        o = ns["test_sort"](copy.deepcopy(v))
+        data[name + "_hits"] = np.array([(e[0], e[1], e[2]) for e in v], np.float64)
+        data[name + "_paired_tets"] = np.array([o[i][1] for i in range(0, len(o), 2)], np.int64)
+        assert all(o[i][1] == o[i + 1][1] for i in range(0, len(o), 2))
+        print("sort vector", name, len(v), "sides ->", len(o) // 2, "paired tetrahedra")
+    np.savez_compressed(out / "sort_vectors.npz", **data)
+
+
 def biased_sampler_golden():
     import torch
 
@@ -113,3 +142,4 @@ def biased_sampler_golden():
 if __name__ == "__main__":
     main()
     biased_sampler_golden()
+    sort_vectors_golden()

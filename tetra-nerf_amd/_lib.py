@@ -17,7 +17,7 @@ SYMBOLS = (
     "tn_num_faces", "tn_get_faces", "tn_trace_rays", "tn_trace_rays_triangles", "tn_find_tetrahedra",
     "tn_find_matched_cells", "tn_find_matched_cells_indexed",
     "tn_interpolate_values", "tn_interpolate_values_backward", "tn_interpolate_values_backward_rows",
-    "tn_postprocess_hits",
+    "tn_postprocess_hits", "tn_postprocess_hits_tables",
     "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_set_mode", "tn_mlp_get_mode",
     "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
 )
@@ -55,6 +55,7 @@ def load():
     lib.tn_interpolate_values_backward.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
     lib.tn_interpolate_values_backward_rows.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
     lib.tn_postprocess_hits.argtypes = [vp, sz, u32] + [vp] * 10
+    lib.tn_postprocess_hits_tables.argtypes = [i32, sz, u32] + [vp] * 12
     lib.tn_trace_stats.argtypes = [vp, C.POINTER(C.c_uint64 * 4)]
     lib.tn_trace_flag_reasons.argtypes = [vp, C.POINTER(C.c_uint64 * 16)]
     lib.tn_set_option.argtypes = [vp, C.c_char_p, i32]

@@ -405,6 +405,30 @@ int tn_postprocess_hits(tn_tracer_t tracer, size_t R, uint32_t M, const uint32_t
     });
 }
 
+int tn_postprocess_hits_tables(int device, size_t R, uint32_t M, const uint32_t *faces, const uint32_t *face_tets,
+                               const uint32_t *hit_count, const uint32_t *hit_ids, const float *hit_t,
+                               const float *hit_uv, uint32_t *num_visited, uint32_t *visited, float *bary, float *dist,
+                               uint32_t *verts, void *stream_) {
+    return guarded([&] {
+        if (M == 0 || (M & (M - 1)) != 0) throw tn::Error("max_ray_triangles must be a power of 2.");
+        if (!faces || !face_tets) throw tn::Error("null face table");
+        if (R == 0) return;
+        DeviceGuard g(device);
+        tn::TraceParams p{};
+        p.M = M;
+        p.num_items = R;
+        p.faces = faces;
+        p.face_tets = face_tets;
+        p.out_num = num_visited;
+        p.out_cells = visited;
+        p.out_bary = bary;
+        p.out_dist = dist;
+        p.out_verts = verts;
+        tn::launch_postprocess_hits(p, hit_count, hit_ids, hit_t, hit_uv, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
 int tn_trace_rays_triangles(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins, const float *directions,
                             uint32_t *num_visited, uint32_t *visited, float *bary, float *dist, uint32_t *verts,
                             void *stream_) {

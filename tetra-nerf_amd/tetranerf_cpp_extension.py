@@ -233,8 +233,9 @@ class TetrahedraTracer:
         _lib.check(self._lib.tn_get_faces(self._h, _ptr(faces), _ptr(ft)))
         return faces, ft
 
-    def postprocess_hits(self, hit_count, hit_ids, hit_t, hit_uv):
-        """Run only the dedupe/pairing stage on sorted hit rows (test aid)."""
+    def postprocess_hits(self, hit_count, hit_ids, hit_t, hit_uv, faces=None, face_tets=None):
+        """Run only the dedupe/pairing stage on sorted hit rows (test aid); with `faces` [F,3] / `face_tets` [F,2]
+        (int32) on those tables instead of the loaded mesh's."""
         R, M = hit_ids.shape
         dev = self._device
         out = {
@@ -244,6 +245,15 @@ class TetrahedraTracer:
             "hit_distances": torch.empty((R, M, 2), dtype=torch.float32, device=dev),
             "vertex_indices": torch.empty((R, M, 4), dtype=torch.int32, device=dev),
         }
+        if faces is not None:
+            _check(face_tets is not None and faces.dtype == torch.int32 and face_tets.dtype == torch.int32
+                   and faces.is_contiguous() and face_tets.is_contiguous(), "faces / face_tets must be contiguous int32")
+            _lib.check(self._lib.tn_postprocess_hits_tables(
+                dev.index or 0, R, M, _ptr(faces), _ptr(face_tets), _ptr(hit_count), _ptr(hit_ids), _ptr(hit_t),
+                _ptr(hit_uv), _ptr(out["num_visited_cells"]), _ptr(out["visited_cells"]),
+                _ptr(out["barycentric_coordinates"]), _ptr(out["hit_distances"]), _ptr(out["vertex_indices"]),
+                _stream(dev)))
+            return out
         _lib.check(self._lib.tn_postprocess_hits(
             self._h, R, M, _ptr(hit_count), _ptr(hit_ids), _ptr(hit_t), _ptr(hit_uv),
             _ptr(out["num_visited_cells"]), _ptr(out["visited_cells"]), _ptr(out["barycentric_coordinates"]),
