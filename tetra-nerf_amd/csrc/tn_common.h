@@ -67,6 +67,22 @@ struct alignas(128) TetRec {
 };
 static_assert(sizeof(TetRec) == 128, "TetRec must be one 128-B line");
 
+// Entry-face-specialised walk record: one per (tet record r, entry local face e), index 4r + e, 64 B.
+// Local numbering {0: n, 1: a, 2: b, 3: c}: n = the vertex opposite the entry face, (a,b,c) = the entry face's
+// STORED triple -- exactly the order the previous step left the face's sheared vertices and edge functions in,
+// so nothing of the entry face is permuted or recomputed.  Exit x in {0,1,2} = the face opposite a / b / c.
+struct alignas(64) WalkVar {
+    float pn[3];      // position of n
+    uint32_t orig;    // the caller's tet id
+    uint32_t vid[4];  // vertex ids n, a, b, c (= vertex_indices of a segment entered through this face)
+    uint32_t nb[3];   // variant entered through exit x (TN_EMPTY: hull)
+    uint32_t code_hi; // bits 32..35 of the code word
+    uint32_t fid[3];  // face id of exit x
+    uint32_t code_lo; // per exit x, 12 bits at 12x: p0 p1 p2 (2 bits each: the exit face's stored order in local
+                      // numbers), then c0 c1 c2 (2 bits each: position of a / b / c in that order, 3 = absent)
+};
+static_assert(sizeof(WalkVar) == 64, "WalkVar must be 64 bytes");
+
 struct DeviceMesh {
     const float *xyz = nullptr;       // borrowed [V,3]
     const uint32_t *cells = nullptr;  // borrowed [T,4]
@@ -76,6 +92,7 @@ struct DeviceMesh {
     WideBvh bvh{};                  // over all faces
     // adjacency walk
     TetRec *tets = nullptr;         // [T]
+    WalkVar *vars = nullptr;        // [4T] entry-face-specialised records of the walk
     const float4 *hull_nodes = nullptr;  // threaded binary BVH over the hull faces (2 float4 per node)
     const float4 *hull_tris = nullptr;   // 3 float4 per hull face
     uint32_t n_hull_nodes = 0;
@@ -114,5 +131,8 @@ void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<u
 // adjacency records
 void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const HostMesh &hm,
                        std::vector<TetRec> &out, std::vector<uint32_t> &rec_of_tet);
+
+// entry-face-specialised walk records from the (Morton-ordered) tet records
+void build_walk_variants(const std::vector<TetRec> &recs, std::vector<WalkVar> &out);
 
 }  // namespace tn

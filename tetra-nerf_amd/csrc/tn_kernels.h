@@ -37,6 +37,7 @@ void launch_find_tetrahedra(const TraceParams &p, const float *points, uint32_t 
 struct WalkParams {
     TraceParams t;
     const TetRec *tets;
+    const WalkVar *vars;       // entry-face-specialised records of the walk (k_trace_walk)
     float scene_max;           // max |coordinate| of the mesh (box padding)
     const float4 *hull_nodes;  // threaded per-lane hull tree
     const float4 *hull_tris;

@@ -337,6 +337,44 @@ void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const 
     }
 }
 
+void build_walk_variants(const std::vector<TetRec> &recs, std::vector<WalkVar> &out) {
+    const size_t T = recs.size();
+    out.assign(4 * T, WalkVar{});
+    for (size_t r = 0; r < T; ++r) {
+        const TetRec &t = recs[r];
+        uint32_t loc[4][3];  // stored order of face k in the tet's local vertex indices
+        for (int k = 0; k < 4; ++k)
+            for (int m = 0; m < 3; ++m) loc[k][m] = (t.perm >> (6 * k + 2 * m)) & 3u;
+        for (uint32_t e = 0; e < 4; ++e) {
+            WalkVar &v = out[4 * r + e];
+            uint32_t canon[4] = {0, 0, 0, 0};  // tet-local vertex index -> {0: n, 1: a, 2: b, 3: c}
+            canon[e] = 0;
+            for (int m = 2; m >= 0; --m) canon[loc[e][m]] = (uint32_t)m + 1;  // first match wins on degenerate tets
+            for (int a = 0; a < 3; ++a) v.pn[a] = t.pos[e][a];
+            v.orig = t.orig;
+            v.vid[0] = t.vert[e];
+            for (int m = 0; m < 3; ++m) v.vid[m + 1] = t.vert[loc[e][m]];
+            uint64_t codes = 0;
+            for (uint32_t x = 0; x < 3; ++x) {
+                const uint32_t k = loc[e][x];  // the exit face is the one opposite a / b / c
+                v.fid[x] = t.face[k];
+                v.nb[x] = t.nbr[k] == TN_EMPTY ? TN_EMPTY : 4u * t.nbr[k] + ((t.back >> (2 * k)) & 3u);
+                uint32_t p[3];
+                for (int m = 0; m < 3; ++m) p[m] = canon[loc[k][m]];
+                uint32_t code = p[0] | (p[1] << 2) | (p[2] << 4);
+                for (uint32_t j = 0; j < 3; ++j) {
+                    uint32_t pos = 3;
+                    for (uint32_t m = 0; m < 3; ++m) if (p[m] == j + 1) { pos = m; break; }
+                    code |= pos << (6 + 2 * j);
+                }
+                codes |= (uint64_t)code << (12 * x);
+            }
+            v.code_lo = (uint32_t)codes;
+            v.code_hi = (uint32_t)(codes >> 32);
+        }
+    }
+}
+
 // Threaded binary BVH over the hull faces, nodes in DFS pre-order: the "hit" successor of a node
 // is the next node, the "miss" successor is `skip`.  A lane can traverse it without a stack and in
 // a ray-independent order (all crossings are wanted, not the nearest).  Leaves hold <= 4 faces.

@@ -110,8 +110,31 @@ __device__ __forceinline__ bool face_tuv(const WalkRec &rc, const SV &P0, const 
                       sel4f(P0.z, P1.z, P2.z, P3.z, (pm >> 4) & 3u), tt, uu, vv);
 }
 
+// a walk variant record as four 16-B quads: q0 = (pn.xyz, orig), q1 = vid, q2 = (nb0..2, code_hi), q3 = (fid0..2, code_lo)
+struct Var { uint4 q0, q1, q2, q3; };
+__device__ __forceinline__ Var load_var(const WalkVar *vars, uint32_t c) {
+    const uint4 *r = reinterpret_cast<const uint4 *>(vars + c);
+    Var v;
+    v.q0 = r[0]; v.q1 = r[1]; v.q2 = r[2]; v.q3 = r[3];
+    return v;
+}
+__device__ __forceinline__ uint32_t sel3u(const uint4 &v, uint32_t i) {  // i in 0..2 (3 -> z)
+    const bool b0 = (i & 1u) != 0, b1 = (i & 2u) != 0;
+    const uint32_t lo = b0 ? v.y : v.x;
+    return b1 ? v.z : lo;
+}
+__device__ __forceinline__ SV selsv(const SV &p0, const SV &p1, const SV &p2, const SV &p3, uint32_t i) {
+    SV r;
+    r.x = sel4f(p0.x, p1.x, p2.x, p3.x, i); r.y = sel4f(p0.y, p1.y, p2.y, p3.y, i); r.z = sel4f(p0.z, p1.z, p2.z, p3.z, i);
+    return r;
+}
+
 }  // namespace
 
+// The walk runs on entry-face-specialised records (WalkVar, tn_common.h): nothing of the entry face is permuted
+// or recomputed, one vertex is sheared per step, three edge functions against it decide the exit, and the exit
+// face's edge functions are evaluated directly in its stored order (E(P,Q) == -E(Q,P) bitwise, so they equal the
+// shared ones): bit-identical hits for 30 % fewer instructions than a per-tet record with dynamic selects.
 __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     const TraceParams &t = p.t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -146,9 +169,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     // its padded box; box / triangle data are read through uniform (scalar) loads, every lane
     // tests its own ray.  No stack: the tree has a fixed depth (<= 3 internal levels).
     uint32_t nhull = 0;
-    uint32_t hf0 = TN_EMPTY, hf1 = TN_EMPTY, hc0 = 0, hc1 = 0, he0 = 0, he1 = 0;
+    uint32_t hf0 = TN_EMPTY, hf1 = TN_EMPTY, hc0 = 0, hc1 = 0, he0 = 0, he1 = 0, hs0 = 0, hs1 = 0;
     float ht0 = 0.f, ht1 = 0.f;
-    auto hull_face = [&](const SV &A, const SV &B, const SV &C, uint32_t fid, uint32_t rec, uint32_t loc) {
+    auto hull_face = [&](const SV &A, const SV &B, const SV &C, uint32_t fid, uint32_t rec, uint32_t loc, uint32_t slot) {
         const float U = edge_f(B, C), V = edge_f(C, A), W = edge_f(A, B);
         const bool mixed = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
         if (!mixed) {
@@ -157,8 +180,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             if (U == 0.0f || V == 0.0f || W == 0.0f || det == 0.0f) { flag = true; why = 1; }
             const float T = (U * A.z + V * B.z) + W * C.z;
             const float tt = T / det;
-            if (nhull == 0) { hf0 = fid; ht0 = tt; hc0 = rec; he0 = loc; }
-            else if (nhull == 1) { hf1 = fid; ht1 = tt; hc1 = rec; he1 = loc; }
+            if (nhull == 0) { hf0 = fid; ht0 = tt; hc0 = rec; he0 = loc; hs0 = slot; }
+            else if (nhull == 1) { hf1 = fid; ht1 = tt; hc1 = rec; he1 = loc; hs1 = slot; }
             nhull++;
         }
     };
@@ -179,7 +202,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
                     const float4 *tp = p.hull_tris + 3 * (size_t)(first + k);
                     const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
                     hull_face(shear(rp, v0.x, v0.y, v0.z), shear(rp, v1.x, v1.y, v1.z), shear(rp, v2.x, v2.y, v2.z),
-                              __float_as_uint(v0.w), __float_as_uint(v1.w), __float_as_uint(v2.w));
+                              __float_as_uint(v0.w), __float_as_uint(v1.w), __float_as_uint(v2.w), first + k);
                 }
             }
             i = i + 1;
@@ -190,95 +213,90 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     if (!active) { flag = false; nhull = 0; }
 
     // ------------------------------------------------------------------ the walk
-    uint32_t *row_cells = t.out_cells + rr * M;
-    float *row_dist = t.out_dist + rr * M * 2;
-    float *row_bary = t.out_bary + rr * M * 6;
-    uint32_t *row_verts = t.out_verts ? t.out_verts + rr * M * 4 : nullptr;
+    // Segment stores go through LDS: a lane appends its segments to a 4-slot buffer (cells[4] | dist[4][2] |
+    // bary[4][6] | verts[4][4] = 13 x 16 B), and whenever a lane's buffer is full the WAVE writes it out, four rays
+    // per store instruction, lane i copying 16-B chunk i % 13 of ray i / 13: consecutive lanes hit consecutive
+    // addresses, so a ray's 208 B leave as ~5 line transactions instead of 14 scattered 16-B ones (the per-lane
+    // stores were the larger half of the walk: 1.64 ms -> 0.85 ms without them).  All 64 lanes stay in the loop
+    // until the last ray of the wave is done so that they can help.
+    extern __shared__ __attribute__((aligned(16))) uint32_t seg_lds[];
+    uint32_t *mybuf = seg_lds + (size_t)threadIdx.x * 52;
+    const size_t wave_ray0 = (size_t)lb * WALK_BLOCK + (size_t)wave * 64;
 
     uint32_t nseg = 0;
     uint32_t c_start = 0, e_start = 0, f_end = 0;  // chain start / hull exit face, for the re-walk of an uncertified chain
-    if (nhull == 2 && !flag) {
-        const uint32_t f_out = ht0 < ht1 ? hf1 : hf0;
-        uint32_t c = ht0 < ht1 ? hc0 : hc1;  // record of the entry face's tet (a hull face has exactly one)
-        uint32_t e = ht0 < ht1 ? he0 : he1;  // local index of the entry face in it
-        c_start = c; e_start = e; f_end = f_out;
-        // state of the previous recorded (valid) hit
-        bool have_prev = false, have_pp = false, pending_inv = false, had_special = false;
-        float pt = 0.f, pu = 0.f, pv = 0.f, ppt = 0.f;
-        uint32_t run = 0;  // current run of consecutive gaps below eps
-        uint32_t nhits = 0;
-        uint32_t steps = 0;
-        uint32_t h_cell = 0;  // stashed even-slot segment
-        uint4 h_vi = make_uint4(0, 0, 0, 0);
-        float h_t0 = 0.f, h_t1 = 0.f, h_b0 = 0.f, h_b1 = 0.f, h_b2 = 0.f, h_b3 = 0.f, h_b4 = 0.f, h_b5 = 0.f;
-        // Record of the current tet.  gfx950's vmcnt retires loads and stores in issue order, so the
-        // NEXT record is always requested BEFORE this step's segment stores.  PREFETCH variant: it is
-        // requested as soon as the exit face is known (shortest dependent chain per step: load ->
-        // 4 shears -> 6 edge functions -> sign logic -> address), and the (t,u,v) / segment
-        // arithmetic of this step runs under the load's latency.
-        WalkRec cur = load_rec(p.tets, c);
+    bool alive = nhull == 2 && !flag;
+    const bool first0 = ht0 < ht1;
+    const uint32_t f_out = first0 ? hf1 : hf0;
+    uint32_t fid_in = first0 ? hf0 : hf1;                        // id of the face the current tet was entered through
+    uint32_t c = 4u * (first0 ? hc0 : hc1) + (first0 ? he0 : he1);  // variant = (tet record, entry face)
+    if (!alive) c = 0;
+    c_start = c >> 2; e_start = c & 3u; f_end = f_out;
+    // The entry face in its STORED order: sheared vertices A,B,C and edge functions U=E(B,C), V=E(C,A), W=E(A,B).
+    // From here on they are carried: the exit face of a step, evaluated in its stored order, is the entry face of
+    // the next (same face-table entry), so per step only ONE vertex is sheared and three edge functions against
+    // it decide the exit.
+    SV A = {0.f, 0.f, 0.f}, B = A, C = A;
+    if (alive) {
+        const float4 *tp = p.hull_tris + 3 * (size_t)(first0 ? hs0 : hs1);
+        const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+        A = shear(rp, v0.x, v0.y, v0.z); B = shear(rp, v1.x, v1.y, v1.z); C = shear(rp, v2.x, v2.y, v2.z);
+    }
+    float Uc = edge_f(B, C), Vc = edge_f(C, A), Wc = edge_f(A, B);
+    // state of the previous recorded (valid) hit
+    bool have_prev = false, have_pp = false, pending_inv = false, had_special = false;
+    float pt = 0.f, pu = 0.f, pv = 0.f, ppt = 0.f;
+    uint32_t run = 0;  // current run of consecutive gaps below eps
+    uint32_t nhits = 0;
+    uint32_t steps = 0;
+    Var cur = load_var(p.vars, c);
+    if (alive) {
+        // the entry hull face itself may be the first recorded hit
+        float tt, uu, vv;
+        if (tri_finish(Uc, Vc, Wc, A.z, B.z, C.z, tt, uu, vv)) { have_prev = true; pt = tt; pu = uu; pv = vv; nhits = 1; }
+    }
 
-        // vertex ids of the entry face in its stored order (carried: the exit face of one step is the
-        // entry face of the next, same face table entry => same triple)
-        uint32_t in0, in1, in2;
-        {
-            const uint32_t pe = cur.m0.x >> (6u * e);
-            in0 = sel4u(cur.vert, pe & 3u); in1 = sel4u(cur.vert, (pe >> 2) & 3u); in2 = sel4u(cur.vert, (pe >> 4) & 3u);
-            // the entry hull face itself may be the first recorded hit
-            const SV P0 = shear(rp, __uint_as_float(cur.q0.x), __uint_as_float(cur.q0.y), __uint_as_float(cur.q0.z));
-            const SV P1 = shear(rp, __uint_as_float(cur.q0.w), __uint_as_float(cur.q1.x), __uint_as_float(cur.q1.y));
-            const SV P2 = shear(rp, __uint_as_float(cur.q1.z), __uint_as_float(cur.q1.w), __uint_as_float(cur.q2.x));
-            const SV P3 = shear(rp, __uint_as_float(cur.q2.y), __uint_as_float(cur.q2.z), __uint_as_float(cur.q2.w));
-            float tt, uu, vv;
-            if (face_tuv(cur, P0, P1, P2, P3, edge_f(P0, P1), edge_f(P0, P2), edge_f(P0, P3), edge_f(P1, P2), edge_f(P1, P3),
-                         edge_f(P2, P3), e, tt, uu, vv)) {
-                have_prev = true; pt = tt; pu = uu; pv = vv; nhits = 1;
-            }
-        }
-
-        for (;;) {
+    for (;;) {
+        bool need_flush = false;
+        if (alive) {
             // All checks of a step accumulate into `bad` (first reason kept) and are acted on ONCE at the
             // end of the step: one divergence point per step instead of a dozen.
             uint32_t bad = 0;
-            const SV P0 = shear(rp, __uint_as_float(cur.q0.x), __uint_as_float(cur.q0.y), __uint_as_float(cur.q0.z));
-            const SV P1 = shear(rp, __uint_as_float(cur.q0.w), __uint_as_float(cur.q1.x), __uint_as_float(cur.q1.y));
-            const SV P2 = shear(rp, __uint_as_float(cur.q1.z), __uint_as_float(cur.q1.w), __uint_as_float(cur.q2.x));
-            const SV P3 = shear(rp, __uint_as_float(cur.q2.y), __uint_as_float(cur.q2.z), __uint_as_float(cur.q2.w));
-            const float e01 = edge_f(P0, P1), e02 = edge_f(P0, P2), e03 = edge_f(P0, P3);
-            const float e12 = edge_f(P1, P2), e13 = edge_f(P1, P3), e23 = edge_f(P2, P3);
-            if (e01 == 0.0f || e02 == 0.0f || e03 == 0.0f || e12 == 0.0f || e13 == 0.0f || e23 == 0.0f) bad = 5;
-            // face k (opposite vertex k) is crossed iff its three cyclic edge functions agree in sign
-            const bool h3 = (e01 > 0.0f) == (e12 > 0.0f) && (e12 > 0.0f) == (e02 < 0.0f);   // 0->1, 1->2, 2->0
-            const bool h2 = (e01 > 0.0f) == (e13 > 0.0f) && (e13 > 0.0f) == (e03 < 0.0f);   // 0->1, 1->3, 3->0
-            const bool h1 = (e02 > 0.0f) == (e23 > 0.0f) && (e23 > 0.0f) == (e03 < 0.0f);   // 0->2, 2->3, 3->0
-            const bool h0 = (e12 > 0.0f) == (e23 > 0.0f) && (e23 > 0.0f) == (e13 < 0.0f);   // 1->2, 2->3, 3->1
-            const uint32_t hmask = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
-            if (!bad && (__popc(hmask) != 2 || !((hmask >> e) & 1u))) bad = 6;
-            const uint32_t x = (__ffs(hmask & ~(1u << e)) - 1) & 3u;  // exit face
-            const uint32_t nb = sel4u(cur.nbr, x);
-            const uint32_t back = (cur.m0.y >> (2 * x)) & 3u;
+            const SV P = shear(rp, __uint_as_float(cur.q0.x), __uint_as_float(cur.q0.y), __uint_as_float(cur.q0.z));
+            const float ea = edge_f(P, A), eb = edge_f(P, B), ec = edge_f(P, C);
+            if (ea == 0.0f || eb == 0.0f || ec == 0.0f) bad = 5;
+            // exit candidates: the faces opposite a {n,b,c}, b {n,c,a}, c {n,a,b}; a face is crossed iff its three
+            // cyclic edge functions agree in sign: E(n,b), E(b,c) = Uc, E(c,n) = -ec, and cyclically
+            const bool sa = ea > 0.0f, sb = eb > 0.0f, sc = ec > 0.0f;
+            const bool su = Uc > 0.0f, sv = Vc > 0.0f, sw = Wc > 0.0f;
+            const bool ha = (sb == su) && (su != sc);
+            const bool hb = (sc == sv) && (sv != sa);
+            const bool hc = (sa == sw) && (sw != sb);
+            const uint32_t hmask = (ha ? 1u : 0u) | (hb ? 2u : 0u) | (hc ? 4u : 0u);
+            if (!bad && __popc(hmask) != 1) bad = 6;
+            const uint32_t x = (__ffs(hmask) - 1) & 3u;  // exit 0..2 (3 only together with bad)
+            const uint32_t nb = sel3u(cur.q2, x);
+            const uint32_t fx = sel3u(cur.q3, x);        // id of the exit face
             const bool last = nb == TN_EMPTY;
-            // the next record is requested as soon as the exit face is known (shortest dependent chain per
-            // step) and before this step's stores (vmcnt retires loads and stores in issue order)
-            const WalkRec nxt = load_rec(p.tets, (last || bad) ? c : nb);
+            // the next record is requested as soon as the exit is known
+            const Var nxt = load_var(p.vars, (last || bad) ? c : nb);
             __builtin_amdgcn_sched_barrier(0);
 
+            // the exit face in its stored order: 12-bit code of exit x out of the 36-bit word
+            const bool x0 = (x & 1u) != 0, x1 = (x & 2u) != 0;
+            const uint32_t w01 = x0 ? (cur.q3.w >> 12) : cur.q3.w;
+            const uint32_t w2 = (cur.q3.w >> 24) | (cur.q2.w << 8);
+            const uint32_t code = (x1 ? w2 : w01) & 0xFFFu;
+            const SV A2 = selsv(P, A, B, C, code & 3u), B2 = selsv(P, A, B, C, (code >> 2) & 3u), C2 = selsv(P, A, B, C, (code >> 4) & 3u);
+            const float U = edge_f(B2, C2), V = edge_f(C2, A2), W = edge_f(A2, B2);
             float ct = 0.f, cu = 0.f, cv = 0.f;
-            const bool valid = face_tuv(cur, P0, P1, P2, P3, e01, e02, e03, e12, e13, e23, x, ct, cu, cv);
-
-            // exit face's stored vertex triple (next step's entry triple)
-            const uint32_t px = cur.m0.x >> (6u * x);
-            const uint32_t ex0 = sel4u(cur.vert, px & 3u), ex1 = sel4u(cur.vert, (px >> 2) & 3u), ex2 = sel4u(cur.vert, (px >> 4) & 3u);
+            const bool valid = tri_finish(U, V, W, A2.z, B2.z, C2.z, ct, cu, cv);
 
             bool do_emit = false;
             if (valid && have_prev) {
                 const bool is_short = fabsf(pt - ct) < TN_EPS;
                 bool ascending = ct > pt;
-                if (ct == pt) {
-                    // exact tie: the sort orders the two faces by id
-                    const uint4 face = reinterpret_cast<const uint4 *>(p.tets + c)[2];
-                    ascending = sel4u(face, x) > sel4u(face, e);
-                }
+                if (ct == pt) ascending = fx > fid_in;  // exact tie: the sort orders the two faces by id
                 if (ascending) {
                     // the face after an inverted pair must clear BOTH of its faces by eps
                     if (pending_inv && !(ct - ppt >= TN_EPS) && !bad) bad = 7;
@@ -298,74 +316,95 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             if (valid && ++nhits > M - 1 && !bad) bad = 9;  // more than M-1 faces
 
             if (do_emit && !bad) {
-                // combine_indices by local indices: entry slot j <- position of its vertex in the exit face
-                const uint32_t bit = 6u * (3u * e + x - (x > e ? 1u : 0u));
-                const uint32_t w = bit >> 5;
-                const bool w0 = (w & 1u) != 0, w1 = (w & 2u) != 0;
-                const uint32_t lo = w1 ? cur.m1.w : (w0 ? cur.m1.z : cur.m1.y);
-                const uint32_t hi = w1 ? 0u : (w0 ? cur.m1.w : cur.m1.z);
-                const uint32_t cc = __builtin_amdgcn_alignbit(hi, lo, bit & 31u);
+                // combine_indices: entry slot j <- position of its vertex in the exit face's stored order
                 const float r0 = 1.0f - cu - cv;
-                const uint32_t c0 = cc & 3u, c1 = (cc >> 2) & 3u, c2 = (cc >> 4) & 3u;
-                const float s_b0 = 1.0f - pu - pv, s_b1 = pu, s_b2 = pv;
-                const float s_b3 = sel4f(r0, cu, cv, 0.f, c0), s_b4 = sel4f(r0, cu, cv, 0.f, c1), s_b5 = sel4f(r0, cu, cv, 0.f, c2);
-                const uint32_t s_cell = cur.m0.z;  // the caller's tet id
-                const uint4 s_vi = make_uint4(sel4u(cur.vert, e), in0, in1, in2);
-                // rows are written two segments at a time (even slot stashed, odd slot flushes the
-                // pair): 7 store transactions per pair instead of 12 -- the per-lane stores are
-                // transaction-bound, not byte-bound
-                if (nseg & 1u) {
-                    {
-                        const size_t s0 = nseg - 1;
-                        *reinterpret_cast<uint2 *>(row_cells + s0) = make_uint2(h_cell, s_cell);
-                        *reinterpret_cast<float4 *>(row_dist + 2 * s0) = make_float4(h_t0, h_t1, pt, ct);
-                        float4 *bp = reinterpret_cast<float4 *>(row_bary + 6 * s0);
-                        bp[0] = make_float4(h_b0, h_b1, h_b2, h_b3);
-                        bp[1] = make_float4(h_b4, h_b5, s_b0, s_b1);
-                        bp[2] = make_float4(s_b2, s_b3, s_b4, s_b5);
-                        if (row_verts) {
-                            uint4 *vp = reinterpret_cast<uint4 *>(row_verts + 4 * s0);
-                            vp[0] = h_vi;
-                            vp[1] = s_vi;
-                        }
-                    }
-                } else {
-                    h_cell = s_cell; h_vi = s_vi; h_t0 = pt; h_t1 = ct;
-                    h_b0 = s_b0; h_b1 = s_b1; h_b2 = s_b2; h_b3 = s_b3; h_b4 = s_b4; h_b5 = s_b5;
-                }
+                const uint32_t c0 = (code >> 6) & 3u, c1 = (code >> 8) & 3u, c2 = (code >> 10) & 3u;
+                const uint32_t k = nseg & 3u;
+                mybuf[k] = cur.q0.w;  // the caller's tet id
+                *reinterpret_cast<float2 *>(mybuf + 4 + 2 * k) = make_float2(pt, ct);
+                float2 *bp = reinterpret_cast<float2 *>(mybuf + 12 + 6 * k);
+                bp[0] = make_float2(1.0f - pu - pv, pu);
+                bp[1] = make_float2(pv, sel4f(r0, cu, cv, 0.f, c0));
+                bp[2] = make_float2(sel4f(r0, cu, cv, 0.f, c1), sel4f(r0, cu, cv, 0.f, c2));
+                *reinterpret_cast<uint4 *>(mybuf + 36 + 4 * k) = cur.q1;  // (n, a, b, c)
                 nseg++;
+                need_flush = (nseg & 3u) == 0;
             }
             if (valid) {
                 have_pp = have_prev; ppt = pt;
                 have_prev = true; pt = ct; pu = cu; pv = cv;
             }
             if (last && !bad) {
-                const uint4 face = reinterpret_cast<const uint4 *>(p.tets + c)[2];
-                if (sel4u(face, x) != f_out) bad = 11;
-                // Tie handling is certified away from the chain ends only: in a short chain the
-                // reference's look-ahead can pair the two hull faces through their common EMPTY tet
-                // (get_common_tetrahedra, optix_trace_rays.cu:22-37); a pair inverted at the very end
-                // has no following face to clear it.
+                if (fx != f_out) bad = 11;
+                // Tie handling is certified away from the chain ends only: in a short chain the reference's
+                // look-ahead can pair the two hull faces through their common EMPTY tet (get_common_tetrahedra,
+                // optix_trace_rays.cu:22-37); a pair inverted at the very end has no following face to clear it.
                 else if ((had_special && nhits <= 8) || pending_inv) bad = 8;
             }
             if (!bad && !last && ++steps > MAX_WALK_STEPS) bad = 12;
-            if (bad) { flag = true; why = bad; break; }
-            if (last) break;
-            e = back;
-            c = nb;
-            cur = nxt;
-            in0 = ex0; in1 = ex1; in2 = ex2;
+            if (bad) { flag = true; why = bad; alive = false; need_flush = false; }
+            else if (last) alive = false;
+            else {
+                c = nb;
+                cur = nxt;
+                fid_in = fx;
+                A = A2; B = B2; C = C2;
+                Uc = U; Vc = V; Wc = W;
+            }
         }
-        if (!flag && (nseg & 1u)) {
-            // odd segment count: the stashed last segment goes out alone
-            const size_t s0 = nseg - 1;
-            row_cells[s0] = h_cell;
-            *reinterpret_cast<float2 *>(row_dist + 2 * s0) = make_float2(h_t0, h_t1);
-            float2 *bp = reinterpret_cast<float2 *>(row_bary + 6 * s0);
-            bp[0] = make_float2(h_b0, h_b1);
-            bp[1] = make_float2(h_b2, h_b3);
-            bp[2] = make_float2(h_b4, h_b5);
-            if (row_verts) *reinterpret_cast<uint4 *>(row_verts + 4 * s0) = h_vi;
+        // ---- cooperative write-out of the full buffers (wave-uniform)
+        unsigned long long fm = __ballot(need_flush);
+        if (fm) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the owners' LDS writes are done
+            const uint32_t grp = (uint32_t)lane / 13u, chunk = (uint32_t)lane - 13u * grp;  // lanes 52..63 idle
+            while (fm) {
+                // the next (up to) four rays with a full buffer
+                int src = -1;
+#pragma unroll
+                for (uint32_t g = 0; g < 4; ++g) {
+                    if (fm) {
+                        const int l = __ffsll(fm) - 1;
+                        fm &= fm - 1;
+                        if (grp == g) src = l;
+                    }
+                }
+                // ds_bpermute reads only ACTIVE source lanes: every lane takes part in the exchange
+                const uint32_t ns = (uint32_t)__shfl((int)nseg, src >= 0 ? src : 0);
+                if (src >= 0 && grp < 4) {
+                    const size_t row = (wave_ray0 + (size_t)src) * M + (ns - 4);   // first of the four slots
+                    const uint4 data = *reinterpret_cast<const uint4 *>(seg_lds + ((size_t)wave * 64 + src) * 52 + 4 * chunk);
+                    uint32_t *dst;
+                    if (chunk == 0) dst = t.out_cells + row;
+                    else if (chunk < 3) dst = reinterpret_cast<uint32_t *>(t.out_dist) + 2 * row + 4 * (chunk - 1);
+                    else if (chunk < 9) dst = reinterpret_cast<uint32_t *>(t.out_bary) + 6 * row + 4 * (chunk - 3);
+                    else dst = t.out_verts ? t.out_verts + 4 * row + 4 * (chunk - 9) : nullptr;
+                    if (dst) *reinterpret_cast<uint4 *>(dst) = data;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // buffers are read before their owners refill them
+        }
+        if (__ballot(alive) == 0ull) break;
+    }
+    // ---- left-over segments (1..3 per ray): one ray per pass, lane w copies word w of its buffer
+    {
+        const uint32_t left = (active && !flag) ? (nseg & 3u) : 0u;
+        unsigned long long lm = __ballot(left != 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        while (lm) {
+            const int src = __ffsll(lm) - 1;
+            lm &= lm - 1;
+            const uint32_t nl = (uint32_t)__shfl((int)left, src), ns = (uint32_t)__shfl((int)nseg, src);
+            const size_t row = (wave_ray0 + (size_t)src) * M + (ns - nl);
+            const uint32_t w = (uint32_t)lane;
+            if (w < 52) {
+                const uint32_t val = seg_lds[((size_t)wave * 64 + src) * 52 + w];
+                uint32_t *dst = nullptr;
+                if (w < 4) { if (w < nl) dst = t.out_cells + row + w; }
+                else if (w < 12) { if (w - 4 < 2 * nl) dst = reinterpret_cast<uint32_t *>(t.out_dist) + 2 * row + (w - 4); }
+                else if (w < 36) { if (w - 12 < 6 * nl) dst = reinterpret_cast<uint32_t *>(t.out_bary) + 6 * row + (w - 12); }
+                else if (w - 36 < 4 * nl && t.out_verts) dst = t.out_verts + 4 * row + (w - 36);
+                if (dst) *dst = val;
+            }
         }
     }
 
@@ -392,7 +431,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     if (!p.fused_tails) return;  // a separate k_fill_tails launch (other stream) writes the tails
 
     // wave-cooperative constant tails of the 64 rows this wave owns
-    const size_t wave_ray0 = (size_t)lb * WALK_BLOCK + (size_t)wave * 64;
     for (int i = 0; i < 64; ++i) {
         if (wave_ray0 + i >= t.num_items) break;
         const uint32_t n_i = __shfl(nseg, i);
@@ -405,6 +443,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         if (t.out_verts) fill_dwords(t.out_verts + r_i * M * 4, 4 * n_i, 4 * M, TN_EMPTY, lane);
     }
 }
+
 
 // Re-walk of the chains whose ORDER the walk could not certify (reasons 7 / 8 / 10): lane per ray, same
 // chain, same per-face arithmetic, but every valid hit (face id, t, u, v) is only RECORDED -- into the ray's
@@ -548,7 +587,7 @@ void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
     // grid padded so that both remaps (runs of XCD_GROUP blocks / one band per XCD) are bijections
     const uint32_t unit = 8 * ((p.debug & 8u) ? (nblk + 7) / 8 : XCD_GROUP);
     const uint32_t grid = (nblk + unit - 1) / unit * unit;
-    hipLaunchKernelGGL(k_trace_walk, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL(k_trace_walk, dim3(grid), dim3(WALK_BLOCK), WALK_BLOCK * 52 * sizeof(uint32_t), stream, p);
 }
 
 }  // namespace tn
