@@ -360,7 +360,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
                 tn::launch_trace_general(p, t->side);
-                if (t->dense_tails) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream);
+                if (t->dense_tails) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream, t->fill_blocks);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
             } else {
