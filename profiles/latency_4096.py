@@ -18,7 +18,7 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 for name, (o, d) in (("outside_in", scenes.outside_in_rays(4096, 1)), ("inside_out", scenes.inside_out_rays(4096, 2))):
     o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
-    for walk in (1, 0):
+    for walk in (1, 0, 2):   # 2 = adjacency walk forced at this size
         tr.set_option("walk", walk)
         us = timeit(lambda: tr.trace_rays(o, d, M))
         out = tr.trace_rays(o, d, M)

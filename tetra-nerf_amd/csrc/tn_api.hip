@@ -66,7 +66,6 @@ struct tn_tracer {
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
     unsigned fill_blocks = 0;            // cap of the tail-fill grid (0 = default); throttle knob of mode 2
     int mode = 1;                        // launch structure of the walk path (see tn_trace_rays)
-    tn::DevBuf<tn::TetRec> tets;
     tn::DevBuf<tn::WalkVar> vars;
     tn::DevBuf<float> hull_nodes, hull_tris;
     tn::DevWideBvh bvh;
@@ -210,7 +209,6 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         t->faces.upload(t->host.faces);
         t->face_tets.upload(t->host.face_tets);
         t->bvh.upload(hb, smax);
-        t->tets.upload(recs);
         {
             std::vector<tn::WalkVar> vars;
             tn::build_walk_variants(recs, vars);
@@ -224,7 +222,7 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         m.V = (uint32_t)V; m.T = (uint32_t)T; m.F = (uint32_t)F;
         m.faces = t->faces.p; m.face_tets = t->face_tets.p;
         m.bvh = t->bvh.view;
-        m.tets = t->tets.p; m.vars = t->vars.p; m.n_hull = (uint32_t)hull_ids.size();
+        m.vars = t->vars.p; m.n_hull = (uint32_t)hull_ids.size();
         m.hull_nodes = reinterpret_cast<const float4 *>(t->hull_nodes.p);
         m.hull_tris = reinterpret_cast<const float4 *>(t->hull_tris.p);
         m.n_hull_nodes = (uint32_t)(hth.nodes.size() / 8);
@@ -305,7 +303,6 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 w.t = make_params(t, n, M, origins + 3 * r0, directions + 3 * r0, num_visited + r0,
                                   visited + r0 * M, bary + r0 * M * 6, dist + r0 * M * 2,
                                   verts ? verts + r0 * M * 4 : nullptr);
-                w.tets = t->mesh.tets;
                 w.vars = t->mesh.vars;
                 w.scene_max = t->mesh.bvh.scene_max;
                 w.hull_nodes = t->mesh.hull_nodes;
@@ -341,7 +338,8 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 if (!t->rewalk) return;
                 tn::WalkParams w{};
                 w.t = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
-                w.tets = t->mesh.tets;
+                w.vars = t->mesh.vars;
+                w.hull_tris = t->mesh.hull_tris;
                 w.fallback_list = t->fallback_list.p;
                 w.fallback_count = t->fallback_count.p;
                 w.rewalk_list = t->rewalk_list.p;

@@ -91,7 +91,6 @@ struct DeviceMesh {
     uint32_t *face_tets = nullptr;  // [F,2]
     WideBvh bvh{};                  // over all faces
     // adjacency walk
-    TetRec *tets = nullptr;         // [T]
     WalkVar *vars = nullptr;        // [4T] entry-face-specialised records of the walk
     const float4 *hull_nodes = nullptr;  // threaded binary BVH over the hull faces (2 float4 per node)
     const float4 *hull_tris = nullptr;   // 3 float4 per hull face

@@ -36,7 +36,6 @@ void launch_find_tetrahedra(const TraceParams &p, const float *points, uint32_t 
 // adjacency walk, one lane per ray (tn_trace_walk.hip)
 struct WalkParams {
     TraceParams t;
-    const TetRec *tets;
     const WalkVar *vars;       // entry-face-specialised records of the walk (k_trace_walk)
     float scene_max;           // max |coordinate| of the mesh (box padding)
     const float4 *hull_nodes;  // threaded per-lane hull tree

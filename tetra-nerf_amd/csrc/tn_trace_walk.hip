@@ -39,14 +39,9 @@ constexpr int WALK_BLOCK = 256;
 constexpr uint32_t XCD_GROUP = 16;  // consecutive blocks per XCD run (4096 rays)
 constexpr uint32_t MAX_WALK_STEPS = 1u << 20;
 
-// Branch-free 4-way selects on the two index bits (three v_cndmask).  Written as bit tests on
-// purpose: an `i == 0 ? a : i == 1 ? b : ...` chain is turned into a switch by the optimiser and then
-// lowered to exec-masked branches -- a dozen of those per step cost more than the arithmetic.
-__device__ __forceinline__ uint32_t sel4u(const uint4 &v, uint32_t i) {
-    const bool b0 = (i & 1u) != 0, b1 = (i & 2u) != 0;
-    const uint32_t lo = b0 ? v.y : v.x, hi = b0 ? v.w : v.z;
-    return b1 ? hi : lo;
-}
+// Selects are written as bit tests on purpose (v_cndmask): an `i == 0 ? a : i == 1 ? b : ...` chain is turned into a
+// switch by the optimiser and then lowered to exec-masked branches -- a dozen of those per step cost more than the
+// arithmetic.
 
 // fill dwords [start, end) of `base` with `value`; base 16-byte aligned.  Wave-cooperative.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -65,49 +60,10 @@ __device__ __forceinline__ void fill_dwords(uint32_t *__restrict__ base, uint32_
     if (a1 + lane < end) base[a1 + lane] = value;
 }
 
-// the fields of a TetRec the walk needs every step (face ids are only read at both ends)
-struct WalkRec {
-    uint4 vert, nbr, q0, q1, q2;
-    uint4 m0;  // perm, back, orig, euv[0]
-    uint4 m1;  // euv[1], cmb[0..2]
-};
-
-// one of the six shared edge functions, by 4-bit code (bits 0-2 pair index, bit 3 negate)
-__device__ __forceinline__ float sel_edge(float e01, float e02, float e03, float e12, float e13, float e23, uint32_t c) {
-    const bool b0 = (c & 1u) != 0, b1 = (c & 2u) != 0, b2 = (c & 4u) != 0;
-    const float p0 = b0 ? e02 : e01, p1 = b0 ? e12 : e03, p2 = b0 ? e23 : e13;  // indices {0,1} {2,3} {4,5}
-    const float q = b1 ? p1 : p0;
-    const float v = b2 ? p2 : q;
-    return __uint_as_float(__float_as_uint(v) ^ ((c & 8u) << 28));
-}
-
 __device__ __forceinline__ float sel4f(float a, float b, float c, float d, uint32_t i) {
     const bool b0 = (i & 1u) != 0, b1 = (i & 2u) != 0;
     const float lo = b0 ? b : a, hi = b0 ? d : c;
     return b1 ? hi : lo;
-}
-
-__device__ __forceinline__ WalkRec load_rec(const TetRec *tets, uint32_t c) {
-    const uint4 *r = reinterpret_cast<const uint4 *>(tets + c);
-    WalkRec x;
-    x.vert = r[0]; x.nbr = r[1]; x.q0 = r[3]; x.q1 = r[4]; x.q2 = r[5];
-    x.m0 = r[6]; x.m1 = r[7];
-    return x;
-}
-
-// (t,u,v) of face k of the current tet in the face's STORED vertex order: U,V,W are picked (with sign) from
-// the six shared edge functions -- E(Q,P) == -E(P,Q) bitwise -- by the record's codes.
-__device__ __forceinline__ bool face_tuv(const WalkRec &rc, const SV &P0, const SV &P1, const SV &P2, const SV &P3, float e01,
-                                         float e02, float e03, float e12, float e13, float e23, uint32_t k, float &tt,
-                                         float &uu, float &vv) {
-    const uint32_t word = (k & 2u) ? rc.m1.x : rc.m0.w;
-    const uint32_t code = (word >> (12u * (k & 1u))) & 0xFFFu;
-    const uint32_t pm = rc.m0.x >> (6u * k);
-    const float U = sel_edge(e01, e02, e03, e12, e13, e23, code);
-    const float V = sel_edge(e01, e02, e03, e12, e13, e23, code >> 4);
-    const float W = sel_edge(e01, e02, e03, e12, e13, e23, code >> 8);
-    return tri_finish(U, V, W, sel4f(P0.z, P1.z, P2.z, P3.z, pm & 3u), sel4f(P0.z, P1.z, P2.z, P3.z, (pm >> 2) & 3u),
-                      sel4f(P0.z, P1.z, P2.z, P3.z, (pm >> 4) & 3u), tt, uu, vv);
 }
 
 // a walk variant record as four 16-B quads: q0 = (pn.xyz, orig), q1 = vid, q2 = (nb0..2, code_hi), q3 = (fid0..2, code_lo)
@@ -224,14 +180,14 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     const size_t wave_ray0 = (size_t)lb * WALK_BLOCK + (size_t)wave * 64;
 
     uint32_t nseg = 0;
-    uint32_t c_start = 0, e_start = 0, f_end = 0;  // chain start / hull exit face, for the re-walk of an uncertified chain
+    uint32_t slot_start = 0, f_end = 0;  // entry hull triangle / hull exit face, for the re-walk of an uncertified chain
     bool alive = nhull == 2 && !flag;
     const bool first0 = ht0 < ht1;
     const uint32_t f_out = first0 ? hf1 : hf0;
     uint32_t fid_in = first0 ? hf0 : hf1;                        // id of the face the current tet was entered through
     uint32_t c = 4u * (first0 ? hc0 : hc1) + (first0 ? he0 : he1);  // variant = (tet record, entry face)
     if (!alive) c = 0;
-    c_start = c >> 2; e_start = c & 3u; f_end = f_out;
+    slot_start = first0 ? hs0 : hs1; f_end = f_out;
     // The entry face in its STORED order: sheared vertices A,B,C and edge functions U=E(B,C), V=E(C,A), W=E(A,B).
     // From here on they are carried: the exit face of a step, evaluated in its stored order, is the entry face of
     // the next (same face-table entry), so per step only ONE vertex is sheared and three edge functions against
@@ -416,7 +372,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             // (k_walk_collect) and goes through the literal sort + pairing; anything else -> BVH all-hits path
             if (p.rewalk_list && (why == 7 || why == 8 || why == 10)) {
                 const uint32_t slot = atomicAdd(p.rewalk_count, 1u);
-                p.rewalk_list[slot] = make_uint4((uint32_t)(p.ray_base + ray), c_start, e_start, f_end);
+                p.rewalk_list[slot] = make_uint4((uint32_t)(p.ray_base + ray), slot_start, f_end, 0u);
             } else {
                 const uint32_t slot = atomicAdd(p.fallback_count, 1u);
                 p.fallback_list[slot] = (uint32_t)(p.ray_base + ray);
@@ -462,7 +418,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_walk_collect(WalkParams p) {
     // entries are handed to that list unchanged (decided on the device: no host round trip).
     const bool hand_over = n_items < p.rewalk_min;
     for (uint32_t it = blockIdx.x * WALK_BLOCK + threadIdx.x; it < n_items; it += gridDim.x * WALK_BLOCK) {
-        const uint4 ent = p.rewalk_list[it];
+        const uint4 ent = p.rewalk_list[it];  // ray, hull triangle of the entry face, hull exit face id
         if (hand_over) {
             const uint32_t slot = atomicAdd(p.fallback_count, 1u);
             p.fallback_list[slot] = ent.x;
@@ -471,8 +427,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_walk_collect(WalkParams p) {
             continue;
         }
         const size_t ray = ent.x;
-        uint32_t c = ent.y, e = ent.z;
-        const uint32_t f_out = ent.w;
+        const uint32_t f_out = ent.z;
         const RayPre rp = ray_pre(t.origins[3 * ray], t.origins[3 * ray + 1], t.origins[3 * ray + 2], t.dirs[3 * ray],
                                   t.dirs[3 * ray + 1], t.dirs[3 * ray + 2]);
         uint32_t *row_id = t.out_cells + ray * M;
@@ -487,44 +442,50 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_walk_collect(WalkParams p) {
             }
             nhits++;
         };
-        WalkRec cur = load_rec(p.tets, c);
-        bool first = true;
+        // the entry hull face in its stored order (as in k_trace_walk)
+        const float4 *tp = p.hull_tris + 3 * (size_t)ent.y;
+        const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+        SV A = shear(rp, v0.x, v0.y, v0.z), B = shear(rp, v1.x, v1.y, v1.z), C = shear(rp, v2.x, v2.y, v2.z);
+        float Uc = edge_f(B, C), Vc = edge_f(C, A), Wc = edge_f(A, B);
+        uint32_t c = 4u * __float_as_uint(v1.w) + __float_as_uint(v2.w);
+        {
+            float tt, uu, vv;
+            if (tri_finish(Uc, Vc, Wc, A.z, B.z, C.z, tt, uu, vv)) record(__float_as_uint(v0.w), tt, uu, vv);
+        }
+        Var cur = load_var(p.vars, c);
         for (;;) {
-            const SV P0 = shear(rp, __uint_as_float(cur.q0.x), __uint_as_float(cur.q0.y), __uint_as_float(cur.q0.z));
-            const SV P1 = shear(rp, __uint_as_float(cur.q0.w), __uint_as_float(cur.q1.x), __uint_as_float(cur.q1.y));
-            const SV P2 = shear(rp, __uint_as_float(cur.q1.z), __uint_as_float(cur.q1.w), __uint_as_float(cur.q2.x));
-            const SV P3 = shear(rp, __uint_as_float(cur.q2.y), __uint_as_float(cur.q2.z), __uint_as_float(cur.q2.w));
-            const float e01 = edge_f(P0, P1), e02 = edge_f(P0, P2), e03 = edge_f(P0, P3);
-            const float e12 = edge_f(P1, P2), e13 = edge_f(P1, P3), e23 = edge_f(P2, P3);
-            if (e01 == 0.0f || e02 == 0.0f || e03 == 0.0f || e12 == 0.0f || e13 == 0.0f || e23 == 0.0f) bad = 5;
-            const bool h3 = (e01 > 0.0f) == (e12 > 0.0f) && (e12 > 0.0f) == (e02 < 0.0f);
-            const bool h2 = (e01 > 0.0f) == (e13 > 0.0f) && (e13 > 0.0f) == (e03 < 0.0f);
-            const bool h1 = (e02 > 0.0f) == (e23 > 0.0f) && (e23 > 0.0f) == (e03 < 0.0f);
-            const bool h0 = (e12 > 0.0f) == (e23 > 0.0f) && (e23 > 0.0f) == (e13 < 0.0f);
-            const uint32_t hmask = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
-            if (!bad && (__popc(hmask) != 2 || !((hmask >> e) & 1u))) bad = 6;
-            const uint32_t x = (__ffs(hmask & ~(1u << e)) - 1) & 3u;  // exit face
-            const uint32_t nb = sel4u(cur.nbr, x);
-            const uint32_t back = (cur.m0.y >> (2 * x)) & 3u;
+            const SV P = shear(rp, __uint_as_float(cur.q0.x), __uint_as_float(cur.q0.y), __uint_as_float(cur.q0.z));
+            const float ea = edge_f(P, A), eb = edge_f(P, B), ec = edge_f(P, C);
+            if (ea == 0.0f || eb == 0.0f || ec == 0.0f) bad = 5;
+            const bool sa = ea > 0.0f, sb = eb > 0.0f, sc = ec > 0.0f;
+            const bool su = Uc > 0.0f, sv = Vc > 0.0f, sw = Wc > 0.0f;
+            const bool ha = (sb == su) && (su != sc), hb = (sc == sv) && (sv != sa), hc = (sa == sw) && (sw != sb);
+            const uint32_t hmask = (ha ? 1u : 0u) | (hb ? 2u : 0u) | (hc ? 4u : 0u);
+            if (!bad && __popc(hmask) != 1) bad = 6;
+            const uint32_t x = (__ffs(hmask) - 1) & 3u;
+            const uint32_t nb = sel3u(cur.q2, x);
+            const uint32_t fx = sel3u(cur.q3, x);
             const bool last = nb == TN_EMPTY;
-            const WalkRec nxt = load_rec(p.tets, (last || bad) ? c : nb);  // requested before this step's stores
+            const Var nxt = load_var(p.vars, (last || bad) ? c : nb);  // requested before this step's stores
             __builtin_amdgcn_sched_barrier(0);
             if (bad) break;
-            const uint4 face = reinterpret_cast<const uint4 *>(p.tets + c)[2];
+            const bool x0 = (x & 1u) != 0, x1 = (x & 2u) != 0;
+            const uint32_t w01 = x0 ? (cur.q3.w >> 12) : cur.q3.w;
+            const uint32_t w2 = (cur.q3.w >> 24) | (cur.q2.w << 8);
+            const uint32_t code = (x1 ? w2 : w01) & 0xFFFu;
+            const SV A2 = selsv(P, A, B, C, code & 3u), B2 = selsv(P, A, B, C, (code >> 2) & 3u), C2 = selsv(P, A, B, C, (code >> 4) & 3u);
+            const float U = edge_f(B2, C2), V = edge_f(C2, A2), W = edge_f(A2, B2);
             float tt, uu, vv;
-            if (first) {  // the hull entry face itself
-                first = false;
-                if (face_tuv(cur, P0, P1, P2, P3, e01, e02, e03, e12, e13, e23, e, tt, uu, vv)) record(sel4u(face, e), tt, uu, vv);
-            }
-            if (face_tuv(cur, P0, P1, P2, P3, e01, e02, e03, e12, e13, e23, x, tt, uu, vv)) record(sel4u(face, x), tt, uu, vv);
+            if (tri_finish(U, V, W, A2.z, B2.z, C2.z, tt, uu, vv)) record(fx, tt, uu, vv);
             if (last) {
-                if (sel4u(face, x) != f_out) bad = 11;
+                if (fx != f_out) bad = 11;
                 break;
             }
             if (++steps > MAX_WALK_STEPS) { bad = 12; break; }
-            e = back;
             c = nb;
             cur = nxt;
+            A = A2; B = B2; C = C2;
+            Uc = U; Vc = V; Wc = W;
         }
         if (!bad && nhits > M - 1) bad = 9;  // overflow: the BVH path keeps the M-1 nearest
         if (bad) {
