@@ -4,9 +4,10 @@
 // f0 < f1 < ... < fn in which consecutive faces bound the tetrahedron between them.  Instead
 // of collecting all hits through a BVH and sorting them (the reference's structure,
 // src/optix/optix_trace_rays.cu:268-331 + :78-108), a lane walks the chain: find the two hull
-// faces the ray's line crosses, then step tet -> neighbour tet through 128-byte per-tet
-// records, producing the faces already in order.  Per step: one dependent 128-B line, 4 vertex
-// shears, 6 edge functions (shared by the 4 faces: E(P,Q) == -E(Q,P) bitwise), one (t,u,v).
+// faces the ray's line crosses, then step tet -> neighbour tet through 64-byte records specialised
+// by entry face (WalkVar, tn_common.h), producing the faces already in order.  Per step: one
+// dependent 64-B record, ONE vertex shear, three edge functions against the carried entry face to
+// pick the exit, the exit face's three edge functions in its stored order, one (t,u,v).
 //
 // Parity by construction: every (t,u,v) is computed by the same expression tree, in the face's
 // STORED vertex order, as the general path / the oracle (tri_finish in tn_device.h); the
