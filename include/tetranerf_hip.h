@@ -182,7 +182,7 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *   "rewalk"  1 (default) = chains whose order the walk cannot certify are re-walked and paired literally,
  *             0 = every uncertified ray is re-traced through the BVH all-hits path;
  *             "rewalk_min" (default 4096): fewer such chains in a call also take the BVH path (decided on the device)
- *   "mode", "chunk_rays", "fill_blocks", "debug", "gdebug": launch-structure / ablation knobs (profiles/) */
+ *   "fill_blocks", "debug", "gdebug": ablation knobs (profiles/) */
 int tn_set_option(tn_tracer_t tracer, const char *name, int value);
 
 /* gather_uint32<T> / scatter_ema_uint32<T>              src/tetrahedra_tracer.cu:30-113,

@@ -55,17 +55,14 @@ struct tn_tracer {
     int device = 0;
     tn::DeviceMesh mesh;
     tn::HostMesh host;  // kept for tn_get_faces
-    static constexpr int kEvents = 4;
     tn::DevBuf<uint32_t> faces, face_tets, fallback_list, fallback_count, walk_n, rewalk_count;
     tn::DevBuf<uint4> rewalk_list;
     uint32_t rewalk_min = 4096;          // fewer uncertified chains than this per call: BVH re-trace instead
     bool rewalk = true;                  // re-walk chains with uncertified order instead of the BVH re-trace
     hipStream_t side = nullptr;          // tail-fill stream (overlaps the walk of the next chunk)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chunk[kEvents] = {};
-    size_t chunk_rays = 65536;           // rays per walk launch when pipelining
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
-    unsigned fill_blocks = 0;            // cap of the tail-fill grid (0 = default); throttle knob of mode 2
-    int mode = 1;                        // launch structure of the walk path (see tn_trace_rays)
+    unsigned fill_blocks = 0;            // cap of the tail-fill grid (0 = default 2 blocks per CU); ablation knob
     tn::DevBuf<tn::WalkVar> vars;
     tn::DevBuf<float> hull_nodes, hull_tris;
     tn::DevWideBvh bvh;
@@ -146,11 +143,6 @@ int tn_tracer_create(int device, tn_tracer_t *out) {
         TN_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
         TN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
         TN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
-        for (auto &e : t->ev_chunk) TN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        if (const char *c = std::getenv("TETRANERF_HIP_CHUNK_RAYS")) {
-            const long v = std::atol(c);
-            if (v >= 256) t->chunk_rays = (size_t)v;
-        }
         *out = t.release();
     });
 }
@@ -163,7 +155,6 @@ int tn_tracer_destroy(tn_tracer_t tracer) {
         if (tracer->side) (void)hipStreamDestroy(tracer->side);
         if (tracer->ev_fork) (void)hipEventDestroy(tracer->ev_fork);
         if (tracer->ev_join) (void)hipEventDestroy(tracer->ev_join);
-        for (auto e : tracer->ev_chunk) if (e) (void)hipEventDestroy(e);
         delete tracer;
     });
 }
@@ -280,29 +271,15 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                           t->mesh.n_hull > 0;
         t->last_walk = walk;
         if (walk) {
-            // 1. adjacency walk for every ray (segments + counts), in chunks on `stream`;
-            // 2. constant tails of each finished chunk on the tracer's side stream (pure HBM
-            //    streaming, overlaps the latency-bound walk of the next chunk);
-            // 3. general all-hits path on `stream` for the rays the walk could not certify.
+            // The walk writes segments + counts; k_fill_tails then streams the constant tails of all rows (calls
+            // below 8192 rays: the walk kernel writes its own tails).
             if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->rewalk_list.alloc(R); }
             TN_HIP(hipMemsetAsync(t->fallback_count.p, 0, sizeof(uint32_t), stream));
             TN_HIP(hipMemsetAsync(t->rewalk_count.p, 0, sizeof(uint32_t), stream));
-            // mode 0: one launch, the walk kernel writes its own tails; mode 1: walk launch, then one
-            // tail launch on the same stream; mode 2: chunked, tails on the side stream
-            const int mode = !t->dense_tails ? 1 : (R < 8192 ? 0 : t->mode);
-            const size_t chunk = mode == 2 ? t->chunk_rays : R;
-            const bool pipelined = mode == 2 && R > chunk;
-            if (pipelined) {
-                TN_HIP(hipEventRecord(t->ev_fork, stream));
-                TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
-            }
-            size_t k = 0;
-            for (size_t r0 = 0; r0 < R; r0 += chunk, ++k) {
-                const size_t n = R - r0 < chunk ? R - r0 : chunk;
+            const bool fused_tails = t->dense_tails && R < 8192;
+            {
                 tn::WalkParams w{};
-                w.t = make_params(t, n, M, origins + 3 * r0, directions + 3 * r0, num_visited + r0,
-                                  visited + r0 * M, bary + r0 * M * 6, dist + r0 * M * 2,
-                                  verts ? verts + r0 * M * 4 : nullptr);
+                w.t = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
                 w.vars = t->mesh.vars;
                 w.scene_max = t->mesh.bvh.scene_max;
                 w.hull_nodes = t->mesh.hull_nodes;
@@ -312,18 +289,11 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 w.fallback_count = t->fallback_count.p;
                 w.rewalk_list = t->rewalk ? t->rewalk_list.p : nullptr;
                 w.rewalk_count = t->rewalk_count.p;
-                w.walk_n = t->walk_n.p + r0;
-                w.ray_base = r0;
-                w.fused_tails = mode == 0 ? 1u : 0u;
+                w.walk_n = t->walk_n.p;
+                w.ray_base = 0;
+                w.fused_tails = fused_tails ? 1u : 0u;
                 w.debug = t->debug;
                 tn::launch_trace_walk(w, stream);
-                if (pipelined) {
-                    hipEvent_t ev = t->ev_chunk[k % tn_tracer::kEvents];
-                    TN_HIP(hipEventRecord(ev, stream));
-                    TN_HIP(hipStreamWaitEvent(t->side, ev, 0));
-                    tn::launch_fill_tails(n, M, w.walk_n, w.t.out_cells, w.t.out_bary, w.t.out_dist, w.t.out_verts,
-                                          t->side, t->fill_blocks);
-                }
             }
             p.ray_list = t->fallback_list.p;
             p.item_count = t->fallback_count.p;
@@ -352,23 +322,17 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 const tn::TraceParams q = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
                 tn::launch_postprocess_rows(q, t->rewalk_list.p, t->rewalk_count.p, R, st);
             };
-            if (mode == 1) {
-                launch_collect(stream);
-                launch_pairing(stream);
+            launch_collect(stream);
+            launch_pairing(stream);
+            if (fused_tails) {
+                tn::launch_trace_general(p, stream);
+            } else {
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
                 tn::launch_trace_general(p, t->side);
                 if (t->dense_tails) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream, t->fill_blocks);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
-            } else {
-                launch_collect(stream);
-                launch_pairing(stream);
-                tn::launch_trace_general(p, stream);
-                if (pipelined) {
-                    TN_HIP(hipEventRecord(t->ev_join, t->side));
-                    TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
-                }
             }
         } else {
             tn::launch_trace_general(p, stream);
@@ -505,12 +469,10 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && std::strcmp(name, "walk_min_rays") == 0) t->walk_min_rays = value < 0 ? 0 : (size_t)value;
         else if (name && std::strcmp(name, "debug") == 0) t->debug = (uint32_t)value;
         else if (name && std::strcmp(name, "gdebug") == 0) t->gdebug = (uint32_t)value;
-        else if (name && std::strcmp(name, "mode") == 0) t->mode = value;
         else if (name && std::strcmp(name, "dense_tails") == 0) t->dense_tails = value != 0;
         else if (name && std::strcmp(name, "rewalk") == 0) t->rewalk = value != 0;
         else if (name && std::strcmp(name, "rewalk_min") == 0) t->rewalk_min = value < 0 ? 0u : (uint32_t)value;
         else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
-        else if (name && std::strcmp(name, "chunk_rays") == 0) t->chunk_rays = value >= 256 ? (size_t)value : 256;
         else throw tn::Error(std::string("unknown option ") + (name ? name : "(null)"));
     });
 }
