@@ -94,3 +94,41 @@ def test_th_file_roundtrip(tmp_path):
     np.testing.assert_allclose(field[0].numpy(), colors[:, 3].float().numpy() * 2 / 255 - 1, atol=1e-6)
     with pytest.raises(RuntimeError, match="does not exist"):
         io.load_tetrahedra(tmp_path / "missing.th")
+
+
+@pytest.mark.parametrize("cfg", [(64, 0, False), (32, 32, False), (32, 32, True)])
+def test_render_reference_on_cpu(oracle, scenes, bottle, cfg):
+    """The plain-PyTorch statement of the model's evaluation forward (render.render_reference) runs end to end on
+    the CPU with the oracle as tracer: the reference's bottle mesh + ray generator, all three sampling schemes."""
+    S, S_fine, biased = cfg
+    pts, cells = bottle["vertices"], bottle["cells"]
+    o, d = scenes.pinhole_rays(64, 64)
+
+    class CpuTracer:
+        def __init__(self):
+            self.t = oracle.OracleTracer(use_bvh=True)
+            self.t.load_tetrahedra(pts, cells)
+
+        def trace_rays(self, o_, d_, M_):
+            return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in self.t.trace_rays(o_.numpy(), d_.numpy(), M_).items()}
+
+        def find_visited_cells(self, *a):
+            return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in self.t.find_visited_cells(*[x.numpy() for x in a]).items()}
+
+    def interp(vi, bc, f):
+        return torch.from_numpy(np.ascontiguousarray(oracle.interpolate_values(vi.numpy(), bc.numpy(), f.numpy())))
+
+    torch.manual_seed(0)
+    mlp = render.TetraMLP()
+    field = torch.randn(64, len(pts)) * 0.5
+    with torch.no_grad():
+        out = render.render_reference(CpuTracer(), interp, field, mlp, torch.from_numpy(o), torch.from_numpy(d), S, 256,
+                                      num_fine_samples=S_fine, biased=biased)
+    hit = out["ray_mask"]
+    assert int(hit.sum()) == 146                      # rays of the reference's generator that hit the bottle
+    assert torch.all(out["rgb"][~hit] == 1.0) and torch.all(out["accumulation"][~hit] == 0.0)
+    assert torch.all(out["depth"][~hit] == 1000.0)
+    acc = out["accumulation"][hit]
+    assert torch.all((acc > 0) & (acc <= 1.0 + 1e-5))
+    assert torch.all((out["rgb"] >= -1e-5) & (out["rgb"] <= 1.0 + 1e-5))
+    assert torch.all((out["depth"][hit] > 0.8) & (out["depth"][hit] < 1.3))   # the bottle sits ~1 from the eye
