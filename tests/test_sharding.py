@@ -87,3 +87,72 @@ def test_single_process_passthrough():
     assert torch.equal(sh.gather_rendered(x, 5)["rgb"], x["rgb"])
     assert sh.max_over_ranks(2.5) == 2.5
     assert sh.sum_over_ranks([1, 2]) == [1.0, 2.0]
+
+
+def _render_worker(rank, world, port, q):
+    """Each rank renders its contiguous slice of the frame with its own (replicated) mesh / field / MLP and the
+    slices are all-gathered in one collective -- the multi-GPU render flow, on CPU tensors with the oracle as
+    tracer."""
+    import numpy as np
+    import torch.distributed as dist
+
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = importlib.import_module("tetra-nerf_amd.sharding")
+        render = importlib.import_module("tetra-nerf_amd.render")
+        scenes = importlib.import_module("tetra-nerf_amd.scenes")
+        from oracle import tn_oracle
+
+        pts, cells = scenes.random_mesh(400, 5)
+        o, d = scenes.pinhole_rays(48, 31, eye=(0.5, 2.4, 0.6), lookat=(0.5, 0.5, 0.5))   # 1488 rays: uneven shards
+        ot = tn_oracle.OracleTracer(use_bvh=True)
+        ot.load_tetrahedra(pts, cells)
+
+        class Tracer:
+            def trace_rays(self, o_, d_, M_):
+                return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ot.trace_rays(o_.numpy(), d_.numpy(), M_).items()}
+
+            def find_visited_cells(self, *a):
+                return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ot.find_visited_cells(*[x.numpy() for x in a]).items()}
+
+        def interp(vi, bc, f):
+            return torch.from_numpy(np.ascontiguousarray(tn_oracle.interpolate_values(vi.numpy(), bc.numpy(), f.numpy())))
+
+        torch.manual_seed(0)   # replicated parameters, as DDP keeps them
+        mlp = render.TetraMLP()
+        field = torch.randn(64, len(pts)) * 0.5
+        to, td = torch.from_numpy(o), torch.from_numpy(d)
+        R = len(o)
+        lo, hi = sh.shard_range(R, rank, world)
+        with torch.no_grad():
+            local = render.render_reference(Tracer(), interp, field, mlp, to[lo:hi], td[lo:hi], 24, 128, num_fine_samples=8)
+            local = {k: (v.float()[:, None] if v.dim() == 1 else v) for k, v in local.items()}
+            full = sh.gather_rendered(local, R)
+            ok = True
+            if rank == 0:
+                ref = render.render_reference(Tracer(), interp, field, mlp, to, td, 24, 128, num_fine_samples=8)
+                for k in ("rgb", "accumulation", "depth"):
+                    ok = ok and torch.equal(full[k], ref[k])
+                ok = ok and torch.equal(full["ray_mask"][:, 0] > 0.5, ref["ray_mask"]) and int(ref["ray_mask"].sum()) > 200
+        q.put((rank, ok, hi - lo))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_render_equals_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_render_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert sum(n for _, _, n in res) == 48 * 31
