@@ -12,8 +12,13 @@ own frame (camera rotated per rank), no data-path collective; scaling = weak.
 
 Prints ONE JSON line on rank 0 (see the driver contract): metric/value = whole-job ray-tet
 intersections per second, plus `roofline` (dense-output HBM bytes of the dominant kernel over
-its HIP-event duration) and `cpu_baseline` (the CPU oracle's BVH path on a bounded sample of
-the same rays, all host cores).
+its HIP-event duration), `cpu_baseline` (the CPU oracle's BVH path, timing build -O3
+-march=native, on a bounded sample of the same rays, all host cores), and -- single-GPU runs --
+`configs`: the other sizes BASELINE.json names (C4 300k-tet frame and both 4096-ray training
+batches, C5 1M-tet 2^20-ray stress), each with ms, rays/s, intersections/s and its roofline
+fraction.  `sharded_render` (every N): the 800x800 frame rendered in ray shards over the N ranks
+and all-gathered as ONE RCCL collective (north_star's multi-GPU flow), with the time of the
+collective.
 """
 from __future__ import annotations
 
@@ -136,11 +141,89 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
                                    "fp32 accumulate; same 1e-5 parity tests; not the default"}}
 
 
+def trace_leg(tracer, o, d, M, reps):
+    """ms per trace_rays call (HIP events on the launch stream), intersections, path statistics."""
+    def run():
+        out = tracer.trace_rays(o, d, M)
+        k = out["num_visited_cells"]
+        del out
+        return k
+    inter = int(run().sum())
+    stats = tracer.trace_stats()
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    R = o.shape[0]
+    gbs = R * (28 + 52 * M) / (ms * 1e-3) / 1e9
+    return {"rays": R, "ms": ms, "rays_per_s": R / (ms * 1e-3), "intersections_per_s": inter / (ms * 1e-3),
+            "intersections": inter, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": gbs / HBM_PEAK_GBS}, "paths": stats}
+
+
+def config_legs(tn, scenes, dev, M):
+    """The other BASELINE.json sizes: C4 = 45,000 points seed 2 (~302k tets): the 800x800 frame and the
+    two 4096-ray training batches; C5 = 150,000 points seed 3 (~1.01M tets): 2^20 outside-in rays seed 4."""
+    out = {}
+    for cfg, npts, seed in (("C4", 45000, 2), ("C5", 150000, 3)):
+        pts, cells = scenes.random_mesh(npts, seed)
+        tr = tn.TetrahedraTracer(dev)
+        t0 = time.perf_counter()
+        tr.load_tetrahedra(torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev))
+        torch.cuda.synchronize()
+        load_s = time.perf_counter() - t0
+        sets = ((("C4_frame_800x800", frame_rays(scenes, 0, 800, 800), 5),
+                 ("C4_batch_4096_outside_in", scenes.outside_in_rays(4096, 1), 20),
+                 ("C4_batch_4096_inside_out", scenes.inside_out_rays(4096, 2), 20)) if cfg == "C4" else
+                (("C5_2^20_outside_in", scenes.outside_in_rays(1 << 20, 4), 3),))
+        for name, (o, d), reps in sets:
+            leg = trace_leg(tr, torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), M, reps)
+            leg.update(tets=int(len(cells)), load_tetrahedra_s=load_s)
+            out[name] = leg
+        del tr
+        torch.cuda.empty_cache()
+    return out
+
+
+def sharded_render_leg(tn, tracer, num_vertices, scenes, width, height, M, dev, reps=2, samples=256, chunk=65536):
+    """north_star's multi-GPU flow: every rank renders its contiguous slice of ONE 800x800 frame (replicated mesh /
+    field / MLP) and the rendered tiles are all-gathered as one RCCL collective.  Returns max-over-ranks times."""
+    render = importlib.import_module("tetra-nerf_amd.render")
+    sharding = importlib.import_module("tetra-nerf_amd.sharding")
+    torch.manual_seed(0)   # replicated parameters, as DDP keeps them
+    mlp = render.TetraMLP().to(dev)
+    field = ((torch.rand(64, num_vertices, device=dev) * 2 - 1) * 1e-4)
+    field[1:4] = torch.rand(3, num_vertices, device=dev) * 2 - 1
+    rd = render.TetraRenderer(tracer, field, mlp, samples, M, fused=True)
+    o, d = frame_rays(scenes, 0, width, height)   # the SAME frame on every rank
+    o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    sharding.render_sharded(rd.render, o, d, chunk=chunk)   # warm-up (RCCL communicator, allocator)
+    tot = {"render": 0.0, "all_gather": 0.0}
+    for _ in range(reps):
+        tm = {}
+        full = sharding.render_sharded(rd.render, o, d, chunk=chunk, timings=tm)
+        for k in tot:
+            tot[k] += tm[k] / reps
+    t_render = sharding.max_over_ranks(tot["render"], device=dev)
+    t_gather = sharding.max_over_ranks(tot["all_gather"], device=dev)
+    R = o.shape[0]
+    return {"rays": R, "hitting_rays": int(full["ray_mask"].sum()), "samples_per_ray": samples,
+            "ms_per_frame": (t_render + t_gather) * 1e3, "render_ms": t_render * 1e3, "all_gather_ms": t_gather * 1e3,
+            "rendered_rays_per_s": R / (t_render + t_gather),
+            "collective": "one all_gather_into_tensor of [rays/N, 6] f32 (rgb, accumulation, depth, mask) per frame",
+            "pass": "coarse only (uniform samples), fused MLP + composite"}
+
+
 def cpu_baseline(pts, cells, o, d, M, target_s=30.0):
     """Oracle (BVH all-hits + sort + pairing, OpenMP) on a bounded sample of the bench rays."""
     from oracle import tn_oracle
 
-    ot = tn_oracle.OracleTracer(use_bvh=True)
+    ot = tn_oracle.OracleTracer(use_bvh=True, fast=True)  # timing-only build: -O3 -march=native (SURVEY.md 8d)
     ot.load_tetrahedra(pts, cells)
     rng = np.random.default_rng(0)
     perm = rng.permutation(len(o))
@@ -158,7 +241,7 @@ def cpu_baseline(pts, cells, o, d, M, target_s=30.0):
     dt = time.perf_counter() - t0
     inter = int(res["num_visited_cells"].astype(np.int64).sum())
     return {"value": inter / dt, "unit": "ray-tet intersections/s", "cores": tn_oracle.num_threads(),
-            "kind": "port", "rays_per_s": n / dt,
+            "kind": "port", "rays_per_s": n / dt, "build": "gcc -O3 -march=native -fopenmp (timing build of oracle/tn_oracle.c)",
             "sample": f"{n} random rays of the same frame, M={M}, oracle BVH path, {dt:.1f} s"}
 
 
@@ -173,7 +256,8 @@ def main():
     ap.add_argument("--mesh-points", type=int, default=15000)
     ap.add_argument("--mesh-seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-render", action="store_true", help="skip the rendered-rays/s leg")
+    ap.add_argument("--no-render", action="store_true", help="skip the rendered-rays/s legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C4 / C5 legs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -267,6 +351,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, R, M),
+                "traffic_source": "committed rocprofv3 PMC passes of this command (profiles/traffic.json), not read in this run",
                 "kernel": "trace_rays launch (walk + general fallback)",
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
@@ -297,6 +382,23 @@ def main():
                                  "note": "non-reference option dense_tails=0: 28 B/ray + 52 B/segment; instruction-issue-bound walk"}
         if not args.no_render and world == 1:   # secondary legs: single-GPU runs only (rank 0 alone would hold the job)
             line["render"] = render_leg(tn, tracer, len(pts), o, d, M, dev)
+    # the sharded render: a collective leg, every rank takes part
+    shr = None
+    if not args.no_render:
+        shr = sharded_render_leg(tn, tracer, len(pts), scenes, args.width, args.height, M, dev)
+    if rank == 0:
+        if shr is not None:
+            shr["n_gpus"] = world
+            line["sharded_render"] = shr
+        if not args.no_configs and world == 1:
+            del tracer
+            torch.cuda.empty_cache()
+            line["configs"] = config_legs(tn, scenes, dev, M)
+            line["configs"]["C2_frame_800x800"] = {"rays": R, "ms": kern_ms, "rays_per_s": R / (kern_ms * 1e-3),
+                                                   "intersections_per_s": inter / (kern_ms * 1e-3), "intersections": inter,
+                                                   "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS},
+                                                   "paths": stats, "tets": int(len(cells)), "note": "the headline workload"}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(pts, cells, o_np, d_np, M)
         print(json.dumps(line), flush=True)

@@ -80,7 +80,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_triangle
  *   device programs                                      src/optix/optix_trace_rays_triangles.cu:50-115
  * the sorted all-hits list of each ray, without the pairing stage (not called by the model).
  * visited u32 [R,M] face ids; bary f32 [R,M,2] = (u,v); dist f32 [R,M] = t; verts u32 [R,M,3] = the face's
- * stored vertex triple.  Slots >= num_visited[r]: ids 0xFFFFFFFF, floats 0. */
+ * stored vertex triple.  Slots >= num_visited[r]: 0 in every array (the reference's torch::zeros defaults). */
 int tn_trace_rays_triangles(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_triangles,
                             const float *origins, const float *directions, uint32_t *num_visited,
                             uint32_t *visited, float *bary, float *dist, uint32_t *verts, void *stream);
@@ -156,19 +156,19 @@ int tn_postprocess_hits_tables(int device, size_t num_rays, uint32_t max_ray_tri
                                float *bary, float *dist, uint32_t *verts, void *stream);
 
 /* per-call statistics of the last tn_trace_rays on this tracer (host values; forces a
- * stream sync).  stats[0] = rays served by the adjacency walk, stats[1] = rays re-traced by
- * the general all-hits path, stats[2] = rays whose post-process ran the serial literal
- * branch, stats[3] = rays that overflowed M-1 hits. */
+ * stream sync).  stats[0] = rays certified by the adjacency walk, stats[1] = all other rays (literal pairing of
+ * their logged hits, or re-traced by the general all-hits path), stats[2] = rays whose post-process ran the serial
+ * literal branch, stats[3] = rays that overflowed M-1 hits. */
 int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]);
 
-/* diagnostic: why the adjacency walk handed rays of the last tn_trace_rays to the general path.
+/* diagnostic: why the adjacency walk did not certify rays of the last tn_trace_rays.
  * reasons[k], k = 1..12: 1 zero edge function / zero determinant on a hull face, 2 not exactly two
- * hull crossings, 3 equal hull distances, 4 entry face not in its tet, 5 zero edge function,
- * 6 not exactly two crossed faces in a tet, 7 non-increasing t, 8 two consecutive gaps < eps,
- * 9 more than M-1 faces, 10 invalid t after a valid one, 11 exit face mismatch, 12 step limit.
- * Reasons 7 / 8 / 10 concern only the ORDER of a sound chain: those rays are re-walked (raw hit list -> literal
- * sort + pairing) instead of re-traced through the BVH; reasons[13] = rays handled that way, reasons[14] =
- * re-walked chains that went to the BVH path after all. */
+ * hull crossings, 3 equal hull distances, 4 a vertex of a visited tet within rounding distance of the ray,
+ * 5 zero edge function, 6 not exactly two crossed faces in a tet, 7 a gap below eps / a tie / an inversion in t
+ * (the chain is sound, its order is not certified), 9 more than M-1 faces, 10 invalid t after a valid one,
+ * 11 exit face mismatch, 12 step limit (8: unused since round 2).
+ * Reason 7 rays keep their logged hits, which go through the literal sort + pairing (reasons[13] counts them);
+ * all others are re-traced through the BVH all-hits path. */
 int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
 
 /* knobs (also settable through the environment):
@@ -179,10 +179,12 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *   "dense_tails"  1 (default) = every slot of the [R,M] rows is written, as the reference does;
  *             0 = slots >= num_visited[r] of walked rows are left UNWRITTEN (non-reference: for callers
  *             that only read rows through num_visited, e.g. tn_find_matched_cells; saves ~88 % of the bytes)
- *   "rewalk"  1 (default) = chains whose order the walk cannot certify are re-walked and paired literally,
- *             0 = every uncertified ray is re-traced through the BVH all-hits path;
- *             "rewalk_min" (default 4096): fewer such chains in a call also take the BVH path (decided on the device)
- *   "fill_blocks", "debug", "gdebug": ablation knobs (profiles/) */
+ *   "literal" 1 (default) = rays whose order the walk cannot certify have their logged hits sorted and paired
+ *             literally; 0 = they are re-traced through the BVH all-hits path (ablation / cross-check)
+ *   "prefill" 1 = the tail slots no certified ray reaches are streamed beside the segment writer (default 0:
+ *             measured slower, the latency-bound segment writer crawls beside a saturating fill)
+ *   "log_cap_mb"  cap of the hit log (default 16384): larger calls are processed in ray chunks
+ *   "fill_blocks", "seg_blocks", "debug", "gdebug": ablation knobs (profiles/) */
 int tn_set_option(tn_tracer_t tracer, const char *name, int value);
 
 /* gather_uint32<T> / scatter_ema_uint32<T>              src/tetrahedra_tracer.cu:30-113,

@@ -32,10 +32,38 @@ def build(force: bool = False) -> Path:
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(str(build()))
-        _LIB.tno_bvh_build.restype = C.c_void_p
-        _LIB.tno_bvh_free.argtypes = [C.c_void_p]
+        _LIB = _declare(C.CDLL(str(build())))
     return _LIB
+
+
+def _declare(L):
+    L.tno_bvh_build.restype = C.c_void_p
+    L.tno_bvh_free.argtypes = [C.c_void_p]
+    return L
+
+
+_FAST = None
+
+
+def lib_fast():
+    """TIMING-ONLY build of the same source: -O3 -march=native (FMA contraction allowed, so NOT bit-exact and never
+    used as a checker) -- what bench.py's cpu_baseline leg times.  -march=native is only valid on
+    the machine that compiled it, so it is built at run time into the temp directory, not shipped in-tree."""
+    global _FAST
+    if _FAST is None:
+        import hashlib
+        import tempfile
+
+        src = _HERE / "tn_oracle.c"
+        tag = hashlib.sha1(src.read_bytes()).hexdigest()[:12]
+        so = Path(tempfile.gettempdir()) / f"libtn_oracle_fast_{tag}.so"
+        if not so.exists():
+            tmp = so.with_suffix(f".{os.getpid()}.tmp")
+            subprocess.run([os.environ.get("CC", "gcc"), "-O3", "-march=native", "-std=c11", "-fPIC", "-fopenmp",
+                            "-shared", "-o", str(tmp), str(src), "-lm"], check=True)
+            os.replace(tmp, so)
+        _FAST = _declare(C.CDLL(str(so)))
+    return _FAST
 
 
 def _p(a):
@@ -72,11 +100,12 @@ def build_faces(cells: np.ndarray):
 class OracleTracer:
     """Mirror of tetranerf_cpp_extension.TetrahedraTracer on numpy arrays."""
 
-    def __init__(self, use_bvh: bool = False, threads: int = 0):
+    def __init__(self, use_bvh: bool = False, threads: int = 0, fast: bool = False):
         self.use_bvh = use_bvh
         self.threads = threads
         self._bvh = None
         self.xyz = None
+        self._L = lib_fast() if fast else lib()   # fast: timing-only -O3 -march=native build (not bit-exact)
 
     def load_tetrahedra(self, xyz, cells):
         self.xyz = _f32(xyz).reshape(-1, 3)
@@ -84,12 +113,12 @@ class OracleTracer:
         self.faces, self.face_tets = build_faces(self.cells)
         self._free()
         if self.use_bvh:
-            self._bvh = C.c_void_p(lib().tno_bvh_build(
+            self._bvh = C.c_void_p(self._L.tno_bvh_build(
                 C.c_uint64(len(self.xyz)), _p(self.xyz), C.c_uint64(len(self.faces)), _p(self.faces)))
 
     def _free(self):
         if self._bvh is not None:
-            lib().tno_bvh_free(self._bvh)
+            self._L.tno_bvh_free(self._bvh)
             self._bvh = None
 
     def __del__(self):
@@ -116,7 +145,7 @@ class OracleTracer:
         if with_raw:
             raw = {"count": np.zeros(R, np.uint32), "ids": np.zeros((R, M), np.uint32),
                    "t": np.zeros((R, M), np.float32), "uv": np.zeros((R, M, 2), np.float32)}
-        rc = lib().tno_trace_rays(
+        rc = self._L.tno_trace_rays(
             C.c_uint64(len(self.xyz)), _p(self.xyz), C.c_uint64(len(self.faces)), _p(self.faces),
             _p(self.face_tets), self._bvh, C.c_uint64(R), C.c_uint32(M), _p(o), _p(d),
             _p(out["num_visited_cells"]), _p(out["visited_cells"]), _p(out["barycentric_coordinates"]),
@@ -133,8 +162,10 @@ class OracleTracer:
     def trace_rays_triangles(self, origins, directions, max_ray_triangles):
         """Sorted all-hits list (reference: trace_rays_triangles, py_binding.cpp:78-113)."""
         raw = self.trace_rays(origins, directions, max_ray_triangles, with_raw=True)["raw"]
-        ids = raw["ids"]
-        v3 = np.where((ids != 0xFFFFFFFF)[..., None], self.faces[np.minimum(ids, len(self.faces) - 1).astype(np.int64)], 0xFFFFFFFF)
+        ids = raw["ids"].copy()
+        live = np.arange(ids.shape[1])[None, :] < raw["count"][:, None]
+        ids[~live] = 0  # slots >= count keep the zeros of the reference's torch::zeros outputs (py_binding.cpp:90-94)
+        v3 = np.where(live[..., None], self.faces[np.minimum(ids, len(self.faces) - 1).astype(np.int64)], 0)
         return {"num_visited_triangles": raw["count"].view(np.int32), "visited_triangles": ids.view(np.int32),
                 "barycentric_coordinates": raw["uv"], "hit_distances": raw["t"],
                 "vertex_indices": np.ascontiguousarray(v3.astype(np.uint32)).view(np.int32)}

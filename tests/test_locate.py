@@ -65,7 +65,7 @@ def test_triangles_on_ray_oracle(oracle, scenes, bottle):
         t = out["hit_distances"][r, :k]
         assert np.all(np.diff(t) >= 0)
         np.testing.assert_allclose(p, o[r] + t[:, None] * d[r], atol=5e-5)
-    assert np.all(out["visited_triangles"][np.arange(256)[None] >= n[:, None]] == -1)
+    assert np.all(out["visited_triangles"][np.arange(256)[None] >= n[:, None]] == 0)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,217 @@
+"""GPU parity at BASELINE.json's FULL sizes and on adversarial geometry, bit for bit against the CPU oracle.
+
+ * C2: the bench workload itself -- 99,899 tets, the whole 800x800 frame (640,000 rays) traced in ONE call at
+   M = 512, all five outputs including every tail byte;
+ * C4: 301,874 tets -- the 800x800 frame and both 4096-ray training batches (outside-in / inside-out);
+ * C5: 1,009,317 tets -- 2^20 outside-in rays traced in one call, 65,536 of them and a frame slice compared;
+ * adversarial meshes: the reference's bottle under a multi-view orbit + inside-out rays, an exact lattice and a
+   jittered one (cospherical points: Qhull slivers, zero-volume tets, exact ties in t), two thin shells,
+   near-duplicate points (edges of ~1e-7, far below the pairing stage's 1e-6 window), a COLMAP-like clustered
+   cloud with jittered copies (scripts/triangulate.py:36-55), and rays through pairs of mesh vertices;
+ * a seeded sample of the randomised stress script (profiles/stress_parity.py).
+
+The reference semantics under test: src/optix/optix_trace_rays.cu:110-266 (sort + dedupe/pairing + tail fill).
+Every comparison is on raw bits (`view(uint32)`); the tolerance of BASELINE.json (1e-5 on floats) is implied.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("num_visited_cells", "visited_cells", "vertex_indices", "hit_distances", "barycentric_coordinates")
+
+
+def _tracer(tn, device, pts, cells, walk=2, **opts):
+    import torch
+
+    tr = tn.TetrahedraTracer(device)
+    tr.set_option("walk", walk)
+    for k, v in opts.items():
+        tr.set_option(k, v)
+    tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+    return tr
+
+
+def _oracle(oracle, pts, cells):
+    ot = oracle.OracleTracer(use_bvh=True)
+    ot.load_tetrahedra(pts, cells)
+    return ot
+
+
+def _compare(out, ot, o, d, M, rows=None, chunk=65536, ctx=""):
+    """`out`: GPU result of ONE trace_rays call over (o, d); compared against the oracle in row chunks
+    (bounded host memory).  rows: optional index array -- only those rays are compared."""
+    import torch
+
+    idx = np.arange(len(o)) if rows is None else np.asarray(rows)
+    total = 0
+    for s in range(0, len(idx), chunk):
+        sel = idx[s:s + chunk]
+        want = ot.trace_rays(o[sel], d[sel], M)
+        contiguous = rows is None
+        tsel = None if contiguous else torch.from_numpy(sel).to(out[KEYS[0]].device)
+        for k in KEYS:
+            g = out[k][s:s + chunk] if contiguous else out[k].index_select(0, tsel)
+            g = g.cpu().numpy()
+            w = np.ascontiguousarray(want[k])
+            if not np.array_equal(g.view(np.uint32), w.view(np.uint32)):
+                bad = np.nonzero((g.view(np.uint32) != w.view(np.uint32)).reshape(len(sel), -1).any(1))[0]
+                raise AssertionError(f"{ctx}: {k} differs from the oracle on {len(bad)} rays of chunk {s} "
+                                     f"(first: ray {sel[bad[0]]}, oracle n={want['num_visited_cells'][bad[0]]})")
+        total += int(want["num_visited_cells"].astype(np.int64).sum())
+    return total
+
+
+def _trace(tr, device, o, d, M):
+    import torch
+
+    return tr.trace_rays(torch.from_numpy(o).to(device), torch.from_numpy(d).to(device), M)
+
+
+def _frame(scenes, width=800, height=800):
+    c = np.array([0.5, 0.5, 0.5], np.float32)
+    return scenes.pinhole_rays(width, height, eye=tuple(c + np.array([0.0, 2.0, 0.0], np.float32)), lookat=tuple(c),
+                               up=(0.0, 0.0, 1.0), fov_y=45.0)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs
+def test_c2_full_bench_frame_bit_exact(tn, device, oracle, scenes):
+    """configs[1]: the exact bench.py workload, all 640,000 rays, M = 512, default path selection."""
+    pts, cells = scenes.random_mesh(15000, 0)
+    o, d = _frame(scenes)
+    tr = _tracer(tn, device, pts, cells, walk=1)
+    out = _trace(tr, device, o, d, 512)
+    st = tr.trace_stats()
+    assert st["walk"] > 0.97 * len(o), st
+    total = _compare(out, _oracle(oracle, pts, cells), o, d, 512, ctx="C2 frame")
+    assert total == int(out["num_visited_cells"].sum()) and total > 25_000_000
+
+
+def test_c4_frame_and_training_batches_bit_exact(tn, device, oracle, scenes):
+    """configs[3]: 300k-tet stand-in; the 800x800 frame and the two 4096-ray batches (default small-batch path AND
+    the walk forced onto them)."""
+    pts, cells = scenes.random_mesh(45000, 2)
+    assert len(cells) > 300_000
+    ot = _oracle(oracle, pts, cells)
+    tr = _tracer(tn, device, pts, cells, walk=1)
+    o, d = _frame(scenes)
+    out = _trace(tr, device, o, d, 512)
+    st = tr.trace_stats()
+    assert st["walk"] > 0.93 * len(o), st
+    _compare(out, ot, o, d, 512, ctx="C4 frame")
+    del out
+    for name, (bo, bd) in (("outside-in", scenes.outside_in_rays(4096, 1)), ("inside-out", scenes.inside_out_rays(4096, 2))):
+        for walk in (1, 2):
+            tr.set_option("walk", walk)
+            _compare(_trace(tr, device, bo, bd, 512), ot, bo, bd, 512, ctx=f"C4 {name} walk={walk}")
+
+
+def test_c5_stress_sample_bit_exact(tn, device, oracle, scenes):
+    """configs[4]: 1M tets; all 2^20 outside-in rays traced in one call (28 GB of rows), 65,536 of them compared
+    (the first 32,768 and a random 32,768), plus 64 rows of the 800x800 frame."""
+    pts, cells = scenes.random_mesh(150000, 3)
+    assert len(cells) > 1_000_000
+    ot = _oracle(oracle, pts, cells)
+    tr = _tracer(tn, device, pts, cells, walk=1)
+    o, d = scenes.outside_in_rays(1 << 20, 4)
+    out = _trace(tr, device, o, d, 512)
+    st = tr.trace_stats()
+    assert st["walk"] + st["general"] == len(o) and st["walk"] > 0.8 * len(o), st
+    rows = np.concatenate([np.arange(32768), np.sort(np.random.default_rng(9).choice(np.arange(32768, 1 << 20), 32768, replace=False))])
+    _compare(out, ot, o, d, 512, rows=rows, chunk=32768, ctx="C5 2^20 rays")
+    del out
+    fo, fd = _frame(scenes)
+    sl = slice(368 * 800, 432 * 800)  # 64 image rows through the middle of the frame (51,200 rays)
+    fo, fd = np.ascontiguousarray(fo[sl]), np.ascontiguousarray(fd[sl])
+    _compare(_trace(tr, device, fo, fd, 512), ot, fo, fd, 512, ctx="C5 frame slice")
+
+
+# ------------------------------------------------------------------------------------------------ adversarial geometry
+def _ray_sets(scenes, pts, n_random, seed, lo, hi):
+    """camera orbit + outside-in + inside-out + vertex-to-vertex rays scaled to the mesh's bounding box."""
+    c = 0.5 * (lo + hi)
+    ext = float(np.max(hi - lo))
+    sets = {"orbit": scenes.orbit_rays(160, 160, 6, center=tuple(c), radius=1.6 * ext)}
+    o, d = scenes.outside_in_rays(n_random, seed)
+    sets["outside_in"] = (np.ascontiguousarray(((o - 0.5) * ext + c).astype(np.float32)), d)
+    o, d = scenes.inside_out_rays(n_random, seed + 1)
+    sets["inside_out"] = (np.ascontiguousarray(((o - 0.5) * ext + c).astype(np.float32)), d)
+    sets["vertex_to_vertex"] = scenes.vertex_to_vertex_rays(pts, n_random // 2, seed + 2, extend=1.2 * ext)
+    return sets
+
+
+ADVERSARIAL = {
+    "lattice_exact": lambda sc: sc.grid_mesh(12, 0.0),
+    "lattice_jittered": lambda sc: sc.grid_mesh(16, 1e-6),
+    "thin_shells": lambda sc: sc.shells_mesh(),
+    "near_duplicates": lambda sc: sc.near_duplicates_mesh(),
+    "colmap_like": lambda sc: sc.colmap_like_mesh(),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ADVERSARIAL))
+def test_adversarial_meshes_bit_exact(tn, device, oracle, scenes, name):
+    pts, cells = ADVERSARIAL[name](scenes)
+    ot = _oracle(oracle, pts, cells)
+    flagged = {}
+    for walk, extra in ((2, {}), (2, {"prefill": 1}), (0, {})):
+        tr = _tracer(tn, device, pts, cells, walk=walk, **extra)
+        for sname, (o, d) in _ray_sets(scenes, pts, 20000, 40, pts.min(0), pts.max(0)).items():
+            out = _trace(tr, device, o, d, 512)
+            _compare(out, ot, o, d, 512, ctx=f"{name}/{sname} walk={walk} {extra}")
+            if walk:
+                st = tr.trace_stats()
+                assert st["walk"] + st["general"] == len(o), st
+                for k, v in tr.flag_reasons().items():
+                    flagged[k] = flagged.get(k, 0) + v
+    # the point of these meshes: the walk's certification has to REJECT rays here (ties, zero edge functions,
+    # uncertified order), and what it rejects must come out right through the re-walk / BVH paths
+    assert sum(flagged.values()) > 0, f"{name}: the walk certified every ray -- not adversarial"
+    if name in ("lattice_exact", "near_duplicates"):
+        assert any(k in flagged for k in (1, 4, 5, 6)) and 7 in flagged, flagged
+
+
+def test_bottle_orbit_and_inside_out_bit_exact(tn, device, oracle, scenes, bottle):
+    """The reference's test asset (375 zero-volume tets) seen from a 512x512 multi-view orbit, from inside, and along
+    vertex-to-vertex lines (the reference's own test uses one 64x64 view of which 146 rays hit)."""
+    pts, cells = bottle["vertices"], bottle["cells"]
+    ot = _oracle(oracle, pts, cells)
+    lo, hi = pts.min(0), pts.max(0)
+    c, ext = 0.5 * (lo + hi), float(np.max(hi - lo))
+    sets = {"orbit512": scenes.orbit_rays(512, 512, 4, center=tuple(c), radius=1.2 * ext, fov_y=50.0)}
+    o, d = scenes.inside_out_rays(60000, 50)
+    sets["inside_out"] = (np.ascontiguousarray((c + (o - 0.5) * 0.6 * (hi - lo)).astype(np.float32)), d)
+    sets["vertex_to_vertex"] = scenes.vertex_to_vertex_rays(pts, 30000, 51, extend=0.7 * ext)
+    hits = 0
+    flagged = 0
+    for walk in (2, 0):
+        tr = _tracer(tn, device, pts, cells, walk=walk)
+        for sname, (ro, rd) in sets.items():
+            out = _trace(tr, device, ro, rd, 256)
+            hits += _compare(out, ot, ro, rd, 256, ctx=f"bottle/{sname} walk={walk}")
+            if walk:
+                flagged += sum(tr.flag_reasons().values())
+    assert hits > 5_000_000 and flagged > 0
+
+
+# ------------------------------------------------------------------------------------------------ randomised stress
+def test_randomised_stress_sample(tn, device, oracle, scenes):
+    """Seeded sample of profiles/stress_parity.py: random mesh sizes / ray sets / M / re-walk thresholds."""
+    rng = np.random.default_rng(2024)
+    for case in range(6):
+        npts = int(rng.choice([300, 1500, 5000, 20000, 60000]))
+        seed = int(rng.integers(0, 10_000))
+        M = int(rng.choice([64, 256, 512]))
+        kind = int(rng.integers(0, 3))
+        R = int(rng.choice([20000, 70000]))
+        pts, cells = scenes.random_mesh(npts, seed)
+        if kind == 0:
+            o, d = scenes.outside_in_rays(R, seed + 1)
+        elif kind == 1:
+            o, d = scenes.inside_out_rays(R, seed + 2)
+        else:
+            w = int(np.sqrt(R))
+            o, d = scenes.pinhole_rays(w, w, eye=(0.5 + 1.7 * np.cos(seed), 0.5 + 1.7 * np.sin(seed), 0.6), lookat=(0.5, 0.5, 0.5))
+        tr = _tracer(tn, device, pts, cells, walk=2, prefill=int(rng.choice([0, 1])))
+        _compare(_trace(tr, device, o, d, M), _oracle(oracle, pts, cells), o, d, M,
+                 ctx=f"stress case {case}: npts={npts} seed={seed} M={M} kind={kind}")

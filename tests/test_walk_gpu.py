@@ -152,32 +152,50 @@ def test_dense_tails_off_keeps_the_valid_prefix(tn, device, scenes):
         assert torch.equal(m1[k], m2[k]), k
 
 
-def test_rewalk_equals_bvh_fallback(tn, device, oracle, scenes):
-    """Chains whose ORDER the walk cannot certify are re-walked (raw hit list -> literal sort + pairing) instead
-    of re-traced through the BVH: both fallbacks, and the oracle, must agree bit for bit -- on a mesh / ray set
-    dense enough that hundreds of rays take that route."""
+def test_literal_pairing_of_the_log_equals_bvh_fallback(tn, device, oracle, scenes):
+    """Chains whose ORDER the walk cannot certify (a gap below eps, a tie, an inversion) are not re-traced through the
+    BVH: their logged hits go through the literal sort + pairing.  That route, the BVH route (option literal = 0),
+    the variant with the tail prefill and the oracle must agree bit for bit -- on a mesh / ray set dense enough
+    that hundreds of rays take it."""
     import torch
 
     pts, cells = scenes.random_mesh(20000, 11)
     o, d = scenes.outside_in_rays(120000, 12)
     tr = _tracer(tn, device, pts, cells, 1)
-    tr.set_option("rewalk_min", 0)   # default: fewer than 4096 such chains per call take the BVH path
     a = _trace(tr, device, o, d, 512)
     reasons = tr.flag_reasons()
-    assert reasons.get(13, 0) > 100, reasons
+    assert reasons.get(13, 0) > 100 and reasons.get(13, 0) == reasons.get(7, 0), reasons
     st = tr.trace_stats()
     assert st["walk"] + st["general"] == len(o)
-    tr.set_option("rewalk", 0)
+    tr.set_option("literal", 0)
     b = _trace(tr, device, o, d, 512)
     assert 13 not in tr.flag_reasons()
+    tr.set_option("literal", 1)
+    tr.set_option("prefill", 1)
+    c = _trace(tr, device, o, d, 512)
     for k in KEYS:
         assert _bits_equal(a[k], b[k]), k
-    # and against the oracle on a slice that contains re-walked rays
+        assert _bits_equal(a[k], c[k]), k
+    # and against the oracle on a slice that contains such rays
     ot = oracle.OracleTracer(use_bvh=True)
     ot.load_tetrahedra(pts, cells)
     want = ot.trace_rays(o[:30000], d[:30000], 512)
     for k in KEYS:
         assert _bits_equal(a[k][:30000], want[k]), k
+
+
+def test_chunked_log_equals_single_launch(tn, device, scenes):
+    """Calls whose hit log would exceed the cap are walked and written in ray chunks: same bits."""
+    pts, cells = scenes.random_mesh(6000, 13)
+    o, d = scenes.outside_in_rays(50000, 14)
+    tr = _tracer(tn, device, pts, cells, 1)
+    a = _trace(tr, device, o, d, 256)
+    tr.set_option("log_cap_mb", 48)   # 4096-ray chunks at M = 256 need 16 MB each: 12288 rays per chunk
+    b = _trace(tr, device, o, d, 256)
+    for k in KEYS:
+        assert _bits_equal(a[k], b[k]), k
+    st = tr.trace_stats()
+    assert st["walk"] + st["general"] == len(o) and st["walk"] > 0.8 * len(o), st
 
 
 def test_find_visited_cells_ray_index(tn, device, scenes):

@@ -55,18 +55,26 @@ struct tn_tracer {
     int device = 0;
     tn::DeviceMesh mesh;
     tn::HostMesh host;  // kept for tn_get_faces
-    tn::DevBuf<uint32_t> faces, face_tets, fallback_list, fallback_count, walk_n, rewalk_count;
-    tn::DevBuf<uint4> rewalk_list;
-    uint32_t rewalk_min = 4096;          // fewer uncertified chains than this per call: BVH re-trace instead
-    bool rewalk = true;                  // re-walk chains with uncertified order instead of the BVH re-trace
-    hipStream_t side = nullptr;          // tail-fill stream (overlaps the walk of the next chunk)
+    tn::DevBuf<uint32_t> faces, face_tets, fallback_list, walk_n;
+    tn::DevBuf<uint2> literal_list;      // rays whose logged hits go through the literal sort + pairing
+    tn::DevBuf<uint4> hit_log;           // walk -> segment writer / literal pairing: 16 B per recorded hit, [rays / 64][M][64]
+    size_t log_cap_bytes = (size_t)16 << 30;  // larger calls are walked + written in ray chunks
+    bool literal = true;                 // false: rays with uncertified order are re-traced through the BVH instead (ablation)
+    bool prefill = false;                // stream the tail slots no certified ray reaches beside the segment writer (measured
+                                         // slower: the latency-bound segment writer crawls beside a saturating fill)
+    hipStream_t side = nullptr;          // second stream: tail prefill, literal pairing, BVH re-trace
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
     unsigned fill_blocks = 0;            // cap of the tail-fill grid (0 = default 2 blocks per CU); ablation knob
+    unsigned seg_blocks = 0;             // cap of the segment-writer grid (0 = default 7 blocks per CU); ablation knob
     tn::DevBuf<tn::WalkVar> vars;
     tn::DevBuf<float> hull_nodes, hull_tris;
     tn::DevWideBvh bvh;
-    tn::DevBuf<unsigned long long> stats;
+    tn::DevBuf<unsigned long long> stats;   // [24] counters of the last call + [24..26) three uint32: fallback count,
+                                            // literal count, kmax (one memset clears them all)
+    uint32_t *fallback_count() { return reinterpret_cast<uint32_t *>(stats.p + 24); }
+    uint32_t *literal_count() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 1; }
+    uint32_t *kmax() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 2; }
     size_t last_num_rays = 0;
     int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
     size_t walk_min_rays = 16384;
@@ -136,11 +144,15 @@ int tn_tracer_create(int device, tn_tracer_t *out) {
         auto t = std::make_unique<tn_tracer>();
         t->device = device;
         t->use_walk = env_flag("TETRANERF_HIP_WALK", true) ? 1 : 0;
-        t->stats.alloc(24);
-        TN_HIP(hipMemset(t->stats.p, 0, 24 * sizeof(unsigned long long)));
-        t->fallback_count.alloc(1);
-        t->rewalk_count.alloc(1);
-        TN_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+        t->stats.alloc(26);
+        TN_HIP(hipMemset(t->stats.p, 0, 26 * sizeof(unsigned long long)));
+        {
+            // the side stream carries the few rays the walk does not certify: lowest priority, so that the dispatcher
+            // hands wave slots to the main stream's kernels first when both have blocks waiting
+            int least = 0, greatest = 0;
+            TN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            TN_HIP(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, least));
+        }
         TN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
         TN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
         *out = t.release();
@@ -191,6 +203,9 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         }
         tn::HostWideBvh hb;
         tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), all, hb);
+        if (hb.max_stack > (uint32_t)tn::STACK_CAP)
+            throw tn::Error("face BVH too deep for the traversal stack (" + std::to_string(hb.max_stack) + " > " +
+                            std::to_string(tn::STACK_CAP) + " entries)");
         std::vector<tn::TetRec> recs;
         std::vector<uint32_t> rec_of_tet;
         tn::build_tet_records(T, hcells.data(), hxyz.data(), t->host, recs, rec_of_tet);
@@ -262,7 +277,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
         hipStream_t stream = (hipStream_t)stream_;
         t->last_stream = stream;
         t->last_num_rays = R;
-        TN_HIP(hipMemsetAsync(t->stats.p, 0, 24 * sizeof(unsigned long long), stream));
+        TN_HIP(hipMemsetAsync(t->stats.p, 0, 26 * sizeof(unsigned long long), stream));
         tn::TraceParams p = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
         // Small batches are latency-bound: a lane walking ~180 dependent steps is slower than one
         // wavefront per ray through the wide BVH (measured: 4096 rays, 300k tets: 1.5 ms vs 0.75 ms),
@@ -271,68 +286,90 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                           t->mesh.n_hull > 0;
         t->last_walk = walk;
         if (walk) {
-            // The walk writes segments + counts; k_fill_tails then streams the constant tails of all rows (calls
-            // below 8192 rays: the walk kernel writes its own tails).
-            if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->rewalk_list.alloc(R); }
-            TN_HIP(hipMemsetAsync(t->fallback_count.p, 0, sizeof(uint32_t), stream));
-            TN_HIP(hipMemsetAsync(t->rewalk_count.p, 0, sizeof(uint32_t), stream));
-            const bool fused_tails = t->dense_tails && R < 8192;
-            {
+            // main stream: walk (hits -> log; classes; K) -> segment writer -> tails [ceil32(n), K) of the certified rows
+            // side stream: tails [K, M) of all rows -> literal pairing of the logged hits -> BVH re-trace of the rest
+            // The side stream needs only the walk: its bandwidth-bound fill runs beside the latency-bound segment
+            // writer, and the few literal / fallback rays (whole rows, written after the prefill of the same stream)
+            // ride beside the second fill.  The log holds 16 B per hit slot; calls whose log would exceed
+            // `log_cap_bytes` are processed in ray chunks (multiples of 4096 rays, the walk's XCD run), serially.
+            if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); }
+            size_t chunk = t->log_cap_bytes / ((size_t)M * sizeof(uint4));
+            chunk = chunk / 4096 * 4096;
+            if (chunk < 4096) chunk = 4096;
+            if (chunk > R) chunk = R;
+            const size_t log_entries = (chunk + 255) / 256 * 256 * (size_t)M;
+            if (t->hit_log.n < log_entries) t->hit_log.alloc(log_entries);
+            const bool single = chunk >= R;
+            auto chunk_params = [&](size_t base, size_t n) {
+                return make_params(t, n, M, origins + 3 * base, directions + 3 * base, num_visited + base, visited + base * M,
+                                   bary + base * M * 6, dist + base * M * 2, verts ? verts + base * M * 4 : nullptr);
+            };
+            auto launch_walk = [&](size_t base, size_t n) {
                 tn::WalkParams w{};
-                w.t = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
+                w.t = chunk_params(base, n);
                 w.vars = t->mesh.vars;
                 w.scene_max = t->mesh.bvh.scene_max;
                 w.hull_nodes = t->mesh.hull_nodes;
                 w.hull_tris = t->mesh.hull_tris;
                 w.n_hull_nodes = t->mesh.n_hull_nodes;
                 w.fallback_list = t->fallback_list.p;
-                w.fallback_count = t->fallback_count.p;
-                w.rewalk_list = t->rewalk ? t->rewalk_list.p : nullptr;
-                w.rewalk_count = t->rewalk_count.p;
-                w.walk_n = t->walk_n.p;
-                w.ray_base = 0;
-                w.fused_tails = fused_tails ? 1u : 0u;
+                w.fallback_count = t->fallback_count();
+                w.literal_list = t->literal ? t->literal_list.p : nullptr;
+                w.literal_count = t->literal_count();
+                w.kmax = t->kmax();
+                w.walk_n = t->walk_n.p + base;
+                w.hit_log = t->hit_log.p;
+                w.ray_base = base;
                 w.debug = t->debug;
                 tn::launch_trace_walk(w, stream);
-            }
+            };
+            auto launch_segments = [&](size_t base, size_t n, hipStream_t st) {
+                tn::WriteParams q{};
+                q.num_rays = n; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
+                q.walk_n = t->walk_n.p + base;
+                q.hit_log = t->hit_log.p;
+                q.vars = t->mesh.vars;
+                q.out_cells = visited + base * M;
+                q.out_bary = bary + base * M * 6;
+                q.out_dist = dist + base * M * 2;
+                q.out_verts = verts ? verts + base * M * 4 : nullptr;
+                tn::launch_write_segments(q, st, t->seg_blocks);
+            };
+            auto launch_fill = [&](size_t base, size_t n, bool all_rows, const uint32_t *kmax, hipStream_t st) {
+                if (!t->dense_tails) return;
+                tn::launch_fill_range(n, M, all_rows, kmax, t->walk_n.p + base, num_visited + base, visited + base * M, bary + base * M * 6,
+                                      dist + base * M * 2, verts ? verts + base * M * 4 : nullptr, st, t->fill_blocks);
+            };
+            auto launch_literal = [&](size_t base, size_t n, hipStream_t st) {
+                if (!t->literal) return;
+                tn::launch_postprocess_log(chunk_params(base, n), t->mesh.vars, t->hit_log.p, t->literal_list.p, t->literal_count(),
+                                           n, st);
+            };
             p.ray_list = t->fallback_list.p;
-            p.item_count = t->fallback_count.p;
-            // the rays the walk did not certify: re-walk + literal pairing of the sound chains, then the BVH
-            // all-hits kernel for the rest (the re-walk may still append to its list)
-            // Everything that runs beside the saturating tail fill crawls (measured: re-walk 12 us per step
-            // instead of ~1; literal pairing of 10.7k lists 3.6 ms instead of 0.7), so the re-walk and the pairing
-            // of its lists run ALONE on `stream` between the walk and the fill.  Only the BVH re-trace of the
-            // (few) remaining rays overlaps the fill on the side stream: it is short next to the fill, and when
-            // there are many uncertified chains (>= rewalk_min) they have gone through the re-walk instead.
-            auto launch_collect = [&](hipStream_t st) {
-                if (!t->rewalk) return;
-                tn::WalkParams w{};
-                w.t = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
-                w.vars = t->mesh.vars;
-                w.hull_tris = t->mesh.hull_tris;
-                w.fallback_list = t->fallback_list.p;
-                w.fallback_count = t->fallback_count.p;
-                w.rewalk_list = t->rewalk_list.p;
-                w.rewalk_count = t->rewalk_count.p;
-                w.rewalk_min = t->rewalk_min;
-                tn::launch_walk_collect(w, R, st);
-            };
-            auto launch_pairing = [&](hipStream_t st) {
-                if (!t->rewalk) return;
-                const tn::TraceParams q = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
-                tn::launch_postprocess_rows(q, t->rewalk_list.p, t->rewalk_count.p, R, st);
-            };
-            launch_collect(stream);
-            launch_pairing(stream);
-            if (fused_tails) {
-                tn::launch_trace_general(p, stream);
-            } else {
+            p.item_count = t->fallback_count();
+            if (single) {
+                launch_walk(0, R);
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
+                // the segment writer is enqueued BEFORE the side stream's kernels: their grids are sized for the worst
+                // case (the counts live on the device) and would otherwise take every wave slot first
+                launch_segments(0, R, stream);
+                if (t->prefill) launch_fill(0, R, true, t->kmax(), t->side);
+                launch_literal(0, R, t->side);
                 tn::launch_trace_general(p, t->side);
-                if (t->dense_tails) tn::launch_fill_tails(R, M, t->walk_n.p, visited, bary, dist, verts, stream, t->fill_blocks);
+                launch_fill(0, R, false, t->prefill ? t->kmax() : nullptr, stream);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
+            } else {
+                for (size_t base = 0; base < R; base += chunk) {
+                    const size_t n = R - base < chunk ? R - base : chunk;
+                    TN_HIP(hipMemsetAsync(t->literal_count(), 0, sizeof(uint32_t), stream));
+                    launch_walk(base, n);
+                    launch_segments(base, n, stream);
+                    launch_fill(base, n, false, nullptr, stream);
+                    launch_literal(base, n, stream);   // before the next chunk's walk reuses the log
+                }
+                tn::launch_trace_general(p, stream);
             }
         } else {
             tn::launch_trace_general(p, stream);
@@ -438,10 +475,10 @@ int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]) {
         TN_HIP(hipMemcpy(h, t->stats.p, sizeof h, hipMemcpyDeviceToHost));
         for (int i = 0; i < 4; ++i) stats[i] = h[i];
         if (t->last_walk) {
-            uint32_t fb = 0, rw = 0;  // not certified by the walk: BVH re-trace + re-walked chains
-            TN_HIP(hipMemcpy(&fb, t->fallback_count.p, sizeof fb, hipMemcpyDeviceToHost));
-            TN_HIP(hipMemcpy(&rw, t->rewalk_count.p, sizeof rw, hipMemcpyDeviceToHost));
-            fb += rw - (uint32_t)h[4 + 14];  // chains the re-walk handed on are in both counts
+            // not certified by the walk: literal pairing of the logged hits (h[4 + 13]) + BVH re-trace
+            uint32_t fb = 0;
+            TN_HIP(hipMemcpy(&fb, t->fallback_count(), sizeof fb, hipMemcpyDeviceToHost));
+            fb += (uint32_t)h[4 + 13];
             stats[1] = fb;
             stats[0] = t->last_num_rays - fb;
         } else {
@@ -470,10 +507,32 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && std::strcmp(name, "debug") == 0) t->debug = (uint32_t)value;
         else if (name && std::strcmp(name, "gdebug") == 0) t->gdebug = (uint32_t)value;
         else if (name && std::strcmp(name, "dense_tails") == 0) t->dense_tails = value != 0;
-        else if (name && std::strcmp(name, "rewalk") == 0) t->rewalk = value != 0;
-        else if (name && std::strcmp(name, "rewalk_min") == 0) t->rewalk_min = value < 0 ? 0u : (uint32_t)value;
+        else if (name && std::strcmp(name, "literal") == 0) t->literal = value != 0;
+        else if (name && std::strcmp(name, "prefill") == 0) t->prefill = value != 0;
+        else if (name && (std::strcmp(name, "rewalk") == 0 || std::strcmp(name, "rewalk_min") == 0)) {}  // round-1 knobs: no effect
         else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
+        else if (name && std::strcmp(name, "seg_blocks") == 0) t->seg_blocks = (unsigned)value;
+        else if (name && std::strcmp(name, "log_cap_mb") == 0) t->log_cap_bytes = (size_t)(value < 1 ? 1 : value) << 20;
         else throw tn::Error(std::string("unknown option ") + (name ? name : "(null)"));
+    });
+}
+
+/* probes (profiles/): a stream restricted to the compute units [first_cu, first_cu + num_cus) of the logical CU
+ * numbering (bit i of the mask = XCD i % 8, so a contiguous range is spread evenly over the XCDs), and a pure
+ * write stream with a selectable store flavour.  Not part of the drop-in surface. */
+int tn_probe_stream_create(int first_cu, int num_cus, void **out) {
+    return guarded([&] {
+        uint32_t mask[16] = {0};
+        for (int i = first_cu; i < first_cu + num_cus && i < 512; ++i) mask[i / 32] |= 1u << (i % 32);
+        hipStream_t s = nullptr;
+        TN_HIP(hipExtStreamCreateWithCUMask(&s, 16, mask));
+        *out = (void *)s;
+    });
+}
+int tn_probe_fill(void *dst, size_t bytes, int flavour, int blocks, void *stream) {
+    return guarded([&] {
+        tn::launch_probe_fill(dst, bytes, flavour, (unsigned)blocks, (hipStream_t)stream);
+        TN_HIP(hipGetLastError());
     });
 }
 

@@ -27,6 +27,24 @@ struct Error : std::runtime_error {
                             __FILE__ + ":" + std::to_string(__LINE__) + ")");                \
     } while (0)
 
+// Kernels that ask for more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, and the
+// attribute is per DEVICE: remembered per (call site, device) so that a process driving several GPUs sets it on each.
+struct PerDeviceOnce {
+    unsigned long long done = 0;  // bit d = set on device d (racing threads at worst set it twice)
+    template <typename Fn>
+    void run(Fn &&fn) {
+        int dev = 0;
+        TN_HIP(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit) return;
+        fn();
+        __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
+    }
+};
+inline void allow_dynamic_lds(const void *kernel, size_t bytes) {
+    TN_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
 constexpr int WIDE = 64;            // BVH branching factor = wavefront width
 constexpr int STACK_CAP = 64 * 6;   // traversal stack entries per wave
 
@@ -110,6 +128,7 @@ struct HostWideBvh {
     std::vector<uint32_t> leaf_id;
     std::vector<float> boxes;
     std::vector<uint32_t> child;
+    uint32_t max_stack = 1;  // worst-case entries of the traversal stack (must stay <= STACK_CAP)
 };
 
 struct HostHullBvh {

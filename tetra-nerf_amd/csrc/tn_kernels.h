@@ -41,24 +41,47 @@ struct WalkParams {
     const float4 *hull_nodes;  // threaded per-lane hull tree
     const float4 *hull_tris;
     uint32_t n_hull_nodes;
-    uint32_t *fallback_list;   // [R] rays the walk could not certify
+    uint32_t *fallback_list;   // [R] rays for the BVH all-hits kernel (global ray ids)
     uint32_t *fallback_count;  // [1]
-    uint4 *rewalk_list;        // [R] {ray, first tet record, entry face, hull exit face}: sound chains whose ORDER
-    uint32_t *rewalk_count;    // [1]  is not certified (re-collected by k_walk_collect); nullptr = all to the fallback
-    uint32_t rewalk_min;       // fewer chains than this: k_walk_collect hands them to the BVH list instead
-    uint32_t *walk_n;          // [num_items] segments per certified ray, TN_EMPTY = sent to the fallback
-    size_t ray_base;           // global index of item 0 (rays are traced in chunks)
-    uint32_t fused_tails;      // 1 = the walk kernel writes the constant tails itself
+    uint2 *literal_list;       // [num_items] {ray index within this launch, hits in the log}: sound chains whose ORDER is
+    uint32_t *literal_count;   // [1]            not certified -> literal sort + pairing of the logged hits
+    uint32_t *kmax;            // [1] max segments of a certified ray (atomicMax)
+    uint32_t *walk_n;          // [num_items] hits logged per certified ray (0 = miss), TN_EMPTY = literal / fallback
+    uint4 *hit_log;            // [ceil(num_items / 64)][M][64] x {t, u, v, variant | exit << 30}: hit k of ray r at
+                               // ((r / 64) * M + k) * 64 + r % 64 (a wave's 64 lanes store 1 KB of consecutive bytes per
+                               // step); exit code 3 = entry hull face, its face id in the low 30 bits
+    size_t ray_base;           // global index of item 0 (rays are traced in chunks when the log would be too large)
     uint32_t debug;            // block->XCD mapping ablation (profiles/): 4 = no remap, 8 = one contiguous band per XCD
 };
 void launch_trace_walk(const WalkParams &p, hipStream_t stream);
-// re-walk of the chains in rewalk_list (raw hits into the rays' own rows) and their literal sort + pairing
-void launch_walk_collect(const WalkParams &p, size_t max_items, hipStream_t stream);
-void launch_postprocess_rows(const TraceParams &p, const uint4 *rewalk_list, const uint32_t *rewalk_count, size_t max_items,
-                             hipStream_t stream);
-// constant tails [n, M) of the rows certified by the walk (n = walk_n[ray] != TN_EMPTY)
-void launch_fill_tails(size_t num_rays, uint32_t M, const uint32_t *walk_n, uint32_t *out_cells, float *out_bary,
-                       float *out_dist, uint32_t *out_verts, hipStream_t stream, unsigned max_blocks = 0);
+// literal sort + pairing of the logged hits of the rays in literal_list (tn_trace_general.hip); rows of launch item i
+// are p.out_*[i] (the TraceParams of the same walk launch)
+void launch_postprocess_log(const TraceParams &p, const WalkVar *vars, const uint4 *hit_log, const uint2 *literal_list,
+                            const uint32_t *literal_count, size_t max_items, hipStream_t stream);
+
+// hit log -> rows of the rays the walk certified (walk_n[ray] != TN_EMPTY): k_write_segments writes the segment records
+// + the tail constants up to the next multiple of 32 slots (a 128-byte line boundary in all four row arrays);
+// k_fill_range streams the rest of the constant tails.  Every byte is written once.
+struct WriteParams {
+    size_t num_rays;
+    uint32_t M;
+    uint32_t dense_tails;      // 0: slots >= num_visited are left unwritten (non-reference option)
+    const uint32_t *walk_n;
+    const uint4 *hit_log;
+    const WalkVar *vars;
+    uint32_t *out_cells;
+    float *out_bary;
+    float *out_dist;
+    uint32_t *out_verts;       // nullable
+};
+void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned max_blocks = 0);
+// all_rows: slots [K, M) of every row, K = ceil32(*kmax) (kmax == nullptr: K = M);
+// otherwise slots [ceil32(out_num[r]), K) of the certified rows
+void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *kmax, const uint32_t *walk_n,
+                       const uint32_t *out_num, uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
+                       unsigned max_blocks = 0);
+
+void launch_probe_fill(void *dst, size_t bytes, int flavour, unsigned blocks, hipStream_t stream);  // probe only
 
 // sample -> segment matching (tn_match.hip)
 void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,

@@ -204,6 +204,23 @@ void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<u
             }
         }
     }
+    // Worst-case occupancy of the traversal stack of collect_hits (tn_trace_general.hip): a popped node pushes all
+    // its internal children (in child order) and the last pushed is popped first, so below the j-th pushed child j
+    // entries are waiting.  need(node) = max(#internal children, max_j (j + need(child_j))).  Children have larger
+    // node indices than their parent, so one reverse sweep evaluates it.
+    const size_t nn = out.child.size() / WIDE;
+    std::vector<uint32_t> need(nn, 0);
+    for (size_t w = nn; w-- > 0;) {
+        uint32_t j = 0, m = 0;
+        for (int i = 0; i < WIDE; ++i) {
+            const uint32_t ch = out.child[w * WIDE + i];
+            if (ch == TN_EMPTY || (ch >> 31)) continue;
+            m = std::max(m, j + need[ch]);
+            ++j;
+        }
+        need[w] = std::max(m, j);
+    }
+    out.max_stack = nn ? std::max<uint32_t>(need[0], 1u) : 1u;
 }
 
 void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const HostMesh &hm,

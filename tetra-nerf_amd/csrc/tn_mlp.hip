@@ -407,14 +407,13 @@ void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, con
         launch_transpose(field, fieldT, FD, num_vertices, stream);  // [64, V] -> [V, 64]
     }
     const size_t smem = MAX_STAGE_FLOATS * sizeof(float);  // the largest staged layer (head)
-    static bool attr_set = false;
-    if (!attr_set) {
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static PerDeviceOnce lds_attr;
+    lds_attr.run([&] {
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, false>), smem);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, false>), smem);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, true>), smem);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, true>), smem);
+    });
     const size_t group = (MLP_BLOCK / 64) * 32;
     const size_t ngroups = (n + group - 1) / group;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);  // one 8-wave block per CU

@@ -393,14 +393,13 @@ void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, 
         launch_transpose(field, fieldT, FD, num_vertices, stream);
     }
     const size_t smem = MAX_STAGE_U4 * sizeof(uint4);  // head layer: 120 KB of weight pieces + bias + rgb vectors
-    static bool attr_set = false;
-    if (!attr_set) {
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward_x3<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward_x3<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward_x3<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_forward_x3<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static PerDeviceOnce lds_attr;
+    lds_attr.run([&] {
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward_x3<false, false>), smem);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward_x3<true, false>), smem);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward_x3<false, true>), smem);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward_x3<true, true>), smem);
+    });
     const size_t group = (X3_BLOCK / 64) * 32;
     const size_t ngroups = (n + group - 1) / group;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);

@@ -415,42 +415,60 @@ __global__ __launch_bounds__(64) void k_postprocess_hits(TraceParams p, const ui
     }
 }
 
-// Sort + literal pairing of the raw hit lists k_walk_collect left in the rays' own output rows
-// (ids in the visited row, t in the first M floats of the distance row, (u,v) in the first 2M floats of the
-// barycentric row, count in num_visited; TN_EMPTY = handed to the BVH path).  All hits are in LDS before
-// the first output byte is written.
-__global__ __launch_bounds__(64) void k_postprocess_rows(TraceParams p, const uint4 *__restrict__ rewalk_list,
-                                                         const uint32_t *__restrict__ rewalk_count) {
+// Literal sort + pairing of the hits the walk LOGGED for the rays whose chain is sound but whose order it does not
+// certify (a gap below eps, a tie, an inversion): hit k of launch item r is the 16-byte log entry
+// ((r / 64) * M + k) * 64 + r % 64 = {t, u, v, variant | exit << 30}; its face id is the walk record's fid[exit]
+// (exit code 3: the entry hull face, id in the low bits).  The chain's faces are the ray's all-hits set (two hull
+// crossings, two crossed faces per tet, no zero edge function), so this equals the BVH path -- sort on (t, face id),
+// then the reference's phases literally (optix_trace_rays.cu:110-266) -- without a traversal.
+__global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const WalkVar *__restrict__ vars,
+                                                        const uint4 *__restrict__ hit_log,
+                                                        const uint2 *__restrict__ literal_list,
+                                                        const uint32_t *__restrict__ literal_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WaveSmem s = carve(smem, p.M);
     const int lane = threadIdx.x;
     const uint32_t M = p.M;
-    const size_t n_items = *rewalk_count;
+    const size_t n_items = *literal_count;
     for (size_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const size_t ray = rewalk_list[it].x;
-        const uint32_t cnt = p.out_num[ray];
-        if (cnt == TN_EMPTY) continue;  // wave-uniform
-        const uint32_t nh = cnt < M ? cnt : M;
-        const uint32_t *ids = p.out_cells + ray * M;
-        const float *ts = p.out_dist + ray * M * 2, *uv = p.out_bary + ray * M * 6;
+        const uint2 ent = literal_list[it];
+        const size_t ray = ent.x;
+        const uint32_t nh = ent.y < M ? ent.y : M - 1;
+        const uint4 *lg = hit_log + (ray >> 6) * (size_t)M * 64 + (ray & 63);
         for (uint32_t j = lane; j < nh; j += 64) {
-            s.key[j] = ((uint64_t)__float_as_uint(ts[j]) << 32) | ids[j];
-            s.hu[j] = uv[2 * j];
-            s.hv[j] = uv[2 * j + 1];
+            const uint4 e = lg[(size_t)j * 64];
+            const uint32_t x = e.w >> 30, lo = e.w & 0x3FFFFFFFu;
+            const uint32_t fid = x == 3u ? lo : reinterpret_cast<const uint32_t *>(vars + lo)[12 + x];
+            s.key[j] = ((uint64_t)e.x << 32) | fid;
+            s.hu[j] = __uint_as_float(e.y);
+            s.hv[j] = __uint_as_float(e.z);
         }
         wave_sync();
         sort_hits(s, nh, lane);
         postprocess_and_write(s, nh, M, p.faces, p.face_tets, p.out_num + ray, p.out_cells + ray * M,
                               p.out_bary + ray * M * 6, p.out_dist + ray * M * 2,
                               p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane);
+        if (lane == 0 && p.stats) atomicAdd(&p.stats[4 + 13], 1ull);
         wave_sync();
     }
 }
 
-size_t trace_general_smem_bytes(uint32_t M);
+size_t trace_general_smem_bytes(uint32_t M) {
+    return (size_t)M * (8 + 4 + 4) + (size_t)(M < 32 ? 32 : M) * 8 + STACK_CAP * 4 + 2 * (size_t)M;
+}
+
+// M = 4096 asks for ~108 KB of dynamic LDS per wave: beyond the 64 KB a kernel gets without the attribute
+template <typename K>
+static size_t wave_smem(K kernel, uint32_t M) {
+    const size_t bytes = trace_general_smem_bytes(M);
+    if (bytes > 64 * 1024) allow_dynamic_lds(reinterpret_cast<const void *>(kernel), bytes);
+    return bytes;
+}
+
 
 // trace_rays_triangles: the sorted all-hits list itself, no pairing
-// (src/optix/optix_trace_rays_triangles.cu:50-87).  Slots >= count: ids -1, floats 0.
+// (src/optix/optix_trace_rays_triangles.cu:50-87).  Slots >= count: 0 in every array -- what the reference's
+// torch::zeros outputs hold there (py_binding.cpp:90-94; it never writes them apart from sort padding).
 __global__ __launch_bounds__(64) void k_trace_triangles(TraceParams p, uint32_t *out_ids, float *out_t, float *out_uv,
                                                         uint32_t *out_v3) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -464,13 +482,13 @@ __global__ __launch_bounds__(64) void k_trace_triangles(TraceParams p, uint32_t 
         sort_hits(s, nh, lane);
         for (uint32_t j = lane; j < M; j += 64) {
             const bool ok = j < nh;
-            const uint32_t id = ok ? (uint32_t)s.key[j] : TN_EMPTY;
+            const uint32_t id = ok ? (uint32_t)s.key[j] : 0u;
             const size_t q = ray * M + j;
             out_ids[q] = id;
             out_t[q] = ok ? __uint_as_float((uint32_t)(s.key[j] >> 32)) : 0.f;
             out_uv[2 * q] = ok ? s.hu[j] : 0.f;
             out_uv[2 * q + 1] = ok ? s.hv[j] : 0.f;
-            for (int k = 0; k < 3; ++k) out_v3[3 * q + k] = ok ? p.faces[3 * (size_t)id + k] : TN_EMPTY;
+            for (int k = 0; k < 3; ++k) out_v3[3 * q + k] = ok ? p.faces[3 * (size_t)id + k] : 0u;
         }
         if (lane == 0) p.out_num[ray] = nh;
         wave_sync();
@@ -539,7 +557,7 @@ void launch_trace_triangles(const TraceParams &p, uint32_t *out_ids, float *out_
     if (p.num_items == 0) return;
     const size_t max_blocks = 256 * 16;
     const unsigned grid = (unsigned)(p.num_items < max_blocks ? p.num_items : max_blocks);
-    hipLaunchKernelGGL(k_trace_triangles, dim3(grid), dim3(64), trace_general_smem_bytes(p.M), stream, p, out_ids, out_t, out_uv, out_v3);
+    hipLaunchKernelGGL(k_trace_triangles, dim3(grid), dim3(64), wave_smem(k_trace_triangles, p.M), stream, p, out_ids, out_t, out_uv, out_v3);
 }
 
 void launch_find_tetrahedra(const TraceParams &p, const float *points, uint32_t *out_tet, float *out_bary,
@@ -547,33 +565,30 @@ void launch_find_tetrahedra(const TraceParams &p, const float *points, uint32_t 
     if (p.num_items == 0) return;
     const size_t max_blocks = 256 * 16;
     const unsigned grid = (unsigned)(p.num_items < max_blocks ? p.num_items : max_blocks);
-    hipLaunchKernelGGL(k_find_tetrahedra, dim3(grid), dim3(64), trace_general_smem_bytes(p.M), stream, p, points, out_tet, out_bary, out_verts);
-}
-
-size_t trace_general_smem_bytes(uint32_t M) {
-    return (size_t)M * (8 + 4 + 4) + (size_t)(M < 32 ? 32 : M) * 8 + STACK_CAP * 4 + 2 * (size_t)M;
+    hipLaunchKernelGGL(k_find_tetrahedra, dim3(grid), dim3(64), wave_smem(k_find_tetrahedra, p.M), stream, p, points, out_tet, out_bary, out_verts);
 }
 
 void launch_trace_general(const TraceParams &p, hipStream_t stream) {
     if (p.num_items == 0) return;
-    const size_t smem = trace_general_smem_bytes(p.M);
+    const size_t smem = wave_smem(k_trace_general, p.M);
     const size_t max_blocks = 256 * 16;
     const unsigned grid = (unsigned)(p.num_items < max_blocks ? p.num_items : max_blocks);
     hipLaunchKernelGGL(k_trace_general, dim3(grid), dim3(64), smem, stream, p);
 }
 
-void launch_postprocess_rows(const TraceParams &p, const uint4 *rewalk_list, const uint32_t *rewalk_count, size_t max_items,
-                             hipStream_t stream) {
+void launch_postprocess_log(const TraceParams &p, const WalkVar *vars, const uint4 *hit_log, const uint2 *literal_list,
+                            const uint32_t *literal_count, size_t max_items, hipStream_t stream) {
     if (max_items == 0) return;
     const size_t max_blocks = 256 * 16;
     const unsigned grid = (unsigned)(max_items < max_blocks ? max_items : max_blocks);
-    hipLaunchKernelGGL(k_postprocess_rows, dim3(grid), dim3(64), trace_general_smem_bytes(p.M), stream, p, rewalk_list, rewalk_count);
+    hipLaunchKernelGGL(k_postprocess_log, dim3(grid), dim3(64), wave_smem(k_postprocess_log, p.M), stream, p, vars, hit_log,
+                       literal_list, literal_count);
 }
 
 void launch_postprocess_hits(const TraceParams &p, const uint32_t *hit_count, const uint32_t *hit_ids,
                              const float *hit_t, const float *hit_uv, hipStream_t stream) {
     if (p.num_items == 0) return;
-    const size_t smem = trace_general_smem_bytes(p.M);
+    const size_t smem = wave_smem(k_postprocess_hits, p.M);
     const size_t max_blocks = 256 * 16;
     const unsigned grid = (unsigned)(p.num_items < max_blocks ? p.num_items : max_blocks);
     hipLaunchKernelGGL(k_postprocess_hits, dim3(grid), dim3(64), smem, stream, p, hit_count, hit_ids, hit_t, hit_uv);

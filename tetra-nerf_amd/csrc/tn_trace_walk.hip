@@ -6,29 +6,47 @@
 // src/optix/optix_trace_rays.cu:268-331 + :78-108), a lane walks the chain: find the two hull
 // faces the ray's line crosses, then step tet -> neighbour tet through 64-byte records specialised
 // by entry face (WalkVar, tn_common.h), producing the faces already in order.  Per step: one
-// dependent 64-B record, ONE vertex shear, three edge functions against the carried entry face to
+// dependent record load, ONE vertex shear, three edge functions against the carried entry face to
 // pick the exit, the exit face's three edge functions in its stored order, one (t,u,v).
 //
 // Parity by construction: every (t,u,v) is computed by the same expression tree, in the face's
-// STORED vertex order, as the general path / the oracle (tri_finish in tn_device.h); the
-// emitted segment is bit-identical to what sort + post_process_tetrahedra yield whenever the
-// chain is "certified":
-//   (S1) t strictly increases along the chain   (sorted order == chain order, no id tie-breaks)
-//   (S2) no two consecutive gaps below eps      (reference phase 1 is then a no-op and phase 2
-//                                                pairs j with j+1, dropping pairs < eps;
-//                                                DESIGN.md "clean chain")
-//   (S3) exactly two hull faces are crossed, every tet on the way has exactly two crossed
-//        faces, no edge function is exactly 0, every recorded t is in (0, 1e16), < M-1 faces.
-// A ray that violates a condition is handed over: when only the ORDER of a sound chain is uncertified (S1 /
-// S2; 97 % of the hand-overs) it goes to `rewalk_list` -- k_walk_collect walks the chain again recording raw
-// hits into the ray's own rows and k_postprocess_rows (tn_trace_general.hip) sorts and pairs them literally --
-// otherwise to `fallback_list`, re-traced by the BVH all-hits kernel.  Both rewrite the ray's rows, so the
-// union is oracle-identical.
+// STORED vertex order, as the general path / the oracle (tri_finish in tn_device.h).  The walk
+// sorts its rays into three classes:
+//   certified   exactly two hull faces are crossed, every tet on the way has exactly two crossed
+//               faces, no edge function is exactly 0, no vertex of a visited tet within rounding
+//               distance of the ray, every recorded t in (0, 1e16), fewer than M faces, AND the order
+//               is "clean": t grows by at least eps from face to face, except for ISOLATED pairs closer
+//               than eps -- ascending, or inverted / tied the wrong way round -- whose neighbours are at
+//               least eps away from both members.  For such a list the reference's dedupe / pairing
+//               phases (optix_trace_rays.cu:124-257) provably reduce to "pair face k-1 with face k, drop
+//               the pairs shorter than eps": phase 1 only marks (nothing is cleared: a mark needs a
+//               second sighting inside one eps window), phase 2 finds the partner of face j in the first
+//               slot it examines -- or, for an inverted pair, in the second, followed by the swap that
+//               restores chain order -- so its look-ahead never walks on to the hull face at the far end.
+//   literal     the chain is sound but its order is not clean (a run of gaps below eps, an inversion by
+//               eps or more, an inverted pair at the very end): the hits of the log go through the
+//               literal sort + pairing (k_postprocess_log, tn_trace_general.hip).  Round 1 certified
+//               runs of short gaps in chains longer than 8 faces; the lattice meshes of
+//               tests/test_parity_configs_gpu.py showed that unsound (phase 1 clears the inside of a
+//               cluster, the look-ahead of phase 2 skips cleared slots without counting them and pairs
+//               the two hull faces through their common EMPTY tet).
+//   fallback    anything else -> re-traced by the BVH all-hits kernel.
+// The chain is the connected component of the hull faces in the set of crossed faces.  The rounded
+// projection can contain further components -- e.g. the star of a vertex whose rounded projection
+// lands exactly on the ray while the chain passes through the star of its 1e-7 twin
+// (near_duplicates mesh, vertex-to-vertex rays) -- which no local walk can see; the
+// vertex-proximity rule above is what catches the cases found so far (reason 4).
 //
-// Memory behaviour: the per-step segment stores are per-lane (rows are 26 KB apart, written two segments at a
-// time with 16-B stores); the constant tail of every row (about 88 % of all bytes at M=512) is streamed by
-// k_fill_tails with 16-byte stores, one wave per row span; blockIdx is remapped so each XCD owns runs of 16
-// consecutive blocks (4096 neighbouring rays) and its L2 keeps the tets they cross.
+// Memory behaviour: the walk does NOT touch the output rows.  Rows are 26 KB apart, so anything a lane stores
+// into its own row is a scattered partial-line write (round 1: 1.52x write amplification, the stores were the
+// larger half of the kernel).  Instead every recorded hit goes to a HIT LOG as one 16-byte entry
+// {t, u, v, variant | exit << 30} at log[wave of 64 rays][hit index][lane] -- the 64 lanes of a wave store 1 KB of
+// consecutive bytes per step, and the log is 16 B per hit instead of 52 B per segment.  k_write_segments turns
+// the log of the certified rays into segment records (whole 128-byte lines, one wave per 8 rays),
+// k_fill_range streams the constant tails: slots [K, M) of ALL rows as soon as the walk has published the
+// largest hit count K (beside the segment writer), slots [ceil32(n), K) of the certified rows after it.
+// blockIdx is remapped so each XCD owns runs of 16 consecutive blocks (4096 neighbouring rays) and its L2 keeps
+// the tets they cross.
 #include "tn_device.h"
 #include "tn_kernels.h"
 
@@ -67,18 +85,25 @@ __device__ __forceinline__ float sel4f(float a, float b, float c, float d, uint3
     return b1 ? hi : lo;
 }
 
-// a walk variant record as four 16-B quads: q0 = (pn.xyz, orig), q1 = vid, q2 = (nb0..2, code_hi), q3 = (fid0..2, code_lo)
-struct Var { uint4 q0, q1, q2, q3; };
+// The part of a walk record the walk itself reads (40 of its 64 bytes; the tet id and the vertex ids are only
+// needed by k_write_rows), as SCALARS: with the neighbours / face ids kept in a uint4 the optimiser turns the select
+// chain below into a dynamically indexed vector, parks the record in LDS and reads `nb` back with a ds_read -- an
+// LDS round trip on the one dependent chain of the walk (record -> exit -> next record).
+struct Var { float px, py, pz; uint32_t nb0, nb1, nb2, code_hi, f0, f1, f2, code_lo; };
 __device__ __forceinline__ Var load_var(const WalkVar *vars, uint32_t c) {
-    const uint4 *r = reinterpret_cast<const uint4 *>(vars + c);
+    const uint32_t *r = reinterpret_cast<const uint32_t *>(vars + c);
+    const float4 q0 = *reinterpret_cast<const float4 *>(r);
+    const uint4 q2 = *reinterpret_cast<const uint4 *>(r + 8), q3 = *reinterpret_cast<const uint4 *>(r + 12);
     Var v;
-    v.q0 = r[0]; v.q1 = r[1]; v.q2 = r[2]; v.q3 = r[3];
+    v.px = q0.x; v.py = q0.y; v.pz = q0.z;
+    v.nb0 = q2.x; v.nb1 = q2.y; v.nb2 = q2.z; v.code_hi = q2.w;
+    v.f0 = q3.x; v.f1 = q3.y; v.f2 = q3.z; v.code_lo = q3.w;
     return v;
 }
-__device__ __forceinline__ uint32_t sel3u(const uint4 &v, uint32_t i) {  // i in 0..2 (3 -> z)
+__device__ __forceinline__ uint32_t sel3u(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t i) {  // i in 0..2 (3 -> v2)
     const bool b0 = (i & 1u) != 0, b1 = (i & 2u) != 0;
-    const uint32_t lo = b0 ? v.y : v.x;
-    return b1 ? v.z : lo;
+    const uint32_t lo = b0 ? v1 : v0;
+    return b1 ? v2 : lo;
 }
 __device__ __forceinline__ SV selsv(const SV &p0, const SV &p1, const SV &p2, const SV &p3, uint32_t i) {
     SV r;
@@ -125,29 +150,30 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     // Wave-uniform traversal of the (small) hull BVH: a node is visited if ANY lane's line hits
     // its padded box; box / triangle data are read through uniform (scalar) loads, every lane
     // tests its own ray.  No stack: the tree has a fixed depth (<= 3 internal levels).
+    // rounding distance of a projected vertex: the box padding of the BVH path (tn_device.h: line_box)
+    const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.scene_max);
     uint32_t nhull = 0;
     uint32_t hf0 = TN_EMPTY, hf1 = TN_EMPTY, hc0 = 0, hc1 = 0, he0 = 0, he1 = 0, hs0 = 0, hs1 = 0;
     float ht0 = 0.f, ht1 = 0.f;
     auto hull_face = [&](const SV &A, const SV &B, const SV &C, uint32_t fid, uint32_t rec, uint32_t loc, uint32_t slot) {
         const float U = edge_f(B, C), V = edge_f(C, A), W = edge_f(A, B);
         const bool mixed = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
-        if (!mixed) {
-            // crossed (or degenerate: a zero edge function -> the general path decides)
-            const float det = (U + V) + W;
-            if (U == 0.0f || V == 0.0f || W == 0.0f || det == 0.0f) { flag = true; why = 1; }
-            const float T = (U * A.z + V * B.z) + W * C.z;
-            const float tt = T / det;
-            if (nhull == 0) { hf0 = fid; ht0 = tt; hc0 = rec; he0 = loc; hs0 = slot; }
-            else if (nhull == 1) { hf1 = fid; ht1 = tt; hc1 = rec; he1 = loc; hs1 = slot; }
-            nhull++;
-        }
+        // crossed (or degenerate: a zero edge function -> the general path decides).  Written as selects: with
+        // conditional assignments the captured results end up in scratch memory behind computed pointers.
+        const float det = (U + V) + W;
+        if (!mixed && (U == 0.0f || V == 0.0f || W == 0.0f || det == 0.0f)) { flag = true; why = 1; }
+        const float T = (U * A.z + V * B.z) + W * C.z;
+        const float tt = T / det;
+        const bool s0 = !mixed && nhull == 0, s1 = !mixed && nhull == 1;
+        hf0 = s0 ? fid : hf0; ht0 = s0 ? tt : ht0; hc0 = s0 ? rec : hc0; he0 = s0 ? loc : he0; hs0 = s0 ? slot : hs0;
+        hf1 = s1 ? fid : hf1; ht1 = s1 ? tt : ht1; hc1 = s1 ? rec : hc1; he1 = s1 ? loc : he1; hs1 = s1 ? slot : hs1;
+        nhull += mixed ? 0u : 1u;
     };
     {
         // Per-lane stackless traversal of the threaded hull tree (DFS pre-order, skip links):
         // ray-independent visiting order, every crossing of the ray's LINE is found.  Works for
         // incoherent batches (random training rays) as well as for camera frames.
         const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
-        const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.scene_max);
         uint32_t i = active ? 0u : p.n_hull_nodes;
         while (i < p.n_hull_nodes) {
             const float4 a = p.hull_nodes[2 * (size_t)i], b = p.hull_nodes[2 * (size_t)i + 1];
@@ -170,25 +196,16 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     if (!active) { flag = false; nhull = 0; }
 
     // ------------------------------------------------------------------ the walk
-    // Segment stores go through LDS: a lane appends its segments to a 4-slot buffer (cells[4] | dist[4][2] |
-    // bary[4][6] | verts[4][4] = 13 x 16 B), and whenever a lane's buffer is full the WAVE writes it out, four rays
-    // per store instruction, lane i copying 16-B chunk i % 13 of ray i / 13: consecutive lanes hit consecutive
-    // addresses, so a ray's 208 B leave as ~5 line transactions instead of 14 scattered 16-B ones (the per-lane
-    // stores were the larger half of the walk: 1.64 ms -> 0.85 ms without them).  All 64 lanes stay in the loop
-    // until the last ray of the wave is done so that they can help.
-    extern __shared__ __attribute__((aligned(16))) uint32_t seg_lds[];
-    uint32_t *mybuf = seg_lds + (size_t)threadIdx.x * 52;
-    const size_t wave_ray0 = (size_t)lb * WALK_BLOCK + (size_t)wave * 64;
+    // Every recorded (valid) hit k of this ray is one 16-byte entry of the hit log, at
+    // log[(wave of 64 rays) * M + k][lane]: the lanes of a wave store consecutive bytes.
+    const size_t gw = (size_t)lb * (WALK_BLOCK / 64) + (size_t)wave;
+    uint4 *mylog = p.hit_log + gw * (size_t)M * 64 + (size_t)lane;
 
-    uint32_t nseg = 0;
-    uint32_t slot_start = 0, f_end = 0;  // entry hull triangle / hull exit face, for the re-walk of an uncertified chain
     bool alive = nhull == 2 && !flag;
     const bool first0 = ht0 < ht1;
-    const uint32_t f_out = first0 ? hf1 : hf0;
-    uint32_t fid_in = first0 ? hf0 : hf1;                        // id of the face the current tet was entered through
+    const uint32_t f_in0 = first0 ? hf0 : hf1, f_out = first0 ? hf1 : hf0;
     uint32_t c = 4u * (first0 ? hc0 : hc1) + (first0 ? he0 : he1);  // variant = (tet record, entry face)
     if (!alive) c = 0;
-    slot_start = first0 ? hs0 : hs1; f_end = f_out;
     // The entry face in its STORED order: sheared vertices A,B,C and edge functions U=E(B,C), V=E(C,A), W=E(A,B).
     // From here on they are carried: the exit face of a step, evaluated in its stored order, is the entry face of
     // the next (same face-table entry), so per step only ONE vertex is sheared and three edge functions against
@@ -198,351 +215,319 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         const float4 *tp = p.hull_tris + 3 * (size_t)(first0 ? hs0 : hs1);
         const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
         A = shear(rp, v0.x, v0.y, v0.z); B = shear(rp, v1.x, v1.y, v1.z); C = shear(rp, v2.x, v2.y, v2.z);
+        // a vertex of the entry face within rounding distance of the ray (reason 4, see the header)
+        if (fabsf(A.x) + fabsf(A.y) < pad || fabsf(B.x) + fabsf(B.y) < pad || fabsf(C.x) + fabsf(C.y) < pad) { flag = true; why = 4; alive = false; }
     }
     float Uc = edge_f(B, C), Vc = edge_f(C, A), Wc = edge_f(A, B);
-    // state of the previous recorded (valid) hit
-    bool have_prev = false, have_pp = false, pending_inv = false, had_special = false;
-    float pt = 0.f, pu = 0.f, pv = 0.f, ppt = 0.f;
-    uint32_t run = 0;  // current run of consecutive gaps below eps
-    uint32_t nhits = 0;
+    bool have_prev = false, have_pp = false;  // one / two valid hits have been recorded
+    bool order_ok = true;     // the order of the hits so far is "clean" (header)
+    bool prev_short = false, prev_inv = false;  // the previous pair was closer than eps / and inverted
+    float pt = 0.f, ppt = 0.f;  // t of the previous recorded hit and of the one before
+    uint32_t fid_prev = f_in0;  // face id of the previous recorded hit (ties are ordered by id)
+    uint32_t nhits = 0, nshort = 0;
     uint32_t steps = 0;
     Var cur = load_var(p.vars, c);
     if (alive) {
-        // the entry hull face itself may be the first recorded hit
+        // the entry hull face itself may be the first recorded hit (exit code 3 = "hull face id in the low bits")
         float tt, uu, vv;
-        if (tri_finish(Uc, Vc, Wc, A.z, B.z, C.z, tt, uu, vv)) { have_prev = true; pt = tt; pu = uu; pv = vv; nhits = 1; }
-    }
-
-    for (;;) {
-        bool need_flush = false;
-        if (alive) {
-            // All checks of a step accumulate into `bad` (first reason kept) and are acted on ONCE at the
-            // end of the step: one divergence point per step instead of a dozen.
-            uint32_t bad = 0;
-            const SV P = shear(rp, __uint_as_float(cur.q0.x), __uint_as_float(cur.q0.y), __uint_as_float(cur.q0.z));
-            const float ea = edge_f(P, A), eb = edge_f(P, B), ec = edge_f(P, C);
-            if (ea == 0.0f || eb == 0.0f || ec == 0.0f) bad = 5;
-            // exit candidates: the faces opposite a {n,b,c}, b {n,c,a}, c {n,a,b}; a face is crossed iff its three
-            // cyclic edge functions agree in sign: E(n,b), E(b,c) = Uc, E(c,n) = -ec, and cyclically
-            const bool sa = ea > 0.0f, sb = eb > 0.0f, sc = ec > 0.0f;
-            const bool su = Uc > 0.0f, sv = Vc > 0.0f, sw = Wc > 0.0f;
-            const bool ha = (sb == su) && (su != sc);
-            const bool hb = (sc == sv) && (sv != sa);
-            const bool hc = (sa == sw) && (sw != sb);
-            const uint32_t hmask = (ha ? 1u : 0u) | (hb ? 2u : 0u) | (hc ? 4u : 0u);
-            if (!bad && __popc(hmask) != 1) bad = 6;
-            const uint32_t x = (__ffs(hmask) - 1) & 3u;  // exit 0..2 (3 only together with bad)
-            const uint32_t nb = sel3u(cur.q2, x);
-            const uint32_t fx = sel3u(cur.q3, x);        // id of the exit face
-            const bool last = nb == TN_EMPTY;
-            // the next record is requested as soon as the exit is known
-            const Var nxt = load_var(p.vars, (last || bad) ? c : nb);
-            __builtin_amdgcn_sched_barrier(0);
-
-            // the exit face in its stored order: 12-bit code of exit x out of the 36-bit word
-            const bool x0 = (x & 1u) != 0, x1 = (x & 2u) != 0;
-            const uint32_t w01 = x0 ? (cur.q3.w >> 12) : cur.q3.w;
-            const uint32_t w2 = (cur.q3.w >> 24) | (cur.q2.w << 8);
-            const uint32_t code = (x1 ? w2 : w01) & 0xFFFu;
-            const SV A2 = selsv(P, A, B, C, code & 3u), B2 = selsv(P, A, B, C, (code >> 2) & 3u), C2 = selsv(P, A, B, C, (code >> 4) & 3u);
-            const float U = edge_f(B2, C2), V = edge_f(C2, A2), W = edge_f(A2, B2);
-            float ct = 0.f, cu = 0.f, cv = 0.f;
-            const bool valid = tri_finish(U, V, W, A2.z, B2.z, C2.z, ct, cu, cv);
-
-            bool do_emit = false;
-            if (valid && have_prev) {
-                const bool is_short = fabsf(pt - ct) < TN_EPS;
-                bool ascending = ct > pt;
-                if (ct == pt) ascending = fx > fid_in;  // exact tie: the sort orders the two faces by id
-                if (ascending) {
-                    // the face after an inverted pair must clear BOTH of its faces by eps
-                    if (pending_inv && !(ct - ppt >= TN_EPS) && !bad) bad = 7;
-                    pending_inv = false;
-                    if (is_short) { if (++run >= 2) had_special = true; } else run = 0;   // (S2)
-                } else {
-                    // (S1) sorted order != chain order.  Certified only for an isolated pair closer
-                    // than eps whose neighbours are at least eps away on both sides.
-                    if ((!is_short || !have_pp || run > 0 || pending_inv || !(ct - ppt >= TN_EPS)) && !bad) bad = 7;
-                    pending_inv = true;
-                    had_special = true;
-                }
-                do_emit = !is_short;
-            } else if (!valid && have_prev && !bad) {
-                bad = 10;  // hit list is not a suffix of the chain
-            }
-            if (valid && ++nhits > M - 1 && !bad) bad = 9;  // more than M-1 faces
-
-            if (do_emit && !bad) {
-                // combine_indices: entry slot j <- position of its vertex in the exit face's stored order
-                const float r0 = 1.0f - cu - cv;
-                const uint32_t c0 = (code >> 6) & 3u, c1 = (code >> 8) & 3u, c2 = (code >> 10) & 3u;
-                const uint32_t k = nseg & 3u;
-                mybuf[k] = cur.q0.w;  // the caller's tet id
-                *reinterpret_cast<float2 *>(mybuf + 4 + 2 * k) = make_float2(pt, ct);
-                float2 *bp = reinterpret_cast<float2 *>(mybuf + 12 + 6 * k);
-                bp[0] = make_float2(1.0f - pu - pv, pu);
-                bp[1] = make_float2(pv, sel4f(r0, cu, cv, 0.f, c0));
-                bp[2] = make_float2(sel4f(r0, cu, cv, 0.f, c1), sel4f(r0, cu, cv, 0.f, c2));
-                *reinterpret_cast<uint4 *>(mybuf + 36 + 4 * k) = cur.q1;  // (n, a, b, c)
-                nseg++;
-                need_flush = (nseg & 3u) == 0;
-            }
-            if (valid) {
-                have_pp = have_prev; ppt = pt;
-                have_prev = true; pt = ct; pu = cu; pv = cv;
-            }
-            if (last && !bad) {
-                if (fx != f_out) bad = 11;
-                // Tie handling is certified away from the chain ends only: in a short chain the reference's
-                // look-ahead can pair the two hull faces through their common EMPTY tet (get_common_tetrahedra,
-                // optix_trace_rays.cu:22-37); a pair inverted at the very end has no following face to clear it.
-                else if ((had_special && nhits <= 8) || pending_inv) bad = 8;
-            }
-            if (!bad && !last && ++steps > MAX_WALK_STEPS) bad = 12;
-            if (bad) { flag = true; why = bad; alive = false; need_flush = false; }
-            else if (last) alive = false;
-            else {
-                c = nb;
-                cur = nxt;
-                fid_in = fx;
-                A = A2; B = B2; C = C2;
-                Uc = U; Vc = V; Wc = W;
-            }
-        }
-        // ---- cooperative write-out of the full buffers (wave-uniform)
-        unsigned long long fm = __ballot(need_flush);
-        if (fm) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the owners' LDS writes are done
-            const uint32_t grp = (uint32_t)lane / 13u, chunk = (uint32_t)lane - 13u * grp;  // lanes 52..63 idle
-            while (fm) {
-                // the next (up to) four rays with a full buffer
-                int src = -1;
-#pragma unroll
-                for (uint32_t g = 0; g < 4; ++g) {
-                    if (fm) {
-                        const int l = __ffsll(fm) - 1;
-                        fm &= fm - 1;
-                        if (grp == g) src = l;
-                    }
-                }
-                // ds_bpermute reads only ACTIVE source lanes: every lane takes part in the exchange
-                const uint32_t ns = (uint32_t)__shfl((int)nseg, src >= 0 ? src : 0);
-                if (src >= 0 && grp < 4) {
-                    const size_t row = (wave_ray0 + (size_t)src) * M + (ns - 4);   // first of the four slots
-                    const uint4 data = *reinterpret_cast<const uint4 *>(seg_lds + ((size_t)wave * 64 + src) * 52 + 4 * chunk);
-                    uint32_t *dst;
-                    if (chunk == 0) dst = t.out_cells + row;
-                    else if (chunk < 3) dst = reinterpret_cast<uint32_t *>(t.out_dist) + 2 * row + 4 * (chunk - 1);
-                    else if (chunk < 9) dst = reinterpret_cast<uint32_t *>(t.out_bary) + 6 * row + 4 * (chunk - 3);
-                    else dst = t.out_verts ? t.out_verts + 4 * row + 4 * (chunk - 9) : nullptr;
-                    if (dst) *reinterpret_cast<uint4 *>(dst) = data;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // buffers are read before their owners refill them
-        }
-        if (__ballot(alive) == 0ull) break;
-    }
-    // ---- left-over segments (1..3 per ray): one ray per pass, lane w copies word w of its buffer
-    {
-        const uint32_t left = (active && !flag) ? (nseg & 3u) : 0u;
-        unsigned long long lm = __ballot(left != 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        while (lm) {
-            const int src = __ffsll(lm) - 1;
-            lm &= lm - 1;
-            const uint32_t nl = (uint32_t)__shfl((int)left, src), ns = (uint32_t)__shfl((int)nseg, src);
-            const size_t row = (wave_ray0 + (size_t)src) * M + (ns - nl);
-            const uint32_t w = (uint32_t)lane;
-            if (w < 52) {
-                const uint32_t val = seg_lds[((size_t)wave * 64 + src) * 52 + w];
-                uint32_t *dst = nullptr;
-                if (w < 4) { if (w < nl) dst = t.out_cells + row + w; }
-                else if (w < 12) { if (w - 4 < 2 * nl) dst = reinterpret_cast<uint32_t *>(t.out_dist) + 2 * row + (w - 4); }
-                else if (w < 36) { if (w - 12 < 6 * nl) dst = reinterpret_cast<uint32_t *>(t.out_bary) + 6 * row + (w - 12); }
-                else if (w - 36 < 4 * nl && t.out_verts) dst = t.out_verts + 4 * row + (w - 36);
-                if (dst) *dst = val;
-            }
+        if (tri_finish(Uc, Vc, Wc, A.z, B.z, C.z, tt, uu, vv)) {
+            have_prev = true; pt = tt; nhits = 1;
+            mylog[0] = make_uint4(__float_as_uint(tt), __float_as_uint(uu), __float_as_uint(vv), f_in0 | (3u << 30));
         }
     }
 
-    // ------------------------------------------------------------------ fallback list + tails
-    if (active) {
-        if (flag) {
-            // ordering problems only (7 / 8: the chain itself is sound, its sorted order is not certified;
-            // 10: an invalid t inside the chain): the hit list is re-collected by walking the chain again
-            // (k_walk_collect) and goes through the literal sort + pairing; anything else -> BVH all-hits path
-            if (p.rewalk_list && (why == 7 || why == 8 || why == 10)) {
-                const uint32_t slot = atomicAdd(p.rewalk_count, 1u);
-                p.rewalk_list[slot] = make_uint4((uint32_t)(p.ray_base + ray), slot_start, f_end, 0u);
-            } else {
-                const uint32_t slot = atomicAdd(p.fallback_count, 1u);
-                p.fallback_list[slot] = (uint32_t)(p.ray_base + ray);
-            }
-            if (t.stats) atomicAdd(&t.stats[4 + why], 1ull);
-            p.walk_n[ray] = TN_EMPTY;
-        } else {
-            t.out_num[ray] = nseg;
-            p.walk_n[ray] = nseg;
-        }
-    }
-    if (!p.fused_tails) return;  // a separate k_fill_tails launch (other stream) writes the tails
+    while (alive) {
+        // All checks of a step accumulate into `bad` (first reason kept), straight-line: as nested ifs the checks
+        // became a dozen exec-masked branches per step.
+        uint32_t bad = 0;
+        const SV P = shear(rp, cur.px, cur.py, cur.pz);
+        const float ea = edge_f(P, A), eb = edge_f(P, B), ec = edge_f(P, C);
+        bad = (fabsf(P.x) + fabsf(P.y) < pad) ? 4u : bad;                  // vertex within rounding distance of the ray
+        bad = (!bad && (ea == 0.0f || eb == 0.0f || ec == 0.0f)) ? 5u : bad;
+        // exit candidates: the faces opposite a {n,b,c}, b {n,c,a}, c {n,a,b}; a face is crossed iff its three
+        // cyclic edge functions agree in sign: E(n,b), E(b,c) = Uc, E(c,n) = -ec, and cyclically
+        const bool sa = ea > 0.0f, sb = eb > 0.0f, sc = ec > 0.0f;
+        const bool su = Uc > 0.0f, sv = Vc > 0.0f, sw = Wc > 0.0f;
+        const bool ha = (sb == su) && (su != sc);
+        const bool hb = (sc == sv) && (sv != sa);
+        const bool hc = (sa == sw) && (sw != sb);
+        const uint32_t hmask = (ha ? 1u : 0u) | (hb ? 2u : 0u) | (hc ? 4u : 0u);
+        bad = (!bad && __popc(hmask) != 1) ? 6u : bad;
+        const uint32_t x = (__ffs(hmask) - 1) & 3u;  // exit 0..2 (3 only together with bad)
+        const uint32_t nb = sel3u(cur.nb0, cur.nb1, cur.nb2, x);
+        const uint32_t fx = sel3u(cur.f0, cur.f1, cur.f2, x);        // id of the exit face
+        const bool last = nb == TN_EMPTY;
+        // the next record is requested as soon as the exit is known
+        const Var nxt = load_var(p.vars, (last || bad) ? c : nb);
+        __builtin_amdgcn_sched_barrier(0);
 
-    // wave-cooperative constant tails of the 64 rows this wave owns
-    for (int i = 0; i < 64; ++i) {
-        if (wave_ray0 + i >= t.num_items) break;
-        const uint32_t n_i = __shfl(nseg, i);
-        const bool fl_i = __shfl((int)flag, i) != 0;
-        if (fl_i) continue;  // the general kernel rewrites the whole row
-        const size_t r_i = wave_ray0 + i;
-        fill_dwords(t.out_cells + r_i * M, n_i, M, TN_EMPTY, lane);
-        fill_dwords(reinterpret_cast<uint32_t *>(t.out_dist + r_i * M * 2), 2 * n_i, 2 * M, 0u, lane);
-        fill_dwords(reinterpret_cast<uint32_t *>(t.out_bary + r_i * M * 6), 6 * n_i, 6 * M, 0u, lane);
-        if (t.out_verts) fill_dwords(t.out_verts + r_i * M * 4, 4 * n_i, 4 * M, TN_EMPTY, lane);
-    }
-}
+        // the exit face in its stored order: 12-bit code of exit x out of the 36-bit word
+        const bool x0 = (x & 1u) != 0, x1 = (x & 2u) != 0;
+        const uint32_t w01 = x0 ? (cur.code_lo >> 12) : cur.code_lo;
+        const uint32_t w2 = (cur.code_lo >> 24) | (cur.code_hi << 8);
+        const uint32_t code = (x1 ? w2 : w01) & 0xFFFu;
+        const SV A2 = selsv(P, A, B, C, code & 3u), B2 = selsv(P, A, B, C, (code >> 2) & 3u), C2 = selsv(P, A, B, C, (code >> 4) & 3u);
+        const float U = edge_f(B2, C2), V = edge_f(C2, A2), W = edge_f(A2, B2);
+        float ct = 0.f, cu = 0.f, cv = 0.f;
+        const bool valid = tri_finish(U, V, W, A2.z, B2.z, C2.z, ct, cu, cv);
 
-
-// Re-walk of the chains whose ORDER the walk could not certify (reasons 7 / 8 / 10): lane per ray, same
-// chain, same per-face arithmetic, but every valid hit (face id, t, u, v) is only RECORDED -- into the ray's
-// own output rows, used as scratch exactly like the reference's any-hit program does
-// (optix_trace_rays.cu:310-326): ids -> visited row, t -> first M floats of the distance row, (u,v) -> first
-// 2M floats of the barycentric row, count -> num_visited.  k_postprocess_rows then sorts and pairs them
-// literally.  With two hull crossings, two crossed faces per tet and no zero edge function, the faces of the
-// chain ARE the ray's all-hits set, so this equals the BVH path at a fraction of its cost; a chain that fails
-// those checks here goes to the BVH list after all.
-__global__ __launch_bounds__(WALK_BLOCK) void k_walk_collect(WalkParams p) {
-    const TraceParams &t = p.t;
-    const uint32_t M = t.M;
-    const uint32_t n_items = *p.rewalk_count;
-    // A lane walking ~200 dependent steps only pays off with enough lanes: below `rewalk_min` chains one
-    // wavefront per ray through the BVH finishes sooner (measured: 1021 chains 0.39 ms vs 0.25 ms), so the
-    // entries are handed to that list unchanged (decided on the device: no host round trip).
-    const bool hand_over = n_items < p.rewalk_min;
-    for (uint32_t it = blockIdx.x * WALK_BLOCK + threadIdx.x; it < n_items; it += gridDim.x * WALK_BLOCK) {
-        const uint4 ent = p.rewalk_list[it];  // ray, hull triangle of the entry face, hull exit face id
-        if (hand_over) {
-            const uint32_t slot = atomicAdd(p.fallback_count, 1u);
-            p.fallback_list[slot] = ent.x;
-            t.out_num[ent.x] = TN_EMPTY;
-            if (t.stats) atomicAdd(&t.stats[4 + 14], 1ull);
-            continue;
-        }
-        const size_t ray = ent.x;
-        const uint32_t f_out = ent.z;
-        const RayPre rp = ray_pre(t.origins[3 * ray], t.origins[3 * ray + 1], t.origins[3 * ray + 2], t.dirs[3 * ray],
-                                  t.dirs[3 * ray + 1], t.dirs[3 * ray + 2]);
-        uint32_t *row_id = t.out_cells + ray * M;
-        float *row_t = t.out_dist + ray * M * 2;
-        float *row_uv = t.out_bary + ray * M * 6;
-        uint32_t nhits = 0, steps = 0, bad = 0;
-        auto record = [&](uint32_t fid, float tt, float uu, float vv) {
-            if (nhits < M - 1) {
-                row_id[nhits] = fid;
-                row_t[nhits] = tt;
-                *reinterpret_cast<float2 *>(row_uv + 2 * nhits) = make_float2(uu, vv);
-            }
-            nhits++;
-        };
-        // the entry hull face in its stored order (as in k_trace_walk)
-        const float4 *tp = p.hull_tris + 3 * (size_t)ent.y;
-        const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-        SV A = shear(rp, v0.x, v0.y, v0.z), B = shear(rp, v1.x, v1.y, v1.z), C = shear(rp, v2.x, v2.y, v2.z);
-        float Uc = edge_f(B, C), Vc = edge_f(C, A), Wc = edge_f(A, B);
-        uint32_t c = 4u * __float_as_uint(v1.w) + __float_as_uint(v2.w);
+        // order of the pair (previous hit, this hit); see "certified" in the header
         {
-            float tt, uu, vv;
-            if (tri_finish(Uc, Vc, Wc, A.z, B.z, C.z, tt, uu, vv)) record(__float_as_uint(v0.w), tt, uu, vv);
+            const bool vp = valid && have_prev;
+            const bool is_short = fabsf(pt - ct) < TN_EPS;
+            const bool asc = (ct > pt) || (ct == pt && fx > fid_prev);   // sorted order of the two = chain order
+            const bool clear2 = ct - ppt >= TN_EPS;
+            const bool ok = is_short ? (!prev_short && (asc || (have_pp && clear2)))   // isolated; inverted: clear of the face before
+                                     : (asc && (!prev_inv || clear2));                 // after an inverted pair: clear of both
+            order_ok = order_ok && (!vp || ok);
+            nshort += (vp && is_short) ? 1u : 0u;
+            prev_inv = vp ? (is_short && !asc) : prev_inv;
+            prev_short = vp ? is_short : prev_short;
         }
-        Var cur = load_var(p.vars, c);
-        for (;;) {
-            const SV P = shear(rp, __uint_as_float(cur.q0.x), __uint_as_float(cur.q0.y), __uint_as_float(cur.q0.z));
-            const float ea = edge_f(P, A), eb = edge_f(P, B), ec = edge_f(P, C);
-            if (ea == 0.0f || eb == 0.0f || ec == 0.0f) bad = 5;
-            const bool sa = ea > 0.0f, sb = eb > 0.0f, sc = ec > 0.0f;
-            const bool su = Uc > 0.0f, sv = Vc > 0.0f, sw = Wc > 0.0f;
-            const bool ha = (sb == su) && (su != sc), hb = (sc == sv) && (sv != sa), hc = (sa == sw) && (sw != sb);
-            const uint32_t hmask = (ha ? 1u : 0u) | (hb ? 2u : 0u) | (hc ? 4u : 0u);
-            if (!bad && __popc(hmask) != 1) bad = 6;
-            const uint32_t x = (__ffs(hmask) - 1) & 3u;
-            const uint32_t nb = sel3u(cur.q2, x);
-            const uint32_t fx = sel3u(cur.q3, x);
-            const bool last = nb == TN_EMPTY;
-            const Var nxt = load_var(p.vars, (last || bad) ? c : nb);  // requested before this step's stores
-            __builtin_amdgcn_sched_barrier(0);
-            if (bad) break;
-            const bool x0 = (x & 1u) != 0, x1 = (x & 2u) != 0;
-            const uint32_t w01 = x0 ? (cur.q3.w >> 12) : cur.q3.w;
-            const uint32_t w2 = (cur.q3.w >> 24) | (cur.q2.w << 8);
-            const uint32_t code = (x1 ? w2 : w01) & 0xFFFu;
-            const SV A2 = selsv(P, A, B, C, code & 3u), B2 = selsv(P, A, B, C, (code >> 2) & 3u), C2 = selsv(P, A, B, C, (code >> 4) & 3u);
-            const float U = edge_f(B2, C2), V = edge_f(C2, A2), W = edge_f(A2, B2);
-            float tt, uu, vv;
-            if (tri_finish(U, V, W, A2.z, B2.z, C2.z, tt, uu, vv)) record(fx, tt, uu, vv);
-            if (last) {
-                if (fx != f_out) bad = 11;
-                break;
-            }
-            if (++steps > MAX_WALK_STEPS) { bad = 12; break; }
-            c = nb;
-            cur = nxt;
-            A = A2; B = B2; C = C2;
-            Uc = U; Vc = V; Wc = W;
+        bad = (!bad && !valid && have_prev) ? 10u : bad;        // the hit list is not a suffix of the chain
+        bad = (!bad && valid && nhits >= M - 1) ? 9u : bad;     // more than M-1 faces
+        if (valid && nhits < M - 1) {
+            // hit `nhits` of this ray: (t, u, v) in the face's stored order + the tet it closes (variant, exit)
+            mylog[(size_t)nhits * 64] = make_uint4(__float_as_uint(ct), __float_as_uint(cu), __float_as_uint(cv), c | (x << 30));
         }
-        if (!bad && nhits > M - 1) bad = 9;  // overflow: the BVH path keeps the M-1 nearest
-        if (bad) {
+        nhits += valid ? 1u : 0u;
+        have_pp = valid ? have_prev : have_pp;
+        ppt = valid ? pt : ppt;
+        pt = valid ? ct : pt;
+        fid_prev = valid ? fx : fid_prev;
+        have_prev = have_prev || valid;
+        bad = (!bad && last && fx != f_out) ? 11u : bad;
+        steps++;
+        bad = (!bad && !last && steps > MAX_WALK_STEPS) ? 12u : bad;
+        flag = bad != 0;
+        why = bad;
+        alive = !bad && !last;
+        // a lane that stops never reads its walk state again: advance unconditionally
+        c = nb;
+        cur = nxt;
+        A = A2; B = B2; C = C2;
+        Uc = U; Vc = V; Wc = W;
+    }
+
+    // ------------------------------------------------------------------ classes, hand-over lists, hit counts
+    order_ok = order_ok && !prev_inv;   // a pair inverted at the very end has no following face to clear it
+    const bool certified = active && !flag && order_ok;
+    const uint32_t nseg = nhits ? nhits - 1 - nshort : 0;   // every consecutive pair that is not short
+    if (active) {
+        if (flag || (!order_ok && !p.literal_list)) {
             const uint32_t slot = atomicAdd(p.fallback_count, 1u);
-            p.fallback_list[slot] = (uint32_t)ray;
-            t.out_num[ray] = TN_EMPTY;  // k_postprocess_rows skips it; the BVH kernel rewrites the row
-            if (t.stats) atomicAdd(&t.stats[4 + 14], 1ull);
+            p.fallback_list[slot] = (uint32_t)(p.ray_base + ray);
+            if (t.stats) atomicAdd(&t.stats[4 + (flag ? why : 7u)], 1ull);
+            p.walk_n[ray] = TN_EMPTY;   // the BVH kernel writes the whole row
+        } else if (!order_ok) {
+            if (t.stats) atomicAdd(&t.stats[4 + 7], 1ull);
+            const uint32_t slot = atomicAdd(p.literal_count, 1u);
+            p.literal_list[slot] = make_uint2((uint32_t)ray, nhits);   // index within this walk launch (= log row)
+            p.walk_n[ray] = TN_EMPTY;   // k_postprocess_log writes the whole row
         } else {
-            t.out_num[ray] = nhits;
-            if (t.stats) atomicAdd(&t.stats[4 + 13], 1ull);
+            p.walk_n[ray] = nhits;      // hits in the log (0 for a miss)
+            t.out_num[ray] = nseg;
+        }
+    }
+    // largest segment count of a certified ray: k_fill_range may write the slots from ceil32(K) on of EVERY row
+    uint32_t km = certified ? nseg : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o2 = (uint32_t)__shfl_xor((int)km, off);
+        km = o2 > km ? o2 : km;
+    }
+    if (lane == 0 && km) atomicMax(p.kmax, km);
+}
+
+
+// Hit log -> the SEGMENT part of the rows of the certified rays.  One wave works on EIGHT consecutive rays at a
+// time: lane = (ray a = lane & 7, hit h = lane >> 3), so a load instruction fetches 8 hits of each of the 8 rays as
+// 8 full 128-byte lines of the log (entries of neighbouring rays are neighbours in the log).  For a certified ray
+// (header of this file) hits k-1 and k bound the tet recorded with hit k, and the pair is a segment unless it is
+// shorter than eps; emitted slots are numbered by a per-ray prefix count over the wave ballot.  The tet id /
+// vertex ids / combine_indices code come from the 64-byte walk record of (tet, entry face); bary_out is selected
+// exactly as combine_indices does (optix_trace_rays.cu:39-75).  The slots between the last segment and the next
+// multiple of 32 (where all four row arrays are on a 128-byte line boundary) get their tail constants here, so
+// that k_fill_range starts every row on a line boundary and no line is written by two kernels.
+// The kernel is latency-bound (log -> walk record -> stores): groups are dealt round-robin to the waves (the rays
+// that miss the mesh are clustered), and the 4 x 8 hits per ray of an iteration are requested before any is used.
+__global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
+    constexpr int U = 4;   // chunks of 8 hits per ray in flight
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t a = (uint32_t)lane & 7u, h = (uint32_t)lane >> 3;
+    const uint32_t M = q.M;
+    const size_t G = (q.num_rays + 7) / 8;                 // groups of 8 rays
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    const unsigned long long raymask = 0x0101010101010101ull << a;
+    for (size_t g = (size_t)blockIdx.x * 4 + wave; g < G; g += nwaves) {
+        const size_t r0 = 8 * g, r = r0 + a;
+        uint32_t nh = r < q.num_rays ? q.walk_n[r] : TN_EMPTY;
+        const bool skip = nh == TN_EMPTY;   // literal / fallback ray (or padding): the row belongs to another kernel
+        if (skip) nh = 0;
+        uint32_t mx = nh;             // max over the 8 rays (the value is replicated over h)
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)mx, off);
+            mx = o > mx ? o : mx;
+        }
+        mx = __builtin_amdgcn_readfirstlane(mx);
+        const uint4 *lg = q.hit_log + (r0 >> 6) * (size_t)M * 64 + (r0 & 63) + a;   // entry k at lg[k * 64]
+        const size_t row = r * (size_t)M;
+        uint32_t nseg = 0;
+        uint4 carry = make_uint4(0u, 0u, 0u, 0u);   // hit c0 - 1 of ray a
+        for (uint32_t c0 = 0; c0 < mx; c0 += 8 * U) {
+            uint4 e[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t k = c0 + 8 * u + h;
+                e[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (k < nh) e[u] = lg[(size_t)k * 64];
+            }
+            // previous hit of every lane (lane - 8, or the last hit of the previous chunk), emission, slots
+            uint4 pe[U];
+            uint32_t slot[U];   // TN_EMPTY: no segment
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t k = c0 + 8 * u + h;
+                pe[u].x = (uint32_t)__shfl_up((int)e[u].x, 8); pe[u].y = (uint32_t)__shfl_up((int)e[u].y, 8);
+                pe[u].z = (uint32_t)__shfl_up((int)e[u].z, 8); pe[u].w = 0u;
+                if (h == 0) pe[u] = carry;
+                carry.x = (uint32_t)__shfl((int)e[u].x, (int)a + 56); carry.y = (uint32_t)__shfl((int)e[u].y, (int)a + 56);
+                carry.z = (uint32_t)__shfl((int)e[u].z, (int)a + 56);
+                const bool emit = k >= 1 && k < nh && !(fabsf(__uint_as_float(pe[u].x) - __uint_as_float(e[u].x)) < TN_EPS);
+                const unsigned long long m = __ballot(emit) & raymask;
+                slot[u] = emit ? nseg + (uint32_t)__popcll(m & lanemask_lt()) : TN_EMPTY;
+                nseg += (uint32_t)__popcll(m);
+            }
+            // walk records of the emitted segments
+            uint32_t orig[U], chi[U], clo[U];
+            uint4 vid[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                orig[u] = 0; chi[u] = 0; clo[u] = 0; vid[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (slot[u] != TN_EMPTY) {
+                    const uint32_t *rec = reinterpret_cast<const uint32_t *>(q.vars + (e[u].w & 0x3FFFFFFFu));
+                    orig[u] = rec[3];
+                    vid[u] = *reinterpret_cast<const uint4 *>(rec + 4);
+                    chi[u] = rec[11]; clo[u] = rec[15];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (slot[u] != TN_EMPTY) {
+                    const size_t sl = row + slot[u];
+                    const uint32_t x = e[u].w >> 30;
+                    const bool x0 = (x & 1u) != 0, x1 = (x & 2u) != 0;
+                    const uint32_t w01 = x0 ? (clo[u] >> 12) : clo[u];
+                    const uint32_t w2 = (clo[u] >> 24) | (chi[u] << 8);
+                    const uint32_t code = (x1 ? w2 : w01) & 0xFFFu;
+                    const float pt = __uint_as_float(pe[u].x), pu = __uint_as_float(pe[u].y), pv = __uint_as_float(pe[u].z);
+                    const float ct = __uint_as_float(e[u].x), cu = __uint_as_float(e[u].y), cv = __uint_as_float(e[u].z);
+                    const float r0f = 1.0f - cu - cv;
+                    const uint32_t k0 = (code >> 6) & 3u, k1 = (code >> 8) & 3u, k2 = (code >> 10) & 3u;
+                    q.out_cells[sl] = orig[u];
+                    *reinterpret_cast<float2 *>(q.out_dist + 2 * sl) = make_float2(pt, ct);
+                    float2 *bp = reinterpret_cast<float2 *>(q.out_bary + 6 * sl);
+                    bp[0] = make_float2(1.0f - pu - pv, pu);
+                    bp[1] = make_float2(pv, sel4f(r0f, cu, cv, 0.f, k0));
+                    bp[2] = make_float2(sel4f(r0f, cu, cv, 0.f, k1), sel4f(r0f, cu, cv, 0.f, k2));
+                    if (q.out_verts) *reinterpret_cast<uint4 *>(q.out_verts + 4 * sl) = vid[u];   // (n, a, b, c)
+                }
+            }
+        }
+        // tail constants up to the next multiple of 32 slots (line boundary of all four arrays)
+        if (q.dense_tails && !skip) {
+            uint32_t n32 = (nseg + 31u) & ~31u;
+            if (n32 > M) n32 = M;
+            for (uint32_t sl = nseg + h; sl < n32; sl += 8) {
+                const size_t slot = row + sl;
+                q.out_cells[slot] = TN_EMPTY;
+                *reinterpret_cast<float2 *>(q.out_dist + 2 * slot) = make_float2(0.f, 0.f);
+                float2 *bp = reinterpret_cast<float2 *>(q.out_bary + 6 * slot);
+                bp[0] = make_float2(0.f, 0.f); bp[1] = make_float2(0.f, 0.f); bp[2] = make_float2(0.f, 0.f);
+                if (q.out_verts) *reinterpret_cast<uint4 *>(q.out_verts + 4 * slot) = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
+            }
         }
     }
 }
 
-void launch_walk_collect(const WalkParams &p, size_t max_items, hipStream_t stream) {
-    if (max_items == 0) return;
-    size_t blocks = (max_items + WALK_BLOCK - 1) / WALK_BLOCK;
-    if (blocks > 256 * 4) blocks = 256 * 4;
-    hipLaunchKernelGGL(k_walk_collect, dim3((unsigned)blocks), dim3(WALK_BLOCK), 0, stream, p);
+void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned max_blocks) {
+    if (q.num_rays == 0) return;
+    size_t blocks = (q.num_rays + 31) / 32;        // one group of 8 rays per wave
+    const size_t cap = max_blocks ? max_blocks : 256 * 4;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_write_segments, dim3((unsigned)blocks), dim3(256), 0, stream, q);
 }
 
-// Constant tails of the rows the walk certified: slots [n, M) of the four row arrays.  Pure
-// streaming stores (16 B per lane), one wave per ray per pass, XCD-banded like the walk so a
-// row's lines are written by the XCD whose L2 already holds the row's segment lines.
-__global__ __launch_bounds__(256) void k_fill_tails(size_t num_rays, uint32_t M, const uint32_t *__restrict__ walk_n,
-                                                    uint32_t *__restrict__ out_cells, float *__restrict__ out_bary,
-                                                    float *__restrict__ out_dist, uint32_t *__restrict__ out_verts) {
+// Constant tails: pure streaming stores (16 B per lane, whole 128-byte lines), a contiguous span of rows per wave.
+// This is the bulk of the bytes of a trace_rays call (88 % at M = 512) and runs at the write ceiling.  Two uses:
+//   all_rows = 1: slots [K, M) of EVERY row, K = ceil32(*kmax) = the first slot no certified ray reaches; needs
+//                 only the walk, so it streams beside the (latency-bound) segment writer.  Rows of literal /
+//                 fallback rays are included: the kernels that rewrite them run after this one.
+//   all_rows = 0: slots [ceil32(n), K) of the certified rows (k_write_segments has written [0, ceil32(n))).
+__global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M, uint32_t all_rows, const uint32_t *__restrict__ kmax,
+                                                    const uint32_t *__restrict__ walk_n, const uint32_t *__restrict__ out_num,
+                                                    uint32_t *__restrict__ out_cells,
+                                                    float *__restrict__ out_bary, float *__restrict__ out_dist,
+                                                    uint32_t *__restrict__ out_verts) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t nwaves = (size_t)gridDim.x * 4;
-    const uint32_t per = gridDim.x >> 3;  // gridDim.x is a multiple of 8
-    const size_t lb = (size_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    // contiguous span of rays per wave: consecutive rows are consecutive in memory
-    const size_t span = (num_rays + nwaves - 1) / nwaves;
-    const size_t r0 = (lb * 4 + wave) * span;
+    const size_t span = (num_rays + nwaves - 1) / nwaves;   // consecutive rows are consecutive in memory
+    const size_t r0 = ((size_t)blockIdx.x * 4 + wave) * span;
     const size_t r1 = r0 + span < num_rays ? r0 + span : num_rays;
+    uint32_t K = M;
+    if (kmax) {
+        K = (*kmax + 31u) & ~31u;
+        if (K > M) K = M;
+    }
     for (size_t r = r0; r < r1; ++r) {
-        const uint32_t n = walk_n[r];
-        if (n == TN_EMPTY) continue;  // re-traced by the general kernel, which writes the whole row
-        fill_dwords(out_cells + r * M, n, M, TN_EMPTY, lane);
-        fill_dwords(reinterpret_cast<uint32_t *>(out_dist + r * M * 2), 2 * n, 2 * M, 0u, lane);
-        fill_dwords(reinterpret_cast<uint32_t *>(out_bary + r * M * 6), 6 * n, 6 * M, 0u, lane);
-        if (out_verts) fill_dwords(out_verts + r * M * 4, 4 * n, 4 * M, TN_EMPTY, lane);
+        uint32_t lo = K, hi = M;
+        if (!all_rows) {
+            if (walk_n[r] == TN_EMPTY) continue;  // literal / fallback ray: those kernels write the whole row
+            lo = (out_num[r] + 31u) & ~31u;
+            if (lo > M) lo = M;
+            hi = K;
+        }
+        if (lo >= hi) continue;
+        fill_dwords(out_cells + r * M, lo, hi, TN_EMPTY, lane);
+        fill_dwords(reinterpret_cast<uint32_t *>(out_dist + r * M * 2), 2 * lo, 2 * hi, 0u, lane);
+        fill_dwords(reinterpret_cast<uint32_t *>(out_bary + r * M * 6), 6 * lo, 6 * hi, 0u, lane);
+        if (out_verts) fill_dwords(out_verts + r * M * 4, 4 * lo, 4 * hi, TN_EMPTY, lane);
     }
 }
 
-void launch_fill_tails(size_t num_rays, uint32_t M, const uint32_t *walk_n, uint32_t *out_cells, float *out_bary,
-                       float *out_dist, uint32_t *out_verts, hipStream_t stream, unsigned max_blocks) {
+void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *kmax, const uint32_t *walk_n,
+                       const uint32_t *out_num, uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
+                       unsigned max_blocks) {
     if (num_rays == 0) return;
     size_t blocks = (num_rays + 3) / 4;           // >= one ray per wave
-    // default: 2 blocks (8 waves) per CU -- enough to hold the write ceiling, and measured 3 % faster per launch
-    // than 8 per CU because the BVH re-trace running beside the fill is less starved (profiles/r01_fill_grid.txt)
+    // default: 2 blocks (8 waves) per CU -- enough to hold the write ceiling, and the latency-bound kernels running
+    // beside the fill are less starved than with 8 per CU (profiles/r01_fill_grid.txt)
     const size_t cap = max_blocks ? max_blocks : 256 * 2;
     if (blocks > cap) blocks = cap;
-    blocks = (blocks + 7) & ~(size_t)7;
-    hipLaunchKernelGGL(k_fill_tails, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, walk_n, out_cells, out_bary,
-                       out_dist, out_verts);
+    hipLaunchKernelGGL(k_fill_range, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, kmax, walk_n,
+                       out_num, out_cells, out_bary, out_dist, out_verts);
+}
+
+// Probe kernel (profiles/r02_overlap_probe.py): a pure write stream with a selectable store flavour --
+// 0 plain, 1 nontemporal, 2 sc1 (write-through, the line is dropped from the XCD's L2), 3 sc0 sc1.
+__global__ __launch_bounds__(256) void k_probe_fill(u32x4 *__restrict__ dst, size_t n16, int flavour) {
+    const u32x4 v = {0u, 0u, 0u, 0u};
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x;   // contiguous span per block
+    const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n16 ? b0 + per : n16;
+    (void)nthreads;
+    for (size_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) {
+        u32x4 *p = dst + i;
+        if (flavour == 0) *p = v;
+        else if (flavour == 1) __builtin_nontemporal_store(v, p);
+        else if (flavour == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    }
+}
+void launch_probe_fill(void *dst, size_t bytes, int flavour, unsigned blocks, hipStream_t stream) {
+    if (!bytes) return;
+    hipLaunchKernelGGL(k_probe_fill, dim3(blocks ? blocks : 512), dim3(256), 0, stream, (u32x4 *)dst, bytes / 16, flavour);
 }
 
 void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
@@ -551,7 +536,7 @@ void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
     // grid padded so that both remaps (runs of XCD_GROUP blocks / one band per XCD) are bijections
     const uint32_t unit = 8 * ((p.debug & 8u) ? (nblk + 7) / 8 : XCD_GROUP);
     const uint32_t grid = (nblk + unit - 1) / unit * unit;
-    hipLaunchKernelGGL(k_trace_walk, dim3(grid), dim3(WALK_BLOCK), WALK_BLOCK * 52 * sizeof(uint32_t), stream, p);
+    hipLaunchKernelGGL(k_trace_walk, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
 }
 
 }  // namespace tn

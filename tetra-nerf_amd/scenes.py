@@ -86,3 +86,93 @@ def inside_out_rays(n: int, seed: int):
     v = rng.normal(size=(n, 3))
     v /= np.linalg.norm(v, axis=-1, keepdims=True)
     return np.ascontiguousarray(o), np.ascontiguousarray(v.astype(np.float32))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Adversarial point clouds (parity tests): what real Tetra-NeRF inputs look like -- COLMAP clouds are
+# clustered on surfaces, near-coplanar, and get jittered copies (tetranerf/scripts/triangulate.py:36-55) --
+# and what breaks walk-style traversals: cospherical points (Qhull slivers / zero-volume tets / ties in t),
+# thin shells, near-duplicate points.
+
+def _mesh_of(pts):
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    return pts, delaunay_cells(pts)
+
+
+def grid_mesh(n: int = 16, jitter: float = 0.0, seed: int = 5):
+    """n^3 lattice in [0,1]^3 (jitter 0: every cube's 8 corners are cospherical -> flat slivers, coplanar faces,
+    rays through lattice edges/vertices tie exactly); jitter > 0 perturbs each coordinate uniformly."""
+    g = np.linspace(0.0, 1.0, n)
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    if jitter > 0:
+        pts = pts + np.random.default_rng(seed).uniform(-jitter, jitter, pts.shape)
+    return _mesh_of(pts)
+
+
+def shells_mesh(n: int = 6000, gap: float = 1e-3, seed: int = 6):
+    """Points on two concentric spheres `gap` apart (plus a few interior points): the band between the shells
+    is filled with needle / sliver tetrahedra whose faces are nearly parallel to tangential rays."""
+    rng = np.random.default_rng(seed)
+    v = rng.normal(size=(n, 3))
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    r = np.where(np.arange(n) % 2 == 0, 0.45, 0.45 - gap)[:, None]
+    pts = 0.5 + r * v
+    inner = 0.5 + 0.2 * (rng.random((n // 20, 3)) - 0.5)
+    return _mesh_of(np.concatenate([pts, inner], 0))
+
+
+def near_duplicates_mesh(n: int = 4000, spacing: float = 1e-7, seed: int = 7):
+    """Uniform cloud in which every fourth point has a twin `spacing` away (a few fp32 ulps): tetrahedra with
+    edges of ~1e-7, i.e. crossings far below the 1e-6 tie window of the pairing stage."""
+    rng = np.random.default_rng(seed)
+    pts = rng.random((n, 3)).astype(np.float32).astype(np.float64)
+    twins = pts[::4] + spacing * rng.choice([-1.0, 1.0], size=(len(pts[::4]), 3))
+    allp = np.concatenate([pts, twins], 0).astype(np.float32)
+    allp = np.unique(allp, axis=0)  # exact fp32 duplicates would make Qhull drop vertices silently
+    rng.shuffle(allp)
+    return _mesh_of(allp)
+
+
+def colmap_like_mesh(n: int = 12000, ratio: float = 0.5, seed: int = 8):
+    """Surface-clustered cloud + jittered copies as scripts/triangulate.py:36-55 makes them: points on a few
+    planes / a sphere with small noise, then `ratio`*n copies offset by |N(s, s/2)| in a random direction
+    (s = a spacing estimate)."""
+    rng = np.random.default_rng(seed)
+    k = n // 4
+    plane1 = np.c_[rng.random((k, 2)), 0.3 + 1e-4 * rng.normal(size=k)]
+    plane2 = np.c_[rng.random(k), 0.7 + 1e-4 * rng.normal(size=k), rng.random(k)]
+    v = rng.normal(size=(k, 3)); v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    sphere = 0.5 + 0.25 * v * (1 + 1e-4 * rng.normal(size=(k, 1)))
+    blob = 0.5 + 0.05 * rng.normal(size=(n - 3 * k, 3))
+    pts = np.concatenate([plane1, plane2, sphere, blob], 0)
+    s = 1.0 / np.cbrt(n)
+    m = int(n * ratio)
+    base = pts[rng.choice(len(pts), m, replace=True)]
+    off = rng.normal(size=(m, 3)); off /= np.linalg.norm(off, axis=-1, keepdims=True)
+    off *= np.abs(rng.normal(s, 0.5 * s, size=(m, 1)))
+    return _mesh_of(np.concatenate([pts, base + off], 0))
+
+
+def vertex_to_vertex_rays(pts: np.ndarray, n: int, seed: int, extend: float = 1.0):
+    """Rays that pass exactly (up to fp32 rounding of the direction) through two mesh vertices a -> b, started
+    `extend` before a: they graze edges and vertices of many tetrahedra (zero edge functions, ties)."""
+    rng = np.random.default_rng(seed)
+    a = pts[rng.integers(0, len(pts), n)].astype(np.float64)
+    b = pts[rng.integers(0, len(pts), n)].astype(np.float64)
+    d = b - a
+    nz = np.linalg.norm(d, axis=-1) > 1e-12
+    d[~nz] = (1.0, 0.0, 0.0)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    o = a - extend * d
+    return np.ascontiguousarray(o.astype(np.float32)), np.ascontiguousarray(d.astype(np.float32))
+
+
+def orbit_rays(width: int, height: int, views: int, center=(0.0, 0.0, 0.0), radius: float = 1.0, fov_y: float = 45.0):
+    """`views` pinhole cameras on a tilted orbit around `center`, all looking at it."""
+    os_, ds_ = [], []
+    for k in range(views):
+        a = 2.0 * math.pi * k / views
+        eye = (center[0] + radius * math.cos(a), center[1] + radius * math.sin(a), center[2] + 0.35 * radius * math.sin(2 * a + 0.5))
+        o, d = pinhole_rays(width, height, eye=eye, lookat=center, fov_y=fov_y)
+        os_.append(o); ds_.append(d)
+    return np.ascontiguousarray(np.concatenate(os_, 0)), np.ascontiguousarray(np.concatenate(ds_, 0))

@@ -135,6 +135,7 @@ class TetrahedraTracer:
             self._check_float_dim3(ray_origins, "ray_origins")
             self._check_float_dim3(ray_directions, "ray_directions")
             R = ray_origins.numel() // 3
+            _check(ray_directions.numel() // 3 == R, "ray_origins and ray_directions must have the same number of rays")
             dev = self._device
             num = torch.empty((R,), dtype=torch.int32, device=dev)
             vis = torch.empty((R, M), dtype=torch.int32, device=dev)
@@ -175,6 +176,7 @@ class TetrahedraTracer:
         if ray_index is not None:
             _check_input(ray_index, "ray_index")
             _check(ray_index.dtype == torch.int32 and ray_index.dim() == 1, "ray_index must be int32 [r]")
+            _check(ray_index.device == self._device, "ray_index must be on the same device")
             R = ray_index.size(0)
         _check(distances.dim() == 2 and distances.size(0) == R,
                "distances must be of [num_rays, num_samples_per_ray] shape")
@@ -191,16 +193,18 @@ class TetrahedraTracer:
         matched_cells = torch.empty((R, S), dtype=torch.int32, device=dev)
         barycentric_coordinates_out = torch.empty((R, S, 3), dtype=torch.float32, device=dev)
         vertex_indices_out = torch.empty((R, S, 4), dtype=torch.int32, device=dev)
-        if ray_index is None:
-            _lib.check(self._lib.tn_find_matched_cells(
-                R, S, M, _ptr(num_visited_cells), _ptr(visited_cells), _ptr(hit_distances),
-                _ptr(barycentric_coordinates), _ptr(distances), _ptr(vertex_indices), _ptr(matched_cells),
-                _ptr(vertex_indices_out), _ptr(mask), _ptr(barycentric_coordinates_out), _stream(dev)))
-        else:
-            _lib.check(self._lib.tn_find_matched_cells_indexed(
-                R, S, M, _ptr(ray_index), _ptr(num_visited_cells), _ptr(visited_cells), _ptr(hit_distances),
-                _ptr(barycentric_coordinates), _ptr(distances), _ptr(vertex_indices), _ptr(matched_cells),
-                _ptr(vertex_indices_out), _ptr(mask), _ptr(barycentric_coordinates_out), _stream(dev)))
+        # the C entry points take no device argument: launch with the tracer's device current (its stream, its pointers)
+        with torch.cuda.device(dev):
+            if ray_index is None:
+                _lib.check(self._lib.tn_find_matched_cells(
+                    R, S, M, _ptr(num_visited_cells), _ptr(visited_cells), _ptr(hit_distances),
+                    _ptr(barycentric_coordinates), _ptr(distances), _ptr(vertex_indices), _ptr(matched_cells),
+                    _ptr(vertex_indices_out), _ptr(mask), _ptr(barycentric_coordinates_out), _stream(dev)))
+            else:
+                _lib.check(self._lib.tn_find_matched_cells_indexed(
+                    R, S, M, _ptr(ray_index), _ptr(num_visited_cells), _ptr(visited_cells), _ptr(hit_distances),
+                    _ptr(barycentric_coordinates), _ptr(distances), _ptr(vertex_indices), _ptr(matched_cells),
+                    _ptr(vertex_indices_out), _ptr(mask), _ptr(barycentric_coordinates_out), _stream(dev)))
         return {
             "cell_indices": matched_cells,
             "vertex_indices": vertex_indices_out,
@@ -210,14 +214,16 @@ class TetrahedraTracer:
 
     # -- additions (not in the reference surface) ------------------------------------------
     def trace_stats(self):
-        """Counters of the last trace_rays call: walk / general / serial-literal / overflow rays."""
+        """Counters of the last trace_rays call: rays certified by the walk / all others (literal pairing of the log +
+        BVH re-trace) / rays whose pairing ran the serial literal branch / rays that overflowed M-1 hits."""
         arr = (C.c_uint64 * 4)()
         _lib.check(self._lib.tn_trace_stats(self._h, C.byref(arr)))
         return {"walk": arr[0], "general": arr[1], "serial": arr[2], "overflow": arr[3]}
 
     def flag_reasons(self):
-        """Why the walk handed rays of the last trace_rays over (reason code 1..12 -> count); 13 = chains
-        re-walked and paired literally (order not certified), 14 = re-walked chains sent on to the BVH path."""
+        """Why the walk did not certify rays of the last trace_rays (reason code 1..12 -> count; include/tetranerf_hip.h);
+        7 = sound chain with a gap below eps / a tie / an inversion, 13 = such rays whose logged hits went through the
+        literal sort + pairing (the others were re-traced through the BVH)."""
         arr = (C.c_uint64 * 16)()
         _lib.check(self._lib.tn_trace_flag_reasons(self._h, C.byref(arr)))
         return {k: int(arr[k]) for k in range(1, 15) if arr[k]}
