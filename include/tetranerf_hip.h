@@ -140,6 +140,21 @@ int tn_interpolate_values_backward_rows(uint32_t interpolation_dim, uint32_t num
                                         const uint32_t *vertex_indices, const float *barycentric,
                                         const float *grad_rows, float *field_grad_out, void *stream);
 
+/* Vertex-major variants (additions): the reference keeps its field feature-major [F,V] (checkpoint layout,
+ * model.py:269-271), which makes every vertex row a 4-byte gather; these take a [V,F] shadow copy that the caller
+ * refreshes once per field version with tn_transpose_f32 -- no per-call O(V) transposition and no temporaries.
+ *   tn_transpose_f32: in [rows, cols] -> out [cols, rows]
+ *   tn_interpolate_values_vm: field_vm f32 [V,F]; result f32 [F,n] as tn_interpolate_values
+ *   tn_interpolate_values_backward_vm: grad_rows f32 [n,F]; field_grad_vm f32 [V,F] is ACCUMULATED into
+ *     (zero it first; the adjoint of tn_transpose_f32 brings it back to [F,V]) */
+int tn_transpose_f32(uint32_t rows, uint32_t cols, const float *in, float *out, void *stream);
+int tn_interpolate_values_vm(uint32_t interpolation_dim, uint32_t num_values, uint32_t field_dim,
+                             const uint32_t *vertex_indices, const float *barycentric, const float *field_vm,
+                             float *result, void *stream);
+int tn_interpolate_values_backward_vm(uint32_t interpolation_dim, uint32_t num_values, uint32_t field_dim,
+                                      const uint32_t *vertex_indices, const float *barycentric,
+                                      const float *grad_rows, float *field_grad_vm, void *stream);
+
 /* Test aid: run only the dedupe / pairing / tail-fill stage
  * (post_process_tetrahedra, src/optix/optix_trace_rays.cu:110-266) on caller-supplied
  * sorted hit rows: hit_count u32 [R], hit_ids u32 [R,M], hit_t f32 [R,M], hit_uv f32 [R,M,2]. */
@@ -239,6 +254,30 @@ int tn_mlp_get_mode(void);
 int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, const float *rgb, const float *edges,
                  float background, float *out_rgb, float *out_acc, float *out_depth, float *out_weights,
                  void *stream);
+
+/* ---- training adjoints of the MLP and the composite (PyTorch autograd in the reference:
+ * the trainer back-propagates through nerfstudio's MLP / renderers, model.py:602-638).
+ * tn_mlp_backward recomputes the forward pass (nothing is saved by tn_mlp_forward_gather) and runs the reverse
+ * network on the fp32 matrix cores.  All buffers are FEATURE-MAJOR [F, n] device memory owned by the caller:
+ *   x0 [64,n] gathered features; h1..h4 [128,n] layer outputs after ReLU; d1..d4 [128,n] gradients w.r.t. the
+ *   pre-activations of mlp_base layers 0..2 and of mlp_head; dhead [4,n] = d sigma_raw, d rgb_raw[0..2];
+ *   dx0 [64,n] = gradient of the gathered features (feed it to tn_interpolate_values_backward).
+ * field_vm is the field vertex-major [V,64] (tn_transpose_f32); d_sigma f32 [n], d_rgb f32 [n,3].
+ * Weight gradients: dW_l = d_l * (input of layer l)^T via tn_mlp_weight_grad:
+ *   dw f32 [128, rows_b] += a [128,n] * b [rows_b,n]^T, db f32 [128] += row sums of a (nullable); rows_b in {64,128}. */
+typedef struct tn_mlp_backward_buffers {
+    float *x0, *h1, *h2, *h3, *h4, *d1, *d2, *d3, *d4, *dhead, *dx0;
+} tn_mlp_backward_buffers;
+int tn_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices, const float *barycentric,
+                    const float *field_vm, const float *dirs, const tn_mlp_weights *weights, const float *d_sigma,
+                    const float *d_rgb, const tn_mlp_backward_buffers *buffers, void *stream);
+int tn_mlp_weight_grad(size_t n, uint32_t rows_b, const float *a, const float *b, float *dw, float *db, void *stream);
+
+/* adjoint of tn_composite w.r.t. sigma [R,S] and rgb [R,S,3], given the gradients of the rendered rgb [R,3] and
+ * accumulation [R] (either nullable); the median depth carries no gradient. */
+int tn_composite_backward(size_t num_rays, uint32_t num_samples, const float *sigma, const float *rgb, const float *edges,
+                          float background, const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb,
+                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -33,12 +33,12 @@ for cfg, npts, seed in (("c2", 15000, 0), ("c4", 45000, 2), ("c5", 150000, 3)):
         out = tr.trace_rays(o, d, M); k = out["num_visited_cells"]; del out; return k
     inter = int(run().sum()); R = o.shape[0]; gb = R * (28 + 52 * M) / 1e9
     print(f"{cfg}: {len(cells)} tets, {R} rays, {inter} intersections, paths {tr.trace_stats()} reasons {tr.flag_reasons()}", flush=True)
-    for opts in ({}, {"prefill": 1}, {"fill_blocks": 384}, {"fill_blocks": 1024}, {"seg_blocks": 512}, {"seg_blocks": 1792},
-                 {"literal": 0}):
+    for opts in ({}, {"seg_unroll": 2}, {"seg_blocks": 512}, {"seg_blocks": 1024}, {"seg_unroll": 2, "seg_blocks": 768},
+                 {"seg_unroll": 2, "seg_blocks": 1792}, {"fill_blocks": 1024}):
         for k, v in opts.items(): tr.set_option(k, v)
         ms = timed(run)
         print(f"{cfg} {opts}: {ms:.3f} ms/frame = {gb/ms:.2f} TB/s = {gb/ms/8*100:.1f} % of 8 TB/s", flush=True)
-        for k in opts: tr.set_option(k, 1 if k == "literal" else 0)
+        for k in opts: tr.set_option(k, 4 if k == "seg_unroll" else 0)
     tr.set_option("dense_tails", 0)
     ms = timed(run); print(f"{cfg} segments only (dense_tails=0): {ms:.3f} ms/frame", flush=True)
     tr.set_option("dense_tails", 1)

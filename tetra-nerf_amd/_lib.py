@@ -17,9 +17,11 @@ SYMBOLS = (
     "tn_num_faces", "tn_get_faces", "tn_trace_rays", "tn_trace_rays_triangles", "tn_find_tetrahedra",
     "tn_find_matched_cells", "tn_find_matched_cells_indexed",
     "tn_interpolate_values", "tn_interpolate_values_backward", "tn_interpolate_values_backward_rows",
+    "tn_transpose_f32", "tn_interpolate_values_vm", "tn_interpolate_values_backward_vm",
     "tn_postprocess_hits", "tn_postprocess_hits_tables",
     "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_set_mode", "tn_mlp_get_mode",
     "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
+    "tn_mlp_backward", "tn_mlp_weight_grad", "tn_composite_backward",
 )
 
 _lib = None
@@ -54,6 +56,9 @@ def load():
     lib.tn_interpolate_values.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
     lib.tn_interpolate_values_backward.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
     lib.tn_interpolate_values_backward_rows.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
+    lib.tn_transpose_f32.argtypes = [u32, u32, vp, vp, vp]
+    lib.tn_interpolate_values_vm.argtypes = [u32, u32, u32, vp, vp, vp, vp, vp]
+    lib.tn_interpolate_values_backward_vm.argtypes = [u32, u32, u32, vp, vp, vp, vp, vp]
     lib.tn_postprocess_hits.argtypes = [vp, sz, u32] + [vp] * 10
     lib.tn_postprocess_hits_tables.argtypes = [i32, sz, u32] + [vp] * 12
     lib.tn_trace_stats.argtypes = [vp, C.POINTER(C.c_uint64 * 4)]
@@ -66,6 +71,9 @@ def load():
     lib.tn_gather_uint32.argtypes = [i32, u32, u32, vp, vp, vp, vp]
     lib.tn_scatter_ema_uint32.argtypes = [i32, u32, u32, vp, C.c_double, vp, vp, vp]
     lib.tn_composite.argtypes = [sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
+    lib.tn_mlp_backward.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tn_mlp_weight_grad.argtypes = [sz, u32, vp, vp, vp, vp, vp]
+    lib.tn_composite_backward.argtypes = [sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("tn_last_error", "tn_version", "tn_num_faces"):

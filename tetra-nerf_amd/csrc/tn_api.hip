@@ -66,7 +66,8 @@ struct tn_tracer {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
     unsigned fill_blocks = 0;            // cap of the tail-fill grid (0 = default 2 blocks per CU); ablation knob
-    unsigned seg_blocks = 0;             // cap of the segment-writer grid (0 = default 7 blocks per CU); ablation knob
+    unsigned seg_blocks = 0;             // cap of the segment-writer grid (0 = what the VGPR budget admits); ablation knob
+    unsigned seg_unroll = 4;             // segment writer: chunks of 8 hits per ray per iteration (4 or 2); ablation knob
     tn::DevBuf<tn::WalkVar> vars;
     tn::DevBuf<float> hull_nodes, hull_tris;
     tn::DevWideBvh bvh;
@@ -326,6 +327,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             auto launch_segments = [&](size_t base, size_t n, hipStream_t st) {
                 tn::WriteParams q{};
                 q.num_rays = n; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
+                q.unroll = t->seg_unroll;
                 q.walk_n = t->walk_n.p + base;
                 q.hit_log = t->hit_log.p;
                 q.vars = t->mesh.vars;
@@ -512,6 +514,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && (std::strcmp(name, "rewalk") == 0 || std::strcmp(name, "rewalk_min") == 0)) {}  // round-1 knobs: no effect
         else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
         else if (name && std::strcmp(name, "seg_blocks") == 0) t->seg_blocks = (unsigned)value;
+        else if (name && std::strcmp(name, "seg_unroll") == 0) t->seg_unroll = value == 2 ? 2u : 4u;
         else if (name && std::strcmp(name, "log_cap_mb") == 0) t->log_cap_bytes = (size_t)(value < 1 ? 1 : value) << 20;
         else throw tn::Error(std::string("unknown option ") + (name ? name : "(null)"));
     });
@@ -574,6 +577,31 @@ int tn_interpolate_values_backward_rows(uint32_t D, uint32_t V, uint32_t n, uint
     });
 }
 
+/* vertex-major variants: the caller keeps a [V, Fd] shadow of the field (tn_transpose_f32 makes it, once per field
+ * version) -- no per-call O(V) transposition, no temporaries */
+int tn_transpose_f32(uint32_t rows, uint32_t cols, const float *in, float *out, void *stream_) {
+    return guarded([&] {
+        tn::launch_transpose(in, out, rows, cols, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_interpolate_values_vm(uint32_t D, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
+                             const float *field_vm, float *result, void *stream_) {
+    return guarded([&] {
+        tn::launch_interpolate_values_vm(D, n, Fd, vi, bc, field_vm, result, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_interpolate_values_backward_vm(uint32_t D, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
+                                      const float *grad_rows, float *field_grad_vm, void *stream_) {
+    return guarded([&] {
+        tn::launch_interpolate_values_backward_vm(D, n, Fd, vi, bc, grad_rows, field_grad_vm, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
 static std::atomic<int> g_mlp_mode{0};
 
 int tn_mlp_set_mode(int mode) {
@@ -609,6 +637,38 @@ int tn_mlp_forward_gather(size_t n, uint32_t samples_per_ray, uint32_t num_verti
         (g_mlp_mode.load() ? tn::launch_mlp_forward_x3 : tn::launch_mlp_forward)(
             n, samples_per_ray, n / samples_per_ray, nullptr, vertex_indices, barycentric, field, num_vertices, dirs, m, sigma, rgb,
             (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices, const float *barycentric,
+                    const float *field_vm, const float *dirs, const tn_mlp_weights *w, const float *d_sigma,
+                    const float *d_rgb, const tn_mlp_backward_buffers *b, void *stream_) {
+    return guarded([&] {
+        if (n == 0) return;
+        if (!w || !b || !vertex_indices || !barycentric || !field_vm || !dirs || !d_sigma || !d_rgb) throw tn::Error("null pointer");
+        if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
+        tn::MlpWeights m{w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
+        tn::MlpBackwardBuffers bb{b->x0, b->h1, b->h2, b->h3, b->h4, b->d1, b->d2, b->d3, b->d4, b->dhead, b->dx0};
+        tn::launch_mlp_backward(n, samples_per_ray, vertex_indices, barycentric, field_vm, dirs, m, d_sigma, d_rgb, bb,
+                                (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_mlp_weight_grad(size_t n, uint32_t rows_b, const float *a, const float *b, float *dw, float *db, void *stream_) {
+    return guarded([&] {
+        tn::launch_weight_grad(n, rows_b, a, b, dw, db, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_composite_backward(size_t num_rays, uint32_t num_samples, const float *sigma, const float *rgb, const float *edges,
+                          float background, const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb,
+                          void *stream_) {
+    return guarded([&] {
+        tn::launch_composite_backward(num_rays, num_samples, sigma, rgb, edges, background, d_out_rgb, d_out_acc, d_sigma,
+                                      d_rgb, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }

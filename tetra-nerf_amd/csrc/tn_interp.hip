@@ -26,11 +26,13 @@ namespace {
 constexpr int TS = 64;   // samples per tile
 constexpr int TP = 65;   // padded LDS row (floats)
 
-// [rows, cols] -> [cols, rows], 64x64 tiles through LDS
+// [rows, cols] -> [cols, rows], 64x64 tiles through LDS.  1-D grid over the tiles (row-tile major): neither dimension
+// is bounded by the 65535 blocks of gridDim.y (a [64, V] field with V > 4.19 M vertices has that many column tiles).
 __global__ __launch_bounds__(256) void k_transpose(const float *__restrict__ in, float *__restrict__ out,
                                                    uint32_t rows, uint32_t cols) {
     __shared__ float tile[64][TP];
-    const uint32_t c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const uint32_t tiles_c = (cols + 63) / 64;
+    const uint32_t c0 = (blockIdx.x % tiles_c) * 64, r0 = (blockIdx.x / tiles_c) * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int r = ty; r < 64; r += 4)
         if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = in[(size_t)(r0 + r) * cols + c0 + tx];
@@ -98,6 +100,82 @@ __global__ __launch_bounds__(256) void k_interp_fwd(uint32_t n, uint32_t Fd, con
     }
 }
 
+// Forward, Fd = 64 (the model's field): one wavefront = 64 samples in 8 iterations of 8 samples.  Lane (q = lane & 7,
+// s = lane >> 3) owns features {4q..4q+3} and {32+4q..32+4q+3} of samples base + 8s + it: the 8 lanes of a sample read
+// a vertex row as two instructions of 8 x 16 B = one full 128-byte line each (8 line requests per sample for its
+// 4 vertices; the 32-samples-per-wave kernel above issues 64, one per lane per 16-byte piece, and was bound by the
+// L1 request rate, not by HBM), 8 row loads are in flight per lane, and every feature row of the reference's
+// [Fd, n] result receives 8 consecutive samples = 32 B per lane, 256 contiguous bytes per wave.  Same summation
+// order as the reference -> bit-identical to the oracle.
+template <int D>
+__global__ __launch_bounds__(256) void k_interp_fwd64(uint32_t n, const uint32_t *__restrict__ vi,
+                                                      const float *__restrict__ bc, const float *__restrict__ fieldT,
+                                                      float *__restrict__ result) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = (uint32_t)lane & 7u, sg = (uint32_t)lane >> 3;
+    const uint32_t ntiles = (n + 63) / 64;
+    const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t tix = wave0; tix < ntiles; tix += nwaves) {
+        const uint32_t base = tix * 64 + 8 * sg;
+        float acc[8][8];
+        // the rows of the previous sample: consecutive samples of a ray mostly lie in the same tetrahedron, and the
+        // vertex rows (1 KB per sample out of the Infinity Cache -- the field does not fit an XCD's L2) are what
+        // bounds this kernel, so a row that repeats is taken from registers
+        uint32_t pv[D];
+        float4 p0[D], p1[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) { pv[k] = TN_EMPTY; p0[k] = make_float4(0.f, 0.f, 0.f, 0.f); p1[k] = p0[k]; }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[it][j] = 0.f;
+            const uint32_t smp = base + it;
+            const bool ok = smp < n;
+            uint32_t v[D];
+            float b[D - 1];
+#pragma unroll
+            for (int k = 0; k < D; ++k) v[k] = ok ? vi[(size_t)smp * D + k] : TN_EMPTY;
+#pragma unroll
+            for (int k = 0; k < D - 1; ++k) b[k] = ok ? bc[(size_t)smp * (D - 1) + k] : 0.f;
+            float w = 0.f;
+#pragma unroll
+            for (int k = 0; k < D - 1; ++k) w += b[k];
+            const float w0 = 1.0f - w;
+            // reference order: the D-1 weighted vertices first, the implicit-weight vertex last
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const int kk = k < D - 1 ? k + 1 : 0;
+                const float wk = k < D - 1 ? b[k < D - 1 ? k : 0] : w0;
+                if (v[kk] != TN_EMPTY) {
+                    float4 x0 = p0[kk], x1 = p1[kk];
+                    if (v[kk] != pv[kk]) {
+                        const float4 *row = reinterpret_cast<const float4 *>(fieldT + (size_t)v[kk] * 64);
+                        x0 = row[q]; x1 = row[8 + q];
+                        pv[kk] = v[kk]; p0[kk] = x0; p1[kk] = x1;
+                    }
+                    acc[it][0] += wk * x0.x; acc[it][1] += wk * x0.y; acc[it][2] += wk * x0.z; acc[it][3] += wk * x0.w;
+                    acc[it][4] += wk * x1.x; acc[it][5] += wk * x1.y; acc[it][6] += wk * x1.z; acc[it][7] += wk * x1.w;
+                }
+            }
+        }
+        const bool wide = (n & 3u) == 0 && base + 8 <= n;   // 16-byte aligned rows, all 8 samples valid
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t f = (j < 4 ? 4 * q + j : 32 + 4 * q + (j - 4));
+            float *dst = result + (size_t)f * n + base;
+            if (wide) {
+                reinterpret_cast<float4 *>(dst)[0] = make_float4(acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
+                reinterpret_cast<float4 *>(dst)[1] = make_float4(acc[4][j], acc[5][j], acc[6][j], acc[7][j]);
+            } else {
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    if (base + it < n) dst[it] = acc[it][j];
+            }
+        }
+    }
+}
+
 // Backward: one wavefront = 64 consecutive samples, LANE = FEATURE.  The incoming gradient is read
 // sample-major ([n, Fd] rows: one coalesced 256-B load per sample at Fd = 64); vertex ids and weights
 // are wave-uniform and come through scalar loads; consecutive samples with the same vertex tuple
@@ -159,16 +237,49 @@ __global__ __launch_bounds__(256) void k_interp_bwd(uint32_t n, uint32_t Fd, con
     }
 }
 
+// stream-ordered temporary, released when the scope is left (also when a launch check throws)
+struct AsyncBuf {
+    float *p = nullptr;
+    hipStream_t s;
+    AsyncBuf(size_t floats, hipStream_t stream) : s(stream) {
+        if (floats) TN_HIP(hipMallocAsync((void **)&p, floats * sizeof(float), stream));
+    }
+    ~AsyncBuf() { if (p) (void)hipFreeAsync(p, s); }
+    AsyncBuf(const AsyncBuf &) = delete;
+    AsyncBuf &operator=(const AsyncBuf &) = delete;
+};
+
+// fieldT: the field vertex-major [V, Fd]
 template <int D>
-void run_fwd(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc, const float *field,
-             float *result, hipStream_t stream) {
-    float *fieldT = nullptr;
-    TN_HIP(hipMallocAsync((void **)&fieldT, (size_t)V * Fd * sizeof(float), stream));
-    hipLaunchKernelGGL(k_transpose, dim3((V + 63) / 64, (Fd + 63) / 64), dim3(256), 0, stream, field, fieldT, Fd, V);
+void run_fwd_vm(uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc, const float *fieldT, float *result,
+                hipStream_t stream) {
+    if (Fd == 64) {
+        const uint32_t nblocks = ((n + 63) / 64 + 3) / 4;  // 4 waves (256 samples) per block
+        const unsigned grid = nblocks < 256u * 16u ? nblocks : 256u * 16u;
+        hipLaunchKernelGGL(k_interp_fwd64<D>, dim3(grid), dim3(256), 0, stream, n, vi, bc, fieldT, result);
+        return;
+    }
     const uint32_t nblocks = ((n + 31) / 32 + 3) / 4;  // 4 waves (128 samples) per block
     const unsigned grid = nblocks < 256u * 16u ? nblocks : 256u * 16u;
     hipLaunchKernelGGL(k_interp_fwd<D>, dim3(grid), dim3(256), 0, stream, n, Fd, vi, bc, fieldT, result);
-    TN_HIP(hipFreeAsync(fieldT, stream));
+}
+
+// gradT: vertex-major [V, Fd] gradient, ACCUMULATED into; rows: gradient rows [n, Fd]
+template <int D>
+void run_bwd_vm(uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc, const float *rows, float *gradT,
+                hipStream_t stream) {
+    if (n == 0) return;
+    const uint32_t nblocks = ((n + TS - 1) / TS + 3) / 4;  // 4 waves per block
+    const unsigned grid = nblocks < 256u * 32u ? nblocks : 256u * 32u;
+    hipLaunchKernelGGL(k_interp_bwd<D>, dim3(grid), dim3(256), 0, stream, n, Fd, vi, bc, rows, gradT);
+}
+
+template <int D>
+void run_fwd(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc, const float *field,
+             float *result, hipStream_t stream) {
+    AsyncBuf fieldT((size_t)V * Fd, stream);
+    launch_transpose(field, fieldT.p, Fd, V, stream);
+    run_fwd_vm<D>(n, Fd, vi, bc, fieldT.p, result, stream);
 }
 
 // rows_major: grad_in is [n, Fd] (what autograd hands over for a contiguous [..., Fd] gradient);
@@ -176,29 +287,26 @@ void run_fwd(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const floa
 template <int D>
 void run_bwd(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc, const float *grad_in,
              bool rows_major, float *field_grad, hipStream_t stream) {
-    float *gradT = nullptr, *rows = nullptr;
-    TN_HIP(hipMallocAsync((void **)&gradT, (size_t)V * Fd * sizeof(float), stream));
-    TN_HIP(hipMemsetAsync(gradT, 0, (size_t)V * Fd * sizeof(float), stream));
+    AsyncBuf gradT((size_t)V * Fd, stream);
+    TN_HIP(hipMemsetAsync(gradT.p, 0, (size_t)V * Fd * sizeof(float), stream));
     if (n) {
+        AsyncBuf rows(rows_major ? 0 : (size_t)n * Fd, stream);
         if (!rows_major) {
-            TN_HIP(hipMallocAsync((void **)&rows, (size_t)n * Fd * sizeof(float), stream));
-            hipLaunchKernelGGL(k_transpose, dim3((n + 63) / 64, (Fd + 63) / 64), dim3(256), 0, stream, grad_in, rows, Fd, n);
-            grad_in = rows;
+            launch_transpose(grad_in, rows.p, Fd, n, stream);
+            grad_in = rows.p;
         }
-        const uint32_t nblocks = ((n + TS - 1) / TS + 3) / 4;  // 4 waves per block
-        const unsigned grid = nblocks < 256u * 32u ? nblocks : 256u * 32u;
-        hipLaunchKernelGGL(k_interp_bwd<D>, dim3(grid), dim3(256), 0, stream, n, Fd, vi, bc, grad_in, gradT);
-        if (rows) TN_HIP(hipFreeAsync(rows, stream));
+        run_bwd_vm<D>(n, Fd, vi, bc, grad_in, gradT.p, stream);
     }
-    hipLaunchKernelGGL(k_transpose, dim3((Fd + 63) / 64, (V + 63) / 64), dim3(256), 0, stream, gradT, field_grad, V, Fd);
-    TN_HIP(hipFreeAsync(gradT, stream));
+    launch_transpose(gradT.p, field_grad, V, Fd, stream);
 }
 
 }  // namespace
 
 void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols, hipStream_t stream) {
     if (rows == 0 || cols == 0) return;
-    hipLaunchKernelGGL(k_transpose, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, stream, in, out, rows, cols);
+    const size_t tiles = (size_t)((cols + 63) / 64) * ((rows + 63) / 64);
+    if (tiles > 0x7FFFFFFFull) throw Error("transpose: matrix too large");
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)tiles), dim3(256), 0, stream, in, out, rows, cols);
 }
 
 void launch_interpolate_values(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
@@ -209,6 +317,30 @@ void launch_interpolate_values(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, 
         case 3: run_fwd<3>(V, n, Fd, vi, bc, field, result, stream); break;
         case 4: run_fwd<4>(V, n, Fd, vi, bc, field, result, stream); break;
         case 6: run_fwd<6>(V, n, Fd, vi, bc, field, result, stream); break;
+        default: throw Error("Unsupported interpolation dimension with value " + std::to_string(D));
+    }
+}
+
+void launch_interpolate_values_vm(uint32_t D, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
+                                  const float *fieldT, float *result, hipStream_t stream) {
+    if (n == 0 || Fd == 0) return;
+    switch (D) {
+        case 2: run_fwd_vm<2>(n, Fd, vi, bc, fieldT, result, stream); break;
+        case 3: run_fwd_vm<3>(n, Fd, vi, bc, fieldT, result, stream); break;
+        case 4: run_fwd_vm<4>(n, Fd, vi, bc, fieldT, result, stream); break;
+        case 6: run_fwd_vm<6>(n, Fd, vi, bc, fieldT, result, stream); break;
+        default: throw Error("Unsupported interpolation dimension with value " + std::to_string(D));
+    }
+}
+
+void launch_interpolate_values_backward_vm(uint32_t D, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
+                                           const float *grad_rows, float *gradT, hipStream_t stream) {
+    if (n == 0 || Fd == 0) return;
+    switch (D) {
+        case 2: run_bwd_vm<2>(n, Fd, vi, bc, grad_rows, gradT, stream); break;
+        case 3: run_bwd_vm<3>(n, Fd, vi, bc, grad_rows, gradT, stream); break;
+        case 4: run_bwd_vm<4>(n, Fd, vi, bc, grad_rows, gradT, stream); break;
+        case 6: run_bwd_vm<6>(n, Fd, vi, bc, grad_rows, gradT, stream); break;
         default: throw Error("Unsupported interpolation dimension with value " + std::to_string(D));
     }
 }

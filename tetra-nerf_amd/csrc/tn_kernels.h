@@ -66,6 +66,7 @@ struct WriteParams {
     size_t num_rays;
     uint32_t M;
     uint32_t dense_tails;      // 0: slots >= num_visited are left unwritten (non-reference option)
+    uint32_t unroll;           // chunks of 8 hits per ray per iteration: 4 (default) or 2
     const uint32_t *walk_n;
     const uint4 *hit_log;
     const WalkVar *vars;
@@ -97,6 +98,13 @@ void launch_interpolate_values_backward(uint32_t D, uint32_t V, uint32_t n, uint
                                         const float *bc, const float *grad_in, bool rows_major, float *field_grad,
                                         hipStream_t stream);
 
+// the same on a VERTEX-MAJOR field [V, Fd] / into a vertex-major gradient (accumulated; the caller zeroes it): no
+// per-call transposition and no temporaries -- what a caller that keeps a vertex-major shadow of the field uses
+void launch_interpolate_values_vm(uint32_t D, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
+                                  const float *fieldT, float *result, hipStream_t stream);
+void launch_interpolate_values_backward_vm(uint32_t D, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
+                                           const float *grad_rows, float *gradT, hipStream_t stream);
+
 // shallow MLP + heads (tn_mlp.hip); all weights in nn.Linear layout [out, in] row-major, fp32
 struct MlpWeights {
     const float *w1, *b1;  // [128,64],  [128]   mlp_base layer 0
@@ -115,6 +123,23 @@ void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, con
 void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
                         const float *bc, const float *field, uint32_t num_vertices, const float *dirs,
                         const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream);
+// training adjoint of the MLP (tn_mlp_bwd.hip).  All buffers feature-major [F, n] device memory owned by the caller.
+struct MlpBackwardBuffers {
+    float *x0;                 // [64, n]   gathered features (layer-1 input)
+    float *h1, *h2, *h3, *h4;  // [128, n]  layer outputs after ReLU (inputs of the next layer's weight gradient)
+    float *d1, *d2, *d3, *d4;  // [128, n]  gradients w.r.t. the pre-activations of layers 1, 2, 3 and the head layer
+    float *dhead;              // [4, n]    d sigma_raw, d rgb_raw[0..2]
+    float *dx0;                // [64, n]   gradient w.r.t. the gathered features
+};
+// recompute + dX chain: field_vm is the field vertex-major [V, 64]; d_sigma [n], d_rgb [n, 3]
+void launch_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vi, const float *bc, const float *field_vm,
+                         const float *dirs, const MlpWeights &w, const float *d_sigma, const float *d_rgb,
+                         const MlpBackwardBuffers &b, hipStream_t stream);
+// dW[128, rows_b] += A[128, n] * B[rows_b, n]^T, db[128] += row sums of A (db nullable); rows_b in {64, 128}
+void launch_weight_grad(size_t n, uint32_t rows_b, const float *A, const float *B, float *dW, float *db, hipStream_t stream);
+// adjoint of launch_composite: d sigma [R,S], d rgb [R,S,3] from the gradients of the rendered rgb / accumulation
+void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
+                               const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb, hipStream_t stream);
 void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols, hipStream_t stream);
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
                       float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream);

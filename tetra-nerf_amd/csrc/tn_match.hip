@@ -62,39 +62,64 @@ __global__ __launch_bounds__(64) void k_find_matched(size_t R, uint32_t S, uint3
         __syncthreads();
 
         if (ascending) {
-            for (uint32_t base = 0; base < S; base += 64) {
-                const uint32_t j = base + lane;
-                if (j >= S) break;
-                const float cur = srow[j];
-                // first p with pmax[p] >= cur  (== first p with t_out[p] >= cur)
-                uint32_t lo = 0, hi = n;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (pmax[mid] < cur) lo = mid + 1; else hi = mid;
+            // four sample chunks of 64 per iteration: their searches (LDS) and segment gathers (global) are
+            // independent, so the dependent chain search -> gather -> store is paid once per 256 samples
+            constexpr int UM = 4;
+            uint32_t top = 1;                       // largest power of two <= n (0 for n == 0)
+            while ((top << 1) <= n && (top << 1) != 0) top <<= 1;
+            if (n == 0) top = 0;
+            for (uint32_t base = 0; base < S; base += 64 * UM) {
+                float cur[UM];
+                uint32_t p[UM];
+#pragma unroll
+                for (int u = 0; u < UM; ++u) {
+                    const uint32_t j = base + 64 * u + lane;
+                    cur[u] = j < S ? srow[j] : 0.f;
+                    p[u] = 0;
                 }
-                const uint32_t p = lo;
-                uint8_t mk = 0;
-                uint32_t cell = TN_EMPTY;
-                uint4 vv = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
-                float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-                if (p < n && tin[p] <= cur) {
-                    const size_t g = src * M + p;
-                    const float t_in = tin[p], t_out = drow[p].y;
-                    mk = 1;
-                    cell = visited[g];
-                    vv = *reinterpret_cast<const uint4 *>(verts + 4 * g);
-                    const float mult = (cur - t_in) / (t_out - t_in);
-                    const float2 *bp = reinterpret_cast<const float2 *>(bary + 6 * g);
-                    const float2 q0 = bp[0], q1 = bp[1], q2 = bp[2];  // c1.xyz = q0.x q0.y q1.x ; c2.xyz = q1.y q2.x q2.y
-                    b0 = (1 - mult) * q0.x + mult * q1.y;
-                    b1 = (1 - mult) * q0.y + mult * q2.x;
-                    b2 = (1 - mult) * q1.x + mult * q2.y;
+                // p = number of segments whose running-max t_out is below the sample = first p with pmax[p] >= cur
+                for (uint32_t bit = top; bit > 0; bit >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < UM; ++u)
+                        if (p[u] + bit <= n && pmax[p[u] + bit - 1] < cur[u]) p[u] += bit;
                 }
-                const size_t o = ray * S + j;
-                mask_out[o] = mk;
-                cells_out[o] = cell;
-                *reinterpret_cast<uint4 *>(verts_out + 4 * o) = vv;
-                bary_out[3 * o] = b0; bary_out[3 * o + 1] = b1; bary_out[3 * o + 2] = b2;
+                uint8_t mk[UM];
+                uint32_t cell[UM];
+                uint4 vv[UM];
+                float t_in[UM], t_out[UM];
+                float2 q0[UM], q1[UM], q2[UM];
+#pragma unroll
+                for (int u = 0; u < UM; ++u) {
+                    const uint32_t j = base + 64 * u + lane;
+                    mk[u] = 0; cell[u] = TN_EMPTY; vv[u] = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
+                    t_in[u] = 0.f; t_out[u] = 1.f; q0[u] = q1[u] = q2[u] = make_float2(0.f, 0.f);
+                    if (j < S && p[u] < n && tin[p[u]] <= cur[u]) {
+                        const size_t g = src * M + p[u];
+                        mk[u] = 1;
+                        t_in[u] = tin[p[u]]; t_out[u] = drow[p[u]].y;
+                        cell[u] = visited[g];
+                        vv[u] = *reinterpret_cast<const uint4 *>(verts + 4 * g);
+                        const float2 *bp = reinterpret_cast<const float2 *>(bary + 6 * g);
+                        q0[u] = bp[0]; q1[u] = bp[1]; q2[u] = bp[2];  // c1.xyz = q0.x q0.y q1.x ; c2.xyz = q1.y q2.x q2.y
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UM; ++u) {
+                    const uint32_t j = base + 64 * u + lane;
+                    if (j >= S) continue;
+                    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+                    if (mk[u]) {
+                        const float mult = (cur[u] - t_in[u]) / (t_out[u] - t_in[u]);
+                        b0 = (1 - mult) * q0[u].x + mult * q1[u].y;
+                        b1 = (1 - mult) * q0[u].y + mult * q2[u].x;
+                        b2 = (1 - mult) * q1[u].x + mult * q2[u].y;
+                    }
+                    const size_t o = ray * S + j;
+                    mask_out[o] = mk[u];
+                    cells_out[o] = cell[u];
+                    *reinterpret_cast<uint4 *>(verts_out + 4 * o) = vv[u];
+                    bary_out[3 * o] = b0; bary_out[3 * o + 1] = b1; bary_out[3 * o + 2] = b2;
+                }
             }
         } else {
             // defaults everywhere, then the literal pointer walk on lane 0

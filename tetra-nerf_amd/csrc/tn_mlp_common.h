@@ -1,0 +1,131 @@
+// tn_mlp_common.h -- geometry of the packed MLP layers and the device helpers shared by the forward kernels
+// (tn_mlp.hip) and the training kernels (tn_mlp_bwd.hip).  See the header of tn_mlp.hip for the dataflow.
+#pragma once
+#include "tn_device.h"
+#include "tn_kernels.h"
+
+namespace tn {
+namespace mlp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int HID = 128;          // hidden width
+constexpr int FD = 64;            // field dim
+constexpr int ENC = 27;           // direction encoding width
+constexpr int ENC_PAD = 28;       // padded to an even K
+constexpr int KS1 = FD / 2;       // k-steps of layer 1
+constexpr int KSH = HID / 2;      // k-steps over 128 features held in accumulators
+constexpr int KSE = ENC_PAD / 2;  // k-steps over the direction encoding
+constexpr int OT = HID / 32;      // output tiles of a hidden layer
+constexpr int MLP_BLOCK = 512;    // 8 waves share one staged layer: 256 samples per group
+
+// One staged layer = [k-steps + 1][tiles][64 lanes] floats; the extra last k-step carries the bias
+// (A = bias for the lower half-wave, 0 for the upper; B = 1.0), so the bias add is part of the GEMM.
+// The head layer has a 5th output tile whose row 0 is the density head (it consumes the same B
+// operands, the mlp_base output); the rgb head is a 1-tile layer (rows 0..2).
+struct LayerGeom { int ksteps, tiles; size_t off; };
+constexpr size_t lfloats(int ksteps, int tiles) { return (size_t)(ksteps + 1) * tiles * 64; }
+constexpr int HEAD_KS = KSE + KSH;
+// The two narrow heads (density 128 -> 1 on the mlp_base output, rgb 128 -> 3 on the head output) are NOT
+// MFMA layers: as 32-row tiles they would spend 130 of 1098 MFMAs per 32 samples on 4 useful rows.  Their
+// weights ride behind the layer that produces their input ([half][64] floats in the lane's K order + bias)
+// and each lane does its half of the dot products on the otherwise idle VALU (64 fma per output).
+constexpr size_t DVEC = 2 * 64 + 4;        // density: wd in K order per half, bd, pad
+constexpr size_t CVEC = 3 * 2 * 64 + 4;    // rgb: wr rows in K order per half, br, pad
+constexpr size_t OFF_W1 = 0;
+constexpr size_t OFF_W2 = OFF_W1 + lfloats(KS1, OT);
+constexpr size_t OFF_W3 = OFF_W2 + lfloats(KSH, OT);
+constexpr size_t N_W3 = lfloats(KSH, OT) + DVEC;
+constexpr size_t OFF_WHEAD = OFF_W3 + N_W3;
+constexpr size_t N_WHEAD = lfloats(HEAD_KS, OT) + CVEC;
+constexpr size_t PACK_FLOATS = OFF_WHEAD + N_WHEAD;
+constexpr size_t MAX_STAGE_FLOATS = N_WHEAD;
+
+__host__ __device__ constexpr int acc_feature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// k index consumed by k-step `ks` (0..63) of a layer whose input lives in accumulators, half h
+__host__ __device__ constexpr int acc_k(int ks, int h) { return 32 * (ks >> 4) + acc_feature(ks & 15, h); }
+
+// Packed layer -> LDS with the async global->LDS path (global_load_lds_dwordx4: no staging registers, all
+// of a thread's loads in flight at once; a load-wait-write loop exposes one L2 latency per 8 KB).  The LDS
+// destination of a wave is uniform base + lane * 16, which is exactly a linear copy.
+template <int BLOCK = MLP_BLOCK>
+static __device__ __forceinline__ void stage_weights(float *lds, const float *__restrict__ src, size_t n_floats) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(lds);
+    const uint32_t n16 = (uint32_t)(n_floats / 4), lane = threadIdx.x & 63;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+    for (uint32_t base = wave0; base < n16; base += BLOCK) {
+        const uint32_t i = base + lane;
+        if (i < n16)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s4 + i),
+                                             (__attribute__((address_space(3))) void *)(d4 + base), 16, 0, 0);
+    }
+}
+static __device__ __forceinline__ void stage_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// acc[t] += W_staged[k-steps KS0 .. KS0+KS) * bin[0..KS)
+template <int KS, int KS0, int TILES>
+static __device__ __forceinline__ void gemm_steps(f32x16 (&acc)[TILES], const float (&bin)[KSH], const float *lds, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const float *wrow = lds + (size_t)(KS0 + ks) * TILES * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], bin[ks], acc[t], 0, 0, 0);
+        // keep the scheduler from hoisting hundreds of A-operand reads (register blow-up); the
+        // MFMAs of one k-step (>= 256 cycles) already cover the next step's LDS latency
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int STEP, int TILES>
+static __device__ __forceinline__ void bias_step(f32x16 (&acc)[TILES], const float *lds, int lane) {
+    const float *wrow = lds + (size_t)STEP * TILES * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], 1.0f, acc[t], 0, 0, 0);
+}
+
+template <int TILES>
+static __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TILES]) {
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+}
+
+// This lane's half of a 128-long dot product with the activations it holds (wl: 64 floats in the lane's K
+// order, broadcast LDS reads), plus the other half-wave's half.
+static __device__ __forceinline__ float head_dot(const float *wl, const float (&bin)[KSH]) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float4 w4 = reinterpret_cast<const float4 *>(wl)[i];
+        a0 = __builtin_fmaf(w4.x, bin[4 * i], a0);
+        a1 = __builtin_fmaf(w4.y, bin[4 * i + 1], a1);
+        a2 = __builtin_fmaf(w4.z, bin[4 * i + 2], a2);
+        a3 = __builtin_fmaf(w4.w, bin[4 * i + 3], a3);
+    }
+    const float part = (a0 + a1) + (a2 + a3);
+    return part + __shfl_xor(part, 32);
+}
+
+template <int TILES>
+static __device__ __forceinline__ void relu_to_bin(const f32x16 (&acc)[TILES], float (&bin)[KSH]) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bin[t * 16 + r] = fmaxf(acc[t][r], 0.f);
+}
+
+
+}  // namespace mlp
+
+// packers / encoders of tn_mlp.hip, used by the training path as well
+void launch_mlp_pack(const MlpWeights &w, float *pk, bool gather_l1, hipStream_t stream);
+void launch_dir_encoding(size_t num_rays, const float *dirs, float *enc, hipStream_t stream);
+size_t mlp_pack_floats();
+
+}  // namespace tn

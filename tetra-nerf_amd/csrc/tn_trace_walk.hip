@@ -349,41 +349,75 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
 // exactly as combine_indices does (optix_trace_rays.cu:39-75).  The slots between the last segment and the next
 // multiple of 32 (where all four row arrays are on a 128-byte line boundary) get their tail constants here, so
 // that k_fill_range starts every row on a line boundary and no line is written by two kernels.
-// The kernel is latency-bound (log -> walk record -> stores): groups are dealt round-robin to the waves (the rays
-// that miss the mesh are clustered), and the 4 x 8 hits per ray of an iteration are requested before any is used.
+// The kernel is latency-bound: per iteration (4 x 8 hits of each of the 8 rays) the chain is log entries -> walk
+// records -> stores, and gfx950 retires loads and stores of a wave in issue order (one vmcnt), so a load issued
+// after an iteration's ~24 scattered stores is only "back" once those are acknowledged.  Hence the software
+// pipeline: the entries of the NEXT iteration -- of this group, or of the wave's next group, whose hit counts were
+// requested a whole group earlier -- are requested BEFORE this iteration's record loads and stores; waiting for
+// them later never waits for a store.  One exposed round trip per iteration instead of three.  Groups are dealt
+// round-robin to the waves (the rays that miss the mesh are clustered).
+template <int U>   // chunks of 8 hits per ray per iteration
 __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
-    constexpr int U = 4;   // chunks of 8 hits per ray in flight
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t a = (uint32_t)lane & 7u, h = (uint32_t)lane >> 3;
     const uint32_t M = q.M;
     const size_t G = (q.num_rays + 7) / 8;                 // groups of 8 rays
     const size_t nwaves = (size_t)gridDim.x * 4;
     const unsigned long long raymask = 0x0101010101010101ull << a;
-    for (size_t g = (size_t)blockIdx.x * 4 + wave; g < G; g += nwaves) {
-        const size_t r0 = 8 * g, r = r0 + a;
-        uint32_t nh = r < q.num_rays ? q.walk_n[r] : TN_EMPTY;
-        const bool skip = nh == TN_EMPTY;   // literal / fallback ray (or padding): the row belongs to another kernel
-        if (skip) nh = 0;
-        uint32_t mx = nh;             // max over the 8 rays (the value is replicated over h)
+
+    auto hits_of = [&](size_t g) -> uint32_t {             // walk_n of ray 8g + a (TN_EMPTY: not this kernel's row)
+        const size_t r = 8 * g + a;
+        return (g < G && r < q.num_rays) ? q.walk_n[r] : TN_EMPTY;
+    };
+    auto log_of = [&](size_t g) -> const uint4 * {         // entry k of ray 8g + a at [k * 64]
+        const size_t r0 = 8 * g;
+        return q.hit_log + (r0 >> 6) * (size_t)M * 64 + (r0 & 63) + a;
+    };
+    auto load_entries = [&](uint4 (&e)[U], const uint4 *lg, uint32_t nh, uint32_t c0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t k = c0 + 8 * u + h;
+            e[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (k < nh) e[u] = lg[(size_t)k * 64];
+        }
+    };
+
+    size_t g = (size_t)blockIdx.x * 4 + wave;
+    if (g >= G) return;
+    uint32_t nh_raw = hits_of(g);
+    uint32_t nh_next_raw = hits_of(g + nwaves);            // in flight during the whole first group
+    uint4 e[U];
+    {
+        const uint32_t nh0 = nh_raw == TN_EMPTY ? 0u : nh_raw;
+        load_entries(e, log_of(g), nh0, 0);
+    }
+    for (; g < G; g += nwaves) {
+        const bool skip = nh_raw == TN_EMPTY;   // literal / fallback ray (or padding): the row belongs to another kernel
+        const uint32_t nh = skip ? 0u : nh_raw;
+        uint32_t mx = nh;                       // max over the 8 rays (the value is replicated over h)
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {
             const uint32_t o = (uint32_t)__shfl_xor((int)mx, off);
             mx = o > mx ? o : mx;
         }
         mx = __builtin_amdgcn_readfirstlane(mx);
-        const uint4 *lg = q.hit_log + (r0 >> 6) * (size_t)M * 64 + (r0 & 63) + a;   // entry k at lg[k * 64]
-        const size_t row = r * (size_t)M;
+        const uint4 *lg = log_of(g);
+        const size_t row = (8 * g + a) * (size_t)M;
+        // the group after the next: its hit counts are requested now, needed one group later
+        const size_t g_next = g + nwaves;
+        const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : nh_next_raw;
+        const uint32_t nh_next2_raw = hits_of(g_next + nwaves);
         uint32_t nseg = 0;
         uint4 carry = make_uint4(0u, 0u, 0u, 0u);   // hit c0 - 1 of ray a
-        for (uint32_t c0 = 0; c0 < mx; c0 += 8 * U) {
-            uint4 e[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t k = c0 + 8 * u + h;
-                e[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (k < nh) e[u] = lg[(size_t)k * 64];
-            }
-            // previous hit of every lane (lane - 8, or the last hit of the previous chunk), emission, slots
+        uint32_t c0 = 0;
+        do {
+            // ---- request the next iteration's entries first (see the header comment)
+            uint4 en[U];
+            const bool more = c0 + 8 * U < mx;   // wave-uniform
+            if (more) load_entries(en, lg, nh, c0 + 8 * U);
+            else load_entries(en, log_of(g_next), g_next < G ? nh_next : 0u, 0);
+            // ---- this iteration: previous hit of every lane (lane - 8, or the last hit of the previous chunk),
+            //      emission, slots
             uint4 pe[U];
             uint32_t slot[U];   // TN_EMPTY: no segment
 #pragma unroll
@@ -399,7 +433,7 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
                 slot[u] = emit ? nseg + (uint32_t)__popcll(m & lanemask_lt()) : TN_EMPTY;
                 nseg += (uint32_t)__popcll(m);
             }
-            // walk records of the emitted segments
+            // ---- walk records of the emitted segments
             uint32_t orig[U], chi[U], clo[U];
             uint4 vid[U];
 #pragma unroll
@@ -434,7 +468,10 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
                     if (q.out_verts) *reinterpret_cast<uint4 *>(q.out_verts + 4 * sl) = vid[u];   // (n, a, b, c)
                 }
             }
-        }
+#pragma unroll
+            for (int u = 0; u < U; ++u) e[u] = en[u];
+            c0 += 8 * U;
+        } while (c0 < mx);
         // tail constants up to the next multiple of 32 slots (line boundary of all four arrays)
         if (q.dense_tails && !skip) {
             uint32_t n32 = (nseg + 31u) & ~31u;
@@ -448,15 +485,22 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
                 if (q.out_verts) *reinterpret_cast<uint4 *>(q.out_verts + 4 * slot) = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
             }
         }
+        nh_raw = nh_next_raw;
+        nh_next_raw = nh_next2_raw;
     }
 }
 
 void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned max_blocks) {
     if (q.num_rays == 0) return;
     size_t blocks = (q.num_rays + 31) / 32;        // one group of 8 rays per wave
-    const size_t cap = max_blocks ? max_blocks : 256 * 4;
+    const bool u2 = q.unroll == 2;
+    // default: 2 blocks (8 waves) per CU -- measured best on the 100k / 300k / 1M-tet frames (profiles/r02_walk_sweep.txt):
+    // the software pipeline keeps enough loads in flight per wave, and the literal-pairing / BVH kernels of the side
+    // stream find free wave slots beside it
+    const size_t cap = max_blocks ? max_blocks : 256 * 2;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_write_segments, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    if (u2) hipLaunchKernelGGL(k_write_segments<2>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    else hipLaunchKernelGGL(k_write_segments<4>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
 }
 
 // Constant tails: pure streaming stores (16 B per lane, whole 128-byte lines), a contiguous span of rows per wave.

@@ -65,19 +65,32 @@ class TetraMLP(torch.nn.Module):
         return sigma, rgb
 
 
-def uniform_sample_bins(nears: torch.Tensor, fars: torch.Tensor, num_samples: int) -> torch.Tensor:
-    """[R,S+1] euclidean bin edges of nerfstudio's UniformSampler in eval mode."""
-    bins = torch.linspace(0.0, 1.0, num_samples + 1, dtype=nears.dtype, device=nears.device)[None]
+def stratified_bins(num_samples: int, t_rand: torch.Tensor) -> torch.Tensor:
+    """Train-mode spacing bins of TetrahedraSampler / nerfstudio's UniformSampler (model.py:166-175): every edge of
+    linspace(0, 1, S+1) is jittered between the centres of its two neighbouring bins.  t_rand: U[0,1) [R, S+1]."""
+    bins = torch.linspace(0.0, 1.0, num_samples + 1, dtype=t_rand.dtype, device=t_rand.device)[None]
+    centers = (bins[..., 1:] + bins[..., :-1]) / 2.0
+    upper = torch.cat([centers, bins[..., -1:]], -1)
+    lower = torch.cat([bins[..., :1], centers], -1)
+    return lower + (upper - lower) * t_rand
+
+
+def uniform_sample_bins(nears: torch.Tensor, fars: torch.Tensor, num_samples: int, t_rand: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[R,S+1] euclidean bin edges of nerfstudio's UniformSampler (eval mode; train mode with `t_rand` [R,S+1])."""
+    if t_rand is None:
+        bins = torch.linspace(0.0, 1.0, num_samples + 1, dtype=nears.dtype, device=nears.device)[None]
+    else:
+        bins = stratified_bins(num_samples, t_rand)
     return bins * fars + (1.0 - bins) * nears
 
 
 def biased_sample_bins(nears: torch.Tensor, fars: torch.Tensor, num_samples: int, num_visited_cells: torch.Tensor,
-                       hit_distances: torch.Tensor) -> torch.Tensor:
+                       hit_distances: torch.Tensor, t_rand: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[R,S+1] euclidean bin edges of the biased TetrahedraSampler in eval mode (model.py:111-192):
     the uniform edges are re-mapped so that every visited tetrahedron receives the same share of the
     samples, placed proportionally inside its [t_in, t_out] segment (the mapping stacks the segment
     lengths from the first entry point; negative lengths -- the cell -1 closing segments -- count 0)."""
-    return map_to_biased(num_visited_cells, hit_distances, uniform_sample_bins(nears, fars, num_samples))
+    return map_to_biased(num_visited_cells, hit_distances, uniform_sample_bins(nears, fars, num_samples, t_rand))
 
 
 def map_to_biased(num_visited_cells: torch.Tensor, hit_distances: torch.Tensor, uni: torch.Tensor) -> torch.Tensor:
@@ -95,7 +108,8 @@ def map_to_biased(num_visited_cells: torch.Tensor, hit_distances: torch.Tensor, 
 
 
 def pdf_sample_bins(spacing_edges: torch.Tensor, weights: torch.Tensor, num_fine: int, nears: torch.Tensor,
-                    fars: torch.Tensor, histogram_padding: float = 0.01, eps: float = 1e-5) -> torch.Tensor:
+                    fars: torch.Tensor, histogram_padding: float = 0.01, eps: float = 1e-5,
+                    u_rand: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[R, S + num_fine + 2] euclidean bin edges of nerfstudio's PDFSampler in eval mode with
     include_original=True (model.py:463,584): inverse-CDF samples of the padded coarse weights at the
     num_fine+1 bin-centred quantiles, merged with the coarse edges and sorted, then mapped back with
@@ -110,7 +124,10 @@ def pdf_sample_bins(spacing_edges: torch.Tensor, weights: torch.Tensor, num_fine
     cdf = torch.min(torch.ones_like(pdf), torch.cumsum(pdf, dim=-1))
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
     u = torch.linspace(0.0, 1.0 - (1.0 / num_bins), steps=num_bins, dtype=cdf.dtype, device=cdf.device)
-    u = (u + 1.0 / (2 * num_bins)).expand(*cdf.shape[:-1], num_bins).contiguous()
+    if u_rand is None:   # eval: bin-centred quantiles
+        u = (u + 1.0 / (2 * num_bins)).expand(*cdf.shape[:-1], num_bins).contiguous()
+    else:                # train_stratified: one uniform draw per quantile bin, u_rand U[0,1) [R, num_fine+1]
+        u = (u + u_rand / num_bins).contiguous()
     inds = torch.searchsorted(cdf.contiguous(), u, side="right")
     last = spacing_edges.shape[-1] - 1
     below, above = (inds - 1).clamp(0, last), inds.clamp(0, last)
@@ -197,6 +214,69 @@ def render_reference(tracer, interpolate_values, field: torch.Tensor, mlp: Tetra
     return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
 
 
+class GradientScaler(torch.autograd.Function):
+    """Radiance-field gradient scaling of the `tetra-nerf` configuration (model.py:195-205, applied :625-630):
+    identity forward; the gradients of colours and densities are multiplied by clamp(ray_dist^2, 0, 1)."""
+
+    @staticmethod
+    def forward(ctx, colors, sigmas, ray_dist):
+        ctx.save_for_backward(ray_dist)
+        return colors, sigmas, ray_dist
+
+    @staticmethod
+    def backward(ctx, grad_colors, grad_sigmas, grad_ray_dist):
+        (ray_dist,) = ctx.saved_tensors
+        scaling = torch.square(ray_dist).clamp(0, 1)
+        return grad_colors * scaling, grad_sigmas * scaling, grad_ray_dist
+
+
+class _FusedMlpFunction(torch.autograd.Function):
+    """gather + MLP + heads as ONE autograd node: forward = tn_mlp_forward_gather (nothing saved but the inputs),
+    backward = tn_mlp_backward + tn_mlp_weight_grad + tn_interpolate_values_backward (recompute, dX chain and weight
+    gradients on the fp32 matrix cores).  Gradients flow to the field and the 12 weight tensors."""
+
+    @staticmethod
+    def forward(ctx, vertex_indices, barycentric_coordinates, field, dirs, samples_per_ray, *weights):
+        from . import tetranerf_cpp_extension as cpp
+
+        ctx.save_for_backward(vertex_indices, barycentric_coordinates, field, dirs, *weights)
+        ctx.S = int(samples_per_ray)
+        return cpp.mlp_forward_gather(vertex_indices, barycentric_coordinates, field.detach(), dirs,
+                                      [w.detach() for w in weights], ctx.S)
+
+    @staticmethod
+    def backward(ctx, d_sigma, d_rgb):
+        from . import tetranerf_cpp_extension as cpp
+
+        vi, bc, field, dirs, *weights = ctx.saved_tensors
+        grad_field, grads = cpp.mlp_backward(vi, bc, field, dirs, [w.detach() for w in weights], ctx.S,
+                                             d_sigma.contiguous(), d_rgb.contiguous())
+        return (None, None, grad_field, None, None, *grads)
+
+
+class _FusedCompositeFunction(torch.autograd.Function):
+    """get_weights + RGB / accumulation / median-depth renderers as one node (tn_composite / tn_composite_backward)."""
+
+    @staticmethod
+    def forward(ctx, sigma, rgb, edges, background):
+        from . import tetranerf_cpp_extension as cpp
+
+        ctx.save_for_backward(sigma, rgb, edges)
+        ctx.background = float(background)
+        out_rgb, acc, depth = cpp.composite(sigma.detach(), rgb.detach(), edges, ctx.background)
+        ctx.mark_non_differentiable(depth)
+        return out_rgb, acc, depth
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_acc, _d_depth):
+        from . import tetranerf_cpp_extension as cpp
+
+        sigma, rgb, edges = ctx.saved_tensors
+        d_sigma, d_col = cpp.composite_backward(sigma, rgb, edges, d_rgb, None if d_acc is None else d_acc.reshape(-1),
+                                                ctx.background)
+        return d_sigma, d_col, None, None
+
+
 def mlp_weights(mlp: TetraMLP):
     """The 12 tensors tn_mlp_forward takes, in its order."""
     b = mlp.base
@@ -279,4 +359,92 @@ class TetraRenderer:
             rgb[idx] = rgb_r
             acc[idx] = acc_r
             depth[idx] = depth_r
+        return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
+
+    def render_train(self, origins: torch.Tensor, directions: torch.Tensor, gradient_scaling: bool = False,
+                     generator: Optional[torch.Generator] = None, rand: Optional[Dict[str, torch.Tensor]] = None,
+                     fused: bool = True) -> Dict[str, torch.Tensor]:
+        """One training forward (TetrahedraNerf.get_outputs in training mode, model.py:520-662): stratified coarse samples
+        (uniform or biased), optional PDF fine pass on the detached coarse weights (nerfstudio's PDFSampler detaches
+        them), gather + MLP + heads, optional GradientScaler, weights and renderers -- differentiable w.r.t. the field
+        and the MLP parameters.  fused=True: the MLP and the composite are single autograd nodes backed by the HIP
+        forward / adjoint kernels; fused=False: the plain PyTorch statement (autograd through nn.Linear etc.), which is
+        what the parity tests compare against.  `rand` may carry the uniform draws ("coarse" [r,S+1], "fine"
+        [r,S_fine+1] over the hitting rays) so that two calls see the same samples."""
+        cpp, S = self.cpp, self.S
+        with torch.no_grad():
+            if not self.dense_tails:
+                self.tracer.set_option("dense_tails", 0)
+            try:
+                out = self.tracer.trace_rays(origins.contiguous(), directions.contiguous(), self.M)
+            finally:
+                if not self.dense_tails:
+                    self.tracer.set_option("dense_tails", 1)
+            nv = out["num_visited_cells"]
+            ray_mask = nv > 0
+            nears = torch.where(ray_mask, out["hit_distances"][:, 0, 0], 0.0)[:, None]
+            fars = torch.where(ray_mask[:, None], torch.gather(out["hit_distances"][:, :, 1], 1,
+                                                              (nv[:, None].long() - 1).clamp_min(0)), 0.0)
+            idx = torch.nonzero(ray_mask)[:, 0]
+        R, dev = origins.shape[0], origins.device
+        rgb = torch.ones((R, 3), dtype=torch.float32, device=dev)
+        acc = torch.zeros((R, 1), dtype=torch.float32, device=dev)
+        depth = torch.full((R, 1), self.far_plane, dtype=torch.float32, device=dev)
+        if idx.numel() == 0:
+            return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
+        lists = [out[k] for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates", "hit_distances",
+                                  "vertex_indices")]
+        ridx = idx.to(torch.int32)
+        near_r, far_r = nears[idx], fars[idx]
+        r = idx.numel()
+        rand = rand or {}
+        with torch.no_grad():
+            t_rand = rand.get("coarse")
+            if t_rand is None:
+                t_rand = torch.rand((r, S + 1), device=dev, generator=generator)
+            if self.biased:
+                edges = biased_sample_bins(near_r, far_r, S, lists[0][idx], lists[3][idx], t_rand).contiguous()
+            else:
+                edges = uniform_sample_bins(near_r, far_r, S, t_rand).contiguous()
+
+            def locate(e):
+                dist = ((e[:, 1:] + e[:, :-1]) / 2).contiguous()
+                return self.tracer.find_visited_cells(*lists, dist, ray_index=ridx)
+
+            traced = locate(edges)
+            w = mlp_weights(self.mlp)
+            if self.S_fine > 0:
+                sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field.detach(),
+                                                 None, [x.detach() for x in w], S)
+                weights_c = cpp.composite(sigma_c.view(-1, S), None, edges)
+                spacing = (edges - near_r) / (far_r - near_r)
+                u_rand = rand.get("fine")
+                if u_rand is None:
+                    u_rand = torch.rand((r, self.S_fine + 1), device=dev, generator=generator)
+                edges = pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r, u_rand=u_rand).contiguous()
+                traced = locate(edges)
+                S = edges.shape[1] - 1
+        dirs = directions[idx].contiguous()
+        vi, bc = traced["vertex_indices"], traced["barycentric_coordinates"]
+        if fused:
+            sigma, col = _FusedMlpFunction.apply(vi, bc, self.field, dirs, S, *w)
+            sigma, col = sigma.view(-1, S), col.view(-1, S, 3)
+        else:
+            from . import interpolate_values
+
+            feats = interpolate_values(vi, bc, self.field)
+            sg, col = self.mlp(feats, dirs[:, None, :].expand(-1, S, -1))
+            sigma = sg[..., 0]
+        if gradient_scaling:
+            spacing = (edges - near_r) / (far_r - near_r)
+            ray_dist = (spacing[:, 1:] + spacing[:, :-1])[..., None]      # model.py:625-630
+            col, sg, _ = GradientScaler.apply(col, sigma[..., None], ray_dist)
+            sigma = sg[..., 0]
+        if fused:
+            rgb_r, acc_r, depth_r = _FusedCompositeFunction.apply(sigma, col, edges, 1.0)
+        else:
+            rgb_r, acc_r, depth_r, _ = composite(sigma[..., None], col, edges[:, :-1, None], edges[:, 1:, None])
+        rgb = rgb.index_copy(0, idx, rgb_r)
+        acc = acc.index_copy(0, idx, acc_r.reshape(-1, 1))
+        depth = depth.index_copy(0, idx, depth_r.reshape(-1, 1).detach())
         return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}

@@ -267,6 +267,44 @@ class TetrahedraTracer:
         return out
 
 
+# Vertex-major shadow copies [V, F] of feature-major fields [F, V] (the checkpoint layout, model.py:269-271): the O(V)
+# transposition is paid once per field VERSION, not once per call (with 4096-ray batches on a multi-million-vertex
+# field it would dominate the gather).  An entry belongs to one live tensor OBJECT (weak reference: a new tensor that
+# the allocator places at the same address is a different object) and is refreshed when that tensor's version counter
+# moves (every in-place optimiser step bumps it) or its storage pointer changes.  The model passes its
+# `tetrahedra_field` parameter itself (model.py:569-573), which is what hits; a fresh view object per call (.data,
+# .detach()) simply misses and is transposed again.
+_FIELD_VM = {}
+
+
+def field_vertex_major(field):
+    """[V, F] copy of `field` [F, V], cached per (tensor object, version)."""
+    import weakref
+
+    key = id(field)
+    hit = _FIELD_VM.get(key)
+    if hit is not None and hit[0]() is field and hit[1] == field._version and hit[2] == field.data_ptr():
+        return hit[3]
+    Fd, V = field.shape
+    ft = torch.empty((V, Fd), dtype=torch.float32, device=field.device)
+    with torch.cuda.device(field.device):
+        _lib.check(_lib.load().tn_transpose_f32(Fd, V, _ptr(field), _ptr(ft), _stream(field.device)))
+    for k in [k for k, v in _FIELD_VM.items() if v[0]() is None]:
+        del _FIELD_VM[k]
+    if len(_FIELD_VM) >= 8:
+        _FIELD_VM.clear()
+    try:
+        _FIELD_VM[key] = (weakref.ref(field), field._version, field.data_ptr(), ft)
+    except TypeError:
+        pass
+    return ft
+
+
+def invalidate_field_cache():
+    """Drop the cached vertex-major copies (needed only after writing a field through a raw pointer)."""
+    _FIELD_VM.clear()
+
+
 def interpolate_values(vertex_indices, barycentric_coordinates, field):
     """py_interpolate_values (py_binding.cpp:298-330): returns [..., field_dim] as a
     moveaxis(0,-1) view of a contiguous [field_dim, n] buffer."""
@@ -279,13 +317,14 @@ def interpolate_values(vertex_indices, barycentric_coordinates, field):
            "barycentric_coordinates must have the same last dimension as vertex_indices - 1")
     _check(field.dtype == torch.float32, "field must be a tensor of type float32")
     D = vertex_indices.size(-1)
+    _check(D in (2, 3, 4, 6), f"Unsupported interpolation dimension with value {D}")
     n = vertex_indices.numel() // D
-    Fd, V = field.size(0), field.size(-1)
+    Fd = field.size(0)
     result = torch.empty((Fd,) + tuple(vertex_indices.shape[:-1]), dtype=field.dtype, device=field.device)
+    ft = field_vertex_major(field)
     with torch.cuda.device(field.device):
-        _lib.check(_lib.load().tn_interpolate_values(
-            D, V, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates), _ptr(field), _ptr(result),
-            _stream(field.device)))
+        _lib.check(_lib.load().tn_interpolate_values_vm(
+            D, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates), _ptr(ft), _ptr(result), _stream(field.device)))
     return result.moveaxis(0, -1)
 
 
@@ -301,20 +340,26 @@ def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, 
     _check(barycentric_coordinates.size(-1) + 1 == vertex_indices.size(-1),
            "barycentric_coordinates must have the same last dimension as vertex_indices - 1")
     D = vertex_indices.size(-1)
+    _check(D in (2, 3, 4, 6), f"Unsupported interpolation dimension with value {D}")
     n = vertex_indices.numel() // D
     Fd, V = field.size(0), field.size(-1)
     _check(grad_in.size(-1) == Fd, "grad_in must have shape [..., field_dim]")
     grad_field_out = torch.empty((Fd, V), dtype=grad_in.dtype, device=grad_in.device)
     lib = _lib.load()
-    if grad_in.moveaxis(-1, 0).is_contiguous():
+    if grad_in.moveaxis(-1, 0).is_contiguous() and Fd > 1:
         # the reference's layout: a [Fd, n] buffer viewed as [..., Fd] (what py_binding.cpp:369 produces)
-        fn, g = lib.tn_interpolate_values_backward, grad_in.moveaxis(-1, 0)
-    else:
-        # sample-major rows, the usual autograd gradient: consumed as is (no transposed copy)
-        fn, g = lib.tn_interpolate_values_backward_rows, grad_in.contiguous()
+        with torch.cuda.device(field.device):
+            _lib.check(lib.tn_interpolate_values_backward(D, V, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates),
+                                                          _ptr(grad_in.moveaxis(-1, 0)), _ptr(grad_field_out),
+                                                          _stream(field.device)))
+        return grad_field_out
+    # sample-major rows, the usual autograd gradient: consumed as is, accumulated vertex-major, transposed back once
+    g = grad_in.contiguous()
+    grad_vm = torch.zeros((V, Fd), dtype=torch.float32, device=grad_in.device)
     with torch.cuda.device(field.device):
-        _lib.check(fn(D, V, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates), _ptr(g), _ptr(grad_field_out),
-                      _stream(field.device)))
+        _lib.check(lib.tn_interpolate_values_backward_vm(D, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates),
+                                                         _ptr(g), _ptr(grad_vm), _stream(field.device)))
+        _lib.check(lib.tn_transpose_f32(V, Fd, _ptr(grad_vm), _ptr(grad_field_out), _stream(field.device)))
     return grad_field_out
 
 
@@ -432,6 +477,95 @@ def composite(sigma, rgb, edges, background=1.0, return_weights=False):
         _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), _ptr(rgb), _ptr(edges), float(background), _ptr(out_rgb),
                                             _ptr(acc), _ptr(depth), _ptr(weights), _stream(dev)))
     return (out_rgb, acc, depth, weights) if return_weights else (out_rgb, acc, depth)
+
+
+class _MlpBackwardBuffers(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("x0", "h1", "h2", "h3", "h4", "d1", "d2", "d3", "d4", "dhead", "dx0")]
+
+
+def _direction_encoding(d):
+    """NeRFEncoding(3, 4 freqs, include_input) as the MLP kernels evaluate it (tn_mlp.hip: k_dir_encoding)."""
+    import math
+
+    freqs = 2.0 ** torch.linspace(0.0, 4.0, 4, dtype=d.dtype, device=d.device)
+    scaled = ((2.0 * math.pi * d)[..., None] * freqs).reshape(*d.shape[:-1], 12)
+    return torch.cat([torch.sin(torch.cat([scaled, scaled + math.pi / 2.0], dim=-1)), d], dim=-1)
+
+
+def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray, d_sigma, d_rgb,
+                 chunk_samples=1 << 20):
+    """Adjoint of mlp_forward_gather (addition; the reference leaves this to PyTorch autograd, model.py:602-630):
+    given dL/dsigma [n] and dL/drgb [n,3] returns (grad_field [64,V], [12 weight gradients in the order of `weights`]).
+    Two HIP kernels per chunk of samples: the dX chain on the fp32 matrix cores (recomputing the forward pass) and
+    K-streaming weight-gradient GEMMs; the three narrow head gradients (enc part of mlp_head, density, rgb) are
+    bandwidth-bound matrix-vector products done by PyTorch on the buffers the first kernel left."""
+    st, keep = _weights_struct(weights)
+    n = vertex_indices.numel() // 4
+    S = int(samples_per_ray)
+    _check(S > 0 and n % S == 0, "n must be a multiple of samples_per_ray")
+    _check(d_sigma.numel() == n and d_rgb.numel() == 3 * n, "d_sigma / d_rgb must have n / 3n elements")
+    dev = field.device
+    V = field.size(1)
+    vi = vertex_indices.reshape(n, 4)
+    bc = barycentric_coordinates.reshape(n, 3)
+    d_sigma = d_sigma.reshape(n).contiguous().float()
+    d_rgb = d_rgb.reshape(n, 3).contiguous().float()
+    dirs = dirs.contiguous()
+    lib = _lib.load()
+    field_vm = field_vertex_major(field)
+    grads = [torch.zeros_like(w, dtype=torch.float32) for w in keep]
+    gw1, gb1, gw2, gb2, gw3, gb3, gwd, gbd, gwh, gbh, gwr, gbr = grads
+    gwh_base = torch.zeros((128, 128), dtype=torch.float32, device=dev)
+    grad_vm = torch.zeros((V, 64), dtype=torch.float32, device=dev)
+    rays_per_chunk = max(1, int(chunk_samples) // S)
+    R = n // S
+    stream = _stream(dev)
+    with torch.cuda.device(dev):
+        for r0 in range(0, R, rays_per_chunk):
+            r1 = min(R, r0 + rays_per_chunk)
+            m = (r1 - r0) * S
+            c0 = r0 * S
+            buf = torch.empty((64 + 8 * 128 + 4 + 64, m), dtype=torch.float32, device=dev)
+            x0, h1, h2, h3, h4 = buf[0:64], buf[64:192], buf[192:320], buf[320:448], buf[448:576]
+            d1, d2, d3, d4 = buf[576:704], buf[704:832], buf[832:960], buf[960:1088]
+            dhead, dx0 = buf[1088:1092], buf[1092:1156]
+            bs = _MlpBackwardBuffers(*[t.data_ptr() for t in (x0, h1, h2, h3, h4, d1, d2, d3, d4, dhead, dx0)])
+            _lib.check(lib.tn_mlp_backward(m, S, _ptr(vi[c0:]), _ptr(bc[c0:]), _ptr(field_vm), _ptr(dirs[r0:]), C.byref(st),
+                                           _ptr(d_sigma[c0:]), _ptr(d_rgb[c0:]), C.byref(bs), stream))
+            for a, b, rows_b, gw, gb in ((d1, x0, 64, gw1, gb1), (d2, h1, 128, gw2, gb2), (d3, h2, 128, gw3, gb3),
+                                         (d4, h3, 128, gwh_base, gbh)):
+                _lib.check(lib.tn_mlp_weight_grad(m, rows_b, _ptr(a), _ptr(b), _ptr(gw), _ptr(gb), stream))
+            # narrow heads: [128, m] x [m] products and the per-ray direction encoding
+            gwd += (h3 @ dhead[0])[None]
+            gbd += dhead[0].sum()
+            gwr += dhead[1:4] @ h4.t()
+            gbr += dhead[1:4].sum(1)
+            gwh[:, :27] += d4.view(128, r1 - r0, S).sum(-1) @ _direction_encoding(dirs[r0:r1])
+            # gradient of the gathered features -> field (vertex-major accumulation)
+            rows = torch.empty((m, 64), dtype=torch.float32, device=dev)
+            _lib.check(lib.tn_transpose_f32(64, m, _ptr(dx0), _ptr(rows), stream))
+            _lib.check(lib.tn_interpolate_values_backward_vm(4, m, 64, _ptr(vi[c0:]), _ptr(bc[c0:]), _ptr(rows), _ptr(grad_vm),
+                                                             stream))
+            del buf, rows
+        gwh[:, 27:] += gwh_base
+        grad_field = torch.empty((64, V), dtype=torch.float32, device=dev)
+        _lib.check(lib.tn_transpose_f32(V, 64, _ptr(grad_vm), _ptr(grad_field), stream))
+    return grad_field, grads
+
+
+def composite_backward(sigma, rgb, edges, d_out_rgb, d_out_acc, background=1.0):
+    """Adjoint of composite() w.r.t. sigma [R,S] and rgb [R,S,3] (the median depth has no gradient)."""
+    R, S = sigma.shape
+    dev = sigma.device
+    d_sigma = torch.empty((R, S), dtype=torch.float32, device=dev)
+    d_rgb = torch.empty((R, S, 3), dtype=torch.float32, device=dev)
+    g_rgb = None if d_out_rgb is None else d_out_rgb.contiguous().float()
+    g_acc = None if d_out_acc is None else d_out_acc.contiguous().float()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tn_composite_backward(R, S, _ptr(sigma.contiguous()), _ptr(rgb.contiguous()), _ptr(edges.contiguous()),
+                                                     float(background), _ptr(g_rgb), _ptr(g_acc), _ptr(d_sigma), _ptr(d_rgb),
+                                                     _stream(dev)))
+    return d_sigma, d_rgb
 
 
 def triangulate(points):
