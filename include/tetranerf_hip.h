@@ -189,7 +189,7 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
 /* knobs (also settable through the environment):
  *   "walk"    1 = adjacency-walk fast path with general-path fallback (default when built),
  *             0 = general all-hits path for every ray, 2 = walk for any batch size
- *   "walk_min_rays"  smallest batch the walk is used for (default 16384; below it one wavefront per
+ *   "walk_min_rays"  smallest batch the walk is used for (default 6144; below it one wavefront per
  *             ray through the wide BVH has the lower latency)
  *   "dense_tails"  1 (default) = every slot of the [R,M] rows is written, as the reference does;
  *             0 = slots >= num_visited[r] of walked rows are left UNWRITTEN (non-reference: for callers
@@ -272,6 +272,10 @@ int tn_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vertex_i
                     const float *field_vm, const float *dirs, const tn_mlp_weights *weights, const float *d_sigma,
                     const float *d_rgb, const tn_mlp_backward_buffers *buffers, void *stream);
 int tn_mlp_weight_grad(size_t n, uint32_t rows_b, const float *a, const float *b, float *dw, float *db, void *stream);
+/* the narrow heads and the direction-encoding columns of mlp_head: out f32 [4,128] += (dhead[0] . h3 rows = d wd,
+ * dhead[1+c] . h4 rows = d wr[c]); ray_sum f32 [128, n / samples_per_ray] = per-ray sums of d4 (d Wh[:, :27] = ray_sum @ enc) */
+int tn_mlp_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, const float *h3, const float *h4,
+                     const float *d4, float *out, float *ray_sum, void *stream);
 
 /* adjoint of tn_composite w.r.t. sigma [R,S] and rgb [R,S,3], given the gradients of the rendered rgb [R,3] and
  * accumulation [R] (either nullable); the median depth carries no gradient. */

@@ -138,9 +138,19 @@ def test_composite_matches_torch(tn, device, render):
         np.testing.assert_allclose(g_w.cpu().numpy(), w_w[..., 0].numpy(), rtol=0, atol=1e-5)
         np.testing.assert_allclose(g_rgb.cpu().numpy(), w_rgb.numpy(), rtol=0, atol=1e-5)
         np.testing.assert_allclose(g_acc.cpu().numpy(), w_acc.numpy(), rtol=0, atol=1e-5)
-        # the median sample may flip when a cumulative weight sits within round-off of 0.5
-        same = np.isclose(g_depth.cpu().numpy(), w_depth.numpy(), rtol=0, atol=1e-5)
-        assert same.mean() >= 0.98
+        # median depth: the tolerance of north_star (1e-5) on every ray whose median is DECIDED -- the chosen sample
+        # may only differ where a cumulative weight of the reference sits within round-off of 0.5 (then the two
+        # summation orders legitimately pick neighbouring samples), and in that case it must be the neighbour
+        same = np.isclose(g_depth.cpu().numpy(), w_depth.numpy(), rtol=0, atol=1e-5)[:, 0]
+        cum = torch.cumsum(w_w[..., 0].double(), -1).numpy()
+        undecided = (np.abs(cum - 0.5) < 1e-5 * S).any(-1)
+        assert np.all(same | undecided), f"{R}x{S}: median depth differs on a decided ray"
+        mid = ((edges[:, :-1] + edges[:, 1:]) / 2).numpy()
+        for r in np.nonzero(~same)[0]:
+            i_ref = int(np.argmin(np.abs(mid[r] - float(w_depth[r, 0]))))
+            i_got = int(np.argmin(np.abs(mid[r] - float(g_depth[r, 0]))))
+            assert abs(i_ref - i_got) <= 1, (r, i_ref, i_got)
+        assert same.mean() >= 0.9
 
 
 @pytest.mark.parametrize("cfg", ["coarse", "tetra-nerf-original", "tetra-nerf"])
@@ -194,5 +204,7 @@ def test_render_c3(tn, device, oracle, scenes, render, cfg, mlp_mode):
         assert torch.equal(got["ray_mask"].cpu(), want["ray_mask"])
         np.testing.assert_allclose(got["rgb"].cpu().numpy(), want["rgb"].numpy(), rtol=0, atol=1e-5, err_msg=f"fused={fused}")
         np.testing.assert_allclose(got["accumulation"].cpu().numpy(), want["accumulation"].numpy(), rtol=0, atol=1e-5)
+        # (median depth: decided rays are asserted at 1e-5 in test_composite_matches_torch, where the cumulative weights
+        #  are at hand; here only the undecided ones -- cumulative weight within round-off of 0.5 -- may differ)
         dd = np.isclose(got["depth"].cpu().numpy(), want["depth"].numpy(), rtol=0, atol=1e-4)
         assert dd.mean() > 0.98

@@ -87,8 +87,9 @@ def test_mlp_backward_matches_autograd(tn, device, S):
 
 
 def test_render_train_fused_equals_autograd_statement(tn, device, scenes):
-    """Whole training forward/backward of both shipped configurations on a real mesh: fused nodes vs the plain PyTorch
-    statement with the same random draws (stratified coarse samples, stratified PDF samples, gradient scaling)."""
+    """Whole training forward/backward of both shipped configurations on a real mesh: fused nodes and the plain float32
+    PyTorch statement, with the same random draws (stratified coarse samples, stratified PDF samples, gradient
+    scaling), each measured against the FLOAT64 statement on the same sample placement."""
     import torch
 
     render = importlib.import_module("tetra-nerf_amd.render")
@@ -98,6 +99,10 @@ def test_render_train_fused_equals_autograd_statement(tn, device, scenes):
     o, d = scenes.outside_in_rays(512, 6)
     to, td = torch.from_numpy(o).to(device), torch.from_numpy(d).to(device)
     target = torch.rand(len(o), 3, device=device)
+
+    def loss_of(rgb, acc):
+        return ((rgb - target.to(rgb.dtype)) ** 2).mean() + 0.1 * acc.mean()
+
     for S, S_fine, biased, scaling in ((48, 0, False, False), (32, 32, False, False), (24, 24, True, True)):
         torch.manual_seed(0)
         mlp = render.TetraMLP().to(device)
@@ -105,17 +110,37 @@ def test_render_train_fused_equals_autograd_statement(tn, device, scenes):
         rd = render.TetraRenderer(tr, field, mlp, S, 256, fused=True, num_fine_samples=S_fine, biased=biased)
         hit = int((tr.trace_rays(to, td, 256)["num_visited_cells"] > 0).sum())
         rand = {"coarse": torch.rand(hit, S + 1, device=device), "fine": torch.rand(hit, S_fine + 1, device=device)}
-        grads = []
+        grads, cap = [], {}
         for fused in (True, False):
             field.grad = None
             mlp.zero_grad()
-            out = rd.render_train(to, td, gradient_scaling=scaling, rand=rand, fused=fused)
-            loss = ((out["rgb"] - target) ** 2).mean() + 0.1 * out["accumulation"].mean()
-            loss.backward()
+            out = rd.render_train(to, td, gradient_scaling=scaling, rand=rand, fused=fused, capture=cap)
+            loss_of(out["rgb"], out["accumulation"]).backward()
             grads.append((out["rgb"].detach().clone(), field.grad.clone(), [p.grad.clone() for p in render.mlp_weights(mlp)]))
+        # float64 statement on the captured sample placement
+        dt = torch.float64
+        m64 = render.TetraMLP().to(device).to(dt)
+        m64.load_state_dict({k: v.to(dt) for k, v in mlp.state_dict().items()})
+        f64 = field.detach().to(dt).requires_grad_(True)
+        vi, bc, edges, S2 = cap["vertex_indices"], cap["barycentric_coordinates"].to(dt), cap["edges"].to(dt), cap["samples_per_ray"]
+        wts = torch.cat([1 - bc.sum(-1, keepdim=True), bc], -1)
+        wts = torch.where(vi < 0, torch.zeros_like(wts), wts)
+        feats = (f64.t()[vi.long().clamp_min(0)] * wts[..., None]).sum(-2)
+        sg, col = m64(feats, cap["dirs"].to(dt)[:, None, :].expand(-1, S2, -1))
+        if scaling:
+            spacing = (edges - cap["near"].to(dt)) / (cap["far"].to(dt) - cap["near"].to(dt))
+            col, sg, _ = render.GradientScaler.apply(col, sg, (spacing[:, 1:] + spacing[:, :-1])[..., None])
+        rgb_r, acc_r, _, _ = render.composite(sg, col, edges[:, :-1, None], edges[:, 1:, None])
+        rgb = torch.ones(len(o), 3, dtype=dt, device=device).index_copy(0, cap["idx"], rgb_r)
+        acc = torch.zeros(len(o), 1, dtype=dt, device=device).index_copy(0, cap["idx"], acc_r)
+        loss_of(rgb, acc).backward()
+        want_f, want_w = f64.grad, [p.grad for p in render.mlp_weights(m64)]
         (rgb_a, gf_a, gw_a), (rgb_b, gf_b, gw_b) = grads
-        np.testing.assert_allclose(rgb_a.cpu().numpy(), rgb_b.cpu().numpy(), rtol=0, atol=2e-5)
-        assert float(gf_b.abs().max()) > 0
-        assert _rel(gf_a, gf_b) < 2e-4, ("field", S, S_fine, biased, _rel(gf_a, gf_b))
-        for a, b in zip(gw_a, gw_b):
-            assert _rel(a, b) < 2e-4, (S, S_fine, biased, _rel(a, b))
+        np.testing.assert_allclose(rgb_a.cpu().numpy(), rgb.detach().float().cpu().numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(rgb_b.cpu().numpy(), rgb.detach().float().cpu().numpy(), rtol=0, atol=1e-5)
+        assert float(want_f.abs().max()) > 0
+        errs = [("field", _rel(gf_a, want_f), _rel(gf_b, want_f))] + [(f"w{i}", _rel(a, w), _rel(b, w)) for i, (a, b, w) in enumerate(zip(gw_a, gw_b, want_w))]
+        for name, ours, torch32 in errs:
+            # the fused path must be as close to float64 as the float32 autograd statement is (x3: the sums over the
+            # samples are split differently -- 4096-sample slices + float atomics here), or within 3e-5
+            assert ours < max(3e-5, 3.0 * torch32), ((S, S_fine, biased), name, ours, torch32, errs)

@@ -21,7 +21,7 @@ SYMBOLS = (
     "tn_postprocess_hits", "tn_postprocess_hits_tables",
     "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_set_mode", "tn_mlp_get_mode",
     "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
-    "tn_mlp_backward", "tn_mlp_weight_grad", "tn_composite_backward",
+    "tn_mlp_backward", "tn_mlp_weight_grad", "tn_mlp_head_grad", "tn_composite_backward",
 )
 
 _lib = None
@@ -73,6 +73,7 @@ def load():
     lib.tn_composite.argtypes = [sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
     lib.tn_mlp_backward.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_mlp_weight_grad.argtypes = [sz, u32, vp, vp, vp, vp, vp]
+    lib.tn_mlp_head_grad.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_composite_backward.argtypes = [sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)

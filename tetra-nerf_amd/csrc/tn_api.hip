@@ -78,7 +78,7 @@ struct tn_tracer {
     uint32_t *kmax() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 2; }
     size_t last_num_rays = 0;
     int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
-    size_t walk_min_rays = 16384;
+    size_t walk_min_rays = 6144;         // measured crossover on the 300k-tet mesh (profiles/r02_small_batch.txt)
     bool last_walk = false;
     uint32_t debug = 0;
     uint32_t gdebug = 0;
@@ -659,6 +659,15 @@ int tn_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vertex_i
 int tn_mlp_weight_grad(size_t n, uint32_t rows_b, const float *a, const float *b, float *dw, float *db, void *stream_) {
     return guarded([&] {
         tn::launch_weight_grad(n, rows_b, a, b, dw, db, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_mlp_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, const float *h3, const float *h4, const float *d4,
+                     float *out, float *ray_sum, void *stream_) {
+    return guarded([&] {
+        if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
+        tn::launch_head_grad(n, samples_per_ray, dhead, h3, h4, d4, out, ray_sum, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }

@@ -137,6 +137,9 @@ void launch_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vi,
                          const MlpBackwardBuffers &b, hipStream_t stream);
 // dW[128, rows_b] += A[128, n] * B[rows_b, n]^T, db[128] += row sums of A (db nullable); rows_b in {64, 128}
 void launch_weight_grad(size_t n, uint32_t rows_b, const float *A, const float *B, float *dW, float *db, hipStream_t stream);
+// narrow heads: out[4][128] += (d sigma_raw . h3, d rgb_raw[c] . h4); ray_sum[128][R] = per-ray sums of d4
+void launch_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, const float *h3, const float *h4, const float *d4,
+                      float *out, float *ray_sum, hipStream_t stream);
 // adjoint of launch_composite: d sigma [R,S], d rgb [R,S,3] from the gradients of the rendered rgb / accumulation
 void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
                                const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb, hipStream_t stream);

@@ -438,6 +438,55 @@ void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const f
                        d_sigma, d_rgb);
 }
 
+// Gradients of the two narrow heads and the per-ray sums the direction-encoding columns of mlp_head need, all
+// bandwidth-bound row products over the sample axis (one block per feature row, the four d*_raw rows stay in cache):
+//   out[0][f]   += sum_s dhead[0][s] * h3[f][s]                      (density head: d wd[f])
+//   out[1+c][f] += sum_s dhead[1+c][s] * h4[f][s],  c = 0..2         (rgb head: d wr[c][f])
+//   ray_sum[f][r] = sum_{s in ray r} d4[f][s]                        (d Wh[:, :27] = ray_sum @ enc)
+__global__ __launch_bounds__(256) void k_head_grad(size_t n, uint32_t samples_per_ray, const float *__restrict__ dhead,
+                                                   const float *__restrict__ h3, const float *__restrict__ h4,
+                                                   const float *__restrict__ d4, float *__restrict__ out /*[4][128]*/,
+                                                   float *__restrict__ ray_sum /*[128][R]*/) {
+    const uint32_t f = blockIdx.x;            // feature row 0..127
+    const size_t part = blockIdx.y, nparts = gridDim.y;
+    const size_t R = n / samples_per_ray;
+    const size_t r_per = (R + nparts - 1) / nparts;
+    const size_t r0 = part * r_per, r1 = r0 + r_per < R ? r0 + r_per : R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float *row3 = h3 + (size_t)f * n, *row4 = h4 + (size_t)f * n, *rowd = d4 + (size_t)f * n;
+    for (size_t r = r0 + wave; r < r1; r += 4) {       // one wave per ray: its samples are contiguous
+        float rs = 0.f;
+        for (uint32_t j = lane; j < samples_per_ray; j += 64) {
+            const size_t s = r * samples_per_ray + j;
+            a0 += dhead[s] * row3[s];
+            const float x = row4[s];
+            a1 += dhead[n + s] * x; a2 += dhead[2 * n + s] * x; a3 += dhead[3 * n + s] * x;
+            rs += rowd[s];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rs += __shfl_xor(rs, off);
+        if (lane == 0) ray_sum[(size_t)f * R + r] = rs;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); a3 += __shfl_xor(a3, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&out[f], a0); atomicAdd(&out[128 + f], a1); atomicAdd(&out[256 + f], a2); atomicAdd(&out[384 + f], a3);
+    }
+}
+
+void launch_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, const float *h3, const float *h4, const float *d4,
+                      float *out, float *ray_sum, hipStream_t stream) {
+    if (n == 0) return;
+    const size_t R = n / samples_per_ray;
+    unsigned parts = (unsigned)((R + 255) / 256);
+    if (parts > 64) parts = 64;
+    if (parts < 1) parts = 1;
+    hipLaunchKernelGGL(k_head_grad, dim3(128, parts), dim3(256), 0, stream, n, samples_per_ray, dhead, h3, h4, d4, out, ray_sum);
+}
+
 size_t mlp_backward_pack_floats() { return PACKT_FLOATS; }
 
 void launch_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vi, const float *bc, const float *field_vm,

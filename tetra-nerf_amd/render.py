@@ -363,7 +363,7 @@ class TetraRenderer:
 
     def render_train(self, origins: torch.Tensor, directions: torch.Tensor, gradient_scaling: bool = False,
                      generator: Optional[torch.Generator] = None, rand: Optional[Dict[str, torch.Tensor]] = None,
-                     fused: bool = True) -> Dict[str, torch.Tensor]:
+                     fused: bool = True, capture: Optional[dict] = None) -> Dict[str, torch.Tensor]:
         """One training forward (TetrahedraNerf.get_outputs in training mode, model.py:520-662): stratified coarse samples
         (uniform or biased), optional PDF fine pass on the detached coarse weights (nerfstudio's PDFSampler detaches
         them), gather + MLP + heads, optional GradientScaler, weights and renderers -- differentiable w.r.t. the field
@@ -426,6 +426,9 @@ class TetraRenderer:
                 S = edges.shape[1] - 1
         dirs = directions[idx].contiguous()
         vi, bc = traced["vertex_indices"], traced["barycentric_coordinates"]
+        if capture is not None:   # the (non-differentiable) sample placement, for tests that restate the rest in float64
+            capture.update(idx=idx, vertex_indices=vi, barycentric_coordinates=bc, edges=edges, dirs=dirs,
+                           near=near_r, far=far_r, samples_per_ray=S)
         if fused:
             sigma, col = _FusedMlpFunction.apply(vi, bc, self.field, dirs, S, *w)
             sigma, col = sigma.view(-1, S), col.view(-1, S, 3)

@@ -516,6 +516,7 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
     grads = [torch.zeros_like(w, dtype=torch.float32) for w in keep]
     gw1, gb1, gw2, gb2, gw3, gb3, gwd, gbd, gwh, gbh, gwr, gbr = grads
     gwh_base = torch.zeros((128, 128), dtype=torch.float32, device=dev)
+    head_out = torch.zeros((4, 128), dtype=torch.float32, device=dev)   # d wd, d wr[0..2]
     grad_vm = torch.zeros((V, 64), dtype=torch.float32, device=dev)
     rays_per_chunk = max(1, int(chunk_samples) // S)
     R = n // S
@@ -535,12 +536,13 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
             for a, b, rows_b, gw, gb in ((d1, x0, 64, gw1, gb1), (d2, h1, 128, gw2, gb2), (d3, h2, 128, gw3, gb3),
                                          (d4, h3, 128, gwh_base, gbh)):
                 _lib.check(lib.tn_mlp_weight_grad(m, rows_b, _ptr(a), _ptr(b), _ptr(gw), _ptr(gb), stream))
-            # narrow heads: [128, m] x [m] products and the per-ray direction encoding
-            gwd += (h3 @ dhead[0])[None]
-            gbd += dhead[0].sum()
-            gwr += dhead[1:4] @ h4.t()
-            gbr += dhead[1:4].sum(1)
-            gwh[:, :27] += d4.view(128, r1 - r0, S).sum(-1) @ _direction_encoding(dirs[r0:r1])
+            # narrow heads + the direction-encoding columns of mlp_head: one bandwidth-bound pass over h3 / h4 / d4
+            ray_sum = torch.empty((128, r1 - r0), dtype=torch.float32, device=dev)
+            _lib.check(lib.tn_mlp_head_grad(m, S, _ptr(dhead), _ptr(h3), _ptr(h4), _ptr(d4), _ptr(head_out), _ptr(ray_sum), stream))
+            gwh[:, :27] += ray_sum @ _direction_encoding(dirs[r0:r1])
+            hsum = dhead.sum(1)
+            gbd += hsum[0]
+            gbr += hsum[1:4]
             # gradient of the gathered features -> field (vertex-major accumulation)
             rows = torch.empty((m, 64), dtype=torch.float32, device=dev)
             _lib.check(lib.tn_transpose_f32(64, m, _ptr(dx0), _ptr(rows), stream))
@@ -548,6 +550,8 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
                                                              stream))
             del buf, rows
         gwh[:, 27:] += gwh_base
+        gwd += head_out[0:1]
+        gwr += head_out[1:4]
         grad_field = torch.empty((64, V), dtype=torch.float32, device=dev)
         _lib.check(lib.tn_transpose_f32(V, 64, _ptr(grad_vm), _ptr(grad_field), stream))
     return grad_field, grads
