@@ -52,7 +52,10 @@ int tn_tracer_destroy(tn_tracer_t tracer);
  *   src/tetrahedra_tracer.h:304-309, src/tetrahedra_tracer.cpp:244-340;
  *   face table = convert_tetrahedra_to_triangles, src/tetrahedra_tracer.cpp:45-71
  * xyz   f32 [V,3] device, cells u32 [T,4] device (borrowed).
- * Errors: "A triangle is shared by more than two tetrahedra!" */
+ * The structures are built ON THE DEVICE from these buffers (csrc/tn_build.hip; option "gpu_build" = 0 selects the
+ * single-threaded host build of csrc/tn_mesh.cpp, which produces identical face tables, walk records and hull tree).
+ * Blocking, like the reference's.
+ * Errors: "A triangle is shared by more than two tetrahedra!", "cells contains a vertex index that is out of bounds" */
 int tn_load_tetrahedra(tn_tracer_t tracer, size_t num_vertices, size_t num_cells,
                        const float *xyz, const uint32_t *cells, void *stream);
 
@@ -62,6 +65,11 @@ size_t tn_num_faces(tn_tracer_t tracer);
 /* copies the face tables to HOST buffers (test/debug aid; faces u32 [F,3] in first-seen
  * order with the unsorted first-seen triple, face_tets u32 [F,2]) */
 int tn_get_faces(tn_tracer_t tracer, uint32_t *faces_host, uint32_t *face_tets_host);
+
+/* test aid: copies one structure load_tetrahedra built to a HOST buffer.  which: 0 faces, 1 face_tets, 2 walk records
+ * (64 B each), 3 hull nodes, 4 hull triangles, 5 BVH child rows, 6 BVH boxes, 7 BVH leaf ids, 8 BVH leaf triangles.
+ * *bytes receives the size in bytes; dst may be NULL (size query). */
+int tn_get_build_table(tn_tracer_t tracer, int which, void *dst, size_t *bytes);
 
 /* TetrahedraTracer::trace_rays                         src/tetrahedra_tracer.h:311-331,
  *   TraceRaysPipeline::trace_rays                       src/tetrahedra_tracer.cpp:137-176,

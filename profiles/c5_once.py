@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One warm-up + two trace_rays calls on a chosen config, for a per-dispatch rocprofv3 timeline.
-usage: c5_once.py <mesh points> <seed> <rays: N outside-in | frame> [walk_variant]"""
+usage: c5_once.py <mesh points> <seed> <rays: N outside-in | frame> [option=value ...]"""
 import importlib, sys
 from pathlib import Path
 import torch
@@ -13,8 +13,8 @@ pts, cells = scenes.random_mesh(npts, seed)
 tr = tn.TetrahedraTracer(dev); tr.load_tetrahedra(torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev))
 o, d = bench.frame_rays(scenes, 0, 800, 800) if rays == "frame" else scenes.outside_in_rays(int(rays), 4)
 o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
-if len(sys.argv) > 4:
-    tr.set_option("walk_variant", int(sys.argv[4]))
+for kv in sys.argv[4:]:        # option=value pairs
+    k, v = kv.split("="); tr.set_option(k, int(v))
 for _ in range(3):
     out = tr.trace_rays(o, d, 512); del out
     torch.cuda.synchronize()

@@ -77,7 +77,7 @@ int main(int argc, char **argv) {
             for (int a = 0; a < 3; ++a) CHECK(v.pn[a] == xyz[3 * (size_t)v.vid[0] + a]);
             const uint64_t codes = (uint64_t)v.code_lo | ((uint64_t)v.code_hi << 32);
             for (uint32_t x = 0; x < 3; ++x) {
-                const uint32_t fx = v.fid[x];
+                const uint32_t fx = v.fid(x);
                 CHECK(fx < F && fx != fe);
                 // the exit face contains n and the two entry vertices other than a/b/c[x], in ITS stored order = p-code
                 const uint32_t code = (uint32_t)(codes >> (12 * x)) & 0xFFFu;

@@ -14,7 +14,7 @@ LIB_PATH = _HERE / "libtetranerf_hip.so"
 # every symbol include/tetranerf_hip.h declares
 SYMBOLS = (
     "tn_last_error", "tn_version", "tn_tracer_create", "tn_tracer_destroy", "tn_load_tetrahedra",
-    "tn_num_faces", "tn_get_faces", "tn_trace_rays", "tn_trace_rays_triangles", "tn_find_tetrahedra",
+    "tn_num_faces", "tn_get_faces", "tn_get_build_table", "tn_trace_rays", "tn_trace_rays_triangles", "tn_find_tetrahedra",
     "tn_find_matched_cells", "tn_find_matched_cells_indexed",
     "tn_interpolate_values", "tn_interpolate_values_backward", "tn_interpolate_values_backward_rows",
     "tn_transpose_f32", "tn_interpolate_values_vm", "tn_interpolate_values_backward_vm",
@@ -48,6 +48,7 @@ def load():
     lib.tn_num_faces.restype = sz
     lib.tn_num_faces.argtypes = [vp]
     lib.tn_get_faces.argtypes = [vp, vp, vp]
+    lib.tn_get_build_table.argtypes = [vp, i32, vp, C.POINTER(sz)]
     lib.tn_trace_rays.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_trace_rays_triangles.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_find_tetrahedra.argtypes = [vp, sz, vp, vp, vp, vp, vp]

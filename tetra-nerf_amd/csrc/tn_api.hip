@@ -6,7 +6,9 @@
 #include <mutex>
 
 #include "../../include/tetranerf_hip.h"
+#include "tn_build.h"
 #include "tn_common.h"
+#include "tn_devbuf.h"
 #include "tn_kernels.h"
 
 namespace tn {
@@ -14,47 +16,14 @@ namespace tn {
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
 
-template <typename T>
-struct DevBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    void alloc(size_t count) {
-        release();
-        if (count) TN_HIP(hipMalloc((void **)&p, count * sizeof(T)));
-        n = count;
-    }
-    void upload(const std::vector<T> &h) {
-        alloc(h.size());
-        if (!h.empty()) TN_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
-    }
-    ~DevBuf() { release(); }
-};
-
-struct DevWideBvh {
-    DevBuf<float> leaf_tri, boxes;
-    DevBuf<uint32_t> leaf_id, child;
-    WideBvh view{};
-    void upload(const HostWideBvh &h, float scene_max) {
-        leaf_tri.upload(h.leaf_tri);
-        leaf_id.upload(h.leaf_id);
-        boxes.upload(h.boxes);
-        child.upload(h.child);
-        view.leaf_tri = leaf_tri.p; view.leaf_id = leaf_id.p; view.boxes = boxes.p; view.child = child.p;
-        view.n_nodes = (uint32_t)(h.child.size() / WIDE);
-        view.scene_max = scene_max;
-    }
-};
-
 }  // namespace tn
 
 struct tn_tracer {
     int device = 0;
     tn::DeviceMesh mesh;
-    tn::HostMesh host;  // kept for tn_get_faces
+    tn::HostMesh host;  // kept for tn_get_faces (device build: downloaded on first use)
+    bool gpu_build = true;   // structures built on the device (tn_build.hip); false: the single-threaded host build (tn_mesh.cpp)
+    uint32_t bvh_max_stack = 1;
     tn::DevBuf<uint32_t> faces, face_tets, fallback_list, walk_n;
     tn::DevBuf<uint2> literal_list;      // rays whose logged hits go through the literal sort + pairing
     tn::DevBuf<uint4> hit_log;           // walk -> segment writer / literal pairing: 16 B per recorded hit, [rays / 64][M][64]
@@ -67,6 +36,8 @@ struct tn_tracer {
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
     unsigned fill_blocks = 0;            // cap of the tail-fill grid (0 = default 2 blocks per CU); ablation knob
     unsigned seg_blocks = 0;             // cap of the segment-writer grid (0 = what the VGPR budget admits); ablation knob
+    unsigned seg_variant = 0;            // segment writer: 0 direct stores; 1 LDS-staged whole-line stores (faster alone, but its 55 KB of
+                                         // LDS per block starves the literal-pairing kernel beside it: profiles/r02c_*)
     unsigned seg_unroll = 4;             // segment writer: chunks of 8 hits per ray per iteration (4 or 2); ablation knob
     tn::DevBuf<tn::WalkVar> vars;
     tn::DevBuf<float> hull_nodes, hull_tris;
@@ -145,6 +116,7 @@ int tn_tracer_create(int device, tn_tracer_t *out) {
         auto t = std::make_unique<tn_tracer>();
         t->device = device;
         t->use_walk = env_flag("TETRANERF_HIP_WALK", true) ? 1 : 0;
+        t->gpu_build = env_flag("TETRANERF_HIP_GPU_BUILD", true);
         t->stats.alloc(26);
         TN_HIP(hipMemset(t->stats.p, 0, 26 * sizeof(unsigned long long)));
         {
@@ -181,7 +153,21 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         if ((V && !xyz) || (T && !cells)) throw tn::Error("xyz / cells must not be null");
         if (V >= 0xFFFFFFFFull || T >= 0x0FFFFFFFull) throw tn::Error("mesh too large (uint32 ids)");
         t->loaded = false;
-        // blocking D2H of the mesh (the reference does the same: tetrahedra_tracer.cpp:255-259)
+        t->host.faces.clear(); t->host.face_tets.clear();
+        size_t F = 0, n_hull = 0, n_hull_nodes = 0;
+        if (t->gpu_build && T > 0) {
+            // everything is built on the device from the caller's buffers (tn_build.hip)
+            tn::BuildInfo bi;
+            tn::device_build(V, T, xyz, cells, stream,
+                             tn::BuildTargets{t->faces, t->face_tets, t->vars, t->hull_nodes, t->hull_tris, t->bvh}, bi);
+            if (bi.max_stack > (uint32_t)tn::STACK_CAP)
+                throw tn::Error("face BVH too deep for the traversal stack (" + std::to_string(bi.max_stack) + " > " +
+                                std::to_string(tn::STACK_CAP) + " entries)");
+            t->host.scene_max = bi.scene_max;
+            t->bvh_max_stack = bi.max_stack;
+            F = bi.F; n_hull = bi.n_hull; n_hull_nodes = bi.n_hull_nodes;
+        } else {
+        // host build: blocking D2H of the mesh (the reference does the same: tetrahedra_tracer.cpp:255-259)
         std::vector<float> hxyz(3 * V);
         std::vector<uint32_t> hcells(4 * T);
         TN_HIP(hipStreamSynchronize(stream));
@@ -191,7 +177,7 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
             if (hcells[i] >= V) throw tn::Error("cells contains a vertex index that is out of bounds");
 
         tn::build_face_table(T, hcells.data(), t->host);
-        const size_t F = t->host.face_tets.size() / 2;
+        F = t->host.face_tets.size() / 2;
         float smax = 0.f;
         for (size_t i = 0; i < hcells.size(); ++i)
             for (int k = 0; k < 3; ++k) smax = std::max(smax, std::fabs(hxyz[3 * (size_t)hcells[i] + k]));
@@ -207,6 +193,7 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         if (hb.max_stack > (uint32_t)tn::STACK_CAP)
             throw tn::Error("face BVH too deep for the traversal stack (" + std::to_string(hb.max_stack) + " > " +
                             std::to_string(tn::STACK_CAP) + " entries)");
+        t->bvh_max_stack = hb.max_stack;
         std::vector<tn::TetRec> recs;
         std::vector<uint32_t> rec_of_tet;
         tn::build_tet_records(T, hcells.data(), hxyz.data(), t->host, recs, rec_of_tet);
@@ -223,16 +210,18 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         }
         t->hull_nodes.upload(hth.nodes);
         t->hull_tris.upload(hth.tris);
+        n_hull = hull_ids.size(); n_hull_nodes = hth.nodes.size() / 8;
+        }
 
         tn::DeviceMesh &m = t->mesh;
         m.xyz = xyz; m.cells = cells;
         m.V = (uint32_t)V; m.T = (uint32_t)T; m.F = (uint32_t)F;
         m.faces = t->faces.p; m.face_tets = t->face_tets.p;
         m.bvh = t->bvh.view;
-        m.vars = t->vars.p; m.n_hull = (uint32_t)hull_ids.size();
+        m.vars = t->vars.p; m.n_hull = (uint32_t)n_hull;
         m.hull_nodes = reinterpret_cast<const float4 *>(t->hull_nodes.p);
         m.hull_tris = reinterpret_cast<const float4 *>(t->hull_tris.p);
-        m.n_hull_nodes = (uint32_t)(hth.nodes.size() / 8);
+        m.n_hull_nodes = (uint32_t)n_hull_nodes;
         t->loaded = true;
     });
 }
@@ -243,9 +232,45 @@ int tn_get_faces(tn_tracer_t tracer, uint32_t *faces_host, uint32_t *face_tets_h
     return guarded([&] {
         tn_tracer *t = checked(tracer);
         if (!t->loaded) throw tn::Error("load_tetrahedra must be called first");
+        if (t->host.face_tets.size() != 2 * (size_t)t->mesh.F) {   // device build: the tables live on the device only
+            DeviceGuard g(t->device);
+            t->host.faces.resize(3 * (size_t)t->mesh.F);
+            t->host.face_tets.resize(2 * (size_t)t->mesh.F);
+            if (t->mesh.F) {
+                TN_HIP(hipMemcpy(t->host.faces.data(), t->faces.p, t->host.faces.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                TN_HIP(hipMemcpy(t->host.face_tets.data(), t->face_tets.p, t->host.face_tets.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            }
+        }
         if (faces_host) std::memcpy(faces_host, t->host.faces.data(), t->host.faces.size() * sizeof(uint32_t));
         if (face_tets_host)
             std::memcpy(face_tets_host, t->host.face_tets.data(), t->host.face_tets.size() * sizeof(uint32_t));
+    });
+}
+
+/* Test aid: copies one of the structures load_tetrahedra built to the host.  which: 0 faces, 1 face_tets, 2 walk records,
+ * 3 hull nodes, 4 hull triangles, 5 BVH child rows, 6 BVH boxes, 7 BVH leaf ids, 8 BVH leaf triangles.  *bytes receives
+ * the size; dst may be null (size query). */
+int tn_get_build_table(tn_tracer_t tracer, int which, void *dst, size_t *bytes) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        if (!t->loaded) throw tn::Error("load_tetrahedra must be called first");
+        DeviceGuard g(t->device);
+        const void *src = nullptr;
+        size_t n = 0;
+        switch (which) {
+            case 0: src = t->faces.p; n = t->faces.n * 4; break;
+            case 1: src = t->face_tets.p; n = t->face_tets.n * 4; break;
+            case 2: src = t->vars.p; n = t->vars.n * sizeof(tn::WalkVar); break;
+            case 3: src = t->hull_nodes.p; n = t->hull_nodes.n * 4; break;
+            case 4: src = t->hull_tris.p; n = t->hull_tris.n * 4; break;
+            case 5: src = t->bvh.child.p; n = t->bvh.child.n * 4; break;
+            case 6: src = t->bvh.boxes.p; n = t->bvh.boxes.n * 4; break;
+            case 7: src = t->bvh.leaf_id.p; n = t->bvh.leaf_id.n * 4; break;
+            case 8: src = t->bvh.leaf_tri.p; n = t->bvh.leaf_tri.n * 4; break;
+            default: throw tn::Error("unknown table");
+        }
+        if (bytes) *bytes = n;
+        if (dst && n) TN_HIP(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
     });
 }
 
@@ -327,7 +352,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             auto launch_segments = [&](size_t base, size_t n, hipStream_t st) {
                 tn::WriteParams q{};
                 q.num_rays = n; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
-                q.unroll = t->seg_unroll;
+                q.unroll = t->seg_unroll; q.variant = t->seg_variant;
                 q.walk_n = t->walk_n.p + base;
                 q.hit_log = t->hit_log.p;
                 q.vars = t->mesh.vars;
@@ -504,7 +529,8 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]) {
 int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);
-        if (name && std::strcmp(name, "walk") == 0) t->use_walk = value < 0 ? 0 : (value > 2 ? 2 : value);
+        if (name && std::strcmp(name, "gpu_build") == 0) t->gpu_build = value != 0;
+        else if (name && std::strcmp(name, "walk") == 0) t->use_walk = value < 0 ? 0 : (value > 2 ? 2 : value);
         else if (name && std::strcmp(name, "walk_min_rays") == 0) t->walk_min_rays = value < 0 ? 0 : (size_t)value;
         else if (name && std::strcmp(name, "debug") == 0) t->debug = (uint32_t)value;
         else if (name && std::strcmp(name, "gdebug") == 0) t->gdebug = (uint32_t)value;
@@ -514,6 +540,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && (std::strcmp(name, "rewalk") == 0 || std::strcmp(name, "rewalk_min") == 0)) {}  // round-1 knobs: no effect
         else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
         else if (name && std::strcmp(name, "seg_blocks") == 0) t->seg_blocks = (unsigned)value;
+        else if (name && std::strcmp(name, "seg_variant") == 0) t->seg_variant = value ? 1u : 0u;
         else if (name && std::strcmp(name, "seg_unroll") == 0) t->seg_unroll = value == 2 ? 2u : 4u;
         else if (name && std::strcmp(name, "log_cap_mb") == 0) t->log_cap_bytes = (size_t)(value < 1 ? 1 : value) << 20;
         else throw tn::Error(std::string("unknown option ") + (name ? name : "(null)"));
@@ -530,6 +557,22 @@ int tn_probe_stream_create(int first_cu, int num_cus, void **out) {
         hipStream_t s = nullptr;
         TN_HIP(hipExtStreamCreateWithCUMask(&s, 16, mask));
         *out = (void *)s;
+    });
+}
+/* re-runs the segment writer on the hit log of the tracer's last trace_rays call (same ray count, same M) into the given
+ * rows; `ablate` as WriteParams::ablate.  Timing probe only. */
+int tn_probe_write_segments(tn_tracer_t tracer, uint32_t M, uint32_t *visited, float *bary, float *dist, uint32_t *verts,
+                            int ablate, int blocks, void *stream) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        if (!t->last_walk) throw tn::Error("the last trace_rays call did not take the walk path");
+        tn::WriteParams q{};
+        q.num_rays = t->last_num_rays; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
+        q.unroll = t->seg_unroll; q.variant = t->seg_variant; q.ablate = (uint32_t)ablate;
+        q.walk_n = t->walk_n.p; q.hit_log = t->hit_log.p; q.vars = t->mesh.vars;
+        q.out_cells = visited; q.out_bary = bary; q.out_dist = dist; q.out_verts = verts;
+        tn::launch_write_segments(q, (hipStream_t)stream, (unsigned)blocks);
+        TN_HIP(hipGetLastError());
     });
 }
 int tn_probe_fill(void *dst, size_t bytes, int flavour, int blocks, void *stream) {

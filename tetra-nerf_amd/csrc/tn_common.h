@@ -90,14 +90,26 @@ static_assert(sizeof(TetRec) == 128, "TetRec must be one 128-B line");
 // STORED triple -- exactly the order the previous step left the face's sheared vertices and edge functions in,
 // so nothing of the entry face is permuted or recomputed.  Exit x in {0,1,2} = the face opposite a / b / c.
 struct alignas(64) WalkVar {
-    float pn[3];      // position of n
-    uint32_t orig;    // the caller's tet id
-    uint32_t vid[4];  // vertex ids n, a, b, c (= vertex_indices of a segment entered through this face)
-    uint32_t nb[3];   // variant entered through exit x (TN_EMPTY: hull)
-    uint32_t code_hi; // bits 32..35 of the code word
-    uint32_t fid[3];  // face id of exit x
-    uint32_t code_lo; // per exit x, 12 bits at 12x: p0 p1 p2 (2 bits each: the exit face's stored order in local
-                      // numbers), then c0 c1 c2 (2 bits each: position of a / b / c in that order, 3 = absent)
+    // quad 0 + 1 + 2: what the walk reads (three 16-byte loads)
+    float pn[3];       // position of n
+    uint32_t fid0;     // face id of exit 0
+    uint32_t nb[3];    // variant entered through exit x (TN_EMPTY: hull)
+    uint32_t fid1;     // face id of exit 1
+    // quad 2 + 3: what the segment writer reads (two 16-byte loads)
+    uint32_t orig;     // the caller's tet id
+    uint32_t code_lo;  // per exit x, 12 bits at 12x: p0 p1 p2 (2 bits each: the exit face's stored order in local
+                       // numbers), then c0 c1 c2 (2 bits each: position of a / b / c in that order, 3 = absent)
+    uint32_t code_hi;  // bits 32..35 of the code word
+    uint32_t fid2;     // face id of exit 2
+    uint32_t vid[4];   // vertex ids n, a, b, c (= vertex_indices of a segment entered through this face)
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t fid(uint32_t x) const { return x == 0 ? fid0 : (x == 1 ? fid1 : fid2); }   // dword 3 + 4x of the record
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    void set_fid(uint32_t x, uint32_t f) { if (x == 0) fid0 = f; else if (x == 1) fid1 = f; else fid2 = f; }
 };
 static_assert(sizeof(WalkVar) == 64, "WalkVar must be 64 bytes");
 
@@ -140,6 +152,10 @@ struct HostHullBvh {
 void build_hull_threaded(const float *xyz, const uint32_t *faces, const uint32_t *face_tets,
                          const std::vector<uint32_t> &ids, const std::vector<TetRec> &recs,
                          const std::vector<uint32_t> &rec_of_tet, HostHullBvh &out);
+
+// the same from 12 floats per hull face in ascending face-id order (v0.xyz, face id | v1.xyz, tet record | v2.xyz, local face)
+void build_hull_from_info(const std::vector<float> &info, HostHullBvh &out);
+uint32_t wide_bvh_max_stack(const uint32_t *child, size_t n_nodes);
 
 // first-seen face table; throws tn::Error("A triangle is shared by more than two tetrahedra!")
 void build_face_table(size_t T, const uint32_t *cells, HostMesh &out);

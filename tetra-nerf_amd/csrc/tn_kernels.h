@@ -67,6 +67,8 @@ struct WriteParams {
     uint32_t M;
     uint32_t dense_tails;      // 0: slots >= num_visited are left unwritten (non-reference option)
     uint32_t unroll;           // chunks of 8 hits per ray per iteration: 4 (default) or 2
+    uint32_t variant;          // 0 (default): direct stores; 1: LDS-staged whole-line stores
+    uint32_t ablate;           // probe only (profiles/): 1 no record loads, 2 only the cell-id store, 4 no stores
     const uint32_t *walk_n;
     const uint4 *hit_log;
     const WalkVar *vars;

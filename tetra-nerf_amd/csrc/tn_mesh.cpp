@@ -15,6 +15,7 @@
 #include <limits>
 #include <numeric>
 
+#include "tn_build_core.h"
 #include "tn_common.h"
 
 namespace tn {
@@ -158,10 +159,6 @@ void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<u
     if (out.leaf_id.empty()) { out.leaf_tri.assign(9 * WIDE, 0.0f); out.leaf_id.assign(WIDE, TN_EMPTY); }
 
     // 3. collapse to 64-wide nodes: open the child with the largest box until 64 children (or only leaves)
-    auto area = [&](int b) {
-        const float dx = bn[b].hi[0] - bn[b].lo[0], dy = bn[b].hi[1] - bn[b].lo[1], dz = bn[b].hi[2] - bn[b].lo[2];
-        return dx * dy + dy * dz + dz * dx;
-    };
     std::vector<std::pair<int, uint32_t>> todo;  // (binary subtree root, wide node index)
     auto new_node = [&]() -> uint32_t {
         const uint32_t id = (uint32_t)(out.child.size() / WIDE);
@@ -177,19 +174,15 @@ void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<u
     while (!todo.empty()) {
         const auto [sub, wid] = todo.back();
         todo.pop_back();
-        std::vector<int> kids;
-        if (bn[sub].left < 0) kids.push_back(sub);
-        else { kids.push_back(bn[sub].left); kids.push_back(bn[sub].right); }
-        for (;;) {
-            int best = -1;
-            float best_a = -1.f;
-            for (size_t i = 0; i < kids.size(); ++i)
-                if (bn[kids[i]].left >= 0 && area(kids[i]) > best_a) { best_a = area(kids[i]); best = (int)i; }
-            if (best < 0 || kids.size() >= (size_t)WIDE) break;
-            const int k = kids[best];
-            kids[best] = bn[k].left;
-            kids.push_back(bn[k].right);
-        }
+        struct HostTree {
+            const std::vector<BNode> &bn;
+            int left(int k) const { return bn[k].left; }
+            int right(int k) const { return bn[k].right; }
+            float area(int k) const { return core::box_area(bn[k].lo, bn[k].hi); }
+        };
+        int kid_buf[WIDE];
+        const int nk = core::collapse_node(sub, HostTree{bn}, kid_buf);
+        const std::vector<int> kids(kid_buf, kid_buf + nk);
         for (size_t i = 0; i < kids.size(); ++i) {
             const int k = kids[i];
             for (int a = 0; a < 3; ++a) {
@@ -208,19 +201,7 @@ void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<u
     // its internal children (in child order) and the last pushed is popped first, so below the j-th pushed child j
     // entries are waiting.  need(node) = max(#internal children, max_j (j + need(child_j))).  Children have larger
     // node indices than their parent, so one reverse sweep evaluates it.
-    const size_t nn = out.child.size() / WIDE;
-    std::vector<uint32_t> need(nn, 0);
-    for (size_t w = nn; w-- > 0;) {
-        uint32_t j = 0, m = 0;
-        for (int i = 0; i < WIDE; ++i) {
-            const uint32_t ch = out.child[w * WIDE + i];
-            if (ch == TN_EMPTY || (ch >> 31)) continue;
-            m = std::max(m, j + need[ch]);
-            ++j;
-        }
-        need[w] = std::max(m, j);
-    }
-    out.max_stack = nn ? std::max<uint32_t>(need[0], 1u) : 1u;
+    out.max_stack = wide_bvh_max_stack(out.child.data(), out.child.size() / WIDE);
 }
 
 void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const HostMesh &hm,
@@ -359,97 +340,77 @@ void build_walk_variants(const std::vector<TetRec> &recs, std::vector<WalkVar> &
     out.assign(4 * T, WalkVar{});
     for (size_t r = 0; r < T; ++r) {
         const TetRec &t = recs[r];
-        uint32_t loc[4][3];  // stored order of face k in the tet's local vertex indices
-        for (int k = 0; k < 4; ++k)
-            for (int m = 0; m < 3; ++m) loc[k][m] = (t.perm >> (6 * k + 2 * m)) & 3u;
-        for (uint32_t e = 0; e < 4; ++e) {
-            WalkVar &v = out[4 * r + e];
-            uint32_t canon[4] = {0, 0, 0, 0};  // tet-local vertex index -> {0: n, 1: a, 2: b, 3: c}
-            canon[e] = 0;
-            for (int m = 2; m >= 0; --m) canon[loc[e][m]] = (uint32_t)m + 1;  // first match wins on degenerate tets
-            for (int a = 0; a < 3; ++a) v.pn[a] = t.pos[e][a];
-            v.orig = t.orig;
-            v.vid[0] = t.vert[e];
-            for (int m = 0; m < 3; ++m) v.vid[m + 1] = t.vert[loc[e][m]];
-            uint64_t codes = 0;
-            for (uint32_t x = 0; x < 3; ++x) {
-                const uint32_t k = loc[e][x];  // the exit face is the one opposite a / b / c
-                v.fid[x] = t.face[k];
-                v.nb[x] = t.nbr[k] == TN_EMPTY ? TN_EMPTY : 4u * t.nbr[k] + ((t.back >> (2 * k)) & 3u);
-                uint32_t p[3];
-                for (int m = 0; m < 3; ++m) p[m] = canon[loc[k][m]];
-                uint32_t code = p[0] | (p[1] << 2) | (p[2] << 4);
-                for (uint32_t j = 0; j < 3; ++j) {
-                    uint32_t pos = 3;
-                    for (uint32_t m = 0; m < 3; ++m) if (p[m] == j + 1) { pos = m; break; }
-                    code |= pos << (6 + 2 * j);
-                }
-                codes |= (uint64_t)code << (12 * x);
-            }
-            v.code_lo = (uint32_t)codes;
-            v.code_hi = (uint32_t)(codes >> 32);
+        core::TetAdj adj;
+        adj.ok = true;
+        for (int k = 0; k < 4; ++k) {
+            adj.vert[k] = t.vert[k];
+            adj.fid[k] = t.face[k];
+            adj.nbr[k] = t.nbr[k];
+            adj.back[k] = (t.back >> (2 * k)) & 3u;
+            for (int m = 0; m < 3; ++m) adj.loc[k][m] = (t.perm >> (6 * k + 2 * m)) & 3u;  // stored order of face k in local ids
         }
+        for (uint32_t e = 0; e < 4; ++e) out[4 * r + e] = core::make_walk_var(adj, t.nbr, t.pos[e], t.orig, e);
     }
 }
 
-// Threaded binary BVH over the hull faces, nodes in DFS pre-order: the "hit" successor of a node
-// is the next node, the "miss" successor is `skip`.  A lane can traverse it without a stack and in
-// a ray-independent order (all crossings are wanted, not the nearest).  Leaves hold <= 4 faces.
 void build_hull_threaded(const float *xyz, const uint32_t *faces, const uint32_t *face_tets,
                          const std::vector<uint32_t> &ids, const std::vector<TetRec> &recs,
                          const std::vector<uint32_t> &rec_of_tet, HostHullBvh &out) {
+    // per hull face, in `ids` order: v0.xyz, face id | v1.xyz, tet record | v2.xyz, local face
     const size_t n = ids.size();
-    out.nodes.clear();
-    out.tris.clear();
-    if (n == 0) return;
-    // Morton order (same code as the wide tree)
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    std::vector<float> cent(3 * n);
+    std::vector<float> info(n * 12);
     for (size_t i = 0; i < n; ++i) {
-        const uint32_t *f = faces + 3 * (size_t)ids[i];
-        for (int k = 0; k < 3; ++k) {
-            const float c = (xyz[3 * (size_t)f[0] + k] + xyz[3 * (size_t)f[1] + k] + xyz[3 * (size_t)f[2] + k]) * (1.0f / 3.0f);
-            cent[3 * i + k] = c;
-            lo[k] = std::min(lo[k], c); hi[k] = std::max(hi[k], c);
-        }
-    }
-    std::vector<std::pair<uint64_t, uint32_t>> order(n);
-    for (size_t i = 0; i < n; ++i) {
-        uint64_t code = 0;
-        for (int k = 0; k < 3; ++k) {
-            const double ext = (double)hi[k] - (double)lo[k];
-            const double u = ext > 0 ? ((double)cent[3 * i + k] - lo[k]) / ext : 0.0;
-            const uint64_t q = (uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0));
-            code |= spread21(q) << k;
-        }
-        order[i] = {code, (uint32_t)i};
-    }
-    std::sort(order.begin(), order.end());
-    // triangle slots in Morton order: 3 x float4 (v.xyz, w): w of v0 carries the face id bits
-    out.tris.resize(n * 12);
-    std::vector<float> fb(6 * n);
-    for (size_t s = 0; s < n; ++s) {
-        const uint32_t fid = ids[order[s].second];
+        const uint32_t fid = ids[i];
         const uint32_t *f = faces + 3 * (size_t)fid;
-        for (int k = 0; k < 3; ++k) { fb[6 * s + k] = INFINITY; fb[6 * s + 3 + k] = -INFINITY; }
-        for (int v = 0; v < 3; ++v) {
-            for (int k = 0; k < 3; ++k) {
-                const float x = xyz[3 * (size_t)f[v] + k];
-                out.tris[s * 12 + v * 4 + k] = x;
-                fb[6 * s + k] = std::min(fb[6 * s + k], x); fb[6 * s + 3 + k] = std::max(fb[6 * s + 3 + k], x);
-            }
-            out.tris[s * 12 + v * 4 + 3] = 0.0f;
-        }
-        std::memcpy(&out.tris[s * 12 + 3], &fid, 4);
+        for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < 3; ++k) info[i * 12 + v * 4 + k] = xyz[3 * (size_t)f[v] + k];
         // the hull face's only tet (as a record index) and the face's local index in it
         const uint32_t rec = rec_of_tet[face_tets[2 * (size_t)fid]];
         uint32_t loc = 0;
         for (; loc < 4; ++loc) if (recs[rec].face[loc] == fid) break;
         if (loc == 4) throw Error("internal: hull face not found in its tetrahedron");
-        std::memcpy(&out.tris[s * 12 + 7], &rec, 4);
-        std::memcpy(&out.tris[s * 12 + 11], &loc, 4);
+        std::memcpy(&info[i * 12 + 3], &fid, 4);
+        std::memcpy(&info[i * 12 + 7], &rec, 4);
+        std::memcpy(&info[i * 12 + 11], &loc, 4);
     }
-    struct Frame { size_t a, b; };
+    build_hull_from_info(info, out);
+}
+
+// Threaded binary BVH over the hull faces, nodes in DFS pre-order: the "hit" successor of a node
+// is the next node, the "miss" successor is `skip`.  A lane can traverse it without a stack and in
+// a ray-independent order (all crossings are wanted, not the nearest).  Leaves hold <= 4 faces.
+// `info` = 12 floats per hull face in ascending face-id order (see build_hull_threaded / core::hull_face_info).
+void build_hull_from_info(const std::vector<float> &info, HostHullBvh &out) {
+    const size_t n = info.size() / 12;
+    out.nodes.clear();
+    out.tris.clear();
+    if (n == 0) return;
+    // Morton order of the face centroids
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    std::vector<float> cent(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) {
+            const float c = (info[i * 12 + k] + info[i * 12 + 4 + k] + info[i * 12 + 8 + k]) * (1.0f / 3.0f);
+            cent[3 * i + k] = c;
+            lo[k] = std::min(lo[k], c); hi[k] = std::max(hi[k], c);
+        }
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = {core::morton63(&cent[3 * i], lo, hi), (uint32_t)i};
+    std::sort(order.begin(), order.end());
+    // triangle slots in Morton order: 3 x float4 (v.xyz, w)
+    out.tris.resize(n * 12);
+    std::vector<float> fb(6 * n);
+    for (size_t s = 0; s < n; ++s) {
+        const float *src = &info[(size_t)order[s].second * 12];
+        std::memcpy(&out.tris[s * 12], src, 12 * sizeof(float));
+        for (int k = 0; k < 3; ++k) { fb[6 * s + k] = INFINITY; fb[6 * s + 3 + k] = -INFINITY; }
+        for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < 3; ++k) {
+                const float x = src[v * 4 + k];
+                fb[6 * s + k] = std::min(fb[6 * s + k], x); fb[6 * s + 3 + k] = std::max(fb[6 * s + 3 + k], x);
+            }
+    }
     // recursive emit in pre-order
     std::function<void(size_t, size_t)> emit = [&](size_t a, size_t b) {
         const size_t me = out.nodes.size() / 8;
@@ -470,6 +431,60 @@ void build_hull_threaded(const float *xyz, const uint32_t *faces, const uint32_t
         nd[4] = bhi[0]; nd[5] = bhi[1]; nd[6] = bhi[2]; std::memcpy(&nd[7], &leaf, 4);
     };
     emit(0, n);
+}
+
+// Shape of the median-split binary tree over n faces (core::BinNode): BFS order, level by level; a node of `count`
+// faces splits into count / 2 and count - count / 2 while count > WIDE.  frontier[l] = the partition of [0, n) after
+// l splitting rounds, as node indices in position order (nodes that stopped splitting stay in the later frontiers).
+void build_bin_topology(size_t n, std::vector<core::BinNode> &bn, std::vector<std::vector<uint32_t>> &frontier,
+                        std::vector<uint32_t> &level_start, std::vector<uint32_t> &leaf_nodes) {
+    bn.clear(); frontier.clear(); level_start.clear(); leaf_nodes.clear();
+    if (n == 0) return;
+    bn.push_back(core::BinNode{0u, (uint32_t)n, -1, -1, -1, 0u});
+    level_start.push_back(0u);
+    std::vector<uint32_t> cur{0u};
+    for (uint32_t level = 0;; ++level) {
+        frontier.push_back(cur);
+        bool any = false;
+        for (uint32_t k : cur) any = any || bn[k].count > (uint32_t)WIDE;
+        if (!any) break;
+        level_start.push_back((uint32_t)bn.size());
+        std::vector<uint32_t> next;
+        next.reserve(2 * cur.size());
+        for (uint32_t k : cur) {
+            if (bn[k].count > (uint32_t)WIDE && bn[k].left < 0) {
+                const uint32_t half = bn[k].count / 2;
+                const int l = (int)bn.size();
+                bn.push_back(core::BinNode{bn[k].first, half, -1, -1, -1, level + 1});
+                bn.push_back(core::BinNode{bn[k].first + half, bn[k].count - half, -1, -1, -1, level + 1});
+                bn[k].left = l; bn[k].right = l + 1;
+                next.push_back((uint32_t)l); next.push_back((uint32_t)l + 1);
+            } else {
+                next.push_back(k);
+            }
+        }
+        cur.swap(next);
+    }
+    level_start.push_back((uint32_t)bn.size());
+    // leaves in position order = the last frontier
+    for (uint32_t k : frontier.back()) { bn[k].leaf = (int32_t)leaf_nodes.size(); leaf_nodes.push_back(k); }
+}
+
+// Worst-case occupancy of the traversal stack of collect_hits for a wide tree whose children have larger node
+// indices than their parent (see build_wide_bvh).
+uint32_t wide_bvh_max_stack(const uint32_t *child, size_t n_nodes) {
+    std::vector<uint32_t> need(n_nodes, 0);
+    for (size_t w = n_nodes; w-- > 0;) {
+        uint32_t j = 0, m = 0;
+        for (int i = 0; i < WIDE; ++i) {
+            const uint32_t ch = child[w * WIDE + i];
+            if (ch == TN_EMPTY || (ch >> 31)) continue;
+            m = std::max(m, j + need[ch]);
+            ++j;
+        }
+        need[w] = std::max(m, j);
+    }
+    return n_nodes ? std::max<uint32_t>(need[0], 1u) : 1u;
 }
 
 }  // namespace tn

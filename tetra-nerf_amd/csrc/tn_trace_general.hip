@@ -417,7 +417,7 @@ __global__ __launch_bounds__(64) void k_postprocess_hits(TraceParams p, const ui
 
 // Literal sort + pairing of the hits the walk LOGGED for the rays whose chain is sound but whose order it does not
 // certify (a gap below eps, a tie, an inversion): hit k of launch item r is the 16-byte log entry
-// ((r / 64) * M + k) * 64 + r % 64 = {t, u, v, variant | exit << 30}; its face id is the walk record's fid[exit]
+// ((r / 64) * M + k) * 64 + r % 64 = {t, u, v, variant | exit << 30}; its face id is the walk record's fid(exit) (dword 3 + 4 * exit)
 // (exit code 3: the entry hull face, id in the low bits).  The chain's faces are the ray's all-hits set (two hull
 // crossings, two crossed faces per tet, no zero edge function), so this equals the BVH path -- sort on (t, face id),
 // then the reference's phases literally (optix_trace_rays.cu:110-266) -- without a traversal.
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const Wal
         for (uint32_t j = lane; j < nh; j += 64) {
             const uint4 e = lg[(size_t)j * 64];
             const uint32_t x = e.w >> 30, lo = e.w & 0x3FFFFFFFu;
-            const uint32_t fid = x == 3u ? lo : reinterpret_cast<const uint32_t *>(vars + lo)[12 + x];
+            const uint32_t fid = x == 3u ? lo : reinterpret_cast<const uint32_t *>(vars + lo)[3 + 4 * x];
             s.key[j] = ((uint64_t)e.x << 32) | fid;
             s.hu[j] = __uint_as_float(e.y);
             s.hv[j] = __uint_as_float(e.z);

@@ -85,19 +85,19 @@ __device__ __forceinline__ float sel4f(float a, float b, float c, float d, uint3
     return b1 ? hi : lo;
 }
 
-// The part of a walk record the walk itself reads (40 of its 64 bytes; the tet id and the vertex ids are only
-// needed by k_write_rows), as SCALARS: with the neighbours / face ids kept in a uint4 the optimiser turns the select
+// The part of a walk record the walk itself reads (quads 0..2 of its 64 bytes; the tet id and the vertex ids are only
+// needed by the segment writer), as SCALARS: with the neighbours / face ids kept in a uint4 the optimiser turns the select
 // chain below into a dynamically indexed vector, parks the record in LDS and reads `nb` back with a ds_read -- an
 // LDS round trip on the one dependent chain of the walk (record -> exit -> next record).
 struct Var { float px, py, pz; uint32_t nb0, nb1, nb2, code_hi, f0, f1, f2, code_lo; };
 __device__ __forceinline__ Var load_var(const WalkVar *vars, uint32_t c) {
     const uint32_t *r = reinterpret_cast<const uint32_t *>(vars + c);
     const float4 q0 = *reinterpret_cast<const float4 *>(r);
-    const uint4 q2 = *reinterpret_cast<const uint4 *>(r + 8), q3 = *reinterpret_cast<const uint4 *>(r + 12);
+    const uint4 q1 = *reinterpret_cast<const uint4 *>(r + 4), q2 = *reinterpret_cast<const uint4 *>(r + 8);
     Var v;
-    v.px = q0.x; v.py = q0.y; v.pz = q0.z;
-    v.nb0 = q2.x; v.nb1 = q2.y; v.nb2 = q2.z; v.code_hi = q2.w;
-    v.f0 = q3.x; v.f1 = q3.y; v.f2 = q3.z; v.code_lo = q3.w;
+    v.px = q0.x; v.py = q0.y; v.pz = q0.z; v.f0 = __float_as_uint(q0.w);
+    v.nb0 = q1.x; v.nb1 = q1.y; v.nb2 = q1.z; v.f1 = q1.w;
+    v.code_lo = q2.y; v.code_hi = q2.z; v.f2 = q2.w;
     return v;
 }
 __device__ __forceinline__ uint32_t sel3u(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t i) {  // i in 0..2 (3 -> v2)
@@ -277,8 +277,12 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             const bool is_short = fabsf(pt - ct) < TN_EPS;
             const bool asc = (ct > pt) || (ct == pt && fx > fid_prev);   // sorted order of the two = chain order
             const bool clear2 = ct - ppt >= TN_EPS;
-            const bool ok = is_short ? (!prev_short && (asc || (have_pp && clear2)))   // isolated; inverted: clear of the face before
-                                     : (asc && (!prev_inv || clear2));                 // after an inverted pair: clear of both
+            // short + ascending: any run of them is fine (header), except a run that starts at the entry hull face
+            // (pairs 1 and 2 both short: nhits == 2 here); short + inverted: isolated and clear of the face before;
+            // after an inverted pair: a long gap, clear of both of its members
+            const bool ok = is_short ? (asc ? (!prev_inv && !(prev_short && nhits == 2))
+                                            : (!prev_short && have_pp && clear2))
+                                     : (asc && (!prev_inv || clear2));
             order_ok = order_ok && (!vp || ok);
             nshort += (vp && is_short) ? 1u : 0u;
             prev_inv = vp ? (is_short && !asc) : prev_inv;
@@ -439,11 +443,11 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 orig[u] = 0; chi[u] = 0; clo[u] = 0; vid[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (slot[u] != TN_EMPTY) {
+                if (slot[u] != TN_EMPTY && !(q.ablate & 1u)) {
                     const uint32_t *rec = reinterpret_cast<const uint32_t *>(q.vars + (e[u].w & 0x3FFFFFFFu));
-                    orig[u] = rec[3];
-                    vid[u] = *reinterpret_cast<const uint4 *>(rec + 4);
-                    chi[u] = rec[11]; clo[u] = rec[15];
+                    const uint4 q2 = *reinterpret_cast<const uint4 *>(rec + 8);
+                    orig[u] = q2.x; clo[u] = q2.y; chi[u] = q2.z;
+                    vid[u] = *reinterpret_cast<const uint4 *>(rec + 12);
                 }
             }
 #pragma unroll
@@ -459,7 +463,9 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
                     const float ct = __uint_as_float(e[u].x), cu = __uint_as_float(e[u].y), cv = __uint_as_float(e[u].z);
                     const float r0f = 1.0f - cu - cv;
                     const uint32_t k0 = (code >> 6) & 3u, k1 = (code >> 8) & 3u, k2 = (code >> 10) & 3u;
+                    if (q.ablate & 4u) { if (orig[u] == 0xFFFFFFF1u) q.out_cells[sl] = code + k0; continue; }
                     q.out_cells[sl] = orig[u];
+                    if (q.ablate & 2u) { if (k0 + k1 + k2 + vid[u].x == 0xFFFFFFF1u) q.out_cells[sl] = __float_as_uint(pt + ct + pu + pv); continue; }
                     *reinterpret_cast<float2 *>(q.out_dist + 2 * sl) = make_float2(pt, ct);
                     float2 *bp = reinterpret_cast<float2 *>(q.out_bary + 6 * sl);
                     bp[0] = make_float2(1.0f - pu - pv, pu);
@@ -490,17 +496,209 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
     }
 }
 
+// The same hit log -> segment rows, with the stores made whole-line: round 2b's ablation of the kernel above
+// (profiles/r02b_writer_ablate.txt) showed that half of its time is the ~24 scattered store instructions per
+// iteration -- lane (ray a, hit h) writes its own 4 / 8 / 24 / 16 bytes, so one instruction touches 8 rows in pieces of
+// 32..192 bytes -- and a fifth the four scattered record loads per hit.  Here the 52-byte segment records of an
+// iteration (8 rays x up to 32 slots) are staged in the wave's LDS region laid out [array][ray][slot], and read back
+// with lane = (ray, consecutive dword / 8-byte / 16-byte unit of that ray's run): every store instruction writes
+// contiguous runs of up to 128 B (cell ids), 256 B (distances), 512 B (vertex ids, barycentrics) per ray.  The
+// record is read as two 16-byte quads (tet id + code, vertex ids).  LDS: 13.8 KB per wave (rows padded to 33 slots
+// against bank conflicts between the 8 rays).  Everything else (pipeline, pairing, slot numbering) as above.
+namespace {
+constexpr int SW_STRIDE = 33;                       // padded slots per ray
+constexpr int SW_CELLS = 0;                         // [8][33] dwords
+constexpr int SW_DIST = 8 * SW_STRIDE;              // [8][33][2]
+constexpr int SW_BARY = SW_DIST + 8 * SW_STRIDE * 2;   // [8][33][6]
+constexpr int SW_VERTS = SW_BARY + 8 * SW_STRIDE * 6;  // [8][33][4]
+constexpr int SW_META = SW_VERTS + 8 * SW_STRIDE * 4;  // [8] x {segments of this iteration, first slot}
+constexpr int SW_TOTAL = SW_META + 16;              // 3448 dwords = 13,792 B per wave
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
+    constexpr int U = 4;
+    __shared__ __attribute__((aligned(16))) uint32_t smem[4 * SW_TOTAL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *L = smem + wave * SW_TOTAL;
+    const uint32_t a = (uint32_t)lane & 7u, h = (uint32_t)lane >> 3;
+    const uint32_t M = q.M;
+    const size_t G = (q.num_rays + 7) / 8;                 // groups of 8 rays
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    const unsigned long long raymask = 0x0101010101010101ull << a;
+
+    auto hits_of = [&](size_t g) -> uint32_t {             // walk_n of ray 8g + a (TN_EMPTY: not this kernel's row)
+        const size_t r = 8 * g + a;
+        return (g < G && r < q.num_rays) ? q.walk_n[r] : TN_EMPTY;
+    };
+    auto log_of = [&](size_t g) -> const uint4 * {         // entry k of ray 8g + a at [k * 64]
+        const size_t r0 = 8 * g;
+        return q.hit_log + (r0 >> 6) * (size_t)M * 64 + (r0 & 63) + a;
+    };
+    auto load_entries = [&](uint4 (&e)[U], const uint4 *lg, uint32_t nh, uint32_t c0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t k = c0 + 8 * u + h;
+            e[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (k < nh) e[u] = lg[(size_t)k * 64];
+        }
+    };
+
+    size_t g = (size_t)blockIdx.x * 4 + wave;
+    if (g >= G) return;
+    uint32_t nh_raw = hits_of(g);
+    uint32_t nh_next_raw = hits_of(g + nwaves);
+    uint4 e[U];
+    {
+        const uint32_t nh0 = nh_raw == TN_EMPTY ? 0u : nh_raw;
+        load_entries(e, log_of(g), nh0, 0);
+    }
+    for (; g < G; g += nwaves) {
+        const bool skip = nh_raw == TN_EMPTY;
+        const uint32_t nh = skip ? 0u : nh_raw;
+        uint32_t mx = nh;
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)mx, off);
+            mx = o > mx ? o : mx;
+        }
+        mx = __builtin_amdgcn_readfirstlane(mx);
+        const uint4 *lg = log_of(g);
+        const size_t row0 = 8 * g * (size_t)M;             // first slot of ray 8g
+        const size_t row = row0 + (size_t)a * M;
+        const size_t g_next = g + nwaves;
+        const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : nh_next_raw;
+        const uint32_t nh_next2_raw = hits_of(g_next + nwaves);
+        uint32_t nseg = 0;
+        uint4 carry = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t c0 = 0;
+        do {
+            uint4 en[U];
+            const bool more = c0 + 8 * U < mx;   // wave-uniform
+            if (more) load_entries(en, lg, nh, c0 + 8 * U);
+            else load_entries(en, log_of(g_next), g_next < G ? nh_next : 0u, 0);
+            const uint32_t base = nseg;
+            uint4 pe[U];
+            uint32_t slot[U];   // slot within this iteration (0..31), TN_EMPTY: no segment
+            unsigned long long any = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t k = c0 + 8 * u + h;
+                pe[u].x = (uint32_t)__shfl_up((int)e[u].x, 8); pe[u].y = (uint32_t)__shfl_up((int)e[u].y, 8);
+                pe[u].z = (uint32_t)__shfl_up((int)e[u].z, 8); pe[u].w = 0u;
+                if (h == 0) pe[u] = carry;
+                carry.x = (uint32_t)__shfl((int)e[u].x, (int)a + 56); carry.y = (uint32_t)__shfl((int)e[u].y, (int)a + 56);
+                carry.z = (uint32_t)__shfl((int)e[u].z, (int)a + 56);
+                const bool emit = k >= 1 && k < nh && !(fabsf(__uint_as_float(pe[u].x) - __uint_as_float(e[u].x)) < TN_EPS);
+                const unsigned long long mall = __ballot(emit);
+                const unsigned long long m = mall & raymask;
+                any |= mall;
+                slot[u] = emit ? (nseg - base) + (uint32_t)__popcll(m & lanemask_lt()) : TN_EMPTY;
+                nseg += (uint32_t)__popcll(m);
+            }
+            if (any) {   // wave-uniform
+                // ---- walk records of the emitted segments: quad 2 = {tet id, code_lo, code_hi, .}, quad 3 = vertex ids
+                uint4 qa[U], qv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    qa[u] = make_uint4(0u, 0u, 0u, 0u); qv[u] = qa[u];
+                    if (slot[u] != TN_EMPTY) {
+                        const uint32_t *rec = reinterpret_cast<const uint32_t *>(q.vars + (e[u].w & 0x3FFFFFFFu));
+                        qa[u] = *reinterpret_cast<const uint4 *>(rec + 8);
+                        qv[u] = *reinterpret_cast<const uint4 *>(rec + 12);
+                    }
+                }
+                // ---- segment records -> LDS [array][ray][slot]
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (slot[u] != TN_EMPTY) {
+                        const uint32_t at = a * SW_STRIDE + slot[u];
+                        const uint32_t x = e[u].w >> 30;
+                        const bool x0 = (x & 1u) != 0, x1 = (x & 2u) != 0;
+                        const uint32_t w01 = x0 ? (qa[u].y >> 12) : qa[u].y;
+                        const uint32_t w2 = (qa[u].y >> 24) | (qa[u].z << 8);
+                        const uint32_t code = (x1 ? w2 : w01) & 0xFFFu;
+                        const float pt = __uint_as_float(pe[u].x), pu = __uint_as_float(pe[u].y), pv = __uint_as_float(pe[u].z);
+                        const float ct = __uint_as_float(e[u].x), cu = __uint_as_float(e[u].y), cv = __uint_as_float(e[u].z);
+                        const float r0f = 1.0f - cu - cv;
+                        const uint32_t k0 = (code >> 6) & 3u, k1 = (code >> 8) & 3u, k2 = (code >> 10) & 3u;
+                        L[SW_CELLS + at] = qa[u].x;
+                        *reinterpret_cast<float2 *>(L + SW_DIST + 2 * at) = make_float2(pt, ct);
+                        float2 *bp = reinterpret_cast<float2 *>(L + SW_BARY + 6 * at);
+                        bp[0] = make_float2(1.0f - pu - pv, pu);
+                        bp[1] = make_float2(pv, sel4f(r0f, cu, cv, 0.f, k0));
+                        bp[2] = make_float2(sel4f(r0f, cu, cv, 0.f, k1), sel4f(r0f, cu, cv, 0.f, k2));
+                        *reinterpret_cast<uint4 *>(L + SW_VERTS + 4 * at) = qv[u];   // (n, a, b, c)
+                    }
+                }
+                if (h == 0) *reinterpret_cast<uint2 *>(L + SW_META + 2 * a) = make_uint2(nseg - base, base);
+                wave_lds_fence();
+                // ---- LDS -> rows: lane = (ray a2, unit d of that ray's run of this iteration)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {           // cell ids (4 B), distances (8 B), vertex ids (16 B) per slot
+                    const uint32_t a2 = 2u * qd + ((uint32_t)lane >> 5), d = (uint32_t)lane & 31u;
+                    const uint2 meta = *reinterpret_cast<const uint2 *>(L + SW_META + 2 * a2);
+                    if (d < meta.x) {
+                        const uint32_t at = a2 * SW_STRIDE + d;
+                        const size_t sl = row0 + (size_t)a2 * M + meta.y + d;
+                        q.out_cells[sl] = L[SW_CELLS + at];
+                        *reinterpret_cast<float2 *>(q.out_dist + 2 * sl) = *reinterpret_cast<const float2 *>(L + SW_DIST + 2 * at);
+                        if (q.out_verts) *reinterpret_cast<uint4 *>(q.out_verts + 4 * sl) = *reinterpret_cast<const uint4 *>(L + SW_VERTS + 4 * at);
+                    }
+                }
+#pragma unroll
+                for (int qd = 0; qd < 12; ++qd) {          // barycentrics: 3 x 8 B per slot, 96 units per ray
+                    const uint32_t gi = 64u * qd + (uint32_t)lane;
+                    const uint32_t a2 = gi / 96u, d = gi - 96u * a2;
+                    const uint2 meta = *reinterpret_cast<const uint2 *>(L + SW_META + 2 * a2);
+                    if (d < 3u * meta.x) {
+                        const size_t sl = row0 + (size_t)a2 * M + meta.y;
+                        *reinterpret_cast<float2 *>(q.out_bary + 6 * sl + 2 * d) =
+                            *reinterpret_cast<const float2 *>(L + SW_BARY + 6 * (a2 * SW_STRIDE) + 2 * d);
+                    }
+                }
+                wave_lds_fence();
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) e[u] = en[u];
+            c0 += 8 * U;
+        } while (c0 < mx);
+        // tail constants up to the next multiple of 32 slots (line boundary of all four arrays)
+        if (q.dense_tails && !skip) {
+            uint32_t n32 = (nseg + 31u) & ~31u;
+            if (n32 > M) n32 = M;
+            for (uint32_t sl = nseg + h; sl < n32; sl += 8) {
+                const size_t slot = row + sl;
+                q.out_cells[slot] = TN_EMPTY;
+                *reinterpret_cast<float2 *>(q.out_dist + 2 * slot) = make_float2(0.f, 0.f);
+                float2 *bp = reinterpret_cast<float2 *>(q.out_bary + 6 * slot);
+                bp[0] = make_float2(0.f, 0.f); bp[1] = make_float2(0.f, 0.f); bp[2] = make_float2(0.f, 0.f);
+                if (q.out_verts) *reinterpret_cast<uint4 *>(q.out_verts + 4 * slot) = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
+            }
+        }
+        nh_raw = nh_next_raw;
+        nh_next_raw = nh_next2_raw;
+    }
+}
+
 void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned max_blocks) {
     if (q.num_rays == 0) return;
     size_t blocks = (q.num_rays + 31) / 32;        // one group of 8 rays per wave
-    const bool u2 = q.unroll == 2;
     // default: 2 blocks (8 waves) per CU -- measured best on the 100k / 300k / 1M-tet frames (profiles/r02_walk_sweep.txt):
     // the software pipeline keeps enough loads in flight per wave, and the literal-pairing / BVH kernels of the side
     // stream find free wave slots beside it
     const size_t cap = max_blocks ? max_blocks : 256 * 2;
     if (blocks > cap) blocks = cap;
-    if (u2) hipLaunchKernelGGL(k_write_segments<2>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
-    else hipLaunchKernelGGL(k_write_segments<4>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    if (q.variant == 0) {
+        if (q.unroll == 2) hipLaunchKernelGGL(k_write_segments<2>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL(k_write_segments<4>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    } else {
+        hipLaunchKernelGGL(k_write_segments_lds, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    }
 }
 
 // Constant tails: pure streaming stores (16 B per lane, whole 128-byte lines), a contiguous span of rows per wave.

@@ -239,6 +239,15 @@ class TetrahedraTracer:
         _lib.check(self._lib.tn_get_faces(self._h, _ptr(faces), _ptr(ft)))
         return faces, ft
 
+    def build_table(self, which: int):
+        """One of the structures load_tetrahedra built, as a uint8 CPU tensor (test aid; see tn_get_build_table)."""
+        n = C.c_size_t(0)
+        _lib.check(self._lib.tn_get_build_table(self._h, int(which), None, C.byref(n)))
+        out = torch.empty((n.value,), dtype=torch.uint8)
+        if n.value:
+            _lib.check(self._lib.tn_get_build_table(self._h, int(which), _ptr(out), C.byref(n)))
+        return out
+
     def postprocess_hits(self, hit_count, hit_ids, hit_t, hit_uv, faces=None, face_tets=None):
         """Run only the dedupe/pairing stage on sorted hit rows (test aid); with `faces` [F,3] / `face_tets` [F,2]
         (int32) on those tables instead of the loaded mesh's."""
