@@ -103,6 +103,12 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
             dtf = timed(render.TetraRenderer(tracer, field, mlp, s_c, M, fused=True, num_fine_samples=s_f, biased=biased))
             full.setdefault(name, {"samples_per_ray": f"{s_c} coarse" + (f" (density only) + {s_c + s_f + 1} fine" if s_f else "")})
             full[name][mode] = {"rendered_rays_per_s": R / dtf, "ms_per_frame": dtf * 1e3}
+            if mode == "fp32":
+                # fp32 runs every pass as ONE launch (tn_render_pass); the same config through the separate match /
+                # gather+MLP / composite kernels of round 2a, for comparison
+                dtu = timed(render.TetraRenderer(tracer, field, mlp, s_c, M, fused=True, num_fine_samples=s_f, biased=biased,
+                                                 fused_pass=False))
+                full[name]["fp32_separate_kernels"] = {"rendered_rays_per_s": R / dtu, "ms_per_frame": dtu * 1e3}
     tn.cpp.mlp_set_mode("fp32")
     # MLP kernel alone on one chunk worth of samples of hitting rays (MFMA roofline)
     n = min(hit, chunk) * samples
@@ -131,7 +137,7 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
     tn.cpp.mlp_set_mode("fp32")
     x3_ms = e0.elapsed_time(e1) / 5
     return {"rendered_rays_per_s": R / dt, "ms_per_frame": dt * 1e3, "rays": R, "hitting_rays": hit,
-            "samples_per_ray": samples, "pass": "coarse only (uniform samples), fused MLP + composite",
+            "samples_per_ray": samples, "pass": "coarse only (uniform samples): match + gather + MLP + composite in ONE launch (tn_render_pass)",
             "eval_configs": full,
             "roofline_mlp": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
                              "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "samples": n, "kernel_ms": mlp_ms,
@@ -173,17 +179,23 @@ def config_legs(tn, scenes, dev, M):
     for cfg, npts, seed in (("C4", 45000, 2), ("C5", 150000, 3)):
         pts, cells = scenes.random_mesh(npts, seed)
         tr = tn.TetrahedraTracer(dev)
-        t0 = time.perf_counter()
-        tr.load_tetrahedra(torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev))
-        torch.cuda.synchronize()
-        load_s = time.perf_counter() - t0
+        x_dev, c_dev = torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev)
+        loads = {}
+        for what, opt in (("host_build", 0), ("device_build_first_call", 1), ("device_build", 1)):
+            tr.set_option("gpu_build", opt)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tr.load_tetrahedra(x_dev, c_dev)
+            torch.cuda.synchronize()
+            loads[what] = time.perf_counter() - t0
+        load_s = loads["device_build"]
         sets = ((("C4_frame_800x800", frame_rays(scenes, 0, 800, 800), 5),
                  ("C4_batch_4096_outside_in", scenes.outside_in_rays(4096, 1), 20),
                  ("C4_batch_4096_inside_out", scenes.inside_out_rays(4096, 2), 20)) if cfg == "C4" else
                 (("C5_2^20_outside_in", scenes.outside_in_rays(1 << 20, 4), 3),))
         for name, (o, d), reps in sets:
             leg = trace_leg(tr, torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), M, reps)
-            leg.update(tets=int(len(cells)), load_tetrahedra_s=load_s)
+            leg.update(tets=int(len(cells)), load_tetrahedra_s=load_s, load_tetrahedra_host_build_s=loads["host_build"])
             out[name] = leg
         del tr
         torch.cuda.empty_cache()
@@ -283,10 +295,14 @@ def main():
     R, M = len(o_np), args.max_ray_triangles
 
     tracer = tn.TetrahedraTracer(dev)
-    t0 = time.perf_counter()
-    tracer.load_tetrahedra(torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev))
-    torch.cuda.synchronize()
-    load_s = time.perf_counter() - t0
+    x_dev, c_dev = torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev)
+    load_s = 0.0
+    for _ in range(2):   # the second call is the steady-state figure (the first one loads the build kernels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tracer.load_tetrahedra(x_dev, c_dev)
+        torch.cuda.synchronize()
+        load_s = time.perf_counter() - t0
     o = torch.from_numpy(o_np).to(dev)
     d = torch.from_numpy(d_np).to(dev)
 

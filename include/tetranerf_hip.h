@@ -247,6 +247,22 @@ int tn_mlp_forward_gather(size_t n, uint32_t samples_per_ray, uint32_t num_verti
                           const uint32_t *vertex_indices, const float *barycentric, const float *field,
                           const float *dirs, const tn_mlp_weights *weights, float *sigma, float *rgb, void *stream);
 
+/* One render PASS of TetrahedraNerf.get_outputs as ONE launch (reference span
+ * tetranerf/nerfstudio/model.py:560-662 = find_visited_cells -> interpolate_values -> mlp_base + heads -> get_weights ->
+ * renderers): sample matching, barycentric gather, MLP and composite fused; nothing per sample goes through HBM but the
+ * coarse weights.  The trace rows (outputs of tn_trace_rays, rows of M slots, M <= 1024) are read IN PLACE:
+ * ray_index u32 [r] names the row of hitting ray q.  edges f32 [r, S+1] = the sampler's bin edges (non-decreasing per
+ * ray, S >= 64); field_vm f32 [V,64] vertex-major (tn_transpose_f32).
+ *   dirs == NULL : density-only coarse pass (model.py:577-582): out_weights f32 [r, S] = get_weights.
+ *   dirs f32 [r,3]: full pass: out_rgb f32 [R,3], out_acc f32 [R], out_depth f32 [R] (arrays over ALL rays of the trace
+ *                  call, written at ray_index[q]; pre-fill them with the background values); out_weights optional.
+ * Always the fp32 MFMA arithmetic (tn_mlp_set_mode does not apply). */
+int tn_render_pass(uint32_t max_ray_triangles, const uint32_t *num_visited, const float *hit_distances,
+                   const float *barycentric, const uint32_t *vertex_indices, const uint32_t *ray_index, size_t num_hit_rays,
+                   uint32_t num_samples, const float *edges, const float *field_vm, const float *dirs,
+                   const tn_mlp_weights *weights, float background, float *out_weights, float *out_rgb, float *out_acc,
+                   float *out_depth, void *stream);
+
 /* Arithmetic of tn_mlp_forward / tn_mlp_forward_gather (process-wide):
  *   0 (default)  v_mfma_f32_32x32x2_f32: an exact fp32 fma chain (157 TFLOP/s peak);
  *   1 "bf16x3"   v_mfma_f32_32x32x16_bf16 on operands split into three bf16 pieces, six partial products per

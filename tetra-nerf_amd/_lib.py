@@ -20,7 +20,7 @@ SYMBOLS = (
     "tn_transpose_f32", "tn_interpolate_values_vm", "tn_interpolate_values_backward_vm",
     "tn_postprocess_hits", "tn_postprocess_hits_tables",
     "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_set_mode", "tn_mlp_get_mode",
-    "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
+    "tn_mlp_forward", "tn_mlp_forward_gather", "tn_render_pass", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
     "tn_mlp_backward", "tn_mlp_weight_grad", "tn_mlp_head_grad", "tn_composite_backward",
 )
 
@@ -69,6 +69,7 @@ def load():
     lib.tn_mlp_get_mode.argtypes = []
     lib.tn_mlp_forward.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp]
     lib.tn_mlp_forward_gather.argtypes = [sz, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tn_render_pass.argtypes = [u32, vp, vp, vp, vp, vp, sz, u32, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
     lib.tn_gather_uint32.argtypes = [i32, u32, u32, vp, vp, vp, vp]
     lib.tn_scatter_ema_uint32.argtypes = [i32, u32, u32, vp, C.c_double, vp, vp, vp]
     lib.tn_composite.argtypes = [sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]

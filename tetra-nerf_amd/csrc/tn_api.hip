@@ -1,4 +1,5 @@
 // tn_api.hip -- the C-ABI of libtetranerf_hip.so (see include/tetranerf_hip.h).
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -33,11 +34,16 @@ struct tn_tracer {
                                          // slower: the latency-bound segment writer crawls beside a saturating fill)
     hipStream_t side = nullptr;          // second stream: tail prefill, literal pairing, BVH re-trace
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t writer = nullptr;        // pipelined mode: the segment writer of chunk i runs beside the walk of chunk i + 1
+    hipEvent_t ev_chunk[8] = {}, ev_writer = nullptr;
+    bool side_late = true;               // literal pairing starts after the segment writer (beside the fill), not beside it
+    bool aux_general = true;             // BVH fallback rays on a third stream (forked right after the walk)
+    unsigned pipe = 1;                   // ray chunks of the walk -> writer pipeline (1 = one walk, then one writer)
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
     unsigned fill_blocks = 0;            // cap of the tail-fill grid (0 = default 2 blocks per CU); ablation knob
     unsigned seg_blocks = 0;             // cap of the segment-writer grid (0 = what the VGPR budget admits); ablation knob
-    unsigned seg_variant = 0;            // segment writer: 0 direct stores; 1 LDS-staged whole-line stores (faster alone, but its 55 KB of
-                                         // LDS per block starves the literal-pairing kernel beside it: profiles/r02c_*)
+    unsigned seg_variant = 1;            // segment writer: 1 LDS-staged whole-line stores; 0 direct stores (ablation).  With the literal
+                                         // pairing scheduled beside the fill (side_late) the LDS writer wins: profiles/r02f_sched_sweep.txt
     unsigned seg_unroll = 4;             // segment writer: chunks of 8 hits per ray per iteration (4 or 2); ablation knob
     tn::DevBuf<tn::WalkVar> vars;
     tn::DevBuf<float> hull_nodes, hull_tris;
@@ -128,6 +134,9 @@ int tn_tracer_create(int device, tn_tracer_t *out) {
         }
         TN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
         TN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+        TN_HIP(hipStreamCreateWithFlags(&t->writer, hipStreamNonBlocking));
+        for (auto &e : t->ev_chunk) TN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        TN_HIP(hipEventCreateWithFlags(&t->ev_writer, hipEventDisableTiming));
         *out = t.release();
     });
 }
@@ -140,6 +149,9 @@ int tn_tracer_destroy(tn_tracer_t tracer) {
         if (tracer->side) (void)hipStreamDestroy(tracer->side);
         if (tracer->ev_fork) (void)hipEventDestroy(tracer->ev_fork);
         if (tracer->ev_join) (void)hipEventDestroy(tracer->ev_join);
+        if (tracer->writer) (void)hipStreamDestroy(tracer->writer);
+        for (auto &e : tracer->ev_chunk) if (e) (void)hipEventDestroy(e);
+        if (tracer->ev_writer) (void)hipEventDestroy(tracer->ev_writer);
         delete tracer;
     });
 }
@@ -330,7 +342,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 return make_params(t, n, M, origins + 3 * base, directions + 3 * base, num_visited + base, visited + base * M,
                                    bary + base * M * 6, dist + base * M * 2, verts ? verts + base * M * 4 : nullptr);
             };
-            auto launch_walk = [&](size_t base, size_t n) {
+            auto launch_walk = [&](size_t base, size_t n, size_t log_base = 0) {
                 tn::WalkParams w{};
                 w.t = chunk_params(base, n);
                 w.vars = t->mesh.vars;
@@ -344,17 +356,18 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 w.literal_count = t->literal_count();
                 w.kmax = t->kmax();
                 w.walk_n = t->walk_n.p + base;
-                w.hit_log = t->hit_log.p;
+                w.hit_log = t->hit_log.p + (log_base / 64) * (size_t)M * 64;
                 w.ray_base = base;
+                w.lit_base = (uint32_t)log_base;
                 w.debug = t->debug;
                 tn::launch_trace_walk(w, stream);
             };
-            auto launch_segments = [&](size_t base, size_t n, hipStream_t st) {
+            auto launch_segments = [&](size_t base, size_t n, hipStream_t st, size_t log_base = 0) {
                 tn::WriteParams q{};
                 q.num_rays = n; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
                 q.unroll = t->seg_unroll; q.variant = t->seg_variant;
                 q.walk_n = t->walk_n.p + base;
-                q.hit_log = t->hit_log.p;
+                q.hit_log = t->hit_log.p + (log_base / 64) * (size_t)M * 64;
                 q.vars = t->mesh.vars;
                 q.out_cells = visited + base * M;
                 q.out_bary = bary + base * M * 6;
@@ -374,19 +387,54 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             };
             p.ray_list = t->fallback_list.p;
             p.item_count = t->fallback_count();
-            if (single) {
+            const size_t npipe = single ? std::min<size_t>(t->pipe, 8) : 1;
+            if (single && npipe > 1 && R >= npipe * 8192) {
+                // Pipelined: the walk (issue / latency-bound) of chunk i + 1 runs beside the segment writer (bound by the
+                // texture-address rate of its scattered stores) of chunk i, on a second stream; the log holds every chunk.
+                size_t pc = (R + npipe - 1) / npipe;
+                pc = (pc + 4095) / 4096 * 4096;
+                unsigned ci = 0;
+                for (size_t base = 0; base < R; base += pc, ++ci) {
+                    const size_t n = R - base < pc ? R - base : pc;
+                    launch_walk(base, n, base);
+                    TN_HIP(hipEventRecord(t->ev_chunk[ci], stream));
+                    TN_HIP(hipStreamWaitEvent(t->writer, t->ev_chunk[ci], 0));
+                    launch_segments(base, n, t->writer, base);
+                }
+                TN_HIP(hipEventRecord(t->ev_fork, stream));
+                TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
+                TN_HIP(hipEventRecord(t->ev_writer, t->writer));
+                TN_HIP(hipStreamWaitEvent(stream, t->ev_writer, 0));
+                launch_literal(0, R, t->side);
+                tn::launch_trace_general(p, t->side);
+                launch_fill(0, R, false, nullptr, stream);
+                TN_HIP(hipEventRecord(t->ev_join, t->side));
+                TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
+            } else if (single) {
                 launch_walk(0, R);
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
+                if (t->aux_general) {
+                    // the handful of BVH fallback rays (one wavefront each, ~0.7 ms of pure latency) on a stream of their
+                    // own instead of behind the literal pairing
+                    TN_HIP(hipStreamWaitEvent(t->writer, t->ev_fork, 0));
+                    tn::launch_trace_general(p, t->writer);
+                    TN_HIP(hipEventRecord(t->ev_writer, t->writer));
+                }
                 // the segment writer is enqueued BEFORE the side stream's kernels: their grids are sized for the worst
                 // case (the counts live on the device) and would otherwise take every wave slot first
                 launch_segments(0, R, stream);
+                if (t->side_late) {   // literal pairing beside the fill instead of beside the segment writer
+                    TN_HIP(hipEventRecord(t->ev_chunk[0], stream));
+                    TN_HIP(hipStreamWaitEvent(t->side, t->ev_chunk[0], 0));
+                }
                 if (t->prefill) launch_fill(0, R, true, t->kmax(), t->side);
                 launch_literal(0, R, t->side);
-                tn::launch_trace_general(p, t->side);
+                if (!t->aux_general) tn::launch_trace_general(p, t->side);
                 launch_fill(0, R, false, t->prefill ? t->kmax() : nullptr, stream);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
+                if (t->aux_general) TN_HIP(hipStreamWaitEvent(stream, t->ev_writer, 0));
             } else {
                 for (size_t base = 0; base < R; base += chunk) {
                     const size_t n = R - base < chunk ? R - base : chunk;
@@ -540,6 +588,9 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && (std::strcmp(name, "rewalk") == 0 || std::strcmp(name, "rewalk_min") == 0)) {}  // round-1 knobs: no effect
         else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
         else if (name && std::strcmp(name, "seg_blocks") == 0) t->seg_blocks = (unsigned)value;
+        else if (name && std::strcmp(name, "side_late") == 0) t->side_late = value != 0;
+        else if (name && std::strcmp(name, "aux_general") == 0) t->aux_general = value != 0;
+        else if (name && std::strcmp(name, "pipe") == 0) t->pipe = value < 1 ? 1u : (value > 8 ? 8u : (unsigned)value);
         else if (name && std::strcmp(name, "seg_variant") == 0) t->seg_variant = value ? 1u : 0u;
         else if (name && std::strcmp(name, "seg_unroll") == 0) t->seg_unroll = value == 2 ? 2u : 4u;
         else if (name && std::strcmp(name, "log_cap_mb") == 0) t->log_cap_bytes = (size_t)(value < 1 ? 1 : value) << 20;
@@ -680,6 +731,22 @@ int tn_mlp_forward_gather(size_t n, uint32_t samples_per_ray, uint32_t num_verti
         (g_mlp_mode.load() ? tn::launch_mlp_forward_x3 : tn::launch_mlp_forward)(
             n, samples_per_ray, n / samples_per_ray, nullptr, vertex_indices, barycentric, field, num_vertices, dirs, m, sigma, rgb,
             (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_render_pass(uint32_t M, const uint32_t *num_visited, const float *hit_distances, const float *barycentric,
+                   const uint32_t *vertex_indices, const uint32_t *ray_index, size_t num_hit_rays, uint32_t num_samples,
+                   const float *edges, const float *field_vm, const float *dirs, const tn_mlp_weights *w, float background,
+                   float *out_weights, float *out_rgb, float *out_acc, float *out_depth, void *stream_) {
+    return guarded([&] {
+        if (num_hit_rays == 0) return;
+        if (!w || !num_visited || !hit_distances || !barycentric || !vertex_indices || !ray_index || !edges || !field_vm)
+            throw tn::Error("null pointer");
+        if (!dirs && !out_weights) throw tn::Error("density-only pass without out_weights");
+        tn::MlpWeights m{w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
+        tn::launch_render_pass(num_visited, hit_distances, barycentric, vertex_indices, M, ray_index, num_hit_rays, num_samples,
+                               edges, field_vm, dirs, m, background, out_weights, out_rgb, out_acc, out_depth, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }

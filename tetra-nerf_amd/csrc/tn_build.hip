@@ -177,9 +177,28 @@ __global__ __launch_bounds__(BT) void k_seg_bounds(size_t n, const uint32_t *__r
         const size_t f = order[i];
         c[0] = cen[3 * f]; c[1] = cen[3 * f + 1]; c[2] = cen[3 * f + 2];
     }
-    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
-    const bool uniform = s0 != TN_EMPTY && __ballot(s != s0) == 0ull;
-    bounds_update(segb + 6 * (size_t)(uniform ? s0 : (active ? s : 0u)), c, active, uniform);
+    // segmented reduction over the wave: a segment is a run of consecutive positions, so its lanes are consecutive.
+    // Inclusive segmented min / max scan by shuffles; the last lane of each run adds the run's result with 6 atomics
+    // (2-3 runs per wave at the deep levels instead of 64 x 6 same-address atomics).
+    const int lane = threadIdx.x & 63;
+    float lo[3] = {c[0], c[1], c[2]}, hi[3] = {c[0], c[1], c[2]};
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t so = (uint32_t)__shfl_up((int)s, off);
+        const bool take = lane >= off && so == s;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float l2 = __shfl_up(lo[a], off), h2 = __shfl_up(hi[a], off);
+            lo[a] = take ? fminf(lo[a], l2) : lo[a];
+            hi[a] = take ? fmaxf(hi[a], h2) : hi[a];
+        }
+    }
+    const uint32_t snext = (uint32_t)__shfl_down((int)s, 1);
+    if (active && (lane == 63 || snext != s)) {
+        uint32_t *b = segb + 6 * (size_t)s;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicMin(b + a, core::float_ordered(lo[a])); atomicMax(b + 3 + a, core::float_ordered(hi[a])); }
+    }
 }
 __global__ __launch_bounds__(BT) void k_seg_keys(size_t n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ seg_of,
                                                  const uint32_t *__restrict__ segb, const float *__restrict__ cen, uint64_t *keys) {

@@ -50,6 +50,7 @@ struct WalkParams {
     uint4 *hit_log;            // [ceil(num_items / 64)][M][64] x {t, u, v, variant | exit << 30}: hit k of ray r at
                                // ((r / 64) * M + k) * 64 + r % 64 (a wave's 64 lanes store 1 KB of consecutive bytes per
                                // step); exit code 3 = entry hull face, its face id in the low 30 bits
+    uint32_t lit_base;         // added to the launch-local ray index stored in literal_list (= the launch's first row of the log)
     size_t ray_base;           // global index of item 0 (rays are traced in chunks when the log would be too large)
     uint32_t debug;            // block->XCD mapping ablation (profiles/): 4 = no remap, 8 = one contiguous band per XCD
 };
@@ -67,7 +68,7 @@ struct WriteParams {
     uint32_t M;
     uint32_t dense_tails;      // 0: slots >= num_visited are left unwritten (non-reference option)
     uint32_t unroll;           // chunks of 8 hits per ray per iteration: 4 (default) or 2
-    uint32_t variant;          // 0 (default): direct stores; 1: LDS-staged whole-line stores
+    uint32_t variant;          // 1 (default): LDS-staged whole-line stores; 0: direct stores
     uint32_t ablate;           // probe only (profiles/): 1 no record loads, 2 only the cell-id store, 4 no stores
     const uint32_t *walk_n;
     const uint4 *hit_log;
@@ -146,6 +147,13 @@ void launch_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, co
 void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
                                const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb, hipStream_t stream);
 void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols, hipStream_t stream);
+// one render pass as one launch (tn_render.hip): match -> gather -> MLP -> composite on the trace rows of the hitting
+// rays (ray_index [r]) from the bin edges [r, S + 1]; dirs == nullptr: density only, out_weights [r, S] written;
+// otherwise out_rgb / out_acc / out_depth (arrays over ALL rays) are written at ray_index[q]
+void launch_render_pass(const uint32_t *num_visited, const float *dist, const float *bary, const uint32_t *verts, uint32_t M,
+                        const uint32_t *ray_index, size_t r, uint32_t S, const float *edges, const float *fieldT,
+                        const float *dirs, const MlpWeights &w, float background, float *out_weights, float *out_rgb,
+                        float *out_acc, float *out_depth, hipStream_t stream);
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
                       float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream);
 

@@ -1,0 +1,320 @@
+// tn_render.hip -- one render PASS of the Tetra-NeRF model as ONE launch:
+//   sample -> segment matching (find_visited_cells, src/tetrahedra_tracer.cu:115-160)
+//   -> barycentric feature gather (interpolate_values, src/tetrahedra_tracer.cu:195-221)
+//   -> mlp_base + density head [+ direction encoding ++ mlp_head + rgb head] (model.py:414-455, 577-621)
+//   -> RaySamples.get_weights [+ RGB over background / accumulation / median depth] (model.py:632-662)
+// on the trace rows of the hitting rays IN PLACE (ray_index), from the [r, S+1] bin edges a sampler produced.
+// Nothing per-sample goes through HBM except the 4-byte coarse weights the PDF sampler needs: the unfused path
+// writes and re-reads 33 B (match outputs) + 16 B (sigma, rgb) per sample and launches three kernels per pass.
+//
+// Work decomposition = tn_mlp.hip's: a block of 8 wavefronts processes 256 consecutive samples per step, one
+// wavefront = 32 samples x 2 feature halves, weights staged per layer in LDS, activations fed back from the
+// accumulators (see tn_mlp.hip).  What is new around the four layers:
+//   * a block owns a contiguous range of RAYS and walks their samples as one stream, so a ray never straddles two
+//     blocks and the per-ray scans need no inter-block hand-over;
+//   * per step the segments (t_in and the running maximum of t_out, as k_find_matched) of the <= 6 rays the step
+//     touches are staged in LDS; every sample does the matcher's binary lifting there, reads its segment's vertex ids
+//     and entry / exit barycentrics straight from the trace rows, lerps them and gathers its features into the
+//     B-operand registers (same expression trees as tn_match.hip / tn_interp.hip);
+//   * sigma * delta (and the colour) of the 256 samples go to a 5 KB LDS exchange; one wavefront per ray piece runs
+//     the composite scan over it (k_composite's arithmetic), carrying the state of the one ray that continues into
+//     the next step through an LDS slot; finished rays write rgb / accumulation / depth (or every sample its weight).
+// Preconditions (checked by the host entry): 64 <= S, M <= 1024, bin edges non-decreasing per ray.
+#include "tn_mlp_common.h"
+
+namespace tn {
+
+using namespace mlp;
+
+namespace {
+
+constexpr int RP_PIECES = 6;        // rays a step of 256 samples can touch when S >= 64
+constexpr int RP_GROUP = 256;
+
+struct RenderPassParams {
+    const uint32_t *num_visited;   // [R_all]
+    const float *dist;             // [R_all, M, 2]
+    const float *bary;             // [R_all, M, 2, 3]
+    const uint32_t *verts;         // [R_all, M, 4]
+    const uint32_t *ray_index;     // [r] trace row of hitting ray q
+    const float *edges;            // [r, S + 1]
+    const float *fieldT;           // [V, 64]
+    const float *enc;              // [r, 28] or null (density only)
+    const float *pk;               // packed weights (k_mlp_pack, gather order)
+    float *out_weights;            // [r, S] or null
+    float *out_rgb, *out_acc, *out_depth;   // [R_all, 3], [R_all], [R_all] or null: written at ray_index[q]
+    size_t r;
+    uint32_t S, M;
+    float background;
+};
+
+struct RayState { float carry, acc, r0, r1, r2, depth; uint32_t found, pad; };
+
+}  // namespace
+
+template <bool DENSITY_ONLY>
+__global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lds = reinterpret_cast<float *>(smem);                 // staged layer
+    float *seg_t = lds + MAX_STAGE_FLOATS;                        // [RP_PIECES][M] t_in
+    float *seg_p = seg_t + (size_t)RP_PIECES * p.M;               // [RP_PIECES][M] running max of t_out
+    uint32_t *seg_n = reinterpret_cast<uint32_t *>(seg_p + (size_t)RP_PIECES * p.M);   // [8]
+    float *c_dd = reinterpret_cast<float *>(seg_n + 8);           // [256] sigma * delta
+    float *c_mid = c_dd + RP_GROUP;                               // [256] bin centre
+    float *c_rgb = c_mid + RP_GROUP;                              // [3][256]
+    RayState *open = reinterpret_cast<RayState *>(c_rgb + 3 * RP_GROUP);   // [2]: written by step g into [g & 1]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const uint32_t S = p.S, M = p.M;
+    const size_t q0 = p.r * blockIdx.x / gridDim.x;             // r < 2^32, gridDim <= 256: no overflow
+    const size_t q1 = p.r * (blockIdx.x + 1) / gridDim.x;
+    const uint32_t stream_len = (uint32_t)((q1 - q0) * S);
+    const uint32_t ngroups = (stream_len + RP_GROUP - 1) / RP_GROUP;
+
+    for (uint32_t g = 0; g < ngroups; ++g) {
+        const uint32_t gs = g * RP_GROUP, ge = gs + RP_GROUP < stream_len ? gs + RP_GROUP : stream_len;
+        const uint32_t qa = gs / S, qb = (ge - 1) / S;            // block-local ray slots of this step
+        const uint32_t P = qb - qa + 1;
+        __syncthreads();
+        // ---- segments of the rays of this step -> LDS (t_in, running max of t_out)
+        for (uint32_t piece = wave; piece < P; piece += MLP_BLOCK / 64) {
+            const size_t ray = p.ray_index[q0 + qa + piece];
+            uint32_t n = p.num_visited[ray];
+            if (n > M) n = M;
+            const float2 *drow = reinterpret_cast<const float2 *>(p.dist) + ray * M;
+            float carry = -INFINITY;
+            for (uint32_t base = 0; base < n; base += 64) {
+                const uint32_t j = base + lane;
+                float2 d = make_float2(0.f, -INFINITY);
+                if (j < n) d = drow[j];
+                float m = d.y;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const float o = __shfl_up(m, off);
+                    if (lane >= off) m = fmaxf(m, o);
+                }
+                m = fmaxf(m, carry);
+                if (j < n) { seg_t[(size_t)piece * M + j] = d.x; seg_p[(size_t)piece * M + j] = m; }
+                carry = __shfl(m, 63);
+            }
+            if (lane == 0) seg_n[piece] = n;
+        }
+        __syncthreads();
+        stage_weights(lds, p.pk + OFF_W1, lfloats(KS1, OT));
+
+        // ---- this lane's sample: match, lerp, gather
+        const uint32_t sl = gs + (uint32_t)wave * 32 + ((uint32_t)lane & 31u);
+        const bool valid = sl < ge;
+        const uint32_t slc = valid ? sl : ge - 1;                 // out-of-range lanes compute a duplicate, store nothing
+        const uint32_t ql = slc / S, j = slc - ql * S, piece = ql - qa;
+        const size_t q = q0 + ql;
+        const float e0 = p.edges[q * (S + 1) + j], e1 = p.edges[q * (S + 1) + j + 1];
+        const float cur = (e1 + e0) / 2.0f;
+        float bin[KSH];
+        {
+            const uint32_t n = seg_n[piece];
+            const float *pm = seg_p + (size_t)piece * M, *ti = seg_t + (size_t)piece * M;
+            uint32_t pos = 0;
+            for (uint32_t bit = n ? (1u << (31 - __clz((int)n))) : 0u; bit > 0; bit >>= 1)
+                if (pos + bit <= n && pm[pos + bit - 1] < cur) pos += bit;
+            uint4 v4 = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            if (pos < n && ti[pos] <= cur) {
+                const size_t gi = (size_t)p.ray_index[q] * M + pos;
+                const float t_in = ti[pos], t_out = p.dist[2 * gi + 1];
+                v4 = *reinterpret_cast<const uint4 *>(p.verts + 4 * gi);
+                const float2 *bp = reinterpret_cast<const float2 *>(p.bary + 6 * gi);
+                const float2 q0f = bp[0], q1f = bp[1], q2f = bp[2];   // c1.xyz = q0.x q0.y q1.x ; c2.xyz = q1.y q2.x q2.y
+                const float mult = (cur - t_in) / (t_out - t_in);
+                b0 = (1 - mult) * q0f.x + mult * q1f.y;
+                b1 = (1 - mult) * q0f.y + mult * q2f.x;
+                b2 = (1 - mult) * q1f.x + mult * q2f.y;
+            }
+            const float w0 = 1.0f - ((b0 + b1) + b2);
+            const uint32_t vv[4] = {v4.y, v4.z, v4.w, v4.x};
+            const float ww[4] = {b0, b1, b2, w0};
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) bin[ks] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (vv[k] != TN_EMPTY) {
+                    const float4 *row = reinterpret_cast<const float4 *>(p.fieldT + (size_t)vv[k] * FD + 32 * h);
+#pragma unroll
+                    for (int qq = 0; qq < 8; ++qq) {
+                        const float4 x = row[qq];
+                        bin[4 * qq] += ww[k] * x.x; bin[4 * qq + 1] += ww[k] * x.y;
+                        bin[4 * qq + 2] += ww[k] * x.z; bin[4 * qq + 3] += ww[k] * x.w;
+                    }
+                }
+            }
+        }
+        stage_wait();
+        {
+            f32x16 acc[OT];
+            zero_acc(acc);
+            gemm_steps<KS1, 0, OT>(acc, bin, lds, lane);
+            bias_step<KS1, OT>(acc, lds, lane);
+            relu_to_bin(acc, bin);
+        }
+        __syncthreads();
+        stage_weights(lds, p.pk + OFF_W2, lfloats(KSH, OT));
+        stage_wait();
+        {
+            f32x16 acc[OT];
+            zero_acc(acc);
+            gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
+            bias_step<KSH, OT>(acc, lds, lane);
+            relu_to_bin(acc, bin);
+        }
+        __syncthreads();
+        stage_weights(lds, p.pk + OFF_W3, N_W3);
+        stage_wait();
+        {
+            f32x16 acc[OT];
+            zero_acc(acc);
+            gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
+            bias_step<KSH, OT>(acc, lds, lane);
+            relu_to_bin(acc, bin);
+        }
+        {
+            const float *dv = lds + lfloats(KSH, OT);
+            const float raw = head_dot(dv + 64 * h, bin) + dv[128];
+            const float sp = raw > 20.0f ? raw : log1pf(expf(raw));
+            if (h == 0) {
+                const uint32_t li = (uint32_t)wave * 32 + ((uint32_t)lane & 31u);
+                c_dd[li] = (e1 - e0) * sp;
+                c_mid[li] = 0.5f * (e0 + e1);
+            }
+        }
+        if constexpr (!DENSITY_ONLY) {
+            __syncthreads();
+            stage_weights(lds, p.pk + OFF_WHEAD, N_WHEAD);
+            stage_wait();
+            {
+                f32x16 acc[OT];
+                zero_acc(acc);
+                const float *e = p.enc + q * ENC_PAD;
+#pragma unroll
+                for (int ks = 0; ks < KSE; ++ks) {
+                    const float b = e[2 * ks + h];
+                    const float *wrow = lds + (size_t)ks * OT * 64 + lane;
+#pragma unroll
+                    for (int t = 0; t < OT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], b, acc[t], 0, 0, 0);
+                }
+                gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
+                bias_step<HEAD_KS, OT>(acc, lds, lane);
+                relu_to_bin(acc, bin);
+            }
+            const float *cv = lds + lfloats(HEAD_KS, OT);
+            const float c0 = head_dot(cv + 64 * h, bin) + cv[384];
+            const float c1 = head_dot(cv + 128 + 64 * h, bin) + cv[385];
+            const float c2 = head_dot(cv + 256 + 64 * h, bin) + cv[386];
+            if (h == 0) {
+                const uint32_t li = (uint32_t)wave * 32 + ((uint32_t)lane & 31u);
+                c_rgb[li] = 1.0f / (1.0f + expf(-c0));
+                c_rgb[RP_GROUP + li] = 1.0f / (1.0f + expf(-c1));
+                c_rgb[2 * RP_GROUP + li] = 1.0f / (1.0f + expf(-c2));
+            }
+        }
+        __syncthreads();
+        // ---- composite: one wavefront per ray piece of this step
+        for (uint32_t piece2 = wave; piece2 < P; piece2 += MLP_BLOCK / 64) {
+            const uint32_t qq = qa + piece2;
+            const uint32_t ray_start = qq * S, ray_end = ray_start + S;
+            const uint32_t ps = gs > ray_start ? gs : ray_start, pe = ge < ray_end ? ge : ray_end;
+            RayState st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+            if (ps > ray_start) st = open[(g + 1) & 1];   // the ray that continues from the previous step
+            float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+            for (uint32_t base = ps; base < pe; base += 64) {
+                const uint32_t idx = base + lane;
+                const bool ok = idx < pe;
+                const uint32_t li = (ok ? idx : pe - 1) - gs;
+                const float dd = ok ? c_dd[li] : 0.f;
+                float inc = dd;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const float o = __shfl_up(inc, off);
+                    if (lane >= off) inc += o;
+                }
+                const float excl = st.carry + (inc - dd);
+                float w = (1.0f - expf(-dd)) * expf(-excl);
+                if (!(w == w) || !ok) w = 0.f;   // nan_to_num
+                if (p.out_weights && ok) p.out_weights[(q0 + qq) * S + (idx - ray_start)] = w;
+                if constexpr (!DENSITY_ONLY) {
+                    l0 += w * c_rgb[li]; l1 += w * c_rgb[RP_GROUP + li]; l2 += w * c_rgb[2 * RP_GROUP + li];
+                }
+                float winc = w;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const float o = __shfl_up(winc, off);
+                    if (lane >= off) winc += o;
+                }
+                const float cum = st.acc + winc;
+                const uint64_t m = __ballot(ok && cum >= 0.5f);
+                if (!st.found && m) {
+                    const int src = __ffsll((unsigned long long)m) - 1;
+                    st.depth = __shfl(c_mid[li], src);
+                    st.found = 1u;
+                }
+                st.carry += __shfl(inc, 63);
+                st.acc += __shfl(winc, 63);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                l0 += __shfl_xor(l0, off); l1 += __shfl_xor(l1, off); l2 += __shfl_xor(l2, off);
+            }
+            st.r0 += l0; st.r1 += l1; st.r2 += l2;
+            if (pe == ray_end) {
+                if (!DENSITY_ONLY && p.out_rgb && lane == 0) {
+                    const size_t ray = p.ray_index[q0 + qq];
+                    if (!st.found) st.depth = c_mid[pe - 1 - gs];   // searchsorted clamps to the last sample
+                    p.out_rgb[3 * ray] = st.r0 + p.background * (1.0f - st.acc);
+                    p.out_rgb[3 * ray + 1] = st.r1 + p.background * (1.0f - st.acc);
+                    p.out_rgb[3 * ray + 2] = st.r2 + p.background * (1.0f - st.acc);
+                    p.out_acc[ray] = st.acc;
+                    p.out_depth[ray] = st.depth;
+                }
+            } else if (lane == 0) {
+                open[g & 1] = st;
+            }
+        }
+    }
+}
+
+void launch_render_pass(const uint32_t *num_visited, const float *dist, const float *bary, const uint32_t *verts, uint32_t M,
+                        const uint32_t *ray_index, size_t r, uint32_t S, const float *edges, const float *fieldT,
+                        const float *dirs, const MlpWeights &w, float background, float *out_weights, float *out_rgb,
+                        float *out_acc, float *out_depth, hipStream_t stream) {
+    if (r == 0) return;
+    if (S < 64) throw Error("render_pass needs at least 64 samples per ray");
+    if (M > 1024) throw Error("render_pass supports max_ray_triangles <= 1024");
+    if ((size_t)S * ((r + 255) / 256 + 1) >= 0xFFFFFFFFull) throw Error("render_pass: too many samples per block");
+    const bool density_only = dirs == nullptr;
+    if (!density_only && !(out_rgb && out_acc && out_depth)) throw Error("render_pass: colour pass without output buffers");
+    float *pk = nullptr, *enc = nullptr;
+    TN_HIP(hipMallocAsync((void **)&pk, PACK_FLOATS * sizeof(float), stream));
+    launch_mlp_pack(w, pk, true, stream);
+    if (!density_only) {
+        TN_HIP(hipMallocAsync((void **)&enc, r * ENC_PAD * sizeof(float), stream));
+        launch_dir_encoding(r, dirs, enc, stream);
+    }
+    RenderPassParams p{};
+    p.num_visited = num_visited; p.dist = dist; p.bary = bary; p.verts = verts; p.ray_index = ray_index; p.edges = edges;
+    p.fieldT = fieldT; p.enc = enc; p.pk = pk; p.out_weights = out_weights; p.out_rgb = out_rgb; p.out_acc = out_acc;
+    p.out_depth = out_depth; p.r = r; p.S = S; p.M = M; p.background = background;
+    auto smem_for = [](size_t m) { return (MAX_STAGE_FLOATS + 2 * (size_t)RP_PIECES * m + 8 + 5 * RP_GROUP) * sizeof(float) + 2 * sizeof(RayState); };
+    const size_t smem = smem_for(M);
+    static PerDeviceOnce lds_attr;
+    lds_attr.run([&] {
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_pass<false>), smem_for(1024));
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_pass<true>), smem_for(1024));
+    });
+    const unsigned grid = (unsigned)(r < 256 ? r : 256);   // one 8-wave block per CU, each owns a range of rays
+    if (density_only) hipLaunchKernelGGL(k_render_pass<true>, dim3(grid), dim3(MLP_BLOCK), smem, stream, p);
+    else hipLaunchKernelGGL(k_render_pass<false>, dim3(grid), dim3(MLP_BLOCK), smem, stream, p);
+    TN_HIP(hipFreeAsync(pk, stream));
+    if (enc) TN_HIP(hipFreeAsync(enc, stream));
+}
+
+}  // namespace tn

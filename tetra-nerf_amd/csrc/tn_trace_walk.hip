@@ -15,21 +15,36 @@
 //   certified   exactly two hull faces are crossed, every tet on the way has exactly two crossed
 //               faces, no edge function is exactly 0, no vertex of a visited tet within rounding
 //               distance of the ray, every recorded t in (0, 1e16), fewer than M faces, AND the order
-//               is "clean": t grows by at least eps from face to face, except for ISOLATED pairs closer
-//               than eps -- ascending, or inverted / tied the wrong way round -- whose neighbours are at
-//               least eps away from both members.  For such a list the reference's dedupe / pairing
-//               phases (optix_trace_rays.cu:124-257) provably reduce to "pair face k-1 with face k, drop
-//               the pairs shorter than eps": phase 1 only marks (nothing is cleared: a mark needs a
-//               second sighting inside one eps window), phase 2 finds the partner of face j in the first
-//               slot it examines -- or, for an inverted pair, in the second, followed by the swap that
-//               restores chain order -- so its look-ahead never walks on to the hull face at the far end.
-//   literal     the chain is sound but its order is not clean (a run of gaps below eps, an inversion by
-//               eps or more, an inverted pair at the very end): the hits of the log go through the
-//               literal sort + pairing (k_postprocess_log, tn_trace_general.hip).  Round 1 certified
-//               runs of short gaps in chains longer than 8 faces; the lattice meshes of
-//               tests/test_parity_configs_gpu.py showed that unsound (phase 1 clears the inside of a
-//               cluster, the look-ahead of phase 2 skips cleared slots without counting them and pairs
-//               the two hull faces through their common EMPTY tet).
+//               is "clean": the hits ascend in the total order (t, face id), with gaps of ANY size -- or
+//               contain ISOLATED pairs that are inverted / tied the wrong way round by less than eps whose
+//               neighbours are at least eps away from both members.  For such a list the reference's
+//               dedupe / pairing phases (optix_trace_rays.cu:124-257) provably reduce to "pair face k-1
+//               with face k, drop the pairs shorter than eps":
+//               * ascending list (sorted order == chain order).  Only chain neighbours share a tet (every
+//                 tet of a sound chain has exactly two crossed faces), except the two hull faces, which
+//                 "share" EMPTY.  Phase 1 at slot j looks at the following slots within eps of t_j: of
+//                 those only the chain successor j+1 shares a tet with j, so j marks j+1 iff gap(j, j+1) <
+//                 eps, and j is cleared iff it was marked (gap(j-1, j) < eps) and marks (gap(j, j+1) < eps):
+//                 exactly the INTERIOR faces of every run of short gaps are cleared, the two ends of a run
+//                 survive.  Phase 2 at a surviving j: if slot j+1 survives it is the chain successor and
+//                 the pair is emitted iff its gap is >= eps; if slot j+1 was cleared (j opens a run of >= 2
+//                 short gaps) the look-ahead skips the cleared slots and examines the next two surviving
+//                 faces (and on while they are eps-chained), none of which shares a tet with j -- no
+//                 emission, no swap.  Every pair with a gap >= eps has two surviving ends in adjacent
+//                 slots, so the emitted set is { (k-1, k) : gap >= eps }, each from its own two slots.
+//                 The one exception is the EMPTY == EMPTY quirk of get_common_tetrahedra: a look-ahead
+//                 from the ENTRY hull face that reaches the exit hull face pairs the two.  The entry face
+//                 only looks ahead when slot 1 was cleared, i.e. when the first TWO gaps are short: such
+//                 rays are not certified (the lattice meshes of tests/test_parity_configs_gpu.py hit this).
+//               * an isolated inverted pair: phase 1 only marks, phase 2 finds the partner of the face before
+//                 the pair in the second slot it examines and the swap restores chain order.
+//               Runs that contain an inversion are NOT certified: a face whose two chain neighbours both sort
+//               after it survives phase 1 inside the run, and the look-ahead of the run's last face can then
+//               stop short of its partner (worked example in DESIGN.md section 2).
+//   literal     the chain is sound but its order is not clean (an inversion inside a run of short gaps, an
+//               inversion by eps or more, an inverted pair at the very end, two short gaps right at the entry
+//               face): the hits of the log go through the literal sort + pairing (k_postprocess_log,
+//               tn_trace_general.hip).
 //   fallback    anything else -> re-traced by the BVH all-hits kernel.
 // The chain is the connected component of the hull faces in the set of crossed faces.  The rounded
 // projection can contain further components -- e.g. the star of a vertex whose rounded projection
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         } else if (!order_ok) {
             if (t.stats) atomicAdd(&t.stats[4 + 7], 1ull);
             const uint32_t slot = atomicAdd(p.literal_count, 1u);
-            p.literal_list[slot] = make_uint2((uint32_t)ray, nhits);   // index within this walk launch (= log row)
+            p.literal_list[slot] = make_uint2(p.lit_base + (uint32_t)ray, nhits);   // index within this walk launch (= log row)
             p.walk_n[ray] = TN_EMPTY;   // k_postprocess_log writes the whole row
         } else {
             p.walk_n[ray] = nhits;      // hits in the log (0 for a miss)

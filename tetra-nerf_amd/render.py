@@ -290,7 +290,7 @@ class TetraRenderer:
 
     def __init__(self, tracer, field: torch.Tensor, mlp: TetraMLP, num_samples: int = 256,
                  max_ray_triangles: int = 512, fused: bool = True, far_plane: float = 1000.0,
-                 num_fine_samples: int = 0, biased: bool = False, dense_tails: bool = False):
+                 num_fine_samples: int = 0, biased: bool = False, dense_tails: bool = False, fused_pass: bool = True):
         from . import tetranerf_cpp_extension as cpp
 
         self.cpp = cpp
@@ -300,6 +300,8 @@ class TetraRenderer:
         # the render path only reads the trace rows through num_visited_cells, so the constant tails of the
         # dense reference layout need not be written (non-materialising trace: 52 B per segment, not 52*M per ray)
         self.dense_tails = bool(dense_tails)
+        # match + gather + MLP + composite of a pass as ONE launch (tn_render_pass) when its preconditions hold
+        self.fused_pass = bool(fused_pass) and self.S >= 64 and self.M <= 1024
 
     @torch.no_grad()
     def render(self, origins: torch.Tensor, directions: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -342,6 +344,15 @@ class TetraRenderer:
                 edges = biased_sample_bins(near_r, far_r, S, lists[0][idx], lists[3][idx]).contiguous()
             else:
                 edges = uniform_sample_bins(near_r, far_r, S).contiguous()
+            if self.fused_pass and cpp.mlp_get_mode() == "fp32":
+                # every pass is ONE launch: match + gather + MLP + composite (tn_render.hip); per sample only the coarse
+                # weights go through HBM; the finished rays are written straight into the frame buffers
+                if self.S_fine > 0:
+                    weights_c = cpp.render_pass(lists, ridx, edges, self.field, None, w)
+                    spacing = (edges - near_r) / (far_r - near_r)
+                    edges = pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r).contiguous()
+                cpp.render_pass(lists, ridx, edges, self.field, directions[idx].contiguous(), w, out=(rgb, acc, depth))
+                return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
             traced = locate(edges)
             if self.S_fine > 0:
                 # coarse pass: gather + mlp_base + density head in one kernel, weights in one more

@@ -462,6 +462,50 @@ def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, wei
     return sigma if density_only else (sigma, rgb)
 
 
+def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, background=1.0):
+    """One render pass as ONE launch (tn_render_pass): sample matching + barycentric gather + MLP + composite on the
+    trace rows of the hitting rays in place.  trace_lists = (num_visited_cells [R], visited_cells, barycentric_coordinates
+    [R,M,2,3], hit_distances [R,M,2], vertex_indices [R,M,4]) as returned by trace_rays; ray_index i32 [r]; edges f32
+    [r, S+1].  dirs=None: density-only coarse pass -> weights f32 [r, S].  Otherwise dirs f32 [r, 3] and
+    out = (rgb [R,3], accumulation [R,1] or [R], depth [R,1] or [R]) pre-filled with the background values: the rows at
+    ray_index are overwritten; returns None."""
+    nv, _cells, bary, dist, verts = trace_lists
+    for x, name in ((nv, "num_visited_cells"), (bary, "barycentric_coordinates"), (dist, "hit_distances"),
+                    (verts, "vertex_indices"), (ray_index, "ray_index"), (edges, "edges"), (field, "field")):
+        _check_input(x, name)
+    M = dist.size(1)
+    _check(dist.dim() == 3 and dist.size(2) == 2 and verts.size(1) == M and bary.size(1) == M, "trace rows must share M")
+    _check(ray_index.dtype == torch.int32 and ray_index.dim() == 1, "ray_index must be i32 [r]")
+    r, S = ray_index.numel(), edges.size(-1) - 1
+    _check(edges.dtype == torch.float32 and tuple(edges.shape) == (r, S + 1), "edges must be f32 [r, S+1]")
+    _check(S >= 64 and M <= 1024, "render_pass needs S >= 64 samples per ray and max_ray_triangles <= 1024")
+    _check(field.dtype == torch.float32 and field.dim() == 2 and field.size(0) == 64, "field must be f32 [64, V]")
+    st, keep = _weights_struct(weights)
+    dev = field.device
+    field_vm = field_vertex_major(field)
+    density_only = dirs is None
+    w_out = None
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        if density_only:
+            w_out = torch.empty((r, S), dtype=torch.float32, device=dev)
+            _lib.check(lib.tn_render_pass(M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S, _ptr(edges),
+                                          _ptr(field_vm), None, C.byref(st), float(background), _ptr(w_out), None, None, None,
+                                          _stream(dev)))
+        else:
+            _check_input(dirs, "dirs")
+            _check(dirs.dtype == torch.float32 and tuple(dirs.shape) == (r, 3), "dirs must be f32 [r, 3]")
+            rgb, acc, depth = out
+            for x, name in ((rgb, "rgb"), (acc, "accumulation"), (depth, "depth")):
+                _check_input(x, name)
+                _check(x.dtype == torch.float32 and x.size(0) == nv.numel(), f"{name} must be f32 over all rays")
+            _lib.check(lib.tn_render_pass(M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S, _ptr(edges),
+                                          _ptr(field_vm), _ptr(dirs), C.byref(st), float(background), None, _ptr(rgb), _ptr(acc),
+                                          _ptr(depth), _stream(dev)))
+    del keep
+    return w_out
+
+
 def composite(sigma, rgb, edges, background=1.0, return_weights=False):
     """RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers
     (model.py:632-638) in one kernel.  sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1].
