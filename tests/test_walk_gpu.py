@@ -164,9 +164,20 @@ def test_literal_pairing_of_the_log_equals_bvh_fallback(tn, device, oracle, scen
     tr = _tracer(tn, device, pts, cells, 1)
     a = _trace(tr, device, o, d, 512)
     reasons = tr.flag_reasons()
+    # 7 = chains whose order the walk does not certify; 13 = paired literally from the log
     assert reasons.get(13, 0) > 100 and reasons.get(13, 0) == reasons.get(7, 0), reasons
     st = tr.trace_stats()
     assert st["walk"] + st["general"] == len(o)
+    # the same pairing delivered as an emit mask to the segment writer (option literal_rows = 0): 14 / 15 = the few rays
+    # the mask kernel hands to the BVH path (a pair against chain direction, segments out of chain order)
+    tr.set_option("literal_rows", 0)
+    m = _trace(tr, device, o, d, 512)
+    reasons = tr.flag_reasons()
+    assert reasons.get(13, 0) + reasons.get(14, 0) + reasons.get(15, 0) == reasons.get(7, 0), reasons
+    assert reasons.get(13, 0) >= 0.9 * reasons.get(7, 0), reasons
+    tr.set_option("literal_rows", 1)
+    for k in KEYS:
+        assert _bits_equal(a[k], m[k]), k
     tr.set_option("literal", 0)
     b = _trace(tr, device, o, d, 512)
     assert 13 not in tr.flag_reasons()

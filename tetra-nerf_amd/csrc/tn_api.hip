@@ -30,6 +30,11 @@ struct tn_tracer {
     tn::DevBuf<uint4> hit_log;           // walk -> segment writer / literal pairing: 16 B per recorded hit, [rays / 64][M][64]
     size_t log_cap_bytes = (size_t)16 << 30;  // larger calls are walked + written in ray chunks
     bool literal = true;                 // false: rays with uncertified order are re-traced through the BVH instead (ablation)
+    bool literal_rows = true;            // true (default): one wavefront sorts, pairs and WRITES the row of a literal ray, on the side
+                                         // stream beside the tail fill; false: k_literal_mask turns the ray into a segment-writer ray
+                                         // (emit mask over the log) -- bit-identical, measured 5-10 % slower per frame because the mask
+                                         // kernel sits on the critical path between walk and writer (profiles/r02i_mask.txt)
+    tn::DevBuf<uint32_t> emit_mask;      // [rays][M / 32]
     bool prefill = false;                // stream the tail slots no certified ray reaches beside the segment writer (measured
                                          // slower: the latency-bound segment writer crawls beside a saturating fill)
     hipStream_t side = nullptr;          // second stream: tail prefill, literal pairing, BVH re-trace
@@ -331,6 +336,8 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             // ride beside the second fill.  The log holds 16 B per hit slot; calls whose log would exceed
             // `log_cap_bytes` are processed in ray chunks (multiples of 4096 rays, the walk's XCD run), serially.
             if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); }
+            const bool use_mask = t->literal && !t->literal_rows && !t->prefill && M >= 32 && M <= 512;
+            if (use_mask && t->emit_mask.n < R * (size_t)(M / 32)) t->emit_mask.alloc(R * (size_t)(M / 32));
             size_t chunk = t->log_cap_bytes / ((size_t)M * sizeof(uint4));
             chunk = chunk / 4096 * 4096;
             if (chunk < 4096) chunk = 4096;
@@ -367,6 +374,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 q.num_rays = n; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
                 q.unroll = t->seg_unroll; q.variant = t->seg_variant;
                 q.walk_n = t->walk_n.p + base;
+                q.emit_mask = use_mask ? t->emit_mask.p + base * (size_t)(M / 32) : nullptr;
                 q.hit_log = t->hit_log.p + (log_base / 64) * (size_t)M * 64;
                 q.vars = t->mesh.vars;
                 q.out_cells = visited + base * M;
@@ -379,6 +387,11 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 if (!t->dense_tails) return;
                 tn::launch_fill_range(n, M, all_rows, kmax, t->walk_n.p + base, num_visited + base, visited + base * M, bary + base * M * 6,
                                       dist + base * M * 2, verts ? verts + base * M * 4 : nullptr, st, t->fill_blocks);
+            };
+            auto launch_mask = [&](size_t base, size_t n, hipStream_t st, size_t log_base = 0) {
+                tn::launch_literal_mask(M, t->mesh.vars, t->hit_log.p + (log_base / 64) * (size_t)M * 64, t->literal_list.p, t->literal_count(), n,
+                                        t->walk_n.p + base, num_visited + base, t->emit_mask.p + base * (size_t)(M / 32),
+                                        t->fallback_list.p, t->fallback_count(), t->kmax(), base, t->stats.p, st);
             };
             auto launch_literal = [&](size_t base, size_t n, hipStream_t st) {
                 if (!t->literal) return;
@@ -410,11 +423,26 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 launch_fill(0, R, false, nullptr, stream);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
+            } else if (single && use_mask) {
+                // walk -> literal pairing as an emit mask (a few percent of the rays, LDS only) -> every sound ray goes
+                // through the segment writer and the tail fill; the handful of BVH fallback rays on a stream of their own
+                launch_walk(0, R);
+                launch_mask(0, R, stream);
+                TN_HIP(hipEventRecord(t->ev_fork, stream));
+                TN_HIP(hipStreamWaitEvent(t->writer, t->ev_fork, 0));
+                tn::launch_trace_general(p, t->writer);
+                TN_HIP(hipEventRecord(t->ev_writer, t->writer));
+                launch_segments(0, R, stream);
+                launch_fill(0, R, false, nullptr, stream);
+                TN_HIP(hipStreamWaitEvent(stream, t->ev_writer, 0));
             } else if (single) {
                 launch_walk(0, R);
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
-                if (t->aux_general) {
+                // (with the `prefill` ablation the all-rows fill of the side stream must precede every kernel that writes whole
+                //  rows, so the fallback rays stay behind it on the side stream)
+                const bool aux = t->aux_general && !t->prefill;
+                if (aux) {
                     // the handful of BVH fallback rays (one wavefront each, ~0.7 ms of pure latency) on a stream of their
                     // own instead of behind the literal pairing
                     TN_HIP(hipStreamWaitEvent(t->writer, t->ev_fork, 0));
@@ -430,19 +458,20 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 }
                 if (t->prefill) launch_fill(0, R, true, t->kmax(), t->side);
                 launch_literal(0, R, t->side);
-                if (!t->aux_general) tn::launch_trace_general(p, t->side);
+                if (!aux) tn::launch_trace_general(p, t->side);
                 launch_fill(0, R, false, t->prefill ? t->kmax() : nullptr, stream);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
-                if (t->aux_general) TN_HIP(hipStreamWaitEvent(stream, t->ev_writer, 0));
+                if (aux) TN_HIP(hipStreamWaitEvent(stream, t->ev_writer, 0));
             } else {
                 for (size_t base = 0; base < R; base += chunk) {
                     const size_t n = R - base < chunk ? R - base : chunk;
                     TN_HIP(hipMemsetAsync(t->literal_count(), 0, sizeof(uint32_t), stream));
                     launch_walk(base, n);
+                    if (use_mask) launch_mask(base, n, stream);
                     launch_segments(base, n, stream);
                     launch_fill(base, n, false, nullptr, stream);
-                    launch_literal(base, n, stream);   // before the next chunk's walk reuses the log
+                    if (!use_mask) launch_literal(base, n, stream);   // before the next chunk's walk reuses the log
                 }
                 tn::launch_trace_general(p, stream);
             }
@@ -584,6 +613,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && std::strcmp(name, "gdebug") == 0) t->gdebug = (uint32_t)value;
         else if (name && std::strcmp(name, "dense_tails") == 0) t->dense_tails = value != 0;
         else if (name && std::strcmp(name, "literal") == 0) t->literal = value != 0;
+        else if (name && std::strcmp(name, "literal_rows") == 0) t->literal_rows = value != 0;
         else if (name && std::strcmp(name, "prefill") == 0) t->prefill = value != 0;
         else if (name && (std::strcmp(name, "rewalk") == 0 || std::strcmp(name, "rewalk_min") == 0)) {}  // round-1 knobs: no effect
         else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
@@ -620,7 +650,7 @@ int tn_probe_write_segments(tn_tracer_t tracer, uint32_t M, uint32_t *visited, f
         tn::WriteParams q{};
         q.num_rays = t->last_num_rays; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
         q.unroll = t->seg_unroll; q.variant = t->seg_variant; q.ablate = (uint32_t)ablate;
-        q.walk_n = t->walk_n.p; q.hit_log = t->hit_log.p; q.vars = t->mesh.vars;
+        q.walk_n = t->walk_n.p; q.emit_mask = t->emit_mask.p; q.hit_log = t->hit_log.p; q.vars = t->mesh.vars;
         q.out_cells = visited; q.out_bary = bary; q.out_dist = dist; q.out_verts = verts;
         tn::launch_write_segments(q, (hipStream_t)stream, (unsigned)blocks);
         TN_HIP(hipGetLastError());

@@ -159,20 +159,22 @@ __global__ __launch_bounds__(BT) void k_face_boxes(size_t F, const uint32_t *__r
     if (f < F) core::face_box((uint32_t)f, faces, xyz, fb + 6 * f, cen + 3 * f);
 }
 
-// position i -> its segment of this level (seg_first ascending, seg_first[0] = 0); centroid bounds per segment
-__global__ __launch_bounds__(BT) void k_seg_bounds(size_t n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ seg_first,
-                                                   uint32_t nseg, const float *__restrict__ cen, uint32_t *__restrict__ seg_of, uint32_t *segb) {
+// position i -> its segment of this level, from its segment of the previous level (child_first / split_pos per previous
+// segment: the first of its one or two successors and the position where the second one starts, ~0 if it did not split;
+// both null at level 0: everything is segment 0); centroid bounds per segment
+__global__ __launch_bounds__(BT) void k_seg_bounds(size_t n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ child_first,
+                                                   const uint32_t *__restrict__ split_pos, const float *__restrict__ cen,
+                                                   uint32_t *__restrict__ seg_of, uint32_t *segb) {
     const size_t i = gid();
     const bool active = i < n;
     uint32_t s = TN_EMPTY;
     float c[3] = {0.f, 0.f, 0.f};
     if (active) {
-        uint32_t lo = 0, hi = nseg;   // last segment with seg_first <= i
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (seg_first[mid] <= (uint32_t)i) lo = mid; else hi = mid;
+        s = 0;
+        if (child_first) {
+            const uint32_t sp = seg_of[i];
+            s = child_first[sp] + ((uint32_t)i >= split_pos[sp] ? 1u : 0u);
         }
-        s = lo;
         seg_of[i] = s;
         const size_t f = order[i];
         c[0] = cen[3 * f]; c[1] = cen[3 * f + 1]; c[2] = cen[3 * f + 2];
@@ -396,30 +398,41 @@ void device_build(size_t V, size_t T, const float *xyz, const uint32_t *cells, h
     DevBuf<float> fb, cen, node_lo, node_hi;
     fb.alloc(6 * F); cen.alloc(3 * F); node_lo.alloc(3 * nn); node_hi.alloc(3 * nn);
     hipLaunchKernelGGL(k_face_boxes, dim3(grid_for(F)), dim3(BT), 0, s, F, out.faces.p, xyz, fb.p, cen.p);
-    DevBuf<uint32_t> ord_a, ord_b, seg_of, seg_first, segb;
+    DevBuf<uint32_t> ord_a, ord_b, seg_of, segb;
     DevBuf<uint64_t> keys_a, keys_b;
     ord_a.alloc(F); ord_b.alloc(F); seg_of.alloc(F); keys_a.alloc(F); keys_b.alloc(F);
     hipLaunchKernelGGL(k_iota, dim3(grid_for(F)), dim3(BT), 0, s, F, ord_a.p);
     const size_t split_rounds = frontier.size() - 1;
     {
-        std::vector<uint32_t> firsts;
-        std::vector<size_t> offs;
+        // per split round l >= 1: for every segment of round l - 1 its first successor and the position of the second
+        std::vector<uint32_t> child_first, split_pos;
+        std::vector<size_t> offs(split_rounds, 0);
         size_t max_seg = 1;
         for (size_t l = 0; l < split_rounds; ++l) {
-            offs.push_back(firsts.size());
-            for (uint32_t k : frontier[l]) firsts.push_back(bn[k].first);
             max_seg = std::max(max_seg, frontier[l].size());
+            if (l == 0) continue;
+            offs[l] = child_first.size();
+            uint32_t running = 0;
+            for (uint32_t k : frontier[l - 1]) {
+                child_first.push_back(running);
+                const bool split = bn[k].left >= 0 && bn[k].level + 1 == (uint32_t)l;   // it split in round l - 1 -> l
+                split_pos.push_back(split ? bn[bn[k].right].first : 0xFFFFFFFFu);
+                running += split ? 2u : 1u;
+            }
         }
-        if (!firsts.empty()) seg_first.upload(firsts);
+        DevBuf<uint32_t> d_child_first, d_split_pos;
+        if (!child_first.empty()) { d_child_first.upload(child_first); d_split_pos.upload(split_pos); }
         segb.alloc(6 * max_seg);
         for (size_t l = 0; l < split_rounds; ++l) {
             const uint32_t nseg = (uint32_t)frontier[l].size();
             hipLaunchKernelGGL(k_init_bounds, dim3(grid_for((size_t)nseg * 6)), dim3(BT), 0, s, segb.p, (size_t)nseg);
-            hipLaunchKernelGGL(k_seg_bounds, dim3(grid_for(F)), dim3(BT), 0, s, F, ord_a.p, seg_first.p + offs[l], nseg, cen.p, seg_of.p, segb.p);
+            hipLaunchKernelGGL(k_seg_bounds, dim3(grid_for(F)), dim3(BT), 0, s, F, ord_a.p, l ? d_child_first.p + offs[l] : nullptr,
+                               l ? d_split_pos.p + offs[l] : nullptr, cen.p, seg_of.p, segb.p);
             hipLaunchKernelGGL(k_seg_keys, dim3(grid_for(F)), dim3(BT), 0, s, F, ord_a.p, seg_of.p, segb.p, cen.p, keys_a.p);
             sort_pairs(tmp, keys_a.p, keys_b.p, ord_a.p, ord_b.p, F, 32u + bit_length(nseg - 1), s);
             ord_a.swap(ord_b);
         }
+        TN_HIP(hipStreamSynchronize(s));   // d_child_first / d_split_pos go out of scope
     }
     for (size_t l = level_start.size() - 1; l-- > 0;) {
         const uint32_t first_node = level_start[l], cnt = level_start[l + 1] - level_start[l];

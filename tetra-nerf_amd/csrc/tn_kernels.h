@@ -60,6 +60,14 @@ void launch_trace_walk(const WalkParams &p, hipStream_t stream);
 void launch_postprocess_log(const TraceParams &p, const WalkVar *vars, const uint4 *hit_log, const uint2 *literal_list,
                             const uint32_t *literal_count, size_t max_items, hipStream_t stream);
 
+// literal pairing of the logged hits as an EMIT MASK over the log (tn_trace_general.hip: k_literal_mask): the rays of
+// literal_list become writer rays (walk_n = hits | LITERAL_MASK_FLAG, out_num set, emit_mask [ray][M / 32]) or go to the
+// BVH fallback list
+constexpr uint32_t LITERAL_MASK_FLAG = 0x40000000u;
+void launch_literal_mask(uint32_t M, const WalkVar *vars, const uint4 *hit_log, const uint2 *literal_list, const uint32_t *literal_count, size_t max_items,
+                         uint32_t *walk_n, uint32_t *out_num, uint32_t *emit_mask, uint32_t *fallback_list, uint32_t *fallback_count,
+                         uint32_t *kmax, size_t ray_base, unsigned long long *stats, hipStream_t stream);
+
 // hit log -> rows of the rays the walk certified (walk_n[ray] != TN_EMPTY): k_write_segments writes the segment records
 // + the tail constants up to the next multiple of 32 slots (a 128-byte line boundary in all four row arrays);
 // k_fill_range streams the rest of the constant tails.  Every byte is written once.
@@ -70,7 +78,8 @@ struct WriteParams {
     uint32_t unroll;           // chunks of 8 hits per ray per iteration: 4 (default) or 2
     uint32_t variant;          // 1 (default): LDS-staged whole-line stores; 0: direct stores
     uint32_t ablate;           // probe only (profiles/): 1 no record loads, 2 only the cell-id store, 4 no stores
-    const uint32_t *walk_n;
+    const uint32_t *walk_n;    // hits in the log | LITERAL_MASK_FLAG (segments = the set bits of emit_mask, not the eps rule)
+    const uint32_t *emit_mask; // [num_rays][M / 32] or null
     const uint4 *hit_log;
     const WalkVar *vars;
     uint32_t *out_cells;

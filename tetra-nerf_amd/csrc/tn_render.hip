@@ -15,10 +15,14 @@
 //   * per step the segments (t_in and the running maximum of t_out, as k_find_matched) of the <= 6 rays the step
 //     touches are staged in LDS; every sample does the matcher's binary lifting there, reads its segment's vertex ids
 //     and entry / exit barycentrics straight from the trace rows, lerps them and gathers its features into the
-//     B-operand registers (same expression trees as tn_match.hip / tn_interp.hip);
-//   * sigma * delta (and the colour) of the 256 samples go to a 5 KB LDS exchange; one wavefront per ray piece runs
-//     the composite scan over it (k_composite's arithmetic), carrying the state of the one ray that continues into
-//     the next step through an LDS slot; finished rays write rgb / accumulation / depth (or every sample its weight).
+//     B-operand registers (same expression trees as tn_match.hip / tn_interp.hip).  The match of step g + 1 is
+//     software-pipelined into step g (its loads ride with the weight copies of layer 3 and of the head layer), so a
+//     step starts with the feature gather like tn_mlp.hip's kernel and the match adds no exposed round trip;
+//   * sigma * delta (and the colour) of the samples go to an LDS exchange ring holding two steps; one wavefront per
+//     ray runs the composite scan (k_composite's arithmetic) over the ray's 64-sample chunks -- aligned to the RAY's
+//     first sample, each processed in the step that completes it, so that a ray's result does not depend on where it
+//     sits in the batch -- carrying the state of the one ray that continues into the next step through an LDS slot;
+//     finished rays write rgb / accumulation / depth (or every sample its weight).
 // Preconditions (checked by the host entry): 64 <= S, M <= 1024, bin edges non-decreasing per ray.
 #include "tn_mlp_common.h"
 
@@ -30,6 +34,7 @@ namespace {
 
 constexpr int RP_PIECES = 6;        // rays a step of 256 samples can touch when S >= 64
 constexpr int RP_GROUP = 256;
+constexpr int RP_RING = 2 * RP_GROUP;
 
 struct RenderPassParams {
     const uint32_t *num_visited;   // [R_all]
@@ -52,6 +57,10 @@ struct RayState { float carry, acc, r0, r1, r2, depth; uint32_t found, pad; };
 
 }  // namespace
 
+// what a lane carries from the match of its sample to the gather: the segment's vertex ids, the sample's barycentrics
+// and its bin edges
+struct Matched { uint4 v4; float b0, b1, b2, e0, e1; };
+
 template <bool DENSITY_ONLY>
 __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -59,10 +68,13 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
     float *seg_t = lds + MAX_STAGE_FLOATS;                        // [RP_PIECES][M] t_in
     float *seg_p = seg_t + (size_t)RP_PIECES * p.M;               // [RP_PIECES][M] running max of t_out
     uint32_t *seg_n = reinterpret_cast<uint32_t *>(seg_p + (size_t)RP_PIECES * p.M);   // [8]
-    float *c_dd = reinterpret_cast<float *>(seg_n + 8);           // [256] sigma * delta
-    float *c_mid = c_dd + RP_GROUP;                               // [256] bin centre
-    float *c_rgb = c_mid + RP_GROUP;                              // [3][256]
-    RayState *open = reinterpret_cast<RayState *>(c_rgb + 3 * RP_GROUP);   // [2]: written by step g into [g & 1]
+    // composite exchange: a ring of TWO steps (block-local sample index & 511), because the composite scans a ray in
+    // chunks of 64 samples aligned to the RAY's first sample -- a chunk may straddle two steps and is processed in the
+    // step that completes it.  Ray-aligned chunks make a ray's result independent of where the ray sits in the batch.
+    float *c_dd = reinterpret_cast<float *>(seg_n + 8);           // [512] sigma * delta
+    float *c_mid = c_dd + RP_RING;                                // [512] bin centre
+    float *c_rgb = c_mid + RP_RING;                               // [3][512]
+    RayState *open = reinterpret_cast<RayState *>(c_rgb + 3 * RP_RING);   // [2]: written by step g into [g & 1]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const uint32_t S = p.S, M = p.M;
@@ -71,12 +83,25 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
     const uint32_t stream_len = (uint32_t)((q1 - q0) * S);
     const uint32_t ngroups = (stream_len + RP_GROUP - 1) / RP_GROUP;
 
-    for (uint32_t g = 0; g < ngroups; ++g) {
-        const uint32_t gs = g * RP_GROUP, ge = gs + RP_GROUP < stream_len ? gs + RP_GROUP : stream_len;
-        const uint32_t qa = gs / S, qb = (ge - 1) / S;            // block-local ray slots of this step
-        const uint32_t P = qb - qa + 1;
-        __syncthreads();
-        // ---- segments of the rays of this step -> LDS (t_in, running max of t_out)
+    // The match of step g + 1 is software-pipelined into step g: its segments are staged (and its bin edges requested)
+    // while layer 3's weights are in flight, its search runs and its segment records are requested while the head
+    // layer's weights are in flight, the lerp consumes them after the head layer.  Step g itself then starts with the
+    // feature gather, exactly like tn_mlp.hip's fused-gather kernel: the match adds no exposed round trip.
+    auto step_geometry = [&](uint32_t g, uint32_t &gs, uint32_t &ge, uint32_t &qa, uint32_t &P) {
+        gs = g * RP_GROUP; ge = gs + RP_GROUP < stream_len ? gs + RP_GROUP : stream_len;
+        qa = gs / S; P = (ge - 1) / S - qa + 1;
+    };
+    auto sample_of = [&](uint32_t g, uint32_t &ql, uint32_t &j) {   // this lane's sample of step g (clamped: duplicates store nothing)
+        uint32_t gs, ge, qa, P;
+        step_geometry(g, gs, ge, qa, P);
+        const uint32_t sl = gs + (uint32_t)wave * 32 + ((uint32_t)lane & 31u);
+        const uint32_t slc = sl < ge ? sl : ge - 1;
+        ql = slc / S; j = slc - ql * S;
+    };
+    // part A: segments of the rays of step g -> LDS (t_in, running max of t_out); this lane's bin edges requested
+    auto match_stage = [&](uint32_t g, Matched &m) {
+        uint32_t gs, ge, qa, P;
+        step_geometry(g, gs, ge, qa, P);
         for (uint32_t piece = wave; piece < P; piece += MLP_BLOCK / 64) {
             const size_t ray = p.ray_index[q0 + qa + piece];
             uint32_t n = p.num_visited[ray];
@@ -84,55 +109,88 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
             const float2 *drow = reinterpret_cast<const float2 *>(p.dist) + ray * M;
             float carry = -INFINITY;
             for (uint32_t base = 0; base < n; base += 64) {
-                const uint32_t j = base + lane;
+                const uint32_t jj = base + lane;
                 float2 d = make_float2(0.f, -INFINITY);
-                if (j < n) d = drow[j];
-                float m = d.y;
+                if (jj < n) d = drow[jj];
+                float mx = d.y;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
-                    const float o = __shfl_up(m, off);
-                    if (lane >= off) m = fmaxf(m, o);
+                    const float o = __shfl_up(mx, off);
+                    if (lane >= off) mx = fmaxf(mx, o);
                 }
-                m = fmaxf(m, carry);
-                if (j < n) { seg_t[(size_t)piece * M + j] = d.x; seg_p[(size_t)piece * M + j] = m; }
-                carry = __shfl(m, 63);
+                mx = fmaxf(mx, carry);
+                if (jj < n) { seg_t[(size_t)piece * M + jj] = d.x; seg_p[(size_t)piece * M + jj] = mx; }
+                carry = __shfl(mx, 63);
             }
             if (lane == 0) seg_n[piece] = n;
         }
+        uint32_t ql, j;
+        sample_of(g, ql, j);
+        const size_t q = q0 + ql;
+        m.e0 = p.edges[q * (S + 1) + j]; m.e1 = p.edges[q * (S + 1) + j + 1];
+    };
+    // part B (after a barrier): the matcher's binary lifting in LDS; the segment's record requested
+    struct Pending { float2 q0f, q1f, q2f; float t_in, t_out, cur; bool hit; };
+    auto match_search = [&](uint32_t g, Matched &m, Pending &pd) {
+        uint32_t gs, ge, qa, P, ql, j;
+        step_geometry(g, gs, ge, qa, P);
+        sample_of(g, ql, j);
+        const uint32_t piece = ql - qa;
+        const uint32_t n = seg_n[piece];
+        const float *pm = seg_p + (size_t)piece * M, *ti = seg_t + (size_t)piece * M;
+        pd.cur = (m.e1 + m.e0) / 2.0f;
+        uint32_t pos = 0;
+        for (uint32_t bit = n ? (1u << (31 - __clz((int)n))) : 0u; bit > 0; bit >>= 1)
+            if (pos + bit <= n && pm[pos + bit - 1] < pd.cur) pos += bit;
+        m.v4 = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
+        pd.hit = pos < n && ti[pos] <= pd.cur;
+        pd.t_in = 0.f; pd.t_out = 1.f; pd.q0f = pd.q1f = pd.q2f = make_float2(0.f, 0.f);
+        if (pd.hit) {
+            const size_t gi = (size_t)p.ray_index[q0 + ql] * M + pos;
+            pd.t_in = ti[pos]; pd.t_out = p.dist[2 * gi + 1];
+            m.v4 = *reinterpret_cast<const uint4 *>(p.verts + 4 * gi);
+            const float2 *bp = reinterpret_cast<const float2 *>(p.bary + 6 * gi);
+            pd.q0f = bp[0]; pd.q1f = bp[1]; pd.q2f = bp[2];   // c1.xyz = q0.x q0.y q1.x ; c2.xyz = q1.y q2.x q2.y
+        }
+    };
+    // part C: lerp of the entry / exit barycentrics (tn_match.hip's expression)
+    auto match_finish = [&](Matched &m, const Pending &pd) {
+        m.b0 = m.b1 = m.b2 = 0.f;
+        if (pd.hit) {
+            const float mult = (pd.cur - pd.t_in) / (pd.t_out - pd.t_in);
+            m.b0 = (1 - mult) * pd.q0f.x + mult * pd.q1f.y;
+            m.b1 = (1 - mult) * pd.q0f.y + mult * pd.q2f.x;
+            m.b2 = (1 - mult) * pd.q1f.x + mult * pd.q2f.y;
+        }
+    };
+
+    Matched cur, nxt;
+    if (ngroups) {
+        Pending pd;
+        match_stage(0, cur);
+        __syncthreads();
+        match_search(0, cur, pd);
+        match_finish(cur, pd);
+    }
+    nxt = cur;
+
+    for (uint32_t g = 0; g < ngroups; ++g) {
+        uint32_t gs, ge, qa, P;
+        step_geometry(g, gs, ge, qa, P);
+        const bool more = g + 1 < ngroups;
+        const uint32_t sl = gs + (uint32_t)wave * 32 + ((uint32_t)lane & 31u);
+        uint32_t ql, jdummy;
+        sample_of(g, ql, jdummy);
+        const size_t q = q0 + ql;
+        const float e0 = cur.e0, e1 = cur.e1;
         __syncthreads();
         stage_weights(lds, p.pk + OFF_W1, lfloats(KS1, OT));
-
-        // ---- this lane's sample: match, lerp, gather
-        const uint32_t sl = gs + (uint32_t)wave * 32 + ((uint32_t)lane & 31u);
-        const bool valid = sl < ge;
-        const uint32_t slc = valid ? sl : ge - 1;                 // out-of-range lanes compute a duplicate, store nothing
-        const uint32_t ql = slc / S, j = slc - ql * S, piece = ql - qa;
-        const size_t q = q0 + ql;
-        const float e0 = p.edges[q * (S + 1) + j], e1 = p.edges[q * (S + 1) + j + 1];
-        const float cur = (e1 + e0) / 2.0f;
+        // ---- barycentric gather of this lane's sample (tn_interp.hip's summation order)
         float bin[KSH];
         {
-            const uint32_t n = seg_n[piece];
-            const float *pm = seg_p + (size_t)piece * M, *ti = seg_t + (size_t)piece * M;
-            uint32_t pos = 0;
-            for (uint32_t bit = n ? (1u << (31 - __clz((int)n))) : 0u; bit > 0; bit >>= 1)
-                if (pos + bit <= n && pm[pos + bit - 1] < cur) pos += bit;
-            uint4 v4 = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
-            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-            if (pos < n && ti[pos] <= cur) {
-                const size_t gi = (size_t)p.ray_index[q] * M + pos;
-                const float t_in = ti[pos], t_out = p.dist[2 * gi + 1];
-                v4 = *reinterpret_cast<const uint4 *>(p.verts + 4 * gi);
-                const float2 *bp = reinterpret_cast<const float2 *>(p.bary + 6 * gi);
-                const float2 q0f = bp[0], q1f = bp[1], q2f = bp[2];   // c1.xyz = q0.x q0.y q1.x ; c2.xyz = q1.y q2.x q2.y
-                const float mult = (cur - t_in) / (t_out - t_in);
-                b0 = (1 - mult) * q0f.x + mult * q1f.y;
-                b1 = (1 - mult) * q0f.y + mult * q2f.x;
-                b2 = (1 - mult) * q1f.x + mult * q2f.y;
-            }
-            const float w0 = 1.0f - ((b0 + b1) + b2);
-            const uint32_t vv[4] = {v4.y, v4.z, v4.w, v4.x};
-            const float ww[4] = {b0, b1, b2, w0};
+            const float w0 = 1.0f - ((cur.b0 + cur.b1) + cur.b2);
+            const uint32_t vv[4] = {cur.v4.y, cur.v4.z, cur.v4.w, cur.v4.x};
+            const float ww[4] = {cur.b0, cur.b1, cur.b2, w0};
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) bin[ks] = 0.f;
 #pragma unroll
@@ -168,6 +226,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
         }
         __syncthreads();
         stage_weights(lds, p.pk + OFF_W3, N_W3);
+        if (more) match_stage(g + 1, nxt);        // its loads ride with the weight copy
         stage_wait();
         {
             f32x16 acc[OT];
@@ -181,14 +240,17 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
             const float raw = head_dot(dv + 64 * h, bin) + dv[128];
             const float sp = raw > 20.0f ? raw : log1pf(expf(raw));
             if (h == 0) {
-                const uint32_t li = (uint32_t)wave * 32 + ((uint32_t)lane & 31u);
+                const uint32_t li = sl & (RP_RING - 1);
                 c_dd[li] = (e1 - e0) * sp;
                 c_mid[li] = 0.5f * (e0 + e1);
             }
         }
+        Pending pd;
+        pd.hit = false; pd.t_in = 0.f; pd.t_out = 1.f; pd.cur = 0.f; pd.q0f = pd.q1f = pd.q2f = make_float2(0.f, 0.f);
         if constexpr (!DENSITY_ONLY) {
             __syncthreads();
             stage_weights(lds, p.pk + OFF_WHEAD, N_WHEAD);
+            if (more) match_search(g + 1, nxt, pd);   // LDS search + record loads beside the weight copy
             stage_wait();
             {
                 f32x16 acc[OT];
@@ -211,25 +273,32 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
             const float c1 = head_dot(cv + 128 + 64 * h, bin) + cv[385];
             const float c2 = head_dot(cv + 256 + 64 * h, bin) + cv[386];
             if (h == 0) {
-                const uint32_t li = (uint32_t)wave * 32 + ((uint32_t)lane & 31u);
+                const uint32_t li = sl & (RP_RING - 1);
                 c_rgb[li] = 1.0f / (1.0f + expf(-c0));
-                c_rgb[RP_GROUP + li] = 1.0f / (1.0f + expf(-c1));
-                c_rgb[2 * RP_GROUP + li] = 1.0f / (1.0f + expf(-c2));
+                c_rgb[RP_RING + li] = 1.0f / (1.0f + expf(-c1));
+                c_rgb[2 * RP_RING + li] = 1.0f / (1.0f + expf(-c2));
             }
+        } else {
+            if (more) match_search(g + 1, nxt, pd);
         }
+        if (more) match_finish(nxt, pd);
         __syncthreads();
-        // ---- composite: one wavefront per ray piece of this step
+        // ---- composite: one wavefront per ray of this step; ray-aligned chunks of 64 samples, each processed in the step
+        //      that holds its last sample (k_composite's arithmetic per chunk)
         for (uint32_t piece2 = wave; piece2 < P; piece2 += MLP_BLOCK / 64) {
             const uint32_t qq = qa + piece2;
             const uint32_t ray_start = qq * S, ray_end = ray_start + S;
-            const uint32_t ps = gs > ray_start ? gs : ray_start, pe = ge < ray_end ? ge : ray_end;
+            uint32_t k = gs > ray_start ? (gs - ray_start) / 64 : 0;   // chunks 0 .. k-1 were completed by earlier steps
             RayState st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
-            if (ps > ray_start) st = open[(g + 1) & 1];   // the ray that continues from the previous step
-            float l0 = 0.f, l1 = 0.f, l2 = 0.f;
-            for (uint32_t base = ps; base < pe; base += 64) {
-                const uint32_t idx = base + lane;
-                const bool ok = idx < pe;
-                const uint32_t li = (ok ? idx : pe - 1) - gs;
+            if (k > 0) st = open[(g + 1) & 1];       // the one ray that continues from the previous step
+            bool done = false, any = false;
+            for (;; ++k) {
+                const uint32_t cb = ray_start + 64 * k;
+                const uint32_t ce = cb + 64 < ray_end ? cb + 64 : ray_end;
+                if (ce - 1 >= ge) break;             // completed by a later step
+                const uint32_t idx = cb + lane;
+                const bool ok = idx < ce;
+                const uint32_t li = (ok ? idx : ce - 1) & (RP_RING - 1);
                 const float dd = ok ? c_dd[li] : 0.f;
                 float inc = dd;
 #pragma unroll
@@ -241,14 +310,17 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
                 float w = (1.0f - expf(-dd)) * expf(-excl);
                 if (!(w == w) || !ok) w = 0.f;   // nan_to_num
                 if (p.out_weights && ok) p.out_weights[(q0 + qq) * S + (idx - ray_start)] = w;
-                if constexpr (!DENSITY_ONLY) {
-                    l0 += w * c_rgb[li]; l1 += w * c_rgb[RP_GROUP + li]; l2 += w * c_rgb[2 * RP_GROUP + li];
-                }
                 float winc = w;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
                     const float o = __shfl_up(winc, off);
                     if (lane >= off) winc += o;
+                }
+                if constexpr (!DENSITY_ONLY) {
+                    float l0 = w * c_rgb[li], l1 = w * c_rgb[RP_RING + li], l2 = w * c_rgb[2 * RP_RING + li];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) { l0 += __shfl_xor(l0, off); l1 += __shfl_xor(l1, off); l2 += __shfl_xor(l2, off); }
+                    st.r0 += l0; st.r1 += l1; st.r2 += l2;
                 }
                 const float cum = st.acc + winc;
                 const uint64_t m = __ballot(ok && cum >= 0.5f);
@@ -259,26 +331,24 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
                 }
                 st.carry += __shfl(inc, 63);
                 st.acc += __shfl(winc, 63);
+                any = true;
+                if (ce == ray_end) { done = true; break; }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                l0 += __shfl_xor(l0, off); l1 += __shfl_xor(l1, off); l2 += __shfl_xor(l2, off);
-            }
-            st.r0 += l0; st.r1 += l1; st.r2 += l2;
-            if (pe == ray_end) {
+            if (done) {
                 if (!DENSITY_ONLY && p.out_rgb && lane == 0) {
                     const size_t ray = p.ray_index[q0 + qq];
-                    if (!st.found) st.depth = c_mid[pe - 1 - gs];   // searchsorted clamps to the last sample
+                    if (!st.found) st.depth = c_mid[(ray_end - 1) & (RP_RING - 1)];   // searchsorted clamps to the last sample
                     p.out_rgb[3 * ray] = st.r0 + p.background * (1.0f - st.acc);
                     p.out_rgb[3 * ray + 1] = st.r1 + p.background * (1.0f - st.acc);
                     p.out_rgb[3 * ray + 2] = st.r2 + p.background * (1.0f - st.acc);
                     p.out_acc[ray] = st.acc;
                     p.out_depth[ray] = st.depth;
                 }
-            } else if (lane == 0) {
+            } else if (any && lane == 0) {
                 open[g & 1] = st;
             }
         }
+        cur = nxt;
     }
 }
 
@@ -303,7 +373,7 @@ void launch_render_pass(const uint32_t *num_visited, const float *dist, const fl
     p.num_visited = num_visited; p.dist = dist; p.bary = bary; p.verts = verts; p.ray_index = ray_index; p.edges = edges;
     p.fieldT = fieldT; p.enc = enc; p.pk = pk; p.out_weights = out_weights; p.out_rgb = out_rgb; p.out_acc = out_acc;
     p.out_depth = out_depth; p.r = r; p.S = S; p.M = M; p.background = background;
-    auto smem_for = [](size_t m) { return (MAX_STAGE_FLOATS + 2 * (size_t)RP_PIECES * m + 8 + 5 * RP_GROUP) * sizeof(float) + 2 * sizeof(RayState); };
+    auto smem_for = [](size_t m) { return (MAX_STAGE_FLOATS + 2 * (size_t)RP_PIECES * m + 8 + 5 * RP_RING) * sizeof(float) + 2 * sizeof(RayState); };
     const size_t smem = smem_for(M);
     static PerDeviceOnce lds_attr;
     lds_attr.run([&] {

@@ -407,12 +407,13 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
     uint32_t nh_next_raw = hits_of(g + nwaves);            // in flight during the whole first group
     uint4 e[U];
     {
-        const uint32_t nh0 = nh_raw == TN_EMPTY ? 0u : nh_raw;
+        const uint32_t nh0 = nh_raw == TN_EMPTY ? 0u : (nh_raw & ~LITERAL_MASK_FLAG);
         load_entries(e, log_of(g), nh0, 0);
     }
     for (; g < G; g += nwaves) {
-        const bool skip = nh_raw == TN_EMPTY;   // literal / fallback ray (or padding): the row belongs to another kernel
-        const uint32_t nh = skip ? 0u : nh_raw;
+        const bool skip = nh_raw == TN_EMPTY;   // fallback ray (or padding): the row belongs to another kernel
+        const bool masked = !skip && (nh_raw & LITERAL_MASK_FLAG) != 0;   // segments = set bits of the ray's emit mask
+        const uint32_t nh = skip ? 0u : (nh_raw & ~LITERAL_MASK_FLAG);
         uint32_t mx = nh;                       // max over the 8 rays (the value is replicated over h)
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
         const size_t row = (8 * g + a) * (size_t)M;
         // the group after the next: its hit counts are requested now, needed one group later
         const size_t g_next = g + nwaves;
-        const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : nh_next_raw;
+        const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : (nh_next_raw & ~LITERAL_MASK_FLAG);
         const uint32_t nh_next2_raw = hits_of(g_next + nwaves);
         uint32_t nseg = 0;
         uint4 carry = make_uint4(0u, 0u, 0u, 0u);   // hit c0 - 1 of ray a
@@ -439,6 +440,8 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
             //      emission, slots
             uint4 pe[U];
             uint32_t slot[U];   // TN_EMPTY: no segment
+            uint32_t mword = 0u;   // literal ray: bit k = "the pair (k - 1, k) is a segment" (k_literal_mask)
+            if (masked) mword = q.emit_mask[(8 * g + a) * (size_t)(M / 32) + (c0 >> 5)];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t k = c0 + 8 * u + h;
@@ -447,7 +450,9 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
                 if (h == 0) pe[u] = carry;
                 carry.x = (uint32_t)__shfl((int)e[u].x, (int)a + 56); carry.y = (uint32_t)__shfl((int)e[u].y, (int)a + 56);
                 carry.z = (uint32_t)__shfl((int)e[u].z, (int)a + 56);
-                const bool emit = k >= 1 && k < nh && !(fabsf(__uint_as_float(pe[u].x) - __uint_as_float(e[u].x)) < TN_EPS);
+                const bool pair_ok = masked ? ((mword >> (k & 31u)) & 1u) != 0
+                                            : !(fabsf(__uint_as_float(pe[u].x) - __uint_as_float(e[u].x)) < TN_EPS);
+                const bool emit = k >= 1 && k < nh && pair_ok;
                 const unsigned long long m = __ballot(emit) & raymask;
                 slot[u] = emit ? nseg + (uint32_t)__popcll(m & lanemask_lt()) : TN_EMPTY;
                 nseg += (uint32_t)__popcll(m);
@@ -569,12 +574,13 @@ __global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
     uint32_t nh_next_raw = hits_of(g + nwaves);
     uint4 e[U];
     {
-        const uint32_t nh0 = nh_raw == TN_EMPTY ? 0u : nh_raw;
+        const uint32_t nh0 = nh_raw == TN_EMPTY ? 0u : (nh_raw & ~LITERAL_MASK_FLAG);
         load_entries(e, log_of(g), nh0, 0);
     }
     for (; g < G; g += nwaves) {
-        const bool skip = nh_raw == TN_EMPTY;
-        const uint32_t nh = skip ? 0u : nh_raw;
+        const bool skip = nh_raw == TN_EMPTY;   // fallback ray (or padding): the row belongs to another kernel
+        const bool masked = !skip && (nh_raw & LITERAL_MASK_FLAG) != 0;   // segments = set bits of the ray's emit mask
+        const uint32_t nh = skip ? 0u : (nh_raw & ~LITERAL_MASK_FLAG);
         uint32_t mx = nh;
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
         const size_t row0 = 8 * g * (size_t)M;             // first slot of ray 8g
         const size_t row = row0 + (size_t)a * M;
         const size_t g_next = g + nwaves;
-        const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : nh_next_raw;
+        const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : (nh_next_raw & ~LITERAL_MASK_FLAG);
         const uint32_t nh_next2_raw = hits_of(g_next + nwaves);
         uint32_t nseg = 0;
         uint4 carry = make_uint4(0u, 0u, 0u, 0u);
@@ -600,6 +606,8 @@ __global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
             uint4 pe[U];
             uint32_t slot[U];   // slot within this iteration (0..31), TN_EMPTY: no segment
             unsigned long long any = 0;
+            uint32_t mword = 0u;   // literal ray: bit k = "the pair (k - 1, k) is a segment" (k_literal_mask)
+            if (masked) mword = q.emit_mask[(8 * g + a) * (size_t)(M / 32) + (c0 >> 5)];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t k = c0 + 8 * u + h;
@@ -608,7 +616,9 @@ __global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
                 if (h == 0) pe[u] = carry;
                 carry.x = (uint32_t)__shfl((int)e[u].x, (int)a + 56); carry.y = (uint32_t)__shfl((int)e[u].y, (int)a + 56);
                 carry.z = (uint32_t)__shfl((int)e[u].z, (int)a + 56);
-                const bool emit = k >= 1 && k < nh && !(fabsf(__uint_as_float(pe[u].x) - __uint_as_float(e[u].x)) < TN_EPS);
+                const bool pair_ok = masked ? ((mword >> (k & 31u)) & 1u) != 0
+                                            : !(fabsf(__uint_as_float(pe[u].x) - __uint_as_float(e[u].x)) < TN_EPS);
+                const bool emit = k >= 1 && k < nh && pair_ok;
                 const unsigned long long mall = __ballot(emit);
                 const unsigned long long m = mall & raymask;
                 any |= mall;
