@@ -104,11 +104,12 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
             full.setdefault(name, {"samples_per_ray": f"{s_c} coarse" + (f" (density only) + {s_c + s_f + 1} fine" if s_f else "")})
             full[name][mode] = {"rendered_rays_per_s": R / dtf, "ms_per_frame": dtf * 1e3}
             if mode == "fp32":
-                # fp32 runs every pass as ONE launch (tn_render_pass); the same config through the separate match /
-                # gather+MLP / composite kernels of round 2a, for comparison
+                # the same config with every pass as ONE launch (tn_render_pass: match + gather + MLP + composite); the
+                # default renderer uses that up to 16,384 hitting rays per call and the separate match / gather+MLP /
+                # composite kernels on these 65,536-ray chunks, where they are a few per cent faster
                 dtu = timed(render.TetraRenderer(tracer, field, mlp, s_c, M, fused=True, num_fine_samples=s_f, biased=biased,
-                                                 fused_pass=False))
-                full[name]["fp32_separate_kernels"] = {"rendered_rays_per_s": R / dtu, "ms_per_frame": dtu * 1e3}
+                                                 fused_pass=True))
+                full[name]["fp32_one_launch_per_pass"] = {"rendered_rays_per_s": R / dtu, "ms_per_frame": dtu * 1e3}
     tn.cpp.mlp_set_mode("fp32")
     # MLP kernel alone on one chunk worth of samples of hitting rays (MFMA roofline)
     n = min(hit, chunk) * samples
@@ -137,7 +138,7 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
     tn.cpp.mlp_set_mode("fp32")
     x3_ms = e0.elapsed_time(e1) / 5
     return {"rendered_rays_per_s": R / dt, "ms_per_frame": dt * 1e3, "rays": R, "hitting_rays": hit,
-            "samples_per_ray": samples, "pass": "coarse only (uniform samples): match + gather + MLP + composite in ONE launch (tn_render_pass)",
+            "samples_per_ray": samples, "pass": "coarse only (uniform samples), 65,536-ray chunks: match kernel, fused gather + MLP kernel, composite kernel",
             "eval_configs": full,
             "roofline_mlp": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
                              "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "samples": n, "kernel_ms": mlp_ms,

@@ -250,7 +250,7 @@ int tn_mlp_forward_gather(size_t n, uint32_t samples_per_ray, uint32_t num_verti
 /* One render PASS of TetrahedraNerf.get_outputs as ONE launch (reference span
  * tetranerf/nerfstudio/model.py:560-662 = find_visited_cells -> interpolate_values -> mlp_base + heads -> get_weights ->
  * renderers): sample matching, barycentric gather, MLP and composite fused; nothing per sample goes through HBM but the
- * coarse weights.  The trace rows (outputs of tn_trace_rays, rows of M slots, M <= 1024) are read IN PLACE:
+ * coarse weights.  The trace rows (outputs of tn_trace_rays, rows of M slots, M <= 512) are read IN PLACE:
  * ray_index u32 [r] names the row of hitting ray q.  edges f32 [r, S+1] = the sampler's bin edges (non-decreasing per
  * ray, S >= 64); field_vm f32 [V,64] vertex-major (tn_transpose_f32).
  *   dirs == NULL : density-only coarse pass (model.py:577-582): out_weights f32 [r, S] = get_weights.

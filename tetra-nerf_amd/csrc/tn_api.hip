@@ -1,6 +1,7 @@
 // tn_api.hip -- the C-ABI of libtetranerf_hip.so (see include/tetranerf_hip.h).
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -41,6 +42,7 @@ struct tn_tracer {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t writer = nullptr;        // pipelined mode: the segment writer of chunk i runs beside the walk of chunk i + 1
     hipEvent_t ev_chunk[8] = {}, ev_writer = nullptr;
+    bool small_lds = true;               // small batches: LDS hit arrays sized for the mesh, overflow rays in a second launch
     bool side_late = true;               // literal pairing starts after the segment writer (beside the fill), not beside it
     bool aux_general = true;             // BVH fallback rays on a third stream (forked right after the walk)
     unsigned pipe = 1;                   // ray chunks of the walk -> writer pipeline (1 = one walk, then one writer)
@@ -476,6 +478,21 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 tn::launch_trace_general(p, stream);
             }
         } else {
+            // Small batch (below walk_min_rays): one wavefront per ray through the BVH.  Latency-bound, so every ray should
+            // be resident at once: LDS hit arrays sized for the hits a ray of THIS mesh is expected to have (a uniform mesh
+            // of T tets: at most ~3.45 T^(1/3) faces on a ray), rays with more go through a second launch
+            // with the full M-entry arrays.
+            uint32_t C = 64;
+            const double expect = 3.6 * std::cbrt((double)std::max<uint32_t>(t->mesh.T, 1u));
+            while (C < expect && C < M) C <<= 1;
+            if (t->small_lds && C < M) {
+                if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); }
+                tn::TraceParams p1 = p;
+                p1.lds_cap = C; p1.overflow_list = t->fallback_list.p; p1.overflow_count = t->fallback_count();
+                tn::launch_trace_general(p1, stream);
+                p.ray_list = t->fallback_list.p;
+                p.item_count = t->fallback_count();
+            }
             tn::launch_trace_general(p, stream);
         }
         TN_HIP(hipGetLastError());
@@ -618,6 +635,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && (std::strcmp(name, "rewalk") == 0 || std::strcmp(name, "rewalk_min") == 0)) {}  // round-1 knobs: no effect
         else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
         else if (name && std::strcmp(name, "seg_blocks") == 0) t->seg_blocks = (unsigned)value;
+        else if (name && std::strcmp(name, "small_lds") == 0) t->small_lds = value != 0;
         else if (name && std::strcmp(name, "side_late") == 0) t->side_late = value != 0;
         else if (name && std::strcmp(name, "aux_general") == 0) t->aux_general = value != 0;
         else if (name && std::strcmp(name, "pipe") == 0) t->pipe = value < 1 ? 1u : (value > 8 ? 8u : (unsigned)value);

@@ -19,6 +19,9 @@ struct TraceParams {
     size_t num_items;          // rays (or entries of ray_list) to process
     const uint32_t *ray_list;  // optional indirection: item -> ray index
     const uint32_t *item_count; // optional device-side item count (overrides num_items in-kernel)
+    uint32_t lds_cap;          // k_trace_general: entries of the LDS hit arrays (0 = M); rays with more hits go to overflow_list
+    uint32_t *overflow_list;   // [num_items] / [1]
+    uint32_t *overflow_count;
     unsigned long long *stats; // [4] device counters or null
     uint32_t gdebug;           // ablation of the general kernel (bench only): 1 stop after traversal, 2 skip sort, 8 count node/leaf visits in stats[18]/[19]
 };

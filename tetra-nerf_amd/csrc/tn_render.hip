@@ -19,11 +19,11 @@
 //     software-pipelined into step g (its loads ride with the weight copies of layer 3 and of the head layer), so a
 //     step starts with the feature gather like tn_mlp.hip's kernel and the match adds no exposed round trip;
 //   * sigma * delta (and the colour) of the samples go to an LDS exchange ring holding two steps; one wavefront per
-//     ray runs the composite scan (k_composite's arithmetic) over the ray's 64-sample chunks -- aligned to the RAY's
-//     first sample, each processed in the step that completes it, so that a ray's result does not depend on where it
-//     sits in the batch -- carrying the state of the one ray that continues into the next step through an LDS slot;
+//     ray runs the composite scan (k_composite's expressions) over the ray's 256-sample chunks (4 samples per lane) --
+//     aligned to the RAY's first sample, each processed in the step that completes it, so that a ray's result does not
+//     depend on where it sits in the batch -- carrying the state of the one ray that continues into the next step through an LDS slot;
 //     finished rays write rgb / accumulation / depth (or every sample its weight).
-// Preconditions (checked by the host entry): 64 <= S, M <= 1024, bin edges non-decreasing per ray.
+// Preconditions (checked by the host entry): 64 <= S, M <= 512, bin edges non-decreasing per ray.
 #include "tn_mlp_common.h"
 
 namespace tn {
@@ -42,6 +42,7 @@ struct RenderPassParams {
     const float *bary;             // [R_all, M, 2, 3]
     const uint32_t *verts;         // [R_all, M, 4]
     const uint32_t *ray_index;     // [r] trace row of hitting ray q
+    const uint32_t *nv_hit;        // [r] num_visited[ray_index[q]] (gathered once per launch: no dependent load chain in the pipeline)
     const float *edges;            // [r, S + 1]
     const float *fieldT;           // [V, 64]
     const float *enc;              // [r, 28] or null (density only)
@@ -54,6 +55,12 @@ struct RenderPassParams {
 };
 
 struct RayState { float carry, acc, r0, r1, r2, depth; uint32_t found, pad; };
+
+__global__ void k_gather_counts(size_t r, const uint32_t *__restrict__ ray_index, const uint32_t *__restrict__ num_visited,
+                                uint32_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < r) out[i] = num_visited[ray_index[i]];
+}
 
 }  // namespace
 
@@ -129,6 +136,50 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
         const size_t q = q0 + ql;
         m.e0 = p.edges[q * (S + 1) + j]; m.e1 = p.edges[q * (S + 1) + j + 1];
     };
+    // The same, split for the software pipeline (one ray per wavefront: a step touches <= 6 rays, a block has 8 waves):
+    // the ray's row index and segment count are requested a layer early, the rows of its segment bounds (<= 8 chunks of
+    // 64, M <= 512) at the start of the next layer, the scan + LDS stores run at that layer's end.
+    struct SegLoad { size_t ray; uint32_t n; bool on; float2 d[8]; };
+    auto seg_issue_count = [&](uint32_t g, SegLoad &sl, Matched &m) {
+        uint32_t gs, ge, qa, P;
+        step_geometry(g, gs, ge, qa, P);
+        sl.on = (uint32_t)wave < P;
+        sl.ray = 0; sl.n = 0;
+        if (sl.on) { sl.ray = p.ray_index[q0 + qa + wave]; sl.n = p.nv_hit[q0 + qa + wave]; }
+        uint32_t ql, j;
+        sample_of(g, ql, j);
+        const size_t q = q0 + ql;
+        m.e0 = p.edges[q * (S + 1) + j]; m.e1 = p.edges[q * (S + 1) + j + 1];
+    };
+    auto seg_issue_rows = [&](SegLoad &sl) {
+        if (sl.n > M) sl.n = M;
+        const float2 *drow = reinterpret_cast<const float2 *>(p.dist) + sl.ray * M;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t jj = (uint32_t)c * 64 + lane;
+            sl.d[c] = make_float2(0.f, -INFINITY);
+            if (sl.on && jj < sl.n) sl.d[c] = drow[jj];
+        }
+    };
+    auto seg_store = [&](const SegLoad &sl) {
+        if (!sl.on) return;                         // wave-uniform
+        float carry = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if ((uint32_t)c * 64 >= sl.n) break;     // wave-uniform
+            const uint32_t jj = (uint32_t)c * 64 + lane;
+            float mx = sl.d[c].y;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float o = __shfl_up(mx, off);
+                if (lane >= off) mx = fmaxf(mx, o);
+            }
+            mx = fmaxf(mx, carry);
+            if (jj < sl.n) { seg_t[(size_t)wave * M + jj] = sl.d[c].x; seg_p[(size_t)wave * M + jj] = mx; }
+            carry = __shfl(mx, 63);
+        }
+        if (lane == 0) seg_n[wave] = sl.n;
+    };
     // part B (after a barrier): the matcher's binary lifting in LDS; the segment's record requested
     struct Pending { float2 q0f, q1f, q2f; float t_in, t_out, cur; bool hit; };
     auto match_search = [&](uint32_t g, Matched &m, Pending &pd) {
@@ -162,6 +213,100 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
             m.b1 = (1 - mult) * pd.q0f.y + mult * pd.q2f.x;
             m.b2 = (1 - mult) * pd.q1f.x + mult * pd.q2f.y;
         }
+    };
+
+    // ---- composite of step g2: one wavefront per ray of the step; ray-aligned chunks of 256 samples (4 consecutive
+    //      samples per lane: a lane-local prefix + ONE wave scan per 256 samples -- the cross-lane shuffles are what a scan
+    //      costs), each chunk processed in the step that holds its last sample.  Called one step LATE, in the shadow of
+    //      the next step's layer-2 weight copy (the exchange ring still holds the two steps a chunk can straddle).
+    auto composite_step = [&](uint32_t g) {
+        uint32_t gs, ge, qa, P;
+        step_geometry(g, gs, ge, qa, P);
+        for (uint32_t piece2 = wave; piece2 < P; piece2 += MLP_BLOCK / 64) {
+        const uint32_t qq = qa + piece2;
+        const uint32_t ray_start = qq * S, ray_end = ray_start + S;
+        uint32_t k = gs > ray_start ? (gs - ray_start) / RP_GROUP : 0;   // chunks 0 .. k-1 were completed by earlier steps
+        RayState st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        if (k > 0) st = open[(g + 1) & 1];       // the one ray that continues from the previous step
+        bool done = false, any = false;
+        for (;; ++k) {
+            const uint32_t cb = ray_start + RP_GROUP * k;
+            const uint32_t ce = cb + RP_GROUP < ray_end ? cb + RP_GROUP : ray_end;
+            if (ce - 1 >= ge) break;             // completed by a later step
+            float dd[4], w[4];
+            uint32_t li[4];
+            bool ok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t idx = cb + 4u * (uint32_t)lane + (uint32_t)i;
+                ok[i] = idx < ce;
+                li[i] = (ok[i] ? idx : ce - 1) & (RP_RING - 1);
+                dd[i] = ok[i] ? c_dd[li[i]] : 0.f;
+            }
+            const float p1 = dd[0], p2 = p1 + dd[1], p3 = p2 + dd[2], tot = p3 + dd[3];
+            float inc = tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+            }
+            const float ex0 = st.carry + (inc - tot);
+            const float excl[4] = {ex0, ex0 + p1, ex0 + p2, ex0 + p3};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float wi = (1.0f - expf(-dd[i])) * expf(-excl[i]);
+                if (!(wi == wi) || !ok[i]) wi = 0.f;   // nan_to_num
+                w[i] = wi;
+                if (p.out_weights && ok[i]) p.out_weights[(q0 + qq) * S + (cb - ray_start) + 4u * (uint32_t)lane + (uint32_t)i] = wi;
+            }
+            if constexpr (!DENSITY_ONLY) {
+                float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { l0 += w[i] * c_rgb[li[i]]; l1 += w[i] * c_rgb[RP_RING + li[i]]; l2 += w[i] * c_rgb[2 * RP_RING + li[i]]; }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { l0 += __shfl_xor(l0, off); l1 += __shfl_xor(l1, off); l2 += __shfl_xor(l2, off); }
+                st.r0 += l0; st.r1 += l1; st.r2 += l2;
+            }
+            const float c1 = w[0], c2 = c1 + w[1], c3 = c2 + w[2], wtot = c3 + w[3];
+            float winc = wtot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float o = __shfl_up(winc, off);
+                if (lane >= off) winc += o;
+            }
+            const float cum0 = st.acc + (winc - wtot);
+            const float cum[4] = {cum0 + c1, cum0 + c2, cum0 + c3, cum0 + wtot};
+            // median depth: the first sample whose cumulative weight reaches 0.5
+            float mymid = 0.f;
+            bool mine = false;
+#pragma unroll
+            for (int i = 3; i >= 0; --i)
+                if (ok[i] && cum[i] >= 0.5f) { mine = true; mymid = c_mid[li[i]]; }
+            const uint64_t m = __ballot(mine);
+            if (!st.found && m) {
+                const int src = __ffsll((unsigned long long)m) - 1;
+                st.depth = __shfl(mymid, src);
+                st.found = 1u;
+            }
+            st.carry += __shfl(inc, 63);
+            st.acc += __shfl(winc, 63);
+            any = true;
+            if (ce == ray_end) { done = true; break; }
+        }
+        if (done) {
+            if (!DENSITY_ONLY && p.out_rgb && lane == 0) {
+                const size_t ray = p.ray_index[q0 + qq];
+                if (!st.found) st.depth = c_mid[(ray_end - 1) & (RP_RING - 1)];   // searchsorted clamps to the last sample
+                p.out_rgb[3 * ray] = st.r0 + p.background * (1.0f - st.acc);
+                p.out_rgb[3 * ray + 1] = st.r1 + p.background * (1.0f - st.acc);
+                p.out_rgb[3 * ray + 2] = st.r2 + p.background * (1.0f - st.acc);
+                p.out_acc[ray] = st.acc;
+                p.out_depth[ray] = st.depth;
+            }
+        } else if (any && lane == 0) {
+            open[g & 1] = st;
+        }
+    }
     };
 
     Matched cur, nxt;
@@ -207,6 +352,11 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
             }
         }
         stage_wait();
+        // (every stage_wait drains the wave's outstanding loads, so the loads of the NEXT step's match are issued right
+        //  after one and consumed a whole MFMA layer later)
+        SegLoad sgl;
+        sgl.on = false; sgl.ray = 0; sgl.n = 0;
+        if (more) seg_issue_count(g + 1, sgl, nxt);
         {
             f32x16 acc[OT];
             zero_acc(acc);
@@ -216,7 +366,9 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
         }
         __syncthreads();
         stage_weights(lds, p.pk + OFF_W2, lfloats(KSH, OT));
+        if (g > 0) composite_step(g - 1);        // LDS + shuffles only: rides with the weight copy
         stage_wait();
+        if (more) seg_issue_rows(sgl);
         {
             f32x16 acc[OT];
             zero_acc(acc);
@@ -224,10 +376,13 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
             bias_step<KSH, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);
         }
+        if (more) seg_store(sgl);                 // visible to everyone after the next barrier
         __syncthreads();
         stage_weights(lds, p.pk + OFF_W3, N_W3);
-        if (more) match_stage(g + 1, nxt);        // its loads ride with the weight copy
         stage_wait();
+        Pending pd;
+        pd.hit = false; pd.t_in = 0.f; pd.t_out = 1.f; pd.cur = 0.f; pd.q0f = pd.q1f = pd.q2f = make_float2(0.f, 0.f);
+        if (more) match_search(g + 1, nxt, pd);   // LDS search; the segment's record is in flight during layer 3
         {
             f32x16 acc[OT];
             zero_acc(acc);
@@ -245,12 +400,10 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
                 c_mid[li] = 0.5f * (e0 + e1);
             }
         }
-        Pending pd;
-        pd.hit = false; pd.t_in = 0.f; pd.t_out = 1.f; pd.cur = 0.f; pd.q0f = pd.q1f = pd.q2f = make_float2(0.f, 0.f);
+        if (more) match_finish(nxt, pd);
         if constexpr (!DENSITY_ONLY) {
             __syncthreads();
             stage_weights(lds, p.pk + OFF_WHEAD, N_WHEAD);
-            if (more) match_search(g + 1, nxt, pd);   // LDS search + record loads beside the weight copy
             stage_wait();
             {
                 f32x16 acc[OT];
@@ -278,77 +431,12 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
                 c_rgb[RP_RING + li] = 1.0f / (1.0f + expf(-c1));
                 c_rgb[2 * RP_RING + li] = 1.0f / (1.0f + expf(-c2));
             }
-        } else {
-            if (more) match_search(g + 1, nxt, pd);
-        }
-        if (more) match_finish(nxt, pd);
-        __syncthreads();
-        // ---- composite: one wavefront per ray of this step; ray-aligned chunks of 64 samples, each processed in the step
-        //      that holds its last sample (k_composite's arithmetic per chunk)
-        for (uint32_t piece2 = wave; piece2 < P; piece2 += MLP_BLOCK / 64) {
-            const uint32_t qq = qa + piece2;
-            const uint32_t ray_start = qq * S, ray_end = ray_start + S;
-            uint32_t k = gs > ray_start ? (gs - ray_start) / 64 : 0;   // chunks 0 .. k-1 were completed by earlier steps
-            RayState st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
-            if (k > 0) st = open[(g + 1) & 1];       // the one ray that continues from the previous step
-            bool done = false, any = false;
-            for (;; ++k) {
-                const uint32_t cb = ray_start + 64 * k;
-                const uint32_t ce = cb + 64 < ray_end ? cb + 64 : ray_end;
-                if (ce - 1 >= ge) break;             // completed by a later step
-                const uint32_t idx = cb + lane;
-                const bool ok = idx < ce;
-                const uint32_t li = (ok ? idx : ce - 1) & (RP_RING - 1);
-                const float dd = ok ? c_dd[li] : 0.f;
-                float inc = dd;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const float o = __shfl_up(inc, off);
-                    if (lane >= off) inc += o;
-                }
-                const float excl = st.carry + (inc - dd);
-                float w = (1.0f - expf(-dd)) * expf(-excl);
-                if (!(w == w) || !ok) w = 0.f;   // nan_to_num
-                if (p.out_weights && ok) p.out_weights[(q0 + qq) * S + (idx - ray_start)] = w;
-                float winc = w;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const float o = __shfl_up(winc, off);
-                    if (lane >= off) winc += o;
-                }
-                if constexpr (!DENSITY_ONLY) {
-                    float l0 = w * c_rgb[li], l1 = w * c_rgb[RP_RING + li], l2 = w * c_rgb[2 * RP_RING + li];
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) { l0 += __shfl_xor(l0, off); l1 += __shfl_xor(l1, off); l2 += __shfl_xor(l2, off); }
-                    st.r0 += l0; st.r1 += l1; st.r2 += l2;
-                }
-                const float cum = st.acc + winc;
-                const uint64_t m = __ballot(ok && cum >= 0.5f);
-                if (!st.found && m) {
-                    const int src = __ffsll((unsigned long long)m) - 1;
-                    st.depth = __shfl(c_mid[li], src);
-                    st.found = 1u;
-                }
-                st.carry += __shfl(inc, 63);
-                st.acc += __shfl(winc, 63);
-                any = true;
-                if (ce == ray_end) { done = true; break; }
-            }
-            if (done) {
-                if (!DENSITY_ONLY && p.out_rgb && lane == 0) {
-                    const size_t ray = p.ray_index[q0 + qq];
-                    if (!st.found) st.depth = c_mid[(ray_end - 1) & (RP_RING - 1)];   // searchsorted clamps to the last sample
-                    p.out_rgb[3 * ray] = st.r0 + p.background * (1.0f - st.acc);
-                    p.out_rgb[3 * ray + 1] = st.r1 + p.background * (1.0f - st.acc);
-                    p.out_rgb[3 * ray + 2] = st.r2 + p.background * (1.0f - st.acc);
-                    p.out_acc[ray] = st.acc;
-                    p.out_depth[ray] = st.depth;
-                }
-            } else if (any && lane == 0) {
-                open[g & 1] = st;
-            }
         }
         cur = nxt;
+    }
+    if (ngroups) {
+        __syncthreads();
+        composite_step(ngroups - 1);
     }
 }
 
@@ -358,32 +446,36 @@ void launch_render_pass(const uint32_t *num_visited, const float *dist, const fl
                         float *out_acc, float *out_depth, hipStream_t stream) {
     if (r == 0) return;
     if (S < 64) throw Error("render_pass needs at least 64 samples per ray");
-    if (M > 1024) throw Error("render_pass supports max_ray_triangles <= 1024");
+    if (M > 512) throw Error("render_pass supports max_ray_triangles <= 512");
     if ((size_t)S * ((r + 255) / 256 + 1) >= 0xFFFFFFFFull) throw Error("render_pass: too many samples per block");
     const bool density_only = dirs == nullptr;
     if (!density_only && !(out_rgb && out_acc && out_depth)) throw Error("render_pass: colour pass without output buffers");
     float *pk = nullptr, *enc = nullptr;
+    uint32_t *nvh = nullptr;
     TN_HIP(hipMallocAsync((void **)&pk, PACK_FLOATS * sizeof(float), stream));
+    TN_HIP(hipMallocAsync((void **)&nvh, r * sizeof(uint32_t), stream));
     launch_mlp_pack(w, pk, true, stream);
+    hipLaunchKernelGGL(k_gather_counts, dim3((unsigned)((r + 255) / 256)), dim3(256), 0, stream, r, ray_index, num_visited, nvh);
     if (!density_only) {
         TN_HIP(hipMallocAsync((void **)&enc, r * ENC_PAD * sizeof(float), stream));
         launch_dir_encoding(r, dirs, enc, stream);
     }
     RenderPassParams p{};
     p.num_visited = num_visited; p.dist = dist; p.bary = bary; p.verts = verts; p.ray_index = ray_index; p.edges = edges;
-    p.fieldT = fieldT; p.enc = enc; p.pk = pk; p.out_weights = out_weights; p.out_rgb = out_rgb; p.out_acc = out_acc;
+    p.nv_hit = nvh; p.fieldT = fieldT; p.enc = enc; p.pk = pk; p.out_weights = out_weights; p.out_rgb = out_rgb; p.out_acc = out_acc;
     p.out_depth = out_depth; p.r = r; p.S = S; p.M = M; p.background = background;
     auto smem_for = [](size_t m) { return (MAX_STAGE_FLOATS + 2 * (size_t)RP_PIECES * m + 8 + 5 * RP_RING) * sizeof(float) + 2 * sizeof(RayState); };
     const size_t smem = smem_for(M);
     static PerDeviceOnce lds_attr;
     lds_attr.run([&] {
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_pass<false>), smem_for(1024));
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_pass<true>), smem_for(1024));
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_pass<false>), smem_for(512));
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_pass<true>), smem_for(512));
     });
     const unsigned grid = (unsigned)(r < 256 ? r : 256);   // one 8-wave block per CU, each owns a range of rays
     if (density_only) hipLaunchKernelGGL(k_render_pass<true>, dim3(grid), dim3(MLP_BLOCK), smem, stream, p);
     else hipLaunchKernelGGL(k_render_pass<false>, dim3(grid), dim3(MLP_BLOCK), smem, stream, p);
     TN_HIP(hipFreeAsync(pk, stream));
+    TN_HIP(hipFreeAsync(nvh, stream));
     if (enc) TN_HIP(hipFreeAsync(enc, stream));
 }
 

@@ -306,13 +306,17 @@ __device__ void sort_hits(const WaveSmem &s, uint32_t nh, int lane) {
 
 // All faces of the mesh the ray (o, d) hits with 0 < t < 1e16, into the LDS hit arrays (unsorted).
 // Returns the number kept (<= cap; beyond cap the nearest are kept).
+// defer: on the first hit beyond `cap` stop the traversal (overflow = true) instead of keeping the nearest cap hits --
+// the caller hands the ray to a launch with larger LDS arrays
 __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, uint32_t cap, float ox, float oy, float oz,
-                                 float dx, float dy, float dz, unsigned long long *stats, int lane, bool &overflow) {
+                                 float dx, float dy, float dz, unsigned long long *stats, int lane, bool &overflow,
+                                 bool defer = false) {
     const RayPre rp = ray_pre(ox, oy, oz, dx, dy, dz);
     const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
     const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + bvh.scene_max);
         uint32_t nh = 0;      // hits stored (wave-uniform)
         overflow = false;
+        bool aborted = false; // wave-uniform
 
         // One leaf: 64 triangles against the ray, hits appended to the LDS hit arrays.
         auto test_leaf = [&](float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2,
@@ -330,6 +334,9 @@ __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, ui
                         s.key[slot] = k; s.hu[slot] = u; s.hv[slot] = v;
                     }
                     nh += c;
+                } else if (defer) {
+                    overflow = true;
+                    aborted = true;
                 } else {
                     overflow = true;
                     wave_sync();
@@ -370,7 +377,7 @@ __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, ui
             float cur[9], nxt[9];
             uint32_t cfid, nfid = TN_EMPTY;
             fetch(leaf_list[0], cur, cfid);
-            for (uint32_t i = 0; i < nleaf; ++i) {
+            for (uint32_t i = 0; i < nleaf && !aborted; ++i) {
                 if (i + 1 < nleaf) fetch(leaf_list[i + 1], nxt, nfid);
                 test_leaf(cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7], cur[8], cfid);
 #pragma unroll
@@ -384,7 +391,7 @@ __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, ui
         uint32_t sp = 1;      // stack of internal nodes (wave-uniform)
         if (lane == 0) s.stack[0] = 0u;  // root = internal node 0
         wave_sync();
-        while (sp > 0) {
+        while (sp > 0 && !aborted) {
             const uint32_t idx = s.stack[sp - 1];
             sp--;
             wave_sync();  // everyone has read the top before it can be overwritten
@@ -403,25 +410,35 @@ __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, ui
             sp += __popcll(mn);
             wave_sync();
         }
-        run_leaves();
+        if (!aborted) run_leaves();
+        wave_sync();
         return nh;
 }
 
 __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    WaveSmem s = carve(smem, p.M);
     const int lane = threadIdx.x;
     const uint32_t M = p.M;
-    const uint32_t cap = M - 1;  // at most M-1 hits are kept (optix_trace_rays.cu:312-315)
+    // LDS arrays of C <= M entries (lds_cap): a small batch is latency-bound and wants every ray resident at once -- at
+    // M = 512 the full arrays (14.8 KB) admit 11 wavefronts per CU, 256-entry arrays (8 KB) admit 20.  A ray with more
+    // than C - 1 hits is handed to the overflow list (a second launch with full arrays).
+    const uint32_t C = p.lds_cap && p.lds_cap < M ? p.lds_cap : M;
+    const bool defer = C < M;
+    WaveSmem s = carve(smem, C);
+    const uint32_t cap = C - 1;  // at most M-1 hits are kept (optix_trace_rays.cu:312-315)
 
     const size_t n_items = p.item_count ? (size_t)*p.item_count : p.num_items;
     for (size_t it = blockIdx.x; it < n_items; it += gridDim.x) {
         const size_t ray = p.ray_list ? (size_t)p.ray_list[it] : it;
         bool overflow = false;
-        uint32_t nh = collect_hits(p.bvh, s, M, cap, p.origins[3 * ray], p.origins[3 * ray + 1], p.origins[3 * ray + 2],
+        uint32_t nh = collect_hits(p.bvh, s, C, cap, p.origins[3 * ray], p.origins[3 * ray + 1], p.origins[3 * ray + 2],
                                    p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2],
                                    (p.gdebug & 8u) ? p.stats : nullptr /* visit counters: same-address atomics, debug only */,
-                                   lane, overflow);
+                                   lane, overflow, defer);
+        if (overflow && defer) {
+            if (lane == 0) p.overflow_list[atomicAdd(p.overflow_count, 1u)] = (uint32_t)ray;
+            continue;
+        }
         if (overflow && lane == 0 && p.stats) atomicAdd(&p.stats[3], 1ull);
 
         if (p.gdebug & 1u) nh = 0;
@@ -906,7 +923,7 @@ void launch_find_tetrahedra(const TraceParams &p, const float *points, uint32_t 
 
 void launch_trace_general(const TraceParams &p, hipStream_t stream) {
     if (p.num_items == 0) return;
-    const size_t smem = wave_smem(k_trace_general, p.M);
+    const size_t smem = wave_smem(k_trace_general, p.lds_cap && p.lds_cap < p.M ? p.lds_cap : p.M);
     const size_t max_blocks = 256 * 16;
     const unsigned grid = (unsigned)(p.num_items < max_blocks ? p.num_items : max_blocks);
     hipLaunchKernelGGL(k_trace_general, dim3(grid), dim3(64), smem, stream, p);

@@ -28,6 +28,7 @@ from typing import Dict, Optional
 import torch
 
 FIELD_DIM = 64
+FUSED_PASS_MAX_RAYS = 16384   # TetraRenderer(fused_pass="auto"): one launch per pass up to this many hitting rays
 HIDDEN = 128
 DIR_ENC = 27
 
@@ -290,7 +291,7 @@ class TetraRenderer:
 
     def __init__(self, tracer, field: torch.Tensor, mlp: TetraMLP, num_samples: int = 256,
                  max_ray_triangles: int = 512, fused: bool = True, far_plane: float = 1000.0,
-                 num_fine_samples: int = 0, biased: bool = False, dense_tails: bool = False, fused_pass: bool = True):
+                 num_fine_samples: int = 0, biased: bool = False, dense_tails: bool = False, fused_pass="auto"):
         from . import tetranerf_cpp_extension as cpp
 
         self.cpp = cpp
@@ -300,8 +301,15 @@ class TetraRenderer:
         # the render path only reads the trace rows through num_visited_cells, so the constant tails of the
         # dense reference layout need not be written (non-materialising trace: 52 B per segment, not 52*M per ray)
         self.dense_tails = bool(dense_tails)
-        # match + gather + MLP + composite of a pass as ONE launch (tn_render_pass) when its preconditions hold
-        self.fused_pass = bool(fused_pass) and self.S >= 64 and self.M <= 1024
+        # match + gather + MLP + composite of a pass as ONE launch (tn_render_pass) when its preconditions hold.
+        # True / False / "auto": measured (profiles/r02j_render_bench.txt) the one-launch pass ties with or beats the
+        # separate match / gather+MLP / composite kernels on nerfstudio-sized batches (4096 rays: launch-bound, and it
+        # moves no per-sample intermediates through HBM) and is 3-4 % slower on 65,536-ray chunks (the match and the
+        # composite then run inside an MFMA-bound kernel at 2 waves per SIMD instead of as cheap, fully parallel kernels
+        # of their own), so "auto" uses it up to FUSED_PASS_MAX_RAYS hitting rays per call.
+        self.fused_pass = fused_pass if fused_pass == "auto" else bool(fused_pass)
+        if not (self.S >= 64 and self.M <= 512):
+            self.fused_pass = False
 
     @torch.no_grad()
     def render(self, origins: torch.Tensor, directions: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -344,7 +352,7 @@ class TetraRenderer:
                 edges = biased_sample_bins(near_r, far_r, S, lists[0][idx], lists[3][idx]).contiguous()
             else:
                 edges = uniform_sample_bins(near_r, far_r, S).contiguous()
-            if self.fused_pass and cpp.mlp_get_mode() == "fp32":
+            if (self.fused_pass is True or (self.fused_pass == "auto" and idx.numel() <= FUSED_PASS_MAX_RAYS)) and cpp.mlp_get_mode() == "fp32":
                 # every pass is ONE launch: match + gather + MLP + composite (tn_render.hip); per sample only the coarse
                 # weights go through HBM; the finished rays are written straight into the frame buffers
                 if self.S_fine > 0:

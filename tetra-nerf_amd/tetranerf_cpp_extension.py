@@ -478,7 +478,7 @@ def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, b
     _check(ray_index.dtype == torch.int32 and ray_index.dim() == 1, "ray_index must be i32 [r]")
     r, S = ray_index.numel(), edges.size(-1) - 1
     _check(edges.dtype == torch.float32 and tuple(edges.shape) == (r, S + 1), "edges must be f32 [r, S+1]")
-    _check(S >= 64 and M <= 1024, "render_pass needs S >= 64 samples per ray and max_ray_triangles <= 1024")
+    _check(S >= 64 and M <= 512, "render_pass needs S >= 64 samples per ray and max_ray_triangles <= 512")
     _check(field.dtype == torch.float32 and field.dim() == 2 and field.size(0) == 64, "field must be f32 [64, V]")
     st, keep = _weights_struct(weights)
     dev = field.device
