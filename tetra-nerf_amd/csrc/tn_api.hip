@@ -29,7 +29,11 @@ struct tn_tracer {
     tn::DevBuf<uint32_t> faces, face_tets, fallback_list, walk_n;
     tn::DevBuf<uint2> literal_list;      // rays whose logged hits go through the literal sort + pairing
     tn::DevBuf<uint4> hit_log;           // walk -> segment writer / literal pairing: 16 B per recorded hit, [rays / 64][M][64]
-    size_t log_cap_bytes = (size_t)16 << 30;  // larger calls are walked + written in ray chunks
+    tn::DevBuf<uint4> hit_log_v;         // "fat log": + the vertex ids of the tet a hit closes (16 B) and its tet id | combine code (4 B),
+    tn::DevBuf<uint32_t> hit_log_o;      //   so that the segment writer reads no walk records (random 64-B lines of a 26..258 MB table)
+    bool fat_log = false;                // option log_records: bit-identical, measured 3-15 % slower per frame (the walk stores 36 B per step
+                                         // instead of 16 and runs 7 instead of 8 waves per SIMD: profiles/r02l_fatlog.txt), off
+    size_t log_cap_bytes = (size_t)24 << 30;  // larger calls are walked + written in ray chunks
     bool literal = true;                 // false: rays with uncertified order are re-traced through the BVH instead (ablation)
     bool literal_rows = true;            // true (default): one wavefront sorts, pairs and WRITES the row of a literal ray, on the side
                                          // stream beside the tail fill; false: k_literal_mask turns the ray into a segment-writer ray
@@ -340,12 +344,15 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); }
             const bool use_mask = t->literal && !t->literal_rows && !t->prefill && M >= 32 && M <= 512;
             if (use_mask && t->emit_mask.n < R * (size_t)(M / 32)) t->emit_mask.alloc(R * (size_t)(M / 32));
-            size_t chunk = t->log_cap_bytes / ((size_t)M * sizeof(uint4));
+            const bool fat = t->fat_log && t->mesh.T < (1u << 26);   // tet id and the 6 combine bits share a dword
+            const size_t entry_bytes = fat ? 36 : 16;
+            size_t chunk = t->log_cap_bytes / ((size_t)M * entry_bytes);
             chunk = chunk / 4096 * 4096;
             if (chunk < 4096) chunk = 4096;
             if (chunk > R) chunk = R;
             const size_t log_entries = (chunk + 255) / 256 * 256 * (size_t)M;
             if (t->hit_log.n < log_entries) t->hit_log.alloc(log_entries);
+            if (fat && t->hit_log_v.n < log_entries) { t->hit_log_v.alloc(log_entries); t->hit_log_o.alloc(log_entries); }
             const bool single = chunk >= R;
             auto chunk_params = [&](size_t base, size_t n) {
                 return make_params(t, n, M, origins + 3 * base, directions + 3 * base, num_visited + base, visited + base * M,
@@ -366,6 +373,8 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 w.kmax = t->kmax();
                 w.walk_n = t->walk_n.p + base;
                 w.hit_log = t->hit_log.p + (log_base / 64) * (size_t)M * 64;
+                w.hit_log_v = fat ? t->hit_log_v.p + (log_base / 64) * (size_t)M * 64 : nullptr;
+                w.hit_log_o = fat ? t->hit_log_o.p + (log_base / 64) * (size_t)M * 64 : nullptr;
                 w.ray_base = base;
                 w.lit_base = (uint32_t)log_base;
                 w.debug = t->debug;
@@ -378,6 +387,8 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 q.walk_n = t->walk_n.p + base;
                 q.emit_mask = use_mask ? t->emit_mask.p + base * (size_t)(M / 32) : nullptr;
                 q.hit_log = t->hit_log.p + (log_base / 64) * (size_t)M * 64;
+                q.hit_log_v = fat ? t->hit_log_v.p + (log_base / 64) * (size_t)M * 64 : nullptr;
+                q.hit_log_o = fat ? t->hit_log_o.p + (log_base / 64) * (size_t)M * 64 : nullptr;
                 q.vars = t->mesh.vars;
                 q.out_cells = visited + base * M;
                 q.out_bary = bary + base * M * 6;
@@ -635,6 +646,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && (std::strcmp(name, "rewalk") == 0 || std::strcmp(name, "rewalk_min") == 0)) {}  // round-1 knobs: no effect
         else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
         else if (name && std::strcmp(name, "seg_blocks") == 0) t->seg_blocks = (unsigned)value;
+        else if (name && std::strcmp(name, "log_records") == 0) t->fat_log = value != 0;
         else if (name && std::strcmp(name, "small_lds") == 0) t->small_lds = value != 0;
         else if (name && std::strcmp(name, "side_late") == 0) t->side_late = value != 0;
         else if (name && std::strcmp(name, "aux_general") == 0) t->aux_general = value != 0;
@@ -669,6 +681,8 @@ int tn_probe_write_segments(tn_tracer_t tracer, uint32_t M, uint32_t *visited, f
         q.num_rays = t->last_num_rays; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
         q.unroll = t->seg_unroll; q.variant = t->seg_variant; q.ablate = (uint32_t)ablate;
         q.walk_n = t->walk_n.p; q.emit_mask = t->emit_mask.p; q.hit_log = t->hit_log.p; q.vars = t->mesh.vars;
+        const bool fat = t->fat_log && t->mesh.T < (1u << 26) && t->hit_log_v.n >= t->hit_log.n && t->hit_log_v.n;
+        q.hit_log_v = fat ? t->hit_log_v.p : nullptr; q.hit_log_o = fat ? t->hit_log_o.p : nullptr;
         q.out_cells = visited; q.out_bary = bary; q.out_dist = dist; q.out_verts = verts;
         tn::launch_write_segments(q, (hipStream_t)stream, (unsigned)blocks);
         TN_HIP(hipGetLastError());

@@ -54,6 +54,8 @@ struct WalkParams {
                                // ((r / 64) * M + k) * 64 + r % 64 (a wave's 64 lanes store 1 KB of consecutive bytes per
                                // step); exit code 3 = entry hull face, its face id in the low 30 bits
     uint32_t lit_base;         // added to the launch-local ray index stored in literal_list (= the launch's first row of the log)
+    uint4 *hit_log_v;          // optional ("fat log"): vertex ids (n, a, b, c) of the tet hit k closes, same indexing
+    uint32_t *hit_log_o;       //   and its tet id | combine code << 26 -- the segment writer then never reads the records
     size_t ray_base;           // global index of item 0 (rays are traced in chunks when the log would be too large)
     uint32_t debug;            // block->XCD mapping ablation (profiles/): 4 = no remap, 8 = one contiguous band per XCD
 };
@@ -84,6 +86,8 @@ struct WriteParams {
     const uint32_t *walk_n;    // hits in the log | LITERAL_MASK_FLAG (segments = the set bits of emit_mask, not the eps rule)
     const uint32_t *emit_mask; // [num_rays][M / 32] or null
     const uint4 *hit_log;
+    const uint4 *hit_log_v;    // fat log (or null): see WalkParams
+    const uint32_t *hit_log_o;
     const WalkVar *vars;
     uint32_t *out_cells;
     float *out_bary;

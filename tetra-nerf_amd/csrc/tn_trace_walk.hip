@@ -104,7 +104,9 @@ __device__ __forceinline__ float sel4f(float a, float b, float c, float d, uint3
 // needed by the segment writer), as SCALARS: with the neighbours / face ids kept in a uint4 the optimiser turns the select
 // chain below into a dynamically indexed vector, parks the record in LDS and reads `nb` back with a ds_read -- an
 // LDS round trip on the one dependent chain of the walk (record -> exit -> next record).
-struct Var { float px, py, pz; uint32_t nb0, nb1, nb2, code_hi, f0, f1, f2, code_lo; };
+struct Var { float px, py, pz; uint32_t nb0, nb1, nb2, code_hi, f0, f1, f2, code_lo, orig; };
+// (FAT walks also log the tet id, the combine code and -- quad 3, requested at the top of the step -- the vertex ids)
+template <bool FAT>
 __device__ __forceinline__ Var load_var(const WalkVar *vars, uint32_t c) {
     const uint32_t *r = reinterpret_cast<const uint32_t *>(vars + c);
     const float4 q0 = *reinterpret_cast<const float4 *>(r);
@@ -112,7 +114,7 @@ __device__ __forceinline__ Var load_var(const WalkVar *vars, uint32_t c) {
     Var v;
     v.px = q0.x; v.py = q0.y; v.pz = q0.z; v.f0 = __float_as_uint(q0.w);
     v.nb0 = q1.x; v.nb1 = q1.y; v.nb2 = q1.z; v.f1 = q1.w;
-    v.code_lo = q2.y; v.code_hi = q2.z; v.f2 = q2.w;
+    v.orig = q2.x; v.code_lo = q2.y; v.code_hi = q2.z; v.f2 = q2.w;
     return v;
 }
 __device__ __forceinline__ uint32_t sel3u(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t i) {  // i in 0..2 (3 -> v2)
@@ -132,6 +134,7 @@ __device__ __forceinline__ SV selsv(const SV &p0, const SV &p1, const SV &p2, co
 // or recomputed, one vertex is sheared per step, three edge functions against it decide the exit, and the exit
 // face's edge functions are evaluated directly in its stored order (E(P,Q) == -E(Q,P) bitwise, so they equal the
 // shared ones): bit-identical hits for 30 % fewer instructions than a per-tet record with dynamic selects.
+template <bool FAT>
 __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     const TraceParams &t = p.t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -214,7 +217,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     // Every recorded (valid) hit k of this ray is one 16-byte entry of the hit log, at
     // log[(wave of 64 rays) * M + k][lane]: the lanes of a wave store consecutive bytes.
     const size_t gw = (size_t)lb * (WALK_BLOCK / 64) + (size_t)wave;
-    uint4 *mylog = p.hit_log + gw * (size_t)M * 64 + (size_t)lane;
+    const size_t logoff = gw * (size_t)M * 64 + (size_t)lane;   // same index into the three log arrays (bases stay scalar)
+    uint4 *mylog = p.hit_log + logoff;
 
     bool alive = nhull == 2 && !flag;
     const bool first0 = ht0 < ht1;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     uint32_t fid_prev = f_in0;  // face id of the previous recorded hit (ties are ordered by id)
     uint32_t nhits = 0, nshort = 0;
     uint32_t steps = 0;
-    Var cur = load_var(p.vars, c);
+    Var cur = load_var<FAT>(p.vars, c);
     if (alive) {
         // the entry hull face itself may be the first recorded hit (exit code 3 = "hull face id in the low bits")
         float tt, uu, vv;
@@ -255,6 +259,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         // All checks of a step accumulate into `bad` (first reason kept), straight-line: as nested ifs the checks
         // became a dozen exec-masked branches per step.
         uint32_t bad = 0;
+        uint4 myvid = make_uint4(0u, 0u, 0u, 0u);   // vertex ids of this tet: wanted at the end of the step (log)
+        if constexpr (FAT) myvid = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(p.vars + c) + 12);
         const SV P = shear(rp, cur.px, cur.py, cur.pz);
         const float ea = edge_f(P, A), eb = edge_f(P, B), ec = edge_f(P, C);
         bad = (fabsf(P.x) + fabsf(P.y) < pad) ? 4u : bad;                  // vertex within rounding distance of the ray
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         const uint32_t fx = sel3u(cur.f0, cur.f1, cur.f2, x);        // id of the exit face
         const bool last = nb == TN_EMPTY;
         // the next record is requested as soon as the exit is known
-        const Var nxt = load_var(p.vars, (last || bad) ? c : nb);
+        const Var nxt = load_var<FAT>(p.vars, (last || bad) ? c : nb);
         __builtin_amdgcn_sched_barrier(0);
 
         // the exit face in its stored order: 12-bit code of exit x out of the 36-bit word
@@ -308,6 +314,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         if (valid && nhits < M - 1) {
             // hit `nhits` of this ray: (t, u, v) in the face's stored order + the tet it closes (variant, exit)
             mylog[(size_t)nhits * 64] = make_uint4(__float_as_uint(ct), __float_as_uint(cu), __float_as_uint(cv), c | (x << 30));
+            if constexpr (FAT) {   // what the segment writer needs of record c: it then never touches the records
+                p.hit_log_v[logoff + (size_t)nhits * 64] = myvid;
+                p.hit_log_o[logoff + (size_t)nhits * 64] = cur.orig | ((code >> 6) << 26);
+            }
         }
         nhits += valid ? 1u : 0u;
         have_pp = valid ? have_prev : have_pp;
@@ -392,6 +402,7 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
         const size_t r0 = 8 * g;
         return q.hit_log + (r0 >> 6) * (size_t)M * 64 + (r0 & 63) + a;
     };
+    const bool fat = q.hit_log_v != nullptr;   // the walk logged the tet id / vertex ids / combine code of every hit
     auto load_entries = [&](uint4 (&e)[U], const uint4 *lg, uint32_t nh, uint32_t c0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -464,10 +475,19 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
             for (int u = 0; u < U; ++u) {
                 orig[u] = 0; chi[u] = 0; clo[u] = 0; vid[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (slot[u] != TN_EMPTY && !(q.ablate & 1u)) {
-                    const uint32_t *rec = reinterpret_cast<const uint32_t *>(q.vars + (e[u].w & 0x3FFFFFFFu));
-                    const uint4 q2 = *reinterpret_cast<const uint4 *>(rec + 8);
-                    orig[u] = q2.x; clo[u] = q2.y; chi[u] = q2.z;
-                    vid[u] = *reinterpret_cast<const uint4 *>(rec + 12);
+                    if (fat) {
+                        const size_t at = (size_t)(lg - q.hit_log) + (size_t)(c0 + 8 * u + h) * 64;
+                        const uint32_t o = q.hit_log_o[at];
+                        vid[u] = q.hit_log_v[at];
+                        orig[u] = o & 0x03FFFFFFu;
+                        clo[u] = (o >> 26) << (6 + 12 * (e[u].w >> 30));   // the 6 combine bits where the decode below looks for them
+                        chi[u] = (e[u].w >> 30) == 2u ? ((o >> 26) >> 2) : 0u;
+                    } else {
+                        const uint32_t *rec = reinterpret_cast<const uint32_t *>(q.vars + (e[u].w & 0x3FFFFFFFu));
+                        const uint4 q2 = *reinterpret_cast<const uint4 *>(rec + 8);
+                        orig[u] = q2.x; clo[u] = q2.y; chi[u] = q2.z;
+                        vid[u] = *reinterpret_cast<const uint4 *>(rec + 12);
+                    }
                 }
             }
 #pragma unroll
@@ -559,6 +579,7 @@ __global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
         const size_t r0 = 8 * g;
         return q.hit_log + (r0 >> 6) * (size_t)M * 64 + (r0 & 63) + a;
     };
+    const bool fat = q.hit_log_v != nullptr;   // the walk logged the tet id / vertex ids / combine code of every hit
     auto load_entries = [&](uint4 (&e)[U], const uint4 *lg, uint32_t nh, uint32_t c0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -632,9 +653,18 @@ __global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
                 for (int u = 0; u < U; ++u) {
                     qa[u] = make_uint4(0u, 0u, 0u, 0u); qv[u] = qa[u];
                     if (slot[u] != TN_EMPTY) {
-                        const uint32_t *rec = reinterpret_cast<const uint32_t *>(q.vars + (e[u].w & 0x3FFFFFFFu));
-                        qa[u] = *reinterpret_cast<const uint4 *>(rec + 8);
-                        qv[u] = *reinterpret_cast<const uint4 *>(rec + 12);
+                        if (fat) {
+                            const size_t at = (size_t)(lg - q.hit_log) + (size_t)(c0 + 8 * u + h) * 64;
+                            const uint32_t o = q.hit_log_o[at];
+                            qv[u] = q.hit_log_v[at];
+                            const uint32_t x = e[u].w >> 30, kc = o >> 26;
+                            // tet id, and the 6 combine bits placed where the decode below looks for them
+                            qa[u] = make_uint4(o & 0x03FFFFFFu, kc << (6 + 12 * x), x == 2u ? (kc >> 2) : 0u, 0u);
+                        } else {
+                            const uint32_t *rec = reinterpret_cast<const uint32_t *>(q.vars + (e[u].w & 0x3FFFFFFFu));
+                            qa[u] = *reinterpret_cast<const uint4 *>(rec + 8);
+                            qv[u] = *reinterpret_cast<const uint4 *>(rec + 12);
+                        }
                     }
                 }
                 // ---- segment records -> LDS [array][ray][slot]
@@ -803,7 +833,8 @@ void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
     // grid padded so that both remaps (runs of XCD_GROUP blocks / one band per XCD) are bijections
     const uint32_t unit = 8 * ((p.debug & 8u) ? (nblk + 7) / 8 : XCD_GROUP);
     const uint32_t grid = (nblk + unit - 1) / unit * unit;
-    hipLaunchKernelGGL(k_trace_walk, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
+    if (p.hit_log_v) hipLaunchKernelGGL(k_trace_walk<true>, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
+    else hipLaunchKernelGGL(k_trace_walk<false>, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
 }
 
 }  // namespace tn
