@@ -206,8 +206,15 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *             literally; 0 = they are re-traced through the BVH all-hits path (ablation / cross-check)
  *   "prefill" 1 = the tail slots no certified ray reaches are streamed beside the segment writer (default 0:
  *             measured slower, the latency-bound segment writer crawls beside a saturating fill)
- *   "log_cap_mb"  cap of the hit log (default 16384): larger calls are processed in ray chunks
- *   "fill_blocks", "seg_blocks", "debug", "gdebug": ablation knobs (profiles/) */
+ *   "log_cap_mb"  cap of the hit log (default 24576): larger calls are processed in ray chunks
+ *   "gpu_build"  1 (default) = load_tetrahedra builds its structures on the device; 0 = single-threaded host build
+ *   "small_lds"  1 (default) = batches below walk_min_rays use LDS hit arrays sized for the mesh (every ray resident at
+ *             once) and re-trace the rays with more hits in a second launch; "lds_cap" forces their size (tests)
+ *   measured and left off (all bit-identical; profiles/r02b..r02l): "literal_rows" 0 = literal pairing as an emit mask
+ *             for the segment writer; "log_records" 1 = the walk also logs the record fields the writer needs;
+ *             "pipe" N = walk / writer pipelined over N ray chunks; "seg_variant" 0 = direct (not LDS-staged) segment
+ *             stores; "side_late" 0 / "aux_general" 0 = round 2a's side-stream schedule
+ *   "fill_blocks", "seg_blocks", "seg_unroll", "debug", "gdebug": ablation knobs (profiles/) */
 int tn_set_option(tn_tracer_t tracer, const char *name, int value);
 
 /* gather_uint32<T> / scatter_ema_uint32<T>              src/tetrahedra_tracer.cu:30-113,

@@ -276,3 +276,27 @@ def test_errors(tn, device, scenes):
     out.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
     res = out.trace_rays(torch.zeros((0, 3), device=device), torch.zeros((0, 3), device=device), 16)
     assert res["visited_cells"].shape == (0, 16)
+
+
+def test_small_batch_overflow_relaunch(tn, device, oracle, scenes):
+    """Small batches run the BVH path with LDS hit arrays sized for the mesh; a ray with more hits than they hold stops
+    its traversal and is re-traced by a second launch with the full M-entry arrays.  Forcing tiny arrays (option
+    lds_cap) sends most rays through that second launch: same bits as the one-launch path and as the oracle."""
+    import torch
+
+    pts, cells = scenes.random_mesh(6000, 21)
+    o, d = scenes.outside_in_rays(3000, 22)
+    tr = _gpu_tracer(tn, device, pts, cells, walk=0)
+    ot = oracle.OracleTracer(use_bvh=True)
+    ot.load_tetrahedra(pts, cells)
+    want = ot.trace_rays(o, d, 256)
+    tr.set_option("small_lds", 0)
+    ref = _trace(tr, device, o, d, 256)
+    _assert_same(ref, want, "full arrays")
+    tr.set_option("small_lds", 1)
+    for cap in (0, 128, 32, 8):
+        tr.set_option("lds_cap", cap)
+        got = _trace(tr, device, o, d, 256)
+        _assert_same(got, want, f"lds_cap {cap}")
+    assert int(want["num_visited_cells"].max()) > 40     # caps 32 and 8 really overflow
+    tr.set_option("lds_cap", 0)

@@ -47,6 +47,7 @@ struct tn_tracer {
     hipStream_t writer = nullptr;        // pipelined mode: the segment writer of chunk i runs beside the walk of chunk i + 1
     hipEvent_t ev_chunk[8] = {}, ev_writer = nullptr;
     bool small_lds = true;               // small batches: LDS hit arrays sized for the mesh, overflow rays in a second launch
+    unsigned lds_cap = 0;                // 0: from the mesh size; otherwise the entries of the small arrays (power of two; tests)
     bool side_late = true;               // literal pairing starts after the segment writer (beside the fill), not beside it
     bool aux_general = true;             // BVH fallback rays on a third stream (forked right after the walk)
     unsigned pipe = 1;                   // ray chunks of the walk -> writer pipeline (1 = one walk, then one writer)
@@ -496,6 +497,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             uint32_t C = 64;
             const double expect = 3.6 * std::cbrt((double)std::max<uint32_t>(t->mesh.T, 1u));
             while (C < expect && C < M) C <<= 1;
+            if (t->lds_cap) C = t->lds_cap;
             if (t->small_lds && C < M) {
                 if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); }
                 tn::TraceParams p1 = p;
@@ -648,6 +650,10 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && std::strcmp(name, "seg_blocks") == 0) t->seg_blocks = (unsigned)value;
         else if (name && std::strcmp(name, "log_records") == 0) t->fat_log = value != 0;
         else if (name && std::strcmp(name, "small_lds") == 0) t->small_lds = value != 0;
+        else if (name && std::strcmp(name, "lds_cap") == 0) {
+            if (value < 0 || (value & (value - 1)) != 0 || (value && value < 8)) throw tn::Error("lds_cap must be 0 or a power of two >= 8");
+            t->lds_cap = (unsigned)value;
+        }
         else if (name && std::strcmp(name, "side_late") == 0) t->side_late = value != 0;
         else if (name && std::strcmp(name, "aux_general") == 0) t->aux_general = value != 0;
         else if (name && std::strcmp(name, "pipe") == 0) t->pipe = value < 1 ? 1u : (value > 8 ? 8u : (unsigned)value);
