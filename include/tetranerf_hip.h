@@ -277,6 +277,9 @@ int tn_render_pass(uint32_t max_ray_triangles, const uint32_t *num_visited, cons
  *                parity tests run in both modes) at 2.67x fewer matrix-core cycles. */
 int tn_mlp_set_mode(int mode);
 int tn_mlp_get_mode(void);
+/* shape of the fp32 forward kernel (process-wide; ablation): 0 / 512 = one 8-wave block per CU (default), 256 = two
+ * 4-wave blocks per CU (head layer staged in two halves): same arithmetic, same results, measured neutral */
+int tn_mlp_set_block(int block);
 
 /* RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers.
  * sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1] (bin edges: starts = edges[:, :-1], ends = edges[:, 1:]);

@@ -773,6 +773,10 @@ int tn_mlp_set_mode(int mode) {
     });
 }
 
+int tn_mlp_set_block(int block) {
+    return guarded([&] { tn::mlp_set_block(block); });
+}
+
 int tn_mlp_get_mode(void) { return g_mlp_mode.load(); }
 
 int tn_mlp_forward(size_t n, uint32_t samples_per_ray, const float *feats, const float *dirs,

@@ -162,6 +162,7 @@ void launch_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, co
 // adjoint of launch_composite: d sigma [R,S], d rgb [R,S,3] from the gradients of the rendered rgb / accumulation
 void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
                                const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb, hipStream_t stream);
+void mlp_set_block(int b);   // forward kernel shape: 0 auto, 256 = 4-wave blocks (two per CU), 512 = 8-wave blocks (tn_mlp.hip)
 void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols, hipStream_t stream);
 // one render pass as one launch (tn_render.hip): match -> gather -> MLP -> composite on the trace rows of the hitting
 // rays (ray_index [r]) from the bin edges [r, S + 1]; dirs == nullptr: density only, out_weights [r, S] written;

@@ -27,6 +27,9 @@ namespace tn {
 
 using namespace mlp;
 
+static int g_mlp_block = 0;   // 0 auto, 256, 512 (tn_mlp_set_block: ablation)
+void mlp_set_block(int b) { g_mlp_block = (b == 256 || b == 512) ? b : 0; }
+
 namespace {
 
 __global__ void k_mlp_pack(MlpWeights w, float *__restrict__ pk, int gather_l1) {
@@ -92,8 +95,11 @@ __global__ void k_dir_encoding(size_t R, const float *__restrict__ dirs, float *
 
 }  // namespace
 
-template <bool GATHER, bool DENSITY_ONLY>
-__global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t samples_per_ray, const float *__restrict__ feats,
+// BLOCK = 512: 8 waves share each staged layer, one block per CU.  BLOCK = 256: 4 waves per block and TWO blocks per CU
+// (the head layer staged in two halves so that the largest stage is 67 KB): while one block waits for a weight copy or
+// at a barrier the other one's waves keep the matrix cores busy.
+template <bool GATHER, bool DENSITY_ONLY, int BLOCK = MLP_BLOCK>
+__global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t samples_per_ray, const float *__restrict__ feats,
                                                            const uint32_t *__restrict__ vi, const float *__restrict__ bc,
                                                            const float *__restrict__ fieldT,
                                                            const float *__restrict__ enc, const float *__restrict__ pk,
@@ -101,7 +107,8 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t sa
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    constexpr size_t GROUP = (MLP_BLOCK / 64) * 32;
+    constexpr size_t GROUP = (BLOCK / 64) * 32;
+    constexpr bool SPLIT_HEAD = BLOCK < MLP_BLOCK;
     const size_t ngroups = (n + GROUP - 1) / GROUP;
 
     for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t sa
 
         // ---- layer 1: 64 -> 128, B operands straight from the feature-major input [64, n]
         __syncthreads();
-        stage_weights(lds, pk + OFF_W1, lfloats(KS1, OT));
+        stage_weights<BLOCK>(lds, pk + OFF_W1, lfloats(KS1, OT));
         if constexpr (!GATHER) {
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) bin[ks] = feats[(size_t)(2 * ks + h) * n + sc];
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t sa
         }
         // ---- layers 2, 3: 128 -> 128, accumulators fed back as B operands
         __syncthreads();
-        stage_weights(lds, pk + OFF_W2, lfloats(KSH, OT));
+        stage_weights<BLOCK>(lds, pk + OFF_W2, lfloats(KSH, OT));
         stage_wait();
         {
             f32x16 acc[OT];
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t sa
             relu_to_bin(acc, bin);
         }
         __syncthreads();
-        stage_weights(lds, pk + OFF_W3, N_W3);
+        stage_weights<BLOCK>(lds, pk + OFF_W3, N_W3);
         stage_wait();
         {
             f32x16 acc[OT];
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t sa
         if constexpr (DENSITY_ONLY) continue;  // coarse pass of the model (model.py:577-581)
         // ---- head [enc(27) | base(128)] -> 128 ReLU
         __syncthreads();
-        stage_weights(lds, pk + OFF_WHEAD, N_WHEAD);
+        stage_weights<BLOCK>(lds, pk + OFF_WHEAD, SPLIT_HEAD ? N_WHEAD_A : N_WHEAD);
         stage_wait();
         {
             f32x16 acc[OT];
@@ -192,13 +199,23 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_forward(size_t n, uint32_t sa
                 for (int t = 0; t < OT; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], b, acc[t], 0, 0, 0);
             }
-            gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
-            bias_step<HEAD_KS, OT>(acc, lds, lane);
+            if constexpr (SPLIT_HEAD) {
+                constexpr int KA = HEAD_KS_A - KSE;          // base k-steps in the first half
+                gemm_steps<KA, KSE, OT>(acc, bin, lds, lane);
+                __syncthreads();
+                stage_weights<BLOCK>(lds, pk + OFF_WHEAD + N_WHEAD_A, N_WHEAD_B);
+                stage_wait();
+                gemm_steps<KSH - KA, 0, OT, KA>(acc, bin, lds, lane);
+                bias_step<KSH - KA, OT>(acc, lds, lane);
+            } else {
+                gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
+                bias_step<HEAD_KS, OT>(acc, lds, lane);
+            }
             relu_to_bin(acc, bin);
         }
         {
             // rgb head 128 -> 3 + sigmoid on the VALU
-            const float *cv = lds + lfloats(HEAD_KS, OT);
+            const float *cv = lds + (SPLIT_HEAD ? lfloats(KSH - (HEAD_KS_A - KSE), OT) : lfloats(HEAD_KS, OT));
             const float c0 = head_dot(cv + 64 * h, bin) + cv[384];
             const float c1 = head_dot(cv + 128 + 64 * h, bin) + cv[385];
             const float c2 = head_dot(cv + 256 + 64 * h, bin) + cv[386];
@@ -278,6 +295,7 @@ __global__ __launch_bounds__(64) void k_composite(size_t R, uint32_t S, const fl
 
 size_t mlp_pack_floats() { return PACK_FLOATS; }
 
+
 void launch_mlp_pack(const MlpWeights &w, float *pk, bool gather_l1, hipStream_t stream) {
     hipLaunchKernelGGL(k_mlp_pack, dim3((unsigned)((PACK_FLOATS + 255) / 256)), dim3(256), 0, stream, w, pk, gather_l1 ? 1 : 0);
 }
@@ -304,20 +322,36 @@ void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, con
         TN_HIP(hipMallocAsync((void **)&fieldT, (size_t)num_vertices * FD * sizeof(float), stream));
         launch_transpose(field, fieldT, FD, num_vertices, stream);  // [64, V] -> [V, 64]
     }
-    const size_t smem = MAX_STAGE_FLOATS * sizeof(float);  // the largest staged layer (head)
+    // 4-wave blocks, two per CU: measured neutral (profiles/r02o_mlp_block.txt: 129.7 vs 127.9 TFLOP/s on [64, n]
+    // inputs, 119.3 vs 119.9 with the fused gather, render frame 108.2 vs 106.6 ms) -- the weight staging is not what
+    // idles the matrix cores -- so the 8-wave shape stays the default and this one an ablation (tn_mlp_set_block(256))
+    const bool small_blocks = g_mlp_block == 256;
+    const size_t smem = (small_blocks ? MAX_STAGE_FLOATS_SPLIT : MAX_STAGE_FLOATS) * sizeof(float);  // the largest staged layer
     static PerDeviceOnce lds_attr;
     lds_attr.run([&] {
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, false>), smem);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, false>), smem);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, true>), smem);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, true>), smem);
+        const size_t big = MAX_STAGE_FLOATS * sizeof(float);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, false>), big);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, false>), big);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, true>), big);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, true>), big);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, false, 256>), big);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, false, 256>), big);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, true, 256>), big);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, true, 256>), big);
     });
-    const size_t group = (MLP_BLOCK / 64) * 32;
+    const size_t group = ((small_blocks ? 256 : MLP_BLOCK) / 64) * 32;
     const size_t ngroups = (n + group - 1) / group;
-    const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);  // one 8-wave block per CU
+    const size_t max_grid = small_blocks ? 512 : 256;  // one 8-wave block or two 4-wave blocks per CU
+    const unsigned grid = (unsigned)(ngroups < max_grid ? ngroups : max_grid);
 #define TN_MLP_LAUNCH(G, D)                                                                                         \
-    hipLaunchKernelGGL((k_mlp_forward<G, D>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc, \
-                       fieldT, enc, pk, sigma, rgb)
+    do {                                                                                                            \
+        if (small_blocks)                                                                                           \
+            hipLaunchKernelGGL((k_mlp_forward<G, D, 256>), dim3(grid), dim3(256), smem, stream, n, samples_per_ray, feats, vi, bc, \
+                               fieldT, enc, pk, sigma, rgb);                                                        \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_mlp_forward<G, D>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc, \
+                               fieldT, enc, pk, sigma, rgb);                                                        \
+    } while (0)
     if (gather && density_only) TN_MLP_LAUNCH(true, true);
     else if (gather) TN_MLP_LAUNCH(true, false);
     else if (density_only) TN_MLP_LAUNCH(false, true);

@@ -40,6 +40,11 @@ constexpr size_t OFF_WHEAD = OFF_W3 + N_W3;
 constexpr size_t N_WHEAD = lfloats(HEAD_KS, OT) + CVEC;
 constexpr size_t PACK_FLOATS = OFF_WHEAD + N_WHEAD;
 constexpr size_t MAX_STAGE_FLOATS = N_WHEAD;
+// the head layer staged in two halves (4-wave blocks, two per CU: the largest stage must stay below 80 KB)
+constexpr int HEAD_KS_A = 40;                                    // k-steps of the first half: 14 encoding + 26 base
+constexpr size_t N_WHEAD_A = (size_t)HEAD_KS_A * OT * 64;
+constexpr size_t N_WHEAD_B = N_WHEAD - N_WHEAD_A;                // 38 base k-steps + the bias step + the rgb vectors
+constexpr size_t MAX_STAGE_FLOATS_SPLIT = N_W3;                  // 67 KB
 
 __host__ __device__ constexpr int acc_feature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 // k index consumed by k-step `ks` (0..63) of a layer whose input lives in accumulators, half h
@@ -66,15 +71,15 @@ static __device__ __forceinline__ void stage_wait() {
     __syncthreads();
 }
 
-// acc[t] += W_staged[k-steps KS0 .. KS0+KS) * bin[0..KS)
-template <int KS, int KS0, int TILES>
+// acc[t] += W_staged[k-steps KS0 .. KS0+KS) * bin[BIN0 .. BIN0+KS)
+template <int KS, int KS0, int TILES, int BIN0 = 0>
 static __device__ __forceinline__ void gemm_steps(f32x16 (&acc)[TILES], const float (&bin)[KSH], const float *lds, int lane) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const float *wrow = lds + (size_t)(KS0 + ks) * TILES * 64 + lane;
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], bin[ks], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], bin[BIN0 + ks], acc[t], 0, 0, 0);
         // keep the scheduler from hoisting hundreds of A-operand reads (register blow-up); the
         // MFMAs of one k-step (>= 256 cycles) already cover the next step's LDS latency
         __builtin_amdgcn_sched_barrier(0);

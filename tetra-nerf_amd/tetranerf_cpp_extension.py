@@ -384,6 +384,11 @@ def mlp_set_mode(mode):
     _lib.check(_lib.load().tn_mlp_set_mode(m))
 
 
+def mlp_set_block(block: int):
+    """Shape of the fp32 forward kernel: 0 auto, 512 (one 8-wave block per CU), 256 (two 4-wave blocks per CU)."""
+    _lib.check(_lib.load().tn_mlp_set_block(int(block)))
+
+
 def mlp_get_mode():
     return ("fp32", "bf16x3")[_lib.load().tn_mlp_get_mode()]
 
