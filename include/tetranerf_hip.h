@@ -210,6 +210,8 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *   "gpu_build"  1 (default) = load_tetrahedra builds its structures on the device; 0 = single-threaded host build
  *   "small_lds"  1 (default) = batches below walk_min_rays use LDS hit arrays sized for the mesh (every ray resident at
  *             once) and re-trace the rays with more hits in a second launch; "lds_cap" forces their size (tests)
+ *   "spec_fill"  1 (default) = the last quarter of every row (slots no ray of this mesh is expected to reach) is
+ *             filled beside the walk on a stream of its own; 0 = the whole tail fill after the segment writer
  *   measured and left off (all bit-identical; profiles/r02b..r02l): "literal_rows" 0 = literal pairing as an emit mask
  *             for the segment writer; "log_records" 1 = the walk also logs the record fields the writer needs;
  *             "pipe" N = walk / writer pipelined over N ray chunks; "seg_variant" 0 = direct (not LDS-staged) segment

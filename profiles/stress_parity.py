@@ -26,8 +26,13 @@ for case in range(n_cases):
         w = int(np.sqrt(R)); o, d = scenes.pinhole_rays(w, w, eye=(0.5 + 1.7 * np.cos(seed), 0.5 + 1.7 * np.sin(seed), 0.6), lookat=(0.5, 0.5, 0.5))
     ot = tn_oracle.OracleTracer(use_bvh=True); ot.load_tetrahedra(pts, cells)
     want = ot.trace_rays(o, d, M)
-    tr = tn.TetrahedraTracer(dev); tr.set_option("walk", 2)
-    tr.set_option("rewalk_min", int(rng.choice([0, 4096])))
+    tr = tn.TetrahedraTracer(dev)
+    # round 2b: every path variant is drawn at random (all must be bit-identical): walk or BVH path for every ray, device
+    # or host structure build, literal pairing as rows or as an emit mask, 16-byte or fat hit log, LDS-staged or direct
+    # segment stores, mesh-sized LDS hit arrays with a forced tiny capacity (overflow relaunch)
+    opts = {"walk": int(rng.choice([2, 2, 0])), "gpu_build": int(rng.integers(0, 2)), "literal_rows": int(rng.integers(0, 2)),
+            "log_records": int(rng.integers(0, 2)), "seg_variant": int(rng.integers(0, 2)), "lds_cap": int(rng.choice([0, 0, 16, 64]))}
+    for k, v in opts.items(): tr.set_option(k, v)
     tr.load_tetrahedra(torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev))
     got = tr.trace_rays(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), M)
     st, fr = tr.trace_stats(), tr.flag_reasons()
@@ -37,6 +42,6 @@ for case in range(n_cases):
     if not ok:
         bad += 1
         print(f"MISMATCH case {case}: npts={npts} seed={seed} M={M} kind={kind} R={len(o)}", flush=True)
-    print(f"case {case}: tets={len(cells)} M={M} kind={kind} rays={len(o)} segs/ray={want['num_visited_cells'].mean():.1f} paths={st} {'ok' if ok else 'FAIL'}", flush=True)
+    print(f"case {case}: tets={len(cells)} M={M} kind={kind} rays={len(o)} segs/ray={want['num_visited_cells'].mean():.1f} opts={opts} paths={st} {'ok' if ok else 'FAIL'}", flush=True)
 print(f"stress: {n_cases} cases, {total_rays} rays, {rewalked} re-walked chains, {bvh} BVH re-traces, {bad} mismatching cases, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)

@@ -44,6 +44,11 @@ struct tn_tracer {
                                          // slower: the latency-bound segment writer crawls beside a saturating fill)
     hipStream_t side = nullptr;          // second stream: tail prefill, literal pairing, BVH re-trace
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t pre = nullptr;           // speculative tail fill beside the walk
+    hipEvent_t ev_start = nullptr, ev_pre = nullptr;
+    int spec_fill = 1;                   // 1: slots [K0, M) of every row are filled beside the walk (K0 from the mesh size); 0 off
+    unsigned spec_blocks = 0;            // grid of that fill (0 = 2048 blocks)
+    unsigned spec_k0 = 0;                // override of K0 (multiple of 32; ablation)
     hipStream_t writer = nullptr;        // pipelined mode: the segment writer of chunk i runs beside the walk of chunk i + 1
     hipEvent_t ev_chunk[8] = {}, ev_writer = nullptr;
     bool small_lds = true;               // small batches: LDS hit arrays sized for the mesh, overflow rays in a second launch
@@ -147,6 +152,9 @@ int tn_tracer_create(int device, tn_tracer_t *out) {
         TN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
         TN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
         TN_HIP(hipStreamCreateWithFlags(&t->writer, hipStreamNonBlocking));
+        TN_HIP(hipStreamCreateWithFlags(&t->pre, hipStreamNonBlocking));
+        TN_HIP(hipEventCreateWithFlags(&t->ev_start, hipEventDisableTiming));
+        TN_HIP(hipEventCreateWithFlags(&t->ev_pre, hipEventDisableTiming));
         for (auto &e : t->ev_chunk) TN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         TN_HIP(hipEventCreateWithFlags(&t->ev_writer, hipEventDisableTiming));
         *out = t.release();
@@ -162,6 +170,9 @@ int tn_tracer_destroy(tn_tracer_t tracer) {
         if (tracer->ev_fork) (void)hipEventDestroy(tracer->ev_fork);
         if (tracer->ev_join) (void)hipEventDestroy(tracer->ev_join);
         if (tracer->writer) (void)hipStreamDestroy(tracer->writer);
+        if (tracer->pre) (void)hipStreamDestroy(tracer->pre);
+        if (tracer->ev_start) (void)hipEventDestroy(tracer->ev_start);
+        if (tracer->ev_pre) (void)hipEventDestroy(tracer->ev_pre);
         for (auto &e : tracer->ev_chunk) if (e) (void)hipEventDestroy(e);
         if (tracer->ev_writer) (void)hipEventDestroy(tracer->ev_writer);
         delete tracer;
@@ -397,11 +408,27 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 q.out_verts = verts ? verts + base * M * 4 : nullptr;
                 tn::launch_write_segments(q, st, t->seg_blocks);
             };
-            auto launch_fill = [&](size_t base, size_t n, bool all_rows, const uint32_t *kmax, hipStream_t st) {
+            auto launch_fill = [&](size_t base, size_t n, bool all_rows, const uint32_t *kmax, hipStream_t st, uint32_t k_fixed = 0,
+                                   bool nontemporal = false) {
                 if (!t->dense_tails) return;
                 tn::launch_fill_range(n, M, all_rows, kmax, t->walk_n.p + base, num_visited + base, visited + base * M, bary + base * M * 6,
-                                      dist + base * M * 2, verts ? verts + base * M * 4 : nullptr, st, t->fill_blocks);
+                                      dist + base * M * 2, verts ? verts + base * M * 4 : nullptr, st, t->fill_blocks, k_fixed, nontemporal);
             };
+            // Speculative tail fill: a ray of a uniform mesh of T tets crosses at most ~3.45 T^(1/3) faces, so
+            // the slots from ceil32(3.6 T^(1/3)) + 32 on are constants in (almost) every row and can be streamed BESIDE
+            // the walk.  The walk slows down beside a saturating write stream (x2-4: its record loads queue behind the
+            // writes), so only as many bytes as the walk's own duration buys are filled that way: the last quarter of
+            // every row (measured: profiles/r02p_specfill*.txt -- C2 +1..3 %, 300k frame +2..3.5 %, the 1M-tet configurations
+            // +-1 %).  A ray with more segments than K0 loses nothing: the segment writer runs after this fill and
+            // overwrites its slots.
+            uint32_t K0 = 0;
+            if (t->spec_fill && t->dense_tails && !t->prefill && t->side_late && single) {
+                K0 = (((uint32_t)(3.6 * std::cbrt((double)std::max<uint32_t>(t->mesh.T, 1u))) + 31u) & ~31u) + 32u;
+                const uint32_t quarter = (3u * M / 4u) & ~31u;
+                if (K0 < quarter) K0 = quarter;
+                if (t->spec_k0) K0 = t->spec_k0 & ~31u;
+                if (K0 + 32u > M) K0 = 0;
+            }
             auto launch_mask = [&](size_t base, size_t n, hipStream_t st, size_t log_base = 0) {
                 tn::launch_literal_mask(M, t->mesh.vars, t->hit_log.p + (log_base / 64) * (size_t)M * 64, t->literal_list.p, t->literal_count(), n,
                                         t->walk_n.p + base, num_visited + base, t->emit_mask.p + base * (size_t)(M / 32),
@@ -450,9 +477,21 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 launch_fill(0, R, false, nullptr, stream);
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_writer, 0));
             } else if (single) {
+                if (K0) {
+                    TN_HIP(hipEventRecord(t->ev_start, stream));
+                    TN_HIP(hipStreamWaitEvent(t->pre, t->ev_start, 0));
+                    if (t->dense_tails)
+                        tn::launch_fill_range(R, M, true, nullptr, t->walk_n.p, num_visited, visited, bary, dist, verts, t->pre,
+                                              t->spec_blocks ? t->spec_blocks : 2048u, K0, true);
+                    TN_HIP(hipEventRecord(t->ev_pre, t->pre));
+                }
                 launch_walk(0, R);
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
+                if (K0) {   // everything that writes rows comes after the speculative fill
+                    TN_HIP(hipStreamWaitEvent(t->writer, t->ev_pre, 0));
+                    TN_HIP(hipStreamWaitEvent(stream, t->ev_pre, 0));
+                }
                 // (with the `prefill` ablation the all-rows fill of the side stream must precede every kernel that writes whole
                 //  rows, so the fallback rays stay behind it on the side stream)
                 const bool aux = t->aux_general && !t->prefill;
@@ -473,7 +512,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 if (t->prefill) launch_fill(0, R, true, t->kmax(), t->side);
                 launch_literal(0, R, t->side);
                 if (!aux) tn::launch_trace_general(p, t->side);
-                launch_fill(0, R, false, t->prefill ? t->kmax() : nullptr, stream);
+                launch_fill(0, R, false, t->prefill ? t->kmax() : nullptr, stream, K0);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
                 if (aux) TN_HIP(hipStreamWaitEvent(stream, t->ev_writer, 0));
@@ -649,6 +688,9 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
         else if (name && std::strcmp(name, "seg_blocks") == 0) t->seg_blocks = (unsigned)value;
         else if (name && std::strcmp(name, "log_records") == 0) t->fat_log = value != 0;
+        else if (name && std::strcmp(name, "spec_fill") == 0) t->spec_fill = value != 0;
+        else if (name && std::strcmp(name, "spec_blocks") == 0) t->spec_blocks = (unsigned)value;
+        else if (name && std::strcmp(name, "spec_k0") == 0) t->spec_k0 = (unsigned)value;
         else if (name && std::strcmp(name, "small_lds") == 0) t->small_lds = value != 0;
         else if (name && std::strcmp(name, "lds_cap") == 0) {
             if (value < 0 || (value & (value - 1)) != 0 || (value && value < 8)) throw tn::Error("lds_cap must be 0 or a power of two >= 8");

@@ -99,7 +99,7 @@ void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned ma
 // otherwise slots [ceil32(out_num[r]), K) of the certified rows
 void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *kmax, const uint32_t *walk_n,
                        const uint32_t *out_num, uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
-                       unsigned max_blocks = 0);
+                       unsigned max_blocks = 0, uint32_t k_fixed = 0, bool nontemporal = false);
 
 void launch_probe_fill(void *dst, size_t bytes, int flavour, unsigned blocks, hipStream_t stream);  // probe only
 

@@ -80,6 +80,7 @@ constexpr uint32_t MAX_WALK_STEPS = 1u << 20;
 // fill dwords [start, end) of `base` with `value`; base 16-byte aligned.  Wave-cooperative.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+template <bool NT = false>
 __device__ __forceinline__ void fill_dwords(uint32_t *__restrict__ base, uint32_t start, uint32_t end, uint32_t value, int lane) {
     const uint32_t a0 = (start + 3u) & ~3u;  // first 16-B aligned dword
     const uint32_t head_end = a0 < end ? a0 : end;
@@ -89,7 +90,10 @@ __device__ __forceinline__ void fill_dwords(uint32_t *__restrict__ base, uint32_
     u32x4 *b4 = reinterpret_cast<u32x4 *>(base);
     const u32x4 v4 = {value, value, value, value};
     for (uint32_t i = (a0 >> 2) + lane; i < (a1 >> 2); i += 64) {
-        b4[i] = v4;  // plain stores: nontemporal ones measured slower for this pure write stream
+        // plain stores: nontemporal ones measured slower for a pure write stream running alone; NT = the fill that
+        // streams BESIDE the walk (the walk's records then stay in the XCD's L2)
+        if constexpr (NT) __builtin_nontemporal_store(v4, b4 + i);
+        else b4[i] = v4;
     }
     if (a1 + lane < end) base[a1 + lane] = value;
 }
@@ -762,7 +766,8 @@ void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned ma
 //                 only the walk, so it streams beside the (latency-bound) segment writer.  Rows of literal /
 //                 fallback rays are included: the kernels that rewrite them run after this one.
 //   all_rows = 0: slots [ceil32(n), K) of the certified rows (k_write_segments has written [0, ceil32(n))).
-__global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M, uint32_t all_rows, const uint32_t *__restrict__ kmax,
+template <bool NT>
+__global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M, uint32_t all_rows, uint32_t k_fixed, const uint32_t *__restrict__ kmax,
                                                     const uint32_t *__restrict__ walk_n, const uint32_t *__restrict__ out_num,
                                                     uint32_t *__restrict__ out_cells,
                                                     float *__restrict__ out_bary, float *__restrict__ out_dist,
@@ -773,7 +778,8 @@ __global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M,
     const size_t r0 = ((size_t)blockIdx.x * 4 + wave) * span;
     const size_t r1 = r0 + span < num_rays ? r0 + span : num_rays;
     uint32_t K = M;
-    if (kmax) {
+    if (k_fixed) K = k_fixed;          // host-chosen split point (speculative fill: see launch_fill_range)
+    else if (kmax) {
         K = (*kmax + 31u) & ~31u;
         if (K > M) K = M;
     }
@@ -786,24 +792,30 @@ __global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M,
             hi = K;
         }
         if (lo >= hi) continue;
-        fill_dwords(out_cells + r * M, lo, hi, TN_EMPTY, lane);
-        fill_dwords(reinterpret_cast<uint32_t *>(out_dist + r * M * 2), 2 * lo, 2 * hi, 0u, lane);
-        fill_dwords(reinterpret_cast<uint32_t *>(out_bary + r * M * 6), 6 * lo, 6 * hi, 0u, lane);
-        if (out_verts) fill_dwords(out_verts + r * M * 4, 4 * lo, 4 * hi, TN_EMPTY, lane);
+        fill_dwords<NT>(out_cells + r * M, lo, hi, TN_EMPTY, lane);
+        fill_dwords<NT>(reinterpret_cast<uint32_t *>(out_dist + r * M * 2), 2 * lo, 2 * hi, 0u, lane);
+        fill_dwords<NT>(reinterpret_cast<uint32_t *>(out_bary + r * M * 6), 6 * lo, 6 * hi, 0u, lane);
+        if (out_verts) fill_dwords<NT>(out_verts + r * M * 4, 4 * lo, 4 * hi, TN_EMPTY, lane);
     }
 }
 
+// k_fixed != 0: the split point is chosen by the HOST -- all_rows = 1 then fills slots [k_fixed, M) of EVERY row without
+// needing anything from the walk (speculative fill, streamed beside the walk), all_rows = 0 fills [ceil32(n), k_fixed).
 void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *kmax, const uint32_t *walk_n,
                        const uint32_t *out_num, uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
-                       unsigned max_blocks) {
+                       unsigned max_blocks, uint32_t k_fixed, bool nontemporal) {
     if (num_rays == 0) return;
     size_t blocks = (num_rays + 3) / 4;           // >= one ray per wave
     // default: 2 blocks (8 waves) per CU -- enough to hold the write ceiling, and the latency-bound kernels running
     // beside the fill are less starved than with 8 per CU (profiles/r01_fill_grid.txt)
     const size_t cap = max_blocks ? max_blocks : 256 * 2;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_fill_range, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, kmax, walk_n,
-                       out_num, out_cells, out_bary, out_dist, out_verts);
+    if (nontemporal)
+        hipLaunchKernelGGL(k_fill_range<true>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_fixed, kmax,
+                           walk_n, out_num, out_cells, out_bary, out_dist, out_verts);
+    else
+        hipLaunchKernelGGL(k_fill_range<false>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_fixed, kmax,
+                           walk_n, out_num, out_cells, out_bary, out_dist, out_verts);
 }
 
 // Probe kernel (profiles/r02_overlap_probe.py): a pure write stream with a selectable store flavour --
