@@ -195,7 +195,8 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
             tn::BuildInfo bi;
             tn::device_build(V, T, xyz, cells, stream,
                              tn::BuildTargets{t->faces, t->face_tets, t->vars, t->hull_nodes, t->hull_tris, t->bvh}, bi);
-            if (bi.max_stack > (uint32_t)tn::STACK_CAP)
+            // (+ WIDE: the traversal pops the next node before it pushes the current one's children)
+            if (bi.max_stack + (uint32_t)tn::WIDE > (uint32_t)tn::STACK_CAP)
                 throw tn::Error("face BVH too deep for the traversal stack (" + std::to_string(bi.max_stack) + " > " +
                                 std::to_string(tn::STACK_CAP) + " entries)");
             t->host.scene_max = bi.scene_max;
@@ -225,7 +226,7 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         }
         tn::HostWideBvh hb;
         tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), all, hb);
-        if (hb.max_stack > (uint32_t)tn::STACK_CAP)
+        if (hb.max_stack + (uint32_t)tn::WIDE > (uint32_t)tn::STACK_CAP)
             throw tn::Error("face BVH too deep for the traversal stack (" + std::to_string(hb.max_stack) + " > " +
                             std::to_string(tn::STACK_CAP) + " entries)");
         t->bvh_max_stack = hb.max_stack;

@@ -374,41 +374,65 @@ __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, ui
                 for (int k = 0; k < 9; ++k) d[k] = tr[k * WIDE];
                 fid = bvh.leaf_id[(size_t)li * WIDE + lane];
             };
-            float cur[9], nxt[9];
-            uint32_t cfid, nfid = TN_EMPTY;
+            // three leaves deep: leaf i + 2 is requested before leaf i is tested (a small batch is one wavefront per ray
+            // with every ray resident at once, so a ray's own chain of round trips is the time of the call)
+            float cur[9], nx1[9], nx2[9];
+            uint32_t cfid, f1 = TN_EMPTY, f2 = TN_EMPTY;
             fetch(leaf_list[0], cur, cfid);
+            if (nleaf > 1) fetch(leaf_list[1], nx1, f1);
             for (uint32_t i = 0; i < nleaf && !aborted; ++i) {
-                if (i + 1 < nleaf) fetch(leaf_list[i + 1], nxt, nfid);
+                if (i + 2 < nleaf) fetch(leaf_list[i + 2], nx2, f2);
                 test_leaf(cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7], cur[8], cfid);
 #pragma unroll
-                for (int k = 0; k < 9; ++k) cur[k] = nxt[k];
-                cfid = nfid;
+                for (int k = 0; k < 9; ++k) { cur[k] = nx1[k]; nx1[k] = nx2[k]; }
+                cfid = f1; f1 = f2;
             }
             nleaf = 0;
             wave_sync();
         };
 
-        uint32_t sp = 1;      // stack of internal nodes (wave-uniform)
-        if (lane == 0) s.stack[0] = 0u;  // root = internal node 0
-        wave_sync();
-        while (sp > 0 && !aborted) {
-            const uint32_t idx = s.stack[sp - 1];
-            sp--;
-            wave_sync();  // everyone has read the top before it can be overwritten
+        // Internal nodes: the NEXT node is popped and its boxes requested before the current one is tested (the visiting
+        // order is irrelevant: every crossed leaf is wanted), so a node costs one round trip per two instead of one each.
+        auto load_node = [&](uint32_t idx, float (&bx)[6], uint32_t &ch) {
+            const float *b = bvh.boxes + (size_t)idx * (6 * WIDE) + lane;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) bx[k] = b[k * WIDE];
+            ch = bvh.child[(size_t)idx * WIDE + lane];
+        };
+        uint32_t sp = 0;      // stack of internal nodes (wave-uniform)
+        float cbx[6], nbx[6];
+        uint32_t cch, nch = TN_EMPTY;
+        load_node(0u, cbx, cch);   // root = internal node 0
+        bool have_cur = true;
+        while (have_cur && !aborted) {
+            bool have_nxt = sp > 0;
+            if (have_nxt) {
+                const uint32_t nidx = s.stack[sp - 1];
+                sp--;
+                wave_sync();  // everyone has read the top before it can be overwritten
+                load_node(nidx, nbx, nch);
+            }
             if (lane == 0 && stats) atomicAdd(&stats[22], 1ull);
-            const float *b = bvh.boxes + (size_t)idx * (6 * WIDE);
-            const uint32_t ch = bvh.child[(size_t)idx * WIDE + lane];
-            const bool hit = ch != TN_EMPTY &&
-                             line_box(ox, oy, oz, ix, iy, iz, b[lane], b[WIDE + lane], b[2 * WIDE + lane],
-                                      b[3 * WIDE + lane], b[4 * WIDE + lane], b[5 * WIDE + lane], pad);
-            const bool to_leaf = hit && (ch >> 31) != 0, to_node = hit && (ch >> 31) == 0;
+            const bool hit = cch != TN_EMPTY && line_box(ox, oy, oz, ix, iy, iz, cbx[0], cbx[1], cbx[2], cbx[3], cbx[4], cbx[5], pad);
+            const bool to_leaf = hit && (cch >> 31) != 0, to_node = hit && (cch >> 31) == 0;
             const uint64_t ml = __ballot(to_leaf), mn = __ballot(to_node);
             if (nleaf + __popcll(ml) > leaf_cap) run_leaves();  // flush a full list (tiny M only)
-            if (to_leaf) leaf_list[nleaf + __popcll(ml & lanemask_lt())] = ch & 0x7FFFFFFFu;
+            if (to_leaf) leaf_list[nleaf + __popcll(ml & lanemask_lt())] = cch & 0x7FFFFFFFu;
             nleaf += __popcll(ml);
-            if (to_node) s.stack[sp + __popcll(mn & lanemask_lt())] = ch;
+            if (to_node) s.stack[sp + __popcll(mn & lanemask_lt())] = cch;
             sp += __popcll(mn);
             wave_sync();
+            if (!have_nxt && sp > 0) {   // nothing was waiting: take one of the children just pushed
+                const uint32_t nidx = s.stack[sp - 1];
+                sp--;
+                wave_sync();
+                load_node(nidx, nbx, nch);
+                have_nxt = true;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cbx[k] = nbx[k];
+            cch = nch;
+            have_cur = have_nxt;
         }
         if (!aborted) run_leaves();
         wave_sync();
