@@ -57,9 +57,10 @@
 // larger half of the kernel).  Instead every recorded hit goes to a HIT LOG as one 16-byte entry
 // {t, u, v, variant | exit << 30} at log[wave of 64 rays][hit index][lane] -- the 64 lanes of a wave store 1 KB of
 // consecutive bytes per step, and the log is 16 B per hit instead of 52 B per segment.  k_write_segments turns
-// the log of the certified rays into segment records (whole 128-byte lines, one wave per 8 rays),
-// k_fill_range streams the constant tails: slots [K, M) of ALL rows as soon as the walk has published the
-// largest hit count K (beside the segment writer), slots [ceil32(n), K) of the certified rows after it.
+// the log of the certified rays into segment records (whole 128-byte lines, one wave per 8 rays, staged through LDS so
+// that every store instruction writes contiguous runs), k_fill_range streams the constant tails: the last quarter of
+// every row BESIDE the walk (slots no ray of the mesh is expected to reach need nothing from it; the walk is bound by
+// VALU issue, the fill by HBM writes), slots [ceil32(n), 3M/4) of the certified rows after the segment writer.
 // blockIdx is remapped so each XCD owns runs of 16 consecutive blocks (4096 neighbouring rays) and its L2 keeps
 // the tets they cross.
 #include "tn_device.h"
