@@ -208,6 +208,8 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *             measured slower, the latency-bound segment writer crawls beside a saturating fill)
  *   "log_cap_mb"  cap of the hit log (default 24576): larger calls are processed in ray chunks
  *   "gpu_build"  1 (default) = load_tetrahedra builds its structures on the device; 0 = single-threaded host build
+ *   "leaf_width" 16 (default) / 32 / 64: faces per leaf of the face BVH (applies at the next tn_load_tetrahedra); the BVH
+ *             path tests 64 / leaf_width crossed leaves per wave instruction
  *   "small_lds"  1 (default) = batches below walk_min_rays use LDS hit arrays sized for the mesh (every ray resident at
  *             once) and re-trace the rays with more hits in a second launch; "lds_cap" forces their size (tests)
  *   "spec_fill"  1 (default) = the last quarter of every row (slots no ray of this mesh is expected to reach) is

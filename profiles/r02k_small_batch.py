@@ -18,8 +18,12 @@ def timed(fn, n=20):
     return e0.elapsed_time(e1) / n
 for cfg, npts, seed in (("c2", 15000, 0), ("c4", 45000, 2), ("c5", 150000, 3)):
     pts, cells = scenes.random_mesh(npts, seed)
-    tr = tn.TetrahedraTracer(dev); tr.load_tetrahedra(torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev))
-    for name, (o, d) in (("outside-in", scenes.outside_in_rays(4096, 1)), ("inside-out", scenes.inside_out_rays(4096, 2))):
+    ref_out = {}
+    for lw in (16, 32, 64):
+      tr = tn.TetrahedraTracer(dev); tr.set_option("leaf_width", lw); tr.load_tetrahedra(torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev))
+      tr.set_option("gdebug", 8); tr.trace_rays(*[torch.from_numpy(x).to(dev) for x in scenes.outside_in_rays(4096, 1)], M); torch.cuda.synchronize(); tr.set_option("gdebug", 0)
+      print(f"{cfg} leaf width {lw}:", flush=True)
+      for name, (o, d) in (("outside-in", scenes.outside_in_rays(4096, 1)), ("inside-out", scenes.inside_out_rays(4096, 2))):
         o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
         res, outs = {}, {}
         for sl in (1, 0, 1, 0):
@@ -29,6 +33,9 @@ for cfg, npts, seed in (("c2", 15000, 0), ("c4", 45000, 2), ("c5", 150000, 3)):
                 x = tr.trace_rays(o, d, M); del x
             res.setdefault(sl, []).append(timed(call))
         for k in KEYS: assert torch.equal(outs[0][k], outs[1][k]), (cfg, name, k)
+        if lw == 16: ref_out[name] = outs[1]
+        else:
+            for k in KEYS: assert torch.equal(ref_out[name][k], outs[1][k]), (cfg, name, k, lw)
         n = int(outs[1]["num_visited_cells"].sum()); mx = int(outs[1]["num_visited_cells"].max())
-        print(f"{cfg} 4096 rays {name}: mesh-sized LDS arrays {min(res[1]):.3f} ms, full arrays {min(res[0]):.3f} ms  ({n} segments, max {mx} per ray) {tr.trace_stats()}", flush=True)
-    del tr
+        print(f"  {cfg} 4096 rays {name}: mesh-sized LDS arrays {min(res[1]):.3f} ms, full arrays {min(res[0]):.3f} ms  ({n} segments, max {mx} per ray) {tr.trace_stats()}", flush=True)
+      del tr

@@ -14,11 +14,12 @@ pytestmark = pytest.mark.gpu
 KEYS = ("num_visited_cells", "visited_cells", "vertex_indices", "hit_distances", "barycentric_coordinates")
 
 
-def _tracer(tn, device, pts, cells, gpu_build):
+def _tracer(tn, device, pts, cells, gpu_build, leaf_width=16):
     import torch
 
     tr = tn.TetrahedraTracer(device)
     tr.set_option("gpu_build", gpu_build)
+    tr.set_option("leaf_width", leaf_width)
     tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
     return tr
 
@@ -32,11 +33,11 @@ def _meshes(scenes, bottle):
     yield "near_duplicates", scenes.near_duplicates_mesh(3000)
 
 
-def _check_bvh(tr, F):
+def _check_bvh(tr, F, leaf_width=16):
     child = tr.build_table(5).numpy().view(np.uint32).reshape(-1, 64)
     boxes = tr.build_table(6).numpy().view(np.float32).reshape(-1, 6, 64)
-    leaf_id = tr.build_table(7).numpy().view(np.uint32).reshape(-1, 64)
-    leaf_tri = tr.build_table(8).numpy().view(np.float32).reshape(-1, 9, 64)
+    leaf_id = tr.build_table(7).numpy().view(np.uint32).reshape(-1, leaf_width)
+    leaf_tri = tr.build_table(8).numpy().view(np.float32).reshape(-1, 9, leaf_width)
     n_nodes, n_leaves = child.shape[0], leaf_id.shape[0]
     ids = leaf_id[leaf_id != 0xFFFFFFFF]
     assert len(ids) == F and len(np.unique(ids)) == F, "every face must sit in exactly one leaf"
@@ -79,6 +80,17 @@ def test_device_build_matches_host_build(tn, device, scenes, bottle):
         F = host.build_table(1).numel() // 8
         _check_bvh(dev, F)
         _check_bvh(host, F)
+        # the other leaf widths (64 = one leaf per wave instruction, the layout of rounds 1 / 2a)
+        for lw in (32, 64):
+            other = _tracer(tn, device, pts, cells, 1, lw)
+            _check_bvh(other, F, lw)
+            other.set_option("walk", 0)
+            o2, d2 = scenes.outside_in_rays(1000, 6)
+            o2, d2 = torch.from_numpy(o2).to(device), torch.from_numpy(d2).to(device)
+            host.set_option("walk", 0)
+            a2, b2 = host.trace_rays(o2, d2, 256), other.trace_rays(o2, d2, 256)
+            for k in KEYS:
+                assert torch.equal(a2[k], b2[k]), f"{name}: {k} differs with {lw}-face leaves"
         # the BVH all-hits path on either structure: identical rows
         o, d = scenes.outside_in_rays(3000, 5)
         o, d = torch.from_numpy(o).to(device), torch.from_numpy(d).to(device)

@@ -26,6 +26,7 @@ struct tn_tracer {
     tn::HostMesh host;  // kept for tn_get_faces (device build: downloaded on first use)
     bool gpu_build = true;   // structures built on the device (tn_build.hip); false: the single-threaded host build (tn_mesh.cpp)
     uint32_t bvh_max_stack = 1;
+    unsigned leaf_width = 16;            // faces per BVH leaf block (16 / 32 / 64; applies at the next load_tetrahedra)
     tn::DevBuf<uint32_t> faces, face_tets, fallback_list, walk_n;
     tn::DevBuf<uint2> literal_list;      // rays whose logged hits go through the literal sort + pairing
     tn::DevBuf<uint4> hit_log;           // walk -> segment writer / literal pairing: 16 B per recorded hit, [rays / 64][M][64]
@@ -194,7 +195,7 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
             // everything is built on the device from the caller's buffers (tn_build.hip)
             tn::BuildInfo bi;
             tn::device_build(V, T, xyz, cells, stream,
-                             tn::BuildTargets{t->faces, t->face_tets, t->vars, t->hull_nodes, t->hull_tris, t->bvh}, bi);
+                             tn::BuildTargets{t->faces, t->face_tets, t->vars, t->hull_nodes, t->hull_tris, t->bvh}, bi, t->leaf_width);
             // (+ WIDE: the traversal pops the next node before it pushes the current one's children)
             if (bi.max_stack + (uint32_t)tn::WIDE > (uint32_t)tn::STACK_CAP)
                 throw tn::Error("face BVH too deep for the traversal stack (" + std::to_string(bi.max_stack) + " > " +
@@ -225,7 +226,7 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
             if (t->host.face_tets[2 * f + 1] == TN_EMPTY) hull_ids.push_back((uint32_t)f);
         }
         tn::HostWideBvh hb;
-        tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), all, hb);
+        tn::build_wide_bvh(hxyz.data(), t->host.faces.data(), all, hb, t->leaf_width);
         if (hb.max_stack + (uint32_t)tn::WIDE > (uint32_t)tn::STACK_CAP)
             throw tn::Error("face BVH too deep for the traversal stack (" + std::to_string(hb.max_stack) + " > " +
                             std::to_string(tn::STACK_CAP) + " entries)");
@@ -678,6 +679,10 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);
         if (name && std::strcmp(name, "gpu_build") == 0) t->gpu_build = value != 0;
+        else if (name && std::strcmp(name, "leaf_width") == 0) {
+            if (value != 16 && value != 32 && value != 64) throw tn::Error("leaf_width must be 16, 32 or 64");
+            t->leaf_width = (unsigned)value;
+        }
         else if (name && std::strcmp(name, "walk") == 0) t->use_walk = value < 0 ? 0 : (value > 2 ? 2 : value);
         else if (name && std::strcmp(name, "walk_min_rays") == 0) t->walk_min_rays = value < 0 ? 0 : (size_t)value;
         else if (name && std::strcmp(name, "debug") == 0) t->debug = (uint32_t)value;

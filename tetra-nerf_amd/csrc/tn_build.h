@@ -7,7 +7,7 @@ namespace tn {
 
 // shape of the median-split binary tree over n faces (tn_mesh.cpp)
 void build_bin_topology(size_t n, std::vector<core::BinNode> &bn, std::vector<std::vector<uint32_t>> &frontier,
-                        std::vector<uint32_t> &level_start, std::vector<uint32_t> &leaf_nodes);
+                        std::vector<uint32_t> &level_start, std::vector<uint32_t> &leaf_nodes, uint32_t leaf_w = WIDE);
 
 struct BuildTargets {
     DevBuf<uint32_t> &faces, &face_tets;   // [F,3], [F,2]
@@ -24,6 +24,6 @@ struct BuildInfo {
 // Blocking (a handful of small D2H reads: counts, the hull faces, the child rows for the stack bound).
 // Throws the reference's errors ("A triangle is shared by more than two tetrahedra!", out-of-bounds vertex ids).
 void device_build(size_t V, size_t T, const float *xyz, const uint32_t *cells, hipStream_t stream, BuildTargets out,
-                  BuildInfo &info);
+                  BuildInfo &info, uint32_t leaf_w = WIDE);
 
 }  // namespace tn

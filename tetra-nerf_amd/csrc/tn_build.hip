@@ -235,12 +235,14 @@ __global__ __launch_bounds__(BT) void k_node_boxes(uint32_t first_node, uint32_t
     for (int a = 0; a < 3; ++a) { node_lo[3 * k + a] = lo[a]; node_hi[3 * k + a] = hi[a]; }
 }
 
-// one block of 64 threads per leaf: SoA triangle block + face ids
-__global__ __launch_bounds__(64) void k_leaf_soa(const uint32_t *__restrict__ leaf_nodes, const core::BinNode *__restrict__ bn,
-                                                 const uint32_t *__restrict__ order, const uint32_t *__restrict__ faces,
-                                                 const float *__restrict__ xyz, float *leaf_tri, uint32_t *leaf_id) {
-    const size_t l = blockIdx.x;
-    const uint32_t i = threadIdx.x;
+// 64 threads = 64 / leaf_w leaves: SoA triangle blocks of leaf_w slots + face ids
+__global__ __launch_bounds__(64) void k_leaf_soa(uint32_t n_leaves, uint32_t leaf_w, uint32_t leaf_shift, const uint32_t *__restrict__ leaf_nodes,
+                                                 const core::BinNode *__restrict__ bn, const uint32_t *__restrict__ order,
+                                                 const uint32_t *__restrict__ faces, const float *__restrict__ xyz, float *leaf_tri,
+                                                 uint32_t *leaf_id) {
+    const size_t l = (size_t)blockIdx.x * (64u >> leaf_shift) + (threadIdx.x >> leaf_shift);
+    const uint32_t i = threadIdx.x & (leaf_w - 1);
+    if (l >= n_leaves) return;
     const core::BinNode nd = bn[leaf_nodes[l]];
     uint32_t fid = TN_EMPTY;
     float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -250,8 +252,8 @@ __global__ __launch_bounds__(64) void k_leaf_soa(const uint32_t *__restrict__ le
         for (int q = 0; q < 3; ++q)
             for (int k = 0; k < 3; ++k) v[q * 3 + k] = xyz[3 * (size_t)f[q] + k];
     }
-    leaf_id[l * WIDE + i] = fid;
-    for (int q = 0; q < 9; ++q) leaf_tri[(l * 9 + q) * WIDE + i] = v[q];
+    leaf_id[l * leaf_w + i] = fid;
+    for (int q = 0; q < 9; ++q) leaf_tri[(l * 9 + q) * leaf_w + i] = v[q];
 }
 
 // one thread per wide node of level `lev` (node ids [snap[lev], snap[lev + 1])): greedy opening of its binary subtree
@@ -319,7 +321,10 @@ unsigned bit_length(uint64_t v) { unsigned b = 0; while (v) { ++b; v >>= 1; } re
 
 }  // namespace
 
-void device_build(size_t V, size_t T, const float *xyz, const uint32_t *cells, hipStream_t s, BuildTargets out, BuildInfo &info) {
+void device_build(size_t V, size_t T, const float *xyz, const uint32_t *cells, hipStream_t s, BuildTargets out, BuildInfo &info,
+                  uint32_t leaf_w) {
+    if (leaf_w != 16 && leaf_w != 32 && leaf_w != 64) throw Error("leaf width must be 16, 32 or 64");
+    const uint32_t leaf_shift = leaf_w == 16 ? 4u : (leaf_w == 32 ? 5u : 6u);
     if (T == 0) throw Error("device_build needs at least one tetrahedron");
     const size_t n4 = 4 * T;
     Temp tmp;
@@ -384,7 +389,7 @@ void device_build(size_t V, size_t T, const float *xyz, const uint32_t *cells, h
     std::vector<core::BinNode> bn;
     std::vector<std::vector<uint32_t>> frontier;
     std::vector<uint32_t> level_start, leaf_nodes;
-    build_bin_topology(F, bn, frontier, level_start, leaf_nodes);
+    build_bin_topology(F, bn, frontier, level_start, leaf_nodes, leaf_w);
     const size_t nn = bn.size(), n_leaves = leaf_nodes.size();
     HostHullBvh hth;
     build_hull_from_info(hinfo, hth);
@@ -438,10 +443,13 @@ void device_build(size_t V, size_t T, const float *xyz, const uint32_t *cells, h
         const uint32_t first_node = level_start[l], cnt = level_start[l + 1] - level_start[l];
         hipLaunchKernelGGL(k_node_boxes, dim3(grid_for(cnt)), dim3(BT), 0, s, first_node, cnt, dbn.p, ord_a.p, fb.p, node_lo.p, node_hi.p);
     }
-    out.bvh.leaf_tri.alloc(n_leaves * 9 * WIDE);
-    out.bvh.leaf_id.alloc(n_leaves * WIDE);
-    hipLaunchKernelGGL(k_leaf_soa, dim3((unsigned)n_leaves), dim3(64), 0, s, dleaf_nodes.p, dbn.p, ord_a.p, out.faces.p, xyz,
-                       out.bvh.leaf_tri.p, out.bvh.leaf_id.p);
+    out.bvh.leaf_tri.alloc(n_leaves * 9 * leaf_w);
+    out.bvh.leaf_id.alloc(n_leaves * leaf_w);
+    {
+        const unsigned per_block = 64u >> leaf_shift;
+        hipLaunchKernelGGL(k_leaf_soa, dim3((unsigned)((n_leaves + per_block - 1) / per_block)), dim3(64), 0, s, (uint32_t)n_leaves, leaf_w,
+                           leaf_shift, dleaf_nodes.p, dbn.p, ord_a.p, out.faces.p, xyz, out.bvh.leaf_tri.p, out.bvh.leaf_id.p);
+    }
     // collapse, level by level
     const uint32_t wcap = (uint32_t)nn;
     DevBuf<float> boxes_tmp;
@@ -482,7 +490,7 @@ void device_build(size_t V, size_t T, const float *xyz, const uint32_t *cells, h
         const uint32_t bits = read_back(flags.p + 1, s);
         std::memcpy(&info.scene_max, &bits, 4);
     }
-    out.bvh.set_view(n_wide, info.scene_max);
+    out.bvh.set_view(n_wide, info.scene_max, leaf_w);
 }
 
 }  // namespace tn

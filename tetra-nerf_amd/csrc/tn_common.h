@@ -53,8 +53,10 @@ constexpr int STACK_CAP = 64 * 6;   // traversal stack entries per wave
 // triangle vertices inline, SoA, so a wave reads a leaf with 10 coalesced 256-B loads; an internal node
 // is 6 SoA box rows + 1 row of child references (bit 31 = leaf index, TN_EMPTY = no child).
 struct WideBvh {
-    const float *leaf_tri;      // [n_leaves][9][64]  v0.xyz v1.xyz v2.xyz
-    const uint32_t *leaf_id;    // [n_leaves][64]     face id or TN_EMPTY
+    const float *leaf_tri;      // [n_leaves][9][leaf_w]  v0.xyz v1.xyz v2.xyz
+    const uint32_t *leaf_id;    // [n_leaves][leaf_w]     face id or TN_EMPTY
+    uint32_t leaf_w;            // faces per leaf block: 16, 32 or 64 (64 / leaf_w leaves are tested per wave instruction)
+    uint32_t leaf_shift;        // log2(leaf_w)
     const float *boxes;         // [n_nodes][6][64]   lo.xyz hi.xyz of the children
     const uint32_t *child;      // [n_nodes][64]      child reference
     uint32_t n_nodes;           // node 0 is the root
@@ -141,6 +143,7 @@ struct HostWideBvh {
     std::vector<float> boxes;
     std::vector<uint32_t> child;
     uint32_t max_stack = 1;  // worst-case entries of the traversal stack (must stay <= STACK_CAP)
+    uint32_t leaf_w = WIDE;  // faces per leaf block
 };
 
 struct HostHullBvh {
@@ -161,7 +164,7 @@ uint32_t wide_bvh_max_stack(const uint32_t *child, size_t n_nodes);
 void build_face_table(size_t T, const uint32_t *cells, HostMesh &out);
 // wide BVH over the faces listed in `ids` (global face ids)
 void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<uint32_t> &ids,
-                    HostWideBvh &out);
+                    HostWideBvh &out, uint32_t leaf_w = WIDE);
 // adjacency records
 void build_tet_records(size_t T, const uint32_t *cells, const float *xyz, const HostMesh &hm,
                        std::vector<TetRec> &out, std::vector<uint32_t> &rec_of_tet);

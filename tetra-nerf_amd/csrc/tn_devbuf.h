@@ -32,7 +32,8 @@ struct DevWideBvh {
     DevBuf<float> leaf_tri, boxes;
     DevBuf<uint32_t> leaf_id, child;
     WideBvh view{};
-    void set_view(size_t n_nodes, float scene_max) {
+    void set_view(size_t n_nodes, float scene_max, uint32_t leaf_w = WIDE) {
+        view.leaf_w = leaf_w; view.leaf_shift = leaf_w == 16 ? 4u : (leaf_w == 32 ? 5u : 6u);
         view.leaf_tri = leaf_tri.p; view.leaf_id = leaf_id.p; view.boxes = boxes.p; view.child = child.p;
         view.n_nodes = (uint32_t)n_nodes;
         view.scene_max = scene_max;
@@ -42,7 +43,7 @@ struct DevWideBvh {
         leaf_id.upload(h.leaf_id);
         boxes.upload(h.boxes);
         child.upload(h.child);
-        set_view(h.child.size() / WIDE, scene_max);
+        set_view(h.child.size() / WIDE, scene_max, h.leaf_w);
     }
 };
 

@@ -91,7 +91,9 @@ void build_face_table(size_t T, const uint32_t *cells, HostMesh &out) {
 }
 
 void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<uint32_t> &ids,
-                    HostWideBvh &out) {
+                    HostWideBvh &out, uint32_t leaf_w) {
+    const size_t LW = leaf_w;   // faces per leaf block
+    out.leaf_w = leaf_w;
     const size_t n = ids.size();
     out.leaf_tri.clear(); out.leaf_id.clear(); out.boxes.clear(); out.child.clear();
     // per-face boxes and centroids
@@ -125,7 +127,7 @@ void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<u
         nd.first = first; nd.count = count; nd.left = nd.right = -1;
         const int me = (int)bn.size();
         bn.push_back(nd);
-        if (count > (uint32_t)WIDE) {
+        if (count > leaf_w) {
             int ax = 0;
             if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
             if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
@@ -144,19 +146,19 @@ void build_wide_bvh(const float *xyz, const uint32_t *faces, const std::vector<u
     std::vector<int> leaf_of(bn.size(), -1);
     for (size_t b = 0; b < bn.size(); ++b) {
         if (bn[b].left >= 0) continue;
-        const size_t l = out.leaf_id.size() / WIDE;
+        const size_t l = out.leaf_id.size() / LW;
         leaf_of[b] = (int)l;
-        out.leaf_tri.resize((l + 1) * 9 * WIDE, 0.0f);
-        out.leaf_id.resize((l + 1) * WIDE, TN_EMPTY);
+        out.leaf_tri.resize((l + 1) * 9 * LW, 0.0f);
+        out.leaf_id.resize((l + 1) * LW, TN_EMPTY);
         for (uint32_t i = 0; i < bn[b].count; ++i) {
             const uint32_t fid = ids[order[bn[b].first + i]];
             const uint32_t *f = faces + 3 * (size_t)fid;
-            out.leaf_id[l * WIDE + i] = fid;
+            out.leaf_id[l * LW + i] = fid;
             for (int v = 0; v < 3; ++v)
-                for (int k = 0; k < 3; ++k) out.leaf_tri[(l * 9 + v * 3 + k) * WIDE + i] = xyz[3 * (size_t)f[v] + k];
+                for (int k = 0; k < 3; ++k) out.leaf_tri[(l * 9 + v * 3 + k) * LW + i] = xyz[3 * (size_t)f[v] + k];
         }
     }
-    if (out.leaf_id.empty()) { out.leaf_tri.assign(9 * WIDE, 0.0f); out.leaf_id.assign(WIDE, TN_EMPTY); }
+    if (out.leaf_id.empty()) { out.leaf_tri.assign(9 * LW, 0.0f); out.leaf_id.assign(LW, TN_EMPTY); }
 
     // 3. collapse to 64-wide nodes: open the child with the largest box until 64 children (or only leaves)
     std::vector<std::pair<int, uint32_t>> todo;  // (binary subtree root, wide node index)
@@ -437,7 +439,7 @@ void build_hull_from_info(const std::vector<float> &info, HostHullBvh &out) {
 // faces splits into count / 2 and count - count / 2 while count > WIDE.  frontier[l] = the partition of [0, n) after
 // l splitting rounds, as node indices in position order (nodes that stopped splitting stay in the later frontiers).
 void build_bin_topology(size_t n, std::vector<core::BinNode> &bn, std::vector<std::vector<uint32_t>> &frontier,
-                        std::vector<uint32_t> &level_start, std::vector<uint32_t> &leaf_nodes) {
+                        std::vector<uint32_t> &level_start, std::vector<uint32_t> &leaf_nodes, uint32_t leaf_w) {
     bn.clear(); frontier.clear(); level_start.clear(); leaf_nodes.clear();
     if (n == 0) return;
     bn.push_back(core::BinNode{0u, (uint32_t)n, -1, -1, -1, 0u});
@@ -446,13 +448,13 @@ void build_bin_topology(size_t n, std::vector<core::BinNode> &bn, std::vector<st
     for (uint32_t level = 0;; ++level) {
         frontier.push_back(cur);
         bool any = false;
-        for (uint32_t k : cur) any = any || bn[k].count > (uint32_t)WIDE;
+        for (uint32_t k : cur) any = any || bn[k].count > leaf_w;
         if (!any) break;
         level_start.push_back((uint32_t)bn.size());
         std::vector<uint32_t> next;
         next.reserve(2 * cur.size());
         for (uint32_t k : cur) {
-            if (bn[k].count > (uint32_t)WIDE && bn[k].left < 0) {
+            if (bn[k].count > leaf_w && bn[k].left < 0) {
                 const uint32_t half = bn[k].count / 2;
                 const int l = (int)bn.size();
                 bn.push_back(core::BinNode{bn[k].first, half, -1, -1, -1, level + 1});

@@ -368,20 +368,31 @@ __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, ui
             wave_sync();
             if (nleaf == 0) return;
             if (lane == 0 && stats) atomicAdd(&stats[23], (unsigned long long)nleaf);
-            auto fetch = [&](uint32_t li, float (&d)[9], uint32_t &fid) {
-                const float *tr = bvh.leaf_tri + (size_t)li * (9 * WIDE) + lane;
+            // one wave instruction tests G = 64 / leaf_w crossed leaves: lane = (leaf of the group, triangle slot)
+            const uint32_t LW = bvh.leaf_w, LS = bvh.leaf_shift, G = 64u >> LS;
+            const uint32_t sub = (uint32_t)lane >> LS, in = (uint32_t)lane & (LW - 1);
+            const uint32_t ngroups = (nleaf + G - 1) / G;
+            auto fetch = [&](uint32_t gi, float (&d)[9], uint32_t &fid) {
+                const uint32_t e = gi * G + sub;
+                fid = TN_EMPTY;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) d[k] = tr[k * WIDE];
-                fid = bvh.leaf_id[(size_t)li * WIDE + lane];
+                for (int k = 0; k < 9; ++k) d[k] = 0.f;
+                if (e < nleaf) {
+                    const size_t li = leaf_list[e];
+                    const float *tr = bvh.leaf_tri + li * (9 * (size_t)LW) + in;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) d[k] = tr[k * LW];
+                    fid = bvh.leaf_id[li * LW + in];
+                }
             };
             // three leaves deep: leaf i + 2 is requested before leaf i is tested (a small batch is one wavefront per ray
             // with every ray resident at once, so a ray's own chain of round trips is the time of the call)
             float cur[9], nx1[9], nx2[9];
             uint32_t cfid, f1 = TN_EMPTY, f2 = TN_EMPTY;
-            fetch(leaf_list[0], cur, cfid);
-            if (nleaf > 1) fetch(leaf_list[1], nx1, f1);
-            for (uint32_t i = 0; i < nleaf && !aborted; ++i) {
-                if (i + 2 < nleaf) fetch(leaf_list[i + 2], nx2, f2);
+            fetch(0, cur, cfid);
+            if (ngroups > 1) fetch(1, nx1, f1);
+            for (uint32_t i = 0; i < ngroups && !aborted; ++i) {
+                if (i + 2 < ngroups) fetch(i + 2, nx2, f2);
                 test_leaf(cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7], cur[8], cfid);
 #pragma unroll
                 for (int k = 0; k < 9; ++k) { cur[k] = nx1[k]; nx1[k] = nx2[k]; }
