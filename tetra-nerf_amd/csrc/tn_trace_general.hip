@@ -312,9 +312,6 @@ __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, ui
                                  float dx, float dy, float dz, unsigned long long *stats, int lane, bool &overflow,
                                  bool defer = false) {
     const RayPre rp = ray_pre(ox, oy, oz, dx, dy, dz);
-    // one ray per wave: its axis permutation as scalars (row selection in `fetch`), its origin in that order
-    const int ukx = __builtin_amdgcn_readfirstlane(rp.kx), uky = __builtin_amdgcn_readfirstlane(rp.ky), ukz = __builtin_amdgcn_readfirstlane(rp.kz);
-    const float okx = pick(ox, oy, oz, rp.kx), oky = pick(ox, oy, oz, rp.ky), okz = pick(ox, oy, oz, rp.kz);
     const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
     const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + bvh.scene_max);
         uint32_t nh = 0;      // hits stored (wave-uniform)
@@ -324,24 +321,9 @@ __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, ui
         // One leaf: 64 triangles against the ray, hits appended to the LDS hit arrays.
         auto test_leaf = [&](float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2,
                              uint32_t fid) {
-            // the vertex components arrive ALREADY in the ray's (kx, ky, kz) order: the wave traces one ray, so the axis
-            // permutation of the shear is a property of the wave and `fetch` applies it to the row it loads (no per-lane
-            // selects); same operations on the same operands as shear() / tri_hit_sv() otherwise
-            auto shear_p = [&](float pkx, float pky, float pkz) {
-                const float akx = pkx - okx, aky = pky - oky, akz = pkz - okz;
-                SV q;
-                q.x = akx - rp.Sx * akz; q.y = aky - rp.Sy * akz; q.z = rp.Sz * akz;
-                return q;
-            };
-            const SV A = shear_p(a0, a1, a2), B = shear_p(b0, b1, b2), C = shear_p(c0, c1, c2);
+            const SV A = shear(rp, a0, a1, a2), B = shear(rp, b0, b1, b2), C = shear(rp, c0, c1, c2);
             float t = 0.f, u = 0.f, v = 0.f;
-            float U = edge_f(B, C), V = edge_f(C, A), W = edge_f(A, B);
-            if (U == 0.0f || V == 0.0f || W == 0.0f) { U = edge_d(B, C); V = edge_d(C, A); W = edge_d(A, B); }
-            const bool mixed = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
-            bool hit = false;
-            if (__ballot(fid != TN_EMPTY && !mixed)) {   // wave-uniform: the three divisions only when some lane is crossed
-                hit = (fid != TN_EMPTY) && tri_finish(U, V, W, A.z, B.z, C.z, t, u, v);
-            }
+            const bool hit = (fid != TN_EMPTY) && tri_hit_sv(A, B, C, t, u, v);
             const uint64_t m = __ballot(hit);
             const uint32_t c = __popcll(m);
             if (c) {
@@ -399,11 +381,7 @@ __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, ui
                     const size_t li = leaf_list[e];
                     const float *tr = bvh.leaf_tri + li * (9 * (size_t)LW) + in;
 #pragma unroll
-                    for (int vtx = 0; vtx < 3; ++vtx) {   // rows (x, y, z) of vertex vtx, taken in the ray's (kx, ky, kz) order
-                        d[3 * vtx] = tr[(3 * vtx + ukx) * LW];
-                        d[3 * vtx + 1] = tr[(3 * vtx + uky) * LW];
-                        d[3 * vtx + 2] = tr[(3 * vtx + ukz) * LW];
-                    }
+                    for (int k = 0; k < 9; ++k) d[k] = tr[k * LW];
                     fid = bvh.leaf_id[li * LW + in];
                 }
             };
