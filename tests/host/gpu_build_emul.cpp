@@ -7,6 +7,7 @@
 // up, greedy 64-wide collapse) and checks the tree's invariants.  Prints "OK ...".
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <random>
@@ -22,6 +23,7 @@ namespace tn { void set_error(const std::string &) {} }
 
 int main(int argc, char **argv) {
     if (argc < 2) return 2;
+    const uint32_t leaf_w = argc > 2 ? (uint32_t)std::atoi(argv[2]) : (uint32_t)tn::WIDE;   // faces per BVH leaf: 16, 32 or 64
     FILE *f = std::fopen(argv[1], "rb");
     if (!f) return 2;
     uint64_t V = 0, T = 0;
@@ -107,7 +109,7 @@ int main(int argc, char **argv) {
     std::vector<core::BinNode> bn;
     std::vector<std::vector<uint32_t>> frontier;
     std::vector<uint32_t> level_start, leaf_nodes;
-    build_bin_topology(F, bn, frontier, level_start, leaf_nodes);
+    build_bin_topology(F, bn, frontier, level_start, leaf_nodes, leaf_w);
     std::vector<float> fb(6 * F), cen(3 * F);
     for (size_t fi = 0; fi < F; ++fi) core::face_box((uint32_t)fi, faces.data(), xyz.data(), &fb[6 * fi], &cen[3 * fi]);
     std::vector<uint32_t> ord(F);
@@ -151,7 +153,7 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> seen(F, 0);
         size_t covered = 0;
         for (uint32_t k : leaf_nodes) {
-            CHECK(bn[k].count >= 1 && bn[k].count <= (uint32_t)WIDE && bn[k].left < 0);
+            CHECK(bn[k].count >= 1 && bn[k].count <= leaf_w && bn[k].left < 0);
             for (uint32_t i = bn[k].first; i < bn[k].first + bn[k].count; ++i) { CHECK(!seen[ord[i]]); seen[ord[i]] = 1; ++covered; }
         }
         CHECK(covered == F);

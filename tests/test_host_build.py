@@ -100,6 +100,7 @@ def test_device_build_emulated_equals_host_build(emul_check, tmp_path, scenes, b
         f.write(struct.pack("<QQ", len(pts), len(cells)))
         f.write(np.ascontiguousarray(pts, np.float32).tobytes())
         f.write(np.ascontiguousarray(cells).astype(np.uint32).tobytes())
-    r = subprocess.run([str(emul_check), str(path)], capture_output=True, text=True)
-    assert r.returncode == 0 and r.stdout.startswith("OK"), (r.stdout, r.stderr)
-    assert f"variants {4 * len(cells)}" in r.stdout
+    for leaf_width in (16, 64):     # 16 = the default of the face BVH, 64 = one leaf per wave instruction
+        r = subprocess.run([str(emul_check), str(path), str(leaf_width)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.startswith("OK"), (leaf_width, r.stdout, r.stderr)
+        assert f"variants {4 * len(cells)}" in r.stdout
