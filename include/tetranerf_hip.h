@@ -197,7 +197,7 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
 /* knobs (also settable through the environment):
  *   "walk"    1 = adjacency-walk fast path with general-path fallback (default when built),
  *             0 = general all-hits path for every ray, 2 = walk for any batch size
- *   "walk_min_rays"  smallest batch the walk is used for (default 6144; below it one wavefront per
+ *   "walk_min_rays"  smallest batch the walk is used for (default 12288; below it one wavefront per
  *             ray through the wide BVH has the lower latency)
  *   "dense_tails"  1 (default) = every slot of the [R,M] rows is written, as the reference does;
  *             0 = slots >= num_visited[r] of walked rows are left UNWRITTEN (non-reference: for callers

@@ -73,7 +73,9 @@ struct tn_tracer {
     uint32_t *kmax() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 2; }
     size_t last_num_rays = 0;
     int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
-    size_t walk_min_rays = 6144;         // measured crossover on the 300k-tet mesh (profiles/r02_small_batch.txt)
+    size_t walk_min_rays = 12288;        // measured crossover on the 300k-tet mesh after round 2b's faster BVH path
+                                         // (profiles/r02t_crossover.txt: 8192 rays 0.46-0.49 vs 0.61-0.71 ms, 12288 rays 0.68-0.90 vs
+                                         //  0.67-0.82 ms, 16384 rays 0.89-1.16 vs 0.67-0.84 ms; round 2a: 6144)
     bool last_walk = false;
     uint32_t debug = 0;
     uint32_t gdebug = 0;
