@@ -96,11 +96,11 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
     full = {}
     configs = (("coarse-256", (samples, 0, False)), ("tetra-nerf-original", (256, 256, False)), ("tetra-nerf", (128, 128, True)))
     for mode in ("fp32", "bf16x3"):
-        tn.cpp.mlp_set_mode(mode)
         for name, (s_c, s_f, biased) in configs:
             if mode == "fp32" and s_f == 0:
                 continue  # that is `dt` above
-            dtf = timed(render.TetraRenderer(tracer, field, mlp, s_c, M, fused=True, num_fine_samples=s_f, biased=biased))
+            dtf = timed(render.TetraRenderer(tracer, field, mlp, s_c, M, fused=True, num_fine_samples=s_f, biased=biased,
+                                             mlp_mode=mode))
             full.setdefault(name, {"samples_per_ray": f"{s_c} coarse" + (f" (density only) + {s_c + s_f + 1} fine" if s_f else "")})
             full[name][mode] = {"rendered_rays_per_s": R / dtf, "ms_per_frame": dtf * 1e3}
             if mode == "fp32":
@@ -110,7 +110,6 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
                 dtu = timed(render.TetraRenderer(tracer, field, mlp, s_c, M, fused=True, num_fine_samples=s_f, biased=biased,
                                                  fused_pass=True))
                 full[name]["fp32_one_launch_per_pass"] = {"rendered_rays_per_s": R / dtu, "ms_per_frame": dtu * 1e3}
-    tn.cpp.mlp_set_mode("fp32")
     # MLP kernel alone on one chunk worth of samples of hitting rays (MFMA roofline)
     n = min(hit, chunk) * samples
     feats = torch.randn(64, n, device=dev)
@@ -127,15 +126,13 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
     mlp_ms = e0.elapsed_time(e1) / 5
     flop = 2 * (64 * 128 + 128 * 128 * 2 + 128 + 155 * 128 + 128 * 3)
     tf = n * flop / (mlp_ms * 1e-3) / 1e12
-    tn.cpp.mlp_set_mode("bf16x3")
     for _ in range(2):
-        tn.cpp.mlp_forward(feats, dirs, w, samples)
+        tn.cpp.mlp_forward(feats, dirs, w, samples, mode="bf16x3")
     e0.record()
     for _ in range(5):
-        tn.cpp.mlp_forward(feats, dirs, w, samples)
+        tn.cpp.mlp_forward(feats, dirs, w, samples, mode="bf16x3")
     e1.record()
     torch.cuda.synchronize()
-    tn.cpp.mlp_set_mode("fp32")
     x3_ms = e0.elapsed_time(e1) / 5
     return {"rendered_rays_per_s": R / dt, "ms_per_frame": dt * 1e3, "rays": R, "hitting_rays": hit,
             "samples_per_ray": samples, "pass": "coarse only (uniform samples), 65,536-ray chunks: match kernel, fused gather + MLP kernel, composite kernel",

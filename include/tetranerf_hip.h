@@ -194,8 +194,8 @@ int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]);
  * all others are re-traced through the BVH all-hits path. */
 int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
 
-/* knobs (also settable through the environment):
- *   "walk"    1 = adjacency-walk fast path with general-path fallback (default when built),
+/* knobs ("walk" and "gpu_build" also through the environment: TETRANERF_HIP_WALK, TETRANERF_HIP_GPU_BUILD):
+ *   "walk"    1 = adjacency-walk fast path with general-path fallback (default),
  *             0 = general all-hits path for every ray, 2 = walk for any batch size
  *   "walk_min_rays"  smallest batch the walk is used for (default 12288; below it one wavefront per
  *             ray through the wide BVH has the lower latency)
@@ -203,22 +203,20 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *             0 = slots >= num_visited[r] of walked rows are left UNWRITTEN (non-reference: for callers
  *             that only read rows through num_visited, e.g. tn_find_matched_cells; saves ~88 % of the bytes)
  *   "literal" 1 (default) = rays whose order the walk cannot certify have their logged hits sorted and paired
- *             literally; 0 = they are re-traced through the BVH all-hits path (ablation / cross-check)
- *   "prefill" 1 = the tail slots no certified ray reaches are streamed beside the segment writer (default 0:
- *             measured slower, the latency-bound segment writer crawls beside a saturating fill)
- *   "log_cap_mb"  cap of the hit log (default 24576): larger calls are processed in ray chunks
+ *             literally; 0 = they are re-traced through the BVH all-hits path (cross-check of the two paths)
+ *   "spec_fill"  1 (default) = the last quarter of every row (slots no ray of this mesh is expected to reach) is
+ *             filled beside the walk on a stream of its own; 0 = the whole tail fill after the segment writer.
+ *             "spec_k0" = first speculatively filled slot (multiple of 32; 0 = the quarter rule) -- tests force it low
+ *             so that rays of every class overwrite speculatively filled slots
+ *   "log_cap_mb"  cap of the hit log in MiB (0 = default: a quarter of the free device memory, at most 24 GiB);
+ *             larger calls are processed in ray chunks
  *   "gpu_build"  1 (default) = load_tetrahedra builds its structures on the device; 0 = single-threaded host build
  *   "leaf_width" 16 (default) / 32 / 64: faces per leaf of the face BVH (applies at the next tn_load_tetrahedra); the BVH
  *             path tests 64 / leaf_width crossed leaves per wave instruction
  *   "small_lds"  1 (default) = batches below walk_min_rays use LDS hit arrays sized for the mesh (every ray resident at
  *             once) and re-trace the rays with more hits in a second launch; "lds_cap" forces their size (tests)
- *   "spec_fill"  1 (default) = the last quarter of every row (slots no ray of this mesh is expected to reach) is
- *             filled beside the walk on a stream of its own; 0 = the whole tail fill after the segment writer
- *   measured and left off (all bit-identical; profiles/r02b..r02l): "literal_rows" 0 = literal pairing as an emit mask
- *             for the segment writer; "log_records" 1 = the walk also logs the record fields the writer needs;
- *             "pipe" N = walk / writer pipelined over N ray chunks; "seg_variant" 0 = direct (not LDS-staged) segment
- *             stores; "side_late" 0 / "aux_general" 0 = round 2a's side-stream schedule
- *   "fill_blocks", "seg_blocks", "seg_unroll", "debug", "gdebug": ablation knobs (profiles/) */
+ *   "seg_unroll" 4 / 2, "seg_blocks": shape of the segment writer (hits per ray per iteration; grid cap)
+ * Unknown names are an error. */
 int tn_set_option(tn_tracer_t tracer, const char *name, int value);
 
 /* gather_uint32<T> / scatter_ema_uint32<T>              src/tetrahedra_tracer.cu:30-113,
@@ -246,17 +244,31 @@ typedef struct tn_mlp_weights {
     const float *wr, *br; /* [3,128],   [3]    rgb head      */
 } tn_mlp_weights;
 
-/* feats f32 [64, n] feature-major (the buffer tn_interpolate_values writes), dirs f32 [n/samples_per_ray, 3]
+/* A handle owns the packed forms of ONE set of weights (per kernel family: fp32-MFMA forward with / without the fused
+ * gather, bf16x3 pieces, transposed for the backward pass) and the small per-call scratch (direction encodings): the
+ * entry points below neither pack nor allocate.  tn_mlp_set_weights packs; call it once per parameter VERSION (after
+ * an optimiser step, after loading a checkpoint).  One handle serves one stream at a time. */
+typedef struct tn_mlp *tn_mlp_t;
+int tn_mlp_create(int device, tn_mlp_t *out);
+int tn_mlp_destroy(tn_mlp_t mlp);
+int tn_mlp_set_weights(tn_mlp_t mlp, const tn_mlp_weights *weights, void *stream);
+
+/* Arithmetic `mode` of the two forward entry points (per call):
+ *   0  v_mfma_f32_32x32x2_f32: an exact fp32 fma chain (157 TFLOP/s peak) -- what every parity claim refers to;
+ *   1  "bf16x3": v_mfma_f32_32x32x16_bf16 on operands split into three bf16 pieces, six partial products per
+ *      multiply, fp32 accumulation: dropped terms < 2^-24 of a product at 2.67x fewer matrix-core cycles (opt-in).
+ * feats f32 [64, n] feature-major (the buffer tn_interpolate_values writes), dirs f32 [n/samples_per_ray, 3]
  * (one direction per ray; samples of a ray are consecutive) -> sigma f32 [n] (softplus), rgb f32 [n,3] (sigmoid).
  * rgb == NULL: density only (mlp_base + density head: the coarse pass of the model, model.py:577-581); dirs unused. */
-int tn_mlp_forward(size_t n, uint32_t samples_per_ray, const float *feats, const float *dirs,
-                   const tn_mlp_weights *weights, float *sigma, float *rgb, void *stream);
+int tn_mlp_forward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const float *feats, const float *dirs, int mode,
+                   float *sigma, float *rgb, void *stream);
 
 /* the same with the barycentric gather fused in (tn_interpolate_values<4> + tn_mlp_forward without the
- * [64,n] intermediate): vertex_indices u32 [n,4], barycentric f32 [n,3], field f32 [64,V] feature-major */
-int tn_mlp_forward_gather(size_t n, uint32_t samples_per_ray, uint32_t num_vertices,
-                          const uint32_t *vertex_indices, const float *barycentric, const float *field,
-                          const float *dirs, const tn_mlp_weights *weights, float *sigma, float *rgb, void *stream);
+ * [64,n] intermediate): vertex_indices u32 [n,4], barycentric f32 [n,3], field_vm f32 [V,64] VERTEX-major
+ * (tn_transpose_f32 of the [64,V] parameter, refreshed by the caller once per field version) */
+int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices,
+                          const float *barycentric, const float *field_vm, const float *dirs, int mode, float *sigma,
+                          float *rgb, void *stream);
 
 /* One render PASS of TetrahedraNerf.get_outputs as ONE launch (reference span
  * tetranerf/nerfstudio/model.py:560-662 = find_visited_cells -> interpolate_values -> mlp_base + heads -> get_weights ->
@@ -267,23 +279,11 @@ int tn_mlp_forward_gather(size_t n, uint32_t samples_per_ray, uint32_t num_verti
  *   dirs == NULL : density-only coarse pass (model.py:577-582): out_weights f32 [r, S] = get_weights.
  *   dirs f32 [r,3]: full pass: out_rgb f32 [R,3], out_acc f32 [R], out_depth f32 [R] (arrays over ALL rays of the trace
  *                  call, written at ray_index[q]; pre-fill them with the background values); out_weights optional.
- * Always the fp32 MFMA arithmetic (tn_mlp_set_mode does not apply). */
-int tn_render_pass(uint32_t max_ray_triangles, const uint32_t *num_visited, const float *hit_distances,
+ * Always the fp32 MFMA arithmetic. */
+int tn_render_pass(tn_mlp_t mlp, uint32_t max_ray_triangles, const uint32_t *num_visited, const float *hit_distances,
                    const float *barycentric, const uint32_t *vertex_indices, const uint32_t *ray_index, size_t num_hit_rays,
                    uint32_t num_samples, const float *edges, const float *field_vm, const float *dirs,
-                   const tn_mlp_weights *weights, float background, float *out_weights, float *out_rgb, float *out_acc,
-                   float *out_depth, void *stream);
-
-/* Arithmetic of tn_mlp_forward / tn_mlp_forward_gather (process-wide):
- *   0 (default)  v_mfma_f32_32x32x2_f32: an exact fp32 fma chain (157 TFLOP/s peak);
- *   1 "bf16x3"   v_mfma_f32_32x32x16_bf16 on operands split into three bf16 pieces, six partial products per
- *                multiply, fp32 accumulation: fp32-grade accuracy (dropped terms < 2^-24 of a product; the 1e-5
- *                parity tests run in both modes) at 2.67x fewer matrix-core cycles. */
-int tn_mlp_set_mode(int mode);
-int tn_mlp_get_mode(void);
-/* shape of the fp32 forward kernel (process-wide; ablation): 0 / 512 = one 8-wave block per CU (default), 256 = two
- * 4-wave blocks per CU (head layer staged in two halves): same arithmetic, same results, measured neutral */
-int tn_mlp_set_block(int block);
+                   float background, float *out_weights, float *out_rgb, float *out_acc, float *out_depth, void *stream);
 
 /* RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers.
  * sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1] (bin edges: starts = edges[:, :-1], ends = edges[:, 1:]);
@@ -295,7 +295,7 @@ int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, cons
 
 /* ---- training adjoints of the MLP and the composite (PyTorch autograd in the reference:
  * the trainer back-propagates through nerfstudio's MLP / renderers, model.py:602-638).
- * tn_mlp_backward recomputes the forward pass (nothing is saved by tn_mlp_forward_gather) and runs the reverse
+ * tn_mlp_backward (weights: the handle's) recomputes the forward pass (nothing is saved by tn_mlp_forward_gather) and runs the reverse
  * network on the fp32 matrix cores.  All buffers are FEATURE-MAJOR [F, n] device memory owned by the caller:
  *   x0 [64,n] gathered features; h1..h4 [128,n] layer outputs after ReLU; d1..d4 [128,n] gradients w.r.t. the
  *   pre-activations of mlp_base layers 0..2 and of mlp_head; dhead [4,n] = d sigma_raw, d rgb_raw[0..2];
@@ -306,9 +306,9 @@ int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, cons
 typedef struct tn_mlp_backward_buffers {
     float *x0, *h1, *h2, *h3, *h4, *d1, *d2, *d3, *d4, *dhead, *dx0;
 } tn_mlp_backward_buffers;
-int tn_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices, const float *barycentric,
-                    const float *field_vm, const float *dirs, const tn_mlp_weights *weights, const float *d_sigma,
-                    const float *d_rgb, const tn_mlp_backward_buffers *buffers, void *stream);
+int tn_mlp_backward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices, const float *barycentric,
+                    const float *field_vm, const float *dirs, const float *d_sigma, const float *d_rgb,
+                    const tn_mlp_backward_buffers *buffers, void *stream);
 int tn_mlp_weight_grad(size_t n, uint32_t rows_b, const float *a, const float *b, float *dw, float *db, void *stream);
 /* the narrow heads and the direction-encoding columns of mlp_head: out f32 [4,128] += (dhead[0] . h3 rows = d wd,
  * dhead[1+c] . h4 rows = d wr[c]); ray_sum f32 [128, n / samples_per_ray] = per-ray sums of d4 (d Wh[:, :27] = ray_sum @ enc) */

@@ -30,8 +30,8 @@ for case in range(n_cases):
     # round 2b: every path variant is drawn at random (all must be bit-identical): walk or BVH path for every ray, device
     # or host structure build, literal pairing as rows or as an emit mask, 16-byte or fat hit log, LDS-staged or direct
     # segment stores, mesh-sized LDS hit arrays with a forced tiny capacity (overflow relaunch)
-    opts = {"walk": int(rng.choice([2, 2, 0])), "gpu_build": int(rng.integers(0, 2)), "literal_rows": int(rng.integers(0, 2)),
-            "log_records": int(rng.integers(0, 2)), "seg_variant": int(rng.integers(0, 2)), "lds_cap": int(rng.choice([0, 0, 16, 64]))}
+    opts = {"walk": int(rng.choice([2, 2, 0])), "gpu_build": int(rng.integers(0, 2)), "literal": int(rng.integers(0, 2)),
+            "spec_k0": int(rng.choice([0, 32, 96])), "seg_unroll": int(rng.choice([2, 4])), "lds_cap": int(rng.choice([0, 0, 16, 64]))}
     for k, v in opts.items(): tr.set_option(k, v)
     tr.load_tetrahedra(torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev))
     got = tr.trace_rays(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), M)

@@ -154,7 +154,8 @@ def test_adversarial_meshes_bit_exact(tn, device, oracle, scenes, name):
     pts, cells = ADVERSARIAL[name](scenes)
     ot = _oracle(oracle, pts, cells)
     flagged = {}
-    for walk, extra in ((2, {}), (2, {"prefill": 1}), (0, {})):
+    # default schedule; speculative tail fill forced down to slot 64 + the 4-waves-per-SIMD segment writer; BVH path
+    for walk, extra in ((2, {}), (2, {"spec_k0": 64, "seg_unroll": 2}), (0, {})):
         tr = _tracer(tn, device, pts, cells, walk=walk, **extra)
         for sname, (o, d) in _ray_sets(scenes, pts, 20000, 40, pts.min(0), pts.max(0)).items():
             out = _trace(tr, device, o, d, 512)
@@ -212,6 +213,76 @@ def test_randomised_stress_sample(tn, device, oracle, scenes):
         else:
             w = int(np.sqrt(R))
             o, d = scenes.pinhole_rays(w, w, eye=(0.5 + 1.7 * np.cos(seed), 0.5 + 1.7 * np.sin(seed), 0.6), lookat=(0.5, 0.5, 0.5))
-        tr = _tracer(tn, device, pts, cells, walk=2, prefill=int(rng.choice([0, 1])))
+        tr = _tracer(tn, device, pts, cells, walk=2, spec_k0=int(rng.choice([0, 32, 96])), seg_unroll=int(rng.choice([2, 4])),
+                     literal=int(rng.choice([0, 1, 1])))
         _compare(_trace(tr, device, o, d, M), _oracle(oracle, pts, cells), o, d, M,
                  ctx=f"stress case {case}: npts={npts} seed={seed} M={M} kind={kind}")
+
+
+# ------------------------------------------------------------------------------------------------ heuristics under stress
+def test_speculative_fill_is_overwritten_by_every_ray_class(tn, device, oracle, scenes):
+    """The speculative tail fill writes slots [K0, M) of EVERY row beside the walk, K0 from a uniform-mesh heuristic
+    (default: the last quarter of the row); the segment writer (certified rays), k_postprocess_log (literal rays) and the
+    BVH kernel (fallback rays) are ordered behind it and must overwrite those slots when a ray has more than K0
+    segments.  Clustered mesh (dense core: 86 % of the rays aimed at it cross more than 3M/4 = 192 faces at M = 256,
+    1 % overflow M - 1), rays of all three classes, K0 = default / 64 / 32: bit-exact against the oracle incl. every
+    tail byte."""
+    import torch
+
+    pts, cells = scenes.dense_core_mesh()
+    ot = _oracle(oracle, pts, cells)
+    M = 256
+    co, cd = scenes.core_rays(14000, 5)
+    core_pts = pts[np.linalg.norm(pts - 0.5, axis=1) < 0.08]
+    vo, vd = scenes.vertex_to_vertex_rays(core_pts, 5000, 6, extend=1.2)
+    oo, od = scenes.outside_in_rays(3000, 7)
+    o = np.ascontiguousarray(np.concatenate([co, vo, oo], 0))
+    d = np.ascontiguousarray(np.concatenate([cd, vd, od], 0))
+    want = ot.trace_rays(o, d, M)
+    long_rays = np.nonzero(want["num_visited_cells"] > 3 * M // 4)[0]
+    assert len(long_rays) > 10000
+    # every class of the walk occurs among the rays that reach into the speculatively filled quarter
+    tr = _tracer(tn, device, pts, cells, walk=2)
+    _trace(tr, device, np.ascontiguousarray(o[long_rays]), np.ascontiguousarray(d[long_rays]), M)
+    st, why = tr.trace_stats(), tr.flag_reasons()
+    assert st["walk"] > 1000 and why.get(13, 0) > 50 and sum(v for k, v in why.items() if k in (1, 2, 3, 4, 5, 6, 9, 10, 11)) > 50, (st, why)
+    for k0 in (0, 64, 32):
+        for unroll in (4, 2):
+            tr.set_option("spec_k0", k0)
+            tr.set_option("seg_unroll", unroll)
+            out = _trace(tr, device, o, d, M)
+            for k in KEYS:
+                g = out[k].cpu().numpy()
+                assert np.array_equal(g.view(np.uint32), np.ascontiguousarray(want[k]).view(np.uint32)), f"spec_k0={k0} unroll={unroll}: {k}"
+    # the same with the fill switched off and through the BVH path alone
+    for opts in ({"spec_fill": 0}, {"walk": 0}):
+        tr2 = _tracer(tn, device, pts, cells, **{"walk": 2, **opts})
+        out = _trace(tr2, device, o, d, M)
+        for k in KEYS:
+            assert np.array_equal(out[k].cpu().numpy().view(np.uint32), np.ascontiguousarray(want[k]).view(np.uint32)), f"{opts}: {k}"
+
+
+@pytest.mark.parametrize("M,npts", [(1024, 20000), (1024, 40000), (2048, 40000), (4096, 40000)])
+def test_max_ray_triangles_above_512(tn, device, oracle, scenes, M, npts):
+    """max_ray_triangles 1024 / 2048 / 4096 (the model's default is 512, model.py:77; the C-ABI accepts up to 4096) on a
+    mesh whose rays cross 800 - 1100 faces: the walk path (hit log of 16 M bytes per ray), the BVH path (up to 108 KB of
+    LDS hit arrays per wavefront) and -- (1024, 40000) -- the overflow rule (keep the M - 1 nearest hits) on 2/3 of the
+    rays, bit-exact against the oracle."""
+    pts, cells = scenes.needle_mesh(npts)
+    ot = _oracle(oracle, pts, cells)
+    o, d = scenes.needle_rays(2048, 3)
+    o2, d2 = scenes.outside_in_rays(1024, 4)
+    o, d = np.ascontiguousarray(np.concatenate([o, o2], 0)), np.ascontiguousarray(np.concatenate([d, d2], 0))
+    want = ot.trace_rays(o, d, M)
+    nv = want["num_visited_cells"]
+    assert (nv > 512).mean() > 0.5, np.percentile(nv, [1, 50, 99])
+    if (M, npts) == (1024, 40000):
+        assert (nv >= M - 2).mean() > 0.3          # most needle rays overflow
+    else:
+        assert (nv >= M - 2).mean() < 0.01
+    for walk in (2, 0):
+        tr = _tracer(tn, device, pts, cells, walk=walk)
+        out = _trace(tr, device, o, d, M)
+        for k in KEYS:
+            assert np.array_equal(out[k].cpu().numpy().view(np.uint32), np.ascontiguousarray(want[k]).view(np.uint32)), f"M={M} walk={walk}: {k}"
+        del out

@@ -15,12 +15,9 @@ def render():
 
 
 @pytest.fixture(params=["fp32", "bf16x3"])
-def mlp_mode(request, tn):
-    """Both arithmetic modes of the fused MLP kernel (tn_mlp_set_mode) against the same 1e-5 bar."""
-    tn.cpp.mlp_set_mode(request.param)
-    assert tn.cpp.mlp_get_mode() == request.param
-    yield request.param
-    tn.cpp.mlp_set_mode("fp32")
+def mlp_mode(request):
+    """Both arithmetic modes of the fused MLP kernels (a per-call argument) against the same 1e-5 bar."""
+    return request.param
 
 
 def _model(render, seed=0, field_scale=1.0):
@@ -43,7 +40,7 @@ def test_mlp_forward_matches_torch(tn, device, render, mlp_mode):
             ws, wc = mlp(feats.double().float(), dirs[:, None, :].expand(R, S, 3).reshape(n, 3))
         gm = mlp.to(device)
         feats_fm = feats.t().contiguous().to(device)
-        sigma, rgb = tn.cpp.mlp_forward(feats_fm, dirs.to(device), render.mlp_weights(gm), S)
+        sigma, rgb = tn.cpp.mlp_forward(feats_fm, dirs.to(device), render.mlp_weights(gm), S, mode=mlp_mode)
         mlp.cpu()
         np.testing.assert_allclose(sigma.cpu().numpy(), ws[:, 0].numpy(), rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(rgb.cpu().numpy(), wc.numpy(), rtol=0, atol=1e-5)
@@ -66,8 +63,8 @@ def test_mlp_forward_gather_equals_two_step(tn, device, render, mlp_mode):
     tvi, tbc = torch.from_numpy(vi).to(device), torch.from_numpy(bc).to(device)
     w = render.mlp_weights(mlp)
     feats = tn.cpp.interpolate_values(tvi, tbc, field)
-    s2, c2 = tn.cpp.mlp_forward(feats.moveaxis(-1, 0).reshape(64, -1), dirs, w, S)
-    s1, c1 = tn.cpp.mlp_forward_gather(tvi, tbc, field, dirs, w, S)
+    s2, c2 = tn.cpp.mlp_forward(feats.moveaxis(-1, 0).reshape(64, -1), dirs, w, S, mode=mlp_mode)
+    s1, c1 = tn.cpp.mlp_forward_gather(tvi, tbc, field, dirs, w, S, mode=mlp_mode)
     np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(c1.cpu().numpy(), c2.cpu().numpy(), rtol=0, atol=2e-6)
     with torch.no_grad():
@@ -90,8 +87,8 @@ def test_density_only_and_weights_only(tn, device, render, mlp_mode):
     dirs = torch.nn.functional.normalize(torch.randn(R, 3, device=device), dim=-1)
     tvi, tbc = torch.from_numpy(vi).to(device), torch.from_numpy(bc).to(device)
     w = render.mlp_weights(mlp)
-    s_full, _ = tn.cpp.mlp_forward_gather(tvi, tbc, field, dirs, w, S)
-    s_only = tn.cpp.mlp_forward_gather(tvi, tbc, field, None, w, S)
+    s_full, _ = tn.cpp.mlp_forward_gather(tvi, tbc, field, dirs, w, S, mode=mlp_mode)
+    s_only = tn.cpp.mlp_forward_gather(tvi, tbc, field, None, w, S, mode=mlp_mode)
     # the density head alone accumulates the same products in the same order as the 5th tile of the head layer
     np.testing.assert_allclose(s_only.cpu().numpy(), s_full.cpu().numpy(), rtol=1e-6, atol=1e-6)
     edges = (1 + torch.cumsum(torch.rand(R, S + 1, device=device) * 0.02, -1)).contiguous()
@@ -115,7 +112,7 @@ def test_mlp_forward_vs_float64(tn, device, render, mlp_mode):
     with torch.no_grad():
         ws, wc = m64(feats.double(), dirs.double()[:, None, :].expand(R, S, 3).reshape(-1, 3))
     gm = mlp.to(device)
-    sigma, rgb = tn.cpp.mlp_forward(feats.t().contiguous().to(device), dirs.to(device), render.mlp_weights(gm), S)
+    sigma, rgb = tn.cpp.mlp_forward(feats.t().contiguous().to(device), dirs.to(device), render.mlp_weights(gm), S, mode=mlp_mode)
     assert float((sigma.cpu().double() - ws[:, 0]).abs().max()) < 5e-6
     assert float((rgb.cpu().double() - wc).abs().max()) < 2e-6
 
@@ -171,7 +168,7 @@ def test_render_c3(tn, device, oracle, scenes, render, cfg, mlp_mode):
     field[1:4] = torch.rand(3, len(pts)) * 2 - 1
     if cfg != "coarse":
         field[0] = torch.rand(len(pts)) * 6 - 3    # a density-driving row so that the PDF pass has structure
-    o, d = scenes.outside_in_rays(4096 if cfg == "coarse" else 1024, 7)
+    o, d = scenes.outside_in_rays(4096, 7)   # BASELINE configs[2]: 4096 rays, all three configurations
     M = 512
 
     class CpuTracer:
@@ -202,16 +199,19 @@ def test_render_c3(tn, device, oracle, scenes, render, cfg, mlp_mode):
     # match / fused gather+MLP / composite kernels; fused=False: the HIP ops + the PyTorch MLP
     for fused, fused_pass in ((True, True), (True, False), (False, False)):
         rd = render.TetraRenderer(tr, field.to(device), gm, S, M, fused=fused, num_fine_samples=S_fine, biased=biased,
-                                  fused_pass=fused_pass)
+                                  fused_pass=fused_pass, mlp_mode=mlp_mode)
         got = rd.render(torch.from_numpy(o).to(device), torch.from_numpy(d).to(device))
         assert torch.equal(got["ray_mask"].cpu(), want["ray_mask"])
         np.testing.assert_allclose(got["rgb"].cpu().numpy(), want["rgb"].numpy(), rtol=0, atol=1e-5,
                                    err_msg=f"fused={fused} fused_pass={fused_pass}")
         np.testing.assert_allclose(got["accumulation"].cpu().numpy(), want["accumulation"].numpy(), rtol=0, atol=1e-5)
-        # (median depth: decided rays are asserted at 1e-5 in test_composite_matches_torch, where the cumulative weights
-        #  are at hand; here only the undecided ones -- cumulative weight within round-off of 0.5 -- may differ)
-        dd = np.isclose(got["depth"].cpu().numpy(), want["depth"].numpy(), rtol=0, atol=1e-4)
-        assert dd.mean() > 0.98
+        # median depth: asserted at 1e-5 on every DECIDED ray (cumulative weights further than 1e-4 from the threshold
+        # 0.5 at every sample -- two fp32 evaluations of the same weights cannot disagree about the median bin then);
+        # undecided rays may land in a neighbouring bin
+        decided = (want["depth_margin"].numpy() > 1e-4)[:, 0]
+        assert decided.mean() > 0.9
+        np.testing.assert_allclose(got["depth"].cpu().numpy()[decided], want["depth"].numpy()[decided], rtol=0, atol=1e-5,
+                                   err_msg=f"depth fused={fused} fused_pass={fused_pass}")
 
 
 @pytest.mark.parametrize("S", [64, 100, 256, 513])
@@ -222,7 +222,6 @@ def test_render_pass_equals_unfused_kernels(tn, device, scenes, render, S):
     import torch
 
     cpp = tn.cpp
-    assert cpp.mlp_get_mode() == "fp32"
     pts, cells = scenes.random_mesh(4000, 11)
     torch.manual_seed(3)
     gm = render.TetraMLP().to(device)
@@ -254,7 +253,7 @@ def test_render_pass_equals_unfused_kernels(tn, device, scenes, render, S):
     torch.testing.assert_close(got_w, want_w, rtol=0, atol=2e-6)
     # full pass
     sigma, col = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], field, dirs, w, S)
-    want_rgb, want_acc, want_depth = cpp.composite(sigma.view(-1, S), col.view(-1, S, 3), edges)
+    want_rgb, want_acc, want_depth, want_wf = cpp.composite(sigma.view(-1, S), col.view(-1, S, 3), edges, return_weights=True)
     R = o.shape[0]
     rgb = torch.ones((R, 3), device=device); acc = torch.zeros((R, 1), device=device); depth = torch.full((R, 1), 1000.0, device=device)
     cpp.render_pass(lists, ridx, edges, field, dirs, w, out=(rgb, acc, depth))
@@ -262,5 +261,7 @@ def test_render_pass_equals_unfused_kernels(tn, device, scenes, render, S):
     torch.testing.assert_close(acc[idx].reshape(-1), want_acc.reshape(-1), rtol=0, atol=2e-6)
     miss = torch.ones(R, dtype=torch.bool, device=device); miss[idx] = False
     assert bool((rgb[miss] == 1).all()) and bool((acc[miss] == 0).all()) and bool((depth[miss] == 1000.0).all())
-    same = torch.isclose(depth[idx].reshape(-1), want_depth.reshape(-1), rtol=0, atol=1e-6)
-    assert float(same.float().mean()) > 0.99   # undecided medians (cumulative weight within round-off of 0.5) may flip
+    # median depth at 1e-5 on every decided ray (cumulative weights further than 1e-4 from the threshold at every sample)
+    decided = render.median_margin(want_wf)[:, 0] > 1e-4
+    assert float(decided.float().mean()) > 0.9
+    torch.testing.assert_close(depth[idx].reshape(-1)[decided], want_depth.reshape(-1)[decided], rtol=0, atol=1e-5)

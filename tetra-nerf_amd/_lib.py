@@ -19,7 +19,7 @@ SYMBOLS = (
     "tn_interpolate_values", "tn_interpolate_values_backward", "tn_interpolate_values_backward_rows",
     "tn_transpose_f32", "tn_interpolate_values_vm", "tn_interpolate_values_backward_vm",
     "tn_postprocess_hits", "tn_postprocess_hits_tables",
-    "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_set_mode", "tn_mlp_get_mode", "tn_mlp_set_block",
+    "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_create", "tn_mlp_destroy", "tn_mlp_set_weights",
     "tn_mlp_forward", "tn_mlp_forward_gather", "tn_render_pass", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
     "tn_mlp_backward", "tn_mlp_weight_grad", "tn_mlp_head_grad", "tn_composite_backward",
 )
@@ -65,16 +65,16 @@ def load():
     lib.tn_trace_stats.argtypes = [vp, C.POINTER(C.c_uint64 * 4)]
     lib.tn_trace_flag_reasons.argtypes = [vp, C.POINTER(C.c_uint64 * 16)]
     lib.tn_set_option.argtypes = [vp, C.c_char_p, i32]
-    lib.tn_mlp_set_mode.argtypes = [i32]
-    lib.tn_mlp_get_mode.argtypes = []
-    lib.tn_mlp_set_block.argtypes = [i32]
-    lib.tn_mlp_forward.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp]
-    lib.tn_mlp_forward_gather.argtypes = [sz, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.tn_render_pass.argtypes = [u32, vp, vp, vp, vp, vp, sz, u32, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
+    lib.tn_mlp_create.argtypes = [i32, C.POINTER(vp)]
+    lib.tn_mlp_destroy.argtypes = [vp]
+    lib.tn_mlp_set_weights.argtypes = [vp, vp, vp]
+    lib.tn_mlp_forward.argtypes = [vp, sz, u32, vp, vp, i32, vp, vp, vp]
+    lib.tn_mlp_forward_gather.argtypes = [vp, sz, u32, vp, vp, vp, vp, i32, vp, vp, vp]
+    lib.tn_render_pass.argtypes = [vp, u32, vp, vp, vp, vp, vp, sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
     lib.tn_gather_uint32.argtypes = [i32, u32, u32, vp, vp, vp, vp]
     lib.tn_scatter_ema_uint32.argtypes = [i32, u32, u32, vp, C.c_double, vp, vp, vp]
     lib.tn_composite.argtypes = [sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
-    lib.tn_mlp_backward.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tn_mlp_backward.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_mlp_weight_grad.argtypes = [sz, u32, vp, vp, vp, vp, vp]
     lib.tn_mlp_head_grad.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_composite_backward.argtypes = [sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]

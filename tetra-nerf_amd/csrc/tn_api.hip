@@ -1,6 +1,5 @@
 // tn_api.hip -- the C-ABI of libtetranerf_hip.so (see include/tetranerf_hip.h).
 #include <algorithm>
-#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -30,39 +29,21 @@ struct tn_tracer {
     tn::DevBuf<uint32_t> faces, face_tets, fallback_list, walk_n;
     tn::DevBuf<uint2> literal_list;      // rays whose logged hits go through the literal sort + pairing
     tn::DevBuf<uint4> hit_log;           // walk -> segment writer / literal pairing: 16 B per recorded hit, [rays / 64][M][64]
-    tn::DevBuf<uint4> hit_log_v;         // "fat log": + the vertex ids of the tet a hit closes (16 B) and its tet id | combine code (4 B),
-    tn::DevBuf<uint32_t> hit_log_o;      //   so that the segment writer reads no walk records (random 64-B lines of a 26..258 MB table)
-    bool fat_log = false;                // option log_records: bit-identical, measured 3-15 % slower per frame (the walk stores 36 B per step
-                                         // instead of 16 and runs 7 instead of 8 waves per SIMD: profiles/r02l_fatlog.txt), off
-    size_t log_cap_bytes = (size_t)24 << 30;  // larger calls are walked + written in ray chunks
-    bool literal = true;                 // false: rays with uncertified order are re-traced through the BVH instead (ablation)
-    bool literal_rows = true;            // true (default): one wavefront sorts, pairs and WRITES the row of a literal ray, on the side
-                                         // stream beside the tail fill; false: k_literal_mask turns the ray into a segment-writer ray
-                                         // (emit mask over the log) -- bit-identical, measured 5-10 % slower per frame because the mask
-                                         // kernel sits on the critical path between walk and writer (profiles/r02i_mask.txt)
-    tn::DevBuf<uint32_t> emit_mask;      // [rays][M / 32]
-    bool prefill = false;                // stream the tail slots no certified ray reaches beside the segment writer (measured
-                                         // slower: the latency-bound segment writer crawls beside a saturating fill)
-    hipStream_t side = nullptr;          // second stream: tail prefill, literal pairing, BVH re-trace
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    size_t log_cap_bytes = 0;            // 0: a fraction of the free device memory (decided per call); larger calls are walked
+                                         // + written in ray chunks.  Option log_cap_mb (tests)
+    bool literal = true;                 // false: rays with uncertified order are re-traced through the BVH instead of being
+                                         // paired from the log (cross-check of the two paths; tests)
+    hipStream_t side = nullptr;          // literal pairing of the logged hits (beside the tail fill)
+    hipStream_t aux = nullptr;           // BVH re-trace of the fallback rays (forked right after the walk)
     hipStream_t pre = nullptr;           // speculative tail fill beside the walk
-    hipEvent_t ev_start = nullptr, ev_pre = nullptr;
-    int spec_fill = 1;                   // 1: slots [K0, M) of every row are filled beside the walk (K0 from the mesh size); 0 off
-    unsigned spec_blocks = 0;            // grid of that fill (0 = 2048 blocks)
-    unsigned spec_k0 = 0;                // override of K0 (multiple of 32; ablation)
-    hipStream_t writer = nullptr;        // pipelined mode: the segment writer of chunk i runs beside the walk of chunk i + 1
-    hipEvent_t ev_chunk[8] = {}, ev_writer = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_start = nullptr, ev_pre = nullptr, ev_seg = nullptr, ev_aux = nullptr;
+    int spec_fill = 1;                   // 1: the last quarter of every row is filled beside the walk where that is mesh-safe; 0 off
+    unsigned spec_k0 = 0;                // override of the first speculatively filled slot (multiple of 32; tests)
     bool small_lds = true;               // small batches: LDS hit arrays sized for the mesh, overflow rays in a second launch
     unsigned lds_cap = 0;                // 0: from the mesh size; otherwise the entries of the small arrays (power of two; tests)
-    bool side_late = true;               // literal pairing starts after the segment writer (beside the fill), not beside it
-    bool aux_general = true;             // BVH fallback rays on a third stream (forked right after the walk)
-    unsigned pipe = 1;                   // ray chunks of the walk -> writer pipeline (1 = one walk, then one writer)
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
-    unsigned fill_blocks = 0;            // cap of the tail-fill grid (0 = default 2 blocks per CU); ablation knob
-    unsigned seg_blocks = 0;             // cap of the segment-writer grid (0 = what the VGPR budget admits); ablation knob
-    unsigned seg_variant = 1;            // segment writer: 1 LDS-staged whole-line stores; 0 direct stores (ablation).  With the literal
-                                         // pairing scheduled beside the fill (side_late) the LDS writer wins: profiles/r02f_sched_sweep.txt
-    unsigned seg_unroll = 4;             // segment writer: chunks of 8 hits per ray per iteration (4 or 2); ablation knob
+    unsigned seg_blocks = 0;             // cap of the segment-writer grid (0 = what is resident at once)
+    unsigned seg_unroll = 4;             // segment writer: chunks of 8 hits per ray per iteration (4: 2 waves per SIMD; 2: 4 waves per SIMD)
     tn::DevBuf<tn::WalkVar> vars;
     tn::DevBuf<float> hull_nodes, hull_tris;
     tn::DevWideBvh bvh;
@@ -70,15 +51,12 @@ struct tn_tracer {
                                             // literal count, kmax (one memset clears them all)
     uint32_t *fallback_count() { return reinterpret_cast<uint32_t *>(stats.p + 24); }
     uint32_t *literal_count() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 1; }
-    uint32_t *kmax() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 2; }
     size_t last_num_rays = 0;
     int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
     size_t walk_min_rays = 12288;        // measured crossover on the 300k-tet mesh after round 2b's faster BVH path
                                          // (profiles/r02t_crossover.txt: 8192 rays 0.46-0.49 vs 0.61-0.71 ms, 12288 rays 0.68-0.90 vs
                                          //  0.67-0.82 ms, 16384 rays 0.89-1.16 vs 0.67-0.84 ms; round 2a: 6144)
     bool last_walk = false;
-    uint32_t debug = 0;
-    uint32_t gdebug = 0;
     bool loaded = false;
     hipStream_t last_stream = nullptr;
 };
@@ -146,20 +124,16 @@ int tn_tracer_create(int device, tn_tracer_t *out) {
         t->stats.alloc(26);
         TN_HIP(hipMemset(t->stats.p, 0, 26 * sizeof(unsigned long long)));
         {
-            // the side stream carries the few rays the walk does not certify: lowest priority, so that the dispatcher
+            // the side streams carry the few rays the walk does not certify: lowest priority, so that the dispatcher
             // hands wave slots to the main stream's kernels first when both have blocks waiting
             int least = 0, greatest = 0;
             TN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
             TN_HIP(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, least));
+            TN_HIP(hipStreamCreateWithPriority(&t->aux, hipStreamNonBlocking, least));
         }
-        TN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
-        TN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
-        TN_HIP(hipStreamCreateWithFlags(&t->writer, hipStreamNonBlocking));
         TN_HIP(hipStreamCreateWithFlags(&t->pre, hipStreamNonBlocking));
-        TN_HIP(hipEventCreateWithFlags(&t->ev_start, hipEventDisableTiming));
-        TN_HIP(hipEventCreateWithFlags(&t->ev_pre, hipEventDisableTiming));
-        for (auto &e : t->ev_chunk) TN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        TN_HIP(hipEventCreateWithFlags(&t->ev_writer, hipEventDisableTiming));
+        for (hipEvent_t *e : {&t->ev_fork, &t->ev_join, &t->ev_start, &t->ev_pre, &t->ev_seg, &t->ev_aux})
+            TN_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         *out = t.release();
     });
 }
@@ -169,15 +143,10 @@ int tn_tracer_destroy(tn_tracer_t tracer) {
         if (!tracer) return;
         DeviceGuard g(tracer->device);
         (void)hipDeviceSynchronize();
-        if (tracer->side) (void)hipStreamDestroy(tracer->side);
-        if (tracer->ev_fork) (void)hipEventDestroy(tracer->ev_fork);
-        if (tracer->ev_join) (void)hipEventDestroy(tracer->ev_join);
-        if (tracer->writer) (void)hipStreamDestroy(tracer->writer);
-        if (tracer->pre) (void)hipStreamDestroy(tracer->pre);
-        if (tracer->ev_start) (void)hipEventDestroy(tracer->ev_start);
-        if (tracer->ev_pre) (void)hipEventDestroy(tracer->ev_pre);
-        for (auto &e : tracer->ev_chunk) if (e) (void)hipEventDestroy(e);
-        if (tracer->ev_writer) (void)hipEventDestroy(tracer->ev_writer);
+        for (hipStream_t st : {tracer->side, tracer->aux, tracer->pre})
+            if (st) (void)hipStreamDestroy(st);
+        for (hipEvent_t e : {tracer->ev_fork, tracer->ev_join, tracer->ev_start, tracer->ev_pre, tracer->ev_seg, tracer->ev_aux})
+            if (e) (void)hipEventDestroy(e);
         delete tracer;
     });
 }
@@ -322,7 +291,6 @@ static tn::TraceParams make_params(tn_tracer *t, size_t R, uint32_t M, const flo
     p.out_num = num; p.out_cells = cells; p.out_bary = bary; p.out_dist = dist; p.out_verts = verts;
     p.M = M; p.num_items = R; p.ray_list = nullptr;
     p.stats = t->stats.p;
-    p.gdebug = t->gdebug;
     return p;
 }
 
@@ -351,30 +319,34 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                           t->mesh.n_hull > 0;
         t->last_walk = walk;
         if (walk) {
-            // main stream: walk (hits -> log; classes; K) -> segment writer -> tails [ceil32(n), K) of the certified rows
-            // side stream: tails [K, M) of all rows -> literal pairing of the logged hits -> BVH re-trace of the rest
-            // The side stream needs only the walk: its bandwidth-bound fill runs beside the latency-bound segment
-            // writer, and the few literal / fallback rays (whole rows, written after the prefill of the same stream)
-            // ride beside the second fill.  The log holds 16 B per hit slot; calls whose log would exceed
-            // `log_cap_bytes` are processed in ray chunks (multiples of 4096 rays, the walk's XCD run), serially.
+            // main stream: walk (hits -> log; classes) -> segment writer -> tails [ceil32(n), K0) of the certified rows
+            // `pre`:  tails [K0, M) of ALL rows, from the start of the call (speculative, see below)
+            // `side`: literal pairing of the logged hits of the rays whose order the walk did not certify, beside the fill
+            // `aux`:  BVH re-trace of the handful of fallback rays (one wavefront each, pure latency), from the walk on
+            // Everything that writes rows is ordered behind the speculative fill, so a ray with more than K0 segments
+            // (or a literal / fallback row) simply overwrites its slots.  The log holds 16 B per hit slot; calls whose log
+            // would exceed the cap are processed in ray chunks (multiples of 4096 rays, the walk's XCD run), serially.
             if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); }
-            const bool use_mask = t->literal && !t->literal_rows && !t->prefill && M >= 32 && M <= 512;
-            if (use_mask && t->emit_mask.n < R * (size_t)(M / 32)) t->emit_mask.alloc(R * (size_t)(M / 32));
-            const bool fat = t->fat_log && t->mesh.T < (1u << 26);   // tet id and the 6 combine bits share a dword
-            const size_t entry_bytes = fat ? 36 : 16;
-            size_t chunk = t->log_cap_bytes / ((size_t)M * entry_bytes);
+            size_t cap_bytes = t->log_cap_bytes;
+            if (!cap_bytes) {
+                // the log lives for the tracer's lifetime: at most a quarter of what is free now (plus what it already
+                // holds), at most 24 GB; a call that needs more runs in chunks instead of failing in hipMalloc
+                size_t free_b = 0, total_b = 0;
+                TN_HIP(hipMemGetInfo(&free_b, &total_b));
+                cap_bytes = std::min<size_t>((free_b + t->hit_log.n * sizeof(uint4)) / 4, (size_t)24 << 30);
+            }
+            size_t chunk = cap_bytes / ((size_t)M * sizeof(uint4));
             chunk = chunk / 4096 * 4096;
             if (chunk < 4096) chunk = 4096;
             if (chunk > R) chunk = R;
             const size_t log_entries = (chunk + 255) / 256 * 256 * (size_t)M;
             if (t->hit_log.n < log_entries) t->hit_log.alloc(log_entries);
-            if (fat && t->hit_log_v.n < log_entries) { t->hit_log_v.alloc(log_entries); t->hit_log_o.alloc(log_entries); }
             const bool single = chunk >= R;
             auto chunk_params = [&](size_t base, size_t n) {
                 return make_params(t, n, M, origins + 3 * base, directions + 3 * base, num_visited + base, visited + base * M,
                                    bary + base * M * 6, dist + base * M * 2, verts ? verts + base * M * 4 : nullptr);
             };
-            auto launch_walk = [&](size_t base, size_t n, size_t log_base = 0) {
+            auto launch_walk = [&](size_t base, size_t n) {
                 tn::WalkParams w{};
                 w.t = chunk_params(base, n);
                 w.vars = t->mesh.vars;
@@ -386,58 +358,28 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 w.fallback_count = t->fallback_count();
                 w.literal_list = t->literal ? t->literal_list.p : nullptr;
                 w.literal_count = t->literal_count();
-                w.kmax = t->kmax();
                 w.walk_n = t->walk_n.p + base;
-                w.hit_log = t->hit_log.p + (log_base / 64) * (size_t)M * 64;
-                w.hit_log_v = fat ? t->hit_log_v.p + (log_base / 64) * (size_t)M * 64 : nullptr;
-                w.hit_log_o = fat ? t->hit_log_o.p + (log_base / 64) * (size_t)M * 64 : nullptr;
+                w.hit_log = t->hit_log.p;
                 w.ray_base = base;
-                w.lit_base = (uint32_t)log_base;
-                w.debug = t->debug;
                 tn::launch_trace_walk(w, stream);
             };
-            auto launch_segments = [&](size_t base, size_t n, hipStream_t st, size_t log_base = 0) {
+            auto launch_segments = [&](size_t base, size_t n) {
                 tn::WriteParams q{};
                 q.num_rays = n; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
-                q.unroll = t->seg_unroll; q.variant = t->seg_variant;
+                q.unroll = t->seg_unroll;
                 q.walk_n = t->walk_n.p + base;
-                q.emit_mask = use_mask ? t->emit_mask.p + base * (size_t)(M / 32) : nullptr;
-                q.hit_log = t->hit_log.p + (log_base / 64) * (size_t)M * 64;
-                q.hit_log_v = fat ? t->hit_log_v.p + (log_base / 64) * (size_t)M * 64 : nullptr;
-                q.hit_log_o = fat ? t->hit_log_o.p + (log_base / 64) * (size_t)M * 64 : nullptr;
+                q.hit_log = t->hit_log.p;
                 q.vars = t->mesh.vars;
                 q.out_cells = visited + base * M;
                 q.out_bary = bary + base * M * 6;
                 q.out_dist = dist + base * M * 2;
                 q.out_verts = verts ? verts + base * M * 4 : nullptr;
-                tn::launch_write_segments(q, st, t->seg_blocks);
+                tn::launch_write_segments(q, stream, t->seg_blocks);
             };
-            auto launch_fill = [&](size_t base, size_t n, bool all_rows, const uint32_t *kmax, hipStream_t st, uint32_t k_fixed = 0,
-                                   bool nontemporal = false) {
+            auto launch_fill = [&](size_t base, size_t n, uint32_t k_hi) {   // [ceil32(n_r), k_hi) of the certified rows
                 if (!t->dense_tails) return;
-                tn::launch_fill_range(n, M, all_rows, kmax, t->walk_n.p + base, num_visited + base, visited + base * M, bary + base * M * 6,
-                                      dist + base * M * 2, verts ? verts + base * M * 4 : nullptr, st, t->fill_blocks, k_fixed, nontemporal);
-            };
-            // Speculative tail fill: a ray of a uniform mesh of T tets crosses at most ~3.45 T^(1/3) faces, so
-            // the slots from ceil32(3.6 T^(1/3)) + 32 on are constants in (almost) every row and can be streamed BESIDE
-            // the walk.  The walk slows down beside a saturating write stream (x2-4: its record loads queue behind the
-            // writes), so only as many bytes as the walk's own duration buys are filled that way: the last quarter of
-            // every row (measured: profiles/r02p_specfill*.txt -- C2 +1..3 %, 300k frame +2..3.5 %, the 1M-tet configurations
-            // +-1 %).  A ray with more segments than K0 loses nothing: the segment writer runs after this fill and
-            // overwrites its slots.
-            uint32_t K0 = 0;
-            if (t->spec_fill && t->dense_tails && !t->prefill && t->side_late && single) {
-                K0 = (((uint32_t)(3.6 * std::cbrt((double)std::max<uint32_t>(t->mesh.T, 1u))) + 31u) & ~31u) + 32u;
-                const uint32_t quarter = (3u * M / 4u) & ~31u;
-                K0 = K0 <= quarter ? quarter : 0u;   // only where the quarter-row fill is mesh-safe (at 1M tets and M = 512 it
-                                                     // is not: rays reach 346 of 384 slots; measured -1..-6 % there)
-                if (t->spec_k0) K0 = t->spec_k0 & ~31u;
-                if (K0 + 32u > M) K0 = 0;
-            }
-            auto launch_mask = [&](size_t base, size_t n, hipStream_t st, size_t log_base = 0) {
-                tn::launch_literal_mask(M, t->mesh.vars, t->hit_log.p + (log_base / 64) * (size_t)M * 64, t->literal_list.p, t->literal_count(), n,
-                                        t->walk_n.p + base, num_visited + base, t->emit_mask.p + base * (size_t)(M / 32),
-                                        t->fallback_list.p, t->fallback_count(), t->kmax(), base, t->stats.p, st);
+                tn::launch_fill_range(n, M, false, t->walk_n.p + base, num_visited + base, visited + base * M, bary + base * M * 6,
+                                      dist + base * M * 2, verts ? verts + base * M * 4 : nullptr, stream, k_hi, false);
             };
             auto launch_literal = [&](size_t base, size_t n, hipStream_t st) {
                 if (!t->literal) return;
@@ -446,90 +388,54 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             };
             p.ray_list = t->fallback_list.p;
             p.item_count = t->fallback_count();
-            const size_t npipe = single ? std::min<size_t>(t->pipe, 8) : 1;
-            if (single && npipe > 1 && R >= npipe * 8192) {
-                // Pipelined: the walk (issue / latency-bound) of chunk i + 1 runs beside the segment writer (bound by the
-                // texture-address rate of its scattered stores) of chunk i, on a second stream; the log holds every chunk.
-                size_t pc = (R + npipe - 1) / npipe;
-                pc = (pc + 4095) / 4096 * 4096;
-                unsigned ci = 0;
-                for (size_t base = 0; base < R; base += pc, ++ci) {
-                    const size_t n = R - base < pc ? R - base : pc;
-                    launch_walk(base, n, base);
-                    TN_HIP(hipEventRecord(t->ev_chunk[ci], stream));
-                    TN_HIP(hipStreamWaitEvent(t->writer, t->ev_chunk[ci], 0));
-                    launch_segments(base, n, t->writer, base);
+            if (single) {
+                // Speculative tail fill: a ray of a uniform mesh of T tets crosses at most ~3.45 T^(1/3) faces, so
+                // the slots from ceil32(3.6 T^(1/3)) + 32 on are constants in (almost) every row and can be streamed BESIDE
+                // the walk (VALU-issue-bound, the fill HBM-write-bound).  The walk crawls beside a saturating write stream, so
+                // only as many bytes as its own duration buys are filled that way: the last quarter of every row (measured:
+                // profiles/r02p_specfill*.txt, r03a_sched.txt: +1..3 % per frame), and only where that quarter is mesh-safe
+                // (at 1M tets and M = 512 rays reach 346 of the 384 slots: measured -1..-6 %, off).
+                uint32_t K0 = 0;
+                if (t->spec_fill && t->dense_tails) {
+                    K0 = (((uint32_t)(3.6 * std::cbrt((double)std::max<uint32_t>(t->mesh.T, 1u))) + 31u) & ~31u) + 32u;
+                    const uint32_t quarter = (3u * M / 4u) & ~31u;
+                    K0 = K0 <= quarter ? quarter : 0u;
+                    if (t->spec_k0) K0 = t->spec_k0 & ~31u;
+                    if (K0 + 32u > M) K0 = 0;
                 }
-                TN_HIP(hipEventRecord(t->ev_fork, stream));
-                TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
-                TN_HIP(hipEventRecord(t->ev_writer, t->writer));
-                TN_HIP(hipStreamWaitEvent(stream, t->ev_writer, 0));
-                launch_literal(0, R, t->side);
-                tn::launch_trace_general(p, t->side);
-                launch_fill(0, R, false, nullptr, stream);
-                TN_HIP(hipEventRecord(t->ev_join, t->side));
-                TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
-            } else if (single && use_mask) {
-                // walk -> literal pairing as an emit mask (a few percent of the rays, LDS only) -> every sound ray goes
-                // through the segment writer and the tail fill; the handful of BVH fallback rays on a stream of their own
-                launch_walk(0, R);
-                launch_mask(0, R, stream);
-                TN_HIP(hipEventRecord(t->ev_fork, stream));
-                TN_HIP(hipStreamWaitEvent(t->writer, t->ev_fork, 0));
-                tn::launch_trace_general(p, t->writer);
-                TN_HIP(hipEventRecord(t->ev_writer, t->writer));
-                launch_segments(0, R, stream);
-                launch_fill(0, R, false, nullptr, stream);
-                TN_HIP(hipStreamWaitEvent(stream, t->ev_writer, 0));
-            } else if (single) {
                 if (K0) {
                     TN_HIP(hipEventRecord(t->ev_start, stream));
                     TN_HIP(hipStreamWaitEvent(t->pre, t->ev_start, 0));
-                    if (t->dense_tails)
-                        tn::launch_fill_range(R, M, true, nullptr, t->walk_n.p, num_visited, visited, bary, dist, verts, t->pre,
-                                              t->spec_blocks ? t->spec_blocks : 2048u, K0, true);
+                    tn::launch_fill_range(R, M, true, t->walk_n.p, num_visited, visited, bary, dist, verts, t->pre, K0, true);
                     TN_HIP(hipEventRecord(t->ev_pre, t->pre));
                 }
                 launch_walk(0, R);
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
-                TN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
+                TN_HIP(hipStreamWaitEvent(t->aux, t->ev_fork, 0));
                 if (K0) {   // everything that writes rows comes after the speculative fill
-                    TN_HIP(hipStreamWaitEvent(t->writer, t->ev_pre, 0));
+                    TN_HIP(hipStreamWaitEvent(t->aux, t->ev_pre, 0));
                     TN_HIP(hipStreamWaitEvent(stream, t->ev_pre, 0));
                 }
-                // (with the `prefill` ablation the all-rows fill of the side stream must precede every kernel that writes whole
-                //  rows, so the fallback rays stay behind it on the side stream)
-                const bool aux = t->aux_general && !t->prefill;
-                if (aux) {
-                    // the handful of BVH fallback rays (one wavefront each, ~0.7 ms of pure latency) on a stream of their
-                    // own instead of behind the literal pairing
-                    TN_HIP(hipStreamWaitEvent(t->writer, t->ev_fork, 0));
-                    tn::launch_trace_general(p, t->writer);
-                    TN_HIP(hipEventRecord(t->ev_writer, t->writer));
-                }
-                // the segment writer is enqueued BEFORE the side stream's kernels: their grids are sized for the worst
-                // case (the counts live on the device) and would otherwise take every wave slot first
-                launch_segments(0, R, stream);
-                if (t->side_late) {   // literal pairing beside the fill instead of beside the segment writer
-                    TN_HIP(hipEventRecord(t->ev_chunk[0], stream));
-                    TN_HIP(hipStreamWaitEvent(t->side, t->ev_chunk[0], 0));
-                }
-                if (t->prefill) launch_fill(0, R, true, t->kmax(), t->side);
-                launch_literal(0, R, t->side);
-                if (!aux) tn::launch_trace_general(p, t->side);
-                launch_fill(0, R, false, t->prefill ? t->kmax() : nullptr, stream, K0);
+                tn::launch_trace_general(p, t->aux);
+                TN_HIP(hipEventRecord(t->ev_aux, t->aux));
+                // the segment writer is enqueued BEFORE the side stream's kernel: its grid is sized for the worst case (the
+                // count lives on the device) and would otherwise take every wave slot first
+                launch_segments(0, R);
+                TN_HIP(hipEventRecord(t->ev_seg, stream));
+                TN_HIP(hipStreamWaitEvent(t->side, t->ev_seg, 0));   // literal pairing beside the bandwidth-bound fill, not
+                launch_literal(0, R, t->side);                       // beside the latency-bound writer (r02f_sched_sweep.txt)
+                launch_fill(0, R, K0 ? K0 : M);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
-                if (aux) TN_HIP(hipStreamWaitEvent(stream, t->ev_writer, 0));
+                TN_HIP(hipStreamWaitEvent(stream, t->ev_aux, 0));
             } else {
                 for (size_t base = 0; base < R; base += chunk) {
                     const size_t n = R - base < chunk ? R - base : chunk;
                     TN_HIP(hipMemsetAsync(t->literal_count(), 0, sizeof(uint32_t), stream));
                     launch_walk(base, n);
-                    if (use_mask) launch_mask(base, n, stream);
-                    launch_segments(base, n, stream);
-                    launch_fill(base, n, false, nullptr, stream);
-                    if (!use_mask) launch_literal(base, n, stream);   // before the next chunk's walk reuses the log
+                    launch_segments(base, n);
+                    launch_fill(base, n, M);
+                    launch_literal(base, n, stream);   // before the next chunk's walk reuses the log
                 }
                 tn::launch_trace_general(p, stream);
             }
@@ -680,75 +586,27 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]) {
 int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);
-        if (name && std::strcmp(name, "gpu_build") == 0) t->gpu_build = value != 0;
-        else if (name && std::strcmp(name, "leaf_width") == 0) {
+        const std::string k = name ? name : "";
+        if (k == "gpu_build") t->gpu_build = value != 0;
+        else if (k == "leaf_width") {
             if (value != 16 && value != 32 && value != 64) throw tn::Error("leaf_width must be 16, 32 or 64");
             t->leaf_width = (unsigned)value;
         }
-        else if (name && std::strcmp(name, "walk") == 0) t->use_walk = value < 0 ? 0 : (value > 2 ? 2 : value);
-        else if (name && std::strcmp(name, "walk_min_rays") == 0) t->walk_min_rays = value < 0 ? 0 : (size_t)value;
-        else if (name && std::strcmp(name, "debug") == 0) t->debug = (uint32_t)value;
-        else if (name && std::strcmp(name, "gdebug") == 0) t->gdebug = (uint32_t)value;
-        else if (name && std::strcmp(name, "dense_tails") == 0) t->dense_tails = value != 0;
-        else if (name && std::strcmp(name, "literal") == 0) t->literal = value != 0;
-        else if (name && std::strcmp(name, "literal_rows") == 0) t->literal_rows = value != 0;
-        else if (name && std::strcmp(name, "prefill") == 0) t->prefill = value != 0;
-        else if (name && (std::strcmp(name, "rewalk") == 0 || std::strcmp(name, "rewalk_min") == 0)) {}  // round-1 knobs: no effect
-        else if (name && std::strcmp(name, "fill_blocks") == 0) t->fill_blocks = (unsigned)value;
-        else if (name && std::strcmp(name, "seg_blocks") == 0) t->seg_blocks = (unsigned)value;
-        else if (name && std::strcmp(name, "log_records") == 0) t->fat_log = value != 0;
-        else if (name && std::strcmp(name, "spec_fill") == 0) t->spec_fill = value != 0;
-        else if (name && std::strcmp(name, "spec_blocks") == 0) t->spec_blocks = (unsigned)value;
-        else if (name && std::strcmp(name, "spec_k0") == 0) t->spec_k0 = (unsigned)value;
-        else if (name && std::strcmp(name, "small_lds") == 0) t->small_lds = value != 0;
-        else if (name && std::strcmp(name, "lds_cap") == 0) {
+        else if (k == "walk") t->use_walk = value < 0 ? 0 : (value > 2 ? 2 : value);
+        else if (k == "walk_min_rays") t->walk_min_rays = value < 0 ? 0 : (size_t)value;
+        else if (k == "dense_tails") t->dense_tails = value != 0;
+        else if (k == "literal") t->literal = value != 0;
+        else if (k == "spec_fill") t->spec_fill = value != 0;
+        else if (k == "spec_k0") t->spec_k0 = (unsigned)value;
+        else if (k == "small_lds") t->small_lds = value != 0;
+        else if (k == "lds_cap") {
             if (value < 0 || (value & (value - 1)) != 0 || (value && value < 8)) throw tn::Error("lds_cap must be 0 or a power of two >= 8");
             t->lds_cap = (unsigned)value;
         }
-        else if (name && std::strcmp(name, "side_late") == 0) t->side_late = value != 0;
-        else if (name && std::strcmp(name, "aux_general") == 0) t->aux_general = value != 0;
-        else if (name && std::strcmp(name, "pipe") == 0) t->pipe = value < 1 ? 1u : (value > 8 ? 8u : (unsigned)value);
-        else if (name && std::strcmp(name, "seg_variant") == 0) t->seg_variant = value ? 1u : 0u;
-        else if (name && std::strcmp(name, "seg_unroll") == 0) t->seg_unroll = value == 2 ? 2u : 4u;
-        else if (name && std::strcmp(name, "log_cap_mb") == 0) t->log_cap_bytes = (size_t)(value < 1 ? 1 : value) << 20;
-        else throw tn::Error(std::string("unknown option ") + (name ? name : "(null)"));
-    });
-}
-
-/* probes (profiles/): a stream restricted to the compute units [first_cu, first_cu + num_cus) of the logical CU
- * numbering (bit i of the mask = XCD i % 8, so a contiguous range is spread evenly over the XCDs), and a pure
- * write stream with a selectable store flavour.  Not part of the drop-in surface. */
-int tn_probe_stream_create(int first_cu, int num_cus, void **out) {
-    return guarded([&] {
-        uint32_t mask[16] = {0};
-        for (int i = first_cu; i < first_cu + num_cus && i < 512; ++i) mask[i / 32] |= 1u << (i % 32);
-        hipStream_t s = nullptr;
-        TN_HIP(hipExtStreamCreateWithCUMask(&s, 16, mask));
-        *out = (void *)s;
-    });
-}
-/* re-runs the segment writer on the hit log of the tracer's last trace_rays call (same ray count, same M) into the given
- * rows; `ablate` as WriteParams::ablate.  Timing probe only. */
-int tn_probe_write_segments(tn_tracer_t tracer, uint32_t M, uint32_t *visited, float *bary, float *dist, uint32_t *verts,
-                            int ablate, int blocks, void *stream) {
-    return guarded([&] {
-        tn_tracer *t = checked(tracer);
-        if (!t->last_walk) throw tn::Error("the last trace_rays call did not take the walk path");
-        tn::WriteParams q{};
-        q.num_rays = t->last_num_rays; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
-        q.unroll = t->seg_unroll; q.variant = t->seg_variant; q.ablate = (uint32_t)ablate;
-        q.walk_n = t->walk_n.p; q.emit_mask = t->emit_mask.p; q.hit_log = t->hit_log.p; q.vars = t->mesh.vars;
-        const bool fat = t->fat_log && t->mesh.T < (1u << 26) && t->hit_log_v.n >= t->hit_log.n && t->hit_log_v.n;
-        q.hit_log_v = fat ? t->hit_log_v.p : nullptr; q.hit_log_o = fat ? t->hit_log_o.p : nullptr;
-        q.out_cells = visited; q.out_bary = bary; q.out_dist = dist; q.out_verts = verts;
-        tn::launch_write_segments(q, (hipStream_t)stream, (unsigned)blocks);
-        TN_HIP(hipGetLastError());
-    });
-}
-int tn_probe_fill(void *dst, size_t bytes, int flavour, int blocks, void *stream) {
-    return guarded([&] {
-        tn::launch_probe_fill(dst, bytes, flavour, (unsigned)blocks, (hipStream_t)stream);
-        TN_HIP(hipGetLastError());
+        else if (k == "seg_blocks") t->seg_blocks = (unsigned)value;
+        else if (k == "seg_unroll") t->seg_unroll = value == 2 ? 2u : 4u;
+        else if (k == "log_cap_mb") t->log_cap_bytes = value <= 0 ? 0 : (size_t)value << 20;
+        else throw tn::Error("unknown option " + (name ? k : std::string("(null)")));
     });
 }
 
@@ -815,76 +673,148 @@ int tn_interpolate_values_backward_vm(uint32_t D, uint32_t n, uint32_t Fd, const
     });
 }
 
-static std::atomic<int> g_mlp_mode{0};
+/* ---- shallow MLP: a handle owns the packed forms of one set of weights and the per-call scratch ---- */
+}  // extern "C" (the handle type is C++)
 
-int tn_mlp_set_mode(int mode) {
+struct tn_mlp {
+    int device = 0;
+    tn::DevBuf<float> pk_plain, pk_gather, pt, enc;
+    tn::DevBuf<uint4> blob;
+    tn::DevBuf<uint32_t> nvh;
+    bool packed = false;
+    // per-call scratch: grown on demand (blocking hipMalloc, rare), never shrunk; one handle serves one stream at a time
+    tn::MlpPacks packs(size_t rays) {
+        if (!packed) throw tn::Error("tn_mlp_set_weights must be called first");
+        if (enc.n < rays * tn::mlp_enc_floats_per_ray() || nvh.n < rays) {
+            const size_t cap = std::max<size_t>(rays + rays / 4, 4096);
+            TN_HIP(hipDeviceSynchronize());   // the old scratch may still be in use by queued kernels
+            enc.alloc(cap * tn::mlp_enc_floats_per_ray());
+            nvh.alloc(cap);
+        }
+        return tn::MlpPacks{pk_plain.p, pk_gather.p, pt.p, blob.p, enc.p, nvh.p};
+    }
+};
+
+namespace {
+tn_mlp *checked_mlp(tn_mlp_t m) {
+    if (!m) throw tn::Error("mlp handle is null");
+    return m;
+}
+void check_mode(int mode) {
+    if (mode != 0 && mode != 1) throw tn::Error("mlp mode must be 0 (fp32 MFMA) or 1 (bf16x3 MFMA)");
+}
+}  // namespace
+
+extern "C" {
+
+int tn_mlp_create(int device, tn_mlp_t *out) {
     return guarded([&] {
-        if (mode != 0 && mode != 1) throw tn::Error("mlp mode must be 0 (fp32 MFMA) or 1 (bf16x3 MFMA)");
-        g_mlp_mode.store(mode);
+        if (!out) throw tn::Error("out is null");
+        int count = 0;
+        TN_HIP(hipGetDeviceCount(&count));
+        if (device < 0 || device >= count) throw tn::Error("The device argument must be a CUDA device.");
+        DeviceGuard g(device);
+        auto m = std::make_unique<tn_mlp>();
+        m->device = device;
+        m->pk_plain.alloc(tn::mlp_pack_floats());
+        m->pk_gather.alloc(tn::mlp_pack_floats());
+        m->pt.alloc(tn::mlp_backward_pack_floats());
+        m->blob.alloc(tn::mlp_x3_blob_u4());
+        *out = m.release();
     });
 }
 
-int tn_mlp_set_block(int block) {
-    return guarded([&] { tn::mlp_set_block(block); });
+int tn_mlp_destroy(tn_mlp_t mlp) {
+    return guarded([&] {
+        if (!mlp) return;
+        DeviceGuard g(mlp->device);
+        (void)hipDeviceSynchronize();
+        delete mlp;
+    });
 }
 
-int tn_mlp_get_mode(void) { return g_mlp_mode.load(); }
-
-int tn_mlp_forward(size_t n, uint32_t samples_per_ray, const float *feats, const float *dirs,
-                   const tn_mlp_weights *w, float *sigma, float *rgb, void *stream_) {
+int tn_mlp_set_weights(tn_mlp_t mlp, const tn_mlp_weights *w, void *stream_) {
     return guarded([&] {
+        tn_mlp *m = checked_mlp(mlp);
+        if (!w) throw tn::Error("null pointer");
+        const float *const all[12] = {w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
+        for (const float *x : all) if (!x) throw tn::Error("null weight pointer");
+        DeviceGuard g(m->device);
+        hipStream_t stream = (hipStream_t)stream_;
+        tn::MlpWeights mw{w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
+        tn::launch_mlp_pack(mw, m->pk_plain.p, false, stream);
+        tn::launch_mlp_pack(mw, m->pk_gather.p, true, stream);
+        tn::launch_mlp_pack_t(mw, m->pt.p, stream);
+        tn::launch_mlp_pack_x3(mw, m->blob.p, stream);
+        TN_HIP(hipGetLastError());
+        m->packed = true;
+    });
+}
+
+int tn_mlp_forward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const float *feats, const float *dirs, int mode,
+                   float *sigma, float *rgb, void *stream_) {
+    return guarded([&] {
+        tn_mlp *m = checked_mlp(mlp);
+        check_mode(mode);
         if (n == 0) return;
-        if (!w || !feats || !sigma || (rgb && !dirs)) throw tn::Error("null pointer");
+        if (!feats || !sigma || (rgb && !dirs)) throw tn::Error("null pointer");
         if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
-        tn::MlpWeights m{w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
-        (g_mlp_mode.load() ? tn::launch_mlp_forward_x3 : tn::launch_mlp_forward)(
-            n, samples_per_ray, n / samples_per_ray, feats, nullptr, nullptr, nullptr, 0, dirs, m, sigma, rgb, (hipStream_t)stream_);
+        DeviceGuard g(m->device);
+        const size_t rays = n / samples_per_ray;
+        (mode ? tn::launch_mlp_forward_x3 : tn::launch_mlp_forward)(
+            n, samples_per_ray, rays, feats, nullptr, nullptr, nullptr, dirs, m->packs(rays), sigma, rgb, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }
 
-int tn_mlp_forward_gather(size_t n, uint32_t samples_per_ray, uint32_t num_vertices, const uint32_t *vertex_indices,
-                          const float *barycentric, const float *field, const float *dirs, const tn_mlp_weights *w,
-                          float *sigma, float *rgb, void *stream_) {
+int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices,
+                          const float *barycentric, const float *field_vm, const float *dirs, int mode, float *sigma,
+                          float *rgb, void *stream_) {
     return guarded([&] {
+        tn_mlp *m = checked_mlp(mlp);
+        check_mode(mode);
         if (n == 0) return;
-        if (!w || !vertex_indices || !barycentric || !field || !sigma || (rgb && !dirs)) throw tn::Error("null pointer");
+        if (!vertex_indices || !barycentric || !field_vm || !sigma || (rgb && !dirs)) throw tn::Error("null pointer");
         if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
-        tn::MlpWeights m{w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
-        (g_mlp_mode.load() ? tn::launch_mlp_forward_x3 : tn::launch_mlp_forward)(
-            n, samples_per_ray, n / samples_per_ray, nullptr, vertex_indices, barycentric, field, num_vertices, dirs, m, sigma, rgb,
+        DeviceGuard g(m->device);
+        const size_t rays = n / samples_per_ray;
+        (mode ? tn::launch_mlp_forward_x3 : tn::launch_mlp_forward)(
+            n, samples_per_ray, rays, nullptr, vertex_indices, barycentric, field_vm, dirs, m->packs(rays), sigma, rgb,
             (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }
 
-int tn_render_pass(uint32_t M, const uint32_t *num_visited, const float *hit_distances, const float *barycentric,
+int tn_render_pass(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const float *hit_distances, const float *barycentric,
                    const uint32_t *vertex_indices, const uint32_t *ray_index, size_t num_hit_rays, uint32_t num_samples,
-                   const float *edges, const float *field_vm, const float *dirs, const tn_mlp_weights *w, float background,
+                   const float *edges, const float *field_vm, const float *dirs, float background,
                    float *out_weights, float *out_rgb, float *out_acc, float *out_depth, void *stream_) {
     return guarded([&] {
+        tn_mlp *m = checked_mlp(mlp);
         if (num_hit_rays == 0) return;
-        if (!w || !num_visited || !hit_distances || !barycentric || !vertex_indices || !ray_index || !edges || !field_vm)
+        if (!num_visited || !hit_distances || !barycentric || !vertex_indices || !ray_index || !edges || !field_vm)
             throw tn::Error("null pointer");
         if (!dirs && !out_weights) throw tn::Error("density-only pass without out_weights");
-        tn::MlpWeights m{w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
+        DeviceGuard g(m->device);
         tn::launch_render_pass(num_visited, hit_distances, barycentric, vertex_indices, M, ray_index, num_hit_rays, num_samples,
-                               edges, field_vm, dirs, m, background, out_weights, out_rgb, out_acc, out_depth, (hipStream_t)stream_);
+                               edges, field_vm, dirs, m->packs(num_hit_rays), background, out_weights, out_rgb, out_acc, out_depth,
+                               (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }
 
-int tn_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices, const float *barycentric,
-                    const float *field_vm, const float *dirs, const tn_mlp_weights *w, const float *d_sigma,
-                    const float *d_rgb, const tn_mlp_backward_buffers *b, void *stream_) {
+int tn_mlp_backward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices, const float *barycentric,
+                    const float *field_vm, const float *dirs, const float *d_sigma, const float *d_rgb,
+                    const tn_mlp_backward_buffers *b, void *stream_) {
     return guarded([&] {
+        tn_mlp *m = checked_mlp(mlp);
         if (n == 0) return;
-        if (!w || !b || !vertex_indices || !barycentric || !field_vm || !dirs || !d_sigma || !d_rgb) throw tn::Error("null pointer");
+        if (!b || !vertex_indices || !barycentric || !field_vm || !dirs || !d_sigma || !d_rgb) throw tn::Error("null pointer");
         if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
-        tn::MlpWeights m{w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, w->wd, w->bd, w->wh, w->bh, w->wr, w->br};
+        DeviceGuard g(m->device);
         tn::MlpBackwardBuffers bb{b->x0, b->h1, b->h2, b->h3, b->h4, b->d1, b->d2, b->d3, b->d4, b->dhead, b->dx0};
-        tn::launch_mlp_backward(n, samples_per_ray, vertex_indices, barycentric, field_vm, dirs, m, d_sigma, d_rgb, bb,
-                                (hipStream_t)stream_);
+        tn::launch_mlp_backward(n, samples_per_ray, vertex_indices, barycentric, field_vm, dirs, m->packs(n / samples_per_ray),
+                                d_sigma, d_rgb, bb, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }

@@ -23,7 +23,6 @@ struct TraceParams {
     uint32_t *overflow_list;   // [num_items] / [1]
     uint32_t *overflow_count;
     unsigned long long *stats; // [4] device counters or null
-    uint32_t gdebug;           // ablation of the general kernel (bench only): 1 stop after traversal, 2 skip sort, 8 count node/leaf visits in stats[18]/[19]
 };
 
 // general all-hits path, one wavefront per ray (tn_trace_general.hip)
@@ -48,30 +47,17 @@ struct WalkParams {
     uint32_t *fallback_count;  // [1]
     uint2 *literal_list;       // [num_items] {ray index within this launch, hits in the log}: sound chains whose ORDER is
     uint32_t *literal_count;   // [1]            not certified -> literal sort + pairing of the logged hits
-    uint32_t *kmax;            // [1] max segments of a certified ray (atomicMax)
     uint32_t *walk_n;          // [num_items] hits logged per certified ray (0 = miss), TN_EMPTY = literal / fallback
     uint4 *hit_log;            // [ceil(num_items / 64)][M][64] x {t, u, v, variant | exit << 30}: hit k of ray r at
                                // ((r / 64) * M + k) * 64 + r % 64 (a wave's 64 lanes store 1 KB of consecutive bytes per
                                // step); exit code 3 = entry hull face, its face id in the low 30 bits
-    uint32_t lit_base;         // added to the launch-local ray index stored in literal_list (= the launch's first row of the log)
-    uint4 *hit_log_v;          // optional ("fat log"): vertex ids (n, a, b, c) of the tet hit k closes, same indexing
-    uint32_t *hit_log_o;       //   and its tet id | combine code << 26 -- the segment writer then never reads the records
     size_t ray_base;           // global index of item 0 (rays are traced in chunks when the log would be too large)
-    uint32_t debug;            // block->XCD mapping ablation (profiles/): 4 = no remap, 8 = one contiguous band per XCD
 };
 void launch_trace_walk(const WalkParams &p, hipStream_t stream);
 // literal sort + pairing of the logged hits of the rays in literal_list (tn_trace_general.hip); rows of launch item i
 // are p.out_*[i] (the TraceParams of the same walk launch)
 void launch_postprocess_log(const TraceParams &p, const WalkVar *vars, const uint4 *hit_log, const uint2 *literal_list,
                             const uint32_t *literal_count, size_t max_items, hipStream_t stream);
-
-// literal pairing of the logged hits as an EMIT MASK over the log (tn_trace_general.hip: k_literal_mask): the rays of
-// literal_list become writer rays (walk_n = hits | LITERAL_MASK_FLAG, out_num set, emit_mask [ray][M / 32]) or go to the
-// BVH fallback list
-constexpr uint32_t LITERAL_MASK_FLAG = 0x40000000u;
-void launch_literal_mask(uint32_t M, const WalkVar *vars, const uint4 *hit_log, const uint2 *literal_list, const uint32_t *literal_count, size_t max_items,
-                         uint32_t *walk_n, uint32_t *out_num, uint32_t *emit_mask, uint32_t *fallback_list, uint32_t *fallback_count,
-                         uint32_t *kmax, size_t ray_base, unsigned long long *stats, hipStream_t stream);
 
 // hit log -> rows of the rays the walk certified (walk_n[ray] != TN_EMPTY): k_write_segments writes the segment records
 // + the tail constants up to the next multiple of 32 slots (a 128-byte line boundary in all four row arrays);
@@ -80,14 +66,9 @@ struct WriteParams {
     size_t num_rays;
     uint32_t M;
     uint32_t dense_tails;      // 0: slots >= num_visited are left unwritten (non-reference option)
-    uint32_t unroll;           // chunks of 8 hits per ray per iteration: 4 (default) or 2
-    uint32_t variant;          // 1 (default): LDS-staged whole-line stores; 0: direct stores
-    uint32_t ablate;           // probe only (profiles/): 1 no record loads, 2 only the cell-id store, 4 no stores
-    const uint32_t *walk_n;    // hits in the log | LITERAL_MASK_FLAG (segments = the set bits of emit_mask, not the eps rule)
-    const uint32_t *emit_mask; // [num_rays][M / 32] or null
+    uint32_t unroll;           // chunks of 8 hits per ray per iteration: 4 (2 waves per SIMD) or 2 (4 waves per SIMD)
+    const uint32_t *walk_n;    // hits in the log; TN_EMPTY: the row belongs to the literal / BVH kernels
     const uint4 *hit_log;
-    const uint4 *hit_log_v;    // fat log (or null): see WalkParams
-    const uint32_t *hit_log_o;
     const WalkVar *vars;
     uint32_t *out_cells;
     float *out_bary;
@@ -95,13 +76,10 @@ struct WriteParams {
     uint32_t *out_verts;       // nullable
 };
 void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned max_blocks = 0);
-// all_rows: slots [K, M) of every row, K = ceil32(*kmax) (kmax == nullptr: K = M);
-// otherwise slots [ceil32(out_num[r]), K) of the certified rows
-void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *kmax, const uint32_t *walk_n,
-                       const uint32_t *out_num, uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
-                       unsigned max_blocks = 0, uint32_t k_fixed = 0, bool nontemporal = false);
-
-void launch_probe_fill(void *dst, size_t bytes, int flavour, unsigned blocks, hipStream_t stream);  // probe only
+// all_rows: slots [k_split, M) of every row; otherwise slots [ceil32(out_num[r]), k_split) of the certified rows
+void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *walk_n, const uint32_t *out_num,
+                       uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
+                       uint32_t k_split, bool nontemporal);
 
 // sample -> segment matching (tn_match.hip)
 void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,
@@ -133,15 +111,32 @@ struct MlpWeights {
     const float *wh, *bh;  // [128,155], [128]   mlp_head: columns = [dir encoding 27 | base 128]
     const float *wr, *br;  // [3,128],   [3]     rgb head (+ sigmoid)
 };
-// feats != null: input is the [64, n] feature buffer; feats == null: the kernel gathers the features
-// itself from (vi [n,4], bc [n,3], field [64, V] feature-major)
+// The packed forms of one set of weights (tn_mlp_set_weights packs them once per parameter version) + the scratch the
+// kernels need beside them.  Everything is device memory owned by the tn_mlp handle (tn_api.hip).
+struct MlpPacks {
+    const float *pk_plain;     // fp32 MFMA forward, layer-1 K order of a [64, n] feature-major input
+    const float *pk_gather;    // the same with layer-1 K order of the fused gather (forward, render pass, backward)
+    const float *pt;           // transposed weights in accumulator order (backward)
+    const uint4 *blob;         // bf16x3 pieces (forward, mode 1)
+    float *enc;                // [rays][mlp_enc_floats_per_ray()] direction encodings of the current call
+    uint32_t *nvh;             // [rays] segment counts of the hitting rays (render pass)
+};
+size_t mlp_pack_floats();              // tn_mlp.hip
+size_t mlp_backward_pack_floats();     // tn_mlp_bwd.hip
+size_t mlp_x3_blob_u4();               // tn_mlp_x3.hip
+size_t mlp_enc_floats_per_ray();       // 32: covers the fp32 kernels' 28 and the bf16x3 kernel's 32
+void launch_mlp_pack(const MlpWeights &w, float *pk, bool gather_l1, hipStream_t stream);
+void launch_mlp_pack_t(const MlpWeights &w, float *pt, hipStream_t stream);
+void launch_mlp_pack_x3(const MlpWeights &w, uint4 *blob, hipStream_t stream);
+// feats != null: input is the [64, n] feature buffer; feats == null: the kernel gathers the features itself from
+// (vi [n,4], bc [n,3], fieldT [V, 64] VERTEX-major)
 void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
-                        const float *bc, const float *field, uint32_t num_vertices, const float *dirs,
-                        const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream);
+                        const float *bc, const float *fieldT, const float *dirs, const MlpPacks &w, float *sigma, float *rgb,
+                        hipStream_t stream);
 // the same on the bf16 matrix cores with 3-way operand splitting (tn_mlp_x3.hip)
 void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
-                        const float *bc, const float *field, uint32_t num_vertices, const float *dirs,
-                        const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream);
+                           const float *bc, const float *fieldT, const float *dirs, const MlpPacks &w, float *sigma, float *rgb,
+                           hipStream_t stream);
 // training adjoint of the MLP (tn_mlp_bwd.hip).  All buffers feature-major [F, n] device memory owned by the caller.
 struct MlpBackwardBuffers {
     float *x0;                 // [64, n]   gathered features (layer-1 input)
@@ -152,7 +147,7 @@ struct MlpBackwardBuffers {
 };
 // recompute + dX chain: field_vm is the field vertex-major [V, 64]; d_sigma [n], d_rgb [n, 3]
 void launch_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vi, const float *bc, const float *field_vm,
-                         const float *dirs, const MlpWeights &w, const float *d_sigma, const float *d_rgb,
+                         const float *dirs, const MlpPacks &w, const float *d_sigma, const float *d_rgb,
                          const MlpBackwardBuffers &b, hipStream_t stream);
 // dW[128, rows_b] += A[128, n] * B[rows_b, n]^T, db[128] += row sums of A (db nullable); rows_b in {64, 128}
 void launch_weight_grad(size_t n, uint32_t rows_b, const float *A, const float *B, float *dW, float *db, hipStream_t stream);
@@ -162,14 +157,13 @@ void launch_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, co
 // adjoint of launch_composite: d sigma [R,S], d rgb [R,S,3] from the gradients of the rendered rgb / accumulation
 void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
                                const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb, hipStream_t stream);
-void mlp_set_block(int b);   // forward kernel shape: 0 auto, 256 = 4-wave blocks (two per CU), 512 = 8-wave blocks (tn_mlp.hip)
 void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols, hipStream_t stream);
 // one render pass as one launch (tn_render.hip): match -> gather -> MLP -> composite on the trace rows of the hitting
 // rays (ray_index [r]) from the bin edges [r, S + 1]; dirs == nullptr: density only, out_weights [r, S] written;
 // otherwise out_rgb / out_acc / out_depth (arrays over ALL rays) are written at ray_index[q]
 void launch_render_pass(const uint32_t *num_visited, const float *dist, const float *bary, const uint32_t *verts, uint32_t M,
                         const uint32_t *ray_index, size_t r, uint32_t S, const float *edges, const float *fieldT,
-                        const float *dirs, const MlpWeights &w, float background, float *out_weights, float *out_rgb,
+                        const float *dirs, const MlpPacks &w, float background, float *out_weights, float *out_rgb,
                         float *out_acc, float *out_depth, hipStream_t stream);
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
                       float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream);

@@ -27,8 +27,6 @@ namespace tn {
 
 using namespace mlp;
 
-static int g_mlp_block = 0;   // 0 auto, 256, 512 (tn_mlp_set_block: ablation)
-void mlp_set_block(int b) { g_mlp_block = (b == 256 || b == 512) ? b : 0; }
 
 namespace {
 
@@ -305,61 +303,39 @@ void launch_dir_encoding(size_t num_rays, const float *dirs, float *enc, hipStre
     hipLaunchKernelGGL(k_dir_encoding, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, stream, num_rays, dirs, enc);
 }
 
+size_t mlp_enc_floats_per_ray() { return 32; }
+
 void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
-                        const float *bc, const float *field, uint32_t num_vertices, const float *dirs,
-                        const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream) {
+                        const float *bc, const float *fieldT, const float *dirs, const MlpPacks &w, float *sigma, float *rgb,
+                        hipStream_t stream) {
     if (n == 0) return;
     const bool gather = feats == nullptr;
     const bool density_only = rgb == nullptr;  // coarse pass: no colour head, no direction encoding
     if (density_only) num_rays = 0;
-    float *pk = nullptr, *enc = nullptr, *fieldT = nullptr;
-    TN_HIP(hipMallocAsync((void **)&pk, PACK_FLOATS * sizeof(float), stream));
-    TN_HIP(hipMallocAsync((void **)&enc, (num_rays ? num_rays : 1) * ENC_PAD * sizeof(float), stream));
-    hipLaunchKernelGGL(k_mlp_pack, dim3((unsigned)((PACK_FLOATS + 255) / 256)), dim3(256), 0, stream, w, pk, gather ? 1 : 0);
+    const float *pk = gather ? w.pk_gather : w.pk_plain;
+    float *enc = w.enc;
     if (num_rays)
         hipLaunchKernelGGL(k_dir_encoding, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, stream, num_rays, dirs, enc);
-    if (gather) {
-        TN_HIP(hipMallocAsync((void **)&fieldT, (size_t)num_vertices * FD * sizeof(float), stream));
-        launch_transpose(field, fieldT, FD, num_vertices, stream);  // [64, V] -> [V, 64]
-    }
-    // 4-wave blocks, two per CU: measured neutral (profiles/r02o_mlp_block.txt: 129.7 vs 127.9 TFLOP/s on [64, n]
-    // inputs, 119.3 vs 119.9 with the fused gather, render frame 108.2 vs 106.6 ms) -- the weight staging is not what
-    // idles the matrix cores -- so the 8-wave shape stays the default and this one an ablation (tn_mlp_set_block(256))
-    const bool small_blocks = g_mlp_block == 256;
-    const size_t smem = (small_blocks ? MAX_STAGE_FLOATS_SPLIT : MAX_STAGE_FLOATS) * sizeof(float);  // the largest staged layer
+    // one 8-wave block per CU (4-wave blocks, two per CU, measured neutral: profiles/r02o_mlp_block.txt)
+    const size_t smem = MAX_STAGE_FLOATS * sizeof(float);  // the largest staged layer
     static PerDeviceOnce lds_attr;
     lds_attr.run([&] {
-        const size_t big = MAX_STAGE_FLOATS * sizeof(float);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, false>), big);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, false>), big);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, true>), big);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, true>), big);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, false, 256>), big);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, false, 256>), big);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, true, 256>), big);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, true, 256>), big);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, false>), smem);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, false>), smem);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<false, true>), smem);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, true>), smem);
     });
-    const size_t group = ((small_blocks ? 256 : MLP_BLOCK) / 64) * 32;
+    const size_t group = (MLP_BLOCK / 64) * 32;
     const size_t ngroups = (n + group - 1) / group;
-    const size_t max_grid = small_blocks ? 512 : 256;  // one 8-wave block or two 4-wave blocks per CU
-    const unsigned grid = (unsigned)(ngroups < max_grid ? ngroups : max_grid);
+    const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
 #define TN_MLP_LAUNCH(G, D)                                                                                         \
-    do {                                                                                                            \
-        if (small_blocks)                                                                                           \
-            hipLaunchKernelGGL((k_mlp_forward<G, D, 256>), dim3(grid), dim3(256), smem, stream, n, samples_per_ray, feats, vi, bc, \
-                               fieldT, enc, pk, sigma, rgb);                                                        \
-        else                                                                                                        \
-            hipLaunchKernelGGL((k_mlp_forward<G, D>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc, \
-                               fieldT, enc, pk, sigma, rgb);                                                        \
-    } while (0)
+    hipLaunchKernelGGL((k_mlp_forward<G, D>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc, \
+                       fieldT, enc, pk, sigma, rgb)
     if (gather && density_only) TN_MLP_LAUNCH(true, true);
     else if (gather) TN_MLP_LAUNCH(true, false);
     else if (density_only) TN_MLP_LAUNCH(false, true);
     else TN_MLP_LAUNCH(false, false);
 #undef TN_MLP_LAUNCH
-    TN_HIP(hipFreeAsync(pk, stream));
-    TN_HIP(hipFreeAsync(enc, stream));
-    if (fieldT) TN_HIP(hipFreeAsync(fieldT, stream));
 }
 
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,

@@ -489,18 +489,17 @@ void launch_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, co
 
 size_t mlp_backward_pack_floats() { return PACKT_FLOATS; }
 
+void launch_mlp_pack_t(const MlpWeights &w, float *pt, hipStream_t stream) {
+    hipLaunchKernelGGL(k_mlp_pack_t, dim3((unsigned)((PACKT_FLOATS + 255) / 256)), dim3(256), 0, stream, w, pt);
+}
+
 void launch_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vi, const float *bc, const float *field_vm,
-                         const float *dirs, const MlpWeights &w, const float *d_sigma, const float *d_rgb,
+                         const float *dirs, const MlpPacks &w, const float *d_sigma, const float *d_rgb,
                          const MlpBackwardBuffers &b, hipStream_t stream) {
     if (n == 0) return;
     const size_t num_rays = n / samples_per_ray;
-    float *pk = nullptr, *pt = nullptr, *enc = nullptr;
-    TN_HIP(hipMallocAsync((void **)&pk, mlp_pack_floats() * sizeof(float), stream));
-    TN_HIP(hipMallocAsync((void **)&pt, PACKT_FLOATS * sizeof(float), stream));
-    TN_HIP(hipMallocAsync((void **)&enc, (num_rays ? num_rays : 1) * ENC_PAD * sizeof(float), stream));
-    struct Free { float *a, *b, *c; hipStream_t s; ~Free() { (void)hipFreeAsync(a, s); (void)hipFreeAsync(b, s); (void)hipFreeAsync(c, s); } } guard{pk, pt, enc, stream};
-    launch_mlp_pack(w, pk, true, stream);
-    hipLaunchKernelGGL(k_mlp_pack_t, dim3((unsigned)((PACKT_FLOATS + 255) / 256)), dim3(256), 0, stream, w, pt);
+    const float *pk = w.pk_gather, *pt = w.pt;
+    float *enc = w.enc;
     launch_dir_encoding(num_rays, dirs, enc, stream);
     const size_t stage = MAX_STAGE_FLOATS > N_TH ? MAX_STAGE_FLOATS : N_TH;
     const size_t smem = stage * sizeof(float);

@@ -129,8 +129,6 @@ static __device__ __forceinline__ void relu_to_bin(const f32x16 (&acc)[TILES], f
 }  // namespace mlp
 
 // packers / encoders of tn_mlp.hip, used by the training path as well
-void launch_mlp_pack(const MlpWeights &w, float *pk, bool gather_l1, hipStream_t stream);
 void launch_dir_encoding(size_t num_rays, const float *dirs, float *enc, hipStream_t stream);
-size_t mlp_pack_floats();
 
 }  // namespace tn

@@ -374,24 +374,23 @@ __global__ __launch_bounds__(X3_BLOCK) void k_mlp_forward_x3(size_t n, uint32_t 
     }
 }
 
+size_t mlp_x3_blob_u4() { return N_BLOB; }
+
+void launch_mlp_pack_x3(const MlpWeights &w, uint4 *blob, hipStream_t stream) {
+    hipLaunchKernelGGL(k_mlp_pack_x3, dim3((unsigned)((PACK_THREADS + 255) / 256)), dim3(256), 0, stream, w, blob);
+}
+
 void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
-                           const float *bc, const float *field, uint32_t num_vertices, const float *dirs,
-                           const MlpWeights &w, float *sigma, float *rgb, hipStream_t stream) {
+                           const float *bc, const float *fieldT, const float *dirs, const MlpPacks &w, float *sigma, float *rgb,
+                           hipStream_t stream) {
     if (n == 0) return;
     const bool gather = feats == nullptr;
     const bool density_only = rgb == nullptr;
     if (density_only) num_rays = 0;
-    uint4 *blob = nullptr;
-    float *enc = nullptr, *fieldT = nullptr;
-    TN_HIP(hipMallocAsync((void **)&blob, N_BLOB * sizeof(uint4), stream));
-    TN_HIP(hipMallocAsync((void **)&enc, (num_rays ? num_rays : 1) * ENC32 * sizeof(float), stream));
-    hipLaunchKernelGGL(k_mlp_pack_x3, dim3((unsigned)((PACK_THREADS + 255) / 256)), dim3(256), 0, stream, w, blob);
+    const uint4 *blob = w.blob;
+    float *enc = w.enc;
     if (num_rays)
         hipLaunchKernelGGL(k_dir_encoding32, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, stream, num_rays, dirs, enc);
-    if (gather) {
-        TN_HIP(hipMallocAsync((void **)&fieldT, (size_t)num_vertices * FD * sizeof(float), stream));
-        launch_transpose(field, fieldT, FD, num_vertices, stream);
-    }
     const size_t smem = MAX_STAGE_U4 * sizeof(uint4);  // head layer: 120 KB of weight pieces + bias + rgb vectors
     static PerDeviceOnce lds_attr;
     lds_attr.run([&] {
@@ -411,9 +410,6 @@ void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, 
     else if (density_only) TN_X3_LAUNCH(false, true);
     else TN_X3_LAUNCH(false, false);
 #undef TN_X3_LAUNCH
-    TN_HIP(hipFreeAsync(blob, stream));
-    TN_HIP(hipFreeAsync(enc, stream));
-    if (fieldT) TN_HIP(hipFreeAsync(fieldT, stream));
 }
 
 }  // namespace tn

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
 
 void launch_render_pass(const uint32_t *num_visited, const float *dist, const float *bary, const uint32_t *verts, uint32_t M,
                         const uint32_t *ray_index, size_t r, uint32_t S, const float *edges, const float *fieldT,
-                        const float *dirs, const MlpWeights &w, float background, float *out_weights, float *out_rgb,
+                        const float *dirs, const MlpPacks &w, float background, float *out_weights, float *out_rgb,
                         float *out_acc, float *out_depth, hipStream_t stream) {
     if (r == 0) return;
     if (S < 64) throw Error("render_pass needs at least 64 samples per ray");
@@ -450,16 +450,11 @@ void launch_render_pass(const uint32_t *num_visited, const float *dist, const fl
     if ((size_t)S * ((r + 255) / 256 + 1) >= 0xFFFFFFFFull) throw Error("render_pass: too many samples per block");
     const bool density_only = dirs == nullptr;
     if (!density_only && !(out_rgb && out_acc && out_depth)) throw Error("render_pass: colour pass without output buffers");
-    float *pk = nullptr, *enc = nullptr;
-    uint32_t *nvh = nullptr;
-    TN_HIP(hipMallocAsync((void **)&pk, PACK_FLOATS * sizeof(float), stream));
-    TN_HIP(hipMallocAsync((void **)&nvh, r * sizeof(uint32_t), stream));
-    launch_mlp_pack(w, pk, true, stream);
+    const float *pk = w.pk_gather;
+    float *enc = density_only ? nullptr : w.enc;
+    uint32_t *nvh = w.nvh;
     hipLaunchKernelGGL(k_gather_counts, dim3((unsigned)((r + 255) / 256)), dim3(256), 0, stream, r, ray_index, num_visited, nvh);
-    if (!density_only) {
-        TN_HIP(hipMallocAsync((void **)&enc, r * ENC_PAD * sizeof(float), stream));
-        launch_dir_encoding(r, dirs, enc, stream);
-    }
+    if (!density_only) launch_dir_encoding(r, dirs, enc, stream);
     RenderPassParams p{};
     p.num_visited = num_visited; p.dist = dist; p.bary = bary; p.verts = verts; p.ray_index = ray_index; p.edges = edges;
     p.nv_hit = nvh; p.fieldT = fieldT; p.enc = enc; p.pk = pk; p.out_weights = out_weights; p.out_rgb = out_rgb; p.out_acc = out_acc;
@@ -474,9 +469,6 @@ void launch_render_pass(const uint32_t *num_visited, const float *dist, const fl
     const unsigned grid = (unsigned)(r < 256 ? r : 256);   // one 8-wave block per CU, each owns a range of rays
     if (density_only) hipLaunchKernelGGL(k_render_pass<true>, dim3(grid), dim3(MLP_BLOCK), smem, stream, p);
     else hipLaunchKernelGGL(k_render_pass<false>, dim3(grid), dim3(MLP_BLOCK), smem, stream, p);
-    TN_HIP(hipFreeAsync(pk, stream));
-    TN_HIP(hipFreeAsync(nvh, stream));
-    if (enc) TN_HIP(hipFreeAsync(enc, stream));
 }
 
 }  // namespace tn

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
         bool overflow = false;
         uint32_t nh = collect_hits(p.bvh, s, C, cap, p.origins[3 * ray], p.origins[3 * ray + 1], p.origins[3 * ray + 2],
                                    p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2],
-                                   (p.gdebug & 8u) ? p.stats : nullptr /* visit counters: same-address atomics, debug only */,
+                                   nullptr,
                                    lane, overflow, defer);
         if (overflow && defer) {
             if (lane == 0) p.overflow_list[atomicAdd(p.overflow_count, 1u)] = (uint32_t)ray;
@@ -476,8 +476,7 @@ __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
         }
         if (overflow && lane == 0 && p.stats) atomicAdd(&p.stats[3], 1ull);
 
-        if (p.gdebug & 1u) nh = 0;
-        if (!(p.gdebug & 2u)) sort_hits(s, nh, lane);
+        sort_hits(s, nh, lane);
         postprocess_and_write(s, nh, M, p.faces, p.face_tets, p.out_num + ray, p.out_cells + ray * M,
                               p.out_bary + ray * M * 6, p.out_dist + ray * M * 2,
                               p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane);
@@ -558,301 +557,6 @@ static size_t wave_smem(K kernel, uint32_t M) {
     return bytes;
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------
-// Literal pairing of the logged hits WITHOUT writing rows: the result is an EMIT MASK over the log.
-//
-// For a sound chain every tetrahedron has exactly two crossed faces, so two logged faces share a tetrahedron iff
-// their chain indices differ by one (plus the reference's EMPTY == EMPTY quirk for the entry / exit hull faces), and
-// every segment the reference's phases emit is a pair of chain-adjacent faces (k - 1, k): the literal result is a
-// SUBSET of the pairs the segment writer forms anyway.  This kernel sorts the ray's hits on (t, chain index) in LDS,
-// runs the two phases (localised exactly as in postprocess_and_write above, with "share a tetrahedron" decided on
-// chain indices -- no face table, no walk records, no barycentrics) and stores one bit per log entry k: "the pair
-// (k - 1, k) is a segment".  The ray then goes through k_write_segments / k_fill_range like a certified one (walk_n =
-// hits | LITERAL_MASK_FLAG, out_num = number of set bits): whole-line row stores instead of one wavefront writing a
-// 26 KB row, 6.5 KB of LDS per ray instead of 14.8 KB, and nothing of it competes with the tail fill.
-// Exact ties in t are ordered by face id as in the reference (the ids of the tied entries are fetched through their walk
-// records).  Sent to the BVH all-hits kernel instead (always right, rare): an emitted pair that is not (k - 1, k) in
-// chain direction (an inversion by eps or more; the hull quirk), segments that would come out in a different order than
-// chain order.
-__global__ __launch_bounds__(64) void k_literal_mask(uint32_t M, const WalkVar *__restrict__ vars, const uint4 *__restrict__ hit_log,
-                                                     const uint2 *__restrict__ literal_list,
-                                                     const uint32_t *__restrict__ literal_count, uint32_t *__restrict__ walk_n,
-                                                     uint32_t *__restrict__ out_num, uint32_t *__restrict__ emit_mask,
-                                                     uint32_t *__restrict__ fallback_list, uint32_t *__restrict__ fallback_count,
-                                                     uint32_t *__restrict__ kmax, size_t ray_base, unsigned long long *stats) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t *key = reinterpret_cast<uint64_t *>(smem);                 // [M]  t bits << 32 | chain index (EMPTY: cleared)
-    uint32_t *stack = reinterpret_cast<uint32_t *>(key + M);            // [M/2 + 64] run starts, then the anomaly mask
-    uint8_t *mark = reinterpret_cast<uint8_t *>(stack + M / 2 + 64);    // [M]
-    uint8_t *emitf = mark + M;                                          // [M]
-    uint32_t *mwords = reinterpret_cast<uint32_t *>(emitf + M);         // [M / 32] the emit mask
-    const int lane = threadIdx.x;
-    const size_t n_items = *literal_count;
-    auto Tk = [](uint64_t k) { return __uint_as_float((uint32_t)(k >> 32)); };
-    auto T = [&](uint32_t j) { return Tk(key[j]); };
-    auto ID = [&](uint32_t j) { return (uint32_t)key[j]; };
-    for (size_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const uint2 ent = literal_list[it];
-        const size_t ray = ent.x;                                       // row of the log = ray index within the call
-        const uint32_t nh = ent.y < M ? ent.y : M - 1;
-        const uint4 *lg = hit_log + (ray >> 6) * (size_t)M * 64 + (ray & 63);
-        bool hull_first = false;
-        for (uint32_t j = lane; j < nh; j += 64) {
-            const uint4 e = lg[(size_t)j * 64];
-            key[j] = ((uint64_t)e.x << 32) | j;
-            mark[j] = 0;
-            if (j == 0) hull_first = (e.w >> 30) == 3u;
-        }
-        hull_first = __shfl((int)hull_first, 0) != 0;
-        wave_sync();
-        // bitonic sort of the keys (t, chain index)
-        {
-            uint32_t Np = 1;
-            while (Np < nh) Np <<= 1;
-            for (uint32_t i = nh + lane; i < Np; i += 64) key[i] = ~0ull;
-            wave_sync();
-            for (uint32_t k = 2; k <= Np; k <<= 1)
-                for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
-                    for (uint32_t tix = lane; tix < (Np >> 1); tix += 64) {
-                        const uint32_t i = ((tix & ~(jj - 1)) << 1) | (tix & (jj - 1));
-                        const uint32_t ij = i | jj;
-                        const uint64_t a = key[i], b = key[ij];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up && a != b) { key[i] = b; key[ij] = a; }
-                    }
-                    wave_sync();
-                }
-        }
-        // two faces share a tetrahedron iff they are chain neighbours (or the two hull faces: EMPTY == EMPTY)
-        auto common = [&](uint32_t ka, uint32_t kb) {
-            return ka + 1 == kb || kb + 1 == ka || (hull_first && ((ka == 0 && kb == nh - 1) || (kb == 0 && ka == nh - 1)));
-        };
-        uint32_t why = 0;   // -> BVH path: 14 an emitted pair is not (k - 1, k), 15 segments out of chain order
-        // exact ties in t are ordered by FACE ID in the reference's total order (near an edge several faces of the fan
-        // share one fp32 t): fetch the face ids of the tied entries only (log entry -> walk record) and rank every tie
-        // group by them
-        {
-            bool tied[8];
-            uint64_t mine[8];
-            uint32_t newpos[8];
-            bool any_tie = false;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t j = (uint32_t)c * 64 + lane;
-                tied[c] = false; mine[c] = 0; newpos[c] = j;
-                if (j < nh) {
-                    mine[c] = key[j];
-                    const uint32_t tb = (uint32_t)(mine[c] >> 32);
-                    tied[c] = (j > 0 && (uint32_t)(key[j - 1] >> 32) == tb) || (j + 1 < nh && (uint32_t)(key[j + 1] >> 32) == tb);
-                }
-                any_tie |= tied[c];
-            }
-            if (__ballot(any_tie)) {   // wave-uniform
-                uint32_t fid[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    fid[c] = 0;
-                    if (tied[c]) {
-                        const uint32_t k = (uint32_t)mine[c];
-                        const uint32_t w = lg[(size_t)k * 64].w;
-                        const uint32_t x = w >> 30, lo = w & 0x3FFFFFFFu;
-                        fid[c] = x == 3u ? lo : reinterpret_cast<const uint32_t *>(vars + lo)[3 + 4 * x];
-                    }
-                }
-                // publish (t stays in the key's high word; the low word temporarily carries the face id of tied entries)
-                wave_sync();
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const uint32_t j = (uint32_t)c * 64 + lane;
-                    if (j < nh && tied[c]) key[j] = (mine[c] & 0xFFFFFFFF00000000ull) | fid[c];
-                }
-                wave_sync();
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const uint32_t j = (uint32_t)c * 64 + lane;
-                    if (j < nh && tied[c]) {
-                        const uint32_t tb = (uint32_t)(mine[c] >> 32);
-                        uint32_t gs = j, rank = 0;
-                        while (gs > 0 && (uint32_t)(key[gs - 1] >> 32) == tb) --gs;
-                        for (uint32_t m2 = gs; m2 < nh && (uint32_t)(key[m2] >> 32) == tb; ++m2)
-                            if ((uint32_t)key[m2] < fid[c]) ++rank;
-                        newpos[c] = gs + rank;
-                    }
-                }
-                wave_sync();
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const uint32_t j = (uint32_t)c * 64 + lane;
-                    if (j < nh && tied[c]) key[newpos[c]] = mine[c];   // a permutation inside the tie group, chain index restored
-                }
-                wave_sync();
-            }
-        }
-        // ---- phase 1, one lane per run of sub-eps gaps (see postprocess_and_write)
-        uint32_t nruns = 0;
-        for (uint32_t base = 0; base < nh; base += 64) {
-            const uint32_t j = base + lane;
-            bool start = false;
-            if (j + 1 < nh) {
-                const bool sj = fabsf(T(j + 1) - T(j)) < TN_EPS;
-                const bool sp = j > 0 && fabsf(T(j) - T(j - 1)) < TN_EPS;
-                start = sj && !sp;
-            }
-            const uint64_t m = __ballot(start);
-            if (start) stack[nruns + __popcll(m & lanemask_lt())] = j;   // at most nh / 2 runs
-            nruns += __popcll(m);
-        }
-        wave_sync();
-        for (uint32_t ci = lane; ci < nruns; ci += 64) {
-            for (uint32_t j = stack[ci];; ++j) {
-                if (ID(j) != TN_EMPTY) {
-                    const float dn = T(j);
-                    bool clear_self = false;
-                    for (uint32_t off = 1; j + off < nh && (ID(j + off) == TN_EMPTY || fabsf(T(j + off) - dn) < TN_EPS); ++off) {
-                        if (ID(j + off) != TN_EMPTY && common(ID(j), ID(j + off))) {
-                            clear_self = true;   // distinct faces: the ids always differ
-                            if (mark[j + off]) key[j + off] |= 0xFFFFFFFFull;
-                            else mark[j + off] = 1;
-                        }
-                    }
-                    if (clear_self && mark[j]) key[j] |= 0xFFFFFFFFull;
-                    mark[j] = 0;
-                }
-                if (!(j + 1 < nh && fabsf(T(j + 1) - T(j)) < TN_EPS)) break;
-            }
-        }
-        wave_sync();
-        // ---- phase 2: plain steps by all lanes, anomalies by lane 0
-        unsigned long long *amask = reinterpret_cast<unsigned long long *>(stack);
-        for (uint32_t base = 0; base < nh; base += 64) {
-            const uint32_t j = base + lane;
-            bool anomalous = false;
-            uint8_t em = 0;
-            if (j + 1 < nh && ID(j) != TN_EMPTY) {
-                const bool plain = ID(j + 1) != TN_EMPTY && common(ID(j), ID(j + 1));
-                anomalous = !plain;
-                em = (plain && fabsf(T(j) - T(j + 1)) >= TN_EPS) ? 1 : 0;
-            }
-            if (j < nh) emitf[j] = em;
-            const uint64_t m = __ballot(anomalous);
-            if (lane == 0) amask[base >> 6] = m;
-        }
-        wave_sync();
-        if (lane == 0) {
-            const uint32_t nwords = (nh + 63) >> 6;
-            auto next_anomaly = [&](uint32_t from) -> uint32_t {
-                for (uint32_t w = from >> 6; w < nwords; ++w) {
-                    unsigned long long m = amask[w];
-                    if (w == (from >> 6)) m &= ~0ull << (from & 63);
-                    if (m) return (w << 6) + (uint32_t)__ffsll(m) - 1;
-                }
-                return nh;
-            };
-            uint32_t touched = 0;
-            uint32_t j = next_anomaly(0);
-            while (j < nh) {
-                emitf[j] = 0;
-                if (ID(j) != TN_EMPTY) {
-                    if (j + 1 < nh && ID(j + 1) != TN_EMPTY && common(ID(j), ID(j + 1))) {
-                        if (fabsf(T(j) - T(j + 1)) >= TN_EPS) emitf[j] = 1;
-                    } else {
-                        const uint32_t orig = ID(j);
-                        float dn = T(j);
-                        uint32_t real_off = 1;
-                        for (uint32_t off = 1; j + off < nh && (real_off < 3 || ID(j + off) == TN_EMPTY || fabsf(T(j + off) - dn) < TN_EPS); ++off) {
-                            if (ID(j + off) == TN_EMPTY) continue;
-                            if (common(orig, ID(j + off))) {
-                                if (fabsf(T(j) - T(j + off)) >= TN_EPS) emitf[j] = 1;
-                                if (off > 1) {
-                                    const uint64_t k0 = key[j + off]; key[j + off] = key[j + 1]; key[j + 1] = k0;
-                                    const uint8_t m0 = mark[j + off]; mark[j + off] = mark[j + 1]; mark[j + 1] = m0;
-                                    touched = j + off > touched ? j + off : touched;
-                                }
-                                break;
-                            }
-                            dn = T(j + off);
-                            real_off++;
-                        }
-                    }
-                }
-                ++j;
-                if (j > touched) j = next_anomaly(j);
-            }
-        }
-        wave_sync();
-        // ---- emitted pairs -> mask bits; every pair must be (k - 1, k) and the pairs must come in chain order
-        uint32_t nseg = 0, last_k = 0;   // last_k: chain index of the previous emitted pair's exit face
-        for (uint32_t base = 0; base < nh; base += 64) {
-            const uint32_t j = base + lane;
-            const bool emit = j + 1 < nh && emitf[j] != 0;
-            uint32_t kb = 0;
-            if (emit) {
-                const uint32_t ka = ID(j);
-                kb = ID(j + 1);
-                if (kb != ka + 1) why = 14;
-            }
-            // order: the exit indices of the emitted pairs must ascend with the slot
-            const uint64_t m = __ballot(emit);
-            uint32_t prev = last_k;
-            {
-                // exit index of the nearest emitting lane below this one
-                const uint64_t below = m & lanemask_lt();
-                const int src = below ? 63 - __clzll((unsigned long long)below) : 0;
-                const uint32_t pk = (uint32_t)__shfl((int)kb, src);
-                if (below) prev = pk;
-            }
-            if (emit && nseg + __popcll(m & lanemask_lt()) > 0 && kb <= prev && !why) why = 15;
-            if (m) {
-                const int top = 63 - __clzll((unsigned long long)m);
-                last_k = (uint32_t)__shfl((int)kb, top);
-            }
-            nseg += __popcll(m);
-        }
-        const bool bad = __ballot(why != 0) != 0ull;
-        {
-            const uint64_t m14 = __ballot(why == 14);
-            why = m14 ? 14u : 15u;   // wave-uniform reason if bad
-        }
-        // mask words: bit k set iff the pair (k - 1, k) is emitted; built from the final slots, in LDS, stored once
-        for (uint32_t w = lane; w < M / 32; w += 64) mwords[w] = 0u;
-        wave_sync();
-        if (!bad) {
-            for (uint32_t j = lane; j + 1 < nh; j += 64)
-                if (emitf[j]) { const uint32_t kb = ID(j + 1); atomicOr(&mwords[kb >> 5], 1u << (kb & 31)); }
-        }
-        wave_sync();
-        if (!bad) {
-            uint32_t *mrow = emit_mask + ray * (size_t)(M / 32);
-            for (uint32_t w = lane; w < M / 32; w += 64) mrow[w] = mwords[w];
-        }
-        if (lane == 0) {
-            if (bad) {
-                const uint32_t slot = atomicAdd(fallback_count, 1u);
-                fallback_list[slot] = (uint32_t)(ray_base + ray);
-                if (stats) atomicAdd(&stats[4 + why], 1ull);
-            } else {
-                walk_n[ray] = nh | LITERAL_MASK_FLAG;
-                out_num[ray] = nseg;
-                atomicMax(kmax, nseg);
-                if (stats) { atomicAdd(&stats[4 + 13], 1ull); atomicAdd(&stats[2], 1ull); }   // paired literally (trace_stats)
-            }
-        }
-        wave_sync();
-    }
-}
-
-void launch_literal_mask(uint32_t M, const WalkVar *vars, const uint4 *hit_log, const uint2 *literal_list, const uint32_t *literal_count, size_t max_items,
-                         uint32_t *walk_n, uint32_t *out_num, uint32_t *emit_mask, uint32_t *fallback_list, uint32_t *fallback_count,
-                         uint32_t *kmax, size_t ray_base, unsigned long long *stats, hipStream_t stream) {
-    if (max_items == 0) return;
-    if (M > 512) throw Error("literal mask: max_ray_triangles above 512 is handled by the row kernel");
-    const size_t smem = (size_t)M * 8 + ((size_t)M / 2 + 64) * 4 + 2 * (size_t)M + (size_t)(M / 32) * 4;
-    const size_t max_blocks = 256 * 24;
-    const unsigned grid = (unsigned)(max_items < max_blocks ? max_items : max_blocks);
-    hipLaunchKernelGGL(k_literal_mask, dim3(grid), dim3(64), smem, stream, M, vars, hit_log, literal_list, literal_count, walk_n, out_num,
-                       emit_mask, fallback_list, fallback_count, kmax, ray_base, stats);
-}
 
 // trace_rays_triangles: the sorted all-hits list itself, no pairing
 // (src/optix/optix_trace_rays_triangles.cu:50-87).  Slots >= count: 0 in every array -- what the reference's

@@ -110,8 +110,6 @@ __device__ __forceinline__ float sel4f(float a, float b, float c, float d, uint3
 // chain below into a dynamically indexed vector, parks the record in LDS and reads `nb` back with a ds_read -- an
 // LDS round trip on the one dependent chain of the walk (record -> exit -> next record).
 struct Var { float px, py, pz; uint32_t nb0, nb1, nb2, code_hi, f0, f1, f2, code_lo, orig; };
-// (FAT walks also log the tet id, the combine code and -- quad 3, requested at the top of the step -- the vertex ids)
-template <bool FAT>
 __device__ __forceinline__ Var load_var(const WalkVar *vars, uint32_t c) {
     const uint32_t *r = reinterpret_cast<const uint32_t *>(vars + c);
     const float4 q0 = *reinterpret_cast<const float4 *>(r);
@@ -139,7 +137,6 @@ __device__ __forceinline__ SV selsv(const SV &p0, const SV &p1, const SV &p2, co
 // or recomputed, one vertex is sheared per step, three edge functions against it decide the exit, and the exit
 // face's edge functions are evaluated directly in its stored order (E(P,Q) == -E(Q,P) bitwise, so they equal the
 // shared ones): bit-identical hits for 30 % fewer instructions than a per-tet record with dynamic selects.
-template <bool FAT>
 __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     const TraceParams &t = p.t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -151,12 +148,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     // across the frame (an XCD owning one contiguous band would own all the misses or all the
     // long rays).
     const uint32_t nblk = (uint32_t)((t.num_items + WALK_BLOCK - 1) / WALK_BLOCK);
-    uint32_t lb = blockIdx.x;
-    if (!(p.debug & 4u)) {
-        const uint32_t G = (p.debug & 8u) ? (nblk + 7) / 8 : XCD_GROUP;
-        const uint32_t super = blockIdx.x / (8 * G), rem = blockIdx.x % (8 * G);
-        lb = super * 8 * G + (rem & 7) * G + (rem >> 3);
-    }
+    const uint32_t super = blockIdx.x / (8 * XCD_GROUP), rem = blockIdx.x % (8 * XCD_GROUP);
+    const uint32_t lb = super * 8 * XCD_GROUP + (rem & 7) * XCD_GROUP + (rem >> 3);
     if (lb >= nblk) return;
     const size_t ray = (size_t)lb * WALK_BLOCK + threadIdx.x;
     const bool active = ray < t.num_items;
@@ -222,7 +215,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     // Every recorded (valid) hit k of this ray is one 16-byte entry of the hit log, at
     // log[(wave of 64 rays) * M + k][lane]: the lanes of a wave store consecutive bytes.
     const size_t gw = (size_t)lb * (WALK_BLOCK / 64) + (size_t)wave;
-    const size_t logoff = gw * (size_t)M * 64 + (size_t)lane;   // same index into the three log arrays (bases stay scalar)
+    const size_t logoff = gw * (size_t)M * 64 + (size_t)lane;
     uint4 *mylog = p.hit_log + logoff;
 
     bool alive = nhull == 2 && !flag;
@@ -250,7 +243,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     uint32_t fid_prev = f_in0;  // face id of the previous recorded hit (ties are ordered by id)
     uint32_t nhits = 0, nshort = 0;
     uint32_t steps = 0;
-    Var cur = load_var<FAT>(p.vars, c);
+    Var cur = load_var(p.vars, c);
     if (alive) {
         // the entry hull face itself may be the first recorded hit (exit code 3 = "hull face id in the low bits")
         float tt, uu, vv;
@@ -264,8 +257,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         // All checks of a step accumulate into `bad` (first reason kept), straight-line: as nested ifs the checks
         // became a dozen exec-masked branches per step.
         uint32_t bad = 0;
-        uint4 myvid = make_uint4(0u, 0u, 0u, 0u);   // vertex ids of this tet: wanted at the end of the step (log)
-        if constexpr (FAT) myvid = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(p.vars + c) + 12);
         const SV P = shear(rp, cur.px, cur.py, cur.pz);
         const float ea = edge_f(P, A), eb = edge_f(P, B), ec = edge_f(P, C);
         bad = (fabsf(P.x) + fabsf(P.y) < pad) ? 4u : bad;                  // vertex within rounding distance of the ray
@@ -284,7 +275,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         const uint32_t fx = sel3u(cur.f0, cur.f1, cur.f2, x);        // id of the exit face
         const bool last = nb == TN_EMPTY;
         // the next record is requested as soon as the exit is known
-        const Var nxt = load_var<FAT>(p.vars, (last || bad) ? c : nb);
+        const Var nxt = load_var(p.vars, (last || bad) ? c : nb);
         __builtin_amdgcn_sched_barrier(0);
 
         // the exit face in its stored order: 12-bit code of exit x out of the 36-bit word
@@ -319,10 +310,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         if (valid && nhits < M - 1) {
             // hit `nhits` of this ray: (t, u, v) in the face's stored order + the tet it closes (variant, exit)
             mylog[(size_t)nhits * 64] = make_uint4(__float_as_uint(ct), __float_as_uint(cu), __float_as_uint(cv), c | (x << 30));
-            if constexpr (FAT) {   // what the segment writer needs of record c: it then never touches the records
-                p.hit_log_v[logoff + (size_t)nhits * 64] = myvid;
-                p.hit_log_o[logoff + (size_t)nhits * 64] = cur.orig | ((code >> 6) << 26);
-            }
         }
         nhits += valid ? 1u : 0u;
         have_pp = valid ? have_prev : have_pp;
@@ -345,7 +332,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
 
     // ------------------------------------------------------------------ classes, hand-over lists, hit counts
     order_ok = order_ok && !prev_inv;   // a pair inverted at the very end has no following face to clear it
-    const bool certified = active && !flag && order_ok;
     const uint32_t nseg = nhits ? nhits - 1 - nshort : 0;   // every consecutive pair that is not short
     if (active) {
         if (flag || (!order_ok && !p.literal_list)) {
@@ -356,21 +342,13 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         } else if (!order_ok) {
             if (t.stats) atomicAdd(&t.stats[4 + 7], 1ull);
             const uint32_t slot = atomicAdd(p.literal_count, 1u);
-            p.literal_list[slot] = make_uint2(p.lit_base + (uint32_t)ray, nhits);   // index within this walk launch (= log row)
+            p.literal_list[slot] = make_uint2((uint32_t)ray, nhits);   // index within this walk launch (= log row)
             p.walk_n[ray] = TN_EMPTY;   // k_postprocess_log writes the whole row
         } else {
             p.walk_n[ray] = nhits;      // hits in the log (0 for a miss)
             t.out_num[ray] = nseg;
         }
     }
-    // largest segment count of a certified ray: k_fill_range may write the slots from ceil32(K) on of EVERY row
-    uint32_t km = certified ? nseg : 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t o2 = (uint32_t)__shfl_xor((int)km, off);
-        km = o2 > km ? o2 : km;
-    }
-    if (lane == 0 && km) atomicMax(p.kmax, km);
 }
 
 
@@ -379,20 +357,51 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
 // 8 full 128-byte lines of the log (entries of neighbouring rays are neighbours in the log).  For a certified ray
 // (header of this file) hits k-1 and k bound the tet recorded with hit k, and the pair is a segment unless it is
 // shorter than eps; emitted slots are numbered by a per-ray prefix count over the wave ballot.  The tet id /
-// vertex ids / combine_indices code come from the 64-byte walk record of (tet, entry face); bary_out is selected
-// exactly as combine_indices does (optix_trace_rays.cu:39-75).  The slots between the last segment and the next
-// multiple of 32 (where all four row arrays are on a 128-byte line boundary) get their tail constants here, so
-// that k_fill_range starts every row on a line boundary and no line is written by two kernels.
-// The kernel is latency-bound: per iteration (4 x 8 hits of each of the 8 rays) the chain is log entries -> walk
-// records -> stores, and gfx950 retires loads and stores of a wave in issue order (one vmcnt), so a load issued
-// after an iteration's ~24 scattered stores is only "back" once those are acknowledged.  Hence the software
-// pipeline: the entries of the NEXT iteration -- of this group, or of the wave's next group, whose hit counts were
-// requested a whole group earlier -- are requested BEFORE this iteration's record loads and stores; waiting for
-// them later never waits for a store.  One exposed round trip per iteration instead of three.  Groups are dealt
-// round-robin to the waves (the rays that miss the mesh are clustered).
-template <int U>   // chunks of 8 hits per ray per iteration
-__global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// vertex ids / combine_indices code come from the 64-byte walk record of (tet, entry face), read as two 16-byte
+// quads; bary_out is selected exactly as combine_indices does (optix_trace_rays.cu:39-75).  The slots between the
+// last segment and the next multiple of 32 (where all four row arrays are on a 128-byte line boundary) get their
+// tail constants here, so that k_fill_range starts every row on a line boundary and no line is written by two kernels.
+//
+// Stores: the 52-byte segment records of an iteration (8 rays x up to 8U slots) are staged in the wave's LDS region
+// laid out [array][ray][slot] and read back with lane = (ray, consecutive dword / 8-byte / 16-byte unit of that ray's
+// run): every store instruction writes contiguous runs per ray instead of 8 rows in 32..192-byte pieces (round 2b's
+// ablation: the scattered stores were half of the direct-store kernel's time, profiles/r02b_writer_ablate.txt).
+//
+// Loads: the kernel is latency-bound (round 3 PMC, profiles/r03a_pmc_1.txt: its waves spend 66 % of their cycles in
+// s_waitcnt).  Per iteration the chain is log entries -> walk records -> stores, and gfx950 retires loads and stores
+// of a wave in issue order (one vmcnt), so a load issued after an iteration's stores is only "back" once those are
+// acknowledged.  Hence the software pipeline: the entries of the NEXT iteration -- of this group, or of the wave's
+// next group, whose hit counts were requested a whole group earlier -- are requested BEFORE this iteration's record
+// loads and stores.  Groups are dealt round-robin to the waves (the rays that miss the mesh are clustered).
+// U = chunks of 8 hits per ray per iteration: U = 4 keeps 32 hits per ray in flight per wave at 2 waves per SIMD;
+// U = 2 halves registers and LDS (7 KB per wave) for 4 waves per SIMD.  The wave index is made wave-uniform
+// (readfirstlane), so the group index, the log base and the row base live in scalar registers.
+namespace {
+template <int U>
+struct SW {
+    static constexpr int SLOTS = 8 * U;                   // segment slots per ray per iteration
+    static constexpr int STRIDE = SLOTS + 1;              // padded against bank conflicts between the 8 rays
+    static constexpr int CELLS = 0;                       // [8][STRIDE] dwords
+    static constexpr int DIST = 8 * STRIDE;               // [8][STRIDE][2]
+    static constexpr int BARY = DIST + 8 * STRIDE * 2;    // [8][STRIDE][6]
+    static constexpr int VERTS = BARY + 8 * STRIDE * 6;   // [8][STRIDE][4]
+    static constexpr int META = VERTS + 8 * STRIDE * 4;   // [8] x {segments of this iteration, first slot}
+    static constexpr int TOTAL = META + 16;               // U = 4: 3448 dwords = 13,792 B per wave; U = 2: 1784 = 7,136 B
+};
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+}  // namespace
+
+template <int U>
+__global__ __launch_bounds__(256, U == 2 ? 4 : 2) void k_write_segments(WriteParams q) {
+    using W = SW<U>;
+    __shared__ __attribute__((aligned(16))) uint32_t smem[4 * W::TOTAL];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *L = smem + wave * W::TOTAL;
     const uint32_t a = (uint32_t)lane & 7u, h = (uint32_t)lane >> 3;
     const uint32_t M = q.M;
     const size_t G = (q.num_rays + 7) / 8;                 // groups of 8 rays
@@ -403,17 +412,16 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
         const size_t r = 8 * g + a;
         return (g < G && r < q.num_rays) ? q.walk_n[r] : TN_EMPTY;
     };
-    auto log_of = [&](size_t g) -> const uint4 * {         // entry k of ray 8g + a at [k * 64]
+    auto log_of = [&](size_t g) -> const uint4 * {         // (scalar) entry k of ray 8g + a at [k * 64 + a]
         const size_t r0 = 8 * g;
-        return q.hit_log + (r0 >> 6) * (size_t)M * 64 + (r0 & 63) + a;
+        return q.hit_log + (r0 >> 6) * (size_t)M * 64 + (r0 & 63);
     };
-    const bool fat = q.hit_log_v != nullptr;   // the walk logged the tet id / vertex ids / combine code of every hit
     auto load_entries = [&](uint4 (&e)[U], const uint4 *lg, uint32_t nh, uint32_t c0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t k = c0 + 8 * u + h;
             e[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (k < nh) e[u] = lg[(size_t)k * 64];
+            if (k < nh) e[u] = lg[k * 64u + a];             // scalar base + 32-bit lane offset
         }
     };
 
@@ -422,14 +430,10 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
     uint32_t nh_raw = hits_of(g);
     uint32_t nh_next_raw = hits_of(g + nwaves);            // in flight during the whole first group
     uint4 e[U];
-    {
-        const uint32_t nh0 = nh_raw == TN_EMPTY ? 0u : (nh_raw & ~LITERAL_MASK_FLAG);
-        load_entries(e, log_of(g), nh0, 0);
-    }
+    load_entries(e, log_of(g), nh_raw == TN_EMPTY ? 0u : nh_raw, 0);
     for (; g < G; g += nwaves) {
-        const bool skip = nh_raw == TN_EMPTY;   // fallback ray (or padding): the row belongs to another kernel
-        const bool masked = !skip && (nh_raw & LITERAL_MASK_FLAG) != 0;   // segments = set bits of the ray's emit mask
-        const uint32_t nh = skip ? 0u : (nh_raw & ~LITERAL_MASK_FLAG);
+        const bool skip = nh_raw == TN_EMPTY;   // literal / fallback ray (or padding): the row belongs to another kernel
+        const uint32_t nh = skip ? 0u : nh_raw;
         uint32_t mx = nh;                       // max over the 8 rays (the value is replicated over h)
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {
@@ -438,10 +442,16 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
         }
         mx = __builtin_amdgcn_readfirstlane(mx);
         const uint4 *lg = log_of(g);
-        const size_t row = (8 * g + a) * (size_t)M;
+        // rows of the group: scalar bases (first slot of ray 8g) + 32-bit lane offsets (< 8 M slots)
+        const size_t row0 = 8 * g * (size_t)M;
+        uint32_t *const g_cells = q.out_cells + row0;
+        float *const g_dist = q.out_dist + 2 * row0;
+        float *const g_bary = q.out_bary + 6 * row0;
+        uint32_t *const g_verts = q.out_verts ? q.out_verts + 4 * row0 : nullptr;
+        const uint32_t row = a * M;
         // the group after the next: its hit counts are requested now, needed one group later
         const size_t g_next = g + nwaves;
-        const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : (nh_next_raw & ~LITERAL_MASK_FLAG);
+        const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : nh_next_raw;
         const uint32_t nh_next2_raw = hits_of(g_next + nwaves);
         uint32_t nseg = 0;
         uint4 carry = make_uint4(0u, 0u, 0u, 0u);   // hit c0 - 1 of ray a
@@ -452,188 +462,11 @@ __global__ __launch_bounds__(256) void k_write_segments(WriteParams q) {
             const bool more = c0 + 8 * U < mx;   // wave-uniform
             if (more) load_entries(en, lg, nh, c0 + 8 * U);
             else load_entries(en, log_of(g_next), g_next < G ? nh_next : 0u, 0);
-            // ---- this iteration: previous hit of every lane (lane - 8, or the last hit of the previous chunk),
-            //      emission, slots
-            uint4 pe[U];
-            uint32_t slot[U];   // TN_EMPTY: no segment
-            uint32_t mword = 0u;   // literal ray: bit k = "the pair (k - 1, k) is a segment" (k_literal_mask)
-            if (masked) mword = q.emit_mask[(8 * g + a) * (size_t)(M / 32) + (c0 >> 5)];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t k = c0 + 8 * u + h;
-                pe[u].x = (uint32_t)__shfl_up((int)e[u].x, 8); pe[u].y = (uint32_t)__shfl_up((int)e[u].y, 8);
-                pe[u].z = (uint32_t)__shfl_up((int)e[u].z, 8); pe[u].w = 0u;
-                if (h == 0) pe[u] = carry;
-                carry.x = (uint32_t)__shfl((int)e[u].x, (int)a + 56); carry.y = (uint32_t)__shfl((int)e[u].y, (int)a + 56);
-                carry.z = (uint32_t)__shfl((int)e[u].z, (int)a + 56);
-                const bool pair_ok = masked ? ((mword >> (k & 31u)) & 1u) != 0
-                                            : !(fabsf(__uint_as_float(pe[u].x) - __uint_as_float(e[u].x)) < TN_EPS);
-                const bool emit = k >= 1 && k < nh && pair_ok;
-                const unsigned long long m = __ballot(emit) & raymask;
-                slot[u] = emit ? nseg + (uint32_t)__popcll(m & lanemask_lt()) : TN_EMPTY;
-                nseg += (uint32_t)__popcll(m);
-            }
-            // ---- walk records of the emitted segments
-            uint32_t orig[U], chi[U], clo[U];
-            uint4 vid[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                orig[u] = 0; chi[u] = 0; clo[u] = 0; vid[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (slot[u] != TN_EMPTY && !(q.ablate & 1u)) {
-                    if (fat) {
-                        const size_t at = (size_t)(lg - q.hit_log) + (size_t)(c0 + 8 * u + h) * 64;
-                        const uint32_t o = q.hit_log_o[at];
-                        vid[u] = q.hit_log_v[at];
-                        orig[u] = o & 0x03FFFFFFu;
-                        clo[u] = (o >> 26) << (6 + 12 * (e[u].w >> 30));   // the 6 combine bits where the decode below looks for them
-                        chi[u] = (e[u].w >> 30) == 2u ? ((o >> 26) >> 2) : 0u;
-                    } else {
-                        const uint32_t *rec = reinterpret_cast<const uint32_t *>(q.vars + (e[u].w & 0x3FFFFFFFu));
-                        const uint4 q2 = *reinterpret_cast<const uint4 *>(rec + 8);
-                        orig[u] = q2.x; clo[u] = q2.y; chi[u] = q2.z;
-                        vid[u] = *reinterpret_cast<const uint4 *>(rec + 12);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (slot[u] != TN_EMPTY) {
-                    const size_t sl = row + slot[u];
-                    const uint32_t x = e[u].w >> 30;
-                    const bool x0 = (x & 1u) != 0, x1 = (x & 2u) != 0;
-                    const uint32_t w01 = x0 ? (clo[u] >> 12) : clo[u];
-                    const uint32_t w2 = (clo[u] >> 24) | (chi[u] << 8);
-                    const uint32_t code = (x1 ? w2 : w01) & 0xFFFu;
-                    const float pt = __uint_as_float(pe[u].x), pu = __uint_as_float(pe[u].y), pv = __uint_as_float(pe[u].z);
-                    const float ct = __uint_as_float(e[u].x), cu = __uint_as_float(e[u].y), cv = __uint_as_float(e[u].z);
-                    const float r0f = 1.0f - cu - cv;
-                    const uint32_t k0 = (code >> 6) & 3u, k1 = (code >> 8) & 3u, k2 = (code >> 10) & 3u;
-                    if (q.ablate & 4u) { if (orig[u] == 0xFFFFFFF1u) q.out_cells[sl] = code + k0; continue; }
-                    q.out_cells[sl] = orig[u];
-                    if (q.ablate & 2u) { if (k0 + k1 + k2 + vid[u].x == 0xFFFFFFF1u) q.out_cells[sl] = __float_as_uint(pt + ct + pu + pv); continue; }
-                    *reinterpret_cast<float2 *>(q.out_dist + 2 * sl) = make_float2(pt, ct);
-                    float2 *bp = reinterpret_cast<float2 *>(q.out_bary + 6 * sl);
-                    bp[0] = make_float2(1.0f - pu - pv, pu);
-                    bp[1] = make_float2(pv, sel4f(r0f, cu, cv, 0.f, k0));
-                    bp[2] = make_float2(sel4f(r0f, cu, cv, 0.f, k1), sel4f(r0f, cu, cv, 0.f, k2));
-                    if (q.out_verts) *reinterpret_cast<uint4 *>(q.out_verts + 4 * sl) = vid[u];   // (n, a, b, c)
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) e[u] = en[u];
-            c0 += 8 * U;
-        } while (c0 < mx);
-        // tail constants up to the next multiple of 32 slots (line boundary of all four arrays)
-        if (q.dense_tails && !skip) {
-            uint32_t n32 = (nseg + 31u) & ~31u;
-            if (n32 > M) n32 = M;
-            for (uint32_t sl = nseg + h; sl < n32; sl += 8) {
-                const size_t slot = row + sl;
-                q.out_cells[slot] = TN_EMPTY;
-                *reinterpret_cast<float2 *>(q.out_dist + 2 * slot) = make_float2(0.f, 0.f);
-                float2 *bp = reinterpret_cast<float2 *>(q.out_bary + 6 * slot);
-                bp[0] = make_float2(0.f, 0.f); bp[1] = make_float2(0.f, 0.f); bp[2] = make_float2(0.f, 0.f);
-                if (q.out_verts) *reinterpret_cast<uint4 *>(q.out_verts + 4 * slot) = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
-            }
-        }
-        nh_raw = nh_next_raw;
-        nh_next_raw = nh_next2_raw;
-    }
-}
-
-// The same hit log -> segment rows, with the stores made whole-line: round 2b's ablation of the kernel above
-// (profiles/r02b_writer_ablate.txt) showed that half of its time is the ~24 scattered store instructions per
-// iteration -- lane (ray a, hit h) writes its own 4 / 8 / 24 / 16 bytes, so one instruction touches 8 rows in pieces of
-// 32..192 bytes -- and a fifth the four scattered record loads per hit.  Here the 52-byte segment records of an
-// iteration (8 rays x up to 32 slots) are staged in the wave's LDS region laid out [array][ray][slot], and read back
-// with lane = (ray, consecutive dword / 8-byte / 16-byte unit of that ray's run): every store instruction writes
-// contiguous runs of up to 128 B (cell ids), 256 B (distances), 512 B (vertex ids, barycentrics) per ray.  The
-// record is read as two 16-byte quads (tet id + code, vertex ids).  LDS: 13.8 KB per wave (rows padded to 33 slots
-// against bank conflicts between the 8 rays).  Everything else (pipeline, pairing, slot numbering) as above.
-namespace {
-constexpr int SW_STRIDE = 33;                       // padded slots per ray
-constexpr int SW_CELLS = 0;                         // [8][33] dwords
-constexpr int SW_DIST = 8 * SW_STRIDE;              // [8][33][2]
-constexpr int SW_BARY = SW_DIST + 8 * SW_STRIDE * 2;   // [8][33][6]
-constexpr int SW_VERTS = SW_BARY + 8 * SW_STRIDE * 6;  // [8][33][4]
-constexpr int SW_META = SW_VERTS + 8 * SW_STRIDE * 4;  // [8] x {segments of this iteration, first slot}
-constexpr int SW_TOTAL = SW_META + 16;              // 3448 dwords = 13,792 B per wave
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-}  // namespace
-
-__global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
-    constexpr int U = 4;
-    __shared__ __attribute__((aligned(16))) uint32_t smem[4 * SW_TOTAL];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *L = smem + wave * SW_TOTAL;
-    const uint32_t a = (uint32_t)lane & 7u, h = (uint32_t)lane >> 3;
-    const uint32_t M = q.M;
-    const size_t G = (q.num_rays + 7) / 8;                 // groups of 8 rays
-    const size_t nwaves = (size_t)gridDim.x * 4;
-    const unsigned long long raymask = 0x0101010101010101ull << a;
-
-    auto hits_of = [&](size_t g) -> uint32_t {             // walk_n of ray 8g + a (TN_EMPTY: not this kernel's row)
-        const size_t r = 8 * g + a;
-        return (g < G && r < q.num_rays) ? q.walk_n[r] : TN_EMPTY;
-    };
-    auto log_of = [&](size_t g) -> const uint4 * {         // entry k of ray 8g + a at [k * 64]
-        const size_t r0 = 8 * g;
-        return q.hit_log + (r0 >> 6) * (size_t)M * 64 + (r0 & 63) + a;
-    };
-    const bool fat = q.hit_log_v != nullptr;   // the walk logged the tet id / vertex ids / combine code of every hit
-    auto load_entries = [&](uint4 (&e)[U], const uint4 *lg, uint32_t nh, uint32_t c0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t k = c0 + 8 * u + h;
-            e[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (k < nh) e[u] = lg[(size_t)k * 64];
-        }
-    };
-
-    size_t g = (size_t)blockIdx.x * 4 + wave;
-    if (g >= G) return;
-    uint32_t nh_raw = hits_of(g);
-    uint32_t nh_next_raw = hits_of(g + nwaves);
-    uint4 e[U];
-    {
-        const uint32_t nh0 = nh_raw == TN_EMPTY ? 0u : (nh_raw & ~LITERAL_MASK_FLAG);
-        load_entries(e, log_of(g), nh0, 0);
-    }
-    for (; g < G; g += nwaves) {
-        const bool skip = nh_raw == TN_EMPTY;   // fallback ray (or padding): the row belongs to another kernel
-        const bool masked = !skip && (nh_raw & LITERAL_MASK_FLAG) != 0;   // segments = set bits of the ray's emit mask
-        const uint32_t nh = skip ? 0u : (nh_raw & ~LITERAL_MASK_FLAG);
-        uint32_t mx = nh;
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_xor((int)mx, off);
-            mx = o > mx ? o : mx;
-        }
-        mx = __builtin_amdgcn_readfirstlane(mx);
-        const uint4 *lg = log_of(g);
-        const size_t row0 = 8 * g * (size_t)M;             // first slot of ray 8g
-        const size_t row = row0 + (size_t)a * M;
-        const size_t g_next = g + nwaves;
-        const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : (nh_next_raw & ~LITERAL_MASK_FLAG);
-        const uint32_t nh_next2_raw = hits_of(g_next + nwaves);
-        uint32_t nseg = 0;
-        uint4 carry = make_uint4(0u, 0u, 0u, 0u);
-        uint32_t c0 = 0;
-        do {
-            uint4 en[U];
-            const bool more = c0 + 8 * U < mx;   // wave-uniform
-            if (more) load_entries(en, lg, nh, c0 + 8 * U);
-            else load_entries(en, log_of(g_next), g_next < G ? nh_next : 0u, 0);
+            // ---- previous hit of every lane (lane - 8, or the last hit of the previous chunk), emission, slots
             const uint32_t base = nseg;
             uint4 pe[U];
-            uint32_t slot[U];   // slot within this iteration (0..31), TN_EMPTY: no segment
+            uint32_t slot[U];   // slot within this iteration (0 .. 8U-1), TN_EMPTY: no segment
             unsigned long long any = 0;
-            uint32_t mword = 0u;   // literal ray: bit k = "the pair (k - 1, k) is a segment" (k_literal_mask)
-            if (masked) mword = q.emit_mask[(8 * g + a) * (size_t)(M / 32) + (c0 >> 5)];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t k = c0 + 8 * u + h;
@@ -642,9 +475,7 @@ __global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
                 if (h == 0) pe[u] = carry;
                 carry.x = (uint32_t)__shfl((int)e[u].x, (int)a + 56); carry.y = (uint32_t)__shfl((int)e[u].y, (int)a + 56);
                 carry.z = (uint32_t)__shfl((int)e[u].z, (int)a + 56);
-                const bool pair_ok = masked ? ((mword >> (k & 31u)) & 1u) != 0
-                                            : !(fabsf(__uint_as_float(pe[u].x) - __uint_as_float(e[u].x)) < TN_EPS);
-                const bool emit = k >= 1 && k < nh && pair_ok;
+                const bool emit = k >= 1 && k < nh && !(fabsf(__uint_as_float(pe[u].x) - __uint_as_float(e[u].x)) < TN_EPS);
                 const unsigned long long mall = __ballot(emit);
                 const unsigned long long m = mall & raymask;
                 any |= mall;
@@ -658,25 +489,16 @@ __global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
                 for (int u = 0; u < U; ++u) {
                     qa[u] = make_uint4(0u, 0u, 0u, 0u); qv[u] = qa[u];
                     if (slot[u] != TN_EMPTY) {
-                        if (fat) {
-                            const size_t at = (size_t)(lg - q.hit_log) + (size_t)(c0 + 8 * u + h) * 64;
-                            const uint32_t o = q.hit_log_o[at];
-                            qv[u] = q.hit_log_v[at];
-                            const uint32_t x = e[u].w >> 30, kc = o >> 26;
-                            // tet id, and the 6 combine bits placed where the decode below looks for them
-                            qa[u] = make_uint4(o & 0x03FFFFFFu, kc << (6 + 12 * x), x == 2u ? (kc >> 2) : 0u, 0u);
-                        } else {
-                            const uint32_t *rec = reinterpret_cast<const uint32_t *>(q.vars + (e[u].w & 0x3FFFFFFFu));
-                            qa[u] = *reinterpret_cast<const uint4 *>(rec + 8);
-                            qv[u] = *reinterpret_cast<const uint4 *>(rec + 12);
-                        }
+                        const uint32_t *rec = reinterpret_cast<const uint32_t *>(q.vars + (e[u].w & 0x3FFFFFFFu));
+                        qa[u] = *reinterpret_cast<const uint4 *>(rec + 8);
+                        qv[u] = *reinterpret_cast<const uint4 *>(rec + 12);
                     }
                 }
                 // ---- segment records -> LDS [array][ray][slot]
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (slot[u] != TN_EMPTY) {
-                        const uint32_t at = a * SW_STRIDE + slot[u];
+                        const uint32_t at = a * W::STRIDE + slot[u];
                         const uint32_t x = e[u].w >> 30;
                         const bool x0 = (x & 1u) != 0, x1 = (x & 2u) != 0;
                         const uint32_t w01 = x0 ? (qa[u].y >> 12) : qa[u].y;
@@ -686,39 +508,41 @@ __global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
                         const float ct = __uint_as_float(e[u].x), cu = __uint_as_float(e[u].y), cv = __uint_as_float(e[u].z);
                         const float r0f = 1.0f - cu - cv;
                         const uint32_t k0 = (code >> 6) & 3u, k1 = (code >> 8) & 3u, k2 = (code >> 10) & 3u;
-                        L[SW_CELLS + at] = qa[u].x;
-                        *reinterpret_cast<float2 *>(L + SW_DIST + 2 * at) = make_float2(pt, ct);
-                        float2 *bp = reinterpret_cast<float2 *>(L + SW_BARY + 6 * at);
+                        L[W::CELLS + at] = qa[u].x;
+                        *reinterpret_cast<float2 *>(L + W::DIST + 2 * at) = make_float2(pt, ct);
+                        float2 *bp = reinterpret_cast<float2 *>(L + W::BARY + 6 * at);
                         bp[0] = make_float2(1.0f - pu - pv, pu);
                         bp[1] = make_float2(pv, sel4f(r0f, cu, cv, 0.f, k0));
                         bp[2] = make_float2(sel4f(r0f, cu, cv, 0.f, k1), sel4f(r0f, cu, cv, 0.f, k2));
-                        *reinterpret_cast<uint4 *>(L + SW_VERTS + 4 * at) = qv[u];   // (n, a, b, c)
+                        *reinterpret_cast<uint4 *>(L + W::VERTS + 4 * at) = qv[u];   // (n, a, b, c)
                     }
                 }
-                if (h == 0) *reinterpret_cast<uint2 *>(L + SW_META + 2 * a) = make_uint2(nseg - base, base);
+                if (h == 0) *reinterpret_cast<uint2 *>(L + W::META + 2 * a) = make_uint2(nseg - base, base);
                 wave_lds_fence();
                 // ---- LDS -> rows: lane = (ray a2, unit d of that ray's run of this iteration)
+                constexpr uint32_t RPI = 64 / W::SLOTS;       // rays per instruction for the one-unit-per-slot arrays
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {           // cell ids (4 B), distances (8 B), vertex ids (16 B) per slot
-                    const uint32_t a2 = 2u * qd + ((uint32_t)lane >> 5), d = (uint32_t)lane & 31u;
-                    const uint2 meta = *reinterpret_cast<const uint2 *>(L + SW_META + 2 * a2);
+                for (uint32_t qd = 0; qd < 8 / RPI; ++qd) {   // cell ids (4 B), distances (8 B), vertex ids (16 B) per slot
+                    const uint32_t a2 = RPI * qd + (uint32_t)lane / W::SLOTS, d = (uint32_t)lane % W::SLOTS;
+                    const uint2 meta = *reinterpret_cast<const uint2 *>(L + W::META + 2 * a2);
                     if (d < meta.x) {
-                        const uint32_t at = a2 * SW_STRIDE + d;
-                        const size_t sl = row0 + (size_t)a2 * M + meta.y + d;
-                        q.out_cells[sl] = L[SW_CELLS + at];
-                        *reinterpret_cast<float2 *>(q.out_dist + 2 * sl) = *reinterpret_cast<const float2 *>(L + SW_DIST + 2 * at);
-                        if (q.out_verts) *reinterpret_cast<uint4 *>(q.out_verts + 4 * sl) = *reinterpret_cast<const uint4 *>(L + SW_VERTS + 4 * at);
+                        const uint32_t at = a2 * W::STRIDE + d;
+                        const uint32_t sl = a2 * M + meta.y + d;
+                        g_cells[sl] = L[W::CELLS + at];
+                        *reinterpret_cast<float2 *>(g_dist + 2u * sl) = *reinterpret_cast<const float2 *>(L + W::DIST + 2 * at);
+                        if (g_verts) *reinterpret_cast<uint4 *>(g_verts + 4u * sl) = *reinterpret_cast<const uint4 *>(L + W::VERTS + 4 * at);
                     }
                 }
+                constexpr uint32_t UB = 3 * W::SLOTS;         // barycentrics: 3 x 8 B per slot
 #pragma unroll
-                for (int qd = 0; qd < 12; ++qd) {          // barycentrics: 3 x 8 B per slot, 96 units per ray
+                for (uint32_t qd = 0; qd < 8 * UB / 64; ++qd) {
                     const uint32_t gi = 64u * qd + (uint32_t)lane;
-                    const uint32_t a2 = gi / 96u, d = gi - 96u * a2;
-                    const uint2 meta = *reinterpret_cast<const uint2 *>(L + SW_META + 2 * a2);
+                    const uint32_t a2 = gi / UB, d = gi - UB * a2;
+                    const uint2 meta = *reinterpret_cast<const uint2 *>(L + W::META + 2 * a2);
                     if (d < 3u * meta.x) {
-                        const size_t sl = row0 + (size_t)a2 * M + meta.y;
-                        *reinterpret_cast<float2 *>(q.out_bary + 6 * sl + 2 * d) =
-                            *reinterpret_cast<const float2 *>(L + SW_BARY + 6 * (a2 * SW_STRIDE) + 2 * d);
+                        const uint32_t sl = a2 * M + meta.y;
+                        *reinterpret_cast<float2 *>(g_bary + (6u * sl + 2u * d)) =
+                            *reinterpret_cast<const float2 *>(L + W::BARY + 6 * (a2 * W::STRIDE) + 2 * d);
                     }
                 }
                 wave_lds_fence();
@@ -732,12 +556,12 @@ __global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
             uint32_t n32 = (nseg + 31u) & ~31u;
             if (n32 > M) n32 = M;
             for (uint32_t sl = nseg + h; sl < n32; sl += 8) {
-                const size_t slot = row + sl;
-                q.out_cells[slot] = TN_EMPTY;
-                *reinterpret_cast<float2 *>(q.out_dist + 2 * slot) = make_float2(0.f, 0.f);
-                float2 *bp = reinterpret_cast<float2 *>(q.out_bary + 6 * slot);
+                const uint32_t slot = row + sl;
+                g_cells[slot] = TN_EMPTY;
+                *reinterpret_cast<float2 *>(g_dist + 2u * slot) = make_float2(0.f, 0.f);
+                float2 *bp = reinterpret_cast<float2 *>(g_bary + 6u * slot);
                 bp[0] = make_float2(0.f, 0.f); bp[1] = make_float2(0.f, 0.f); bp[2] = make_float2(0.f, 0.f);
-                if (q.out_verts) *reinterpret_cast<uint4 *>(q.out_verts + 4 * slot) = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
+                if (g_verts) *reinterpret_cast<uint4 *>(g_verts + 4u * slot) = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
             }
         }
         nh_raw = nh_next_raw;
@@ -748,49 +572,38 @@ __global__ __launch_bounds__(256) void k_write_segments_lds(WriteParams q) {
 void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned max_blocks) {
     if (q.num_rays == 0) return;
     size_t blocks = (q.num_rays + 31) / 32;        // one group of 8 rays per wave
-    // default: 2 blocks (8 waves) per CU -- measured best on the 100k / 300k / 1M-tet frames (profiles/r02_walk_sweep.txt):
-    // the software pipeline keeps enough loads in flight per wave, and the literal-pairing / BVH kernels of the side
-    // stream find free wave slots beside it
-    const size_t cap = max_blocks ? max_blocks : 256 * 2;
+    // grid = what is resident at once (U = 4: 2 blocks per CU, U = 2: 4): the groups are dealt round-robin over it
+    const size_t cap = max_blocks ? max_blocks : (size_t)256 * (q.unroll == 2 ? 4 : 2);
     if (blocks > cap) blocks = cap;
-    if (q.variant == 0) {
-        if (q.unroll == 2) hipLaunchKernelGGL(k_write_segments<2>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
-        else hipLaunchKernelGGL(k_write_segments<4>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
-    } else {
-        hipLaunchKernelGGL(k_write_segments_lds, dim3((unsigned)blocks), dim3(256), 0, stream, q);
-    }
+    if (q.unroll == 2) hipLaunchKernelGGL(k_write_segments<2>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    else hipLaunchKernelGGL(k_write_segments<4>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
 }
 
 // Constant tails: pure streaming stores (16 B per lane, whole 128-byte lines), a contiguous span of rows per wave.
 // This is the bulk of the bytes of a trace_rays call (88 % at M = 512) and runs at the write ceiling.  Two uses:
-//   all_rows = 1: slots [K, M) of EVERY row, K = ceil32(*kmax) = the first slot no certified ray reaches; needs
-//                 only the walk, so it streams beside the (latency-bound) segment writer.  Rows of literal /
-//                 fallback rays are included: the kernels that rewrite them run after this one.
-//   all_rows = 0: slots [ceil32(n), K) of the certified rows (k_write_segments has written [0, ceil32(n))).
+//   all_rows = 1: slots [k_split, M) of EVERY row -- needs nothing from the walk, so it streams beside it (speculative
+//                 fill, tn_api.hip).  Rows of literal / fallback rays and rays with more than k_split segments are
+//                 included: the kernels that write those slots are ordered behind this one.
+//   all_rows = 0: slots [ceil32(n), k_split) of the certified rows (k_write_segments has written [0, ceil32(n))).
 template <bool NT>
-__global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M, uint32_t all_rows, uint32_t k_fixed, const uint32_t *__restrict__ kmax,
+__global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M, uint32_t all_rows, uint32_t k_split,
                                                     const uint32_t *__restrict__ walk_n, const uint32_t *__restrict__ out_num,
                                                     uint32_t *__restrict__ out_cells,
                                                     float *__restrict__ out_bary, float *__restrict__ out_dist,
                                                     uint32_t *__restrict__ out_verts) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // row span, row bases: scalar
     const size_t nwaves = (size_t)gridDim.x * 4;
     const size_t span = (num_rays + nwaves - 1) / nwaves;   // consecutive rows are consecutive in memory
     const size_t r0 = ((size_t)blockIdx.x * 4 + wave) * span;
     const size_t r1 = r0 + span < num_rays ? r0 + span : num_rays;
-    uint32_t K = M;
-    if (k_fixed) K = k_fixed;          // host-chosen split point (speculative fill: see launch_fill_range)
-    else if (kmax) {
-        K = (*kmax + 31u) & ~31u;
-        if (K > M) K = M;
-    }
     for (size_t r = r0; r < r1; ++r) {
-        uint32_t lo = K, hi = M;
+        uint32_t lo = k_split, hi = M;
         if (!all_rows) {
             if (walk_n[r] == TN_EMPTY) continue;  // literal / fallback ray: those kernels write the whole row
             lo = (out_num[r] + 31u) & ~31u;
             if (lo > M) lo = M;
-            hi = K;
+            hi = k_split;
         }
         if (lo >= hi) continue;
         fill_dwords<NT>(out_cells + r * M, lo, hi, TN_EMPTY, lane);
@@ -800,54 +613,31 @@ __global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M,
     }
 }
 
-// k_fixed != 0: the split point is chosen by the HOST -- all_rows = 1 then fills slots [k_fixed, M) of EVERY row without
-// needing anything from the walk (speculative fill, streamed beside the walk), all_rows = 0 fills [ceil32(n), k_fixed).
-void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *kmax, const uint32_t *walk_n,
-                       const uint32_t *out_num, uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
-                       unsigned max_blocks, uint32_t k_fixed, bool nontemporal) {
+void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *walk_n, const uint32_t *out_num,
+                       uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
+                       uint32_t k_split, bool nontemporal) {
     if (num_rays == 0) return;
     size_t blocks = (num_rays + 3) / 4;           // >= one ray per wave
-    // default: 2 blocks (8 waves) per CU -- enough to hold the write ceiling, and the latency-bound kernels running
-    // beside the fill are less starved than with 8 per CU (profiles/r01_fill_grid.txt)
-    const size_t cap = max_blocks ? max_blocks : 256 * 2;
+    // after the writer: 2 blocks (8 waves) per CU hold the write ceiling, and the latency-bound kernels running beside
+    // the fill are less starved than with 8 per CU (profiles/r01_fill_grid.txt); beside the walk: 2048 blocks
+    // (profiles/r02p_specfill2.txt)
+    const size_t cap = all_rows ? 2048 : 256 * 2;
     if (blocks > cap) blocks = cap;
     if (nontemporal)
-        hipLaunchKernelGGL(k_fill_range<true>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_fixed, kmax,
+        hipLaunchKernelGGL(k_fill_range<true>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split,
                            walk_n, out_num, out_cells, out_bary, out_dist, out_verts);
     else
-        hipLaunchKernelGGL(k_fill_range<false>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_fixed, kmax,
+        hipLaunchKernelGGL(k_fill_range<false>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split,
                            walk_n, out_num, out_cells, out_bary, out_dist, out_verts);
-}
-
-// Probe kernel (profiles/r02_overlap_probe.py): a pure write stream with a selectable store flavour --
-// 0 plain, 1 nontemporal, 2 sc1 (write-through, the line is dropped from the XCD's L2), 3 sc0 sc1.
-__global__ __launch_bounds__(256) void k_probe_fill(u32x4 *__restrict__ dst, size_t n16, int flavour) {
-    const u32x4 v = {0u, 0u, 0u, 0u};
-    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
-    const size_t per = (n16 + gridDim.x - 1) / gridDim.x;   // contiguous span per block
-    const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n16 ? b0 + per : n16;
-    (void)nthreads;
-    for (size_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) {
-        u32x4 *p = dst + i;
-        if (flavour == 0) *p = v;
-        else if (flavour == 1) __builtin_nontemporal_store(v, p);
-        else if (flavour == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-    }
-}
-void launch_probe_fill(void *dst, size_t bytes, int flavour, unsigned blocks, hipStream_t stream) {
-    if (!bytes) return;
-    hipLaunchKernelGGL(k_probe_fill, dim3(blocks ? blocks : 512), dim3(256), 0, stream, (u32x4 *)dst, bytes / 16, flavour);
 }
 
 void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
     if (p.t.num_items == 0) return;
     const uint32_t nblk = (uint32_t)((p.t.num_items + WALK_BLOCK - 1) / WALK_BLOCK);
-    // grid padded so that both remaps (runs of XCD_GROUP blocks / one band per XCD) are bijections
-    const uint32_t unit = 8 * ((p.debug & 8u) ? (nblk + 7) / 8 : XCD_GROUP);
+    // grid padded so that the remap (runs of XCD_GROUP blocks per XCD) is a bijection
+    const uint32_t unit = 8 * XCD_GROUP;
     const uint32_t grid = (nblk + unit - 1) / unit * unit;
-    if (p.hit_log_v) hipLaunchKernelGGL(k_trace_walk<true>, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
-    else hipLaunchKernelGGL(k_trace_walk<false>, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL(k_trace_walk, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
 }
 
 }  // namespace tn

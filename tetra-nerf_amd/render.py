@@ -168,9 +168,17 @@ def composite(sigma: torch.Tensor, rgb: torch.Tensor, starts: torch.Tensor, ends
     return out_rgb, acc, depth, weights
 
 
+def median_margin(weights: torch.Tensor) -> torch.Tensor:
+    """[R,1] distance of a ray's cumulative weights from the median threshold 0.5: the median depth of a ray is DECIDED
+    (independent of round-off in the weights) when this exceeds the accumulated rounding error of the cumulative sum."""
+    cum = torch.cumsum(weights[..., 0] if weights.dim() == 3 else weights, dim=-1)
+    return (cum - 0.5).abs().min(dim=-1, keepdim=True).values
+
+
 def render_reference(tracer, interpolate_values, field: torch.Tensor, mlp: TetraMLP, origins: torch.Tensor,
                      directions: torch.Tensor, num_samples: int = 256, max_ray_triangles: int = 512,
-                     far_plane: float = 1000.0, num_fine_samples: int = 0, biased: bool = False) -> Dict[str, torch.Tensor]:
+                     far_plane: float = 1000.0, num_fine_samples: int = 0, biased: bool = False,
+                     background: float = 1.0) -> Dict[str, torch.Tensor]:
     """Plain-PyTorch statement of the render path; `tracer` needs trace_rays /
     find_visited_cells returning tensors, `interpolate_values(vi, bc, field)` the gather."""
     out = tracer.trace_rays(origins.contiguous(), directions.contiguous(), max_ray_triangles)
@@ -179,9 +187,10 @@ def render_reference(tracer, interpolate_values, field: torch.Tensor, mlp: Tetra
     fars = torch.gather(out["hit_distances"][:, :, 1], 1, (nv[:, None].long() - 1).clamp_min(0))
     ray_mask = nv > 0
     R = origins.shape[0]
-    rgb = torch.ones((R, 3), dtype=torch.float32, device=origins.device)
+    rgb = torch.full((R, 3), float(background), dtype=torch.float32, device=origins.device)
     acc = torch.zeros((R, 1), dtype=torch.float32, device=origins.device)
     depth = torch.full((R, 1), far_plane, dtype=torch.float32, device=origins.device)
+    margin = torch.full((R, 1), 0.5, dtype=torch.float32, device=origins.device)   # test aid: see median_margin
     if bool(ray_mask.any()):
         lists = [out[k][ray_mask].contiguous() for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates",
                                                          "hit_distances", "vertex_indices")]
@@ -208,11 +217,12 @@ def render_reference(tracer, interpolate_values, field: torch.Tensor, mlp: Tetra
         starts, ends = edges[:, :-1, None], edges[:, 1:, None]
         dirs = directions[ray_mask][:, None, :].expand(-1, edges.shape[1] - 1, -1)
         sigma, col = mlp(feats, dirs)
-        rgb_r, acc_r, depth_r, _ = composite(sigma, col, starts, ends)
+        rgb_r, acc_r, depth_r, w_r = composite(sigma, col, starts, ends, background=float(background))
         rgb[ray_mask] = rgb_r
         acc[ray_mask] = acc_r
         depth[ray_mask] = depth_r
-    return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
+        margin[ray_mask] = median_margin(w_r)
+    return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask, "depth_margin": margin}
 
 
 class GradientScaler(torch.autograd.Function):
@@ -242,15 +252,14 @@ class _FusedMlpFunction(torch.autograd.Function):
 
         ctx.save_for_backward(vertex_indices, barycentric_coordinates, field, dirs, *weights)
         ctx.S = int(samples_per_ray)
-        return cpp.mlp_forward_gather(vertex_indices, barycentric_coordinates, field.detach(), dirs,
-                                      [w.detach() for w in weights], ctx.S)
+        return cpp.mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, list(weights), ctx.S)
 
     @staticmethod
     def backward(ctx, d_sigma, d_rgb):
         from . import tetranerf_cpp_extension as cpp
 
         vi, bc, field, dirs, *weights = ctx.saved_tensors
-        grad_field, grads = cpp.mlp_backward(vi, bc, field, dirs, [w.detach() for w in weights], ctx.S,
+        grad_field, grads = cpp.mlp_backward(vi, bc, field, dirs, list(weights), ctx.S,
                                              d_sigma.contiguous(), d_rgb.contiguous())
         return (None, None, grad_field, None, None, *grads)
 
@@ -278,8 +287,11 @@ class _FusedCompositeFunction(torch.autograd.Function):
         return d_sigma, d_col, None, None
 
 
-def mlp_weights(mlp: TetraMLP):
-    """The 12 tensors tn_mlp_forward takes, in its order."""
+def mlp_weights(mlp):
+    """The 12 tensors the fused kernels take, in their order: of a TetraMLP, or of any object that provides
+    `fused_weights()` (the nerfstudio adapter: nerfstudio_plugin.ModelMLP)."""
+    if hasattr(mlp, "fused_weights"):
+        return list(mlp.fused_weights())
     b = mlp.base
     return [b[0].weight, b[0].bias, b[1].weight, b[1].bias, b[2].weight, b[2].bias, mlp.density.weight,
             mlp.density.bias, mlp.head.weight, mlp.head.bias, mlp.rgb.weight, mlp.rgb.bias]
@@ -291,11 +303,21 @@ class TetraRenderer:
 
     def __init__(self, tracer, field: torch.Tensor, mlp: TetraMLP, num_samples: int = 256,
                  max_ray_triangles: int = 512, fused: bool = True, far_plane: float = 1000.0,
-                 num_fine_samples: int = 0, biased: bool = False, dense_tails: bool = False, fused_pass="auto"):
+                 num_fine_samples: int = 0, biased: bool = False, dense_tails: bool = False, fused_pass="auto",
+                 mlp_mode: str = "fp32", background: float = 1.0, cache_field: bool = True):
         from . import tetranerf_cpp_extension as cpp
 
         self.cpp = cpp
         self.tracer, self.field, self.mlp = tracer, field, mlp
+        # arithmetic of the fused forward kernels, per renderer (not process-wide): "fp32" = exact fp32 MFMA chain (what
+        # the parity tests pin), "bf16x3" = split-operand bf16 MFMA (opt-in; inference only -- the training forward is
+        # always fp32 because the backward kernel recomputes the activations in fp32)
+        self.mlp_mode = mlp_mode
+        self.background = float(background)    # RGBRenderer background: 1.0 white (default config), 0.0 black
+        if cache_field:
+            # this renderer owns `field`: cached vertex-major shadow, refreshed per tensor version.  After a write through
+            # `.data` call cpp.invalidate_field_cache(field) (see tetranerf_cpp_extension.register_field)
+            cpp.register_field(field)
         self.S, self.M, self.fused, self.far_plane = int(num_samples), int(max_ray_triangles), fused, far_plane
         self.S_fine, self.biased = int(num_fine_samples), bool(biased)
         # the render path only reads the trace rows through num_visited_cells, so the constant tails of the
@@ -316,7 +338,7 @@ class TetraRenderer:
         cpp, S = self.cpp, self.S
         if not self.fused:
             return render_reference(self.tracer, cpp.interpolate_values, self.field, self.mlp, origins, directions,
-                                    S, self.M, self.far_plane, self.S_fine, self.biased)
+                                    S, self.M, self.far_plane, self.S_fine, self.biased, background=self.background)
         if not self.dense_tails:
             self.tracer.set_option("dense_tails", 0)
         try:
@@ -331,10 +353,11 @@ class TetraRenderer:
         fars = torch.where(ray_mask[:, None], torch.gather(out["hit_distances"][:, :, 1], 1,
                                                           (nv[:, None].long() - 1).clamp_min(0)), 0.0)
         R, dev = origins.shape[0], origins.device
-        rgb = torch.ones((R, 3), dtype=torch.float32, device=dev)
+        rgb = torch.full((R, 3), self.background, dtype=torch.float32, device=dev)
         acc = torch.zeros((R, 1), dtype=torch.float32, device=dev)
         depth = torch.full((R, 1), self.far_plane, dtype=torch.float32, device=dev)
         idx = torch.nonzero(ray_mask)[:, 0]
+        mode, bg = self.mlp_mode, self.background
         if idx.numel():
             # the 26 KB trace rows of the hitting rays are NOT compacted (model.py:546-567 copies them with boolean
             # indexing): find_visited_cells reads them in place through the ray index
@@ -352,20 +375,21 @@ class TetraRenderer:
                 edges = biased_sample_bins(near_r, far_r, S, lists[0][idx], lists[3][idx]).contiguous()
             else:
                 edges = uniform_sample_bins(near_r, far_r, S).contiguous()
-            if (self.fused_pass is True or (self.fused_pass == "auto" and idx.numel() <= FUSED_PASS_MAX_RAYS)) and cpp.mlp_get_mode() == "fp32":
+            if (self.fused_pass is True or (self.fused_pass == "auto" and idx.numel() <= FUSED_PASS_MAX_RAYS)) and mode == "fp32":
                 # every pass is ONE launch: match + gather + MLP + composite (tn_render.hip); per sample only the coarse
                 # weights go through HBM; the finished rays are written straight into the frame buffers
                 if self.S_fine > 0:
                     weights_c = cpp.render_pass(lists, ridx, edges, self.field, None, w)
                     spacing = (edges - near_r) / (far_r - near_r)
                     edges = pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r).contiguous()
-                cpp.render_pass(lists, ridx, edges, self.field, directions[idx].contiguous(), w, out=(rgb, acc, depth))
+                cpp.render_pass(lists, ridx, edges, self.field, directions[idx].contiguous(), w, out=(rgb, acc, depth),
+                                background=bg)
                 return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
             traced = locate(edges)
             if self.S_fine > 0:
                 # coarse pass: gather + mlp_base + density head in one kernel, weights in one more
                 sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
-                                                 None, w, S)
+                                                 None, w, S, mode=mode)
                 weights_c = cpp.composite(sigma_c.view(-1, S), None, edges)
                 spacing = (edges - near_r) / (far_r - near_r)
                 edges = pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r).contiguous()
@@ -373,8 +397,8 @@ class TetraRenderer:
                 S = edges.shape[1] - 1
             # gather + MLP + heads in one kernel (no [64, n] feature buffer)
             sigma, col = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
-                                                directions[idx].contiguous(), w, S)
-            rgb_r, acc_r, depth_r = cpp.composite(sigma.view(-1, S), col.view(-1, S, 3), edges)
+                                                directions[idx].contiguous(), w, S, mode=mode)
+            rgb_r, acc_r, depth_r = cpp.composite(sigma.view(-1, S), col.view(-1, S, 3), edges, background=bg)
             rgb[idx] = rgb_r
             acc[idx] = acc_r
             depth[idx] = depth_r
@@ -406,7 +430,8 @@ class TetraRenderer:
                                                               (nv[:, None].long() - 1).clamp_min(0)), 0.0)
             idx = torch.nonzero(ray_mask)[:, 0]
         R, dev = origins.shape[0], origins.device
-        rgb = torch.ones((R, 3), dtype=torch.float32, device=dev)
+        bg = self.background
+        rgb = torch.full((R, 3), bg, dtype=torch.float32, device=dev)
         acc = torch.zeros((R, 1), dtype=torch.float32, device=dev)
         depth = torch.full((R, 1), self.far_plane, dtype=torch.float32, device=dev)
         if idx.numel() == 0:
@@ -433,8 +458,8 @@ class TetraRenderer:
             traced = locate(edges)
             w = mlp_weights(self.mlp)
             if self.S_fine > 0:
-                sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field.detach(),
-                                                 None, [x.detach() for x in w], S)
+                sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
+                                                 None, w, S)
                 weights_c = cpp.composite(sigma_c.view(-1, S), None, edges)
                 spacing = (edges - near_r) / (far_r - near_r)
                 u_rand = rand.get("fine")
@@ -463,9 +488,9 @@ class TetraRenderer:
             col, sg, _ = GradientScaler.apply(col, sigma[..., None], ray_dist)
             sigma = sg[..., 0]
         if fused:
-            rgb_r, acc_r, depth_r = _FusedCompositeFunction.apply(sigma, col, edges, 1.0)
+            rgb_r, acc_r, depth_r = _FusedCompositeFunction.apply(sigma, col, edges, bg)
         else:
-            rgb_r, acc_r, depth_r, _ = composite(sigma[..., None], col, edges[:, :-1, None], edges[:, 1:, None])
+            rgb_r, acc_r, depth_r, _ = composite(sigma[..., None], col, edges[:, :-1, None], edges[:, 1:, None], background=bg)
         rgb = rgb.index_copy(0, idx, rgb_r)
         acc = acc.index_copy(0, idx, acc_r.reshape(-1, 1))
         depth = depth.index_copy(0, idx, depth_r.reshape(-1, 1).detach())

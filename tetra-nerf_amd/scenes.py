@@ -153,6 +153,48 @@ def colmap_like_mesh(n: int = 12000, ratio: float = 0.5, seed: int = 8):
     return _mesh_of(np.concatenate([pts, base + off], 0))
 
 
+def dense_core_mesh(n: int = 16000, core_frac: float = 0.7, core_sigma: float = 0.03, seed: int = 21):
+    """Uniform cloud with a Gaussian core holding `core_frac` of the points (a COLMAP cloud's dense object in a sparse
+    scene): rays through the core cross several times the ~3.45 T^(1/3) faces of a uniform mesh of the same size --
+    what the mesh-size heuristics of the tracer (speculative tail fill, small-batch LDS arrays) must survive.
+    Defaults: 107k tets; rays aimed at the core (`core_rays`) cross 218 faces in the median, 254+ in 1 % of the cases."""
+    rng = np.random.default_rng(seed)
+    k = int(n * core_frac)
+    core = 0.5 + core_sigma * rng.normal(size=(k, 3))
+    rest = rng.random((n - k, 3))
+    pts = np.unique(np.concatenate([core, rest], 0).astype(np.float32), axis=0)
+    rng.shuffle(pts)
+    return _mesh_of(pts)
+
+
+def core_rays(n: int, seed: int, spread: float = 0.02, radius: float = 1.5):
+    """Origins on a sphere around the unit cube, aimed at N(0.5, spread) targets: through the core of dense_core_mesh."""
+    o, _ = outside_in_rays(n, seed, radius=radius)
+    rng = np.random.default_rng(seed + 1)
+    d = (0.5 + spread * rng.normal(size=(n, 3))) - o
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    return np.ascontiguousarray(o), np.ascontiguousarray(d)
+
+
+def needle_mesh(n: int = 40000, width: float = 0.05, background: int = 2000, seed: int = 22):
+    """`n` points in the needle [0,1] x (0.5 +- width/2)^2 plus a sparse background: rays along the needle
+    (`needle_rays`) cross ~1000 faces at the defaults (n = 20000: ~820) -- the max_ray_triangles > 512 cases."""
+    rng = np.random.default_rng(seed)
+    core = np.c_[rng.random(n), 0.5 + width * (rng.random(n) - 0.5), 0.5 + width * (rng.random(n) - 0.5)]
+    pts = np.unique(np.concatenate([core, rng.random((background, 3))], 0).astype(np.float32), axis=0)
+    rng.shuffle(pts)
+    return _mesh_of(pts)
+
+
+def needle_rays(n: int, seed: int, width: float = 0.05):
+    rng = np.random.default_rng(seed)
+    a = np.c_[np.full(n, -0.5), 0.5 + 0.8 * width * (rng.random(n) - 0.5), 0.5 + 0.8 * width * (rng.random(n) - 0.5)]
+    b = np.c_[np.full(n, 1.5), 0.5 + 0.8 * width * (rng.random(n) - 0.5), 0.5 + 0.8 * width * (rng.random(n) - 0.5)]
+    d = b - a
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    return np.ascontiguousarray(a.astype(np.float32)), np.ascontiguousarray(d.astype(np.float32))
+
+
 def vertex_to_vertex_rays(pts: np.ndarray, n: int, seed: int, extend: float = 1.0):
     """Rays that pass exactly (up to fp32 rounding of the direction) through two mesh vertices a -> b, started
     `extend` before a: they graze edges and vertices of many tetrahedra (zero edge functions, ties)."""

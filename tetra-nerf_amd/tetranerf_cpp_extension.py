@@ -96,6 +96,7 @@ class TetrahedraTracer:
         # borrowed, not copied (tetrahedra_tracer.h:300-303): keep them alive
         self.tetrahedra_cells = cells
         self.tetrahedra_vertices = xyz
+        invalidate_field_cache()   # a new mesh comes with a (re-)initialised field (model.py:349-392 writes it through .data)
         _lib.check(self._lib.tn_load_tetrahedra(
             self._h, xyz.numel() // 3, cells.numel() // 4, _ptr(xyz), _ptr(cells), _stream(self._device)))
 
@@ -276,42 +277,70 @@ class TetrahedraTracer:
         return out
 
 
-# Vertex-major shadow copies [V, F] of feature-major fields [F, V] (the checkpoint layout, model.py:269-271): the O(V)
-# transposition is paid once per field VERSION, not once per call (with 4096-ray batches on a multi-million-vertex
-# field it would dominate the gather).  An entry belongs to one live tensor OBJECT (weak reference: a new tensor that
-# the allocator places at the same address is a different object) and is refreshed when that tensor's version counter
-# moves (every in-place optimiser step bumps it) or its storage pointer changes.  The model passes its
-# `tetrahedra_field` parameter itself (model.py:569-573), which is what hits; a fresh view object per call (.data,
-# .detach()) simply misses and is transposed again.
-_FIELD_VM = {}
+# Vertex-major shadow copies [V, F] of feature-major fields [F, V] (the checkpoint layout, model.py:269-271).
+#
+# The gather kernels want one 256-byte row per vertex, the model keeps `tetrahedra_field` feature-major.  By default the
+# shadow is made PER CALL (tn_transpose_f32: 23 MB of traffic at V = 45k, ~10 us) -- always correct.  A caller that owns
+# the field can opt in to a cached shadow with `register_field(t)`: the copy is then refreshed only when the tensor's
+# version counter or storage pointer moves (every in-place optimiser step, copy_ and load_state_dict bump the counter).
+# What does NOT bump it are writes through `.data` (the reference model initialises the field that way,
+# model.py:336-343,379-386: `self.tetrahedra_field.data[1:4, :] = ...`), so the owner of a registered field must call
+# `invalidate_field_cache()` after any such write.  TetraRenderer and the nerfstudio adapter register their field and
+# invalidate it from the model's initialisation hook; `TetrahedraTracer.load_tetrahedra` invalidates everything.
+# A cached shadow remembers the event that ends its transposition: a consumer on another stream waits for it.
+_FIELD_VM = {}        # id(tensor) -> (weakref, version, data_ptr, shadow, event)
 
 
-def field_vertex_major(field):
-    """[V, F] copy of `field` [F, V], cached per (tensor object, version)."""
+def register_field(field):
+    """Opt in to a cached vertex-major shadow of `field` (see above).  Returns `field`."""
     import weakref
 
-    key = id(field)
-    hit = _FIELD_VM.get(key)
-    if hit is not None and hit[0]() is field and hit[1] == field._version and hit[2] == field.data_ptr():
-        return hit[3]
+    _FIELD_VM.setdefault(id(field), (weakref.ref(field), None, None, None, None))
+    return field
+
+
+def unregister_field(field):
+    _FIELD_VM.pop(id(field), None)
+
+
+def invalidate_field_cache(field=None):
+    """Forget the cached shadow of `field` (all registered fields if None): required after a write through `.data`
+    or a raw pointer; the registration itself stays."""
+    for k, v in list(_FIELD_VM.items()):
+        if v[0]() is None:
+            del _FIELD_VM[k]
+        elif field is None or v[0]() is field:
+            _FIELD_VM[k] = (v[0], None, None, None, None)
+
+
+def _transpose_field(field):
     Fd, V = field.shape
     ft = torch.empty((V, Fd), dtype=torch.float32, device=field.device)
     with torch.cuda.device(field.device):
         _lib.check(_lib.load().tn_transpose_f32(Fd, V, _ptr(field), _ptr(ft), _stream(field.device)))
-    for k in [k for k, v in _FIELD_VM.items() if v[0]() is None]:
-        del _FIELD_VM[k]
-    if len(_FIELD_VM) >= 8:
-        _FIELD_VM.clear()
-    try:
-        _FIELD_VM[key] = (weakref.ref(field), field._version, field.data_ptr(), ft)
-    except TypeError:
-        pass
     return ft
 
 
-def invalidate_field_cache():
-    """Drop the cached vertex-major copies (needed only after writing a field through a raw pointer)."""
-    _FIELD_VM.clear()
+def field_vertex_major(field):
+    """[V, F] copy of `field` [F, V]: per call, or cached per (tensor object, version, pointer) for registered fields."""
+    hit = _FIELD_VM.get(id(field))
+    if hit is None or hit[0]() is not field:
+        # a detach()-ed alias of a registered field (autograd hands those to Function.backward): same storage, same
+        # version counter
+        hit = next((v for v in _FIELD_VM.values() if v[0]() is not None and v[2] == field.data_ptr()
+                    and v[0]().shape == field.shape and v[0]()._version == field._version), None)
+        if hit is None:
+            return _transpose_field(field)
+        field = hit[0]()
+    if hit[1] == field._version and hit[2] == field.data_ptr() and hit[3] is not None:
+        cur = torch.cuda.current_stream(field.device)
+        cur.wait_event(hit[4])   # no-op on the producing stream; orders a consumer on another stream
+        return hit[3]
+    ft = _transpose_field(field)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(field.device))
+    _FIELD_VM[id(field)] = (hit[0], field._version, field.data_ptr(), ft, ev)
+    return ft
 
 
 def interpolate_values(vertex_indices, barycentric_coordinates, field):
@@ -376,29 +405,99 @@ class _MlpWeightsStruct(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd", "wh", "bh", "wr", "br")]
 
 
-def mlp_set_mode(mode):
-    """Arithmetic of mlp_forward / mlp_forward_gather (process-wide): "fp32" (default; exact fp32 MFMA
-    chain) or "bf16x3" (bf16 MFMA on 3-way split operands, fp32-grade accuracy, ~2x faster)."""
-    m = {"fp32": 0, "bf16x3": 1, 0: 0, 1: 1}.get(mode)
+_WEIGHT_SHAPES = [(128, 64), (128,), (128, 128), (128,), (128, 128), (128,), (1, 128), (1,), (128, 155), (128,), (3, 128), (3,)]
+_MODES = {"fp32": 0, "bf16x3": 1, 0: 0, 1: 1}
+
+
+def _mode(mode):
+    m = _MODES.get(mode)
     _check(m is not None, 'mlp mode must be "fp32" or "bf16x3"')
-    _lib.check(_lib.load().tn_mlp_set_mode(m))
+    return m
 
 
-def mlp_set_block(block: int):
-    """Shape of the fp32 forward kernel: 0 auto, 512 (one 8-wave block per CU), 256 (two 4-wave blocks per CU)."""
-    _lib.check(_lib.load().tn_mlp_set_block(int(block)))
+class FusedMLP:
+    """Handle of the fused MLP kernels (tn_mlp_*): holds the packed forms of ONE set of weights on the device.
+    `sync(weights)` packs them when they changed since the last call -- detected through the tensors' identity, version
+    counter and storage pointer, i.e. every in-place optimiser step / copy_ / load_state_dict is seen; a write through
+    `.data` is not (call `sync(weights, force=True)` or `invalidate()` then).  weights = the 12 tensors
+    (w1,b1,w2,b2,w3,b3,wd,bd,wh,bh,wr,br) in nn.Linear layout, contiguous fp32 on the handle's device."""
+
+    def __init__(self, device):
+        device = torch.device(device)
+        _check(device.type == "cuda", "The device argument must be a CUDA device.")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = device
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.tn_mlp_create(int(device.index), C.byref(h)))
+        self._h = h
+        self._key = None
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.tn_mlp_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def invalidate(self):
+        self._key = None
+
+    def sync(self, weights, force=False):
+        _check(len(weights) == 12, "weights must hold 12 tensors")
+        key = tuple((id(w), w._version, w.data_ptr()) for w in weights)
+        if not force and key == self._key:
+            return self
+        st = _MlpWeightsStruct()
+        keep = []
+        for (name, _), w, shp in zip(_MlpWeightsStruct._fields_, weights, _WEIGHT_SHAPES):
+            w = w.detach()
+            _check_input(w, name)
+            _check(w.device == self.device, f"{name} must be on the handle's device")
+            _check(w.dtype == torch.float32 and tuple(w.shape) == shp, f"{name} must be f32 {shp}")
+            keep.append(w)
+            setattr(st, name, w.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.tn_mlp_set_weights(self._h, C.byref(st), _stream(self.device)))
+        del keep
+        self._key = key
+        return self
+
+    @property
+    def handle(self):
+        return self._h
 
 
-def mlp_get_mode():
-    return ("fp32", "bf16x3")[_lib.load().tn_mlp_get_mode()]
+_DEFAULT_MLP = {}    # device -> FusedMLP used by the module-level functions below
 
 
-def mlp_forward(feats_fm, dirs, weights, samples_per_ray):
-    """Fused fp32-MFMA forward of mlp_base + density head + mlp_head + rgb head (addition to the
+def fused_mlp(weights) -> FusedMLP:
+    """The per-device default handle, synchronised with `weights` (re-packed only when they changed)."""
+    dev = weights[0].device
+    m = _DEFAULT_MLP.get(dev)
+    if m is None:
+        m = _DEFAULT_MLP[dev] = FusedMLP(dev)
+    return m.sync(weights)
+
+
+def invalidate_weight_cache():
+    """Needed only after writing MLP parameters through `.data` / a raw pointer."""
+    for m in _DEFAULT_MLP.values():
+        m.invalidate()
+
+
+def mlp_forward(feats_fm, dirs, weights, samples_per_ray, mode="fp32"):
+    """Fused MFMA forward of mlp_base + density head + mlp_head + rgb head (addition to the
     reference surface; the reference runs these through nerfstudio/PyTorch, model.py:602-621).
     feats_fm f32 [64, n] feature-major (interpolate_values(...).moveaxis(-1, 0) is that buffer),
     dirs f32 [n // samples_per_ray, 3], weights: 12 contiguous fp32 CUDA tensors in nn.Linear layout
-    (w1,b1,w2,b2,w3,b3,wd,bd,wh,bh,wr,br).  Returns sigma [n], rgb [n,3]."""
+    (w1,b1,w2,b2,w3,b3,wd,bd,wh,bh,wr,br).  mode: "fp32" (exact fp32 MFMA chain) or "bf16x3" (bf16 MFMA on 3-way
+    split operands; opt-in).  Returns sigma [n], rgb [n,3]."""
     _check_input(feats_fm, "feats")
     _check_input(dirs, "dirs")
     _check(feats_fm.dtype == torch.float32 and feats_fm.dim() == 2 and feats_fm.size(0) == 64, "feats must be f32 [64, n]")
@@ -406,43 +505,20 @@ def mlp_forward(feats_fm, dirs, weights, samples_per_ray):
     S = int(samples_per_ray)
     _check(S > 0 and n % S == 0, "n must be a multiple of samples_per_ray")
     _check(dirs.dtype == torch.float32 and tuple(dirs.shape) == (n // S, 3), "dirs must be f32 [n/samples_per_ray, 3]")
-    shapes = [(128, 64), (128,), (128, 128), (128,), (128, 128), (128,), (1, 128), (1,), (128, 155), (128,), (3, 128), (3,)]
-    _check(len(weights) == 12, "weights must hold 12 tensors")
-    st = _MlpWeightsStruct()
-    keep = []
-    for (name, _), w, shp in zip(_MlpWeightsStruct._fields_, weights, shapes):
-        w = w.detach()
-        _check_input(w, name)
-        _check(w.dtype == torch.float32 and tuple(w.shape) == shp, f"{name} must be f32 {shp}")
-        keep.append(w)
-        setattr(st, name, w.data_ptr())
+    m = fused_mlp(weights)
     dev = feats_fm.device
     sigma = torch.empty((n,), dtype=torch.float32, device=dev)
     rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().tn_mlp_forward(n, S, _ptr(feats_fm), _ptr(dirs), C.byref(st), _ptr(sigma), _ptr(rgb),
+        _lib.check(_lib.load().tn_mlp_forward(m.handle, n, S, _ptr(feats_fm), _ptr(dirs), _mode(mode), _ptr(sigma), _ptr(rgb),
                                               _stream(dev)))
     return sigma, rgb
 
 
-def _weights_struct(weights):
-    shapes = [(128, 64), (128,), (128, 128), (128,), (128, 128), (128,), (1, 128), (1,), (128, 155), (128,), (3, 128), (3,)]
-    _check(len(weights) == 12, "weights must hold 12 tensors")
-    st = _MlpWeightsStruct()
-    keep = []
-    for (name, _), w, shp in zip(_MlpWeightsStruct._fields_, weights, shapes):
-        w = w.detach()
-        _check_input(w, name)
-        _check(w.dtype == torch.float32 and tuple(w.shape) == shp, f"{name} must be f32 {shp}")
-        keep.append(w)
-        setattr(st, name, w.data_ptr())
-    return st, keep
-
-
-def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray):
+def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray, mode="fp32"):
     """interpolate_values + mlp_forward in ONE kernel: the wave gathers its samples' features from the
-    field straight into MFMA operand registers; the [64, n] feature buffer is never written.
-    vertex_indices i32 [..., 4], barycentric_coordinates f32 [..., 3], field f32 [64, V].
+    (vertex-major shadow of the) field straight into MFMA operand registers; the [64, n] feature buffer is never
+    written.  vertex_indices i32 [..., 4], barycentric_coordinates f32 [..., 3], field f32 [64, V].
     dirs=None: density only (the coarse pass of the model, model.py:577-581) -> sigma [n]."""
     density_only = dirs is None
     for x, name in ((vertex_indices, "vertex_indices"), (barycentric_coordinates, "barycentric_coordinates"),
@@ -457,13 +533,15 @@ def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, wei
     _check(S > 0 and n % S == 0, "n must be a multiple of samples_per_ray")
     _check(density_only or (dirs.dtype == torch.float32 and tuple(dirs.shape) == (n // S, 3)),
            "dirs must be f32 [n/samples_per_ray, 3]")
-    st, keep = _weights_struct(weights)
+    m = fused_mlp(weights)
     dev = field.device
+    field_vm = field_vertex_major(field)
     sigma = torch.empty((n,), dtype=torch.float32, device=dev)
     rgb = None if density_only else torch.empty((n, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().tn_mlp_forward_gather(n, S, field.size(1), _ptr(vertex_indices), _ptr(barycentric_coordinates),
-                                                     _ptr(field), _ptr(dirs), C.byref(st), _ptr(sigma), _ptr(rgb), _stream(dev)))
+        _lib.check(_lib.load().tn_mlp_forward_gather(m.handle, n, S, _ptr(vertex_indices), _ptr(barycentric_coordinates),
+                                                     _ptr(field_vm), _ptr(dirs), _mode(mode), _ptr(sigma), _ptr(rgb),
+                                                     _stream(dev)))
     return sigma if density_only else (sigma, rgb)
 
 
@@ -485,7 +563,7 @@ def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, b
     _check(edges.dtype == torch.float32 and tuple(edges.shape) == (r, S + 1), "edges must be f32 [r, S+1]")
     _check(S >= 64 and M <= 512, "render_pass needs S >= 64 samples per ray and max_ray_triangles <= 512")
     _check(field.dtype == torch.float32 and field.dim() == 2 and field.size(0) == 64, "field must be f32 [64, V]")
-    st, keep = _weights_struct(weights)
+    m = fused_mlp(weights)
     dev = field.device
     field_vm = field_vertex_major(field)
     density_only = dirs is None
@@ -494,8 +572,8 @@ def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, b
     with torch.cuda.device(dev):
         if density_only:
             w_out = torch.empty((r, S), dtype=torch.float32, device=dev)
-            _lib.check(lib.tn_render_pass(M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S, _ptr(edges),
-                                          _ptr(field_vm), None, C.byref(st), float(background), _ptr(w_out), None, None, None,
+            _lib.check(lib.tn_render_pass(m.handle, M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S,
+                                          _ptr(edges), _ptr(field_vm), None, float(background), _ptr(w_out), None, None, None,
                                           _stream(dev)))
         else:
             _check_input(dirs, "dirs")
@@ -504,10 +582,9 @@ def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, b
             for x, name in ((rgb, "rgb"), (acc, "accumulation"), (depth, "depth")):
                 _check_input(x, name)
                 _check(x.dtype == torch.float32 and x.size(0) == nv.numel(), f"{name} must be f32 over all rays")
-            _lib.check(lib.tn_render_pass(M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S, _ptr(edges),
-                                          _ptr(field_vm), _ptr(dirs), C.byref(st), float(background), None, _ptr(rgb), _ptr(acc),
+            _lib.check(lib.tn_render_pass(m.handle, M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S,
+                                          _ptr(edges), _ptr(field_vm), _ptr(dirs), float(background), None, _ptr(rgb), _ptr(acc),
                                           _ptr(depth), _stream(dev)))
-    del keep
     return w_out
 
 
@@ -557,7 +634,8 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
     Two HIP kernels per chunk of samples: the dX chain on the fp32 matrix cores (recomputing the forward pass) and
     K-streaming weight-gradient GEMMs; the three narrow head gradients (enc part of mlp_head, density, rgb) are
     bandwidth-bound matrix-vector products done by PyTorch on the buffers the first kernel left."""
-    st, keep = _weights_struct(weights)
+    mh = fused_mlp(weights)
+    keep = [w.detach() for w in weights]
     n = vertex_indices.numel() // 4
     S = int(samples_per_ray)
     _check(S > 0 and n % S == 0, "n must be a multiple of samples_per_ray")
@@ -571,7 +649,7 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
     dirs = dirs.contiguous()
     lib = _lib.load()
     field_vm = field_vertex_major(field)
-    grads = [torch.zeros_like(w, dtype=torch.float32) for w in keep]
+    grads = [torch.zeros_like(w, dtype=torch.float32, requires_grad=False) for w in keep]
     gw1, gb1, gw2, gb2, gw3, gb3, gwd, gbd, gwh, gbh, gwr, gbr = grads
     gwh_base = torch.zeros((128, 128), dtype=torch.float32, device=dev)
     head_out = torch.zeros((4, 128), dtype=torch.float32, device=dev)   # d wd, d wr[0..2]
@@ -589,7 +667,7 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
             d1, d2, d3, d4 = buf[576:704], buf[704:832], buf[832:960], buf[960:1088]
             dhead, dx0 = buf[1088:1092], buf[1092:1156]
             bs = _MlpBackwardBuffers(*[t.data_ptr() for t in (x0, h1, h2, h3, h4, d1, d2, d3, d4, dhead, dx0)])
-            _lib.check(lib.tn_mlp_backward(m, S, _ptr(vi[c0:]), _ptr(bc[c0:]), _ptr(field_vm), _ptr(dirs[r0:]), C.byref(st),
+            _lib.check(lib.tn_mlp_backward(mh.handle, m, S, _ptr(vi[c0:]), _ptr(bc[c0:]), _ptr(field_vm), _ptr(dirs[r0:]),
                                            _ptr(d_sigma[c0:]), _ptr(d_rgb[c0:]), C.byref(bs), stream))
             for a, b, rows_b, gw, gb in ((d1, x0, 64, gw1, gb1), (d2, h1, 128, gw2, gb2), (d3, h2, 128, gw3, gb3),
                                          (d4, h3, 128, gwh_base, gbh)):
