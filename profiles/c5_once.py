@@ -14,7 +14,7 @@ tr = tn.TetrahedraTracer(dev); tr.load_tetrahedra(torch.from_numpy(pts).to(dev),
 o, d = bench.frame_rays(scenes, 0, 800, 800) if rays == "frame" else scenes.outside_in_rays(int(rays), 4)
 o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
 for kv in sys.argv[4:]:        # option=value pairs
-    k, v = kv.split("="); tr.set_option(k, int(v))
+    k, v = kv.split("="); tr.set_option(k, int(v)) if k != "x" else None
 for _ in range(3):
     out = tr.trace_rays(o, d, 512); del out
     torch.cuda.synchronize()

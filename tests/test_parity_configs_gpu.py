@@ -276,10 +276,11 @@ def test_max_ray_triangles_above_512(tn, device, oracle, scenes, M, npts):
     want = ot.trace_rays(o, d, M)
     nv = want["num_visited_cells"]
     assert (nv > 512).mean() > 0.5, np.percentile(nv, [1, 50, 99])
+    # (a ray that overflows keeps its M - 1 nearest hits; the pairing drops a few sub-eps pairs of those)
     if (M, npts) == (1024, 40000):
-        assert (nv >= M - 2).mean() > 0.3          # most needle rays overflow
+        assert (nv >= M - 16).mean() > 0.3         # 2/3 of the needle rays overflow
     else:
-        assert (nv >= M - 2).mean() < 0.01
+        assert (nv >= M - 16).mean() < 0.01
     for walk in (2, 0):
         tr = _tracer(tn, device, pts, cells, walk=walk)
         out = _trace(tr, device, o, d, M)

@@ -37,14 +37,15 @@ def test_composite_backward_matches_autograd(tn, device):
     assert _rel(s2.grad, want_s) < 1e-5 and _rel(c2.grad, want_c) < 1e-5
 
 
-@pytest.mark.parametrize("S", [64, 97])
-def test_mlp_backward_matches_autograd(tn, device, S):
-    """Gradients of the fused gather + MLP + heads node w.r.t. the field and all 12 weight tensors."""
+@pytest.mark.parametrize("R,S,V", [(300, 64, 5000), (300, 97, 5000), (4096, 513, 45000)])
+def test_mlp_backward_matches_autograd(tn, device, R, S, V):
+    """Gradients of the fused gather + MLP + heads node w.r.t. the field and all 12 weight tensors; the last case is
+    the C4 training batch itself (4096 rays x 513 fine samples = 2.1 M samples, V = 45k): two chunks of 2^20 samples,
+    512 slices of 4096 samples per weight-gradient GEMM, float atomics across them."""
     import torch
 
     render = importlib.import_module("tetra-nerf_amd.render")
     torch.manual_seed(1)
-    V, R = 5000, 300
     n = R * S
     mlp = render.TetraMLP().to(device)
     for p in mlp.parameters():      # larger weights than the default init: every ReLU / softplus / sigmoid branch is live
@@ -54,7 +55,7 @@ def test_mlp_backward_matches_autograd(tn, device, S):
     vi[::17, 2] = -1                # EMPTY vertices are skipped by the gather
     bc = (torch.rand(n, 3, device=device) / 3).contiguous()
     dirs = torch.nn.functional.normalize(torch.randn(R, 3, device=device), dim=-1)
-    g_sigma, g_rgb = torch.randn(n, device=device), torch.randn(n, 3, device=device)
+    g_sigma, g_rgb = torch.randn(n, device=device) / R, torch.randn(n, 3, device=device) / R
 
     def reference(dtype):
         m = render.TetraMLP().to(device).to(dtype)

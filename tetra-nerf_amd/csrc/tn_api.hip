@@ -51,6 +51,7 @@ struct tn_tracer {
                                             // literal count, kmax (one memset clears them all)
     uint32_t *fallback_count() { return reinterpret_cast<uint32_t *>(stats.p + 24); }
     uint32_t *literal_count() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 1; }
+    uint32_t *group_counter() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 2; }   // segment writer: next 8-ray group
     size_t last_num_rays = 0;
     int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
     size_t walk_min_rays = 12288;        // measured crossover on the 300k-tet mesh after round 2b's faster BVH path
@@ -368,6 +369,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 q.num_rays = n; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
                 q.unroll = t->seg_unroll;
                 q.walk_n = t->walk_n.p + base;
+                q.group_counter = t->group_counter();
                 q.hit_log = t->hit_log.p;
                 q.vars = t->mesh.vars;
                 q.out_cells = visited + base * M;
@@ -431,7 +433,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             } else {
                 for (size_t base = 0; base < R; base += chunk) {
                     const size_t n = R - base < chunk ? R - base : chunk;
-                    TN_HIP(hipMemsetAsync(t->literal_count(), 0, sizeof(uint32_t), stream));
+                    TN_HIP(hipMemsetAsync(t->literal_count(), 0, 2 * sizeof(uint32_t), stream));   // + the writer's group counter
                     launch_walk(base, n);
                     launch_segments(base, n);
                     launch_fill(base, n, M);

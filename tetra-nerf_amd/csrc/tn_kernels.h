@@ -68,6 +68,7 @@ struct WriteParams {
     uint32_t dense_tails;      // 0: slots >= num_visited are left unwritten (non-reference option)
     uint32_t unroll;           // chunks of 8 hits per ray per iteration: 4 (2 waves per SIMD) or 2 (4 waves per SIMD)
     const uint32_t *walk_n;    // hits in the log; TN_EMPTY: the row belongs to the literal / BVH kernels
+    uint32_t *group_counter;   // [1], zero at launch: dynamic hand-out of the 8-ray groups
     const uint4 *hit_log;
     const WalkVar *vars;
     uint32_t *out_cells;

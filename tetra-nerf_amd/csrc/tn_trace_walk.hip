@@ -372,10 +372,14 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
 // of a wave in issue order (one vmcnt), so a load issued after an iteration's stores is only "back" once those are
 // acknowledged.  Hence the software pipeline: the entries of the NEXT iteration -- of this group, or of the wave's
 // next group, whose hit counts were requested a whole group earlier -- are requested BEFORE this iteration's record
-// loads and stores.  Groups are dealt round-robin to the waves (the rays that miss the mesh are clustered).
-// U = chunks of 8 hits per ray per iteration: U = 4 keeps 32 hits per ray in flight per wave at 2 waves per SIMD;
-// U = 2 halves registers and LDS (7 KB per wave) for 4 waves per SIMD.  The wave index is made wave-uniform
-// (readfirstlane), so the group index, the log base and the row base live in scalar registers.
+// loads and stores.
+// Groups are handed out DYNAMICALLY (one atomic counter per launch; a wave draws its group two groups ahead of its
+// use, which is what the pipeline above needs): with a static round-robin deal the average wave was alive for 55 % of
+// the kernel (SQ_WAVE_CYCLES / SQ_WAVES = 0.44 ms of 0.80 ms, profiles/r03a_pmc_1.txt) -- the kernel waited for its
+// slowest waves.  Drawing in order also keeps the waves of the chip on neighbouring rays (the XCD's L2 holds their
+// records).  U = chunks of 8 hits per ray per iteration: 4 = 32 hits per ray in flight per wave at 2 waves per SIMD
+// (U = 2 at 4 waves per SIMD measured 3-5 % slower per frame: profiles/r03b_writer.txt -- not occupancy-bound).  The
+// wave index is made wave-uniform (readfirstlane): group index, log base and row bases live in scalar registers.
 namespace {
 template <int U>
 struct SW {
@@ -425,13 +429,21 @@ __global__ __launch_bounds__(256, U == 2 ? 4 : 2) void k_write_segments(WritePar
         }
     };
 
+    // the first two groups of a wave are static (wave index, wave index + number of waves); the counter hands out
+    // the groups from 2 * nwaves on
+    auto draw = [&]() -> size_t {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(q.group_counter, 1u);
+        return 2 * nwaves + (size_t)__builtin_amdgcn_readfirstlane(v);
+    };
     size_t g = (size_t)blockIdx.x * 4 + wave;
     if (g >= G) return;
+    size_t g_next = g + nwaves, g_next2 = G;
     uint32_t nh_raw = hits_of(g);
-    uint32_t nh_next_raw = hits_of(g + nwaves);            // in flight during the whole first group
+    uint32_t nh_next_raw = hits_of(g_next);                // in flight during the whole first group
     uint4 e[U];
     load_entries(e, log_of(g), nh_raw == TN_EMPTY ? 0u : nh_raw, 0);
-    for (; g < G; g += nwaves) {
+    for (; g < G; g = g_next, g_next = g_next2) {
         const bool skip = nh_raw == TN_EMPTY;   // literal / fallback ray (or padding): the row belongs to another kernel
         const uint32_t nh = skip ? 0u : nh_raw;
         uint32_t mx = nh;                       // max over the 8 rays (the value is replicated over h)
@@ -449,10 +461,10 @@ __global__ __launch_bounds__(256, U == 2 ? 4 : 2) void k_write_segments(WritePar
         float *const g_bary = q.out_bary + 6 * row0;
         uint32_t *const g_verts = q.out_verts ? q.out_verts + 4 * row0 : nullptr;
         const uint32_t row = a * M;
-        // the group after the next: its hit counts are requested now, needed one group later
-        const size_t g_next = g + nwaves;
+        // the group after the next: drawn now, its hit counts requested now, needed one group later
+        g_next2 = g_next < G ? draw() : G;
         const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : nh_next_raw;
-        const uint32_t nh_next2_raw = hits_of(g_next + nwaves);
+        const uint32_t nh_next2_raw = hits_of(g_next2);
         uint32_t nseg = 0;
         uint4 carry = make_uint4(0u, 0u, 0u, 0u);   // hit c0 - 1 of ray a
         uint32_t c0 = 0;

@@ -207,10 +207,13 @@ def render_reference(tracer, interpolate_values, field: torch.Tensor, mlp: Tetra
             edges = uniform_sample_bins(near_r, far_r, num_samples)
         feats = features(edges)
         if num_fine_samples > 0:
-            x = feats
-            for lin in mlp.base:
-                x = torch.relu(lin(x))
-            sigma_c = torch.nn.functional.softplus(mlp.density(x))[..., 0]
+            if hasattr(mlp, "coarse_sigma"):     # an adapter around other modules (nerfstudio_plugin.ModelMLP)
+                sigma_c = mlp.coarse_sigma(feats)
+            else:
+                x = feats
+                for lin in mlp.base:
+                    x = torch.relu(lin(x))
+                sigma_c = torch.nn.functional.softplus(mlp.density(x))[..., 0]
             spacing = (edges - near_r) / (far_r - near_r)
             edges = pdf_sample_bins(spacing, ray_weights(sigma_c, edges), num_fine_samples, near_r, far_r)
             feats = features(edges)
