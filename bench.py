@@ -16,7 +16,8 @@ its HIP-event duration), `cpu_baseline` (the CPU oracle's BVH path, timing build
 -march=native, on a bounded sample of the same rays, all host cores), and -- single-GPU runs --
 `configs`: the other sizes BASELINE.json names (C4 300k-tet frame and both 4096-ray training
 batches, C5 1M-tet 2^20-ray stress), each with ms, rays/s, intersections/s and its roofline
-fraction.  `sharded_render` (every N): the 800x800 frame rendered in ray shards over the N ranks
+fraction, and `C4_train_4096`: one training iteration (forward + backward + SGD) of both shipped
+configurations on the C4 batch, fused HIP nodes beside PyTorch autograd.  `sharded_render` (every N): the 800x800 frame rendered in ray shards over the N ranks
 and all-gathered as ONE RCCL collective (north_star's multi-GPU flow), with the time of the
 collective.
 """
@@ -195,14 +196,67 @@ def config_legs(tn, scenes, dev, M):
             leg = trace_leg(tr, torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), M, reps)
             leg.update(tets=int(len(cells)), load_tetrahedra_s=load_s, load_tetrahedra_host_build_s=loads["host_build"])
             out[name] = leg
+        if cfg == "C4":
+            out["C4_train_4096"] = train_leg(tn, tr, len(pts), scenes, M, dev)
         del tr
         torch.cuda.empty_cache()
     return out
 
 
+def train_leg(tn, tracer, num_vertices, scenes, M, dev, iters=10):
+    """BASELINE.json configs[3] is a TRAINING batch: one optimisation step's forward + backward on 4096 outside-in rays of
+    the C4 mesh for both shipped configurations (registration.py:20-61): trace_rays + TetraRenderer.render_train (stratified
+    coarse samples, PDF fine pass, gather + MLP + heads, GradientScaler, renderers) + loss.backward() down to
+    tetrahedra_field and the 12 weight tensors -- through the fused HIP nodes and, beside it, through PyTorch autograd of
+    the plain statement (HIP tracer / matcher / gather + nn.Linear MLP: what the unmodified reference model runs).
+    useful FLOP = coarse density pass forward (82,176 / sample) + fine pass forward + dX + dW (3 x 122,624 / sample)."""
+    render = importlib.import_module("tetra-nerf_amd.render")
+    o, d = scenes.outside_in_rays(4096, 1)
+    o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    target = torch.rand(len(o), 3, device=dev)
+    out = {}
+    for name, (s_c, s_f, biased, scaling) in (("tetra-nerf-original", (256, 256, False, False)), ("tetra-nerf", (128, 128, True, True))):
+        torch.manual_seed(0)
+        mlp = render.TetraMLP().to(dev)
+        field = ((torch.rand(64, num_vertices, device=dev) * 2 - 1) * 1e-4)
+        field[1:4] = torch.rand(3, num_vertices, device=dev) * 2 - 1
+        field.requires_grad_(True)
+        params = [field] + list(mlp.parameters())
+        opt = torch.optim.SGD(params, lr=1e-3)
+        rd = render.TetraRenderer(tracer, field, mlp, s_c, M, fused=True, num_fine_samples=s_f, biased=biased)
+        res = {}
+        for what, fused in (("fused", True), ("pytorch_autograd", False)):
+            def step():
+                opt.zero_grad(set_to_none=True)
+                o_ = rd.render_train(o, d, gradient_scaling=scaling, fused=fused)
+                loss = ((o_["rgb"] - target) ** 2).mean()
+                loss.backward()
+                opt.step()
+                return o_
+            hit = int(step()["ray_mask"].sum())
+            step()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                step()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            flop = hit * (s_c * 82176 + 3 * (s_c + s_f + 1) * 122624)
+            res[what] = {"ms_per_iteration": ms, "useful_TFLOPs": flop / (ms * 1e-3) / 1e12,
+                         "frac_of_fp32_mfma_peak_157.3": flop / (ms * 1e-3) / 1e12 / 157.3}
+        res.update(rays=len(o), hitting_rays=hit, samples_per_ray=f"{s_c} coarse (density only, no gradient) + {s_c + s_f + 1} fine",
+                   useful_flop_per_iteration=flop, speedup_vs_pytorch_autograd=res["pytorch_autograd"]["ms_per_iteration"] / res["fused"]["ms_per_iteration"],
+                   step="trace_rays + render_train forward + backward to the field and 12 weight tensors + SGD step")
+        out[name] = res
+    return out
+
+
 def sharded_render_leg(tn, tracer, num_vertices, scenes, width, height, M, dev, reps=2, samples=256, chunk=65536):
-    """north_star's multi-GPU flow: every rank renders its contiguous slice of ONE 800x800 frame (replicated mesh /
-    field / MLP) and the rendered tiles are all-gathered as one RCCL collective.  Returns max-over-ranks times."""
+    """north_star's multi-GPU flow: every rank renders its share of ONE 800x800 frame (replicated mesh / field / MLP;
+    4096-ray tiles dealt round-robin so that the hitting rays -- the MLP work -- are balanced) and the rendered tiles are
+    all-gathered as one RCCL collective.  Returns max-over-ranks times + the per-rank render times."""
     render = importlib.import_module("tetra-nerf_amd.render")
     sharding = importlib.import_module("tetra-nerf_amd.sharding")
     torch.manual_seed(0)   # replicated parameters, as DDP keeps them
@@ -214,6 +268,7 @@ def sharded_render_leg(tn, tracer, num_vertices, scenes, width, height, M, dev, 
     o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
     sharding.render_sharded(rd.render, o, d, chunk=chunk)   # warm-up (RCCL communicator, allocator)
     tot = {"render": 0.0, "all_gather": 0.0}
+    tm = {}
     for _ in range(reps):
         tm = {}
         full = sharding.render_sharded(rd.render, o, d, chunk=chunk, timings=tm)
@@ -221,11 +276,16 @@ def sharded_render_leg(tn, tracer, num_vertices, scenes, width, height, M, dev, 
             tot[k] += tm[k] / reps
     t_render = sharding.max_over_ranks(tot["render"], device=dev)
     t_gather = sharding.max_over_ranks(tot["all_gather"], device=dev)
+    per_rank_ms = [x * 1e3 for x in sharding.gather_scalars(tot["render"], device=dev)]
+    per_rank_hits = [int(x) for x in sharding.gather_scalars(float(tm.get("hitting_rays", 0)), device=dev)]
     R = o.shape[0]
     return {"rays": R, "hitting_rays": int(full["ray_mask"].sum()), "samples_per_ray": samples,
             "ms_per_frame": (t_render + t_gather) * 1e3, "render_ms": t_render * 1e3, "all_gather_ms": t_gather * 1e3,
+            "render_ms_per_rank": {"min": min(per_rank_ms), "max": max(per_rank_ms), "all": per_rank_ms},
+            "hitting_rays_per_rank": per_rank_hits,
             "rendered_rays_per_s": R / (t_render + t_gather),
-            "collective": "one all_gather_into_tensor of [rays/N, 6] f32 (rgb, accumulation, depth, mask) per frame",
+            "partition": f"tiles of {sharding.TILE_RAYS} rays dealt round-robin to the ranks (hitting rays per rank balanced)",
+            "collective": "one all_gather_into_tensor of [rays/N, 6] f32 (rgb, accumulation, depth, mask) per frame + inverse permutation",
             "pass": "coarse only (uniform samples), fused MLP + composite"}
 
 

@@ -191,7 +191,9 @@ int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]);
  * (the chain is sound, its order is not certified), 9 more than M-1 faces, 10 invalid t after a valid one,
  * 11 exit face mismatch, 12 step limit (8: unused since round 2).
  * Reason 7 rays keep their logged hits, which go through the literal sort + pairing (reasons[13] counts them);
- * all others are re-traced through the BVH all-hits path. */
+ * all others are re-traced through the BVH all-hits path.  With option "verify_stride": reasons[15] = certified rays
+ * cross-checked against a count-only BVH traversal, reasons[14] = those whose face count differed from the walk's
+ * (re-traced through the BVH path; never observed). */
 int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
 
 /* knobs ("walk" and "gpu_build" also through the environment: TETRANERF_HIP_WALK, TETRANERF_HIP_GPU_BUILD):
@@ -215,7 +217,11 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *             path tests 64 / leaf_width crossed leaves per wave instruction
  *   "small_lds"  1 (default) = batches below walk_min_rays use LDS hit arrays sized for the mesh (every ray resident at
  *             once) and re-trace the rays with more hits in a second launch; "lds_cap" forces their size (tests)
- *   "seg_unroll" 4 / 2, "seg_blocks": shape of the segment writer (hits per ray per iteration; grid cap)
+ *   "verify_stride"  k > 0: every k-th ray the walk certified is cross-checked before its row is written: a count-only
+ *             BVH all-hits traversal must find exactly the faces the walk logged, otherwise the ray takes the BVH path
+ *             (default 0 = off: the check costs a BVH traversal per checked ray; tests and the fuzzer run it at 1)
+ *   "seg_unroll" 4 / 2, "seg_blocks", "seg_dynamic": shape of the segment writer (hits per ray per iteration; grid cap;
+ *             groups handed out by an atomic counter / dealt round-robin)
  * Unknown names are an error. */
 int tn_set_option(tn_tracer_t tracer, const char *name, int value);
 

@@ -155,7 +155,8 @@ def test_adversarial_meshes_bit_exact(tn, device, oracle, scenes, name):
     ot = _oracle(oracle, pts, cells)
     flagged = {}
     # default schedule; speculative tail fill forced down to slot 64 + the 4-waves-per-SIMD segment writer; BVH path
-    for walk, extra in ((2, {}), (2, {"spec_k0": 64, "seg_unroll": 2}), (0, {})):
+    # (+ the count-only BVH cross-check of EVERY certified ray: it must never disagree with the walk)
+    for walk, extra in ((2, {"verify_stride": 1}), (2, {"spec_k0": 64, "seg_unroll": 2}), (0, {})):
         tr = _tracer(tn, device, pts, cells, walk=walk, **extra)
         for sname, (o, d) in _ray_sets(scenes, pts, 20000, 40, pts.min(0), pts.max(0)).items():
             out = _trace(tr, device, o, d, 512)
@@ -163,8 +164,12 @@ def test_adversarial_meshes_bit_exact(tn, device, oracle, scenes, name):
             if walk:
                 st = tr.trace_stats()
                 assert st["walk"] + st["general"] == len(o), st
-                for k, v in tr.flag_reasons().items():
-                    flagged[k] = flagged.get(k, 0) + v
+                why = tr.flag_reasons()
+                if extra.get("verify_stride"):
+                    assert why.get(15, 0) == st["walk"] and why.get(14, 0) == 0, (name, sname, why, st)
+                for k, v in why.items():
+                    if k < 14:
+                        flagged[k] = flagged.get(k, 0) + v
     # the point of these meshes: the walk's certification has to REJECT rays here (ties, zero edge functions,
     # uncertified order), and what it rejects must come out right through the re-walk / BVH paths
     assert sum(flagged.values()) > 0, f"{name}: the walk certified every ray -- not adversarial"

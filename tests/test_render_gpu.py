@@ -205,11 +205,14 @@ def test_render_c3(tn, device, oracle, scenes, render, cfg, mlp_mode):
         np.testing.assert_allclose(got["rgb"].cpu().numpy(), want["rgb"].numpy(), rtol=0, atol=1e-5,
                                    err_msg=f"fused={fused} fused_pass={fused_pass}")
         np.testing.assert_allclose(got["accumulation"].cpu().numpy(), want["accumulation"].numpy(), rtol=0, atol=1e-5)
-        # median depth: asserted at 1e-5 on every DECIDED ray (cumulative weights further than 1e-4 from the threshold
-        # 0.5 at every sample -- two fp32 evaluations of the same weights cannot disagree about the median bin then);
-        # undecided rays may land in a neighbouring bin
-        decided = (want["depth_margin"].numpy() > 1e-4)[:, 0]
-        assert decided.mean() > 0.9
+        # median depth: asserted at 1e-5 on every DECIDED ray: cumulative weights further from the threshold 0.5 at
+        # every sample than two fp32 evaluations of the weights can drift apart over the ray (4e-6 per sample) -- they
+        # cannot disagree about the median bin then; undecided rays may land in a neighbouring bin.  (In the coarse
+        # configuration the field is ~0, sigma = softplus(0) = ln 2 and a ray of length 1 accumulates exactly 0.5: a
+        # third of the rays is undecided by construction.)
+        n_final = S + S_fine + 1 if S_fine else S
+        decided = (want["depth_margin"].numpy() > 4e-6 * n_final)[:, 0]
+        assert decided.mean() > (0.25 if cfg == "coarse" else 0.6), decided.mean()
         np.testing.assert_allclose(got["depth"].cpu().numpy()[decided], want["depth"].numpy()[decided], rtol=0, atol=1e-5,
                                    err_msg=f"depth fused={fused} fused_pass={fused_pass}")
 
@@ -261,7 +264,8 @@ def test_render_pass_equals_unfused_kernels(tn, device, scenes, render, S):
     torch.testing.assert_close(acc[idx].reshape(-1), want_acc.reshape(-1), rtol=0, atol=2e-6)
     miss = torch.ones(R, dtype=torch.bool, device=device); miss[idx] = False
     assert bool((rgb[miss] == 1).all()) and bool((acc[miss] == 0).all()) and bool((depth[miss] == 1000.0).all())
-    # median depth at 1e-5 on every decided ray (cumulative weights further than 1e-4 from the threshold at every sample)
-    decided = render.median_margin(want_wf)[:, 0] > 1e-4
-    assert float(decided.float().mean()) > 0.9
+    # median depth at 1e-5 on every decided ray (cumulative weights further from the threshold at every sample than the
+    # two evaluations -- 2e-6 apart per weight -- can drift over the ray)
+    decided = render.median_margin(want_wf)[:, 0] > 4e-6 * S
+    assert float(decided.float().mean()) > 0.6
     torch.testing.assert_close(depth[idx].reshape(-1)[decided], want_depth.reshape(-1)[decided], rtol=0, atol=1e-5)

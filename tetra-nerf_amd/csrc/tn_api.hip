@@ -43,6 +43,8 @@ struct tn_tracer {
     unsigned lds_cap = 0;                // 0: from the mesh size; otherwise the entries of the small arrays (power of two; tests)
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
     unsigned seg_blocks = 0;             // cap of the segment-writer grid (0 = what is resident at once)
+    unsigned verify_stride = 0;          // > 0: every stride-th certified ray is cross-checked against a count-only BVH traversal
+    bool seg_dynamic = true;             // groups handed out by an atomic counter (false: static round-robin deal)
     unsigned seg_unroll = 4;             // segment writer: chunks of 8 hits per ray per iteration (4: 2 waves per SIMD; 2: 4 waves per SIMD)
     tn::DevBuf<tn::WalkVar> vars;
     tn::DevBuf<float> hull_nodes, hull_tris;
@@ -363,13 +365,15 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 w.hit_log = t->hit_log.p;
                 w.ray_base = base;
                 tn::launch_trace_walk(w, stream);
+                if (t->verify_stride)   // before anything that reads walk_n / the fallback list (same stream)
+                    tn::launch_verify_counts(w.t, t->verify_stride, w.walk_n, w.fallback_list, w.fallback_count, base, stream);
             };
             auto launch_segments = [&](size_t base, size_t n) {
                 tn::WriteParams q{};
                 q.num_rays = n; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
                 q.unroll = t->seg_unroll;
                 q.walk_n = t->walk_n.p + base;
-                q.group_counter = t->group_counter();
+                q.group_counter = t->seg_dynamic ? t->group_counter() : nullptr;
                 q.hit_log = t->hit_log.p;
                 q.vars = t->mesh.vars;
                 q.out_cells = visited + base * M;
@@ -606,6 +610,8 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
             t->lds_cap = (unsigned)value;
         }
         else if (k == "seg_blocks") t->seg_blocks = (unsigned)value;
+        else if (k == "seg_dynamic") t->seg_dynamic = value != 0;
+        else if (k == "verify_stride") t->verify_stride = value < 0 ? 0u : (unsigned)value;
         else if (k == "seg_unroll") t->seg_unroll = value == 2 ? 2u : 4u;
         else if (k == "log_cap_mb") t->log_cap_bytes = value <= 0 ? 0 : (size_t)value << 20;
         else throw tn::Error("unknown option " + (name ? k : std::string("(null)")));

@@ -59,6 +59,11 @@ void launch_trace_walk(const WalkParams &p, hipStream_t stream);
 void launch_postprocess_log(const TraceParams &p, const WalkVar *vars, const uint4 *hit_log, const uint2 *literal_list,
                             const uint32_t *literal_count, size_t max_items, hipStream_t stream);
 
+// count-only BVH cross-check of every stride-th certified ray (tn_trace_general.hip: k_verify_counts); p = the
+// TraceParams of the walk launch; mismatching rays are appended to the fallback list (global ids: ray_base + index)
+void launch_verify_counts(const TraceParams &p, uint32_t stride, uint32_t *walk_n, uint32_t *fallback_list, uint32_t *fallback_count,
+                          size_t ray_base, hipStream_t stream);
+
 // hit log -> rows of the rays the walk certified (walk_n[ray] != TN_EMPTY): k_write_segments writes the segment records
 // + the tail constants up to the next multiple of 32 slots (a 128-byte line boundary in all four row arrays);
 // k_fill_range streams the rest of the constant tails.  Every byte is written once.

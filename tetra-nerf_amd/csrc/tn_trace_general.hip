@@ -545,6 +545,40 @@ __global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const Wal
     }
 }
 
+// Global cross-check of the walk's certification (option "verify_stride", tests / fuzzing / paranoid callers): the
+// walk only sees the connected component of crossed faces that contains the two hull faces; a second component
+// (the star of a vertex whose rounded projection lands exactly on the ray while the chain passes
+// beside it) is invisible to it and only excluded by the vertex-proximity rule (reason 4).  The BVH all-hits traversal
+// sees EVERY face the triangle routine accepts, so for every stride-th ray the walk certified the number of faces the
+// BVH finds (count only: no sort, no pairing) must equal the number of hits the walk logged.  A mismatch is counted
+// (reason 14) and the ray is handed to the BVH kernel like any other fallback ray -- the kernels that write rows are
+// launched after this one.  reason 15 counts the rays checked.
+__global__ __launch_bounds__(64) void k_verify_counts(TraceParams p, uint32_t stride, uint32_t *__restrict__ walk_n,
+                                                      uint32_t *__restrict__ fallback_list, uint32_t *__restrict__ fallback_count,
+                                                      size_t ray_base) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WaveSmem s = carve(smem, p.M);
+    const int lane = threadIdx.x;
+    const size_t n_checks = (p.num_items + stride - 1) / stride;
+    for (size_t it = blockIdx.x; it < n_checks; it += gridDim.x) {
+        const size_t ray = it * stride;
+        const uint32_t wn = walk_n[ray];
+        if (wn == TN_EMPTY) continue;          // literal / fallback ray: not certified, nothing to verify
+        bool overflow = false;
+        const uint32_t nh = collect_hits(p.bvh, s, p.M, p.M - 1, p.origins[3 * ray], p.origins[3 * ray + 1], p.origins[3 * ray + 2],
+                                         p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2], nullptr, lane, overflow);
+        if (lane == 0) {
+            if (p.stats) atomicAdd(&p.stats[4 + 15], 1ull);
+            if (nh != wn || overflow) {
+                walk_n[ray] = TN_EMPTY;        // the segment writer and the fill skip the row: the BVH kernel writes it
+                fallback_list[atomicAdd(fallback_count, 1u)] = (uint32_t)(ray_base + ray);
+                if (p.stats) atomicAdd(&p.stats[4 + 14], 1ull);
+            }
+        }
+        wave_sync();
+    }
+}
+
 size_t trace_general_smem_bytes(uint32_t M) {
     return (size_t)M * (8 + 4 + 4) + (size_t)(M < 32 ? 32 : M) * 8 + STACK_CAP * 4 + 2 * (size_t)M;
 }
@@ -666,6 +700,15 @@ void launch_trace_general(const TraceParams &p, hipStream_t stream) {
     const size_t max_blocks = 256 * 16;
     const unsigned grid = (unsigned)(p.num_items < max_blocks ? p.num_items : max_blocks);
     hipLaunchKernelGGL(k_trace_general, dim3(grid), dim3(64), smem, stream, p);
+}
+
+void launch_verify_counts(const TraceParams &p, uint32_t stride, uint32_t *walk_n, uint32_t *fallback_list, uint32_t *fallback_count,
+                          size_t ray_base, hipStream_t stream) {
+    if (p.num_items == 0 || stride == 0) return;
+    const size_t smem = wave_smem(k_verify_counts, p.M);
+    const size_t n_checks = (p.num_items + stride - 1) / stride, max_blocks = 256 * 16;
+    hipLaunchKernelGGL(k_verify_counts, dim3((unsigned)(n_checks < max_blocks ? n_checks : max_blocks)), dim3(64), smem, stream, p, stride,
+                       walk_n, fallback_list, fallback_count, ray_base);
 }
 
 void launch_postprocess_log(const TraceParams &p, const WalkVar *vars, const uint4 *hit_log, const uint2 *literal_list,

@@ -430,14 +430,14 @@ __global__ __launch_bounds__(256, U == 2 ? 4 : 2) void k_write_segments(WritePar
     };
 
     // the first two groups of a wave are static (wave index, wave index + number of waves); the counter hands out
-    // the groups from 2 * nwaves on
-    auto draw = [&]() -> size_t {
-        uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(q.group_counter, 1u);
-        return 2 * nwaves + (size_t)__builtin_amdgcn_readfirstlane(v);
-    };
+    // the groups from 2 * nwaves on.  A draw is ISSUED one group before its value is used (`pending`): waiting for a
+    // returning atomic right after issuing it would drain the wave's outstanding stores (one vmcnt, in order).
+    const bool dynamic = q.group_counter != nullptr;
+    uint32_t pending = 0;
+    auto issue_draw = [&]() { if (dynamic && lane == 0) pending = atomicAdd(q.group_counter, 1u); };
     size_t g = (size_t)blockIdx.x * 4 + wave;
     if (g >= G) return;
+    issue_draw();
     size_t g_next = g + nwaves, g_next2 = G;
     uint32_t nh_raw = hits_of(g);
     uint32_t nh_next_raw = hits_of(g_next);                // in flight during the whole first group
@@ -461,8 +461,10 @@ __global__ __launch_bounds__(256, U == 2 ? 4 : 2) void k_write_segments(WritePar
         float *const g_bary = q.out_bary + 6 * row0;
         uint32_t *const g_verts = q.out_verts ? q.out_verts + 4 * row0 : nullptr;
         const uint32_t row = a * M;
-        // the group after the next: drawn now, its hit counts requested now, needed one group later
-        g_next2 = g_next < G ? draw() : G;
+        // the group after the next: the draw issued one group ago is consumed now (its hit counts are requested now and
+        // needed one group later), the following one is issued
+        g_next2 = dynamic ? 2 * nwaves + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pending) : g_next + nwaves;
+        issue_draw();
         const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : nh_next_raw;
         const uint32_t nh_next2_raw = hits_of(g_next2);
         uint32_t nseg = 0;

@@ -224,10 +224,11 @@ class TetrahedraTracer:
     def flag_reasons(self):
         """Why the walk did not certify rays of the last trace_rays (reason code 1..12 -> count; include/tetranerf_hip.h);
         7 = sound chain with a gap below eps / a tie / an inversion, 13 = such rays whose logged hits went through the
-        literal sort + pairing (the others were re-traced through the BVH)."""
+        literal sort + pairing (the others were re-traced through the BVH); with option verify_stride: 15 = certified rays
+        cross-checked against a count-only BVH traversal, 14 = those whose face count differed (handed to the BVH path)."""
         arr = (C.c_uint64 * 16)()
         _lib.check(self._lib.tn_trace_flag_reasons(self._h, C.byref(arr)))
-        return {k: int(arr[k]) for k in range(1, 15) if arr[k]}
+        return {k: int(arr[k]) for k in range(1, 16) if arr[k]}
 
     def set_option(self, name: str, value: int):
         _lib.check(self._lib.tn_set_option(self._h, name.encode(), int(value)))
