@@ -220,8 +220,6 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *   "verify_stride"  k > 0: every k-th ray the walk certified is cross-checked before its row is written: a count-only
  *             BVH all-hits traversal must find exactly the faces the walk logged, otherwise the ray takes the BVH path
  *             (default 0 = off: the check costs a BVH traversal per checked ray; tests and the fuzzer run it at 1)
- *   "seg_unroll" 4 / 2, "seg_blocks", "seg_dynamic": shape of the segment writer (hits per ray per iteration; grid cap;
- *             groups handed out by an atomic counter / dealt round-robin)
  * Unknown names are an error. */
 int tn_set_option(tn_tracer_t tracer, const char *name, int value);
 
@@ -290,6 +288,26 @@ int tn_render_pass(tn_mlp_t mlp, uint32_t max_ray_triangles, const uint32_t *num
                    const float *barycentric, const uint32_t *vertex_indices, const uint32_t *ray_index, size_t num_hit_rays,
                    uint32_t num_samples, const float *edges, const float *field_vm, const float *dirs,
                    float background, float *out_weights, float *out_rgb, float *out_acc, float *out_depth, void *stream);
+
+/* ---- ray samplers between tn_trace_rays and the render passes (model.py:111-192, 549-557, 582-586; nerfstudio's
+ * UniformSampler / PDFSampler for the parts the reference imports).  One wavefront per HITTING ray; the trace rows are
+ * read in place through ray_index u32 [r] (as in tn_render_pass).
+ * tn_sample_coarse: near / far of every hitting ray (near_far f32 [r,2]: first t_in, last t_out, model.py:531-544) and
+ *   its num_samples + 1 coarse bin edges (edges f32 [r, S+1], euclidean): linspace f32 [S+1] = the spacing bins
+ *   (torch.linspace(0, 1, S+1): the caller's table, so that both sides use the same values); t_rand f32 [r, S+1] uniform
+ *   draws = training-mode stratified bins (model.py:166-175), NULL = evaluation; biased != 0: the edges are re-mapped so
+ *   that every visited tetrahedron receives the same share of the samples (map_from_real_distances_to_biased_with_bounds,
+ *   model.py:111-122).
+ * tn_sample_pdf: PDFSampler with include_original (model.py:463,584): inverse-CDF samples of the coarse weights f32 [r,S]
+ *   (+ histogram_padding, eps as in nerfstudio: 0.01, 1e-5) at the num_fine + 1 quantiles u_table f32 [num_fine+1]
+ *   (evaluation: bin centres; training: bin starts + u_rand f32 [r, num_fine+1] / (num_fine+1), u_rand NULL otherwise),
+ *   merged with the coarse edges: edges_out f32 [r, S + num_fine + 2], sorted, euclidean. */
+int tn_sample_coarse(size_t num_hit_rays, uint32_t num_samples, uint32_t max_ray_triangles, const uint32_t *ray_index,
+                     const uint32_t *num_visited, const float *hit_distances, const float *linspace, const float *t_rand,
+                     int biased, float *edges, float *near_far, void *stream);
+int tn_sample_pdf(size_t num_hit_rays, uint32_t num_samples, uint32_t num_fine, const float *edges, const float *weights,
+                  const float *near_far, const float *u_table, const float *u_rand, float histogram_padding, float eps,
+                  float *edges_out, void *stream);
 
 /* RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers.
  * sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1] (bin edges: starts = edges[:, :-1], ends = edges[:, 1:]);

@@ -31,7 +31,7 @@ for case in range(n_cases):
     # or host structure build, literal pairing as rows or as an emit mask, 16-byte or fat hit log, LDS-staged or direct
     # segment stores, mesh-sized LDS hit arrays with a forced tiny capacity (overflow relaunch)
     opts = {"walk": int(rng.choice([2, 2, 0])), "gpu_build": int(rng.integers(0, 2)), "literal": int(rng.integers(0, 2)),
-            "spec_k0": int(rng.choice([0, 32, 96])), "seg_unroll": int(rng.choice([2, 4])), "lds_cap": int(rng.choice([0, 0, 16, 64]))}
+            "spec_k0": int(rng.choice([0, 32, 96])), "lds_cap": int(rng.choice([0, 0, 16, 64]))}
     for k, v in opts.items(): tr.set_option(k, v)
     tr.load_tetrahedra(torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev))
     got = tr.trace_rays(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), M)

@@ -154,9 +154,9 @@ def test_adversarial_meshes_bit_exact(tn, device, oracle, scenes, name):
     pts, cells = ADVERSARIAL[name](scenes)
     ot = _oracle(oracle, pts, cells)
     flagged = {}
-    # default schedule; speculative tail fill forced down to slot 64 + the 4-waves-per-SIMD segment writer; BVH path
+    # default schedule; speculative tail fill forced down to slot 64; BVH path
     # (+ the count-only BVH cross-check of EVERY certified ray: it must never disagree with the walk)
-    for walk, extra in ((2, {"verify_stride": 1}), (2, {"spec_k0": 64, "seg_unroll": 2}), (0, {})):
+    for walk, extra in ((2, {"verify_stride": 1}), (2, {"spec_k0": 64}), (0, {})):
         tr = _tracer(tn, device, pts, cells, walk=walk, **extra)
         for sname, (o, d) in _ray_sets(scenes, pts, 20000, 40, pts.min(0), pts.max(0)).items():
             out = _trace(tr, device, o, d, 512)
@@ -218,7 +218,7 @@ def test_randomised_stress_sample(tn, device, oracle, scenes):
         else:
             w = int(np.sqrt(R))
             o, d = scenes.pinhole_rays(w, w, eye=(0.5 + 1.7 * np.cos(seed), 0.5 + 1.7 * np.sin(seed), 0.6), lookat=(0.5, 0.5, 0.5))
-        tr = _tracer(tn, device, pts, cells, walk=2, spec_k0=int(rng.choice([0, 32, 96])), seg_unroll=int(rng.choice([2, 4])),
+        tr = _tracer(tn, device, pts, cells, walk=2, spec_k0=int(rng.choice([0, 32, 96])),
                      literal=int(rng.choice([0, 1, 1])))
         _compare(_trace(tr, device, o, d, M), _oracle(oracle, pts, cells), o, d, M,
                  ctx=f"stress case {case}: npts={npts} seed={seed} M={M} kind={kind}")
@@ -252,13 +252,11 @@ def test_speculative_fill_is_overwritten_by_every_ray_class(tn, device, oracle, 
     st, why = tr.trace_stats(), tr.flag_reasons()
     assert st["walk"] > 1000 and why.get(13, 0) > 50 and sum(v for k, v in why.items() if k in (1, 2, 3, 4, 5, 6, 9, 10, 11)) > 50, (st, why)
     for k0 in (0, 64, 32):
-        for unroll in (4, 2):
-            tr.set_option("spec_k0", k0)
-            tr.set_option("seg_unroll", unroll)
-            out = _trace(tr, device, o, d, M)
-            for k in KEYS:
-                g = out[k].cpu().numpy()
-                assert np.array_equal(g.view(np.uint32), np.ascontiguousarray(want[k]).view(np.uint32)), f"spec_k0={k0} unroll={unroll}: {k}"
+        tr.set_option("spec_k0", k0)
+        out = _trace(tr, device, o, d, M)
+        for k in KEYS:
+            g = out[k].cpu().numpy()
+            assert np.array_equal(g.view(np.uint32), np.ascontiguousarray(want[k]).view(np.uint32)), f"spec_k0={k0}: {k}"
     # the same with the fill switched off and through the BVH path alone
     for opts in ({"spec_fill": 0}, {"walk": 0}):
         tr2 = _tracer(tn, device, pts, cells, **{"walk": 2, **opts})

@@ -40,21 +40,23 @@ def test_adapter_eval_matches_reference_path(tn, device, scenes, cfg):
 
     standins, plugin, model = _setup(scenes, device, **cfg)
     model.eval()
-    o, d = scenes.outside_in_rays(4096, 32)
+    o, d = scenes.outside_in_rays(3600, 32)
+    o2, d2 = scenes.pinhole_rays(31, 16, eye=(0.5, 3.0, 2.6), lookat=(0.5, 0.5, 0.5))     # + rays that partly miss the mesh
+    o, d = np.ascontiguousarray(np.concatenate([o, o2])), np.ascontiguousarray(np.concatenate([d, d2]))
     rb = standins.RayBundle(torch.from_numpy(o).to(device), torch.from_numpy(d).to(device))
     with torch.no_grad():
         got = model.get_outputs(rb)                                          # fused kernels
         want = standins.StandInTetrahedraNerf.get_outputs(model, rb)         # reference-shaped path
     assert model.reference_calls == 1
-    assert torch.equal(got["ray_mask"], want["ray_mask"]) and 0.3 < float(got["ray_mask"].float().mean()) < 1.0
+    assert torch.equal(got["ray_mask"], want["ray_mask"]) and float(got["ray_mask"].float().mean()) > 0.3
     miss = ~got["ray_mask"]
     bg = 0.0 if cfg.get("background_color") == "black" else 1.0
     assert bool((got["rgb"][miss] == bg).all()) and bool((got["depth"][miss] == 1000.0).all())
     np.testing.assert_allclose(got["rgb"].cpu().numpy(), want["rgb"].cpu().numpy(), rtol=0, atol=1e-5)
     np.testing.assert_allclose(got["accumulation"].cpu().numpy(), want["accumulation"].cpu().numpy(), rtol=0, atol=1e-5)
     n_final = cfg["num_samples"] + cfg["num_fine_samples"] + 1 if cfg["num_fine_samples"] else cfg["num_samples"]
-    decided = (want["depth_margin"] > 4e-6 * n_final)[:, 0].cpu().numpy()     # see tests/test_render_gpu.py::test_render_c3
-    assert decided.mean() > 0.6
+    decided = ((want["depth_margin"] > 4e-6 * n_final)[:, 0] & want["ray_mask"]).cpu().numpy()     # see tests/test_render_gpu.py::test_render_c3
+    assert decided.sum() > 200
     np.testing.assert_allclose(got["depth"].cpu().numpy()[decided], want["depth"].cpu().numpy()[decided], rtol=0, atol=1e-5)
     # a second call reuses the renderer and its packed weights; an optimiser-style in-place update is seen
     rd = model._tn_renderer

@@ -211,8 +211,10 @@ def test_render_c3(tn, device, oracle, scenes, render, cfg, mlp_mode):
         # configuration the field is ~0, sigma = softplus(0) = ln 2 and a ray of length 1 accumulates exactly 0.5: a
         # third of the rays is undecided by construction.)
         n_final = S + S_fine + 1 if S_fine else S
-        decided = (want["depth_margin"].numpy() > 4e-6 * n_final)[:, 0]
-        assert decided.mean() > (0.25 if cfg == "coarse" else 0.6), decided.mean()
+        decided = (want["depth_margin"].numpy() > 4e-6 * n_final)[:, 0] & want["ray_mask"].numpy()
+        assert decided.sum() > 200, decided.sum()
+        # and overall (round-2 form): at most 2 % of the rays land in a neighbouring bin
+        assert np.isclose(got["depth"].cpu().numpy(), want["depth"].numpy(), rtol=0, atol=1e-4).mean() > 0.98
         np.testing.assert_allclose(got["depth"].cpu().numpy()[decided], want["depth"].numpy()[decided], rtol=0, atol=1e-5,
                                    err_msg=f"depth fused={fused} fused_pass={fused_pass}")
 
@@ -267,5 +269,6 @@ def test_render_pass_equals_unfused_kernels(tn, device, scenes, render, S):
     # median depth at 1e-5 on every decided ray (cumulative weights further from the threshold at every sample than the
     # two evaluations -- 2e-6 apart per weight -- can drift over the ray)
     decided = render.median_margin(want_wf)[:, 0] > 4e-6 * S
-    assert float(decided.float().mean()) > 0.6
+    assert int(decided.sum()) > 100
+    assert float(torch.isclose(depth[idx].reshape(-1), want_depth.reshape(-1), rtol=0, atol=1e-6).float().mean()) > 0.99
     torch.testing.assert_close(depth[idx].reshape(-1)[decided], want_depth.reshape(-1)[decided], rtol=0, atol=1e-5)

@@ -173,7 +173,6 @@ def test_literal_pairing_of_the_log_equals_bvh_fallback(tn, device, oracle, scen
     assert 13 not in tr.flag_reasons()
     tr.set_option("literal", 1)
     tr.set_option("spec_k0", 32)     # speculative fill from slot 32 on: the literal rows overwrite it
-    tr.set_option("seg_unroll", 2)
     c = _trace(tr, device, o, d, 512)
     for k in KEYS:
         assert _bits_equal(a[k], b[k]), k

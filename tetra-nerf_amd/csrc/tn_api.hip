@@ -42,10 +42,7 @@ struct tn_tracer {
     bool small_lds = true;               // small batches: LDS hit arrays sized for the mesh, overflow rays in a second launch
     unsigned lds_cap = 0;                // 0: from the mesh size; otherwise the entries of the small arrays (power of two; tests)
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
-    unsigned seg_blocks = 0;             // cap of the segment-writer grid (0 = what is resident at once)
     unsigned verify_stride = 0;          // > 0: every stride-th certified ray is cross-checked against a count-only BVH traversal
-    bool seg_dynamic = true;             // groups handed out by an atomic counter (false: static round-robin deal)
-    unsigned seg_unroll = 4;             // segment writer: chunks of 8 hits per ray per iteration (4: 2 waves per SIMD; 2: 4 waves per SIMD)
     tn::DevBuf<tn::WalkVar> vars;
     tn::DevBuf<float> hull_nodes, hull_tris;
     tn::DevWideBvh bvh;
@@ -53,7 +50,6 @@ struct tn_tracer {
                                             // literal count, kmax (one memset clears them all)
     uint32_t *fallback_count() { return reinterpret_cast<uint32_t *>(stats.p + 24); }
     uint32_t *literal_count() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 1; }
-    uint32_t *group_counter() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 2; }   // segment writer: next 8-ray group
     size_t last_num_rays = 0;
     int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
     size_t walk_min_rays = 12288;        // measured crossover on the 300k-tet mesh after round 2b's faster BVH path
@@ -371,16 +367,14 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             auto launch_segments = [&](size_t base, size_t n) {
                 tn::WriteParams q{};
                 q.num_rays = n; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
-                q.unroll = t->seg_unroll;
                 q.walk_n = t->walk_n.p + base;
-                q.group_counter = t->seg_dynamic ? t->group_counter() : nullptr;
                 q.hit_log = t->hit_log.p;
                 q.vars = t->mesh.vars;
                 q.out_cells = visited + base * M;
                 q.out_bary = bary + base * M * 6;
                 q.out_dist = dist + base * M * 2;
                 q.out_verts = verts ? verts + base * M * 4 : nullptr;
-                tn::launch_write_segments(q, stream, t->seg_blocks);
+                tn::launch_write_segments(q, stream);
             };
             auto launch_fill = [&](size_t base, size_t n, uint32_t k_hi) {   // [ceil32(n_r), k_hi) of the certified rows
                 if (!t->dense_tails) return;
@@ -437,7 +431,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             } else {
                 for (size_t base = 0; base < R; base += chunk) {
                     const size_t n = R - base < chunk ? R - base : chunk;
-                    TN_HIP(hipMemsetAsync(t->literal_count(), 0, 2 * sizeof(uint32_t), stream));   // + the writer's group counter
+                    TN_HIP(hipMemsetAsync(t->literal_count(), 0, sizeof(uint32_t), stream));
                     launch_walk(base, n);
                     launch_segments(base, n);
                     launch_fill(base, n, M);
@@ -609,10 +603,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
             if (value < 0 || (value & (value - 1)) != 0 || (value && value < 8)) throw tn::Error("lds_cap must be 0 or a power of two >= 8");
             t->lds_cap = (unsigned)value;
         }
-        else if (k == "seg_blocks") t->seg_blocks = (unsigned)value;
-        else if (k == "seg_dynamic") t->seg_dynamic = value != 0;
         else if (k == "verify_stride") t->verify_stride = value < 0 ? 0u : (unsigned)value;
-        else if (k == "seg_unroll") t->seg_unroll = value == 2 ? 2u : 4u;
         else if (k == "log_cap_mb") t->log_cap_bytes = value <= 0 ? 0 : (size_t)value << 20;
         else throw tn::Error("unknown option " + (name ? k : std::string("(null)")));
     });
@@ -839,6 +830,32 @@ int tn_mlp_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, con
     return guarded([&] {
         if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
         tn::launch_head_grad(n, samples_per_ray, dhead, h3, h4, d4, out, ray_sum, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_sample_coarse(size_t num_hit_rays, uint32_t num_samples, uint32_t M, const uint32_t *ray_index, const uint32_t *num_visited,
+                     const float *hit_distances, const float *linspace, const float *t_rand, int biased, float *edges,
+                     float *near_far, void *stream_) {
+    return guarded([&] {
+        if (num_hit_rays == 0) return;
+        if (!ray_index || !num_visited || !hit_distances || !linspace || !edges || !near_far) throw tn::Error("null pointer");
+        if (num_samples == 0) throw tn::Error("num_samples must be positive");
+        tn::launch_sample_coarse(num_hit_rays, num_samples, M, ray_index, num_visited, hit_distances, linspace, t_rand, biased != 0,
+                                 edges, near_far, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_sample_pdf(size_t num_hit_rays, uint32_t num_samples, uint32_t num_fine, const float *edges, const float *weights,
+                  const float *near_far, const float *u_table, const float *u_rand, float histogram_padding, float eps,
+                  float *edges_out, void *stream_) {
+    return guarded([&] {
+        if (num_hit_rays == 0) return;
+        if (!edges || !weights || !near_far || !u_table || !edges_out) throw tn::Error("null pointer");
+        if (num_samples == 0) throw tn::Error("num_samples must be positive");
+        tn::launch_sample_pdf(num_hit_rays, num_samples, num_fine, edges, weights, near_far, u_table, u_rand, histogram_padding, eps,
+                              edges_out, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }

@@ -71,9 +71,7 @@ struct WriteParams {
     size_t num_rays;
     uint32_t M;
     uint32_t dense_tails;      // 0: slots >= num_visited are left unwritten (non-reference option)
-    uint32_t unroll;           // chunks of 8 hits per ray per iteration: 4 (2 waves per SIMD) or 2 (4 waves per SIMD)
     const uint32_t *walk_n;    // hits in the log; TN_EMPTY: the row belongs to the literal / BVH kernels
-    uint32_t *group_counter;   // [1], zero at launch: dynamic hand-out of the 8-ray groups
     const uint4 *hit_log;
     const WalkVar *vars;
     uint32_t *out_cells;
@@ -171,6 +169,11 @@ void launch_render_pass(const uint32_t *num_visited, const float *dist, const fl
                         const uint32_t *ray_index, size_t r, uint32_t S, const float *edges, const float *fieldT,
                         const float *dirs, const MlpPacks &w, float background, float *out_weights, float *out_rgb,
                         float *out_acc, float *out_depth, hipStream_t stream);
+// ray samplers (tn_samplers.hip): one wavefront per hitting ray, trace rows read in place through ray_index
+void launch_sample_coarse(size_t r, uint32_t S, uint32_t M, const uint32_t *ray_index, const uint32_t *num_visited, const float *hit_dist,
+                          const float *lin, const float *t_rand, bool biased, float *edges, float *near_far, hipStream_t stream);
+void launch_sample_pdf(size_t r, uint32_t S, uint32_t num_fine, const float *edges, const float *weights, const float *near_far,
+                       const float *u_table, const float *u_rand, float histogram_padding, float eps, float *out, hipStream_t stream);
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
                       float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream);
 

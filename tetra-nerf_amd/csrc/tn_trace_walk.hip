@@ -373,13 +373,15 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
 // acknowledged.  Hence the software pipeline: the entries of the NEXT iteration -- of this group, or of the wave's
 // next group, whose hit counts were requested a whole group earlier -- are requested BEFORE this iteration's record
 // loads and stores.
-// Groups are handed out DYNAMICALLY (one atomic counter per launch; a wave draws its group two groups ahead of its
-// use, which is what the pipeline above needs): with a static round-robin deal the average wave was alive for 55 % of
-// the kernel (SQ_WAVE_CYCLES / SQ_WAVES = 0.44 ms of 0.80 ms, profiles/r03a_pmc_1.txt) -- the kernel waited for its
-// slowest waves.  Drawing in order also keeps the waves of the chip on neighbouring rays (the XCD's L2 holds their
-// records).  U = chunks of 8 hits per ray per iteration: 4 = 32 hits per ray in flight per wave at 2 waves per SIMD
-// (U = 2 at 4 waves per SIMD measured 3-5 % slower per frame: profiles/r03b_writer.txt -- not occupancy-bound).  The
-// wave index is made wave-uniform (readfirstlane): group index, log base and row bases live in scalar registers.
+// Groups are dealt round-robin to the waves (the rays that miss the mesh are clustered).  Round 3 measured what bounds
+// the kernel: its waves spend 66 % of their cycles in s_waitcnt and the average wave is alive for 55 % of the kernel
+// (SQ_WAVE_CYCLES / SQ_WAVES, profiles/r03a_pmc_1.txt), yet neither more waves (U = 2: half the registers and LDS, 4
+// waves per SIMD: 3-5 % slower per frame, profiles/r03b_writer.txt) nor a dynamic hand-out of the groups through an
+// atomic counter (every wave busy to the end: 4-5 % slower, profiles/r03d_writer_ab.txt) help -- with all waves active
+// each one waits longer: the kernel is bound by what the memory system delivers for its mix of 16-byte log reads, 32-byte
+// record gathers and partial-line row writes (4.3-4.6 TB/s of raw traffic).  U = chunks of 8 hits per ray per iteration
+// (4: 32 hits per ray in flight per wave).  The wave index is made wave-uniform (readfirstlane): group index, log base
+// and row bases live in scalar registers.
 namespace {
 template <int U>
 struct SW {
@@ -400,7 +402,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 }  // namespace
 
 template <int U>
-__global__ __launch_bounds__(256, U == 2 ? 4 : 2) void k_write_segments(WriteParams q) {
+__global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
     using W = SW<U>;
     __shared__ __attribute__((aligned(16))) uint32_t smem[4 * W::TOTAL];
     const int lane = threadIdx.x & 63;
@@ -429,15 +431,8 @@ __global__ __launch_bounds__(256, U == 2 ? 4 : 2) void k_write_segments(WritePar
         }
     };
 
-    // the first two groups of a wave are static (wave index, wave index + number of waves); the counter hands out
-    // the groups from 2 * nwaves on.  A draw is ISSUED one group before its value is used (`pending`): waiting for a
-    // returning atomic right after issuing it would drain the wave's outstanding stores (one vmcnt, in order).
-    const bool dynamic = q.group_counter != nullptr;
-    uint32_t pending = 0;
-    auto issue_draw = [&]() { if (dynamic && lane == 0) pending = atomicAdd(q.group_counter, 1u); };
     size_t g = (size_t)blockIdx.x * 4 + wave;
     if (g >= G) return;
-    issue_draw();
     size_t g_next = g + nwaves, g_next2 = G;
     uint32_t nh_raw = hits_of(g);
     uint32_t nh_next_raw = hits_of(g_next);                // in flight during the whole first group
@@ -461,10 +456,8 @@ __global__ __launch_bounds__(256, U == 2 ? 4 : 2) void k_write_segments(WritePar
         float *const g_bary = q.out_bary + 6 * row0;
         uint32_t *const g_verts = q.out_verts ? q.out_verts + 4 * row0 : nullptr;
         const uint32_t row = a * M;
-        // the group after the next: the draw issued one group ago is consumed now (its hit counts are requested now and
-        // needed one group later), the following one is issued
-        g_next2 = dynamic ? 2 * nwaves + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pending) : g_next + nwaves;
-        issue_draw();
+        // the group after the next: its hit counts are requested now, needed one group later
+        g_next2 = g_next + nwaves;
         const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : nh_next_raw;
         const uint32_t nh_next2_raw = hits_of(g_next2);
         uint32_t nseg = 0;
@@ -586,11 +579,10 @@ __global__ __launch_bounds__(256, U == 2 ? 4 : 2) void k_write_segments(WritePar
 void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned max_blocks) {
     if (q.num_rays == 0) return;
     size_t blocks = (q.num_rays + 31) / 32;        // one group of 8 rays per wave
-    // grid = what is resident at once (U = 4: 2 blocks per CU, U = 2: 4): the groups are dealt round-robin over it
-    const size_t cap = max_blocks ? max_blocks : (size_t)256 * (q.unroll == 2 ? 4 : 2);
+    // grid = what is resident at once (2 blocks per CU at 192 VGPRs): the groups are dealt round-robin over it
+    const size_t cap = max_blocks ? max_blocks : (size_t)256 * 2;
     if (blocks > cap) blocks = cap;
-    if (q.unroll == 2) hipLaunchKernelGGL(k_write_segments<2>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
-    else hipLaunchKernelGGL(k_write_segments<4>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    hipLaunchKernelGGL(k_write_segments<4>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
 }
 
 // Constant tails: pure streaming stores (16 B per lane, whole 128-byte lines), a contiguous span of rows per wave.

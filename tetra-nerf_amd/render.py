@@ -307,7 +307,7 @@ class TetraRenderer:
     def __init__(self, tracer, field: torch.Tensor, mlp: TetraMLP, num_samples: int = 256,
                  max_ray_triangles: int = 512, fused: bool = True, far_plane: float = 1000.0,
                  num_fine_samples: int = 0, biased: bool = False, dense_tails: bool = False, fused_pass="auto",
-                 mlp_mode: str = "fp32", background: float = 1.0, cache_field: bool = True):
+                 mlp_mode: str = "fp32", background: float = 1.0, cache_field: bool = True, device_samplers: bool = True):
         from . import tetranerf_cpp_extension as cpp
 
         self.cpp = cpp
@@ -317,6 +317,10 @@ class TetraRenderer:
         # always fp32 because the backward kernel recomputes the activations in fp32)
         self.mlp_mode = mlp_mode
         self.background = float(background)    # RGBRenderer background: 1.0 white (default config), 0.0 black
+        # samplers as device kernels on the trace rows in place (tn_sample_coarse / tn_sample_pdf): a render is then
+        # trace -> [sampler -> pass] x 2 with no PyTorch operator in between (False: the PyTorch statements above, ~15
+        # small kernels per pass -- the parity definition, kept for tests and A/B)
+        self.device_samplers = bool(device_samplers)
         if cache_field:
             # this renderer owns `field`: cached vertex-major shadow, refreshed per tensor version.  After a write through
             # `.data` call cpp.invalidate_field_cache(field) (see tetranerf_cpp_extension.register_field)
@@ -351,10 +355,6 @@ class TetraRenderer:
                 self.tracer.set_option("dense_tails", 1)
         nv = out["num_visited_cells"]
         ray_mask = nv > 0
-        # rows of empty rays are unwritten without dense tails: read nears/fars under the mask
-        nears = torch.where(ray_mask, out["hit_distances"][:, 0, 0], 0.0)[:, None]
-        fars = torch.where(ray_mask[:, None], torch.gather(out["hit_distances"][:, :, 1], 1,
-                                                          (nv[:, None].long() - 1).clamp_min(0)), 0.0)
         R, dev = origins.shape[0], origins.device
         rgb = torch.full((R, 3), self.background, dtype=torch.float32, device=dev)
         acc = torch.zeros((R, 1), dtype=torch.float32, device=dev)
@@ -363,28 +363,41 @@ class TetraRenderer:
         mode, bg = self.mlp_mode, self.background
         if idx.numel():
             # the 26 KB trace rows of the hitting rays are NOT compacted (model.py:546-567 copies them with boolean
-            # indexing): find_visited_cells reads them in place through the ray index
+            # indexing): samplers, find_visited_cells and the render pass read them in place through the ray index
             lists = [out[k] for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates", "hit_distances",
                                       "vertex_indices")]
             ridx = idx.to(torch.int32)
-            near_r, far_r = nears[idx], fars[idx]
             w = mlp_weights(self.mlp)
 
             def locate(edges):
                 dist = ((edges[:, 1:] + edges[:, :-1]) / 2).contiguous()
                 return self.tracer.find_visited_cells(*lists, dist, ray_index=ridx)
 
-            if self.biased:
-                edges = biased_sample_bins(near_r, far_r, S, lists[0][idx], lists[3][idx]).contiguous()
+            if self.device_samplers:
+                edges, near_far = cpp.sample_coarse(lists[0], lists[3], ridx, S, biased=self.biased)
+                near_r, far_r = near_far[:, 0:1], near_far[:, 1:2]
             else:
-                edges = uniform_sample_bins(near_r, far_r, S).contiguous()
+                # (rows of empty rays are unwritten without dense tails: nears / fars only of the hitting rays)
+                near_r = out["hit_distances"][idx, 0, 0][:, None]
+                far_r = out["hit_distances"][idx, (nv[idx].long() - 1), 1][:, None]
+                near_far = torch.cat([near_r, far_r], 1).contiguous()
+                if self.biased:
+                    edges = biased_sample_bins(near_r, far_r, S, lists[0][idx], lists[3][idx]).contiguous()
+                else:
+                    edges = uniform_sample_bins(near_r, far_r, S).contiguous()
+
+            def fine_edges(edges, weights_c):
+                if self.device_samplers:
+                    return cpp.sample_pdf(edges, weights_c, near_far, self.S_fine)
+                spacing = (edges - near_r) / (far_r - near_r)
+                return pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r).contiguous()
+
             if (self.fused_pass is True or (self.fused_pass == "auto" and idx.numel() <= FUSED_PASS_MAX_RAYS)) and mode == "fp32":
                 # every pass is ONE launch: match + gather + MLP + composite (tn_render.hip); per sample only the coarse
                 # weights go through HBM; the finished rays are written straight into the frame buffers
                 if self.S_fine > 0:
                     weights_c = cpp.render_pass(lists, ridx, edges, self.field, None, w)
-                    spacing = (edges - near_r) / (far_r - near_r)
-                    edges = pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r).contiguous()
+                    edges = fine_edges(edges, weights_c)
                 cpp.render_pass(lists, ridx, edges, self.field, directions[idx].contiguous(), w, out=(rgb, acc, depth),
                                 background=bg)
                 return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
@@ -394,8 +407,7 @@ class TetraRenderer:
                 sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
                                                  None, w, S, mode=mode)
                 weights_c = cpp.composite(sigma_c.view(-1, S), None, edges)
-                spacing = (edges - near_r) / (far_r - near_r)
-                edges = pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r).contiguous()
+                edges = fine_edges(edges, weights_c)
                 traced = locate(edges)
                 S = edges.shape[1] - 1
             # gather + MLP + heads in one kernel (no [64, n] feature buffer)
@@ -428,9 +440,6 @@ class TetraRenderer:
                     self.tracer.set_option("dense_tails", 1)
             nv = out["num_visited_cells"]
             ray_mask = nv > 0
-            nears = torch.where(ray_mask, out["hit_distances"][:, 0, 0], 0.0)[:, None]
-            fars = torch.where(ray_mask[:, None], torch.gather(out["hit_distances"][:, :, 1], 1,
-                                                              (nv[:, None].long() - 1).clamp_min(0)), 0.0)
             idx = torch.nonzero(ray_mask)[:, 0]
         R, dev = origins.shape[0], origins.device
         bg = self.background
@@ -442,17 +451,23 @@ class TetraRenderer:
         lists = [out[k] for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates", "hit_distances",
                                   "vertex_indices")]
         ridx = idx.to(torch.int32)
-        near_r, far_r = nears[idx], fars[idx]
         r = idx.numel()
         rand = rand or {}
         with torch.no_grad():
             t_rand = rand.get("coarse")
             if t_rand is None:
                 t_rand = torch.rand((r, S + 1), device=dev, generator=generator)
-            if self.biased:
-                edges = biased_sample_bins(near_r, far_r, S, lists[0][idx], lists[3][idx], t_rand).contiguous()
+            if self.device_samplers:
+                edges, near_far = cpp.sample_coarse(lists[0], lists[3], ridx, S, biased=self.biased, t_rand=t_rand.contiguous())
+                near_r, far_r = near_far[:, 0:1], near_far[:, 1:2]
             else:
-                edges = uniform_sample_bins(near_r, far_r, S, t_rand).contiguous()
+                near_r = out["hit_distances"][idx, 0, 0][:, None]
+                far_r = out["hit_distances"][idx, (nv[idx].long() - 1), 1][:, None]
+                near_far = torch.cat([near_r, far_r], 1).contiguous()
+                if self.biased:
+                    edges = biased_sample_bins(near_r, far_r, S, lists[0][idx], lists[3][idx], t_rand).contiguous()
+                else:
+                    edges = uniform_sample_bins(near_r, far_r, S, t_rand).contiguous()
 
             def locate(e):
                 dist = ((e[:, 1:] + e[:, :-1]) / 2).contiguous()
@@ -464,11 +479,14 @@ class TetraRenderer:
                 sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
                                                  None, w, S)
                 weights_c = cpp.composite(sigma_c.view(-1, S), None, edges)
-                spacing = (edges - near_r) / (far_r - near_r)
                 u_rand = rand.get("fine")
                 if u_rand is None:
                     u_rand = torch.rand((r, self.S_fine + 1), device=dev, generator=generator)
-                edges = pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r, u_rand=u_rand).contiguous()
+                if self.device_samplers:
+                    edges = cpp.sample_pdf(edges, weights_c, near_far, self.S_fine, u_rand=u_rand.contiguous())
+                else:
+                    spacing = (edges - near_r) / (far_r - near_r)
+                    edges = pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r, u_rand=u_rand).contiguous()
                 traced = locate(edges)
                 S = edges.shape[1] - 1
         dirs = directions[idx].contiguous()

@@ -296,7 +296,9 @@ def register_field(field):
     """Opt in to a cached vertex-major shadow of `field` (see above).  Returns `field`."""
     import weakref
 
-    _FIELD_VM.setdefault(id(field), (weakref.ref(field), None, None, None, None))
+    hit = _FIELD_VM.get(id(field))
+    if hit is None or hit[0]() is not field:      # (a dead entry whose id() was reused is replaced)
+        _FIELD_VM[id(field)] = (weakref.ref(field), None, None, None, None)
     return field
 
 
@@ -451,8 +453,12 @@ class FusedMLP:
 
     def sync(self, weights, force=False):
         _check(len(weights) == 12, "weights must hold 12 tensors")
-        key = tuple((id(w), w._version, w.data_ptr()) for w in weights)
-        if not force and key == self._key:
+        import weakref
+
+        # identity through weak references: id() of a collected tensor can be reused by a new one at the same address
+        key = tuple((w._version, w.data_ptr()) for w in weights)
+        if (not force and self._key is not None and key == self._key[0]
+                and all(r() is w for r, w in zip(self._key[1], weights))):
             return self
         st = _MlpWeightsStruct()
         keep = []
@@ -466,7 +472,7 @@ class FusedMLP:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.tn_mlp_set_weights(self._h, C.byref(st), _stream(self.device)))
         del keep
-        self._key = key
+        self._key = (key, [weakref.ref(w) for w in weights])
         return self
 
     @property
@@ -587,6 +593,69 @@ def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, b
                                           _ptr(edges), _ptr(field_vm), _ptr(dirs), float(background), None, _ptr(rgb), _ptr(acc),
                                           _ptr(depth), _stream(dev)))
     return w_out
+
+
+_TABLES = {}    # (kind, n, device) -> small constant tables of the samplers (the values the PyTorch statements use)
+
+
+def _linspace_table(S, device):
+    key = ("lin", S, device)
+    if key not in _TABLES:
+        _TABLES[key] = torch.linspace(0.0, 1.0, S + 1, dtype=torch.float32, device=device)
+    return _TABLES[key]
+
+
+def _quantile_table(num_bins, centred, device):
+    key = ("q", num_bins, centred, device)
+    if key not in _TABLES:
+        u = torch.linspace(0.0, 1.0 - (1.0 / num_bins), steps=num_bins, dtype=torch.float32, device=device)
+        _TABLES[key] = (u + 1.0 / (2 * num_bins)).contiguous() if centred else u
+    return _TABLES[key]
+
+
+def sample_coarse(num_visited_cells, hit_distances, ray_index, num_samples, biased=False, t_rand=None):
+    """Coarse sampler as ONE kernel on the trace rows in place (tn_sample_coarse; model.py:531-557, 111-192): returns
+    (edges f32 [r, S+1] euclidean bin edges, near_far f32 [r, 2]) for the hitting rays ray_index i32 [r].  t_rand
+    [r, S+1]: training-mode stratified bins; biased: the TetrahedraSampler mapping.  Same values as
+    render.uniform_sample_bins / biased_sample_bins up to the rounding of one prefix sum."""
+    for x, name in ((num_visited_cells, "num_visited_cells"), (hit_distances, "hit_distances"), (ray_index, "ray_index")):
+        _check_input(x, name)
+    _check(ray_index.dtype == torch.int32 and ray_index.dim() == 1, "ray_index must be i32 [r]")
+    _check(hit_distances.dtype == torch.float32 and hit_distances.dim() == 3 and hit_distances.size(2) == 2, "hit_distances must be f32 [R,M,2]")
+    r, S, M = ray_index.numel(), int(num_samples), hit_distances.size(1)
+    dev = hit_distances.device
+    if t_rand is not None:
+        _check_input(t_rand, "t_rand")
+        _check(t_rand.dtype == torch.float32 and tuple(t_rand.shape) == (r, S + 1), "t_rand must be f32 [r, S+1]")
+    edges = torch.empty((r, S + 1), dtype=torch.float32, device=dev)
+    near_far = torch.empty((r, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tn_sample_coarse(r, S, M, _ptr(ray_index), _ptr(num_visited_cells), _ptr(hit_distances),
+                                                _ptr(_linspace_table(S, dev)), _ptr(t_rand), 1 if biased else 0, _ptr(edges),
+                                                _ptr(near_far), _stream(dev)))
+    return edges, near_far
+
+
+def sample_pdf(edges, weights, near_far, num_fine, u_rand=None, histogram_padding=0.01, eps=1e-5):
+    """nerfstudio's PDFSampler (include_original) as ONE kernel (tn_sample_pdf; model.py:582-586): edges f32 [r, S+1]
+    euclidean coarse edges, weights f32 [r, S], near_far f32 [r, 2] -> f32 [r, S + num_fine + 2] merged, sorted euclidean
+    edges.  u_rand [r, num_fine+1]: training-mode stratified quantiles."""
+    for x, name in ((edges, "edges"), (weights, "weights"), (near_far, "near_far")):
+        _check_input(x, name)
+        _check(x.dtype == torch.float32, f"{name} must have float32 type")
+    r, S = weights.shape
+    nb = int(num_fine) + 1
+    _check(tuple(edges.shape) == (r, S + 1) and tuple(near_far.shape) == (r, 2), "shape mismatch")
+    dev = edges.device
+    if u_rand is not None:
+        _check_input(u_rand, "u_rand")
+        _check(u_rand.dtype == torch.float32 and tuple(u_rand.shape) == (r, nb), "u_rand must be f32 [r, num_fine+1]")
+    out = torch.empty((r, S + 1 + nb), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tn_sample_pdf(r, S, int(num_fine), _ptr(edges), _ptr(weights), _ptr(near_far),
+                                             _ptr(_quantile_table(nb, u_rand is None, dev)), _ptr(u_rand), float(histogram_padding),
+                                             float(eps), _ptr(out), _stream(dev)))
+    return out
 
 
 def composite(sigma, rgb, edges, background=1.0, return_weights=False):
