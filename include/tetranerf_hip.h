@@ -189,7 +189,8 @@ int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]);
  * hull crossings, 3 equal hull distances, 4 a vertex of a visited tet within rounding distance of the ray,
  * 5 zero edge function, 6 not exactly two crossed faces in a tet, 7 a gap below eps / a tie / an inversion in t
  * (the chain is sound, its order is not certified), 9 more than M-1 faces, 10 invalid t after a valid one,
- * 11 exit face mismatch, 12 step limit (8: unused since round 2).
+ * 11 exit face mismatch, 12 step limit, 8 fold guard: a tet whose neighbourhood holds a tet thinner than 32 rounding
+ * distances AND one of whose edges passes within 8 rounding distances of the ray (csrc/tn_trace_walk.hip header).
  * Reason 7 rays keep their logged hits, which go through the literal sort + pairing (reasons[13] counts them);
  * all others are re-traced through the BVH all-hits path.  With option "verify_stride": reasons[15] = certified rays
  * cross-checked against a count-only BVH traversal, reasons[14] = those whose face count differed from the walk's

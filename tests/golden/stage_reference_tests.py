@@ -9,6 +9,7 @@ they can be run UNMODIFIED on top of libtetranerf_hip.so on a GPU box (where /ro
     tests/golden/ref/tests/{test_uint32,test_barycentrics,test_tetrahedra_tracer,test_tetrahedra_tracer_triangles}.py
     tests/golden/ref/tests/assets/bottle.ply
     tests/golden/ref/trimesh.py                                  <- 20-line stand-in for `trimesh.load` (not installed here)
+    tests/golden/ref/LICENSE                                     <- the reference's MIT licence (required to accompany copies)
 
 The staged reference files are verbatim copies: TEST INFRASTRUCTURE (fixtures), never imported by the product.
 tests/test_reference_suite_gpu.py runs them with pytest in a subprocess.  Re-run this script to refresh them:
@@ -22,6 +23,7 @@ REF = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
 OUT = Path(__file__).resolve().parent / "ref"
 
 COPIES = [
+    "LICENSE",                      # the reference is MIT-licensed: its copyright + permission notice accompanies the copies
     "tetranerf/__init__.py",
     "tetranerf/utils/__init__.py",
     "tetranerf/utils/extension/__init__.py",

@@ -84,11 +84,29 @@ int main(int argc, char **argv) {
     std::vector<uint32_t> order(T), rec_of_tet(T);
     for (size_t r = 0; r < T; ++r) { order[r] = keyed[r].second; rec_of_tet[keyed[r].second] = (uint32_t)r; }
     CHECK(rec_of_tet == rec_of_tet_host);
-    for (size_t i = 0; i < n4; ++i) {
-        const WalkVar v = core::walk_var_of((uint32_t)(i >> 2), (uint32_t)(i & 3), order.data(), rec_of_tet.data(), cells.data(), xyz.data(),
-                                            tet_face.data(), faces.data(), face_tets.data(), &flags);
-        CHECK(std::memcmp(&v, &vars_host[i], sizeof(WalkVar)) == 0);
+    // (k_walk_vars, then k_tet_thin / k_thin_patch: star minima in a shuffled order -- the atomic minimum commutes)
+    std::vector<WalkVar> vars_dev(n4);
+    for (size_t i = 0; i < n4; ++i)
+        vars_dev[i] = core::walk_var_of((uint32_t)(i >> 2), (uint32_t)(i & 3), order.data(), rec_of_tet.data(), cells.data(), xyz.data(),
+                                        tet_face.data(), faces.data(), face_tets.data(), &flags);
+    {
+        size_t V = 0;
+        for (uint32_t c : cells) V = std::max<size_t>(V, c + 1);
+        std::vector<uint32_t> vmin(V, 0x7F800000u);
+        for (size_t k = T; k-- > 0;) {
+            const uint32_t *c = cells.data() + 4 * k;
+            float p[4][3];
+            for (int q = 0; q < 4; ++q) for (int a = 0; a < 3; ++a) p[q][a] = xyz[3 * (size_t)c[q] + a];
+            const uint32_t bits = core::tet_min_height_bits(p);
+            for (int q = 0; q < 4; ++q) core::atomic_min_u32(&vmin[c[q]], bits);
+        }
+        for (size_t k = 0; k < T; ++k) {
+            const uint32_t *c = cells.data() + 4 * k;
+            const uint32_t e = core::thin_exponent(vmin[c[0]], vmin[c[1]], vmin[c[2]], vmin[c[3]]);
+            for (uint32_t q = 0; q < 4; ++q) vars_dev[4 * (size_t)rec_of_tet[k] + q].code_hi |= e << core::THIN_SHIFT;
+        }
     }
+    for (size_t i = 0; i < n4; ++i) CHECK(std::memcmp(&vars_dev[i], &vars_host[i], sizeof(WalkVar)) == 0);
     CHECK(!(flags & core::FLAG_INTERNAL));
 
     // hull tree

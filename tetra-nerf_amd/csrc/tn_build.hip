@@ -153,6 +153,30 @@ __global__ __launch_bounds__(BT) void k_walk_vars(size_t n4, const uint32_t *__r
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
 }
 
+// thin-neighbourhood exponent of every tet (tn_build_core.h): star minima of the smallest tet height, then the patch of
+// the four walk records of the tet
+__global__ __launch_bounds__(BT) void k_fill_u32(size_t n, uint32_t *p, uint32_t v) {
+    const size_t i = gid();
+    if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(BT) void k_tet_thin(size_t T, const uint32_t *__restrict__ cells, const float *__restrict__ xyz, uint32_t *vmin) {
+    const size_t i = gid();
+    if (i >= T) return;
+    const uint32_t *c = cells + 4 * i;
+    float p[4][3];
+    for (int k = 0; k < 4; ++k) for (int a = 0; a < 3; ++a) p[k][a] = xyz[3 * (size_t)c[k] + a];
+    const uint32_t bits = core::tet_min_height_bits(p);
+    for (int k = 0; k < 4; ++k) core::atomic_min_u32(vmin + c[k], bits);
+}
+__global__ __launch_bounds__(BT) void k_thin_patch(size_t T, const uint32_t *__restrict__ cells, const uint32_t *__restrict__ vmin,
+                                                   const uint32_t *__restrict__ rec_of_tet, WalkVar *vars) {
+    const size_t i = gid();
+    if (i >= T) return;
+    const uint32_t *c = cells + 4 * i;
+    const uint32_t e = core::thin_exponent(vmin[c[0]], vmin[c[1]], vmin[c[2]], vmin[c[3]]);
+    for (uint32_t k = 0; k < 4; ++k) vars[4 * (size_t)rec_of_tet[i] + k].code_hi |= e << core::THIN_SHIFT;
+}
+
 // ------------------------------------------------------------------ face BVH
 __global__ __launch_bounds__(BT) void k_face_boxes(size_t F, const uint32_t *__restrict__ faces, const float *__restrict__ xyz, float *fb, float *cen) {
     const size_t f = gid();
@@ -371,6 +395,14 @@ void device_build(size_t V, size_t T, const float *xyz, const uint32_t *cells, h
     out.vars.alloc(n4);
     hipLaunchKernelGGL(k_walk_vars, dim3(grid_for(n4)), dim3(BT), 0, s, n4, order.p, rec_of_tet.p, cells, xyz, tet_face.p,
                        out.faces.p, out.face_tets.p, out.vars.p, flags.p);
+    {
+        DevBuf<uint32_t> vmin;
+        vmin.alloc(V);
+        hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(V)), dim3(BT), 0, s, V, vmin.p, 0x7F800000u);   // +inf
+        hipLaunchKernelGGL(k_tet_thin, dim3(grid_for(T)), dim3(BT), 0, s, T, cells, xyz, vmin.p);
+        hipLaunchKernelGGL(k_thin_patch, dim3(grid_for(T)), dim3(BT), 0, s, T, cells, vmin.p, rec_of_tet.p, out.vars.p);
+        TN_HIP(hipStreamSynchronize(s));   // vmin is freed at the end of this scope
+    }
 
     // ------------------------------------------------------------ hull tree (host threading of the downloaded faces)
     std::vector<float> hinfo(n_hull * 12);

@@ -315,6 +315,58 @@ TN_HD WalkVar walk_var_of(uint32_t r, uint32_t e, const uint32_t *order, const u
     for (int a = 0; a < 3; ++a) pn[a] = xyz[3 * (size_t)adj.vert[e] + a];
     return make_walk_var(adj, nbr_rec, pn, i, e);
 }
+// ---------------------------------------------------------------------------------------------------------
+// "Thin neighbourhood" of a tetrahedron (the walk's certification rule 8, tn_trace_walk.hip): the rounded projection
+// of the mesh along a ray can FOLD only where a tetrahedron is thin enough for the rounding of its projected vertices to
+// invert it (its smallest height comparable to the rounding distance).  Per tet: h = its smallest height; per vertex:
+// the minimum of h over the vertex's star; per tet again: the SECOND smallest of its four vertex minima = a lower
+// bound of min h over the tets around its most suspicious edge (the ring of edge (a,b) lies in star(a) and star(b)).
+// Stored as the float's exponent byte (floor(log2) + 127) in bits 8..15 of WalkVar::code_hi; 0 = degenerate.
+TN_HD uint32_t tet_min_height_bits(const float p[4][3]) {
+    double q[4][3];
+    for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) q[i][a] = (double)p[i][a];
+    auto cross = [](const double *u, const double *v, double *w) {
+        w[0] = u[1] * v[2] - u[2] * v[1]; w[1] = u[2] * v[0] - u[0] * v[2]; w[2] = u[0] * v[1] - u[1] * v[0];
+    };
+    double e1[3], e2[3], e3[3], n[3];
+    for (int a = 0; a < 3; ++a) { e1[a] = q[1][a] - q[0][a]; e2[a] = q[2][a] - q[0][a]; e3[a] = q[3][a] - q[0][a]; }
+    cross(e1, e2, n);
+    const double vol6 = fabs(n[0] * e3[0] + n[1] * e3[1] + n[2] * e3[2]);
+    double hmin = 1e300;
+    const int f[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};
+    for (int k = 0; k < 4; ++k) {
+        double u[3], v[3], w[3];
+        for (int a = 0; a < 3; ++a) { u[a] = q[f[k][1]][a] - q[f[k][0]][a]; v[a] = q[f[k][2]][a] - q[f[k][0]][a]; }
+        cross(u, v, w);
+        const double area2 = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        const double h = area2 > 0.0 ? vol6 / area2 : 0.0;
+        hmin = h < hmin ? h : hmin;
+    }
+    const float hf = (float)hmin;
+    uint32_t bits;
+#if defined(__HIP_DEVICE_COMPILE__)
+    bits = __float_as_uint(hf);
+#else
+    std::memcpy(&bits, &hf, 4);
+#endif
+    return bits;   // non-negative floats order like their bit patterns
+}
+TN_HD void atomic_min_u32(uint32_t *p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
+#endif
+}
+// exponent byte of the second smallest of the four star minima
+TN_HD uint32_t thin_exponent(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t m3) {
+    uint32_t lo = m0 < m1 ? m0 : m1, hi = m0 < m1 ? m1 : m0;   // smallest, second smallest so far
+    if (m2 < lo) { hi = lo; lo = m2; } else if (m2 < hi) hi = m2;
+    if (m3 < lo) { hi = lo; lo = m3; } else if (m3 < hi) hi = m3;
+    return (hi >> 23) & 0xFFu;
+}
+constexpr uint32_t THIN_SHIFT = 8;   // bits 8..15 of WalkVar::code_hi (bits 0..3: the code word's top bits)
+
 // the 12 floats the hull tree build wants per hull face (tn_mesh.cpp: build_hull_from_info): v0.xyz, face id |
 // v1.xyz, tet record | v2.xyz, local face
 TN_HD void hull_face_info(uint32_t fid, const uint32_t *faces, const uint32_t *face_tets, const uint32_t *tet_face,

@@ -353,6 +353,19 @@ void build_walk_variants(const std::vector<TetRec> &recs, std::vector<WalkVar> &
         }
         for (uint32_t e = 0; e < 4; ++e) out[4 * r + e] = core::make_walk_var(adj, t.nbr, t.pos[e], t.orig, e);
     }
+    // thin-neighbourhood exponent (tn_build_core.h): star minima of the smallest tet height, second smallest per tet
+    uint32_t V = 0;
+    for (const TetRec &t : recs) for (int k = 0; k < 4; ++k) V = std::max(V, t.vert[k] + 1);
+    std::vector<uint32_t> vmin(V, 0x7F800000u);
+    for (const TetRec &t : recs) {
+        const uint32_t bits = core::tet_min_height_bits(t.pos);
+        for (int k = 0; k < 4; ++k) core::atomic_min_u32(&vmin[t.vert[k]], bits);
+    }
+    for (size_t r = 0; r < T; ++r) {
+        const TetRec &t = recs[r];
+        const uint32_t e = core::thin_exponent(vmin[t.vert[0]], vmin[t.vert[1]], vmin[t.vert[2]], vmin[t.vert[3]]);
+        for (uint32_t k = 0; k < 4; ++k) out[4 * r + k].code_hi |= e << core::THIN_SHIFT;
+    }
 }
 
 void build_hull_threaded(const float *xyz, const uint32_t *faces, const uint32_t *face_tets,

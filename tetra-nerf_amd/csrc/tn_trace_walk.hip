@@ -46,11 +46,23 @@
 //               face): the hits of the log go through the literal sort + pairing (k_postprocess_log,
 //               tn_trace_general.hip).
 //   fallback    anything else -> re-traced by the BVH all-hits kernel.
-// The chain is the connected component of the hull faces in the set of crossed faces.  The rounded
-// projection can contain further components -- e.g. the star of a vertex whose rounded projection
-// lands exactly on the ray while the chain passes through the star of its 1e-7 twin
-// (near_duplicates mesh, vertex-to-vertex rays) -- which no local walk can see; the
-// vertex-proximity rule above is what catches the cases found so far (reason 4).
+// The chain is the connected component of the hull faces in the set of crossed faces.  Every tet has 0 or 2 crossed
+// faces for ANY rounded 2-D vertex positions (its boundary is a closed surface; edge functions are shared, so faces
+// agree on every edge), hence the crossed faces form the chain plus, possibly, closed CYCLES the walk cannot see.  The
+// rounded positions are the exact projections of a mesh whose vertices moved by at most delta = 7 * 2^-24 * (|o| +
+// scene) perpendicular to the ray; ray casting through a properly embedded mesh yields one chain and no cycle, so a
+// cycle needs a tet that the perturbation can INVERT: one whose smallest height is of the order of delta (a tet of
+// height h loses at most a fraction 4 delta / h of its volume).  Round 3's aimed fuzzer (profiles/r03_hole_fuzz.py)
+// produced such cycles -- 1.4e-5 of the rays aimed at edges and faces of meshes with vertex twins 1e-8..1e-6 apart and
+// of a lattice jittered by 1e-7; never on a well-shaped mesh -- and every one of them passed within 0.13 delta of a mesh
+// edge while all its vertices were far away (profiles/r03e_hole_analyse.txt): the needle faces between two nearly
+// coincident long edges flip under the rounding, and the tets they bound are NOT on the chain, they only share the
+// near edge with it.  Rule 8 therefore combines a mesh-side and a ray-side condition: the record of every tet
+// carries (as an exponent byte) the second smallest of its vertices' star minima of the tet height -- a lower bound
+// of the thinnest tet around its most suspicious edge (tn_build_core.h) -- and a ray leaves the walk when it passes
+// within 8 delta of an edge of a tet whose value is below 32 delta.  Rule 4 (a vertex within the box padding = 4.6
+// delta... 45 delta in L1 of the sheared plane) stays.  The count-only BVH cross-check (option verify_stride) and the
+// fuzzer are the evidence that nothing is left: see DESIGN.md section 2.
 //
 // Memory behaviour: the walk does NOT touch the output rows.  Rows are 26 KB apart, so anything a lane stores
 // into its own row is a scattered partial-line write (round 1: 1.52x write amplification, the stores were the
@@ -168,6 +180,13 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     // tests its own ray.  No stack: the tree has a fixed depth (<= 3 internal levels).
     // rounding distance of a projected vertex: the box padding of the BVH path (tn_device.h: line_box)
     const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.scene_max);
+    // Rule 8 (fold guard, see the header): delta = 7 * 2^-24 * (|o| + scene) bounds the error of a sheared 2-D vertex
+    // position; a tet whose neighbourhood holds a tet thinner than 32 delta (exponent compare, conservative) AND one
+    // of whose edges passes within 8 delta of the ray sends the ray to the BVH path.
+    const float delta = 0.21875f * pad;               // 7/32 of the box padding
+    const float kappa = 8.0f * delta;
+    const uint32_t thin_exp = (__float_as_uint(32.0f * delta) >> 23) & 0xFFu;
+    auto near_edge = [&](float e, const SV &X, const SV &Y) { return fabsf(e) <= kappa * (fabsf(X.x - Y.x) + fabsf(X.y - Y.y)); };
     uint32_t nhull = 0;
     uint32_t hf0 = TN_EMPTY, hf1 = TN_EMPTY, hc0 = 0, hc1 = 0, he0 = 0, he1 = 0, hs0 = 0, hs1 = 0;
     float ht0 = 0.f, ht1 = 0.f;
@@ -244,6 +263,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     uint32_t nhits = 0, nshort = 0;
     uint32_t steps = 0;
     Var cur = load_var(p.vars, c);
+    if (alive && ((cur.code_hi >> 8) & 0xFFu) <= thin_exp &&
+        (near_edge(Uc, B, C) || near_edge(Vc, C, A) || near_edge(Wc, A, B))) { flag = true; why = 8; alive = false; }
     if (alive) {
         // the entry hull face itself may be the first recorded hit (exit code 3 = "hull face id in the low bits")
         float tt, uu, vv;
@@ -261,6 +282,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         const float ea = edge_f(P, A), eb = edge_f(P, B), ec = edge_f(P, C);
         bad = (fabsf(P.x) + fabsf(P.y) < pad) ? 4u : bad;                  // vertex within rounding distance of the ray
         bad = (!bad && (ea == 0.0f || eb == 0.0f || ec == 0.0f)) ? 5u : bad;
+        // fold guard: a thin neighbourhood and one of the tet's NEW edges (n-a, n-b, n-c; the others were new edges of
+        // a tet visited earlier, which carries the same flag when both end points of the edge have thin stars)
+        const bool thin = ((cur.code_hi >> 8) & 0xFFu) <= thin_exp;
+        bad = (!bad && thin && (near_edge(ea, P, A) || near_edge(eb, P, B) || near_edge(ec, P, C))) ? 8u : bad;
         // exit candidates: the faces opposite a {n,b,c}, b {n,c,a}, c {n,a,b}; a face is crossed iff its three
         // cyclic edge functions agree in sign: E(n,b), E(b,c) = Uc, E(c,n) = -ec, and cyclically
         const bool sa = ea > 0.0f, sb = eb > 0.0f, sc = ec > 0.0f;

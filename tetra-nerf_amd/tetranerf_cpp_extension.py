@@ -21,10 +21,29 @@ nothing imports oracle/.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib
+
+
+_POISON = os.environ.get("TETRANERF_HIP_POISON", "") not in ("", "0")
+
+
+def _empty(*shape, dtype=torch.float32, device=None):
+    """torch.empty for outputs and scratch (every kernel writes each byte it owns).  TETRANERF_HIP_POISON=1 (tests,
+    debugging) pre-fills them with NaN / 0x7f7f7f7f so that a byte a kernel failed to write, or read before writing,
+    shows up instead of inheriting whatever the allocator's block held."""
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    if _POISON and t.numel():
+        if t.dtype.is_floating_point:
+            t.fill_(float("nan"))
+        elif t.dtype == torch.bool:
+            t.fill_(True)
+        else:
+            t.fill_(0x7F7F7F7F if t.dtype in (torch.int32, torch.int64) else 0x7F)
+    return t
 
 
 def _check(cond, msg):
@@ -110,11 +129,11 @@ class TetrahedraTracer:
             R = ray_origins.numel() // 3
             _check(ray_directions.numel() // 3 == R, "ray_origins and ray_directions must have the same number of rays")
             dev = self._device
-            num_visited_cells = torch.empty((R,), dtype=torch.int32, device=dev)
-            visited_cells = torch.empty((R, M), dtype=torch.int32, device=dev)
-            barycentric_coordinates = torch.empty((R, M, 2, 3), dtype=torch.float32, device=dev)
-            hit_distances = torch.empty((R, M, 2), dtype=torch.float32, device=dev)
-            vertex_indices = torch.empty((R, M, 4), dtype=torch.int32, device=dev)
+            num_visited_cells = _empty((R,), dtype=torch.int32, device=dev)
+            visited_cells = _empty((R, M), dtype=torch.int32, device=dev)
+            barycentric_coordinates = _empty((R, M, 2, 3), dtype=torch.float32, device=dev)
+            hit_distances = _empty((R, M, 2), dtype=torch.float32, device=dev)
+            vertex_indices = _empty((R, M, 4), dtype=torch.int32, device=dev)
             _lib.check(self._lib.tn_trace_rays(
                 self._h, R, M, _ptr(ray_origins), _ptr(ray_directions), _ptr(num_visited_cells),
                 _ptr(visited_cells), _ptr(barycentric_coordinates), _ptr(hit_distances),
@@ -138,11 +157,11 @@ class TetrahedraTracer:
             R = ray_origins.numel() // 3
             _check(ray_directions.numel() // 3 == R, "ray_origins and ray_directions must have the same number of rays")
             dev = self._device
-            num = torch.empty((R,), dtype=torch.int32, device=dev)
-            vis = torch.empty((R, M), dtype=torch.int32, device=dev)
-            bary = torch.empty((R, M, 2), dtype=torch.float32, device=dev)
-            dist = torch.empty((R, M), dtype=torch.float32, device=dev)
-            verts = torch.empty((R, M, 3), dtype=torch.int32, device=dev)
+            num = _empty((R,), dtype=torch.int32, device=dev)
+            vis = _empty((R, M), dtype=torch.int32, device=dev)
+            bary = _empty((R, M, 2), dtype=torch.float32, device=dev)
+            dist = _empty((R, M), dtype=torch.float32, device=dev)
+            verts = _empty((R, M, 3), dtype=torch.int32, device=dev)
             _lib.check(self._lib.tn_trace_rays_triangles(self._h, R, M, _ptr(ray_origins), _ptr(ray_directions), _ptr(num),
                                                          _ptr(vis), _ptr(bary), _ptr(dist), _ptr(verts), _stream(dev)))
         return {"num_visited_triangles": num, "visited_triangles": vis, "barycentric_coordinates": bary,
@@ -155,9 +174,9 @@ class TetrahedraTracer:
             shape = tuple(positions.shape[:-1])
             N = positions.numel() // 3
             dev = self._device
-            bary = torch.empty(shape + (3,), dtype=torch.float32, device=dev)
-            verts = torch.empty(shape + (4,), dtype=torch.int32, device=dev)
-            tets = torch.empty(shape, dtype=torch.int32, device=dev)
+            bary = _empty(shape + (3,), dtype=torch.float32, device=dev)
+            verts = _empty(shape + (4,), dtype=torch.int32, device=dev)
+            tets = _empty(shape, dtype=torch.int32, device=dev)
             _lib.check(self._lib.tn_find_tetrahedra(self._h, N, _ptr(positions), _ptr(tets), _ptr(bary), _ptr(verts),
                                                     _stream(dev)))
         return {"tetrahedra": tets, "barycentric_coordinates": bary, "vertex_indices": verts, "valid_mask": tets != -1}
@@ -190,10 +209,10 @@ class TetrahedraTracer:
         S = distances.size(-1)
         M = visited_cells.size(1)
         dev = self._device
-        mask = torch.empty((R, S), dtype=torch.bool, device=dev)
-        matched_cells = torch.empty((R, S), dtype=torch.int32, device=dev)
-        barycentric_coordinates_out = torch.empty((R, S, 3), dtype=torch.float32, device=dev)
-        vertex_indices_out = torch.empty((R, S, 4), dtype=torch.int32, device=dev)
+        mask = _empty((R, S), dtype=torch.bool, device=dev)
+        matched_cells = _empty((R, S), dtype=torch.int32, device=dev)
+        barycentric_coordinates_out = _empty((R, S, 3), dtype=torch.float32, device=dev)
+        vertex_indices_out = _empty((R, S, 4), dtype=torch.int32, device=dev)
         # the C entry points take no device argument: launch with the tracer's device current (its stream, its pointers)
         with torch.cuda.device(dev):
             if ray_index is None:
@@ -236,8 +255,8 @@ class TetrahedraTracer:
     def face_tables(self):
         """(faces [F,3], face_tets [F,2]) int64 CPU tensors of the loaded mesh (debug aid)."""
         F = self._lib.tn_num_faces(self._h)
-        faces = torch.empty((F, 3), dtype=torch.int32)
-        ft = torch.empty((F, 2), dtype=torch.int32)
+        faces = _empty((F, 3), dtype=torch.int32)
+        ft = _empty((F, 2), dtype=torch.int32)
         _lib.check(self._lib.tn_get_faces(self._h, _ptr(faces), _ptr(ft)))
         return faces, ft
 
@@ -245,7 +264,7 @@ class TetrahedraTracer:
         """One of the structures load_tetrahedra built, as a uint8 CPU tensor (test aid; see tn_get_build_table)."""
         n = C.c_size_t(0)
         _lib.check(self._lib.tn_get_build_table(self._h, int(which), None, C.byref(n)))
-        out = torch.empty((n.value,), dtype=torch.uint8)
+        out = _empty((n.value,), dtype=torch.uint8)
         if n.value:
             _lib.check(self._lib.tn_get_build_table(self._h, int(which), _ptr(out), C.byref(n)))
         return out
@@ -256,11 +275,11 @@ class TetrahedraTracer:
         R, M = hit_ids.shape
         dev = self._device
         out = {
-            "num_visited_cells": torch.empty((R,), dtype=torch.int32, device=dev),
-            "visited_cells": torch.empty((R, M), dtype=torch.int32, device=dev),
-            "barycentric_coordinates": torch.empty((R, M, 2, 3), dtype=torch.float32, device=dev),
-            "hit_distances": torch.empty((R, M, 2), dtype=torch.float32, device=dev),
-            "vertex_indices": torch.empty((R, M, 4), dtype=torch.int32, device=dev),
+            "num_visited_cells": _empty((R,), dtype=torch.int32, device=dev),
+            "visited_cells": _empty((R, M), dtype=torch.int32, device=dev),
+            "barycentric_coordinates": _empty((R, M, 2, 3), dtype=torch.float32, device=dev),
+            "hit_distances": _empty((R, M, 2), dtype=torch.float32, device=dev),
+            "vertex_indices": _empty((R, M, 4), dtype=torch.int32, device=dev),
         }
         if faces is not None:
             _check(face_tets is not None and faces.dtype == torch.int32 and face_tets.dtype == torch.int32
@@ -318,7 +337,7 @@ def invalidate_field_cache(field=None):
 
 def _transpose_field(field):
     Fd, V = field.shape
-    ft = torch.empty((V, Fd), dtype=torch.float32, device=field.device)
+    ft = _empty((V, Fd), dtype=torch.float32, device=field.device)
     with torch.cuda.device(field.device):
         _lib.check(_lib.load().tn_transpose_f32(Fd, V, _ptr(field), _ptr(ft), _stream(field.device)))
     return ft
@@ -361,7 +380,7 @@ def interpolate_values(vertex_indices, barycentric_coordinates, field):
     _check(D in (2, 3, 4, 6), f"Unsupported interpolation dimension with value {D}")
     n = vertex_indices.numel() // D
     Fd = field.size(0)
-    result = torch.empty((Fd,) + tuple(vertex_indices.shape[:-1]), dtype=field.dtype, device=field.device)
+    result = _empty((Fd,) + tuple(vertex_indices.shape[:-1]), dtype=field.dtype, device=field.device)
     ft = field_vertex_major(field)
     with torch.cuda.device(field.device):
         _lib.check(_lib.load().tn_interpolate_values_vm(
@@ -385,7 +404,7 @@ def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, 
     n = vertex_indices.numel() // D
     Fd, V = field.size(0), field.size(-1)
     _check(grad_in.size(-1) == Fd, "grad_in must have shape [..., field_dim]")
-    grad_field_out = torch.empty((Fd, V), dtype=grad_in.dtype, device=grad_in.device)
+    grad_field_out = _empty((Fd, V), dtype=grad_in.dtype, device=grad_in.device)
     lib = _lib.load()
     if grad_in.moveaxis(-1, 0).is_contiguous() and Fd > 1:
         # the reference's layout: a [Fd, n] buffer viewed as [..., Fd] (what py_binding.cpp:369 produces)
@@ -514,8 +533,8 @@ def mlp_forward(feats_fm, dirs, weights, samples_per_ray, mode="fp32"):
     _check(dirs.dtype == torch.float32 and tuple(dirs.shape) == (n // S, 3), "dirs must be f32 [n/samples_per_ray, 3]")
     m = fused_mlp(weights)
     dev = feats_fm.device
-    sigma = torch.empty((n,), dtype=torch.float32, device=dev)
-    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    sigma = _empty((n,), dtype=torch.float32, device=dev)
+    rgb = _empty((n, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.load().tn_mlp_forward(m.handle, n, S, _ptr(feats_fm), _ptr(dirs), _mode(mode), _ptr(sigma), _ptr(rgb),
                                               _stream(dev)))
@@ -543,8 +562,8 @@ def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, wei
     m = fused_mlp(weights)
     dev = field.device
     field_vm = field_vertex_major(field)
-    sigma = torch.empty((n,), dtype=torch.float32, device=dev)
-    rgb = None if density_only else torch.empty((n, 3), dtype=torch.float32, device=dev)
+    sigma = _empty((n,), dtype=torch.float32, device=dev)
+    rgb = None if density_only else _empty((n, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.load().tn_mlp_forward_gather(m.handle, n, S, _ptr(vertex_indices), _ptr(barycentric_coordinates),
                                                      _ptr(field_vm), _ptr(dirs), _mode(mode), _ptr(sigma), _ptr(rgb),
@@ -578,7 +597,7 @@ def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, b
     lib = _lib.load()
     with torch.cuda.device(dev):
         if density_only:
-            w_out = torch.empty((r, S), dtype=torch.float32, device=dev)
+            w_out = _empty((r, S), dtype=torch.float32, device=dev)
             _lib.check(lib.tn_render_pass(m.handle, M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S,
                                           _ptr(edges), _ptr(field_vm), None, float(background), _ptr(w_out), None, None, None,
                                           _stream(dev)))
@@ -627,8 +646,8 @@ def sample_coarse(num_visited_cells, hit_distances, ray_index, num_samples, bias
     if t_rand is not None:
         _check_input(t_rand, "t_rand")
         _check(t_rand.dtype == torch.float32 and tuple(t_rand.shape) == (r, S + 1), "t_rand must be f32 [r, S+1]")
-    edges = torch.empty((r, S + 1), dtype=torch.float32, device=dev)
-    near_far = torch.empty((r, 2), dtype=torch.float32, device=dev)
+    edges = _empty((r, S + 1), dtype=torch.float32, device=dev)
+    near_far = _empty((r, 2), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.load().tn_sample_coarse(r, S, M, _ptr(ray_index), _ptr(num_visited_cells), _ptr(hit_distances),
                                                 _ptr(_linspace_table(S, dev)), _ptr(t_rand), 1 if biased else 0, _ptr(edges),
@@ -650,7 +669,7 @@ def sample_pdf(edges, weights, near_far, num_fine, u_rand=None, histogram_paddin
     if u_rand is not None:
         _check_input(u_rand, "u_rand")
         _check(u_rand.dtype == torch.float32 and tuple(u_rand.shape) == (r, nb), "u_rand must be f32 [r, num_fine+1]")
-    out = torch.empty((r, S + 1 + nb), dtype=torch.float32, device=dev)
+    out = _empty((r, S + 1 + nb), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.load().tn_sample_pdf(r, S, int(num_fine), _ptr(edges), _ptr(weights), _ptr(near_far),
                                              _ptr(_quantile_table(nb, u_rand is None, dev)), _ptr(u_rand), float(histogram_padding),
@@ -669,15 +688,15 @@ def composite(sigma, rgb, edges, background=1.0, return_weights=False):
     _check((rgb is None or tuple(rgb.shape) == (R, S, 3)) and tuple(edges.shape) == (R, S + 1), "shape mismatch")
     dev = sigma.device
     if rgb is None:
-        weights = torch.empty((R, S), dtype=torch.float32, device=dev)
+        weights = _empty((R, S), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), None, _ptr(edges), float(background), None, None, None,
                                                 _ptr(weights), _stream(dev)))
         return weights
-    out_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
-    acc = torch.empty((R, 1), dtype=torch.float32, device=dev)
-    depth = torch.empty((R, 1), dtype=torch.float32, device=dev)
-    weights = torch.empty((R, S), dtype=torch.float32, device=dev) if return_weights else None
+    out_rgb = _empty((R, 3), dtype=torch.float32, device=dev)
+    acc = _empty((R, 1), dtype=torch.float32, device=dev)
+    depth = _empty((R, 1), dtype=torch.float32, device=dev)
+    weights = _empty((R, S), dtype=torch.float32, device=dev) if return_weights else None
     with torch.cuda.device(dev):
         _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), _ptr(rgb), _ptr(edges), float(background), _ptr(out_rgb),
                                             _ptr(acc), _ptr(depth), _ptr(weights), _stream(dev)))
@@ -732,7 +751,7 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
             r1 = min(R, r0 + rays_per_chunk)
             m = (r1 - r0) * S
             c0 = r0 * S
-            buf = torch.empty((64 + 8 * 128 + 4 + 64, m), dtype=torch.float32, device=dev)
+            buf = _empty((64 + 8 * 128 + 4 + 64, m), dtype=torch.float32, device=dev)
             x0, h1, h2, h3, h4 = buf[0:64], buf[64:192], buf[192:320], buf[320:448], buf[448:576]
             d1, d2, d3, d4 = buf[576:704], buf[704:832], buf[832:960], buf[960:1088]
             dhead, dx0 = buf[1088:1092], buf[1092:1156]
@@ -743,14 +762,14 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
                                          (d4, h3, 128, gwh_base, gbh)):
                 _lib.check(lib.tn_mlp_weight_grad(m, rows_b, _ptr(a), _ptr(b), _ptr(gw), _ptr(gb), stream))
             # narrow heads + the direction-encoding columns of mlp_head: one bandwidth-bound pass over h3 / h4 / d4
-            ray_sum = torch.empty((128, r1 - r0), dtype=torch.float32, device=dev)
+            ray_sum = _empty((128, r1 - r0), dtype=torch.float32, device=dev)
             _lib.check(lib.tn_mlp_head_grad(m, S, _ptr(dhead), _ptr(h3), _ptr(h4), _ptr(d4), _ptr(head_out), _ptr(ray_sum), stream))
             gwh[:, :27] += ray_sum @ _direction_encoding(dirs[r0:r1])
             hsum = dhead.sum(1)
             gbd += hsum[0]
             gbr += hsum[1:4]
             # gradient of the gathered features -> field (vertex-major accumulation)
-            rows = torch.empty((m, 64), dtype=torch.float32, device=dev)
+            rows = _empty((m, 64), dtype=torch.float32, device=dev)
             _lib.check(lib.tn_transpose_f32(64, m, _ptr(dx0), _ptr(rows), stream))
             _lib.check(lib.tn_interpolate_values_backward_vm(4, m, 64, _ptr(vi[c0:]), _ptr(bc[c0:]), _ptr(rows), _ptr(grad_vm),
                                                              stream))
@@ -758,7 +777,7 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
         gwh[:, 27:] += gwh_base
         gwd += head_out[0:1]
         gwr += head_out[1:4]
-        grad_field = torch.empty((64, V), dtype=torch.float32, device=dev)
+        grad_field = _empty((64, V), dtype=torch.float32, device=dev)
         _lib.check(lib.tn_transpose_f32(V, 64, _ptr(grad_vm), _ptr(grad_field), stream))
     return grad_field, grads
 
@@ -767,8 +786,8 @@ def composite_backward(sigma, rgb, edges, d_out_rgb, d_out_acc, background=1.0):
     """Adjoint of composite() w.r.t. sigma [R,S] and rgb [R,S,3] (the median depth has no gradient)."""
     R, S = sigma.shape
     dev = sigma.device
-    d_sigma = torch.empty((R, S), dtype=torch.float32, device=dev)
-    d_rgb = torch.empty((R, S, 3), dtype=torch.float32, device=dev)
+    d_sigma = _empty((R, S), dtype=torch.float32, device=dev)
+    d_rgb = _empty((R, S, 3), dtype=torch.float32, device=dev)
     g_rgb = None if d_out_rgb is None else d_out_rgb.contiguous().float()
     g_acc = None if d_out_acc is None else d_out_acc.contiguous().float()
     with torch.cuda.device(dev):
@@ -815,7 +834,7 @@ def gather_uint32(self, dim, index):
     _check(index.dim() == self.dim(), "self and index must have the same number of dimensions")
     _check(dim == 0, "dim must be 0")
     _check(self.dtype in (torch.float32, torch.float64), "self must be float32 or float64")
-    result = torch.empty(index.shape, dtype=self.dtype, device=self.device)
+    result = _empty(index.shape, dtype=self.dtype, device=self.device)
     with torch.cuda.device(self.device):
         _lib.check(_lib.load().tn_gather_uint32(self.element_size(), self.numel(), index.numel(), _ptr(index), _ptr(self),
                                                 _ptr(result), _stream(self.device)))
