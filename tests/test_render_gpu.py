@@ -272,3 +272,44 @@ def test_render_pass_equals_unfused_kernels(tn, device, scenes, render, S):
     assert int(decided.sum()) > 100
     assert float(torch.isclose(depth[idx].reshape(-1), want_depth.reshape(-1), rtol=0, atol=1e-6).float().mean()) > 0.99
     torch.testing.assert_close(depth[idx].reshape(-1)[decided], want_depth.reshape(-1)[decided], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("scale_w,scale_x", [(1.0, 1.0), (1e-4, 1e4), (1e4, 1e-4), (1e-3, 1e-3), (30.0, 30.0)])
+def test_bf16x3_error_bound_per_layer(tn, device, render, scale_w, scale_x):
+    """Error bound of the split-operand mode (tn_mlp_forward mode 1: every fp32 operand = three bf16 pieces, six partial
+    products per multiply, fp32 accumulation) on ONE layer, against float64, over adversarial operand scales and
+    cancelling sums.  Layers 2 and 3 are the identity and the density head reads a single feature, so
+    softplus^-1(sigma) IS one output of layer 1: y_k = sum_i W1[k,i] x_i + b1[k].  Claim: |y - y64| <= 2^-21 * sum_i
+    |W1[k,i] x_i| (dropped split terms < 2^-24 per product, plus the fp32 accumulation of 64 terms) -- the same bound
+    the exact-fp32 MFMA mode meets; both modes are checked."""
+    import torch
+
+    torch.manual_seed(11)
+    n, S = 4096, 64
+    w1 = torch.randn(128, 64, dtype=torch.float64) * scale_w
+    x = torch.randn(n, 64, dtype=torch.float64) * scale_x
+    x[:, 1::2] = -x[:, 0::2] * (w1[0, 0::2] / w1[0, 1::2]) * (1 + 1e-3 * torch.randn(n, 32, dtype=torch.float64))   # row 0 cancels to 1e-3
+    x[::7] *= 1e-30 / scale_x            # denormal-range activations
+    b1 = torch.zeros(128, dtype=torch.float64)
+    shift = float((w1.abs() @ x.abs().t()).max()) * 1.5 + 1.0       # keeps every pre-activation positive through the ReLUs
+    b1 += shift
+    eye = torch.eye(128, dtype=torch.float64)
+    zeros = lambda *s: torch.zeros(*s, dtype=torch.float64)   # noqa: E731
+    for k in (0, 5, 127):
+        wd = zeros(1, 128); wd[0, k] = 1.0
+        ws = [w1, b1, eye, zeros(128), eye, zeros(128), wd, torch.tensor([-shift], dtype=torch.float64), zeros(128, 155), zeros(128), zeros(3, 128), zeros(3)]
+        w32 = [t.float().contiguous().to(device) for t in ws]
+        w64 = [t.double().cpu() for t in w32]                      # the fp32-representable weights, in float64
+        x32 = x.float().contiguous().to(device)
+        x64 = x32.double().cpu()
+        y64 = (x64 @ w64[0][k]) + w64[1][k] - float(w64[7][0].neg())  # = sum_i W x_i + b1 - shift
+        bound = 2.0 ** -21 * ((x64.abs() @ w64[0][k].abs()) + abs(float(w64[1][k])) + shift)
+        dirs = torch.nn.functional.normalize(torch.randn(n // S, 3), dim=-1).to(device)
+        for mode in ("fp32", "bf16x3"):
+            sigma, _ = tn.cpp.mlp_forward(x32.t().contiguous(), dirs, w32, S, mode=mode)
+            s = sigma.double().cpu()
+            y = torch.where(s > 20, s, torch.log(torch.expm1(s.clamp_min(1e-30))))      # softplus^-1
+            ok = s > 1e-3                                                                # (below: softplus^-1 is ill-conditioned)
+            err = (y - y64).abs()
+            assert int(ok.sum()) > n // 4
+            assert bool((err[ok] <= bound[ok] + 4e-7 * y64.abs()[ok]).all()), (mode, k, float((err[ok] / bound[ok]).max()))

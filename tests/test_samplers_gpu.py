@@ -48,7 +48,7 @@ def test_sample_coarse_matches_torch(tn, device, scenes, S, train, biased):
         assert torch.equal(edges, want)                       # same expression tree, no reduction involved
     scale = (far - near).abs() + far.abs()
     assert float(((edges - want).abs() / scale).max()) < 4e-7, float(((edges - want).abs() / scale).max())
-    assert bool((edges[:, 1:] >= edges[:, :-1]).all())
+    assert bool((edges[:, 1:] >= edges[:, :-1] - 1e-6 * far).all())
 
 
 @pytest.mark.parametrize("train", [False, True])
@@ -70,8 +70,9 @@ def test_sample_pdf_matches_torch(tn, device, scenes, S, S_fine, train):
     got = tn.cpp.sample_pdf(edges, w, nf, S_fine, u_rand=u_rand)
     spacing = (edges - near) / (far - near)
     want = render.pdf_sample_bins(spacing, w, S_fine, near, far, u_rand=u_rand)
-    assert got.shape == want.shape == (r, S + S_fine + 2)
-    assert bool((got[:, 1:] >= got[:, :-1]).all())
+    assert got.shape == want.shape == (r, S + S_fine + 2) and not bool(torch.isnan(got).any())
+    # (sorted in spacing; the euclidean map bins * far + (1 - bins) * near may invert neighbours by an ulp, in torch too)
+    assert bool((got[:, 1:] >= got[:, :-1] - 1e-6 * far).all())
     err = ((got - want).abs() / (far - near)).max(dim=1).values
     # the inverse CDF amplifies the rounding of the cdf by at most (bin width) * wsum / histogram_padding ~ 1.4
     assert float(err.max()) < 2e-5, float(err.max())

@@ -29,6 +29,23 @@ __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
     }
     return v;
 }
+// running maximum over an LDS array of n floats (wave-cooperative): makes a list that is sorted up to rounding
+// (an inversion of an ulp between neighbours) non-decreasing, so that the merge by rank below is a permutation
+__device__ __forceinline__ void lds_running_max(float *a, uint32_t n, int lane) {
+    float carry = -INFINITY;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t k = base + lane;
+        float v = k < n ? a[k] : -INFINITY;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float o = __shfl_up(v, off);
+            if (lane >= off) v = fmaxf(v, o);
+        }
+        v = fmaxf(v, carry);
+        if (k < n) a[k] = v;
+        carry = __shfl(v, 63);
+    }
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -154,7 +171,11 @@ __global__ __launch_bounds__(SB) void k_sample_pdf(size_t r, uint32_t S, uint32_
             nw[k] = b0 + t * (b1 - b0);
         }
         lds_sync();
-        // merge the two sorted lists by rank (coarse edges first on ties), map back to euclidean distances
+        // both lists are sorted up to rounding (the biased mapping and the inverse CDF are monotone functions evaluated
+        // in fp32): enforce it, then merge by rank (coarse edges first on ties) and map back to euclidean distances
+        lds_running_max(sp, S + 1, lane);
+        lds_running_max(nw, nb, lane);
+        lds_sync();
         float *o = out + q * (size_t)(S + 1 + nb);
         for (uint32_t j = lane; j <= S; j += 64) {
             const float v = sp[j];
