@@ -13,7 +13,7 @@ generator aims there:
 
 Every batch is traced three ways on the GPU and compared bit for bit (all five outputs, every tail byte):
   walk path (+ count-only BVH cross-check of every certified ray, option verify_stride = 1)  vs  BVH all-hits path;
-a slice of every batch is also compared with the CPU oracle.   python profiles/r03_hole_fuzz.py [million rays]"""
+a slice of every batch is also compared with the CPU oracle.   python profiles/r03_hole_fuzz.py [million rays] [verify_stride]"""
 import importlib, sys, time
 from pathlib import Path
 import numpy as np
@@ -24,6 +24,7 @@ from oracle import tn_oracle
 dev = torch.device("cuda:0")
 KEYS = ("num_visited_cells", "visited_cells", "vertex_indices", "hit_distances", "barycentric_coordinates")
 target_rays = int(float(sys.argv[1]) * 1e6) if len(sys.argv) > 1 else 50_000_000
+verify = int(sys.argv[2]) if len(sys.argv) > 2 else 1     # 0: the walk path as shipped (no count cross-check)
 
 
 import r03_hole_fuzz_lib as lib   # noqa: E402
@@ -35,7 +36,7 @@ while total < target_rays:
     for name, make in MESHES:
         pts, cells = make()
         x, c = torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev)
-        tw = tn.TetrahedraTracer(dev); tw.set_option("walk", 2); tw.set_option("verify_stride", 1); tw.load_tetrahedra(x, c)
+        tw = tn.TetrahedraTracer(dev); tw.set_option("walk", 2); tw.set_option("verify_stride", verify); tw.load_tetrahedra(x, c)
         tb = tn.TetrahedraTracer(dev); tb.set_option("walk", 0); tb.load_tetrahedra(x, c)
         ot = tn_oracle.OracleTracer(use_bvh=True); ot.load_tetrahedra(pts, cells)
         for kind in ("vertex", "edge", "face", "v2v"):
@@ -66,7 +67,7 @@ while total < target_rays:
         print(f"{name}: tets={len(cells)} total rays {total/1e6:.1f} M, {time.time()-t0:.0f} s, reasons so far {dict(sorted(reasons.items()))}", flush=True)
         del tw, tb
         if total >= target_rays: break
-print(f"hole fuzz: {batches} batches, {total} rays (walk + verify vs BVH, bitwise), {mism_rays} mismatching rays; "
+print(f"hole fuzz (verify_stride={verify}): {batches} batches, {total} rays (walk path vs BVH path, bitwise), {mism_rays} mismatching rays; "
       f"count-only cross-check: {reasons.get(15, 0)} certified rays verified, {reasons.get(14, 0)} count mismatches; "
       f"oracle slices: {oracle_rays} rays, {oracle_bad} mismatching batches; walk hand-over reasons {dict(sorted(reasons.items()))}; {time.time()-t0:.0f} s")
 sys.exit(1 if (mism_rays or oracle_bad) else 0)

@@ -197,6 +197,11 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         // conditional assignments the captured results end up in scratch memory behind computed pointers.
         const float det = (U + V) + W;
         if (!mixed && (U == 0.0f || V == 0.0f || W == 0.0f || det == 0.0f)) { flag = true; why = 1; }
+        // hull graze guard: the line passes within 8 delta of an edge of a hull face near it (crossed or not).  A ray
+        // that grazes the hull can have crossed faces in the rounded projection -- a closed cycle around the grazed
+        // edge / vertex -- although it crosses no hull face at all (nhull == 0: the walk would certify a miss); round 3's
+        // fuzzer found exactly these after rule 8 had removed the interior cycles (profiles/r03g_hole_classify.txt)
+        if (near_edge(U, B, C) || near_edge(V, C, A) || near_edge(W, A, B)) { flag = true; why = why ? why : 2u; }
         const float T = (U * A.z + V * B.z) + W * C.z;
         const float tt = T / det;
         const bool s0 = !mixed && nhull == 0, s1 = !mixed && nhull == 1;
