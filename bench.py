@@ -155,6 +155,7 @@ def trace_leg(tracer, o, d, M, reps):
         return k
     inter = int(run().sum())
     stats = tracer.trace_stats()
+    stats["reasons"] = {str(k): v for k, v in tracer.flag_reasons().items()}
     run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -374,6 +375,7 @@ def main():
     if args.warmup <= 0:
         inter = int(step().sum())
     stats = tracer.trace_stats()
+    reasons = {str(k): v for k, v in tracer.flag_reasons().items()}   # why the walk handed rays over (include/tetranerf_hip.h)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
@@ -432,6 +434,7 @@ def main():
                 "frac_of_measured_write_ceiling_5500": achieved / 5500.0,  # torch fill_ of 15 GB, profiles/r01_overlap_sweep.txt
             },
             "trace_path_stats": stats,
+            "walk_hand_over_reasons": reasons,
             "load_tetrahedra_s": load_s,
         }
         # secondary figure of SURVEY.md 8(d): the same launch without the constant tails of the dense
