@@ -290,3 +290,50 @@ def test_max_ray_triangles_above_512(tn, device, oracle, scenes, M, npts):
         for k in KEYS:
             assert np.array_equal(out[k].cpu().numpy().view(np.uint32), np.ascontiguousarray(want[k]).view(np.uint32)), f"M={M} walk={walk}: {k}"
         del out
+
+
+# ------------------------------------------------------------------------------------------------ certification hole
+@pytest.mark.parametrize("mesh", ["twins_1e-07", "twins_1e-06", "lattice_1e-7", "lattice_exact", "flat_hull_1e-6"])
+def test_aimed_rays_do_not_fall_into_the_certification_hole(tn, device, oracle, scenes, mesh):
+    """The walk sees one connected component of the crossed faces; closed CYCLES of crossed faces (folds of the rounded
+    projection around thin tets, grazing rays) are invisible to it.  Round 3's aimed fuzzer (profiles/r03_hole_fuzz.py:
+    rays through vertices / edge midpoints / face centroids +- ulps of meshes with vertex twins, slivers and flat hulls)
+    produced 1.4e-5 such rays before certification rules 8 (thin neighbourhood x near edge) and the hull graze guard; this
+    is its seeded sample: the walk path as shipped must equal the BVH all-hits path bit for bit, a slice must equal the
+    oracle, and the count-only BVH cross-check of every certified ray must never disagree."""
+    import sys
+    from pathlib import Path
+
+    import torch
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "profiles"))
+    import r03_hole_fuzz_lib as lib
+
+    lib.rng = np.random.default_rng(5)
+    pts, cells = dict(lib.MESHES)[mesh]()
+    ot = _oracle(oracle, pts, cells)
+    tw = _tracer(tn, device, pts, cells, walk=2)
+    tv = _tracer(tn, device, pts, cells, walk=2, verify_stride=1)
+    tb = _tracer(tn, device, pts, cells, walk=0)
+    M, n = 256, 150_000
+    handed, verified = {}, 0
+    for kind, k_ulp, origin in (("edge", 0, "far"), ("edge", 1, "near"), ("face", 0, "inside"), ("face", 1, "far"), ("vertex", 0, "far"),
+                                ("vertex", 2, "inside")):
+        o, d = lib.aimed_rays(pts, cells, n, kind, k_ulp, origin)
+        a, b = _trace(tw, device, o, d, M), _trace(tb, device, o, d, M)
+        for k, v in tw.flag_reasons().items():
+            handed[k] = handed.get(k, 0) + v
+        for k in KEYS:
+            assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), f"{mesh} {kind} ulp={k_ulp} {origin}: {k}"
+        c = _trace(tv, device, o, d, M)
+        why = tv.flag_reasons()
+        assert why.get(14, 0) == 0, (mesh, kind, origin, why)
+        verified += why.get(15, 0)
+        for k in KEYS:
+            assert torch.equal(a[k].view(torch.int32), c[k].view(torch.int32)), k
+        want = ot.trace_rays(o[:3000], d[:3000], M)
+        for k in KEYS:
+            assert np.array_equal(a[k][:3000].cpu().numpy().view(np.uint32), np.ascontiguousarray(want[k]).view(np.uint32)), k
+        del a, b, c
+    assert handed.get(8, 0) > 0 or handed.get(2, 0) > 0, handed      # the new rules do fire on these meshes
+    assert verified > 10_000, verified                               # ... and certified rays remain to be cross-checked
