@@ -43,7 +43,10 @@ struct tn_tracer {
     unsigned lds_cap = 0;                // 0: from the mesh size; otherwise the entries of the small arrays (power of two; tests)
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
     unsigned verify_stride = 0;          // > 0: every stride-th certified ray is cross-checked against a count-only BVH traversal
-    tn::DevBuf<tn::WalkVar> vars;
+    tn::DevBuf<tn::WalkVar> vars;        // the build's 64-byte records: split into the three tables below, then released
+    tn::DevBuf<tn::WalkHot> hot;
+    tn::DevBuf<tn::WalkCold> cold;
+    tn::DevBuf<tn::WalkFid> fidt;
     tn::DevBuf<float> hull_nodes, hull_tris;
     tn::DevWideBvh bvh;
     tn::DevBuf<unsigned long long> stats;   // [24] counters of the last call + [24..26) three uint32: fallback count,
@@ -225,7 +228,14 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         m.V = (uint32_t)V; m.T = (uint32_t)T; m.F = (uint32_t)F;
         m.faces = t->faces.p; m.face_tets = t->face_tets.p;
         m.bvh = t->bvh.view;
-        m.vars = t->vars.p; m.n_hull = (uint32_t)n_hull;
+        {   // de-interleave the records by consumer (tn_common.h: WalkHot / WalkCold / WalkFid)
+            const size_t n4 = t->vars.n;
+            t->hot.alloc(n4); t->cold.alloc(n4); t->fidt.alloc(n4);
+            tn::launch_split_walk_records(n4, t->vars.p, t->hot.p, t->cold.p, t->fidt.p, stream);
+            TN_HIP(hipStreamSynchronize(stream));
+            t->vars.release();
+        }
+        m.hot = t->hot.p; m.cold = t->cold.p; m.fidt = t->fidt.p; m.n_hull = (uint32_t)n_hull;
         m.hull_nodes = reinterpret_cast<const float4 *>(t->hull_nodes.p);
         m.hull_tris = reinterpret_cast<const float4 *>(t->hull_tris.p);
         m.n_hull_nodes = (uint32_t)n_hull_nodes;
@@ -267,7 +277,27 @@ int tn_get_build_table(tn_tracer_t tracer, int which, void *dst, size_t *bytes) 
         switch (which) {
             case 0: src = t->faces.p; n = t->faces.n * 4; break;
             case 1: src = t->face_tets.p; n = t->face_tets.n * 4; break;
-            case 2: src = t->vars.p; n = t->vars.n * sizeof(tn::WalkVar); break;
+            case 2: {   // the 64-byte records, re-assembled from the three tables (the unit of the build equality checks)
+                const size_t n4 = t->hot.n;
+                n = n4 * sizeof(tn::WalkVar);
+                if (bytes) *bytes = n;
+                if (dst && n4) {
+                    std::vector<tn::WalkHot> h(n4); std::vector<tn::WalkCold> c(n4); std::vector<tn::WalkFid> f(n4);
+                    TN_HIP(hipMemcpy(h.data(), t->hot.p, n4 * sizeof(tn::WalkHot), hipMemcpyDeviceToHost));
+                    TN_HIP(hipMemcpy(c.data(), t->cold.p, n4 * sizeof(tn::WalkCold), hipMemcpyDeviceToHost));
+                    TN_HIP(hipMemcpy(f.data(), t->fidt.p, n4 * sizeof(tn::WalkFid), hipMemcpyDeviceToHost));
+                    tn::WalkVar *o = static_cast<tn::WalkVar *>(dst);
+                    for (size_t i = 0; i < n4; ++i) {
+                        tn::WalkVar v{};
+                        for (int k = 0; k < 3; ++k) v.pn[k] = h[i].pn[k];
+                        v.nb[0] = h[i].nb0; v.nb[1] = h[i].nb1; v.nb[2] = h[i].nb2; v.code_lo = h[i].code_lo; v.code_hi = h[i].code_hi;
+                        v.orig = c[i].orig; for (int k = 0; k < 4; ++k) v.vid[k] = c[i].vid[k];
+                        v.fid0 = f[i].fid[0]; v.fid1 = f[i].fid[1]; v.fid2 = f[i].fid[2];
+                        o[i] = v;
+                    }
+                }
+                return;
+            }
             case 3: src = t->hull_nodes.p; n = t->hull_nodes.n * 4; break;
             case 4: src = t->hull_tris.p; n = t->hull_tris.n * 4; break;
             case 5: src = t->bvh.child.p; n = t->bvh.child.n * 4; break;
@@ -348,7 +378,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             auto launch_walk = [&](size_t base, size_t n) {
                 tn::WalkParams w{};
                 w.t = chunk_params(base, n);
-                w.vars = t->mesh.vars;
+                w.vars = t->mesh.hot;
                 w.scene_max = t->mesh.bvh.scene_max;
                 w.hull_nodes = t->mesh.hull_nodes;
                 w.hull_tris = t->mesh.hull_tris;
@@ -369,7 +399,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 q.num_rays = n; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
                 q.walk_n = t->walk_n.p + base;
                 q.hit_log = t->hit_log.p;
-                q.vars = t->mesh.vars;
+                q.vars = t->mesh.cold;
                 q.out_cells = visited + base * M;
                 q.out_bary = bary + base * M * 6;
                 q.out_dist = dist + base * M * 2;
@@ -383,7 +413,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             };
             auto launch_literal = [&](size_t base, size_t n, hipStream_t st) {
                 if (!t->literal) return;
-                tn::launch_postprocess_log(chunk_params(base, n), t->mesh.vars, t->hit_log.p, t->literal_list.p, t->literal_count(),
+                tn::launch_postprocess_log(chunk_params(base, n), t->mesh.fidt, t->hit_log.p, t->literal_list.p, t->literal_count(),
                                            n, st);
             };
             p.ray_list = t->fallback_list.p;

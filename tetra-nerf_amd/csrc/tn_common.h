@@ -115,6 +115,18 @@ struct alignas(64) WalkVar {
 };
 static_assert(sizeof(WalkVar) == 64, "WalkVar must be 64 bytes");
 
+// What the kernels read: the 64-byte record (the build's product; kept as the unit of the host / device / emulation
+// equality checks) is de-interleaved at the end of load_tetrahedra into three tables by consumer, so that each kernel's
+// random accesses fetch only bytes it uses (round 3: the walk read 48 and the segment writer 32 of every 64-byte record,
+// i.e. 37 % / 25 % of each 128-byte line; the tables are 2x / 2x / 4x smaller than the combined one for the XCD's 4 MiB L2):
+//   WalkHot  [4T] 32 B  walk:            position of n, the three neighbour variants, the 36-bit code + thin exponent
+//   WalkCold [4T] 32 B  segment writer:  vertex ids (n, a, b, c), the caller's tet id, the combine code of the 3 exits
+//   WalkFid  [4T] 16 B  literal pairing: face id of exit 0 / 1 / 2 (total order (t, face id) of the sort)
+struct alignas(32) WalkHot { float pn[3]; uint32_t nb0; uint32_t nb1, nb2, code_lo, code_hi; };
+struct alignas(32) WalkCold { uint32_t vid[4]; uint32_t orig, cmb, pad0, pad1; };   // cmb: per exit x 6 bits at 6x (c0 c1 c2)
+struct alignas(16) WalkFid { uint32_t fid[3]; uint32_t pad; };
+static_assert(sizeof(WalkHot) == 32 && sizeof(WalkCold) == 32 && sizeof(WalkFid) == 16, "split walk records");
+
 struct DeviceMesh {
     const float *xyz = nullptr;       // borrowed [V,3]
     const uint32_t *cells = nullptr;  // borrowed [T,4]
@@ -123,7 +135,9 @@ struct DeviceMesh {
     uint32_t *face_tets = nullptr;  // [F,2]
     WideBvh bvh{};                  // over all faces
     // adjacency walk
-    WalkVar *vars = nullptr;        // [4T] entry-face-specialised records of the walk
+    const WalkHot *hot = nullptr;   // [4T] entry-face-specialised records, split by consumer (see WalkHot)
+    const WalkCold *cold = nullptr;
+    const WalkFid *fidt = nullptr;
     const float4 *hull_nodes = nullptr;  // threaded binary BVH over the hull faces (2 float4 per node)
     const float4 *hull_tris = nullptr;   // 3 float4 per hull face
     uint32_t n_hull_nodes = 0;

@@ -35,10 +35,13 @@ void launch_trace_triangles(const TraceParams &p, uint32_t *out_ids, float *out_
 void launch_find_tetrahedra(const TraceParams &p, const float *points, uint32_t *out_tet, float *out_bary,
                             uint32_t *out_verts, hipStream_t stream);
 
+// de-interleaves the 64-byte build records into the three consumer tables (tn_trace_walk.hip)
+void launch_split_walk_records(size_t n4, const WalkVar *vars, WalkHot *hot, WalkCold *cold, WalkFid *fidt, hipStream_t stream);
+
 // adjacency walk, one lane per ray (tn_trace_walk.hip)
 struct WalkParams {
     TraceParams t;
-    const WalkVar *vars;       // entry-face-specialised records of the walk (k_trace_walk)
+    const WalkHot *vars;       // entry-face-specialised records of the walk: the walk's 32 bytes (k_trace_walk)
     float scene_max;           // max |coordinate| of the mesh (box padding)
     const float4 *hull_nodes;  // threaded per-lane hull tree
     const float4 *hull_tris;
@@ -56,7 +59,7 @@ struct WalkParams {
 void launch_trace_walk(const WalkParams &p, hipStream_t stream);
 // literal sort + pairing of the logged hits of the rays in literal_list (tn_trace_general.hip); rows of launch item i
 // are p.out_*[i] (the TraceParams of the same walk launch)
-void launch_postprocess_log(const TraceParams &p, const WalkVar *vars, const uint4 *hit_log, const uint2 *literal_list,
+void launch_postprocess_log(const TraceParams &p, const WalkFid *fidt, const uint4 *hit_log, const uint2 *literal_list,
                             const uint32_t *literal_count, size_t max_items, hipStream_t stream);
 
 // count-only BVH cross-check of every stride-th certified ray (tn_trace_general.hip: k_verify_counts); p = the
@@ -73,7 +76,7 @@ struct WriteParams {
     uint32_t dense_tails;      // 0: slots >= num_visited are left unwritten (non-reference option)
     const uint32_t *walk_n;    // hits in the log; TN_EMPTY: the row belongs to the literal / BVH kernels
     const uint4 *hit_log;
-    const WalkVar *vars;
+    const WalkCold *vars;      // the segment writer's 32 bytes of the walk records
     uint32_t *out_cells;
     float *out_bary;
     float *out_dist;

@@ -509,11 +509,11 @@ __global__ __launch_bounds__(64) void k_postprocess_hits(TraceParams p, const ui
 
 // Literal sort + pairing of the hits the walk LOGGED for the rays whose chain is sound but whose order it does not
 // certify (a gap below eps, a tie, an inversion): hit k of launch item r is the 16-byte log entry
-// ((r / 64) * M + k) * 64 + r % 64 = {t, u, v, variant | exit << 30}; its face id is the walk record's fid(exit) (dword 3 + 4 * exit)
+// ((r / 64) * M + k) * 64 + r % 64 = {t, u, v, variant | exit << 30}; its face id is WalkFid::fid[exit] of the variant
 // (exit code 3: the entry hull face, id in the low bits).  The chain's faces are the ray's all-hits set (two hull
 // crossings, two crossed faces per tet, no zero edge function), so this equals the BVH path -- sort on (t, face id),
 // then the reference's phases literally (optix_trace_rays.cu:110-266) -- without a traversal.
-__global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const WalkVar *__restrict__ vars,
+__global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const WalkFid *__restrict__ fidt,
                                                         const uint4 *__restrict__ hit_log,
                                                         const uint2 *__restrict__ literal_list,
                                                         const uint32_t *__restrict__ literal_count) {
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const Wal
         for (uint32_t j = lane; j < nh; j += 64) {
             const uint4 e = lg[(size_t)j * 64];
             const uint32_t x = e.w >> 30, lo = e.w & 0x3FFFFFFFu;
-            const uint32_t fid = x == 3u ? lo : reinterpret_cast<const uint32_t *>(vars + lo)[3 + 4 * x];
+            const uint32_t fid = x == 3u ? lo : fidt[lo].fid[x];
             s.key[j] = ((uint64_t)e.x << 32) | fid;
             s.hu[j] = __uint_as_float(e.y);
             s.hv[j] = __uint_as_float(e.z);
@@ -711,12 +711,12 @@ void launch_verify_counts(const TraceParams &p, uint32_t stride, uint32_t *walk_
                        walk_n, fallback_list, fallback_count, ray_base);
 }
 
-void launch_postprocess_log(const TraceParams &p, const WalkVar *vars, const uint4 *hit_log, const uint2 *literal_list,
+void launch_postprocess_log(const TraceParams &p, const WalkFid *fidt, const uint4 *hit_log, const uint2 *literal_list,
                             const uint32_t *literal_count, size_t max_items, hipStream_t stream) {
     if (max_items == 0) return;
     const size_t max_blocks = 256 * 16;
     const unsigned grid = (unsigned)(max_items < max_blocks ? max_items : max_blocks);
-    hipLaunchKernelGGL(k_postprocess_log, dim3(grid), dim3(64), wave_smem(k_postprocess_log, p.M), stream, p, vars, hit_log,
+    hipLaunchKernelGGL(k_postprocess_log, dim3(grid), dim3(64), wave_smem(k_postprocess_log, p.M), stream, p, fidt, hit_log,
                        literal_list, literal_count);
 }
 

@@ -117,19 +117,18 @@ __device__ __forceinline__ float sel4f(float a, float b, float c, float d, uint3
     return b1 ? hi : lo;
 }
 
-// The part of a walk record the walk itself reads (quads 0..2 of its 64 bytes; the tet id and the vertex ids are only
-// needed by the segment writer), as SCALARS: with the neighbours / face ids kept in a uint4 the optimiser turns the select
+// The walk's part of a record (WalkHot: 32 bytes; tet id, vertex ids and face ids live in the tables of their own
+// consumers), as SCALARS: with the neighbours / face ids kept in a uint4 the optimiser turns the select
 // chain below into a dynamically indexed vector, parks the record in LDS and reads `nb` back with a ds_read -- an
 // LDS round trip on the one dependent chain of the walk (record -> exit -> next record).
-struct Var { float px, py, pz; uint32_t nb0, nb1, nb2, code_hi, f0, f1, f2, code_lo, orig; };
-__device__ __forceinline__ Var load_var(const WalkVar *vars, uint32_t c) {
+struct Var { float px, py, pz; uint32_t nb0, nb1, nb2, code_lo, code_hi; };
+__device__ __forceinline__ Var load_var(const WalkHot *vars, uint32_t c) {   // two 16-byte loads of one 32-byte record
     const uint32_t *r = reinterpret_cast<const uint32_t *>(vars + c);
     const float4 q0 = *reinterpret_cast<const float4 *>(r);
-    const uint4 q1 = *reinterpret_cast<const uint4 *>(r + 4), q2 = *reinterpret_cast<const uint4 *>(r + 8);
+    const uint4 q1 = *reinterpret_cast<const uint4 *>(r + 4);
     Var v;
-    v.px = q0.x; v.py = q0.y; v.pz = q0.z; v.f0 = __float_as_uint(q0.w);
-    v.nb0 = q1.x; v.nb1 = q1.y; v.nb2 = q1.z; v.f1 = q1.w;
-    v.orig = q2.x; v.code_lo = q2.y; v.code_hi = q2.z; v.f2 = q2.w;
+    v.px = q0.x; v.py = q0.y; v.pz = q0.z; v.nb0 = __float_as_uint(q0.w);
+    v.nb1 = q1.x; v.nb2 = q1.y; v.code_lo = q1.z; v.code_hi = q1.w;
     return v;
 }
 __device__ __forceinline__ uint32_t sel3u(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t i) {  // i in 0..2 (3 -> v2)
@@ -244,7 +243,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
 
     bool alive = nhull == 2 && !flag;
     const bool first0 = ht0 < ht1;
-    const uint32_t f_in0 = first0 ? hf0 : hf1, f_out = first0 ? hf1 : hf0;
+    const uint32_t f_in0 = first0 ? hf0 : hf1;
+    const float t_out = first0 ? ht1 : ht0;
     uint32_t c = 4u * (first0 ? hc0 : hc1) + (first0 ? he0 : he1);  // variant = (tet record, entry face)
     if (!alive) c = 0;
     // The entry face in its STORED order: sheared vertices A,B,C and edge functions U=E(B,C), V=E(C,A), W=E(A,B).
@@ -264,7 +264,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     bool order_ok = true;     // the order of the hits so far is "clean" (header)
     bool prev_short = false, prev_inv = false;  // the previous pair was closer than eps / and inverted
     float pt = 0.f, ppt = 0.f;  // t of the previous recorded hit and of the one before
-    uint32_t fid_prev = f_in0;  // face id of the previous recorded hit (ties are ordered by id)
     uint32_t nhits = 0, nshort = 0;
     uint32_t steps = 0;
     Var cur = load_var(p.vars, c);
@@ -302,7 +301,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         bad = (!bad && __popc(hmask) != 1) ? 6u : bad;
         const uint32_t x = (__ffs(hmask) - 1) & 3u;  // exit 0..2 (3 only together with bad)
         const uint32_t nb = sel3u(cur.nb0, cur.nb1, cur.nb2, x);
-        const uint32_t fx = sel3u(cur.f0, cur.f1, cur.f2, x);        // id of the exit face
         const bool last = nb == TN_EMPTY;
         // the next record is requested as soon as the exit is known
         const Var nxt = load_var(p.vars, (last || bad) ? c : nb);
@@ -322,7 +320,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         {
             const bool vp = valid && have_prev;
             const bool is_short = fabsf(pt - ct) < TN_EPS;
-            const bool asc = (ct > pt) || (ct == pt && fx > fid_prev);   // sorted order of the two = chain order
+            // sorted order of the two = chain order; an exact tie in t is ordered by face id in the total order, which the
+            // walk does not carry (the ids live in WalkFid): a tie counts as 'not ascending', the ray is paired literally
+            const bool asc = ct > pt;
             const bool clear2 = ct - ppt >= TN_EPS;
             // short + ascending: any run of them is fine (header), except a run that starts at the entry hull face
             // (pairs 1 and 2 both short: nhits == 2 here); short + inverted: isolated and clear of the face before;
@@ -345,9 +345,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         have_pp = valid ? have_prev : have_pp;
         ppt = valid ? pt : ppt;
         pt = valid ? ct : pt;
-        fid_prev = valid ? fx : fid_prev;
         have_prev = have_prev || valid;
-        bad = (!bad && last && fx != f_out) ? 11u : bad;
+        // the chain must end in the other crossed hull face: its t was computed by the hull search with the same expression
+        // tree, so the last valid hit carries it bit for bit
+        bad = (!bad && last && valid && !(ct == t_out)) ? 11u : bad;
         steps++;
         bad = (!bad && !last && steps > MAX_WALK_STEPS) ? 12u : bad;
         flag = bad != 0;
@@ -387,8 +388,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
 // 8 full 128-byte lines of the log (entries of neighbouring rays are neighbours in the log).  For a certified ray
 // (header of this file) hits k-1 and k bound the tet recorded with hit k, and the pair is a segment unless it is
 // shorter than eps; emitted slots are numbered by a per-ray prefix count over the wave ballot.  The tet id /
-// vertex ids / combine_indices code come from the 64-byte walk record of (tet, entry face), read as two 16-byte
-// quads; bary_out is selected exactly as combine_indices does (optix_trace_rays.cu:39-75).  The slots between the
+// vertex ids / combine_indices code come from the writer's 32-byte record of (tet, entry face) (WalkCold), two 16-byte
+// quads of one sector; bary_out is selected exactly as combine_indices does (optix_trace_rays.cu:39-75).  The slots between the
 // last segment and the next multiple of 32 (where all four row arrays are on a 128-byte line boundary) get their
 // tail constants here, so that k_fill_range starts every row on a line boundary and no line is written by two kernels.
 //
@@ -520,15 +521,15 @@ __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
                 nseg += (uint32_t)__popcll(m);
             }
             if (any) {   // wave-uniform
-                // ---- walk records of the emitted segments: quad 2 = {tet id, code_lo, code_hi, .}, quad 3 = vertex ids
+                // ---- the writer's records of the emitted segments (WalkCold, one 32-byte sector): vertex ids | tet id, combine code
                 uint4 qa[U], qv[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     qa[u] = make_uint4(0u, 0u, 0u, 0u); qv[u] = qa[u];
                     if (slot[u] != TN_EMPTY) {
                         const uint32_t *rec = reinterpret_cast<const uint32_t *>(q.vars + (e[u].w & 0x3FFFFFFFu));
-                        qa[u] = *reinterpret_cast<const uint4 *>(rec + 8);
-                        qv[u] = *reinterpret_cast<const uint4 *>(rec + 12);
+                        qv[u] = *reinterpret_cast<const uint4 *>(rec);
+                        qa[u] = *reinterpret_cast<const uint4 *>(rec + 4);
                     }
                 }
                 // ---- segment records -> LDS [array][ray][slot]
@@ -537,14 +538,11 @@ __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
                     if (slot[u] != TN_EMPTY) {
                         const uint32_t at = a * W::STRIDE + slot[u];
                         const uint32_t x = e[u].w >> 30;
-                        const bool x0 = (x & 1u) != 0, x1 = (x & 2u) != 0;
-                        const uint32_t w01 = x0 ? (qa[u].y >> 12) : qa[u].y;
-                        const uint32_t w2 = (qa[u].y >> 24) | (qa[u].z << 8);
-                        const uint32_t code = (x1 ? w2 : w01) & 0xFFFu;
+                        const uint32_t cmb = qa[u].y >> (6u * x);     // position of a / b / c in the exit face's stored order
                         const float pt = __uint_as_float(pe[u].x), pu = __uint_as_float(pe[u].y), pv = __uint_as_float(pe[u].z);
                         const float ct = __uint_as_float(e[u].x), cu = __uint_as_float(e[u].y), cv = __uint_as_float(e[u].z);
                         const float r0f = 1.0f - cu - cv;
-                        const uint32_t k0 = (code >> 6) & 3u, k1 = (code >> 8) & 3u, k2 = (code >> 10) & 3u;
+                        const uint32_t k0 = cmb & 3u, k1 = (cmb >> 2) & 3u, k2 = (cmb >> 4) & 3u;
                         L[W::CELLS + at] = qa[u].x;
                         *reinterpret_cast<float2 *>(L + W::DIST + 2 * at) = make_float2(pt, ct);
                         float2 *bp = reinterpret_cast<float2 *>(L + W::BARY + 6 * at);
@@ -665,6 +663,30 @@ void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_
     else
         hipLaunchKernelGGL(k_fill_range<false>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split,
                            walk_n, out_num, out_cells, out_bary, out_dist, out_verts);
+}
+
+// 64-byte build records -> the three consumer tables (tn_common.h: WalkHot / WalkCold / WalkFid)
+__global__ __launch_bounds__(256) void k_split_walk_records(size_t n4, const WalkVar *__restrict__ vars, WalkHot *__restrict__ hot,
+                                                            WalkCold *__restrict__ cold, WalkFid *__restrict__ fidt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const WalkVar v = vars[i];
+    WalkHot h;
+    h.pn[0] = v.pn[0]; h.pn[1] = v.pn[1]; h.pn[2] = v.pn[2];
+    h.nb0 = v.nb[0]; h.nb1 = v.nb[1]; h.nb2 = v.nb[2]; h.code_lo = v.code_lo; h.code_hi = v.code_hi;
+    WalkCold c;
+    for (int k = 0; k < 4; ++k) c.vid[k] = v.vid[k];
+    c.orig = v.orig;
+    const unsigned long long code = (unsigned long long)v.code_lo | ((unsigned long long)(v.code_hi & 0xFu) << 32);
+    c.cmb = (uint32_t)((code >> 6) & 63u) | ((uint32_t)((code >> 18) & 63u) << 6) | ((uint32_t)((code >> 30) & 63u) << 12);
+    c.pad0 = 0; c.pad1 = 0;
+    WalkFid f;
+    f.fid[0] = v.fid0; f.fid[1] = v.fid1; f.fid[2] = v.fid2; f.pad = 0;
+    hot[i] = h; cold[i] = c; fidt[i] = f;
+}
+void launch_split_walk_records(size_t n4, const WalkVar *vars, WalkHot *hot, WalkCold *cold, WalkFid *fidt, hipStream_t stream) {
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(k_split_walk_records, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, n4, vars, hot, cold, fidt);
 }
 
 void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
