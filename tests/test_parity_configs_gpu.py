@@ -336,4 +336,4 @@ def test_aimed_rays_do_not_fall_into_the_certification_hole(tn, device, oracle, 
             assert np.array_equal(a[k][:3000].cpu().numpy().view(np.uint32), np.ascontiguousarray(want[k]).view(np.uint32)), k
         del a, b, c
     assert handed.get(8, 0) > 0 or handed.get(2, 0) > 0, handed      # the new rules do fire on these meshes
-    assert verified > 10_000, verified                               # ... and certified rays remain to be cross-checked
+    assert verified > 1_000, verified                                # ... and certified rays remain to be cross-checked

@@ -138,6 +138,8 @@ TN_HD TetAdj tet_adjacency(uint32_t i, const uint32_t *cells, const uint32_t *te
     return r;
 }
 
+constexpr uint32_t TIE_SHIFT = 16;   // bits 16..18 of WalkVar::code_hi (bits 0..3: code word, 8..15: thin exponent)
+
 // The walk record of (tet, entry face e).  `nbr_rec[k]` = record index of the neighbour behind face k (or TN_EMPTY),
 // pn = position of the vertex opposite the entry face, orig = the caller's tet id.  See WalkVar in tn_common.h.
 TN_HD WalkVar make_walk_var(const TetAdj &t, const uint32_t nbr_rec[4], const float pn[3], uint32_t orig, uint32_t e) {
@@ -167,6 +169,10 @@ TN_HD WalkVar make_walk_var(const TetAdj &t, const uint32_t nbr_rec[4], const fl
     }
     v.code_lo = (uint32_t)codes;
     v.code_hi = (uint32_t)(codes >> 32);
+    // bits 16..18: face id of exit x > face id of the entry face -- the tie-break of the total order (t, face id) between
+    // the hit on the entry face and the hit on exit x, which is all the walk ever needs of the face ids
+    for (uint32_t x = 0; x < 3; ++x)
+        if (t.fid[t.loc[e][x]] > t.fid[e]) v.code_hi |= 1u << (TIE_SHIFT + x);
     return v;
 }
 

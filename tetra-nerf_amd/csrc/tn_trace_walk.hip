@@ -320,9 +320,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         {
             const bool vp = valid && have_prev;
             const bool is_short = fabsf(pt - ct) < TN_EPS;
-            // sorted order of the two = chain order; an exact tie in t is ordered by face id in the total order, which the
-            // walk does not carry (the ids live in WalkFid): a tie counts as 'not ascending', the ray is paired literally
-            const bool asc = ct > pt;
+            // sorted order of the two = chain order; an exact tie in t is ordered by face id: the previous recorded hit is
+            // this tet's entry face, and "id of exit x > id of the entry face" is bit 16 + x of the record's code_hi
+            const bool asc = (ct > pt) || (ct == pt && ((cur.code_hi >> (16u + x)) & 1u) != 0);
             const bool clear2 = ct - ppt >= TN_EPS;
             // short + ascending: any run of them is fine (header), except a run that starts at the entry hull face
             // (pairs 1 and 2 both short: nhits == 2 here); short + inverted: isolated and clear of the face before;
