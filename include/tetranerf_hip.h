@@ -326,19 +326,22 @@ int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, cons
  *   pre-activations of mlp_base layers 0..2 and of mlp_head; dhead [4,n] = d sigma_raw, d rgb_raw[0..2];
  *   dx0 [64,n] = gradient of the gathered features (feed it to tn_interpolate_values_backward).
  * field_vm is the field vertex-major [V,64] (tn_transpose_f32); d_sigma f32 [n], d_rgb f32 [n,3].
- * Weight gradients: dW_l = d_l * (input of layer l)^T via tn_mlp_weight_grad:
- *   dw f32 [128, rows_b] += a [128,n] * b [rows_b,n]^T, db f32 [128] += row sums of a (nullable); rows_b in {64,128}. */
+ * tn_mlp_param_grads then ACCUMULATES the gradients of the twelve parameter tensors (tn_mlp_grads: fp32 gradient
+ * buffers in nn.Linear layout, zeroed by the caller before the first chunk) from those buffers: dW_l = d_l (input of
+ * layer l)^T as sample-streaming fp32-MFMA GEMMs (the 27 direction-encoding columns of mlp_head and the density head's
+ * vector ride along the mlp_head GEMM), the rgb head / bias sums as one bandwidth-bound pass; per-block partial sums are
+ * added in a fixed order (no atomics): bit-reproducible.  dirs f32 [n / samples_per_ray, 3] as in tn_mlp_backward. */
 typedef struct tn_mlp_backward_buffers {
     float *x0, *h1, *h2, *h3, *h4, *d1, *d2, *d3, *d4, *dhead, *dx0;
 } tn_mlp_backward_buffers;
 int tn_mlp_backward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices, const float *barycentric,
                     const float *field_vm, const float *dirs, const float *d_sigma, const float *d_rgb,
                     const tn_mlp_backward_buffers *buffers, void *stream);
-int tn_mlp_weight_grad(size_t n, uint32_t rows_b, const float *a, const float *b, float *dw, float *db, void *stream);
-/* the narrow heads and the direction-encoding columns of mlp_head: out f32 [4,128] += (dhead[0] . h3 rows = d wd,
- * dhead[1+c] . h4 rows = d wr[c]); ray_sum f32 [128, n / samples_per_ray] = per-ray sums of d4 (d Wh[:, :27] = ray_sum @ enc) */
-int tn_mlp_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, const float *h3, const float *h4,
-                     const float *d4, float *out, float *ray_sum, void *stream);
+typedef struct tn_mlp_grads { /* same shapes as tn_mlp_weights */
+    float *w1, *b1, *w2, *b2, *w3, *b3, *wd, *bd, *wh, *bh, *wr, *br;
+} tn_mlp_grads;
+int tn_mlp_param_grads(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const float *dirs,
+                       const tn_mlp_backward_buffers *buffers, const tn_mlp_grads *grads, void *stream);
 
 /* adjoint of tn_composite w.r.t. sigma [R,S] and rgb [R,S,3], given the gradients of the rendered rgb [R,3] and
  * accumulation [R] (either nullable); the median depth carries no gradient. */

@@ -707,7 +707,7 @@ int tn_interpolate_values_backward_vm(uint32_t D, uint32_t n, uint32_t Fd, const
 
 struct tn_mlp {
     int device = 0;
-    tn::DevBuf<float> pk_plain, pk_gather, pt, enc;
+    tn::DevBuf<float> pk_plain, pk_gather, pt, enc, grad_scratch;
     tn::DevBuf<uint4> blob;
     tn::DevBuf<uint32_t> nvh;
     bool packed = false;
@@ -720,7 +720,7 @@ struct tn_mlp {
             enc.alloc(cap * tn::mlp_enc_floats_per_ray());
             nvh.alloc(cap);
         }
-        return tn::MlpPacks{pk_plain.p, pk_gather.p, pt.p, blob.p, enc.p, nvh.p};
+        return tn::MlpPacks{pk_plain.p, pk_gather.p, pt.p, blob.p, enc.p, nvh.p, grad_scratch.p};
     }
 };
 
@@ -848,18 +848,25 @@ int tn_mlp_backward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint
     });
 }
 
-int tn_mlp_weight_grad(size_t n, uint32_t rows_b, const float *a, const float *b, float *dw, float *db, void *stream_) {
+int tn_mlp_param_grads(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const float *dirs, const tn_mlp_backward_buffers *b,
+                       const tn_mlp_grads *grads, void *stream_) {
     return guarded([&] {
-        tn::launch_weight_grad(n, rows_b, a, b, dw, db, (hipStream_t)stream_);
-        TN_HIP(hipGetLastError());
-    });
-}
-
-int tn_mlp_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, const float *h3, const float *h4, const float *d4,
-                     float *out, float *ray_sum, void *stream_) {
-    return guarded([&] {
+        tn_mlp *m = checked_mlp(mlp);
+        if (n == 0) return;
+        if (!b || !grads || !dirs) throw tn::Error("null pointer");
         if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
-        tn::launch_head_grad(n, samples_per_ray, dhead, h3, h4, d4, out, ray_sum, (hipStream_t)stream_);
+        float *const gp[12] = {grads->w1, grads->b1, grads->w2, grads->b2, grads->w3, grads->b3,
+                               grads->wd, grads->bd, grads->wh, grads->bh, grads->wr, grads->br};
+        for (float *p : gp)
+            if (!p) throw tn::Error("null pointer");
+        DeviceGuard g(m->device);
+        if (!m->grad_scratch.p) {   // first training call of this handle
+            TN_HIP(hipDeviceSynchronize());
+            m->grad_scratch.alloc(tn::mlp_param_grad_scratch_floats());
+        }
+        tn::MlpBackwardBuffers bb{b->x0, b->h1, b->h2, b->h3, b->h4, b->d1, b->d2, b->d3, b->d4, b->dhead, b->dx0};
+        tn::MlpParamGrads pg{gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], gp[6], gp[7], gp[8], gp[9], gp[10], gp[11]};
+        tn::launch_mlp_param_grads(n, samples_per_ray, dirs, m->packs(n / samples_per_ray), bb, pg, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }

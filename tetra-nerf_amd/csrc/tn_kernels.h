@@ -127,6 +127,7 @@ struct MlpPacks {
     const uint4 *blob;         // bf16x3 pieces (forward, mode 1)
     float *enc;                // [rays][mlp_enc_floats_per_ray()] direction encodings of the current call
     uint32_t *nvh;             // [rays] segment counts of the hitting rays (render pass)
+    float *grad_scratch;       // [mlp_param_grad_scratch_floats()] per-block partial sums of the parameter gradients
 };
 size_t mlp_pack_floats();              // tn_mlp.hip
 size_t mlp_backward_pack_floats();     // tn_mlp_bwd.hip
@@ -156,11 +157,13 @@ struct MlpBackwardBuffers {
 void launch_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vi, const float *bc, const float *field_vm,
                          const float *dirs, const MlpPacks &w, const float *d_sigma, const float *d_rgb,
                          const MlpBackwardBuffers &b, hipStream_t stream);
-// dW[128, rows_b] += A[128, n] * B[rows_b, n]^T, db[128] += row sums of A (db nullable); rows_b in {64, 128}
-void launch_weight_grad(size_t n, uint32_t rows_b, const float *A, const float *B, float *dW, float *db, hipStream_t stream);
-// narrow heads: out[4][128] += (d sigma_raw . h3, d rgb_raw[c] . h4); ray_sum[128][R] = per-ray sums of d4
-void launch_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, const float *h3, const float *h4, const float *d4,
-                      float *out, float *ray_sum, hipStream_t stream);
+// parameter gradients (tn_mlp_grad.hip), ACCUMULATED into the twelve tensors (nn.Linear layout: w1 [128,64], b1, w2, b2, w3,
+// b3 [128..], wd [1,128], bd [1], wh [128,155], bh, wr [3,128], br [3]) from the buffers launch_mlp_backward left for the
+// same samples; bit-reproducible (no atomics).  dirs: the ray directions of the chunk.
+struct MlpParamGrads { float *w1, *b1, *w2, *b2, *w3, *b3, *wd, *bd, *wh, *bh, *wr, *br; };
+size_t mlp_param_grad_scratch_floats();
+void launch_mlp_param_grads(size_t n, uint32_t samples_per_ray, const float *dirs, const MlpPacks &w, const MlpBackwardBuffers &b,
+                            const MlpParamGrads &g, hipStream_t stream);
 // adjoint of launch_composite: d sigma [R,S], d rgb [R,S,3] from the gradients of the rendered rgb / accumulation
 void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
                                const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb, hipStream_t stream);

@@ -303,69 +303,6 @@ __global__ __launch_bounds__(BWD_BLOCK) void k_mlp_backward(size_t n, uint32_t s
     }
 }
 
-// dW[128, 32*NB] += A[128, n] * B[32*NB, n]^T over the samples [blockIdx.x * slice, ...), db[128] += row sums of A.
-// 4 waves: wave w owns output rows 32w .. 32w+31 (NB tiles of 32x32).  Both operands are staged through LDS in
-// 32-sample steps (every row is one 128-byte line), the next step's lines are in registers while the MFMAs of the
-// current step run.
-template <int NB>
-__global__ __launch_bounds__(256) void k_dw_gemm(size_t n, uint32_t slice, const float *__restrict__ A, const float *__restrict__ B,
-                                                 float *__restrict__ dW, float *__restrict__ db) {
-    constexpr int RA = 128, RB = 32 * NB, LD = 33;        // padded row: conflict-free column reads
-    __shared__ float As[RA * LD];
-    __shared__ float Bs[RB * LD];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int col = tid & 31, row0 = tid >> 5;            // staging: 8 rows of 32 samples per pass
-    constexpr int PA = RA / 8, PB = RB / 8;
-    const size_t s_begin = (size_t)blockIdx.x * slice;
-    const size_t s_end = s_begin + slice < n ? s_begin + slice : n;
-    if (s_begin >= n) return;
-    f32x16 acc[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-    float rsum = 0.f;
-    float ra[PA], rb[PB];
-    auto fetch = [&](size_t s0) {
-        const size_t sidx = s0 + col;
-        const bool in = sidx < s_end;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) ra[p] = in ? A[(size_t)(8 * p + row0) * n + sidx] : 0.f;
-#pragma unroll
-        for (int p = 0; p < PB; ++p) rb[p] = in ? B[(size_t)(8 * p + row0) * n + sidx] : 0.f;
-    };
-    fetch(s_begin);
-    for (size_t s0 = s_begin; s0 < s_end; s0 += 32) {
-        __syncthreads();   // the previous step's reads of the tiles are done
-#pragma unroll
-        for (int p = 0; p < PA; ++p) As[(8 * p + row0) * LD + col] = ra[p];
-#pragma unroll
-        for (int p = 0; p < PB; ++p) Bs[(8 * p + row0) * LD + col] = rb[p];
-        __syncthreads();
-        if (s0 + 32 < s_end) fetch(s0 + 32);
-        const float *ar = As + (32 * w + (lane & 31)) * LD + (lane >> 5);
-        const float *br = Bs + (lane & 31) * LD + (lane >> 5);
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-            const float a = ar[2 * k2];
-            rsum += a;
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, br[32 * c * LD + 2 * k2], acc[c], 0, 0, 0);
-        }
-    }
-    const int hh = lane >> 5;
-#pragma unroll
-    for (int c = 0; c < NB; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            atomicAdd(&dW[(size_t)(32 * w + acc_feature(r, hh)) * RB + 32 * c + (lane & 31)], acc[c][r]);
-    if (db) {
-        rsum += __shfl_xor(rsum, 32);
-        if (lane < 32) atomicAdd(&db[32 * w + lane], rsum);
-    }
-}
-
 // Adjoint of k_composite (RaySamples.get_weights + RGB / accumulation renderers, model.py:632-638; the median depth has
 // no gradient): one wavefront per ray.  With dd_i = delta_i sigma_i, T_i = exp(-sum_{k<i} dd_k), w_i = (1 - exp(-dd_i)) T_i
 // and a_i = dL/dw_i = g_rgb . c_i - bg sum(g_rgb) + g_acc:
@@ -438,55 +375,6 @@ void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const f
                        d_sigma, d_rgb);
 }
 
-// Gradients of the two narrow heads and the per-ray sums the direction-encoding columns of mlp_head need, all
-// bandwidth-bound row products over the sample axis (one block per feature row, the four d*_raw rows stay in cache):
-//   out[0][f]   += sum_s dhead[0][s] * h3[f][s]                      (density head: d wd[f])
-//   out[1+c][f] += sum_s dhead[1+c][s] * h4[f][s],  c = 0..2         (rgb head: d wr[c][f])
-//   ray_sum[f][r] = sum_{s in ray r} d4[f][s]                        (d Wh[:, :27] = ray_sum @ enc)
-__global__ __launch_bounds__(256) void k_head_grad(size_t n, uint32_t samples_per_ray, const float *__restrict__ dhead,
-                                                   const float *__restrict__ h3, const float *__restrict__ h4,
-                                                   const float *__restrict__ d4, float *__restrict__ out /*[4][128]*/,
-                                                   float *__restrict__ ray_sum /*[128][R]*/) {
-    const uint32_t f = blockIdx.x;            // feature row 0..127
-    const size_t part = blockIdx.y, nparts = gridDim.y;
-    const size_t R = n / samples_per_ray;
-    const size_t r_per = (R + nparts - 1) / nparts;
-    const size_t r0 = part * r_per, r1 = r0 + r_per < R ? r0 + r_per : R;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float *row3 = h3 + (size_t)f * n, *row4 = h4 + (size_t)f * n, *rowd = d4 + (size_t)f * n;
-    for (size_t r = r0 + wave; r < r1; r += 4) {       // one wave per ray: its samples are contiguous
-        float rs = 0.f;
-        for (uint32_t j = lane; j < samples_per_ray; j += 64) {
-            const size_t s = r * samples_per_ray + j;
-            a0 += dhead[s] * row3[s];
-            const float x = row4[s];
-            a1 += dhead[n + s] * x; a2 += dhead[2 * n + s] * x; a3 += dhead[3 * n + s] * x;
-            rs += rowd[s];
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) rs += __shfl_xor(rs, off);
-        if (lane == 0) ray_sum[(size_t)f * R + r] = rs;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); a3 += __shfl_xor(a3, off);
-    }
-    if (lane == 0) {
-        atomicAdd(&out[f], a0); atomicAdd(&out[128 + f], a1); atomicAdd(&out[256 + f], a2); atomicAdd(&out[384 + f], a3);
-    }
-}
-
-void launch_head_grad(size_t n, uint32_t samples_per_ray, const float *dhead, const float *h3, const float *h4, const float *d4,
-                      float *out, float *ray_sum, hipStream_t stream) {
-    if (n == 0) return;
-    const size_t R = n / samples_per_ray;
-    unsigned parts = (unsigned)((R + 255) / 256);
-    if (parts > 64) parts = 64;
-    if (parts < 1) parts = 1;
-    hipLaunchKernelGGL(k_head_grad, dim3(128, parts), dim3(256), 0, stream, n, samples_per_ray, dhead, h3, h4, d4, out, ray_sum);
-}
-
 size_t mlp_backward_pack_floats() { return PACKT_FLOATS; }
 
 void launch_mlp_pack_t(const MlpWeights &w, float *pt, hipStream_t stream) {
@@ -511,15 +399,6 @@ void launch_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vi,
     BwdBuffers o{b.x0, b.h1, b.h2, b.h3, b.h4, b.d1, b.d2, b.d3, b.d4, b.dhead, b.dx0};
     hipLaunchKernelGGL(k_mlp_backward, dim3(grid), dim3(BWD_BLOCK), smem, stream, n, samples_per_ray, vi, bc, field_vm, enc, pk, pt,
                        d_sigma, d_rgb, o);
-}
-
-void launch_weight_grad(size_t n, uint32_t rows_b, const float *A, const float *B, float *dW, float *db, hipStream_t stream) {
-    if (n == 0) return;
-    const uint32_t slice = 4096;
-    const unsigned grid = (unsigned)((n + slice - 1) / slice);
-    if (rows_b == 128) hipLaunchKernelGGL(k_dw_gemm<4>, dim3(grid), dim3(256), 0, stream, n, slice, A, B, dW, db);
-    else if (rows_b == 64) hipLaunchKernelGGL(k_dw_gemm<2>, dim3(grid), dim3(256), 0, stream, n, slice, A, B, dW, db);
-    else throw Error("weight_grad: B must have 64 or 128 rows");
 }
 
 }  // namespace tn

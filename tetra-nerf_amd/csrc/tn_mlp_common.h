@@ -72,17 +72,30 @@ static __device__ __forceinline__ void stage_wait() {
 }
 
 // acc[t] += W_staged[k-steps KS0 .. KS0+KS) * bin[BIN0 .. BIN0+KS)
+// The A operands (staged weights) of k-step ks+1 are requested from LDS BEFORE the MFMAs of k-step ks are issued: left to
+// itself the compiler reads them into the same registers right before their use, and a wave that is alone on its SIMD
+// (the training kernel) then idles for one LDS latency per k-step (round 3: the dX kernel ran at 52 % of the MFMA rate).
+// The sched_barrier keeps the scheduler from hoisting hundreds of reads (register blow-up) or sinking these.
 template <int KS, int KS0, int TILES, int BIN0 = 0>
 static __device__ __forceinline__ void gemm_steps(f32x16 (&acc)[TILES], const float (&bin)[KSH], const float *lds, int lane) {
+    float a[TILES], an[TILES];
+    const float *w0 = lds + (size_t)KS0 * TILES * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) a[t] = w0[t * 64];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        const float *wrow = lds + (size_t)(KS0 + ks) * TILES * 64 + lane;
+        if (ks + 1 < KS) {
+            const float *wrow = lds + (size_t)(KS0 + ks + 1) * TILES * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) an[t] = wrow[t * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], bin[BIN0 + ks], acc[t], 0, 0, 0);
-        // keep the scheduler from hoisting hundreds of A-operand reads (register blow-up); the
-        // MFMAs of one k-step (>= 256 cycles) already cover the next step's LDS latency
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bin[BIN0 + ks], acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) a[t] = an[t];
     }
 }
 

@@ -60,8 +60,8 @@
 // near edge with it.  Rule 8 therefore combines a mesh-side and a ray-side condition: the record of every tet
 // carries (as an exponent byte) the second smallest of its vertices' star minima of the tet height -- a lower bound
 // of the thinnest tet around its most suspicious edge (tn_build_core.h) -- and a ray leaves the walk when it passes
-// within 8 delta of an edge of a tet whose value is below 32 delta.  Rule 4 (a vertex within the box padding = 4.6
-// delta... 45 delta in L1 of the sheared plane) stays.  The count-only BVH cross-check (option verify_stride) and the
+// within 8 delta of an edge of a tet whose value is below 32 delta.  Rule 4 (a vertex within the box padding = 32/7
+// delta of the ray, L1 norm in the sheared plane) stays.  The count-only BVH cross-check (option verify_stride) and the
 // fuzzer are the evidence that nothing is left: see DESIGN.md section 2.
 //
 // Memory behaviour: the walk does NOT touch the output rows.  Rows are 26 KB apart, so anything a lane stores

@@ -707,22 +707,13 @@ class _MlpBackwardBuffers(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("x0", "h1", "h2", "h3", "h4", "d1", "d2", "d3", "d4", "dhead", "dx0")]
 
 
-def _direction_encoding(d):
-    """NeRFEncoding(3, 4 freqs, include_input) as the MLP kernels evaluate it (tn_mlp.hip: k_dir_encoding)."""
-    import math
-
-    freqs = 2.0 ** torch.linspace(0.0, 4.0, 4, dtype=d.dtype, device=d.device)
-    scaled = ((2.0 * math.pi * d)[..., None] * freqs).reshape(*d.shape[:-1], 12)
-    return torch.cat([torch.sin(torch.cat([scaled, scaled + math.pi / 2.0], dim=-1)), d], dim=-1)
-
-
 def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray, d_sigma, d_rgb,
-                 chunk_samples=1 << 20):
+                 chunk_samples=1 << 22):
     """Adjoint of mlp_forward_gather (addition; the reference leaves this to PyTorch autograd, model.py:602-630):
     given dL/dsigma [n] and dL/drgb [n,3] returns (grad_field [64,V], [12 weight gradients in the order of `weights`]).
-    Two HIP kernels per chunk of samples: the dX chain on the fp32 matrix cores (recomputing the forward pass) and
-    K-streaming weight-gradient GEMMs; the three narrow head gradients (enc part of mlp_head, density, rgb) are
-    bandwidth-bound matrix-vector products done by PyTorch on the buffers the first kernel left."""
+    Per chunk of samples (4.6 KB of buffers per sample; chunks of equal size): tn_mlp_backward -- the dX chain on the fp32
+    matrix cores, recomputing the forward pass -- then tn_mlp_param_grads -- the twelve parameter gradients as
+    sample-streaming fp32-MFMA GEMMs, summed without atomics (bit-reproducible) -- then the gather's adjoint."""
     mh = fused_mlp(weights)
     keep = [w.detach() for w in weights]
     n = vertex_indices.numel() // 4
@@ -738,13 +729,12 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
     dirs = dirs.contiguous()
     lib = _lib.load()
     field_vm = field_vertex_major(field)
-    grads = [torch.zeros_like(w, dtype=torch.float32, requires_grad=False) for w in keep]
-    gw1, gb1, gw2, gb2, gw3, gb3, gwd, gbd, gwh, gbh, gwr, gbr = grads
-    gwh_base = torch.zeros((128, 128), dtype=torch.float32, device=dev)
-    head_out = torch.zeros((4, 128), dtype=torch.float32, device=dev)   # d wd, d wr[0..2]
+    grads = [torch.zeros(tuple(w.shape), dtype=torch.float32, device=dev) for w in keep]
+    gs = _MlpWeightsStruct(*[g.data_ptr() for g in grads])
     grad_vm = torch.zeros((V, 64), dtype=torch.float32, device=dev)
-    rays_per_chunk = max(1, int(chunk_samples) // S)
     R = n // S
+    nchunks = max(1, -(-n // max(int(chunk_samples), S)))
+    rays_per_chunk = -(-R // nchunks)
     stream = _stream(dev)
     with torch.cuda.device(dev):
         for r0 in range(0, R, rays_per_chunk):
@@ -758,25 +748,13 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
             bs = _MlpBackwardBuffers(*[t.data_ptr() for t in (x0, h1, h2, h3, h4, d1, d2, d3, d4, dhead, dx0)])
             _lib.check(lib.tn_mlp_backward(mh.handle, m, S, _ptr(vi[c0:]), _ptr(bc[c0:]), _ptr(field_vm), _ptr(dirs[r0:]),
                                            _ptr(d_sigma[c0:]), _ptr(d_rgb[c0:]), C.byref(bs), stream))
-            for a, b, rows_b, gw, gb in ((d1, x0, 64, gw1, gb1), (d2, h1, 128, gw2, gb2), (d3, h2, 128, gw3, gb3),
-                                         (d4, h3, 128, gwh_base, gbh)):
-                _lib.check(lib.tn_mlp_weight_grad(m, rows_b, _ptr(a), _ptr(b), _ptr(gw), _ptr(gb), stream))
-            # narrow heads + the direction-encoding columns of mlp_head: one bandwidth-bound pass over h3 / h4 / d4
-            ray_sum = _empty((128, r1 - r0), dtype=torch.float32, device=dev)
-            _lib.check(lib.tn_mlp_head_grad(m, S, _ptr(dhead), _ptr(h3), _ptr(h4), _ptr(d4), _ptr(head_out), _ptr(ray_sum), stream))
-            gwh[:, :27] += ray_sum @ _direction_encoding(dirs[r0:r1])
-            hsum = dhead.sum(1)
-            gbd += hsum[0]
-            gbr += hsum[1:4]
+            _lib.check(lib.tn_mlp_param_grads(mh.handle, m, S, _ptr(dirs[r0:]), C.byref(bs), C.byref(gs), stream))
             # gradient of the gathered features -> field (vertex-major accumulation)
             rows = _empty((m, 64), dtype=torch.float32, device=dev)
             _lib.check(lib.tn_transpose_f32(64, m, _ptr(dx0), _ptr(rows), stream))
             _lib.check(lib.tn_interpolate_values_backward_vm(4, m, 64, _ptr(vi[c0:]), _ptr(bc[c0:]), _ptr(rows), _ptr(grad_vm),
                                                              stream))
             del buf, rows
-        gwh[:, 27:] += gwh_base
-        gwd += head_out[0:1]
-        gwr += head_out[1:4]
         grad_field = _empty((64, V), dtype=torch.float32, device=dev)
         _lib.check(lib.tn_transpose_f32(V, 64, _ptr(grad_vm), _ptr(grad_field), stream))
     return grad_field, grads
