@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64) void k_composite(size_t R, uint32_t S, const fl
     }
 }
 
-size_t mlp_pack_floats() { return PACK_FLOATS; }
+size_t mlp_pack_floats() { return PACK_FLOATS + 1024; }   // + slack: the training kernel copies whole 4 KB passes (tn_mlp_bwd.hip)
 
 
 void launch_mlp_pack(const MlpWeights &w, float *pk, bool gather_l1, hipStream_t stream) {

@@ -39,6 +39,7 @@ constexpr size_t OFFT_3 = OFFT_H + N_TH;
 constexpr size_t OFFT_2 = OFFT_3 + tfloats(OT);
 constexpr size_t OFFT_1 = OFFT_2 + tfloats(OT);
 constexpr size_t PACKT_FLOATS = OFFT_1 + tfloats(OTI1);
+constexpr size_t PACK_SLACK = 1024;   // floats behind the forward pack that a whole-pass stage copy may read (tn_mlp.hip allocates them)
 
 __global__ void k_mlp_pack_t(MlpWeights w, float *__restrict__ pt) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,8 +108,82 @@ __device__ __forceinline__ void masked_to_bin(const f32x16 (&acc)[TILES], unsign
 // 4 waves per block = one per SIMD: the kernel keeps 64 activations, 64 accumulators, four 64-bit ReLU masks and the head
 // gradients live at once, more than the 256 registers a wave gets at two waves per SIMD (the forward kernel's shape);
 // alone on its SIMD a wave has the whole 512-entry file (VGPRs + AGPRs), and one wave per SIMD already reaches the
-// fp32 MFMA issue rate.
+// fp32 MFMA issue rate -- PROVIDED nothing it waits for is on the critical path, because no other wave fills the gap:
+//   * the eight weight stages of a group ping-pong between two LDS buffers: stage l + 1 is requested (async global -> LDS)
+//     when GEMM l starts and has the whole GEMM to land; ONE barrier per layer (it says both "everybody is done with the
+//     buffer about to be overwritten" and "everybody's share of this layer's weights has landed");
+//   * the feature-major stores of a GEMM's input (x0, h1..h3, d4..d1: 64 x 128-byte lines per wave and tensor) are issued
+//     between the MFMAs of the first 32 k-steps of the GEMM that consumes it, so that they have drained long before the
+//     next `s_waitcnt vmcnt(0)` (on gfx9 stores and loads share that counter: round 3a's kernel waited for the 64 stores of
+//     every layer before it could even request the next layer's weights);
+//   * the vertex ids / weights of the NEXT group are requested half a group ahead.
+// (round 3a, profiles/r03m_train_kernel_stats.txt: 5.5 ms per 2.1 M samples = 57 % of the MFMA-bound time.)
 constexpr int BWD_BLOCK = 256;
+constexpr int passes(size_t floats) { return (int)((floats + 1023) / 1024); }   // stage copies: whole 4 KB passes
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int P_W1 = passes(lfloats(KS1, OT)), P_W2 = passes(lfloats(KSH, OT)), P_W3 = passes(N_W3), P_WH = passes(N_WHEAD);
+constexpr int P_TH = passes(N_TH), P_T = passes(tfloats(OT)), P_T1 = passes(tfloats(OTI1));
+constexpr size_t BUF_A = 1024 * (size_t)cmax(cmax(P_W1, P_W3), cmax(P_TH, P_T));    // stages 0, 2, 4, 6
+constexpr size_t BUF_B = 1024 * (size_t)cmax(cmax(P_W2, P_WH), cmax(P_T, P_T1));    // stages 1, 3, 5, 7
+static_assert((BUF_A + BUF_B) * sizeof(float) <= 160 * 1024, "two weight stages must fit the CU's LDS");
+static_assert(OFF_WHEAD + 1024 * (size_t)P_WH <= PACK_FLOATS + PACK_SLACK, "the last stage copy over-reads into the pack's slack");
+static_assert(OFFT_1 + 1024 * (size_t)P_T1 <= PACKT_FLOATS, "transposed pack");
+
+// PASSES x 4 KB of a packed layer -> LDS, every thread the same number of async loads (whole passes: what lies behind the
+// layer in the pack lands in the buffer's padding)
+template <int PASSES>
+__device__ __forceinline__ void stage_fixed(float *lds, const float *__restrict__ src) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(lds);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) {
+        const uint32_t base = (uint32_t)it * BWD_BLOCK + wave0;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s4 + base + lane),
+                                         (__attribute__((address_space(3))) void *)(d4 + base), 16, 0, 0);
+    }
+}
+// every vector-memory operation of this wave has completed (its share of the staged weights has landed, its stores have
+// drained), then the block barrier
+__device__ __forceinline__ void layer_top() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// gemm_steps (tn_mlp_common.h) + the feature-major stores of the B operand: two values after each of the first NST / 2
+// k-steps.  LINEAR: consecutive values are n floats apart (x0); otherwise the accumulator order of store_slots.
+template <int KS, int KS0, int TILES, int NST, bool LINEAR>
+__device__ __forceinline__ void gemm_steps_store(f32x16 (&acc)[TILES], const float (&bin)[KSH], const float *lds, int lane,
+                                                 float *__restrict__ p, size_t n) {
+    const size_t n5 = 5 * n;
+    float a[TILES], an[TILES];
+    const float *w0 = lds + (size_t)KS0 * TILES * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) a[t] = w0[t * 64];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+            const float *wrow = lds + (size_t)(KS0 + ks + 1) * TILES * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) an[t] = wrow[t * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bin[ks], acc[t], 0, 0, 0);
+        if (2 * ks < NST) {
+#pragma unroll
+            for (int j = 2 * ks; j < 2 * ks + 2; ++j) {
+                *p = bin[j];
+                p += (LINEAR || (j & 3) != 3) ? n : n5;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) a[t] = an[t];
+    }
+}
 
 }  // namespace
 
@@ -118,25 +193,30 @@ __global__ __launch_bounds__(BWD_BLOCK) void k_mlp_backward(size_t n, uint32_t s
                                                             const float *__restrict__ pt, const float *__restrict__ d_sigma,
                                                             const float *__restrict__ d_rgb, BwdBuffers o) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *lds = reinterpret_cast<float *>(smem);
+    float *bufA = reinterpret_cast<float *>(smem), *bufB = bufA + BUF_A;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     constexpr size_t GROUP = (BWD_BLOCK / 64) * 32;
     const size_t ngroups = (n + GROUP - 1) / GROUP;
+    // the sample of this lane in group gg, clamped: lanes beyond the end recompute sample n - 1 and store the same values
+    // to the same places as its owner
+    auto sample_of = [&](size_t gg) {
+        const size_t s = gg * GROUP + (size_t)wave * 32 + (lane & 31);
+        return s < n ? s : n - 1;
+    };
+
+    stage_fixed<P_W1>(bufA, pk + OFF_W1);
+    size_t sc = sample_of(blockIdx.x);
+    uint4 v4 = *reinterpret_cast<const uint4 *>(vi + 4 * sc);
+    float b0 = bc[3 * sc], b1 = bc[3 * sc + 1], b2 = bc[3 * sc + 2];
 
     for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const size_t s = g * GROUP + (size_t)wave * 32 + (lane & 31);
-        const bool ok = s < n;
-        const size_t sc = ok ? s : n - 1;  // clamped: out-of-range lanes compute a duplicate, store nothing
         float bin[KSH];
         unsigned long long m1, m2, m3, m4;
+        f32x16 acc[OT];
 
         // ================= forward recompute =================
-        // ---- layer 1: fused barycentric gather (same summation order as interpolate_values) -> x0
-        __syncthreads();
-        stage_weights<BWD_BLOCK>(lds, pk + OFF_W1, lfloats(KS1, OT));
+        // ---- fused barycentric gather (same summation order as interpolate_values) -> x0
         {
-            const uint4 v4 = *reinterpret_cast<const uint4 *>(vi + 4 * sc);
-            const float b0 = bc[3 * sc], b1 = bc[3 * sc + 1], b2 = bc[3 * sc + 2];
             const float w0 = 1.0f - ((b0 + b1) + b2);
             const uint32_t vv[4] = {v4.y, v4.z, v4.w, v4.x};
             const float ww[4] = {b0, b1, b2, w0};
@@ -154,153 +234,135 @@ __global__ __launch_bounds__(BWD_BLOCK) void k_mlp_backward(size_t n, uint32_t s
                     }
                 }
             }
-            if (ok) {
-                float *p = o.x0 + (size_t)(32 * h) * n + s;
+        }
+        // per-sample inputs of the later layers, requested now
+        const float dsg = d_sigma[sc];
+        const float drg0 = d_rgb[3 * sc], drg1 = d_rgb[3 * sc + 1], drg2 = d_rgb[3 * sc + 2];
+        float ev[KSE];
+        {
+            const float *e = enc + (sc / samples_per_ray) * ENC_PAD;
 #pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) { *p = bin[ks]; p += n; }
-            }
+            for (int ks = 0; ks < KSE; ++ks) ev[ks] = e[2 * ks + h];
         }
-        stage_wait();
-        {
-            f32x16 acc[OT];
-            zero_acc(acc);
-            gemm_steps<KS1, 0, OT>(acc, bin, lds, lane);
-            bias_step<KS1, OT>(acc, lds, lane);
-            relu_to_bin(acc, bin);
-        }
+        // ---- layer 1 (weights: buffer A)
+        layer_top();
+        stage_fixed<P_W2>(bufB, pk + OFF_W2);
+        zero_acc(acc);
+        gemm_steps_store<KS1, 0, OT, KS1, true>(acc, bin, bufA, lane, o.x0 + (size_t)(32 * h) * n + sc, n);
+        bias_step<KS1, OT>(acc, bufA, lane);
+        relu_to_bin(acc, bin);
         m1 = mask_of(bin);
-        store_bin(o.h1, n, s, ok, bin, h);
-        // ---- layers 2, 3
-        __syncthreads();
-        stage_weights<BWD_BLOCK>(lds, pk + OFF_W2, lfloats(KSH, OT));
-        stage_wait();
-        {
-            f32x16 acc[OT];
-            zero_acc(acc);
-            gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
-            bias_step<KSH, OT>(acc, lds, lane);
-            relu_to_bin(acc, bin);
-        }
+        // ---- layer 2 (B)
+        layer_top();
+        stage_fixed<P_W3>(bufA, pk + OFF_W3);
+        zero_acc(acc);
+        gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, bufB, lane, o.h1 + (size_t)(4 * h) * n + sc, n);
+        bias_step<KSH, OT>(acc, bufB, lane);
+        relu_to_bin(acc, bin);
         m2 = mask_of(bin);
-        store_bin(o.h2, n, s, ok, bin, h);
-        __syncthreads();
-        stage_weights<BWD_BLOCK>(lds, pk + OFF_W3, N_W3);
-        stage_wait();
-        {
-            f32x16 acc[OT];
-            zero_acc(acc);
-            gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
-            bias_step<KSH, OT>(acc, lds, lane);
-            relu_to_bin(acc, bin);
-        }
+        // ---- layer 3 (A) + density head
+        layer_top();
+        stage_fixed<P_WH>(bufB, pk + OFF_WHEAD);
+        zero_acc(acc);
+        gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, bufA, lane, o.h2 + (size_t)(4 * h) * n + sc, n);
+        bias_step<KSH, OT>(acc, bufA, lane);
+        relu_to_bin(acc, bin);
         m3 = mask_of(bin);
-        store_bin(o.h3, n, s, ok, bin, h);
         float dsr;  // d L / d sigma_raw
         {
-            const float *dv = lds + lfloats(KSH, OT);
+            const float *dv = bufA + lfloats(KSH, OT);
             const float raw = head_dot(dv + 64 * h, bin) + dv[128];
             // softplus(beta = 1, threshold = 20): derivative sigmoid(raw), 1 beyond the threshold
             const float ds = raw > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-raw));
-            dsr = d_sigma[sc] * ds;
+            dsr = dsg * ds;
         }
-        // ---- head [enc(27) | base(128)] -> 128 ReLU, rgb head
-        __syncthreads();
-        stage_weights<BWD_BLOCK>(lds, pk + OFF_WHEAD, N_WHEAD);
-        stage_wait();
-        {
-            f32x16 acc[OT];
-            zero_acc(acc);
-            const float *e = enc + (sc / samples_per_ray) * ENC_PAD;
+        // ---- head [enc(27) | base(128)] -> 128 ReLU (B), rgb head
+        layer_top();
+        stage_fixed<P_TH>(bufA, pt + OFFT_H);
+        zero_acc(acc);
 #pragma unroll
-            for (int ks = 0; ks < KSE; ++ks) {
-                const float b = e[2 * ks + h];
-                const float *wrow = lds + (size_t)ks * OT * 64 + lane;
+        for (int ks = 0; ks < KSE; ++ks) {
+            const float *wrow = bufB + (size_t)ks * OT * 64 + lane;
 #pragma unroll
-                for (int t = 0; t < OT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], b, acc[t], 0, 0, 0);
-            }
-            gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
-            bias_step<HEAD_KS, OT>(acc, lds, lane);
-            relu_to_bin(acc, bin);
+            for (int t = 0; t < OT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], ev[ks], acc[t], 0, 0, 0);
         }
+        gemm_steps_store<KSH, KSE, OT, KSH, false>(acc, bin, bufB, lane, o.h3 + (size_t)(4 * h) * n + sc, n);
+        bias_step<HEAD_KS, OT>(acc, bufB, lane);
+        relu_to_bin(acc, bin);
         m4 = mask_of(bin);
-        store_bin(o.h4, n, s, ok, bin, h);
         // ================= backward =================
+        float d4v[KSH];
         {
             // rgb head: rgb = sigmoid(c), d c = d rgb * rgb * (1 - rgb); d h4 = Wr^T d c, masked by ReLU'(h4)
-            const float *cv = lds + lfloats(HEAD_KS, OT);
+            const float *cv = bufB + lfloats(HEAD_KS, OT);
+            const float drg[3] = {drg0, drg1, drg2};
             float drr[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float raw = head_dot(cv + 128 * c + 64 * h, bin) + cv[384 + c];
                 const float y = 1.0f / (1.0f + expf(-raw));
-                drr[c] = d_rgb[3 * sc + c] * (y * (1.0f - y));
+                drr[c] = drg[c] * (y * (1.0f - y));
             }
-            if (ok && h == 0) {
-                o.dhead[s] = dsr;
-                o.dhead[n + s] = drr[0]; o.dhead[2 * n + s] = drr[1]; o.dhead[3 * n + s] = drr[2];
+            if (h == 0) {
+                o.dhead[sc] = dsr;
+                o.dhead[n + sc] = drr[0]; o.dhead[2 * n + sc] = drr[1]; o.dhead[3 * n + sc] = drr[2];
             }
             const float *w0 = cv + 64 * h, *w1 = cv + 128 + 64 * h, *w2 = cv + 256 + 64 * h;
 #pragma unroll
             for (int j = 0; j < KSH; ++j) {
                 const float v = (w0[j] * drr[0] + w1[j] * drr[1]) + w2[j] * drr[2];
-                bin[j] = ((m4 >> j) & 1ull) ? v : 0.f;
+                d4v[j] = ((m4 >> j) & 1ull) ? v : 0.f;
             }
         }
-        store_bin(o.d4, n, s, ok, bin, h);
-        // ---- d h3 = Wh[:, 27:]^T d_pre4 + wd * d sigma_raw, masked
-        __syncthreads();
-        stage_weights<BWD_BLOCK>(lds, pt + OFFT_H, N_TH);
-        stage_wait();
+        // ---- d h3 = Wh[:, 27:]^T d_pre4 + wd * d sigma_raw, masked (A).  h4 leaves only now: its stores have this GEMM to drain
+        layer_top();
+        stage_fixed<P_T>(bufB, pt + OFFT_3);
+        store_bin(o.h4, n, sc, true, bin, h);
+#pragma unroll
+        for (int j = 0; j < KSH; ++j) bin[j] = d4v[j];
+        // the next group's sample descriptors
+        const size_t scn = sample_of(g + gridDim.x < ngroups ? g + gridDim.x : g);
+        const uint4 v4n = *reinterpret_cast<const uint4 *>(vi + 4 * scn);
+        const float b0n = bc[3 * scn], b1n = bc[3 * scn + 1], b2n = bc[3 * scn + 2];
+        zero_acc(acc);
+        gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, bufA, lane, o.d4 + (size_t)(4 * h) * n + sc, n);
         {
-            f32x16 acc[OT];
-            zero_acc(acc);
-            gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
-            const float *dv = lds + tfloats(OT) + 64 * h;
+            const float *dv = bufA + tfloats(OT) + 64 * h;
 #pragma unroll
             for (int t = 0; t < OT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] += dv[t * 16 + r] * dsr;
             masked_to_bin(acc, m3, bin);
         }
-        store_bin(o.d3, n, s, ok, bin, h);
-        // ---- d h2 = W3^T d_pre3, d h1 = W2^T d_pre2
-        __syncthreads();
-        stage_weights<BWD_BLOCK>(lds, pt + OFFT_3, tfloats(OT));
-        stage_wait();
+        // ---- d h2 = W3^T d_pre3 (B), d h1 = W2^T d_pre2 (A)
+        layer_top();
+        stage_fixed<P_T>(bufA, pt + OFFT_2);
+        zero_acc(acc);
+        gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, bufB, lane, o.d3 + (size_t)(4 * h) * n + sc, n);
+        masked_to_bin(acc, m2, bin);
+        layer_top();
+        stage_fixed<P_T1>(bufB, pt + OFFT_1);
+        zero_acc(acc);
+        gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, bufA, lane, o.d2 + (size_t)(4 * h) * n + sc, n);
+        masked_to_bin(acc, m1, bin);
+        // ---- d x0 = W1^T d_pre1  (64 input features = 2 tiles) (B); the next group's first layer goes to A meanwhile
+        layer_top();
+        stage_fixed<P_W1>(bufA, pk + OFF_W1);
         {
-            f32x16 acc[OT];
-            zero_acc(acc);
-            gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
-            masked_to_bin(acc, m2, bin);
-        }
-        store_bin(o.d2, n, s, ok, bin, h);
-        __syncthreads();
-        stage_weights<BWD_BLOCK>(lds, pt + OFFT_2, tfloats(OT));
-        stage_wait();
-        {
-            f32x16 acc[OT];
-            zero_acc(acc);
-            gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
-            masked_to_bin(acc, m1, bin);
-        }
-        store_bin(o.d1, n, s, ok, bin, h);
-        // ---- d x0 = W1^T d_pre1  (64 input features = 2 tiles)
-        __syncthreads();
-        stage_weights<BWD_BLOCK>(lds, pt + OFFT_1, tfloats(OTI1));
-        stage_wait();
-        {
-            f32x16 acc[OTI1];
-            zero_acc(acc);
-            gemm_steps<KSH, 0, OTI1>(acc, bin, lds, lane);
+            f32x16 acc2[OTI1];
+            zero_acc(acc2);
+            gemm_steps_store<KSH, 0, OTI1, KSH, false>(acc2, bin, bufB, lane, o.d1 + (size_t)(4 * h) * n + sc, n);
             float dx[OTI1 * 16];
 #pragma unroll
             for (int t = 0; t < OTI1; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dx[t * 16 + r] = acc[t][r];
-            store_slots<OTI1 * 16>(o.dx0, n, s, ok, dx, h);
+                for (int r = 0; r < 16; ++r) dx[t * 16 + r] = acc2[t][r];
+            store_slots<OTI1 * 16>(o.dx0, n, sc, true, dx, h);
         }
+        sc = scn; v4 = v4n; b0 = b0n; b1 = b1n; b2 = b2n;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (unused) stage copy must not outlive the block's LDS
 }
 
 // Adjoint of k_composite (RaySamples.get_weights + RGB / accumulation renderers, model.py:632-638; the median depth has
@@ -389,8 +451,7 @@ void launch_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vi,
     const float *pk = w.pk_gather, *pt = w.pt;
     float *enc = w.enc;
     launch_dir_encoding(num_rays, dirs, enc, stream);
-    const size_t stage = MAX_STAGE_FLOATS > N_TH ? MAX_STAGE_FLOATS : N_TH;
-    const size_t smem = stage * sizeof(float);
+    const size_t smem = (BUF_A + BUF_B) * sizeof(float);
     static PerDeviceOnce lds_attr;
     lds_attr.run([&] { allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_backward), smem); });
     const size_t group = (BWD_BLOCK / 64) * 32;
