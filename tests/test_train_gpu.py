@@ -1,5 +1,5 @@
 """Training adjoints on the GPU: the fused MLP node (tn_mlp_forward_gather / tn_mlp_backward /
-tn_mlp_weight_grad / tn_interpolate_values_backward), the composite node (tn_composite / tn_composite_backward) and
+tn_mlp_param_grads / tn_interpolate_values_backward), the composite node (tn_composite / tn_composite_backward) and
 GradientScaler (model.py:195-205), against PyTorch autograd of the plain statement in render.py -- in float64 as the
 ground truth, with the float32 autograd result as the yardstick for what fp32 can deliver."""
 import importlib

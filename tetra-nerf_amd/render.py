@@ -246,7 +246,7 @@ class GradientScaler(torch.autograd.Function):
 
 class _FusedMlpFunction(torch.autograd.Function):
     """gather + MLP + heads as ONE autograd node: forward = tn_mlp_forward_gather (nothing saved but the inputs),
-    backward = tn_mlp_backward + tn_mlp_weight_grad + tn_interpolate_values_backward (recompute, dX chain and weight
+    backward = tn_mlp_backward + tn_mlp_param_grads + tn_interpolate_values_backward (recompute, dX chain and weight
     gradients on the fp32 matrix cores).  Gradients flow to the field and the 12 weight tensors."""
 
     @staticmethod
