@@ -325,7 +325,8 @@ int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, cons
  * network on the fp32 matrix cores.  All buffers are FEATURE-MAJOR [F, n] device memory owned by the caller:
  *   x0 [64,n] gathered features; h1..h4 [128,n] layer outputs after ReLU; d1..d4 [128,n] gradients w.r.t. the
  *   pre-activations of mlp_base layers 0..2 and of mlp_head; dhead [4,n] = d sigma_raw, d rgb_raw[0..2];
- *   dx0 [64,n] = gradient of the gathered features (feed it to tn_interpolate_values_backward).
+ *   and dx0 [n,64] = gradient of the gathered features as SAMPLE-major rows (feed it to
+ *   tn_interpolate_values_backward_vm / _rows).
  * field_vm is the field vertex-major [V,64] (tn_transpose_f32); d_sigma f32 [n], d_rgb f32 [n,3].
  * tn_mlp_param_grads then ACCUMULATES the gradients of the twelve parameter tensors (tn_mlp_grads: fp32 gradient
  * buffers in nn.Linear layout, zeroed by the caller before the first chunk) from those buffers: dW_l = d_l (input of

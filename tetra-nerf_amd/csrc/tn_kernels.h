@@ -151,7 +151,7 @@ struct MlpBackwardBuffers {
     float *h1, *h2, *h3, *h4;  // [128, n]  layer outputs after ReLU (inputs of the next layer's weight gradient)
     float *d1, *d2, *d3, *d4;  // [128, n]  gradients w.r.t. the pre-activations of layers 1, 2, 3 and the head layer
     float *dhead;              // [4, n]    d sigma_raw, d rgb_raw[0..2]
-    float *dx0;                // [64, n]   gradient w.r.t. the gathered features
+    float *dx0;                // [n, 64]   gradient w.r.t. the gathered features, sample-major rows
 };
 // recompute + dX chain: field_vm is the field vertex-major [V, 64]; d_sigma [n], d_rgb [n, 3]
 void launch_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vi, const float *bc, const float *field_vm,

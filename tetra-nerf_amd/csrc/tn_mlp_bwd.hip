@@ -69,7 +69,7 @@ struct BwdBuffers {
     float *h1, *h2, *h3, *h4;  // [128, n] layer outputs after ReLU
     float *d1, *d2, *d3, *d4;  // [128, n] gradients w.r.t. the pre-activations of layers 1, 2, 3 and the head layer
     float *dhead;              // [4, n]   d sigma_raw, d rgb_raw[0..2]
-    float *dx0;                // [64, n]  gradient of the gathered features
+    float *dx0;                // [n, 64]  gradient of the gathered features, SAMPLE-major rows (what the gather adjoint reads)
 };
 
 // bin slot j of half-wave h holds feature acc_k(j, h) = 32 (j >> 4) + (j & 3) + 8 ((j >> 2) & 3) + 4 h: from slot to slot
@@ -128,6 +128,7 @@ constexpr size_t BUF_B = 1024 * (size_t)cmax(cmax(P_W2, P_WH), cmax(P_T, P_T1));
 static_assert((BUF_A + BUF_B) * sizeof(float) <= 160 * 1024, "two weight stages must fit the CU's LDS");
 static_assert(OFF_WHEAD + 1024 * (size_t)P_WH <= PACK_FLOATS + PACK_SLACK, "the last stage copy over-reads into the pack's slack");
 static_assert(OFFT_1 + 1024 * (size_t)P_T1 <= PACKT_FLOATS, "transposed pack");
+static_assert(tfloats(OTI1) + (BWD_BLOCK / 64) * 32 * 65 <= BUF_B, "d x0 transposition behind the last stage");
 
 // PASSES x 4 KB of a packed layer -> LDS, every thread the same number of async loads (whole passes: what lies behind the
 // layer in the pack lands in the buffer's padding)
@@ -353,12 +354,20 @@ __global__ __launch_bounds__(BWD_BLOCK) void k_mlp_backward(size_t n, uint32_t s
             f32x16 acc2[OTI1];
             zero_acc(acc2);
             gemm_steps_store<KSH, 0, OTI1, KSH, false>(acc2, bin, bufB, lane, o.d1 + (size_t)(4 * h) * n + sc, n);
-            float dx[OTI1 * 16];
+            // d x0 leaves as SAMPLE-major rows [n, 64] (the gather adjoint reads a sample's gradient as one 256-byte line;
+            // round 3a wrote it feature-major and transposed 0.5 GB per iteration): through this wave's slice of the free
+            // tail of buffer B ([32 samples][65]: conflict-free both ways), each sample's 64 values then go out as one
+            // coalesced store
+            float *tr = bufB + tfloats(OTI1) + (size_t)wave * (32 * 65);
+            {
+                float *col = tr + (lane & 31) * 65 + 4 * h;
 #pragma unroll
-            for (int t = 0; t < OTI1; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dx[t * 16 + r] = acc2[t][r];
-            store_slots<OTI1 * 16>(o.dx0, n, sc, true, dx, h);
+                for (int j = 0; j < OTI1 * 16; ++j) col[32 * (j >> 4) + (j & 3) + 8 * ((j >> 2) & 3)] = acc2[j >> 4][j & 15];
+            }
+            const size_t s0 = g * GROUP + (size_t)wave * 32;
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i)
+                if (s0 + i < n) o.dx0[(s0 + i) * FD + lane] = tr[i * 65 + lane];
         }
         sc = scn; v4 = v4n; b0 = b0n; b1 = b1n; b2 = b2n;
     }

@@ -741,17 +741,16 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
             r1 = min(R, r0 + rays_per_chunk)
             m = (r1 - r0) * S
             c0 = r0 * S
-            buf = _empty((64 + 8 * 128 + 4 + 64, m), dtype=torch.float32, device=dev)
+            buf = _empty((64 + 8 * 128 + 4, m), dtype=torch.float32, device=dev)
             x0, h1, h2, h3, h4 = buf[0:64], buf[64:192], buf[192:320], buf[320:448], buf[448:576]
             d1, d2, d3, d4 = buf[576:704], buf[704:832], buf[832:960], buf[960:1088]
-            dhead, dx0 = buf[1088:1092], buf[1092:1156]
-            bs = _MlpBackwardBuffers(*[t.data_ptr() for t in (x0, h1, h2, h3, h4, d1, d2, d3, d4, dhead, dx0)])
+            dhead = buf[1088:1092]
+            rows = _empty((m, 64), dtype=torch.float32, device=dev)     # d x0, sample-major
+            bs = _MlpBackwardBuffers(*[t.data_ptr() for t in (x0, h1, h2, h3, h4, d1, d2, d3, d4, dhead, rows)])
             _lib.check(lib.tn_mlp_backward(mh.handle, m, S, _ptr(vi[c0:]), _ptr(bc[c0:]), _ptr(field_vm), _ptr(dirs[r0:]),
                                            _ptr(d_sigma[c0:]), _ptr(d_rgb[c0:]), C.byref(bs), stream))
             _lib.check(lib.tn_mlp_param_grads(mh.handle, m, S, _ptr(dirs[r0:]), C.byref(bs), C.byref(gs), stream))
             # gradient of the gathered features -> field (vertex-major accumulation)
-            rows = _empty((m, 64), dtype=torch.float32, device=dev)
-            _lib.check(lib.tn_transpose_f32(64, m, _ptr(dx0), _ptr(rows), stream))
             _lib.check(lib.tn_interpolate_values_backward_vm(4, m, 64, _ptr(vi[c0:]), _ptr(bc[c0:]), _ptr(rows), _ptr(grad_vm),
                                                              stream))
             del buf, rows
