@@ -319,25 +319,32 @@ int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, cons
                  float background, float *out_rgb, float *out_acc, float *out_depth, float *out_weights,
                  void *stream);
 
-/* ---- training adjoints of the MLP and the composite (PyTorch autograd in the reference:
- * the trainer back-propagates through nerfstudio's MLP / renderers, model.py:602-638).
- * tn_mlp_backward (weights: the handle's) recomputes the forward pass (nothing is saved by tn_mlp_forward_gather) and runs the reverse
- * network on the fp32 matrix cores.  All buffers are FEATURE-MAJOR [F, n] device memory owned by the caller:
- *   x0 [64,n] gathered features; h1..h4 [128,n] layer outputs after ReLU; d1..d4 [128,n] gradients w.r.t. the
- *   pre-activations of mlp_base layers 0..2 and of mlp_head; dhead [4,n] = d sigma_raw, d rgb_raw[0..2];
- *   and dx0 [n,64] = gradient of the gathered features as SAMPLE-major rows (feed it to
- *   tn_interpolate_values_backward_vm / _rows).
- * field_vm is the field vertex-major [V,64] (tn_transpose_f32); d_sigma f32 [n], d_rgb f32 [n,3].
- * tn_mlp_param_grads then ACCUMULATES the gradients of the twelve parameter tensors (tn_mlp_grads: fp32 gradient
- * buffers in nn.Linear layout, zeroed by the caller before the first chunk) from those buffers: dW_l = d_l (input of
- * layer l)^T as sample-streaming fp32-MFMA GEMMs (the 27 direction-encoding columns of mlp_head and the density head's
- * vector ride along the mlp_head GEMM), the rgb head / bias sums as one bandwidth-bound pass; per-block partial sums are
- * added in a fixed order (no atomics): bit-reproducible.  dirs f32 [n / samples_per_ray, 3] as in tn_mlp_backward. */
+/* ---- training: the MLP node and the composite node (PyTorch autograd in the reference: the trainer
+ * back-propagates through nerfstudio's MLP / renderers, model.py:602-638).  Three calls per batch of n samples, all on
+ * the handle's weights, fp32 MFMA:
+ *   tn_mlp_forward_gather_train  = tn_mlp_forward_gather (mode 0) that also SAVES what the backward pass needs:
+ *       x0 [64,n] gathered features, h1..h4 [128,n] layer outputs after ReLU (feature-major: the operands of the
+ *       weight-gradient GEMMs) and masks [4,n,2] u64 = the ReLU masks of h1..h4 (all the dX chain needs);
+ *   tn_mlp_backward  runs the reverse network from the masks and the forward's OUTPUTS sigma [n] / rgb [n,3]
+ *       (softplus' = 1 - exp(-sigma), sigmoid' = rgb (1 - rgb)) -- nothing is recomputed -- given d_sigma f32 [n],
+ *       d_rgb f32 [n,3]; fills d1..d4 [128,n] (gradients w.r.t. the pre-activations of mlp_base layers 0..2 and of
+ *       mlp_head), dhead [4,n] = d sigma_raw, d rgb_raw[0..2], and dx0 [n,64] = the gradient of the gathered features as
+ *       SAMPLE-major rows (feed it to tn_interpolate_values_backward_vm / _rows);
+ *   tn_mlp_param_grads  ACCUMULATES the gradients of the twelve parameter tensors (tn_mlp_grads: fp32 gradient buffers
+ *       in nn.Linear layout, zeroed by the caller before the first batch) from those buffers: dW_l = d_l (input of
+ *       layer l)^T as sample-streaming fp32-MFMA GEMMs (the 27 direction-encoding columns of mlp_head and the density
+ *       head's vector ride along the mlp_head GEMM), the rgb head / bias sums as one bandwidth-bound pass; per-block
+ *       partial sums are added in a fixed order (no atomics): bit-reproducible.  dirs f32 [n / samples_per_ray, 3].
+ * All buffers are device memory owned by the caller (4.4 KB per sample in total). */
 typedef struct tn_mlp_backward_buffers {
-    float *x0, *h1, *h2, *h3, *h4, *d1, *d2, *d3, *d4, *dhead, *dx0;
+    float *x0, *h1, *h2, *h3, *h4;   /* forward -> param_grads */
+    void *masks;                     /* forward -> backward: u64 [4, n, 2] */
+    float *d1, *d2, *d3, *d4, *dhead, *dx0;   /* backward -> param_grads / gather adjoint */
 } tn_mlp_backward_buffers;
-int tn_mlp_backward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices, const float *barycentric,
-                    const float *field_vm, const float *dirs, const float *d_sigma, const float *d_rgb,
+int tn_mlp_forward_gather_train(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices,
+                                const float *barycentric, const float *field_vm, const float *dirs, float *sigma, float *rgb,
+                                const tn_mlp_backward_buffers *buffers, void *stream);
+int tn_mlp_backward(tn_mlp_t mlp, size_t n, const float *sigma, const float *rgb, const float *d_sigma, const float *d_rgb,
                     const tn_mlp_backward_buffers *buffers, void *stream);
 typedef struct tn_mlp_grads { /* same shapes as tn_mlp_weights */
     float *w1, *b1, *w2, *b2, *w3, *b3, *wd, *bd, *wh, *bh, *wr, *br;

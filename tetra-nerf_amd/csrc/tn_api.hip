@@ -833,18 +833,39 @@ int tn_render_pass(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const 
     });
 }
 
-int tn_mlp_backward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices, const float *barycentric,
-                    const float *field_vm, const float *dirs, const float *d_sigma, const float *d_rgb,
+namespace {
+tn::MlpBackwardBuffers training_buffers(const tn_mlp_backward_buffers *b) {
+    return tn::MlpBackwardBuffers{b->x0, b->h1, b->h2, b->h3, b->h4, (unsigned long long *)b->masks,
+                                  b->d1, b->d2, b->d3, b->d4, b->dhead, b->dx0};
+}
+}  // namespace
+
+int tn_mlp_forward_gather_train(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices,
+                                const float *barycentric, const float *field_vm, const float *dirs, float *sigma, float *rgb,
+                                const tn_mlp_backward_buffers *b, void *stream_) {
+    return guarded([&] {
+        tn_mlp *m = checked_mlp(mlp);
+        if (n == 0) return;
+        if (!vertex_indices || !barycentric || !field_vm || !dirs || !sigma || !rgb || !b) throw tn::Error("null pointer");
+        if (!b->x0 || !b->h1 || !b->h2 || !b->h3 || !b->h4 || !b->masks) throw tn::Error("null pointer");
+        if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
+        DeviceGuard g(m->device);
+        const size_t rays = n / samples_per_ray;
+        tn::launch_mlp_forward_train(n, samples_per_ray, rays, vertex_indices, barycentric, field_vm, dirs, m->packs(rays), sigma, rgb,
+                                     training_buffers(b), (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_mlp_backward(tn_mlp_t mlp, size_t n, const float *sigma, const float *rgb, const float *d_sigma, const float *d_rgb,
                     const tn_mlp_backward_buffers *b, void *stream_) {
     return guarded([&] {
         tn_mlp *m = checked_mlp(mlp);
         if (n == 0) return;
-        if (!b || !vertex_indices || !barycentric || !field_vm || !dirs || !d_sigma || !d_rgb) throw tn::Error("null pointer");
-        if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
+        if (!b || !sigma || !rgb || !d_sigma || !d_rgb) throw tn::Error("null pointer");
+        if (!b->masks || !b->d1 || !b->d2 || !b->d3 || !b->d4 || !b->dhead || !b->dx0) throw tn::Error("null pointer");
         DeviceGuard g(m->device);
-        tn::MlpBackwardBuffers bb{b->x0, b->h1, b->h2, b->h3, b->h4, b->d1, b->d2, b->d3, b->d4, b->dhead, b->dx0};
-        tn::launch_mlp_backward(n, samples_per_ray, vertex_indices, barycentric, field_vm, dirs, m->packs(n / samples_per_ray),
-                                d_sigma, d_rgb, bb, (hipStream_t)stream_);
+        tn::launch_mlp_backward(n, sigma, rgb, m->packs(0), d_sigma, d_rgb, training_buffers(b), (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }
@@ -865,7 +886,7 @@ int tn_mlp_param_grads(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const f
             TN_HIP(hipDeviceSynchronize());
             m->grad_scratch.alloc(tn::mlp_param_grad_scratch_floats());
         }
-        tn::MlpBackwardBuffers bb{b->x0, b->h1, b->h2, b->h3, b->h4, b->d1, b->d2, b->d3, b->d4, b->dhead, b->dx0};
+        const tn::MlpBackwardBuffers bb = training_buffers(b);
         tn::MlpParamGrads pg{gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], gp[6], gp[7], gp[8], gp[9], gp[10], gp[11]};
         tn::launch_mlp_param_grads(n, samples_per_ray, dirs, m->packs(n / samples_per_ray), bb, pg, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());

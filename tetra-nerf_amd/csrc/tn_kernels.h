@@ -145,17 +145,25 @@ void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, con
 void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
                            const float *bc, const float *fieldT, const float *dirs, const MlpPacks &w, float *sigma, float *rgb,
                            hipStream_t stream);
-// training adjoint of the MLP (tn_mlp_bwd.hip).  All buffers feature-major [F, n] device memory owned by the caller.
+// Training (tn_mlp.hip: TRAIN variant of the forward kernel, tn_mlp_bwd.hip, tn_mlp_grad.hip).  The training forward SAVES
+// the layer inputs and the ReLU masks; the backward kernel runs the reverse network from the masks alone (no recompute);
+// the parameter-gradient GEMMs contract the saved inputs with the gradients it leaves.  Feature-major [F, n] device memory
+// owned by the caller.
 struct MlpBackwardBuffers {
-    float *x0;                 // [64, n]   gathered features (layer-1 input)
-    float *h1, *h2, *h3, *h4;  // [128, n]  layer outputs after ReLU (inputs of the next layer's weight gradient)
-    float *d1, *d2, *d3, *d4;  // [128, n]  gradients w.r.t. the pre-activations of layers 1, 2, 3 and the head layer
-    float *dhead;              // [4, n]    d sigma_raw, d rgb_raw[0..2]
-    float *dx0;                // [n, 64]   gradient w.r.t. the gathered features, sample-major rows
+    float *x0;                 // [64, n]   gathered features (layer-1 input)                              forward -> grads
+    float *h1, *h2, *h3, *h4;  // [128, n]  layer outputs after ReLU (inputs of the next layer)             forward -> grads
+    unsigned long long *masks; // [4, n, 2] ReLU masks of h1..h4: bit j of word (layer, sample, half) = slot j   forward -> backward
+    float *d1, *d2, *d3, *d4;  // [128, n]  gradients w.r.t. the pre-activations of layers 1, 2, 3 and the head layer   backward -> grads
+    float *dhead;              // [4, n]    d sigma_raw, d rgb_raw[0..2]                                   backward -> grads
+    float *dx0;                // [n, 64]   gradient w.r.t. the gathered features, sample-major rows       backward -> gather adjoint
 };
-// recompute + dX chain: field_vm is the field vertex-major [V, 64]; d_sigma [n], d_rgb [n, 3]
-void launch_mlp_backward(size_t n, uint32_t samples_per_ray, const uint32_t *vi, const float *bc, const float *field_vm,
-                         const float *dirs, const MlpPacks &w, const float *d_sigma, const float *d_rgb,
+// launch_mlp_forward in fp32 with GATHER, which also fills x0, h1..h4 and masks of `save`
+void launch_mlp_forward_train(size_t n, uint32_t samples_per_ray, size_t num_rays, const uint32_t *vi, const float *bc,
+                              const float *fieldT, const float *dirs, const MlpPacks &w, float *sigma, float *rgb,
+                              const MlpBackwardBuffers &save, hipStream_t stream);
+// dX chain from the saved masks and the forward's OUTPUTS sigma [n] / rgb [n, 3] (softplus' = 1 - exp(-sigma),
+// sigmoid' = rgb (1 - rgb)); d_sigma [n], d_rgb [n, 3]; fills d1..d4, dhead, dx0
+void launch_mlp_backward(size_t n, const float *sigma, const float *rgb, const MlpPacks &w, const float *d_sigma, const float *d_rgb,
                          const MlpBackwardBuffers &b, hipStream_t stream);
 // parameter gradients (tn_mlp_grad.hip), ACCUMULATED into the twelve tensors (nn.Linear layout: w1 [128,64], b1, w2, b2, w3,
 // b3 [128..], wd [1,128], bd [1], wh [128,155], bh, wr [3,128], br [3]) from the buffers launch_mlp_backward left for the

@@ -96,12 +96,16 @@ __global__ void k_dir_encoding(size_t R, const float *__restrict__ dirs, float *
 // BLOCK = 512: 8 waves share each staged layer, one block per CU.  BLOCK = 256: 4 waves per block and TWO blocks per CU
 // (the head layer staged in two halves so that the largest stage is 67 KB): while one block waits for a weight copy or
 // at a barrier the other one's waves keep the matrix cores busy.
-template <bool GATHER, bool DENSITY_ONLY, int BLOCK = MLP_BLOCK>
+// TRAIN: the layer inputs x0, h1..h4 (feature-major, what the weight-gradient GEMMs contract) and the ReLU masks (all the
+// dX kernel needs) are saved on the way -- the backward pass recomputes nothing (round 3a recomputed the whole forward
+// inside the dX kernel: 2.2 of its 5 ms).
+struct FwdSave { float *x0, *h1, *h2, *h3, *h4; unsigned long long *masks; };
+template <bool GATHER, bool DENSITY_ONLY, int BLOCK = MLP_BLOCK, bool TRAIN = false>
 __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t samples_per_ray, const float *__restrict__ feats,
                                                            const uint32_t *__restrict__ vi, const float *__restrict__ bc,
                                                            const float *__restrict__ fieldT,
                                                            const float *__restrict__ enc, const float *__restrict__ pk,
-                                                           float *__restrict__ sigma, float *__restrict__ rgb) {
+                                                           float *__restrict__ sigma, float *__restrict__ rgb, FwdSave sv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
@@ -144,6 +148,13 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
                 }
             }
         }
+        if constexpr (TRAIN) {
+            if (s < n) {
+                float *p = sv.x0 + (size_t)(32 * h) * n + s;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) { *p = bin[ks]; p += n; }
+            }
+        }
         stage_wait();
         {
             f32x16 acc[OT];
@@ -152,6 +163,13 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
             bias_step<KS1, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);
         }
+        auto save_layer = [&](float *dst, int layer) {
+            if constexpr (TRAIN) {
+                store_bin(dst, n, s, s < n, bin, h);
+                if (s < n) sv.masks[((size_t)layer * n + s) * 2 + h] = mask_of(bin);
+            }
+        };
+        save_layer(sv.h1, 0);
         // ---- layers 2, 3: 128 -> 128, accumulators fed back as B operands
         __syncthreads();
         stage_weights<BLOCK>(lds, pk + OFF_W2, lfloats(KSH, OT));
@@ -163,6 +181,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
             bias_step<KSH, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);
         }
+        save_layer(sv.h2, 1);
         __syncthreads();
         stage_weights<BLOCK>(lds, pk + OFF_W3, N_W3);
         stage_wait();
@@ -173,6 +192,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
             bias_step<KSH, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);  // mlp_base out_activation = ReLU
         }
+        save_layer(sv.h3, 2);
         {
             // density head 128 -> 1 + softplus on the VALU (the vector rides behind layer 3's weights)
             const float *dv = lds + lfloats(KSH, OT);
@@ -211,6 +231,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
             }
             relu_to_bin(acc, bin);
         }
+        save_layer(sv.h4, 3);
         {
             // rgb head 128 -> 3 + sigmoid on the VALU
             const float *cv = lds + (SPLIT_HEAD ? lfloats(KSH - (HEAD_KS_A - KSE), OT) : lfloats(HEAD_KS, OT));
@@ -330,12 +351,28 @@ void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, con
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
 #define TN_MLP_LAUNCH(G, D)                                                                                         \
     hipLaunchKernelGGL((k_mlp_forward<G, D>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc, \
-                       fieldT, enc, pk, sigma, rgb)
+                       fieldT, enc, pk, sigma, rgb, FwdSave{})
     if (gather && density_only) TN_MLP_LAUNCH(true, true);
     else if (gather) TN_MLP_LAUNCH(true, false);
     else if (density_only) TN_MLP_LAUNCH(false, true);
     else TN_MLP_LAUNCH(false, false);
 #undef TN_MLP_LAUNCH
+}
+
+void launch_mlp_forward_train(size_t n, uint32_t samples_per_ray, size_t num_rays, const uint32_t *vi, const float *bc,
+                              const float *fieldT, const float *dirs, const MlpPacks &w, float *sigma, float *rgb,
+                              const MlpBackwardBuffers &save, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_dir_encoding, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, stream, num_rays, dirs, w.enc);
+    const size_t smem = MAX_STAGE_FLOATS * sizeof(float);
+    static PerDeviceOnce lds_attr;
+    lds_attr.run([&] { allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, false, MLP_BLOCK, true>), smem); });
+    const size_t group = (MLP_BLOCK / 64) * 32;
+    const size_t ngroups = (n + group - 1) / group;
+    const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
+    hipLaunchKernelGGL((k_mlp_forward<true, false, MLP_BLOCK, true>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray,
+                       (const float *)nullptr, vi, bc, fieldT, w.enc, w.pk_gather, sigma, rgb,
+                       FwdSave{save.x0, save.h1, save.h2, save.h3, save.h4, save.masks});
 }
 
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,

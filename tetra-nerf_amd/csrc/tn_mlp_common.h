@@ -139,6 +139,32 @@ static __device__ __forceinline__ void relu_to_bin(const f32x16 (&acc)[TILES], f
 }
 
 
+// slot j of half-wave h holds feature acc_k(j, h) = 32 (j >> 4) + (j & 3) + 8 ((j >> 2) & 3) + 4 h: from slot to slot
+// the feature grows by 1, or by 5 after every fourth slot -- the feature-major stores ([F, n]: a register of the wave = one
+// feature of 32 consecutive samples = one 128-byte line) walk one pointer with two strides (64 independent row addresses
+// would be hoisted out of the sample loop and spill).
+template <int COUNT>
+static __device__ __forceinline__ void store_slots(float *__restrict__ dst, size_t n, size_t s, bool ok, const float (&vals)[COUNT], int h) {
+    if (!ok) return;
+    float *p = dst + (size_t)(4 * h) * n + s;
+    const size_t n1 = n, n5 = 5 * n;
+#pragma unroll
+    for (int j = 0; j < COUNT; ++j) {
+        *p = vals[j];
+        p += ((j & 3) == 3) ? n5 : n1;
+    }
+}
+static __device__ __forceinline__ void store_bin(float *__restrict__ dst, size_t n, size_t s, bool ok, const float (&bin)[KSH], int h) {
+    store_slots<KSH>(dst, n, s, ok, bin, h);
+}
+// ReLU mask of the 64 activations a lane holds (slot j: bit j); stored as masks[(layer * n + sample) * 2 + half]
+static __device__ __forceinline__ unsigned long long mask_of(const float (&bin)[KSH]) {
+    unsigned long long m = 0;
+#pragma unroll
+    for (int j = 0; j < KSH; ++j) m |= (unsigned long long)(bin[j] > 0.f ? 1u : 0u) << j;
+    return m;
+}
+
 }  // namespace mlp
 
 // packers / encoders of tn_mlp.hip, used by the training path as well

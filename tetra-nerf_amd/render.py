@@ -245,25 +245,28 @@ class GradientScaler(torch.autograd.Function):
 
 
 class _FusedMlpFunction(torch.autograd.Function):
-    """gather + MLP + heads as ONE autograd node: forward = tn_mlp_forward_gather (nothing saved but the inputs),
-    backward = tn_mlp_backward + tn_mlp_param_grads + tn_interpolate_values_backward (recompute, dX chain and weight
-    gradients on the fp32 matrix cores).  Gradients flow to the field and the 12 weight tensors."""
+    """gather + MLP + heads as ONE autograd node: forward = tn_mlp_forward_gather_train (fp32; saves the layer inputs and the
+    ReLU masks, 2.3 KB per sample), backward = tn_mlp_backward + tn_mlp_param_grads + tn_interpolate_values_backward (dX
+    chain and weight gradients on the fp32 matrix cores, nothing recomputed).  Gradients flow to the field and the 12
+    weight tensors."""
 
     @staticmethod
     def forward(ctx, vertex_indices, barycentric_coordinates, field, dirs, samples_per_ray, *weights):
         from . import tetranerf_cpp_extension as cpp
 
+        sigma, rgb, saved = cpp.mlp_forward_gather_train(vertex_indices, barycentric_coordinates, field, dirs, list(weights),
+                                                         int(samples_per_ray))
         ctx.save_for_backward(vertex_indices, barycentric_coordinates, field, dirs, *weights)
-        ctx.S = int(samples_per_ray)
-        return cpp.mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, list(weights), ctx.S)
+        ctx.saved = saved
+        return sigma, rgb
 
     @staticmethod
     def backward(ctx, d_sigma, d_rgb):
         from . import tetranerf_cpp_extension as cpp
 
         vi, bc, field, dirs, *weights = ctx.saved_tensors
-        grad_field, grads = cpp.mlp_backward(vi, bc, field, dirs, list(weights), ctx.S,
-                                             d_sigma.contiguous(), d_rgb.contiguous())
+        saved, ctx.saved = ctx.saved, None
+        grad_field, grads = cpp.mlp_backward(saved, vi, bc, field, dirs, list(weights), d_sigma.contiguous(), d_rgb.contiguous())
         return (None, None, grad_field, None, None, *grads)
 
 

@@ -704,21 +704,58 @@ def composite(sigma, rgb, edges, background=1.0, return_weights=False):
 
 
 class _MlpBackwardBuffers(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("x0", "h1", "h2", "h3", "h4", "d1", "d2", "d3", "d4", "dhead", "dx0")]
+    _fields_ = [(k, C.c_void_p) for k in ("x0", "h1", "h2", "h3", "h4", "masks", "d1", "d2", "d3", "d4", "dhead", "dx0")]
 
 
-def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray, d_sigma, d_rgb,
-                 chunk_samples=1 << 22):
-    """Adjoint of mlp_forward_gather (addition; the reference leaves this to PyTorch autograd, model.py:602-630):
-    given dL/dsigma [n] and dL/drgb [n,3] returns (grad_field [64,V], [12 weight gradients in the order of `weights`]).
-    Per chunk of samples (4.6 KB of buffers per sample; chunks of equal size): tn_mlp_backward -- the dX chain on the fp32
-    matrix cores, recomputing the forward pass -- then tn_mlp_param_grads -- the twelve parameter gradients as
-    sample-streaming fp32-MFMA GEMMs, summed without atomics (bit-reproducible) -- then the gather's adjoint."""
-    mh = fused_mlp(weights)
-    keep = [w.detach() for w in weights]
+class MlpSaved:
+    """What mlp_forward_gather_train leaves for mlp_backward: the layer inputs x0 [64,n], h1..h4 [128,n] (feature-major: the
+    operands of the weight-gradient GEMMs), the ReLU masks [4,n,2] (all the dX kernel needs) and the outputs."""
+    __slots__ = ("acts", "masks", "sigma", "rgb", "n", "S")
+
+
+def mlp_forward_gather_train(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray):
+    """mlp_forward_gather (fp32) for training: returns (sigma [n], rgb [n,3], saved) -- `saved` holds 2.3 KB per sample for
+    mlp_backward, which then recomputes nothing."""
+    for x, name in ((vertex_indices, "vertex_indices"), (barycentric_coordinates, "barycentric_coordinates"),
+                    (field, "field"), (dirs, "dirs")):
+        _check_input(x, name)
+    _check(vertex_indices.dtype == torch.int32 and vertex_indices.size(-1) == 4, "vertex_indices must be i32 [...,4]")
+    _check(barycentric_coordinates.dtype == torch.float32 and barycentric_coordinates.size(-1) == 3,
+           "barycentric_coordinates must be f32 [...,3]")
+    _check(field.dtype == torch.float32 and field.dim() == 2 and field.size(0) == 64, "field must be f32 [64, V]")
     n = vertex_indices.numel() // 4
     S = int(samples_per_ray)
     _check(S > 0 and n % S == 0, "n must be a multiple of samples_per_ray")
+    _check(dirs.dtype == torch.float32 and tuple(dirs.shape) == (n // S, 3), "dirs must be f32 [n/samples_per_ray, 3]")
+    m = fused_mlp(weights)
+    dev = field.device
+    field_vm = field_vertex_major(field)
+    sv = MlpSaved()
+    sv.n, sv.S = n, S
+    sv.sigma = _empty((n,), dtype=torch.float32, device=dev)
+    sv.rgb = _empty((n, 3), dtype=torch.float32, device=dev)
+    sv.acts = _empty((64 + 4 * 128, n), dtype=torch.float32, device=dev)
+    sv.masks = _empty((4, n, 2), dtype=torch.int64, device=dev)
+    a = sv.acts
+    bs = _MlpBackwardBuffers(a[0:64].data_ptr(), a[64:192].data_ptr(), a[192:320].data_ptr(), a[320:448].data_ptr(),
+                             a[448:576].data_ptr(), sv.masks.data_ptr(), None, None, None, None, None, None)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tn_mlp_forward_gather_train(m.handle, n, S, _ptr(vertex_indices), _ptr(barycentric_coordinates),
+                                                           _ptr(field_vm), _ptr(dirs.contiguous()), _ptr(sv.sigma), _ptr(sv.rgb),
+                                                           C.byref(bs), _stream(dev)))
+    return sv.sigma, sv.rgb, sv
+
+
+def mlp_backward(saved, vertex_indices, barycentric_coordinates, field, dirs, weights, d_sigma, d_rgb):
+    """Adjoint of mlp_forward_gather_train (addition; the reference leaves this to PyTorch autograd, model.py:602-630):
+    given dL/dsigma [n] and dL/drgb [n,3] returns (grad_field [64,V], [12 weight gradients in the order of `weights`]).
+    tn_mlp_backward -- the dX chain on the fp32 matrix cores from the saved ReLU masks, nothing recomputed -- then
+    tn_mlp_param_grads -- the twelve parameter gradients as sample-streaming fp32-MFMA GEMMs over the saved layer inputs,
+    summed without atomics (bit-reproducible) -- then the gather's adjoint.  2.1 KB of gradient buffers per sample."""
+    mh = fused_mlp(weights)
+    keep = [w.detach() for w in weights]
+    n, S = saved.n, saved.S
+    _check(vertex_indices.numel() == 4 * n, "vertex_indices do not belong to the saved forward pass")
     _check(d_sigma.numel() == n and d_rgb.numel() == 3 * n, "d_sigma / d_rgb must have n / 3n elements")
     dev = field.device
     V = field.size(1)
@@ -728,32 +765,22 @@ def mlp_backward(vertex_indices, barycentric_coordinates, field, dirs, weights, 
     d_rgb = d_rgb.reshape(n, 3).contiguous().float()
     dirs = dirs.contiguous()
     lib = _lib.load()
-    field_vm = field_vertex_major(field)
     grads = [torch.zeros(tuple(w.shape), dtype=torch.float32, device=dev) for w in keep]
     gs = _MlpWeightsStruct(*[g.data_ptr() for g in grads])
     grad_vm = torch.zeros((V, 64), dtype=torch.float32, device=dev)
-    R = n // S
-    nchunks = max(1, -(-n // max(int(chunk_samples), S)))
-    rays_per_chunk = -(-R // nchunks)
+    a = saved.acts
+    buf = _empty((4 * 128 + 4, n), dtype=torch.float32, device=dev)
+    rows = _empty((n, 64), dtype=torch.float32, device=dev)     # d x0, sample-major
+    bs = _MlpBackwardBuffers(a[0:64].data_ptr(), a[64:192].data_ptr(), a[192:320].data_ptr(), a[320:448].data_ptr(),
+                             a[448:576].data_ptr(), saved.masks.data_ptr(), buf[0:128].data_ptr(), buf[128:256].data_ptr(),
+                             buf[256:384].data_ptr(), buf[384:512].data_ptr(), buf[512:516].data_ptr(), rows.data_ptr())
     stream = _stream(dev)
     with torch.cuda.device(dev):
-        for r0 in range(0, R, rays_per_chunk):
-            r1 = min(R, r0 + rays_per_chunk)
-            m = (r1 - r0) * S
-            c0 = r0 * S
-            buf = _empty((64 + 8 * 128 + 4, m), dtype=torch.float32, device=dev)
-            x0, h1, h2, h3, h4 = buf[0:64], buf[64:192], buf[192:320], buf[320:448], buf[448:576]
-            d1, d2, d3, d4 = buf[576:704], buf[704:832], buf[832:960], buf[960:1088]
-            dhead = buf[1088:1092]
-            rows = _empty((m, 64), dtype=torch.float32, device=dev)     # d x0, sample-major
-            bs = _MlpBackwardBuffers(*[t.data_ptr() for t in (x0, h1, h2, h3, h4, d1, d2, d3, d4, dhead, rows)])
-            _lib.check(lib.tn_mlp_backward(mh.handle, m, S, _ptr(vi[c0:]), _ptr(bc[c0:]), _ptr(field_vm), _ptr(dirs[r0:]),
-                                           _ptr(d_sigma[c0:]), _ptr(d_rgb[c0:]), C.byref(bs), stream))
-            _lib.check(lib.tn_mlp_param_grads(mh.handle, m, S, _ptr(dirs[r0:]), C.byref(bs), C.byref(gs), stream))
-            # gradient of the gathered features -> field (vertex-major accumulation)
-            _lib.check(lib.tn_interpolate_values_backward_vm(4, m, 64, _ptr(vi[c0:]), _ptr(bc[c0:]), _ptr(rows), _ptr(grad_vm),
-                                                             stream))
-            del buf, rows
+        _lib.check(lib.tn_mlp_backward(mh.handle, n, _ptr(saved.sigma), _ptr(saved.rgb), _ptr(d_sigma), _ptr(d_rgb),
+                                       C.byref(bs), stream))
+        _lib.check(lib.tn_mlp_param_grads(mh.handle, n, S, _ptr(dirs), C.byref(bs), C.byref(gs), stream))
+        # gradient of the gathered features -> field (vertex-major accumulation)
+        _lib.check(lib.tn_interpolate_values_backward_vm(4, n, 64, _ptr(vi), _ptr(bc), _ptr(rows), _ptr(grad_vm), stream))
         grad_field = _empty((64, V), dtype=torch.float32, device=dev)
         _lib.check(lib.tn_transpose_f32(V, 64, _ptr(grad_vm), _ptr(grad_field), stream))
     return grad_field, grads
