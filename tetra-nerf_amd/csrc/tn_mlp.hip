@@ -148,28 +148,21 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
                 }
             }
         }
-        if constexpr (TRAIN) {
-            if (s < n) {
-                float *p = sv.x0 + (size_t)(32 * h) * n + s;
-#pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) { *p = bin[ks]; p += n; }
-            }
-        }
         stage_wait();
         {
             f32x16 acc[OT];
             zero_acc(acc);
-            gemm_steps<KS1, 0, OT>(acc, bin, lds, lane);
+            // TRAIN: every GEMM's input leaves for HBM under the GEMM's own MFMAs (lanes beyond the end store their
+            // duplicate of sample n - 1 where its owner stores it)
+            if constexpr (TRAIN) gemm_steps_store<KS1, 0, OT, KS1, true>(acc, bin, lds, lane, sv.x0 + (size_t)(32 * h) * n + sc, n);
+            else gemm_steps<KS1, 0, OT>(acc, bin, lds, lane);
             bias_step<KS1, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);
         }
-        auto save_layer = [&](float *dst, int layer) {
-            if constexpr (TRAIN) {
-                store_bin(dst, n, s, s < n, bin, h);
-                if (s < n) sv.masks[((size_t)layer * n + s) * 2 + h] = mask_of(bin);
-            }
+        auto save_mask = [&](int layer) {
+            if constexpr (TRAIN) sv.masks[((size_t)layer * n + sc) * 2 + h] = mask_of(bin);
         };
-        save_layer(sv.h1, 0);
+        save_mask(0);
         // ---- layers 2, 3: 128 -> 128, accumulators fed back as B operands
         __syncthreads();
         stage_weights<BLOCK>(lds, pk + OFF_W2, lfloats(KSH, OT));
@@ -177,22 +170,24 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
         {
             f32x16 acc[OT];
             zero_acc(acc);
-            gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
+            if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, lds, lane, sv.h1 + (size_t)(4 * h) * n + sc, n);
+            else gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
             bias_step<KSH, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);
         }
-        save_layer(sv.h2, 1);
+        save_mask(1);
         __syncthreads();
         stage_weights<BLOCK>(lds, pk + OFF_W3, N_W3);
         stage_wait();
         {
             f32x16 acc[OT];
             zero_acc(acc);
-            gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
+            if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, lds, lane, sv.h2 + (size_t)(4 * h) * n + sc, n);
+            else gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
             bias_step<KSH, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);  // mlp_base out_activation = ReLU
         }
-        save_layer(sv.h3, 2);
+        save_mask(2);
         {
             // density head 128 -> 1 + softplus on the VALU (the vector rides behind layer 3's weights)
             const float *dv = lds + lfloats(KSH, OT);
@@ -226,12 +221,14 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
                 gemm_steps<KSH - KA, 0, OT, KA>(acc, bin, lds, lane);
                 bias_step<KSH - KA, OT>(acc, lds, lane);
             } else {
-                gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
+                if constexpr (TRAIN) gemm_steps_store<KSH, KSE, OT, KSH, false>(acc, bin, lds, lane, sv.h3 + (size_t)(4 * h) * n + sc, n);
+                else gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
                 bias_step<HEAD_KS, OT>(acc, lds, lane);
             }
             relu_to_bin(acc, bin);
         }
-        save_layer(sv.h4, 3);
+        if constexpr (TRAIN) store_bin(sv.h4, n, sc, true, bin, h);   // the last layer's output has no GEMM to hide under
+        save_mask(3);
         {
             // rgb head 128 -> 3 + sigmoid on the VALU
             const float *cv = lds + (SPLIT_HEAD ? lfloats(KSH - (HEAD_KS_A - KSE), OT) : lfloats(HEAD_KS, OT));

@@ -91,15 +91,17 @@ __device__ __forceinline__ void masked_to_bin(const f32x16 (&acc)[TILES], unsign
 //     `s_waitcnt vmcnt(0)` comes (on gfx9 stores and loads share that counter);
 //   * the masks and head gradients of the NEXT group are requested a GEMM ahead.
 constexpr int BWD_BLOCK = 256;
-constexpr int passes(size_t floats) { return (int)((floats + 1023) / 1024); }   // stage copies: whole 4 KB passes
+constexpr int PASS_FLOATS = BWD_BLOCK * 4;                                        // one async copy per thread = 16 bytes
+constexpr int passes(size_t floats) { return (int)((floats + PASS_FLOATS - 1) / PASS_FLOATS); }   // stage copies: whole passes
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int P_TH = passes(N_TH), P_T = passes(tfloats(OT)), P_T1 = passes(tfloats(OTI1));
-constexpr size_t TR_FLOATS = (BWD_BLOCK / 64) * 32 * 65;                         // the d x0 transposition, behind the last stage
-constexpr size_t BUF_A = 1024 * (size_t)cmax(P_TH, P_T);                         // stages 0, 2: Wh^T (+ vectors), W2^T
-constexpr size_t BUF_B = cmax(1024 * P_T, (int)(tfloats(OTI1) + TR_FLOATS));     // stages 1, 3: W3^T, W1^T (+ transposition)
+constexpr bool TR_LDS = BWD_BLOCK == 256;                                        // d x0 rows through LDS (4 waves: it fits behind the last stage)
+constexpr size_t TR_FLOATS = TR_LDS ? (BWD_BLOCK / 64) * 32 * 65 : 0;
+constexpr size_t BUF_A = PASS_FLOATS * (size_t)cmax(P_TH, P_T);                  // stages 0, 2: Wh^T (+ vectors), W2^T
+constexpr size_t BUF_B = cmax(PASS_FLOATS * cmax(P_T, P_T1), (int)(tfloats(OTI1) + TR_FLOATS));   // stages 1, 3: W3^T, W1^T (+ transposition)
 static_assert((BUF_A + BUF_B) * sizeof(float) <= 160 * 1024, "two weight stages must fit the CU's LDS");
-static_assert(OFFT_H + 1024 * (size_t)P_TH <= PACKT_FLOATS, "whole-pass copy of the first stage stays inside the pack");
-static_assert(OFFT_1 + 1024 * (size_t)P_T1 <= PACKT_FLOATS, "whole-pass copy of the last stage stays inside the pack");
+static_assert(OFFT_H + PASS_FLOATS * (size_t)P_TH <= PACKT_FLOATS, "whole-pass copy of the first stage stays inside the pack");
+static_assert(OFFT_1 + PASS_FLOATS * (size_t)P_T1 <= PACKT_FLOATS, "whole-pass copy of the last stage stays inside the pack");
 
 // PASSES x 4 KB of a packed layer -> LDS, every thread the same number of async loads (whole passes: what lies behind the
 // layer in the pack lands in the buffer's padding)
@@ -121,39 +123,6 @@ __device__ __forceinline__ void stage_fixed(float *lds, const float *__restrict_
 __device__ __forceinline__ void layer_top() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-}
-
-// gemm_steps (tn_mlp_common.h) + the feature-major stores of the B operand: two values after each of the first 32 k-steps
-template <int TILES>
-__device__ __forceinline__ void gemm_steps_store(f32x16 (&acc)[TILES], const float (&bin)[KSH], const float *lds, int lane,
-                                                 float *__restrict__ p, size_t n) {
-    const size_t n5 = 5 * n;
-    float a[TILES], an[TILES];
-    const float *w0 = lds + lane;
-#pragma unroll
-    for (int t = 0; t < TILES; ++t) a[t] = w0[t * 64];
-#pragma unroll
-    for (int ks = 0; ks < KSH; ++ks) {
-        if (ks + 1 < KSH) {
-            const float *wrow = lds + (size_t)(ks + 1) * TILES * 64 + lane;
-#pragma unroll
-            for (int t = 0; t < TILES; ++t) an[t] = wrow[t * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < TILES; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bin[ks], acc[t], 0, 0, 0);
-        if (2 * ks < KSH) {
-#pragma unroll
-            for (int j = 2 * ks; j < 2 * ks + 2; ++j) {
-                *p = bin[j];
-                p += ((j & 3) != 3) ? n : n5;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) a[t] = an[t];
-    }
 }
 
 }  // namespace
@@ -217,7 +186,7 @@ __global__ __launch_bounds__(BWD_BLOCK) void k_mlp_backward(size_t n, BwdIn in, 
         // the next group's masks and head gradients
         const Head hn = load_head(g + gridDim.x < ngroups ? g + gridDim.x : g);
         zero_acc(acc);
-        gemm_steps_store<OT>(acc, bin, bufA, lane, o.d4 + (size_t)(4 * h) * n + sc, n);
+        gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, bufA, lane, o.d4 + (size_t)(4 * h) * n + sc, n);
         {
             const float *dv = bufA + tfloats(OT) + 64 * h;
 #pragma unroll
@@ -230,12 +199,12 @@ __global__ __launch_bounds__(BWD_BLOCK) void k_mlp_backward(size_t n, BwdIn in, 
         layer_top();
         stage_fixed<P_T>(bufA, pt + OFFT_2);
         zero_acc(acc);
-        gemm_steps_store<OT>(acc, bin, bufB, lane, o.d3 + (size_t)(4 * h) * n + sc, n);
+        gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, bufB, lane, o.d3 + (size_t)(4 * h) * n + sc, n);
         masked_to_bin(acc, m2, bin);
         layer_top();
         stage_fixed<P_T1>(bufB, pt + OFFT_1);
         zero_acc(acc);
-        gemm_steps_store<OT>(acc, bin, bufA, lane, o.d2 + (size_t)(4 * h) * n + sc, n);
+        gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, bufA, lane, o.d2 + (size_t)(4 * h) * n + sc, n);
         masked_to_bin(acc, m1, bin);
         // ---- d x0 = W1^T d_pre1  (64 input features = 2 tiles) (B); the next group's first stage goes to A meanwhile
         layer_top();
@@ -243,20 +212,29 @@ __global__ __launch_bounds__(BWD_BLOCK) void k_mlp_backward(size_t n, BwdIn in, 
         {
             f32x16 acc2[OTI1];
             zero_acc(acc2);
-            gemm_steps_store<OTI1>(acc2, bin, bufB, lane, o.d1 + (size_t)(4 * h) * n + sc, n);
+            gemm_steps_store<KSH, 0, OTI1, KSH, false>(acc2, bin, bufB, lane, o.d1 + (size_t)(4 * h) * n + sc, n);
             // d x0 leaves as SAMPLE-major rows [n, 64] (the gather adjoint reads a sample's gradient as one 256-byte line):
             // through this wave's slice of the tail of buffer B ([32 samples][65]: conflict-free both ways), each sample's
             // 64 values then go out as one coalesced store
-            float *tr = bufB + tfloats(OTI1) + (size_t)wave * (32 * 65);
-            {
-                float *col = tr + (lane & 31) * 65 + 4 * h;
+            if constexpr (TR_LDS) {
+                float *tr = bufB + tfloats(OTI1) + (size_t)wave * (32 * 65);
+                {
+                    float *col = tr + (lane & 31) * 65 + 4 * h;
 #pragma unroll
-                for (int j = 0; j < OTI1 * 16; ++j) col[32 * (j >> 4) + (j & 3) + 8 * ((j >> 2) & 3)] = acc2[j >> 4][j & 15];
-            }
-            const size_t s0 = g * GROUP + (size_t)wave * 32;
+                    for (int j = 0; j < OTI1 * 16; ++j) col[32 * (j >> 4) + (j & 3) + 8 * ((j >> 2) & 3)] = acc2[j >> 4][j & 15];
+                }
+                const size_t s0 = g * GROUP + (size_t)wave * 32;
 #pragma unroll 8
-            for (int i = 0; i < 32; ++i)
-                if (s0 + i < n) o.dx0[(s0 + i) * FD + lane] = tr[i * 65 + lane];
+                for (int i = 0; i < 32; ++i)
+                    if (s0 + i < n) o.dx0[(s0 + i) * FD + lane] = tr[i * 65 + lane];
+            } else if (s < n) {
+                // every lane writes its 8 quads (4 consecutive features each) into its sample's row
+                float *row = o.dx0 + s * FD + 4 * h;
+#pragma unroll
+                for (int j = 0; j < OTI1 * 16; j += 4)
+                    *reinterpret_cast<float4 *>(row + 32 * (j >> 4) + 8 * ((j >> 2) & 3)) =
+                        make_float4(acc2[j >> 4][j & 15], acc2[j >> 4][(j & 15) + 1], acc2[j >> 4][(j & 15) + 2], acc2[j >> 4][(j & 15) + 3]);
+            }
         }
         hd = hn;
     }

@@ -99,6 +99,41 @@ static __device__ __forceinline__ void gemm_steps(f32x16 (&acc)[TILES], const fl
     }
 }
 
+// gemm_steps + the feature-major stores of the B operand (the training kernels save every GEMM's input): two values after
+// each of the first NST / 2 k-steps, i.e. in the shadow of MFMAs and drained long before the GEMM ends.  LINEAR:
+// consecutive values are n floats apart (x0); otherwise the accumulator order of store_slots.
+template <int KS, int KS0, int TILES, int NST, bool LINEAR>
+static __device__ __forceinline__ void gemm_steps_store(f32x16 (&acc)[TILES], const float (&bin)[KSH], const float *lds, int lane,
+                                                        float *__restrict__ p, size_t n) {
+    const size_t n5 = 5 * n;
+    float a[TILES], an[TILES];
+    const float *w0 = lds + (size_t)KS0 * TILES * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) a[t] = w0[t * 64];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+            const float *wrow = lds + (size_t)(KS0 + ks + 1) * TILES * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) an[t] = wrow[t * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bin[ks], acc[t], 0, 0, 0);
+        if (2 * ks < NST) {
+#pragma unroll
+            for (int j = 2 * ks; j < 2 * ks + 2; ++j) {
+                *p = bin[j];
+                p += (LINEAR || (j & 3) != 3) ? n : n5;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) a[t] = an[t];
+    }
+}
+
 template <int STEP, int TILES>
 static __device__ __forceinline__ void bias_step(f32x16 (&acc)[TILES], const float *lds, int lane) {
     const float *wrow = lds + (size_t)STEP * TILES * 64 + lane;
