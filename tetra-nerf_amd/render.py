@@ -317,7 +317,7 @@ class TetraRenderer:
         self.tracer, self.field, self.mlp = tracer, field, mlp
         # arithmetic of the fused forward kernels, per renderer (not process-wide): "fp32" = exact fp32 MFMA chain (what
         # the parity tests pin), "bf16x3" = split-operand bf16 MFMA (opt-in; inference only -- the training forward is
-        # always fp32 because the backward kernel recomputes the activations in fp32)
+        # always fp32: tn_mlp_forward_gather_train has no bf16x3 mode)
         self.mlp_mode = mlp_mode
         self.background = float(background)    # RGBRenderer background: 1.0 white (default config), 0.0 black
         # samplers as device kernels on the trace rows in place (tn_sample_coarse / tn_sample_pdf): a render is then
