@@ -74,14 +74,6 @@ struct BwdOut {
     float *dx0;                // [n, 64]  gradient of the gathered features, SAMPLE-major rows (what the gather adjoint reads)
 };
 
-template <int TILES>
-__device__ __forceinline__ void masked_to_bin(const f32x16 (&acc)[TILES], unsigned long long m, float (&bin)[KSH]) {
-#pragma unroll
-    for (int t = 0; t < OT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bin[t * 16 + r] = ((m >> (t * 16 + r)) & 1ull) ? acc[t][r] : 0.f;
-}
-
 // 4 waves per block, one per SIMD (64 gradient values + 64 accumulators + the masks per lane; the 8-wave shape of the
 // forward kernel would need them in 256 registers and spills).  A wave alone on its SIMD has nobody to hide its waits, so:
 //   * the four weight stages of a group ping-pong between two LDS buffers: stage l + 1 is requested (async global -> LDS)

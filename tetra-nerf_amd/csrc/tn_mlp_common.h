@@ -194,10 +194,28 @@ static __device__ __forceinline__ void store_bin(float *__restrict__ dst, size_t
 }
 // ReLU mask of the 64 activations a lane holds (slot j: bit j); stored as masks[(layer * n + sample) * 2 + half]
 static __device__ __forceinline__ unsigned long long mask_of(const float (&bin)[KSH]) {
-    unsigned long long m = 0;
+    // the values are ReLU outputs (>= +0): "positive" = "bit pattern not zero"; min(bits, 1) << j | word: two VALU
+    // operations per value
+    uint32_t lo = 0, hi = 0;
 #pragma unroll
-    for (int j = 0; j < KSH; ++j) m |= (unsigned long long)(bin[j] > 0.f ? 1u : 0u) << j;
-    return m;
+    for (int j = 0; j < 32; ++j) {
+        lo |= (__float_as_uint(bin[j]) < 1u ? __float_as_uint(bin[j]) : 1u) << j;
+        hi |= (__float_as_uint(bin[32 + j]) < 1u ? __float_as_uint(bin[32 + j]) : 1u) << j;
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+// bin[j] = bit j of m ? acc[j] : 0, as bit arithmetic (sign-extended bit field AND the value: two VALU operations)
+template <int TILES>
+static __device__ __forceinline__ void masked_to_bin(const f32x16 (&acc)[TILES], unsigned long long m, float (&bin)[KSH]) {
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = t * 16 + r;
+            const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)(j < 32 ? lo : hi), j & 31, 1);   // 0 or 0xFFFFFFFF
+            bin[j] = __uint_as_float(__float_as_uint(acc[t][r]) & sel);
+        }
 }
 
 }  // namespace mlp
