@@ -149,3 +149,37 @@ def test_render_train_fused_equals_autograd_statement(tn, device, scenes):
             # between 0.5 and 6 with the target image (both are conditioning-limited: 1e-4 .. 2e-3 of the largest entry for
             # the field gradient of this loss), hence the absolute alternative
             assert ours < max(5.0 * torch32, 2e-3 if name == "field" else 1e-4), ((S, S_fine, biased), name, ours, torch32, errs)
+
+
+def test_render_train_in_several_autograd_nodes(tn, device, scenes):
+    """Batches beyond `train_node_samples` go through several fused-MLP nodes (one per block of rays): outputs identical,
+    gradients equal up to the order in which the blocks' parameter gradients are summed."""
+    import torch
+
+    render = importlib.import_module("tetra-nerf_amd.render")
+    pts, cells = scenes.random_mesh(4000, 5)
+    tr = tn.TetrahedraTracer(device)
+    tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+    o, d = scenes.outside_in_rays(700, 8)
+    to, td = torch.from_numpy(o).to(device), torch.from_numpy(d).to(device)
+    torch.manual_seed(5)
+    target = torch.rand(len(o), 3, device=device)
+    mlp = render.TetraMLP().to(device)
+    field = ((torch.rand(64, len(pts), device=device) * 2 - 1) * 0.5).requires_grad_(True)
+    S, S_fine = 32, 32
+    rd = render.TetraRenderer(tr, field, mlp, S, 256, fused=True, num_fine_samples=S_fine)
+    hit = int((tr.trace_rays(to, td, 256)["num_visited_cells"] > 0).sum())
+    rand = {"coarse": torch.rand(hit, S + 1, device=device), "fine": torch.rand(hit, S_fine + 1, device=device)}
+    res = []
+    for node_samples in (1 << 22, 100 * (S + S_fine + 1)):      # one node; nodes of 100 rays
+        rd.train_node_samples = node_samples
+        field.grad = None
+        mlp.zero_grad()
+        out = rd.render_train(to, td, rand=rand)
+        ((out["rgb"] - target) ** 2).mean().backward()
+        res.append((out["rgb"].detach().clone(), field.grad.clone(), [p.grad.clone() for p in render.mlp_weights(mlp)]))
+    assert hit > 300
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in [(res[0][1], res[1][1])] + list(zip(res[0][2], res[1][2])):
+        scale = float(a.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale

@@ -319,6 +319,7 @@ class TetraRenderer:
         # the parity tests pin), "bf16x3" = split-operand bf16 MFMA (opt-in; inference only -- the training forward is
         # always fp32: tn_mlp_forward_gather_train has no bf16x3 mode)
         self.mlp_mode = mlp_mode
+        self.train_node_samples = 1 << 22      # render_train: samples per autograd node of the fused MLP (see there)
         self.background = float(background)    # RGBRenderer background: 1.0 white (default config), 0.0 black
         # samplers as device kernels on the trace rows in place (tn_sample_coarse / tn_sample_pdf): a render is then
         # trace -> [sampler -> pass] x 2 with no PyTorch operator in between (False: the PyTorch statements above, ~15
@@ -498,7 +499,15 @@ class TetraRenderer:
             capture.update(idx=idx, vertex_indices=vi, barycentric_coordinates=bc, edges=edges, dirs=dirs,
                            near=near_r, far=far_r, samples_per_ray=S)
         if fused:
-            sigma, col = _FusedMlpFunction.apply(vi, bc, self.field, dirs, S, *w)
+            # the node keeps 2.3 KB per sample from forward to backward (and its backward writes as much again): batches
+            # beyond 2^22 samples (nerfstudio trains on 4096 rays) go through several nodes, one per block of rays
+            rays_per_node = max(1, int(self.train_node_samples) // S)
+            if r <= rays_per_node:
+                sigma, col = _FusedMlpFunction.apply(vi, bc, self.field, dirs, S, *w)
+            else:
+                parts = [_FusedMlpFunction.apply(vi[a:a + rays_per_node], bc[a:a + rays_per_node], self.field,
+                                                 dirs[a:a + rays_per_node], S, *w) for a in range(0, r, rays_per_node)]
+                sigma, col = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
             sigma, col = sigma.view(-1, S), col.view(-1, S, 3)
         else:
             from . import interpolate_values
