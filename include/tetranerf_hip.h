@@ -202,7 +202,7 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *             0 = general all-hits path for every ray, 2 = walk for any batch size
  *   "walk_min_rays"  smallest batch the walk is used for (default 12288; below it one wavefront per
  *             ray through the wide BVH has the lower latency).  Whatever the options say, the walk path needs
- *             max_ray_triangles % 4 == 0 (16-byte stores into 16-byte aligned rows); other values take the BVH path
+ *             max_ray_triangles >= 4 (16-byte stores into the rows); 1 and 2 take the BVH path
  *   "dense_tails"  1 (default) = every slot of the [R,M] rows is written, as the reference does;
  *             0 = slots >= num_visited[r] of walked rows are left UNWRITTEN (non-reference: for callers
  *             that only read rows through num_visited, e.g. tn_find_matched_cells; saves ~88 % of the bytes)

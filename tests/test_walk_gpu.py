@@ -221,19 +221,3 @@ def test_find_visited_cells_ray_index(tn, device, scenes):
         assert torch.equal(a[k], b[k]), k
     assert bool(a["mask"].any())
 
-
-@pytest.mark.parametrize("M", [130, 255])
-def test_rows_that_are_not_16_byte_aligned_take_the_bvh_path(tn, device, oracle, scenes, M):
-    """max_ray_triangles % 4 != 0: the rows of visited_cells start at 4-byte boundaries only and the walk path's writers
-    store 16-byte vectors -- such calls are routed to the BVH path whatever the options say; results = the oracle's."""
-    pts, cells = scenes.random_mesh(3000, 5)
-    ot = oracle.OracleTracer(use_bvh=True)
-    ot.load_tetrahedra(pts, cells)
-    tr = _tracer(tn, device, pts, cells, 1)          # walk forced for any batch size
-    o, d = scenes.outside_in_rays(20000, 6)
-    want = ot.trace_rays(o, d, M)
-    got = _trace(tr, device, o, d, M)
-    for k in KEYS:
-        assert _bits_equal(got[k], want[k]), f"M = {M}: {k} differs from the oracle"
-    st = tr.trace_stats()
-    assert st["walk"] == 0 and st["general"] == len(o), st

@@ -344,8 +344,9 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
         // Small batches are latency-bound: a lane walking ~180 dependent steps is slower than one
         // wavefront per ray through the wide BVH (measured: 4096 rays, 300k tets: 1.5 ms vs 0.75 ms),
         // so the walk is used from `walk_min_rays` on (use_walk == 2 forces it for any size).
-        // M % 4: the writer and the fills store 16-byte vectors into the rows, whose bases are 16-byte aligned only then
-        const bool walk = t->use_walk && (R >= t->walk_min_rays || t->use_walk == 2) && M >= 4 && (M & 3u) == 0 &&
+        // M >= 4: the writer and the fills store 16-byte vectors into the rows; M is a power of two (checked above), so
+        // from 4 on every row base is 16-byte aligned
+        const bool walk = t->use_walk && (R >= t->walk_min_rays || t->use_walk == 2) && M >= 4 &&
                           t->mesh.n_hull > 0;
         t->last_walk = walk;
         if (walk) {
