@@ -882,6 +882,8 @@ int tn_mlp_param_grads(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const f
                                grads->wd, grads->bd, grads->wh, grads->bh, grads->wr, grads->br};
         for (float *p : gp)
             if (!p) throw tn::Error("null pointer");
+        if (!b->x0 || !b->h1 || !b->h2 || !b->h3 || !b->h4 || !b->d1 || !b->d2 || !b->d3 || !b->d4 || !b->dhead)
+            throw tn::Error("null pointer");
         DeviceGuard g(m->device);
         if (!m->grad_scratch.p) {   // first training call of this handle
             TN_HIP(hipDeviceSynchronize());

@@ -265,7 +265,7 @@ class _FusedMlpFunction(torch.autograd.Function):
         from . import tetranerf_cpp_extension as cpp
 
         vi, bc, field, dirs, *weights = ctx.saved_tensors
-        saved, ctx.saved = ctx.saved, None
+        saved = ctx.saved          # (kept: a second backward through a retained graph reads the same activations)
         grad_field, grads = cpp.mlp_backward(saved, vi, bc, field, dirs, list(weights), d_sigma.contiguous(), d_rgb.contiguous())
         return (None, None, grad_field, None, None, *grads)
 
