@@ -119,9 +119,9 @@ __global__ __launch_bounds__(256) void k_interp_fwd64(uint32_t n, const uint32_t
     for (uint32_t tix = wave0; tix < ntiles; tix += nwaves) {
         const uint32_t base = tix * 64 + 8 * sg;
         float acc[8][8];
-        // the rows of the previous sample: consecutive samples of a ray mostly lie in the same tetrahedron, and the
-        // vertex rows (1 KB per sample out of the Infinity Cache -- the field does not fit an XCD's L2) are what
-        // bounds this kernel, so a row that repeats is taken from registers
+        // the rows of the previous sample: consecutive samples of a ray lie in the same or in adjacent tetrahedra, and the
+        // vertex rows (1 KB per sample between the L2 and the CU) are what bounds this kernel, so a row that repeats is
+        // taken from registers
         uint32_t pv[D];
         float4 p0[D], p1[D];
 #pragma unroll
@@ -142,22 +142,37 @@ __global__ __launch_bounds__(256) void k_interp_fwd64(uint32_t n, const uint32_t
 #pragma unroll
             for (int k = 0; k < D - 1; ++k) w += b[k];
             const float w0 = 1.0f - w;
+            // the rows of this sample: from the previous sample's registers wherever the vertex was used there in ANY slot
+            // (the next tetrahedron along a ray shares three of its four vertices, in whatever order the mesh lists them;
+            // round 3's counters: 3.4 row loads per sample with same-slot reuse only), otherwise from the field
+            float4 n0[D], n1[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                n0[k] = make_float4(0.f, 0.f, 0.f, 0.f); n1[k] = n0[k];
+                if (v[k] != TN_EMPTY) {
+                    bool found = false;
+#pragma unroll
+                    for (int c = 0; c < D; ++c)
+                        if (v[k] == pv[c]) { n0[k] = p0[c]; n1[k] = p1[c]; found = true; }
+                    if (!found) {
+                        const float4 *row = reinterpret_cast<const float4 *>(fieldT + (size_t)v[k] * 64);
+                        n0[k] = row[q]; n1[k] = row[8 + q];
+                    }
+                }
+            }
             // reference order: the D-1 weighted vertices first, the implicit-weight vertex last
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 const int kk = k < D - 1 ? k + 1 : 0;
                 const float wk = k < D - 1 ? b[k < D - 1 ? k : 0] : w0;
                 if (v[kk] != TN_EMPTY) {
-                    float4 x0 = p0[kk], x1 = p1[kk];
-                    if (v[kk] != pv[kk]) {
-                        const float4 *row = reinterpret_cast<const float4 *>(fieldT + (size_t)v[kk] * 64);
-                        x0 = row[q]; x1 = row[8 + q];
-                        pv[kk] = v[kk]; p0[kk] = x0; p1[kk] = x1;
-                    }
+                    const float4 x0 = n0[kk], x1 = n1[kk];
                     acc[it][0] += wk * x0.x; acc[it][1] += wk * x0.y; acc[it][2] += wk * x0.z; acc[it][3] += wk * x0.w;
                     acc[it][4] += wk * x1.x; acc[it][5] += wk * x1.y; acc[it][6] += wk * x1.z; acc[it][7] += wk * x1.w;
                 }
             }
+#pragma unroll
+            for (int k = 0; k < D; ++k) { pv[k] = v[k]; p0[k] = n0[k]; p1[k] = n1[k]; }
         }
         const bool wide = (n & 3u) == 0 && base + 8 <= n;   // 16-byte aligned rows, all 8 samples valid
 #pragma unroll
