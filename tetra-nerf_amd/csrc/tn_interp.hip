@@ -194,8 +194,9 @@ __global__ __launch_bounds__(256) void k_interp_fwd64(uint32_t n, const uint32_t
 // Backward: one wavefront = 64 consecutive samples, LANE = FEATURE.  The incoming gradient is read
 // sample-major ([n, Fd] rows: one coalesced 256-B load per sample at Fd = 64); vertex ids and weights
 // are wave-uniform and come through scalar loads; consecutive samples with the same vertex tuple
-// (same tetrahedron along the ray) are combined in registers, and each flush is D atomic instructions
-// whose 64 lanes hit 64 consecutive floats of the vertex-major gradient (one or two cache lines).
+// (same tetrahedron along the ray) are combined in registers; when the tuple changes the sums of the vertices that
+// stay are carried over, and each flush is one atomic instruction whose 64 lanes hit 64 consecutive floats of the
+// vertex-major gradient (one or two cache lines).
 template <int D>
 __global__ __launch_bounds__(256) void k_interp_bwd(uint32_t n, uint32_t Fd, const uint32_t *__restrict__ vi,
                                                     const float *__restrict__ bc,
@@ -234,12 +235,24 @@ __global__ __launch_bounds__(256) void k_interp_bwd(uint32_t n, uint32_t Fd, con
                     for (int k = 0; k < D - 1; ++k) { wgt[k + 1] = bc[i * (D - 1) + k]; w += wgt[k + 1]; }
                     wgt[0] = 1.0f - w;
                     if (!same) {  // wave-uniform
+                        // the next tetrahedron along a ray shares all but one of its vertices, in whatever order the mesh
+                        // lists them: the sums of the vertices that stay MOVE to their new slots, only the others are
+                        // flushed (one atomic instruction per step instead of D; the per-sample path stays slot-wise)
+                        float nacc[D];
+                        uint32_t carried = 0;
 #pragma unroll
-                        for (int k = 0; k < D; ++k) {
-                            if (cur[k] != TN_EMPTY && fok) atomicAdd(&gradT[(size_t)cur[k] * Fd + f], acc[k]);
-                            cur[k] = v[k];
-                            acc[k] = 0.f;
+                        for (int a = 0; a < D; ++a) {
+                            nacc[a] = 0.f;
+                            bool taken = v[a] == TN_EMPTY;
+#pragma unroll
+                            for (int c = 0; c < D; ++c)
+                                if (!taken && cur[c] == v[a] && !((carried >> c) & 1u)) { nacc[a] = acc[c]; carried |= 1u << c; taken = true; }
                         }
+#pragma unroll
+                        for (int c = 0; c < D; ++c)
+                            if (!((carried >> c) & 1u) && cur[c] != TN_EMPTY && fok) atomicAdd(&gradT[(size_t)cur[c] * Fd + f], acc[c]);
+#pragma unroll
+                        for (int k = 0; k < D; ++k) { cur[k] = v[k]; acc[k] = nacc[k]; }
                     }
 #pragma unroll
                     for (int k = 0; k < D; ++k) acc[k] += wgt[k] * g[j];
