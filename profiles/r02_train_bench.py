@@ -31,9 +31,9 @@ for R, S in ((4096, 256), (4096, 513)):
     wd = [x.detach() for x in w]
     def fwd_only():
         with torch.no_grad(): return tn.cpp.mlp_forward_gather_train(vi, bc, field.detach(), dirs, wd, S)
-    saved = fwd_only()[2]
+    s0, c0, saved = fwd_only()
     def bwd_only():
-        tn.cpp.mlp_backward(saved, vi, bc, field.detach(), dirs, wd, gs, gc)
+        tn.cpp.mlp_backward(saved, vi, bc, field.detach(), dirs, wd, s0, c0, gs, gc)
     def autograd():
         field.grad = None; mlp.zero_grad()
         feats = tn.interpolate_values(vi, bc, field)

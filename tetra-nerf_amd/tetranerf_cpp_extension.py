@@ -709,7 +709,8 @@ class _MlpBackwardBuffers(C.Structure):
 
 class MlpSaved:
     """What mlp_forward_gather_train leaves for mlp_backward: the layer inputs x0 [64,n], h1..h4 [128,n] (feature-major: the
-    operands of the weight-gradient GEMMs), the ReLU masks [4,n,2] (all the dX kernel needs) and the outputs."""
+    operands of the weight-gradient GEMMs) and the ReLU masks [4,n,2] (all the dX kernel needs).  (`sigma` / `rgb` are the
+    forward's outputs as returned; an autograd node must hold them through save_for_backward, not through this object.)"""
     __slots__ = ("acts", "masks", "sigma", "rgb", "n", "S")
 
 
@@ -746,9 +747,10 @@ def mlp_forward_gather_train(vertex_indices, barycentric_coordinates, field, dir
     return sv.sigma, sv.rgb, sv
 
 
-def mlp_backward(saved, vertex_indices, barycentric_coordinates, field, dirs, weights, d_sigma, d_rgb):
+def mlp_backward(saved, vertex_indices, barycentric_coordinates, field, dirs, weights, sigma, rgb, d_sigma, d_rgb):
     """Adjoint of mlp_forward_gather_train (addition; the reference leaves this to PyTorch autograd, model.py:602-630):
-    given dL/dsigma [n] and dL/drgb [n,3] returns (grad_field [64,V], [12 weight gradients in the order of `weights`]).
+    given the forward's outputs sigma [n] / rgb [n,3], dL/dsigma [n] and dL/drgb [n,3] returns (grad_field [64,V], [12 weight
+    gradients in the order of `weights`]).
     tn_mlp_backward -- the dX chain on the fp32 matrix cores from the saved ReLU masks, nothing recomputed -- then
     tn_mlp_param_grads -- the twelve parameter gradients as sample-streaming fp32-MFMA GEMMs over the saved layer inputs,
     summed without atomics (bit-reproducible) -- then the gather's adjoint.  2.1 KB of gradient buffers per sample."""
@@ -776,7 +778,7 @@ def mlp_backward(saved, vertex_indices, barycentric_coordinates, field, dirs, we
                              buf[256:384].data_ptr(), buf[384:512].data_ptr(), buf[512:516].data_ptr(), rows.data_ptr())
     stream = _stream(dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.tn_mlp_backward(mh.handle, n, _ptr(saved.sigma), _ptr(saved.rgb), _ptr(d_sigma), _ptr(d_rgb),
+        _lib.check(lib.tn_mlp_backward(mh.handle, n, _ptr(sigma.contiguous()), _ptr(rgb.contiguous()), _ptr(d_sigma), _ptr(d_rgb),
                                        C.byref(bs), stream))
         _lib.check(lib.tn_mlp_param_grads(mh.handle, n, S, _ptr(dirs), C.byref(bs), C.byref(gs), stream))
         # gradient of the gathered features -> field (vertex-major accumulation)
