@@ -93,9 +93,9 @@ __global__ void k_dir_encoding(size_t R, const float *__restrict__ dirs, float *
 
 }  // namespace
 
-// BLOCK = 512: 8 waves share each staged layer, one block per CU.  BLOCK = 256: 4 waves per block and TWO blocks per CU
-// (the head layer staged in two halves so that the largest stage is 67 KB): while one block waits for a weight copy or
-// at a barrier the other one's waves keep the matrix cores busy.
+// 8 waves (BLOCK = 512) share each staged layer, one block per CU, two waves per SIMD: while one waits for a weight copy, at
+// a barrier or in an epilogue the other one's MFMAs run.  (Round 2's 4-wave / two-blocks-per-CU variant with the head layer
+// staged in two halves measured neutral, profiles/r02o_mlp_block.txt, and is gone.)
 // TRAIN: the layer inputs x0, h1..h4 (feature-major, what the weight-gradient GEMMs contract) and the ReLU masks (all the
 // dX kernel needs) are saved on the way -- the backward pass recomputes nothing (round 3a recomputed the whole forward
 // inside the dX kernel: 2.2 of its 5 ms).
@@ -110,7 +110,6 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
     float *lds = reinterpret_cast<float *>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     constexpr size_t GROUP = (BLOCK / 64) * 32;
-    constexpr bool SPLIT_HEAD = BLOCK < MLP_BLOCK;
     const size_t ngroups = (n + GROUP - 1) / GROUP;
 
     for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -198,7 +197,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
         if constexpr (DENSITY_ONLY) continue;  // coarse pass of the model (model.py:577-581)
         // ---- head [enc(27) | base(128)] -> 128 ReLU
         __syncthreads();
-        stage_weights<BLOCK>(lds, pk + OFF_WHEAD, SPLIT_HEAD ? N_WHEAD_A : N_WHEAD);
+        stage_weights<BLOCK>(lds, pk + OFF_WHEAD, N_WHEAD);
         stage_wait();
         {
             f32x16 acc[OT];
@@ -212,26 +211,16 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
                 for (int t = 0; t < OT; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], b, acc[t], 0, 0, 0);
             }
-            if constexpr (SPLIT_HEAD) {
-                constexpr int KA = HEAD_KS_A - KSE;          // base k-steps in the first half
-                gemm_steps<KA, KSE, OT>(acc, bin, lds, lane);
-                __syncthreads();
-                stage_weights<BLOCK>(lds, pk + OFF_WHEAD + N_WHEAD_A, N_WHEAD_B);
-                stage_wait();
-                gemm_steps<KSH - KA, 0, OT, KA>(acc, bin, lds, lane);
-                bias_step<KSH - KA, OT>(acc, lds, lane);
-            } else {
-                if constexpr (TRAIN) gemm_steps_store<KSH, KSE, OT, KSH, false>(acc, bin, lds, lane, sv.h3 + (size_t)(4 * h) * n + sc, n);
-                else gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
-                bias_step<HEAD_KS, OT>(acc, lds, lane);
-            }
+            if constexpr (TRAIN) gemm_steps_store<KSH, KSE, OT, KSH, false>(acc, bin, lds, lane, sv.h3 + (size_t)(4 * h) * n + sc, n);
+            else gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
+            bias_step<HEAD_KS, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);
         }
         if constexpr (TRAIN) store_bin(sv.h4, n, sc, true, bin, h);   // the last layer's output has no GEMM to hide under
         save_mask(3);
         {
             // rgb head 128 -> 3 + sigmoid on the VALU
-            const float *cv = lds + (SPLIT_HEAD ? lfloats(KSH - (HEAD_KS_A - KSE), OT) : lfloats(HEAD_KS, OT));
+            const float *cv = lds + lfloats(HEAD_KS, OT);
             const float c0 = head_dot(cv + 64 * h, bin) + cv[384];
             const float c1 = head_dot(cv + 128 + 64 * h, bin) + cv[385];
             const float c2 = head_dot(cv + 256 + 64 * h, bin) + cv[386];

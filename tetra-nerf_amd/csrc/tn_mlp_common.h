@@ -40,11 +40,6 @@ constexpr size_t OFF_WHEAD = OFF_W3 + N_W3;
 constexpr size_t N_WHEAD = lfloats(HEAD_KS, OT) + CVEC;
 constexpr size_t PACK_FLOATS = OFF_WHEAD + N_WHEAD;
 constexpr size_t MAX_STAGE_FLOATS = N_WHEAD;
-// the head layer staged in two halves (4-wave blocks, two per CU: the largest stage must stay below 80 KB)
-constexpr int HEAD_KS_A = 40;                                    // k-steps of the first half: 14 encoding + 26 base
-constexpr size_t N_WHEAD_A = (size_t)HEAD_KS_A * OT * 64;
-constexpr size_t N_WHEAD_B = N_WHEAD - N_WHEAD_A;                // 38 base k-steps + the bias step + the rgb vectors
-constexpr size_t MAX_STAGE_FLOATS_SPLIT = N_W3;                  // 67 KB
 
 __host__ __device__ constexpr int acc_feature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 // k index consumed by k-step `ks` (0..63) of a layer whose input lives in accumulators, half h
