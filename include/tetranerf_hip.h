@@ -323,13 +323,16 @@ int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, cons
  * back-propagates through nerfstudio's MLP / renderers, model.py:602-638).  Three calls per batch of n samples, all on
  * the handle's weights, fp32 MFMA:
  *   tn_mlp_forward_gather_train  = tn_mlp_forward_gather (mode 0) that also SAVES what the backward pass needs:
- *       x0 [64,n] gathered features, h1..h4 [128,n] layer outputs after ReLU (feature-major: the operands of the
- *       weight-gradient GEMMs) and masks [4,n,2] u64 = the ReLU masks of h1..h4 (all the dX chain needs);
+ *       x0 [64,n] gathered features, h1..h4 [128,n] layer outputs after ReLU (the operands of the weight-gradient
+ *       GEMMs) and masks [4,n,2] u64 = the ReLU masks of h1..h4 (all the dX chain needs);
  *   tn_mlp_backward  runs the reverse network from the masks and the forward's OUTPUTS sigma [n] / rgb [n,3]
  *       (softplus' = 1 - exp(-sigma), sigmoid' = rgb (1 - rgb)) -- nothing is recomputed -- given d_sigma f32 [n],
  *       d_rgb f32 [n,3]; fills d1..d4 [128,n] (gradients w.r.t. the pre-activations of mlp_base layers 0..2 and of
- *       mlp_head), dhead [4,n] = d sigma_raw, d rgb_raw[0..2], and dx0 [n,64] = the gradient of the gathered features as
- *       SAMPLE-major rows (feed it to tn_interpolate_values_backward_vm / _rows);
+ *       mlp_head), dhead [4,n] = d sigma_raw, d rgb_raw[0..2] (four plain rows), and dx0 [n,64] = the gradient of the
+ *       gathered features as SAMPLE-major rows (feed it to tn_interpolate_values_backward_vm / _rows);
+ *   The [F,n] tensors x0, h1..h4, d1..d4 are opaque to the caller and QUAD-major: [F/4][n][4] floats, element (feature
+ *   f, sample s) at ((f / 4) n + s) 4 + f % 4 -- 16-byte stores for the kernels that produce them, 16-byte tile loads for
+ *   the GEMMs that consume them.
  *   tn_mlp_param_grads  ACCUMULATES the gradients of the twelve parameter tensors (tn_mlp_grads: fp32 gradient buffers
  *       in nn.Linear layout, zeroed by the caller before the first batch) from those buffers: dW_l = d_l (input of
  *       layer l)^T as sample-streaming fp32-MFMA GEMMs (the 27 direction-encoding columns of mlp_head and the density

@@ -147,8 +147,8 @@ void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, 
                            hipStream_t stream);
 // Training (tn_mlp.hip: TRAIN variant of the forward kernel, tn_mlp_bwd.hip, tn_mlp_grad.hip).  The training forward SAVES
 // the layer inputs and the ReLU masks; the backward kernel runs the reverse network from the masks alone (no recompute);
-// the parameter-gradient GEMMs contract the saved inputs with the gradients it leaves.  Feature-major [F, n] device memory
-// owned by the caller.
+// the parameter-gradient GEMMs contract the saved inputs with the gradients it leaves.  Device memory owned by the caller;
+// the [F, n] tensors are QUAD-major, [F / 4][n][4] floats (tn_mlp_common.h).
 struct MlpBackwardBuffers {
     float *x0;                 // [64, n]   gathered features (layer-1 input)                              forward -> grads
     float *h1, *h2, *h3, *h4;  // [128, n]  layer outputs after ReLU (inputs of the next layer)             forward -> grads

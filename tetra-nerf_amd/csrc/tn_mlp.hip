@@ -153,7 +153,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
             zero_acc(acc);
             // TRAIN: every GEMM's input leaves for HBM under the GEMM's own MFMAs (lanes beyond the end store their
             // duplicate of sample n - 1 where its owner stores it)
-            if constexpr (TRAIN) gemm_steps_store<KS1, 0, OT, KS1, true>(acc, bin, lds, lane, sv.x0 + (size_t)(32 * h) * n + sc, n);
+            if constexpr (TRAIN) gemm_steps_store<KS1, 0, OT, KS1>(acc, bin, lds, lane, quad_ptr_x0(sv.x0, n, sc, h), n);
             else gemm_steps<KS1, 0, OT>(acc, bin, lds, lane);
             bias_step<KS1, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
         {
             f32x16 acc[OT];
             zero_acc(acc);
-            if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, lds, lane, sv.h1 + (size_t)(4 * h) * n + sc, n);
+            if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h1, n, sc, h), 2 * n);
             else gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
             bias_step<KSH, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
         {
             f32x16 acc[OT];
             zero_acc(acc);
-            if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, lds, lane, sv.h2 + (size_t)(4 * h) * n + sc, n);
+            if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h2, n, sc, h), 2 * n);
             else gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
             bias_step<KSH, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);  // mlp_base out_activation = ReLU
@@ -211,12 +211,12 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
                 for (int t = 0; t < OT; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], b, acc[t], 0, 0, 0);
             }
-            if constexpr (TRAIN) gemm_steps_store<KSH, KSE, OT, KSH, false>(acc, bin, lds, lane, sv.h3 + (size_t)(4 * h) * n + sc, n);
+            if constexpr (TRAIN) gemm_steps_store<KSH, KSE, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h3, n, sc, h), 2 * n);
             else gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
             bias_step<HEAD_KS, OT>(acc, lds, lane);
             relu_to_bin(acc, bin);
         }
-        if constexpr (TRAIN) store_bin(sv.h4, n, sc, true, bin, h);   // the last layer's output has no GEMM to hide under
+        if constexpr (TRAIN) store_bin(sv.h4, n, sc, bin, h);   // the last layer's output has no GEMM to hide under
         save_mask(3);
         {
             // rgb head 128 -> 3 + sigmoid on the VALU

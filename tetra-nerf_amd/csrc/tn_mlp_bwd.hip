@@ -178,7 +178,7 @@ __global__ __launch_bounds__(BWD_BLOCK) void k_mlp_backward(size_t n, BwdIn in, 
         // the next group's masks and head gradients
         const Head hn = load_head(g + gridDim.x < ngroups ? g + gridDim.x : g);
         zero_acc(acc);
-        gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, bufA, lane, o.d4 + (size_t)(4 * h) * n + sc, n);
+        gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, bufA, lane, quad_ptr(o.d4, n, sc, h), 2 * n);
         {
             const float *dv = bufA + tfloats(OT) + 64 * h;
 #pragma unroll
@@ -191,12 +191,12 @@ __global__ __launch_bounds__(BWD_BLOCK) void k_mlp_backward(size_t n, BwdIn in, 
         layer_top();
         stage_fixed<P_T>(bufA, pt + OFFT_2);
         zero_acc(acc);
-        gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, bufB, lane, o.d3 + (size_t)(4 * h) * n + sc, n);
+        gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, bufB, lane, quad_ptr(o.d3, n, sc, h), 2 * n);
         masked_to_bin(acc, m2, bin);
         layer_top();
         stage_fixed<P_T1>(bufB, pt + OFFT_1);
         zero_acc(acc);
-        gemm_steps_store<KSH, 0, OT, KSH, false>(acc, bin, bufA, lane, o.d2 + (size_t)(4 * h) * n + sc, n);
+        gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, bufA, lane, quad_ptr(o.d2, n, sc, h), 2 * n);
         masked_to_bin(acc, m1, bin);
         // ---- d x0 = W1^T d_pre1  (64 input features = 2 tiles) (B); the next group's first stage goes to A meanwhile
         layer_top();
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(BWD_BLOCK) void k_mlp_backward(size_t n, BwdIn in, 
         {
             f32x16 acc2[OTI1];
             zero_acc(acc2);
-            gemm_steps_store<KSH, 0, OTI1, KSH, false>(acc2, bin, bufB, lane, o.d1 + (size_t)(4 * h) * n + sc, n);
+            gemm_steps_store<KSH, 0, OTI1, KSH>(acc2, bin, bufB, lane, quad_ptr(o.d1, n, sc, h), 2 * n);
             // d x0 leaves as SAMPLE-major rows [n, 64] (the gather adjoint reads a sample's gradient as one 256-byte line):
             // through this wave's slice of the tail of buffer B ([32 samples][65]: conflict-free both ways), each sample's
             // 64 values then go out as one coalesced store

@@ -94,13 +94,19 @@ static __device__ __forceinline__ void gemm_steps(f32x16 (&acc)[TILES], const fl
     }
 }
 
-// gemm_steps + the feature-major stores of the B operand (the training kernels save every GEMM's input): two values after
-// each of the first NST / 2 k-steps, i.e. in the shadow of MFMAs and drained long before the GEMM ends.  LINEAR:
-// consecutive values are n floats apart (x0); otherwise the accumulator order of store_slots.
-template <int KS, int KS0, int TILES, int NST, bool LINEAR>
+// Layout of the training buffers ("quad-major"): [F / 4][n][4] floats -- element (feature f, sample s) at
+// ((f / 4) n + s) 4 + f % 4.  A lane holds its sample's features in groups of four consecutive ones (slots 4g .. 4g + 3 of
+// half-wave h = features 32 (g >> 2) + 8 (g & 3) + 4 h + {0..3} = quad 8 (g >> 2) + 2 (g & 3) + h), so a group leaves as ONE
+// 16-byte store per lane, 512 contiguous bytes per half-wave (feature-major [F][n] needed four 4-byte stores: the store
+// instructions themselves, not the bytes, were what saving cost the training kernels), and the weight-gradient GEMMs
+// fetch their tiles as 16-byte loads.
+//
+// gemm_steps + the stores of the B operand (the training kernels save every GEMM's input): one quad after every second
+// k-step of the first NST / 2, i.e. in the shadow of MFMAs and drained long before the GEMM ends.  p: this lane's first
+// quad; qstride: distance of consecutive quads in float4 units (2 n in accumulator order, n for x0).
+template <int KS, int KS0, int TILES, int NST>
 static __device__ __forceinline__ void gemm_steps_store(f32x16 (&acc)[TILES], const float (&bin)[KSH], const float *lds, int lane,
-                                                        float *__restrict__ p, size_t n) {
-    const size_t n5 = 5 * n;
+                                                        float4 *__restrict__ p, size_t qstride) {
     float a[TILES], an[TILES];
     const float *w0 = lds + (size_t)KS0 * TILES * 64 + lane;
 #pragma unroll
@@ -116,17 +122,21 @@ static __device__ __forceinline__ void gemm_steps_store(f32x16 (&acc)[TILES], co
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bin[ks], acc[t], 0, 0, 0);
-        if (2 * ks < NST) {
-#pragma unroll
-            for (int j = 2 * ks; j < 2 * ks + 2; ++j) {
-                *p = bin[j];
-                p += (LINEAR || (j & 3) != 3) ? n : n5;
-            }
+        if ((ks & 1) == 0 && 2 * ks < NST) {
+            *p = make_float4(bin[2 * ks], bin[2 * ks + 1], bin[2 * ks + 2], bin[2 * ks + 3]);
+            p += qstride;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < TILES; ++t) a[t] = an[t];
     }
+}
+// this lane's first quad of a [128 / 4][n][4] tensor in accumulator order / of the [64 / 4][n][4] gathered features
+static __device__ __forceinline__ float4 *quad_ptr(float *base, size_t n, size_t s, int h) {
+    return reinterpret_cast<float4 *>(base) + ((size_t)h * n + s);
+}
+static __device__ __forceinline__ float4 *quad_ptr_x0(float *base, size_t n, size_t s, int h) {
+    return reinterpret_cast<float4 *>(base) + ((size_t)(8 * h) * n + s);
 }
 
 template <int STEP, int TILES>
@@ -169,23 +179,14 @@ static __device__ __forceinline__ void relu_to_bin(const f32x16 (&acc)[TILES], f
 }
 
 
-// slot j of half-wave h holds feature acc_k(j, h) = 32 (j >> 4) + (j & 3) + 8 ((j >> 2) & 3) + 4 h: from slot to slot
-// the feature grows by 1, or by 5 after every fourth slot -- the feature-major stores ([F, n]: a register of the wave = one
-// feature of 32 consecutive samples = one 128-byte line) walk one pointer with two strides (64 independent row addresses
-// would be hoisted out of the sample loop and spill).
-template <int COUNT>
-static __device__ __forceinline__ void store_slots(float *__restrict__ dst, size_t n, size_t s, bool ok, const float (&vals)[COUNT], int h) {
-    if (!ok) return;
-    float *p = dst + (size_t)(4 * h) * n + s;
-    const size_t n1 = n, n5 = 5 * n;
+// all 64 values a lane holds of a [128 / 4][n][4] tensor (see above): 16 quads, 2 n float4 apart
+static __device__ __forceinline__ void store_bin(float *__restrict__ dst, size_t n, size_t s, const float (&bin)[KSH], int h) {
+    float4 *p = quad_ptr(dst, n, s, h);
 #pragma unroll
-    for (int j = 0; j < COUNT; ++j) {
-        *p = vals[j];
-        p += ((j & 3) == 3) ? n5 : n1;
+    for (int g = 0; g < KSH / 4; ++g) {
+        *p = make_float4(bin[4 * g], bin[4 * g + 1], bin[4 * g + 2], bin[4 * g + 3]);
+        p += 2 * n;
     }
-}
-static __device__ __forceinline__ void store_bin(float *__restrict__ dst, size_t n, size_t s, bool ok, const float (&bin)[KSH], int h) {
-    store_slots<KSH>(dst, n, s, ok, bin, h);
 }
 // ReLU mask of the 64 activations a lane holds (slot j: bit j); stored as masks[(layer * n + sample) * 2 + half]
 static __device__ __forceinline__ unsigned long long mask_of(const float (&bin)[KSH]) {

@@ -45,16 +45,16 @@ template <int NBM, bool EXTRA>
 __global__ __launch_bounds__(256, 2) void k_dw_gemm(DwArgs g, size_t n, uint32_t slice) {
     constexpr int NB = NBM + (EXTRA ? 1 : 0);
     constexpr int RA = 128, RBM = 32 * NBM, RB = 32 * NB;
-    constexpr int PA = RA / 8, PBM = RBM / 8, PB = RB / 8;
     __shared__ __attribute__((aligned(16))) float As[RA * LD];
     __shared__ __attribute__((aligned(16))) float Bs[RB * LD];
     __shared__ __attribute__((aligned(16))) float dhs[32];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int col = tid & 31, row0 = tid >> 5;            // staging: 8 rows of 32 samples per pass
+    const int col = tid & 31, row0 = tid >> 5;            // staging: sample of the step, quad (4 feature rows) within a pass of 8
     const int cpos = (col & 1) * 16 + (col >> 1);         // even samples first, then the odd ones
     const size_t s_begin = (size_t)blockIdx.x * slice;
     const size_t s_end = s_begin + slice < n ? s_begin + slice : n;
     float *part = g.part + (size_t)blockIdx.x * (RA * RB + 256);
+    constexpr int QA = RA / 32, QBM = RBM / 32;           // quads per thread: the tiles are [F / 4][n][4] (tn_mlp_common.h)
 
     f32x16 acc[NB];
 #pragma unroll
@@ -63,29 +63,35 @@ __global__ __launch_bounds__(256, 2) void k_dw_gemm(DwArgs g, size_t n, uint32_t
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
     float rsum = 0.f, dv = 0.f;
     if (s_begin < n) {
-        float ra[PA], rb[PB], rdh = 0.f;
+        float4 ra[QA], rb[QBM];
+        float re[EXTRA ? 4 : 1], rdh = 0.f;
+        const float4 *A4 = reinterpret_cast<const float4 *>(g.A), *B4 = reinterpret_cast<const float4 *>(g.B);
         auto fetch = [&](size_t s0) {
             const size_t sidx = s0 + col;
             const bool in = sidx < s_end;
             const size_t sc = in ? sidx : s_end - 1;      // clamped: loads stay unconditional, A (and dh) are zeroed
 #pragma unroll
-            for (int p = 0; p < PA; ++p) ra[p] = g.A[(size_t)(8 * p + row0) * n + sc];
+            for (int p = 0; p < QA; ++p) ra[p] = A4[(size_t)(8 * p + row0) * n + sc];
 #pragma unroll
-            for (int p = 0; p < PBM; ++p) rb[p] = g.B[(size_t)(8 * p + row0) * n + sc];
-            if (EXTRA) {
-                const float *e = g.enc + (sc / g.spr) * ENC_PAD;
+            for (int p = 0; p < QBM; ++p) rb[p] = B4[(size_t)(8 * p + row0) * n + sc];
+            if constexpr (EXTRA) {
+                const float *e = g.enc + (size_t)((uint32_t)sc / g.spr) * ENC_PAD;   // n < 2^32 (checked by the launcher)
 #pragma unroll
-                for (int p = PBM; p < PB; ++p) {
-                    const int j = 8 * (p - PBM) + row0;
-                    rb[p] = j < ENC_PAD ? e[j < ENC_PAD ? j : 0] : 0.f;
+                for (int p = 0; p < 4; ++p) {
+                    const int j = 8 * p + row0;
+                    re[p] = j < ENC_PAD ? e[j < ENC_PAD ? j : 0] : 0.f;
                 }
                 rdh = row0 == 0 ? g.dh[sc] : 0.f;
                 if (!in) rdh = 0.f;
             }
             if (!in) {
 #pragma unroll
-                for (int p = 0; p < PA; ++p) ra[p] = 0.f;
+                for (int p = 0; p < QA; ++p) ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        };
+        auto put4 = [&](float *tile, int quad, const float4 &v) {
+            float *q = tile + (4 * quad) * LD + cpos;
+            q[0] = v.x; q[LD] = v.y; q[2 * LD] = v.z; q[3 * LD] = v.w;
         };
         fetch(s_begin);
         const int m = lane & 31, kk = lane >> 5;
@@ -95,10 +101,14 @@ __global__ __launch_bounds__(256, 2) void k_dw_gemm(DwArgs g, size_t n, uint32_t
         for (size_t s0 = s_begin; s0 < s_end; s0 += 32) {
             __syncthreads();   // the previous step's reads of the tiles are done
 #pragma unroll
-            for (int p = 0; p < PA; ++p) As[(8 * p + row0) * LD + cpos] = ra[p];
+            for (int p = 0; p < QA; ++p) put4(As, 8 * p + row0, ra[p]);
 #pragma unroll
-            for (int p = 0; p < PB; ++p) Bs[(8 * p + row0) * LD + cpos] = rb[p];
-            if (EXTRA && row0 == 0) dhs[cpos] = rdh;
+            for (int p = 0; p < QBM; ++p) put4(Bs, 8 * p + row0, rb[p]);
+            if constexpr (EXTRA) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) Bs[(RBM + 8 * p + row0) * LD + cpos] = re[p];
+                if (row0 == 0) dhs[cpos] = rdh;
+            }
             __syncthreads();
             if (s0 + 32 < s_end) fetch(s0 + 32);
             float4 a4[4], b4[2][4];
@@ -205,19 +215,32 @@ __global__ __launch_bounds__(256) void k_rgb_head_grad(size_t n, uint32_t slice,
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i][0] = acc[i][1] = acc[i][2] = 0.f;
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    const float *rows = h4 + (size_t)(32 * w) * n;
-    for (size_t s0 = s_begin; s0 < s_end; s0 += 64) {
-        const size_t s = s0 + lane;
-        const bool in = s < s_end;
-        const size_t sc = in ? s : s_end - 1;
-        float d0 = dhead[sc], d1 = dhead[n + sc], d2 = dhead[2 * n + sc], d3 = dhead[3 * n + sc];
-        if (!in) d0 = d1 = d2 = d3 = 0.f;
-        t0 += d0; t1 += d1; t2 += d2; t3 += d3;
-        float x[32];
+    const float4 *rows = reinterpret_cast<const float4 *>(h4) + (size_t)(8 * w) * n;   // [F / 4][n][4]: quads 8 w .. 8 w + 7
+    for (size_t s0 = s_begin; s0 < s_end; s0 += 128) {     // two columns of 64 samples per trip: 16 row loads in flight
+        float4 x[2][8];
+        float dd[2][3];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) x[i] = rows[(size_t)i * n + sc];
+        for (int u = 0; u < 2; ++u) {
+            const size_t s = s0 + 64 * u + lane;
+            const bool in = s < s_end;
+            const size_t sc = in ? s : s_end - 1;
+            float d0 = dhead[sc], d1 = dhead[n + sc], d2 = dhead[2 * n + sc], d3 = dhead[3 * n + sc];
+            if (!in) d0 = d1 = d2 = d3 = 0.f;
+            t0 += d0; t1 += d1; t2 += d2; t3 += d3;
+            dd[u][0] = d1; dd[u][1] = d2; dd[u][2] = d3;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) { acc[i][0] += x[i] * d1; acc[i][1] += x[i] * d2; acc[i][2] += x[i] * d3; }
+            for (int i = 0; i < 8; ++i) x[u][i] = rows[(size_t)i * n + sc];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xv[4] = {x[u][i].x, x[u][i].y, x[u][i].z, x[u][i].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[4 * i + c][0] += xv[c] * dd[u][0]; acc[4 * i + c][1] += xv[c] * dd[u][1]; acc[4 * i + c][2] += xv[c] * dd[u][2];
+                }
+            }
     }
     float *part = part_all + (size_t)blockIdx.x * RGB_SLOT;
 #pragma unroll
@@ -280,6 +303,7 @@ size_t mlp_param_grad_scratch_floats() { return (size_t)DW_GRID * (128 * 160 + 2
 void launch_mlp_param_grads(size_t n, uint32_t samples_per_ray, const float *dirs, const MlpPacks &w, const MlpBackwardBuffers &b,
                             const MlpParamGrads &g, hipStream_t stream) {
     if (n == 0) return;
+    if (n > 0xFFFFFFFFull) throw Error("param_grads: more than 2^32 samples per call");
     launch_dir_encoding(n / samples_per_ray, dirs, w.enc, stream);
     float *part = w.grad_scratch;
     // mlp_head: [enc(27) | base(128)] -> 128, and the density head's weight vector
@@ -291,7 +315,7 @@ void launch_mlp_param_grads(size_t n, uint32_t samples_per_ray, const float *dir
                      ReduceArgs{nullptr, 0, 0, 0, g.w2, HID, nullptr, 0, g.b2, nullptr}, stream);
     run_dw<2, false>(n, DwArgs{b.d1, b.x0, nullptr, nullptr, 0, part},
                      ReduceArgs{nullptr, 0, 0, 0, g.w1, FD, nullptr, 0, g.b1, nullptr}, stream);
-    const Slicing sl = slicing(n, 64);
+    const Slicing sl = slicing(n, 128);
     hipLaunchKernelGGL(k_rgb_head_grad, dim3(sl.grid), dim3(256), 0, stream, n, sl.slice, b.dhead, b.h4, part);
     hipLaunchKernelGGL(k_reduce_rgb, dim3((RGB_SLOT + 63) / 64), dim3(256), 0, stream, part, sl.grid, g.wr, g.bd, g.br);
 }
