@@ -96,7 +96,7 @@ __global__ void k_dir_encoding(size_t R, const float *__restrict__ dirs, float *
 // 8 waves (BLOCK = 512) share each staged layer, one block per CU, two waves per SIMD: while one waits for a weight copy, at
 // a barrier or in an epilogue the other one's MFMAs run.  (Round 2's 4-wave / two-blocks-per-CU variant with the head layer
 // staged in two halves measured neutral, profiles/r02o_mlp_block.txt, and is gone.)
-// TRAIN: the layer inputs x0, h1..h4 (feature-major, what the weight-gradient GEMMs contract) and the ReLU masks (all the
+// TRAIN: the layer inputs x0, h1..h4 (quad-major [F/4][n][4], what the weight-gradient GEMMs contract) and the ReLU masks (all the
 // dX kernel needs) are saved on the way -- the backward pass recomputes nothing (round 3a recomputed the whole forward
 // inside the dX kernel: 2.2 of its 5 ms).
 struct FwdSave { float *x0, *h1, *h2, *h3, *h4; unsigned long long *masks; };

@@ -12,10 +12,10 @@
 //       (64 bits per lane and layer), and softplus' / sigmoid' follow from the forward's OUTPUTS
 //       (softplus'(x) = 1 - exp(-softplus(x)), sigmoid' = y (1 - y)).  Round 3a recomputed the forward pass inside this
 //       kernel (1864 MFMAs per 32 samples; now 896).
-//       Outputs: the pre-activation gradients d_pre1..4 and d_sigma_raw / d_rgb_raw FEATURE-MAJOR [F, n] (a register of
-//       the wave = one feature of 32 consecutive samples = one 128-byte line) for the weight-gradient GEMMs
-//       (tn_mlp_grad.hip), and d_x0 [n, 64] = the gradient of the gathered features as sample-major rows, which
-//       tn_interpolate_values_backward_vm scatters into the field.
+//       Outputs: the pre-activation gradients d_pre1..4 QUAD-major ([F/4][n][4], tn_mlp_common.h: a lane's four consecutive
+//       features = one 16-byte store, 512 contiguous bytes per half-wave) and d_sigma_raw / d_rgb_raw as four plain rows
+//       [4, n], for the weight-gradient GEMMs (tn_mlp_grad.hip); and d_x0 [n, 64] = the gradient of the gathered features
+//       as sample-major rows, which tn_interpolate_values_backward_vm scatters into the field.
 //
 // FLOPs per fine sample: forward 122.6 k, dX 114.7 k, dW 122.4 k.
 #include "tn_mlp_common.h"
@@ -78,8 +78,8 @@ struct BwdOut {
 // forward kernel would need them in 256 registers and spills).  A wave alone on its SIMD has nobody to hide its waits, so:
 //   * the four weight stages of a group ping-pong between two LDS buffers: stage l + 1 is requested (async global -> LDS)
 //     when GEMM l starts and has the whole GEMM to land; ONE barrier per layer;
-//   * the feature-major stores of a GEMM's input (d4..d1: 64 x 128-byte lines per wave and tensor) are issued between the
-//     MFMAs of the first 32 k-steps of the GEMM that consumes it, so that they have drained when the next
+//   * the stores of a GEMM's input (d4..d1: 16 quads per lane and tensor) are issued between the MFMAs of the first 32
+//     k-steps of the GEMM that consumes it, so that they have drained when the next
 //     `s_waitcnt vmcnt(0)` comes (on gfx9 stores and loads share that counter);
 //   * the masks and head gradients of the NEXT group are requested a GEMM ahead.
 constexpr int BWD_BLOCK = 256;

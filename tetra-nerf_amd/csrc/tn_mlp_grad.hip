@@ -10,8 +10,9 @@
 //   k_dw_gemm<2, false>  A = d1, B = x0: d W1, d b1
 //   k_rgb_head_grad      d wr[c][f] = sum_s d rgb_raw[c][s] h4[f][s], d bd, d br   (bandwidth-bound: 528 B per sample)
 //
-// k_dw_gemm: dW[128, 32 NB] = A[128, n] B[32 NB, n]^T with K = the sample axis streamed once from HBM (every operand row
-// is read as whole 128-byte lines), 32x32x2 fp32 MFMA tiles.  A block owns a contiguous slice of samples and walks it in
+// k_dw_gemm: dW[128, 32 NB] = A[128, n] B[32 NB, n]^T with K = the sample axis streamed once from HBM (the operands are
+// quad-major, [F/4][n][4], tn_mlp_common.h: a thread fetches four feature rows of one sample as one 16-byte load, a
+// half-wave 512 contiguous bytes), 32x32x2 fp32 MFMA tiles.  A block owns a contiguous slice of samples and walks it in
 // steps of 32: global -> registers (issued one step ahead) -> LDS -> MFMA operands.  The LDS rows hold the even samples
 // of the step followed by the odd ones (row stride 36 floats), so that lane (row, k parity) fetches its 16 operand values
 // of a step with four conflict-free 16-byte reads, and tile c + 1's operands are requested before tile c's MFMAs issue.

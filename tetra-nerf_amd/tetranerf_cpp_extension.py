@@ -708,8 +708,8 @@ class _MlpBackwardBuffers(C.Structure):
 
 
 class MlpSaved:
-    """What mlp_forward_gather_train leaves for mlp_backward: the layer inputs x0 [64,n], h1..h4 [128,n] (feature-major: the
-    operands of the weight-gradient GEMMs) and the ReLU masks [4,n,2] (all the dX kernel needs).  (`sigma` / `rgb` are the
+    """What mlp_forward_gather_train leaves for mlp_backward: the layer inputs x0 [64,n], h1..h4 [128,n] (quad-major
+    [F/4][n][4], opaque to the caller: the operands of the weight-gradient GEMMs) and the ReLU masks [4,n,2] (all the dX kernel needs).  (`sigma` / `rgb` are the
     forward's outputs as returned; an autograd node must hold them through save_for_backward, not through this object.)"""
     __slots__ = ("acts", "masks", "sigma", "rgb", "n", "S")
 
