@@ -84,6 +84,17 @@ int tn_trace_rays(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_triangle
                   const float *origins, const float *directions, uint32_t *num_visited,
                   uint32_t *visited, float *bary, float *dist, uint32_t *verts, void *stream);
 
+/* tn_trace_rays with per-call flags (no reference counterpart: the reference always materialises the dense rows).
+ * TN_TRACE_COMPACT_ROWS: slots >= num_visited[r] are left UNWRITTEN (and rows of rays that miss the mesh untouched but
+ * for num_visited[r] = 0) -- for consumers that read the rows only through num_visited (tn_sample_*, tn_render_pass,
+ * tn_find_matched_cells_indexed): 52 B per segment instead of 52*M B per ray.  A per-call argument rather than a tracer
+ * option, so that threads sharing a tracer (nerfstudio's viewer and trainer share the model) cannot see each other's
+ * choice. */
+#define TN_TRACE_COMPACT_ROWS 1u
+int tn_trace_rays_ex(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_triangles,
+                     const float *origins, const float *directions, uint32_t *num_visited,
+                     uint32_t *visited, float *bary, float *dist, uint32_t *verts, uint32_t flags, void *stream);
+
 /* TetrahedraTracer::trace_rays_triangles                src/tetrahedra_tracer.h:333-352,
  *   device programs                                      src/optix/optix_trace_rays_triangles.cu:50-115
  * the sorted all-hits list of each ray, without the pairing stage (not called by the model).
@@ -286,10 +297,15 @@ int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, cons
  *   dirs f32 [r,3]: full pass: out_rgb f32 [R,3], out_acc f32 [R], out_depth f32 [R] (arrays over ALL rays of the trace
  *                  call, written at ray_index[q]; pre-fill them with the background values); out_weights optional.
  * Always the fp32 MFMA arithmetic. */
+/* background colour of nerfstudio's RGBRenderer as the reference model configures / overrides it (model.py:466,504-518;
+ * `renderers.BACKGROUND_COLOR_OVERRIDE`): comp_rgb + background (1 - accumulation).  clamp != 0 = the renderer's
+ * evaluation mode (RGBRenderer.forward when not training): nan_to_num of the sample colours, result clamped to [0, 1].
+ * A NULL pointer means white without clamp (the shipped configurations in training mode). */
+typedef struct tn_rgb_background { float r, g, b; int clamp; } tn_rgb_background;
 int tn_render_pass(tn_mlp_t mlp, uint32_t max_ray_triangles, const uint32_t *num_visited, const float *hit_distances,
                    const float *barycentric, const uint32_t *vertex_indices, const uint32_t *ray_index, size_t num_hit_rays,
                    uint32_t num_samples, const float *edges, const float *field_vm, const float *dirs,
-                   float background, float *out_weights, float *out_rgb, float *out_acc, float *out_depth, void *stream);
+                   const tn_rgb_background *background, float *out_weights, float *out_rgb, float *out_acc, float *out_depth, void *stream);
 
 /* ---- ray samplers between tn_trace_rays and the render passes (model.py:111-192, 549-557, 582-586; nerfstudio's
  * UniformSampler / PDFSampler for the parts the reference imports).  One wavefront per HITTING ray; the trace rows are
@@ -316,8 +332,8 @@ int tn_sample_pdf(size_t num_hit_rays, uint32_t num_samples, uint32_t num_fine, 
  * out_rgb f32 [R,3], out_acc f32 [R], out_depth f32 [R], out_weights f32 [R,S] (nullable).
  * rgb == NULL and out_rgb == NULL: only out_weights is written (get_weights of the coarse pass, model.py:582). */
 int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, const float *rgb, const float *edges,
-                 float background, float *out_rgb, float *out_acc, float *out_depth, float *out_weights,
-                 void *stream);
+                 const tn_rgb_background *background, float *out_rgb, float *out_acc, float *out_depth,
+                 float *out_weights, void *stream);
 
 /* ---- training: the MLP node and the composite node (PyTorch autograd in the reference: the trainer
  * back-propagates through nerfstudio's MLP / renderers, model.py:602-638).  Three calls per batch of n samples, all on
@@ -358,8 +374,8 @@ int tn_mlp_param_grads(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const f
 /* adjoint of tn_composite w.r.t. sigma [R,S] and rgb [R,S,3], given the gradients of the rendered rgb [R,3] and
  * accumulation [R] (either nullable); the median depth carries no gradient. */
 int tn_composite_backward(size_t num_rays, uint32_t num_samples, const float *sigma, const float *rgb, const float *edges,
-                          float background, const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb,
-                          void *stream);
+                          const tn_rgb_background *background, const float *d_out_rgb, const float *d_out_acc,
+                          float *d_sigma, float *d_rgb, void *stream);
 
 #ifdef __cplusplus
 }

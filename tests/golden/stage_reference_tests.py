@@ -6,6 +6,8 @@ they can be run UNMODIFIED on top of libtetranerf_hip.so on a GPU box (where /ro
     tests/golden/ref/tetranerf/utils/__init__.py                 <- (empty in the reference)
     tests/golden/ref/tetranerf/utils/extension/__init__.py       <- the reference's op wrappers (autograd Function, aliases)
     tests/golden/ref/tetranerf/utils/extension/tetranerf_cpp_extension.py   <- THE SHIM (ours; written below)
+    tests/golden/ref/tetranerf/nerfstudio/{__init__,model}.py    <- the reference's nerfstudio model, verbatim (imports
+                                                                    nerfstudio: tests/golden/nerfstudio_stub/ provides it)
     tests/golden/ref/tests/{test_uint32,test_barycentrics,test_tetrahedra_tracer,test_tetrahedra_tracer_triangles}.py
     tests/golden/ref/tests/assets/bottle.ply
     tests/golden/ref/trimesh.py                                  <- 20-line stand-in for `trimesh.load` (not installed here)
@@ -27,6 +29,9 @@ COPIES = [
     "tetranerf/__init__.py",
     "tetranerf/utils/__init__.py",
     "tetranerf/utils/extension/__init__.py",
+    "tetranerf/nerfstudio/__init__.py",
+    "tetranerf/nerfstudio/model.py",    # the model whose get_outputs / TetrahedraSampler / GradientScaler are the oracle
+                                        # of the fused adapter (tests/test_reference_model*.py; needs ../nerfstudio_stub)
     "tests/test_uint32.py",
     "tests/test_barycentrics.py",
     "tests/test_tetrahedra_tracer.py",
@@ -105,7 +110,7 @@ def main():
     (OUT / "README.md").write_text(
         "Verbatim copies of the reference's Python op layer and tests (jkulhanek/tetra-nerf, `tetranerf/__init__.py`,\n"
         "`tetranerf/utils/extension/__init__.py`, `tests/test_{uint32,barycentrics,tetrahedra_tracer,tetrahedra_tracer_triangles}.py`,\n"
-        "`tests/assets/bottle.ply`), staged by `tests/golden/stage_reference_tests.py` as TEST FIXTURES so that they can run\n"
+        "`tests/assets/bottle.ply`, `tetranerf/nerfstudio/{__init__,model}.py`), staged by `tests/golden/stage_reference_tests.py` as TEST FIXTURES so that they can run\n"
         "unmodified against the MI355X library on a GPU box.  Ours in this directory: `tetranerf/utils/extension/tetranerf_cpp_extension.py`\n"
         "(the one-file shim of INTEGRATION.md section 2), `trimesh.py` (stand-in for `trimesh.load`), `pytest.ini`, this file.\n")
     print("staged", len(COPIES), "reference files under", OUT)

@@ -1,0 +1,184 @@
+"""The reference's UNMODIFIED `TetrahedraNerf` (tests/golden/ref/tetranerf/nerfstudio/model.py, a verbatim copy, imported
+on the stub nerfstudio namespace -- tests/golden/reference_model.py) on MI355X, as the oracle of the fused adapter:
+
+    want = reference body of get_outputs (model.py:520-662) on the HIP ops of the shim + the model's own torch modules
+    got  = the same model object after nerfstudio_plugin.install(): TetraRenderer.render / render_train on the fused kernels
+
+Evaluation: rgb / accumulation at 1e-5, depth at 1e-5 on all but the rays whose median sits on a rounding boundary; both
+shipped configurations, black background, a `BACKGROUND_COLOR_OVERRIDE` context (grey and coloured).  Training: the same
+stratified draws (same seed: both sides draw [r,S+1] then [r,S_fine+1] from torch's generator), outputs at 1e-5 and the
+gradients of all 13 tensors against the reference body under PyTorch autograd.  Unsupported configurations: the adapter
+must fall back to the reference body (bit-identical outputs)."""
+import importlib
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tests" / "golden"))
+import reference_model as rm   # noqa: E402
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return rm.load()
+
+
+@pytest.fixture(scope="module")
+def plugin(ref):
+    p = importlib.import_module("tetra-nerf_amd.nerfstudio_plugin")
+    p.install(ref.TetrahedraNerf)
+    yield p
+    p.uninstall(ref.TetrahedraNerf)
+
+
+def _rays(scenes, n=3600, seed=32):
+    o, d = scenes.outside_in_rays(n, seed)
+    o2, d2 = scenes.pinhole_rays(31, 16, eye=(0.5, 3.0, 2.6), lookat=(0.5, 0.5, 0.5))     # + rays that partly miss the mesh
+    return np.ascontiguousarray(np.concatenate([o, o2])), np.ascontiguousarray(np.concatenate([d, d2]))
+
+
+def _model(ref, scenes, device, **cfg):
+    pts, cells = scenes.random_mesh(6000, 31)
+    return rm.build_model(ref, pts, cells, **cfg).to(device)
+
+
+def _compare_eval(got, want, bg=None):
+    import torch
+
+    assert set(got) >= {"rgb", "accumulation", "depth", "ray_mask"}
+    assert torch.equal(got["ray_mask"], want["ray_mask"]) and 0.3 < float(want["ray_mask"].float().mean()) < 1.0
+    miss = ~want["ray_mask"]
+    assert torch.equal(got["rgb"][miss], want["rgb"][miss]) and torch.equal(got["depth"][miss], want["depth"][miss])
+    if bg is not None:
+        assert bool((got["rgb"][miss] == torch.tensor(bg, device=miss.device)).all())
+    np.testing.assert_allclose(got["rgb"].cpu().numpy(), want["rgb"].cpu().numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got["accumulation"].cpu().numpy(), want["accumulation"].cpu().numpy(), rtol=0, atol=1e-5)
+    same = ((got["depth"] - want["depth"]).abs() <= 1e-5)[:, 0]
+    assert float(same.float().mean()) > 0.995, float(same.float().mean())     # a median on a rounding boundary may flip a sample
+    assert float(want["accumulation"].max()) > 0.9
+
+
+EVAL_CONFIGS = [dict(num_samples=256, num_fine_samples=256),                                                    # tetra-nerf-original
+                dict(num_samples=128, num_fine_samples=128, use_biased_sampler=True, use_gradient_scaling=True),  # tetra-nerf
+                dict(num_samples=96, num_fine_samples=0, background_color="black", max_intersected_triangles=256)]
+
+
+@pytest.mark.parametrize("cfg", EVAL_CONFIGS)
+def test_fused_adapter_eval_equals_the_reference_body(tn, device, scenes, ref, plugin, cfg):
+    import torch
+    from nerfstudio.model_components import renderers
+
+    model = _model(ref, scenes, device, **cfg).eval()
+    o, d = _rays(scenes)
+    rb = rm.ray_bundle(ref, o, d, device)
+    reference_body = ref.TetrahedraNerf._tn_reference_get_outputs
+    assert ref.TetrahedraNerf.get_outputs is plugin.fused_get_outputs and reference_body is not None
+    with torch.no_grad():
+        want = reference_body(model, rb)
+        got = model(rb)                          # Model.forward -> collider -> (patched) get_outputs
+    bg = 0.0 if cfg.get("background_color") == "black" else 1.0
+    _compare_eval(got, want, [bg] * 3)
+    assert model._tn_renderer is not None
+    # the viewer's / exporters' override of the background colour (renderers.background_color_override_context)
+    for colour in ([0.5, 0.5, 0.5], [0.25, 0.5, 0.75]):
+        with renderers.background_color_override_context(torch.tensor(colour)), torch.no_grad():
+            want = reference_body(model, rb)
+            got = model(rb)
+        _compare_eval(got, want, colour)
+    # an optimiser-style in-place update of every parameter is seen by the cached packs / the field shadow
+    rgb0 = got["rgb"]
+    with torch.no_grad():
+        for p in plugin.weights_from_model(model):
+            p.mul_(1.01)
+        model.tetrahedra_field.mul_(0.99)
+        want = reference_body(model, rb)
+        got = model(rb)
+    _compare_eval(got, want)
+    assert float((got["rgb"] - rgb0).abs().max()) > 1e-4
+
+
+TRAIN_CONFIGS = [dict(num_samples=64, num_fine_samples=64),
+                 dict(num_samples=48, num_fine_samples=48, use_biased_sampler=True, use_gradient_scaling=True),
+                 dict(num_samples=128, num_fine_samples=128, use_biased_sampler=True, use_gradient_scaling=True)]
+
+
+@pytest.mark.parametrize("cfg", TRAIN_CONFIGS)
+def test_fused_adapter_training_equals_the_reference_body(tn, device, scenes, ref, plugin, cfg):
+    import torch
+
+    model = _model(ref, scenes, device, **cfg).train()
+    o, d = scenes.outside_in_rays(2048, 33)
+    rb = rm.ray_bundle(ref, o, d, device)
+    target = torch.rand(len(o), 3, device=device)
+    params = [model.tetrahedra_field] + plugin.weights_from_model(model)
+    reference_body = ref.TetrahedraNerf._tn_reference_get_outputs
+
+    def step(fn):
+        for p in params:
+            p.grad = None
+        torch.manual_seed(7)                    # the same stratified draws on both sides
+        out = fn()
+        loss = model.get_loss_dict(out, {"image": target})["rgb_loss"] + 0.1 * out["accumulation"].mean()
+        loss.backward()
+        return {k: out[k].detach().clone() for k in ("rgb", "accumulation", "depth")}, [p.grad.clone() for p in params]
+
+    want, g_want = step(lambda: reference_body(model, rb))      # PyTorch autograd through nerfstudio-shaped modules
+    got, g_got = step(lambda: model(rb))                        # fused autograd nodes (HIP forward / adjoint kernels)
+    np.testing.assert_allclose(got["rgb"].cpu().numpy(), want["rgb"].cpu().numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got["accumulation"].cpu().numpy(), want["accumulation"].cpu().numpy(), rtol=0, atol=1e-5)
+    assert float(((got["depth"] - want["depth"]).abs() <= 1e-5).float().mean()) > 0.995
+    names = ["field", "w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd", "wh", "bh", "wr", "br"]
+    for name, a, b in zip(names, g_got, g_want):
+        assert b is not None and float(b.abs().max()) > 0, name
+        # two fp32 evaluations of one gradient with differently split sums (sample-streaming GEMM slices + fixed-order
+        # partials vs rocBLAS reductions; the field: float atomics on both sides): the float64 yardstick of the fused
+        # nodes is tests/test_train_gpu.py
+        cos = float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()))
+        assert _rel(a, b) < 2e-3 and cos > 0.999999, (name, _rel(a, b), cos)
+    # training mode WITHOUT autograd (nerfstudio evaluates some metrics that way): still the stratified samplers and the
+    # unclamped renderer, and nothing is saved for a backward pass
+    with torch.no_grad():
+        torch.manual_seed(7)
+        want = reference_body(model, rb)
+        torch.manual_seed(7)
+        got = model(rb)
+    assert not got["rgb"].requires_grad
+    np.testing.assert_allclose(got["rgb"].cpu().numpy(), want["rgb"].cpu().numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("cfg", [dict(appearance_embed_dim=8), dict(input_fourier_frequencies=2), dict(hidden_size=64),
+                                 dict(num_density_layers=2), dict(num_color_layers=2)])
+@pytest.mark.parametrize("train", [False, True])
+def test_unsupported_configurations_fall_back_to_the_reference_body(tn, device, scenes, ref, plugin, cfg, train):
+    """The fallback rule under test: the patched get_outputs of a configuration the fused kernels do not implement IS the
+    reference body (HIP tracer / matcher / gather under nerfstudio's PyTorch MLP): bit-identical outputs, and in training
+    mode gradients for every parameter including the appearance embedding."""
+    import torch
+
+    model = _model(ref, scenes, device, num_samples=32, num_fine_samples=32, **cfg).train(train)
+    ok, why = plugin.fused_config_supported(model.config)
+    assert not ok and why
+    o, d = scenes.outside_in_rays(1024, 5)
+    rb = rm.ray_bundle(ref, o, d, device, camera_indices=np.arange(len(o)) % 3)
+    reference_body = ref.TetrahedraNerf._tn_reference_get_outputs
+    with torch.set_grad_enabled(train):
+        torch.manual_seed(3)
+        want = reference_body(model, rb)
+        torch.manual_seed(3)
+        got = model(rb)
+    for k in ("rgb", "accumulation", "depth", "ray_mask"):
+        assert torch.equal(got[k], want[k]), k
+    assert getattr(model, "_tn_renderer", None) is None          # the fused renderer was never built
+    if train:
+        got["rgb"].square().mean().backward()
+        for n, p in model.named_parameters():
+            if n != "device_indicator_param":
+                assert p.grad is not None and float(p.grad.abs().max()) > 0, n

@@ -14,7 +14,7 @@ LIB_PATH = _HERE / "libtetranerf_hip.so"
 # every symbol include/tetranerf_hip.h declares
 SYMBOLS = (
     "tn_last_error", "tn_version", "tn_tracer_create", "tn_tracer_destroy", "tn_load_tetrahedra",
-    "tn_num_faces", "tn_get_faces", "tn_get_build_table", "tn_trace_rays", "tn_trace_rays_triangles", "tn_find_tetrahedra",
+    "tn_num_faces", "tn_get_faces", "tn_get_build_table", "tn_trace_rays", "tn_trace_rays_ex", "tn_trace_rays_triangles", "tn_find_tetrahedra",
     "tn_find_matched_cells", "tn_find_matched_cells_indexed",
     "tn_interpolate_values", "tn_interpolate_values_backward", "tn_interpolate_values_backward_rows",
     "tn_transpose_f32", "tn_interpolate_values_vm", "tn_interpolate_values_backward_vm",
@@ -50,6 +50,7 @@ def load():
     lib.tn_get_faces.argtypes = [vp, vp, vp]
     lib.tn_get_build_table.argtypes = [vp, i32, vp, C.POINTER(sz)]
     lib.tn_trace_rays.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tn_trace_rays_ex.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, u32, vp]
     lib.tn_trace_rays_triangles.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_find_tetrahedra.argtypes = [vp, sz, vp, vp, vp, vp, vp]
     lib.tn_find_matched_cells.argtypes = [sz, sz, sz] + [vp] * 11
@@ -70,14 +71,14 @@ def load():
     lib.tn_mlp_set_weights.argtypes = [vp, vp, vp]
     lib.tn_mlp_forward.argtypes = [vp, sz, u32, vp, vp, i32, vp, vp, vp]
     lib.tn_mlp_forward_gather.argtypes = [vp, sz, u32, vp, vp, vp, vp, i32, vp, vp, vp]
-    lib.tn_render_pass.argtypes = [vp, u32, vp, vp, vp, vp, vp, sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
+    lib.tn_render_pass.argtypes = [vp, u32, vp, vp, vp, vp, vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_gather_uint32.argtypes = [i32, u32, u32, vp, vp, vp, vp]
     lib.tn_scatter_ema_uint32.argtypes = [i32, u32, u32, vp, C.c_double, vp, vp, vp]
-    lib.tn_composite.argtypes = [sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
+    lib.tn_composite.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_mlp_forward_gather_train.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_mlp_backward.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
     lib.tn_mlp_param_grads.argtypes = [vp, sz, u32, vp, vp, vp, vp]
-    lib.tn_composite_backward.argtypes = [sz, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
+    lib.tn_composite_backward.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_sample_coarse.argtypes = [sz, u32, u32, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     lib.tn_sample_pdf.argtypes = [sz, u32, u32, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp]
     for name in SYMBOLS:

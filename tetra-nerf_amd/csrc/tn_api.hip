@@ -323,11 +323,14 @@ static tn::TraceParams make_params(tn_tracer *t, size_t R, uint32_t M, const flo
     return p;
 }
 
-int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins, const float *directions,
-                  uint32_t *num_visited, uint32_t *visited, float *bary, float *dist, uint32_t *verts,
-                  void *stream_) {
+static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins, const float *directions,
+                             uint32_t *num_visited, uint32_t *visited, float *bary, float *dist, uint32_t *verts,
+                             uint32_t flags, void *stream_) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);
+        if (flags & ~(uint32_t)TN_TRACE_COMPACT_ROWS) throw tn::Error("unknown trace flag");
+        // per CALL, not per tracer: a viewer thread and a trainer sharing one tracer may ask for different row forms
+        const bool dense_tails = dense_tails && !(flags & TN_TRACE_COMPACT_ROWS);
         if (M == 0 || (M & (M - 1)) != 0) throw tn::Error("max_ray_triangles must be a power of 2.");
         if (!t->loaded) throw tn::Error("load_tetrahedra must be called first");
         if (M > 4096) throw tn::Error("max_ray_triangles larger than 4096 is not supported");
@@ -398,7 +401,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
             };
             auto launch_segments = [&](size_t base, size_t n) {
                 tn::WriteParams q{};
-                q.num_rays = n; q.M = M; q.dense_tails = t->dense_tails ? 1u : 0u;
+                q.num_rays = n; q.M = M; q.dense_tails = dense_tails ? 1u : 0u;
                 q.walk_n = t->walk_n.p + base;
                 q.hit_log = t->hit_log.p;
                 q.vars = t->mesh.cold;
@@ -409,7 +412,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 tn::launch_write_segments(q, stream);
             };
             auto launch_fill = [&](size_t base, size_t n, uint32_t k_hi) {   // [ceil32(n_r), k_hi) of the certified rows
-                if (!t->dense_tails) return;
+                if (!dense_tails) return;
                 tn::launch_fill_range(n, M, false, t->walk_n.p + base, num_visited + base, visited + base * M, bary + base * M * 6,
                                       dist + base * M * 2, verts ? verts + base * M * 4 : nullptr, stream, k_hi, false);
             };
@@ -428,7 +431,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
                 // profiles/r02p_specfill*.txt, r03a_sched.txt: +1..3 % per frame), and only where that quarter is mesh-safe
                 // (at 1M tets and M = 512 rays reach 346 of the 384 slots: measured -1..-6 %, off).
                 uint32_t K0 = 0;
-                if (t->spec_fill && t->dense_tails) {
+                if (t->spec_fill && dense_tails) {
                     K0 = (((uint32_t)(3.6 * std::cbrt((double)std::max<uint32_t>(t->mesh.T, 1u))) + 31u) & ~31u) + 32u;
                     const uint32_t quarter = (3u * M / 4u) & ~31u;
                     K0 = K0 <= quarter ? quarter : 0u;
@@ -492,6 +495,18 @@ int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins
         }
         TN_HIP(hipGetLastError());
     });
+}
+
+int tn_trace_rays(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins, const float *directions,
+                  uint32_t *num_visited, uint32_t *visited, float *bary, float *dist, uint32_t *verts,
+                  void *stream_) {
+    return trace_rays_common(tracer, R, M, origins, directions, num_visited, visited, bary, dist, verts, 0u, stream_);
+}
+
+int tn_trace_rays_ex(tn_tracer_t tracer, size_t R, uint32_t M, const float *origins, const float *directions,
+                     uint32_t *num_visited, uint32_t *visited, float *bary, float *dist, uint32_t *verts,
+                     uint32_t flags, void *stream_) {
+    return trace_rays_common(tracer, R, M, origins, directions, num_visited, visited, bary, dist, verts, flags, stream_);
 }
 
 int tn_find_matched_cells_indexed(size_t R, size_t S, size_t M, const uint32_t *ray_index, const uint32_t *num_visited,
@@ -727,6 +742,10 @@ struct tn_mlp {
 };
 
 namespace {
+// NULL = the reference configuration's default: white, training-mode renderer (no clamp)
+tn::Background background_of(const tn_rgb_background *b) {
+    return b ? tn::Background{b->r, b->g, b->b, b->clamp} : tn::Background{1.f, 1.f, 1.f, 0};
+}
 tn_mlp *checked_mlp(tn_mlp_t m) {
     if (!m) throw tn::Error("mlp handle is null");
     return m;
@@ -818,7 +837,7 @@ int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, cons
 
 int tn_render_pass(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const float *hit_distances, const float *barycentric,
                    const uint32_t *vertex_indices, const uint32_t *ray_index, size_t num_hit_rays, uint32_t num_samples,
-                   const float *edges, const float *field_vm, const float *dirs, float background,
+                   const float *edges, const float *field_vm, const float *dirs, const tn_rgb_background *background,
                    float *out_weights, float *out_rgb, float *out_acc, float *out_depth, void *stream_) {
     return guarded([&] {
         tn_mlp *m = checked_mlp(mlp);
@@ -828,7 +847,7 @@ int tn_render_pass(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const 
         if (!dirs && !out_weights) throw tn::Error("density-only pass without out_weights");
         DeviceGuard g(m->device);
         tn::launch_render_pass(num_visited, hit_distances, barycentric, vertex_indices, M, ray_index, num_hit_rays, num_samples,
-                               edges, field_vm, dirs, m->packs(num_hit_rays), background, out_weights, out_rgb, out_acc, out_depth,
+                               edges, field_vm, dirs, m->packs(num_hit_rays), background_of(background), out_weights, out_rgb, out_acc, out_depth,
                                (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
@@ -923,20 +942,20 @@ int tn_sample_pdf(size_t num_hit_rays, uint32_t num_samples, uint32_t num_fine, 
 }
 
 int tn_composite_backward(size_t num_rays, uint32_t num_samples, const float *sigma, const float *rgb, const float *edges,
-                          float background, const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb,
-                          void *stream_) {
+                          const tn_rgb_background *background, const float *d_out_rgb, const float *d_out_acc, float *d_sigma,
+                          float *d_rgb, void *stream_) {
     return guarded([&] {
-        tn::launch_composite_backward(num_rays, num_samples, sigma, rgb, edges, background, d_out_rgb, d_out_acc, d_sigma,
+        tn::launch_composite_backward(num_rays, num_samples, sigma, rgb, edges, background_of(background), d_out_rgb, d_out_acc, d_sigma,
                                       d_rgb, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }
 
 int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, const float *rgb, const float *edges,
-                 float background, float *out_rgb, float *out_acc, float *out_depth, float *out_weights,
+                 const tn_rgb_background *background, float *out_rgb, float *out_acc, float *out_depth, float *out_weights,
                  void *stream_) {
     return guarded([&] {
-        tn::launch_composite(num_rays, num_samples, sigma, rgb, edges, background, out_rgb, out_acc, out_depth,
+        tn::launch_composite(num_rays, num_samples, sigma, rgb, edges, background_of(background), out_rgb, out_acc, out_depth,
                              out_weights, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });

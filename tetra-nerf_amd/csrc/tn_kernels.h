@@ -172,8 +172,14 @@ struct MlpParamGrads { float *w1, *b1, *w2, *b2, *w3, *b3, *wd, *bd, *wh, *bh, *
 size_t mlp_param_grad_scratch_floats();
 void launch_mlp_param_grads(size_t n, uint32_t samples_per_ray, const float *dirs, const MlpPacks &w, const MlpBackwardBuffers &b,
                             const MlpParamGrads &g, hipStream_t stream);
+// background colour of the RGB renderer (RGBRenderer.combine_rgb: comp + background (1 - accumulation)) and its evaluation-mode
+// behaviour (RGBRenderer.forward when not training: nan_to_num of the sample colours, result clamped to [0, 1])
+struct Background { float r, g, b; int clamp; };
+__host__ __device__ __forceinline__ float nan_to_num(float x) {
+    return x != x ? 0.f : (x > 3.4028234663852886e38f ? 3.4028234663852886e38f : (x < -3.4028234663852886e38f ? -3.4028234663852886e38f : x));
+}
 // adjoint of launch_composite: d sigma [R,S], d rgb [R,S,3] from the gradients of the rendered rgb / accumulation
-void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
+void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, Background background,
                                const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb, hipStream_t stream);
 void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols, hipStream_t stream);
 // one render pass as one launch (tn_render.hip): match -> gather -> MLP -> composite on the trace rows of the hitting
@@ -181,14 +187,14 @@ void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols,
 // otherwise out_rgb / out_acc / out_depth (arrays over ALL rays) are written at ray_index[q]
 void launch_render_pass(const uint32_t *num_visited, const float *dist, const float *bary, const uint32_t *verts, uint32_t M,
                         const uint32_t *ray_index, size_t r, uint32_t S, const float *edges, const float *fieldT,
-                        const float *dirs, const MlpPacks &w, float background, float *out_weights, float *out_rgb,
+                        const float *dirs, const MlpPacks &w, Background background, float *out_weights, float *out_rgb,
                         float *out_acc, float *out_depth, hipStream_t stream);
 // ray samplers (tn_samplers.hip): one wavefront per hitting ray, trace rows read in place through ray_index
 void launch_sample_coarse(size_t r, uint32_t S, uint32_t M, const uint32_t *ray_index, const uint32_t *num_visited, const float *hit_dist,
                           const float *lin, const float *t_rand, bool biased, float *edges, float *near_far, hipStream_t stream);
 void launch_sample_pdf(size_t r, uint32_t S, uint32_t num_fine, const float *edges, const float *weights, const float *near_far,
                        const float *u_table, const float *u_rand, float histogram_padding, float eps, float *out, hipStream_t stream);
-void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
+void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, Background background,
                       float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream);
 
 // uint32-indexed gather / EMA scatter (tn_uint32.hip); elem_size 4 = f32, 8 = f64

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
 // Per-ray composite: one wavefront per ray, lanes stride the samples; exclusive scan of sigma*delta.
 __global__ __launch_bounds__(64) void k_composite(size_t R, uint32_t S, const float *__restrict__ sigma,
                                                   const float *__restrict__ rgb, const float *__restrict__ edges,
-                                                  float background, float *__restrict__ out_rgb,
+                                                  Background background, float *__restrict__ out_rgb,
                                                   float *__restrict__ out_acc, float *__restrict__ out_depth,
                                                   float *__restrict__ out_weights) {
     const int lane = threadIdx.x;
@@ -264,7 +264,11 @@ __global__ __launch_bounds__(64) void k_composite(size_t R, uint32_t S, const fl
             float w = (1.0f - expf(-dd)) * expf(-excl);
             if (!(w == w) || !ok) w = 0.f;  // nan_to_num
             if (out_weights && ok) out_weights[q] = w;
-            if (rgb) { r0 += w * rgb[3 * q]; r1 += w * rgb[3 * q + 1]; r2 += w * rgb[3 * q + 2]; }
+            if (rgb) {
+                float c0 = rgb[3 * q], c1 = rgb[3 * q + 1], c2 = rgb[3 * q + 2];
+                if (background.clamp) { c0 = nan_to_num(c0); c1 = nan_to_num(c1); c2 = nan_to_num(c2); }
+                r0 += w * c0; r1 += w * c1; r2 += w * c2;
+            }
             accw += w;
             // median depth: first sample whose cumulative weight reaches 0.5
             float winc = w;
@@ -289,9 +293,9 @@ __global__ __launch_bounds__(64) void k_composite(size_t R, uint32_t S, const fl
         }
         if (!found) depth = 0.5f * (e[S - 1] + e[S]);  // searchsorted clamps to the last sample
         if (lane == 0 && out_rgb) {
-            out_rgb[3 * ray] = r0 + background * (1.0f - accw);
-            out_rgb[3 * ray + 1] = r1 + background * (1.0f - accw);
-            out_rgb[3 * ray + 2] = r2 + background * (1.0f - accw);
+            float o0 = r0 + background.r * (1.0f - accw), o1 = r1 + background.g * (1.0f - accw), o2 = r2 + background.b * (1.0f - accw);
+            if (background.clamp) { o0 = fminf(fmaxf(o0, 0.f), 1.f); o1 = fminf(fmaxf(o1, 0.f), 1.f); o2 = fminf(fmaxf(o2, 0.f), 1.f); }
+            out_rgb[3 * ray] = o0; out_rgb[3 * ray + 1] = o1; out_rgb[3 * ray + 2] = o2;
             out_acc[ray] = accw;
             out_depth[ray] = depth;
         }
@@ -361,7 +365,7 @@ void launch_mlp_forward_train(size_t n, uint32_t samples_per_ray, size_t num_ray
                        FwdSave{save.x0, save.h1, save.h2, save.h3, save.h4, save.masks});
 }
 
-void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
+void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, Background background,
                       float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream) {
     if (R == 0 || S == 0) return;
     const unsigned grid = (unsigned)(R < 256u * 32u ? R : 256u * 32u);

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(BWD_BLOCK) void k_mlp_backward(size_t n, BwdIn in, 
 // the total minus the suffix.  Samples whose weight is not finite get zero gradients (nan_to_num in the forward).
 __global__ __launch_bounds__(64) void k_composite_backward(size_t R, uint32_t S, const float *__restrict__ sigma,
                                                            const float *__restrict__ rgb, const float *__restrict__ edges,
-                                                           float background, const float *__restrict__ g_rgb,
+                                                           Background background, const float *__restrict__ g_rgb,
                                                            const float *__restrict__ g_acc, float *__restrict__ d_sigma,
                                                            float *__restrict__ d_rgb) {
     const int lane = threadIdx.x;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void k_composite_backward(size_t R, uint32_t S,
         const float *e = edges + ray * (S + 1);
         const float gr = g_rgb ? g_rgb[3 * ray] : 0.f, gg = g_rgb ? g_rgb[3 * ray + 1] : 0.f, gb = g_rgb ? g_rgb[3 * ray + 2] : 0.f;
         const float ga = g_acc ? g_acc[ray] : 0.f;
-        const float a_const = ga - background * ((gr + gg) + gb);
+        const float a_const = ga - ((background.r * gr + background.g * gg) + background.b * gb);
         // total of dd
         float tot = 0.f;
         for (uint32_t j = lane; j < S; j += 64) tot += (e[j + 1] - e[j]) * sigma[ray * S + j];
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64) void k_composite_backward(size_t R, uint32_t S,
     }
 }
 
-void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, float background,
+void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, Background background,
                                const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb, hipStream_t stream) {
     if (R == 0 || S == 0) return;
     const unsigned grid = (unsigned)(R < 256u * 32u ? R : 256u * 32u);

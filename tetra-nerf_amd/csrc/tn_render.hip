@@ -51,7 +51,7 @@ struct RenderPassParams {
     float *out_rgb, *out_acc, *out_depth;   // [R_all, 3], [R_all], [R_all] or null: written at ray_index[q]
     size_t r;
     uint32_t S, M;
-    float background;
+    Background background;
 };
 
 struct RayState { float carry, acc, r0, r1, r2, depth; uint32_t found, pad; };
@@ -262,7 +262,11 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
             if constexpr (!DENSITY_ONLY) {
                 float l0 = 0.f, l1 = 0.f, l2 = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { l0 += w[i] * c_rgb[li[i]]; l1 += w[i] * c_rgb[RP_RING + li[i]]; l2 += w[i] * c_rgb[2 * RP_RING + li[i]]; }
+                for (int i = 0; i < 4; ++i) {
+                    float k0 = c_rgb[li[i]], k1 = c_rgb[RP_RING + li[i]], k2 = c_rgb[2 * RP_RING + li[i]];
+                    if (p.background.clamp) { k0 = nan_to_num(k0); k1 = nan_to_num(k1); k2 = nan_to_num(k2); }
+                    l0 += w[i] * k0; l1 += w[i] * k1; l2 += w[i] * k2;
+                }
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) { l0 += __shfl_xor(l0, off); l1 += __shfl_xor(l1, off); l2 += __shfl_xor(l2, off); }
                 st.r0 += l0; st.r1 += l1; st.r2 += l2;
@@ -297,9 +301,9 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
             if (!DENSITY_ONLY && p.out_rgb && lane == 0) {
                 const size_t ray = p.ray_index[q0 + qq];
                 if (!st.found) st.depth = c_mid[(ray_end - 1) & (RP_RING - 1)];   // searchsorted clamps to the last sample
-                p.out_rgb[3 * ray] = st.r0 + p.background * (1.0f - st.acc);
-                p.out_rgb[3 * ray + 1] = st.r1 + p.background * (1.0f - st.acc);
-                p.out_rgb[3 * ray + 2] = st.r2 + p.background * (1.0f - st.acc);
+                float o0 = st.r0 + p.background.r * (1.0f - st.acc), o1 = st.r1 + p.background.g * (1.0f - st.acc), o2 = st.r2 + p.background.b * (1.0f - st.acc);
+                if (p.background.clamp) { o0 = fminf(fmaxf(o0, 0.f), 1.f); o1 = fminf(fmaxf(o1, 0.f), 1.f); o2 = fminf(fmaxf(o2, 0.f), 1.f); }
+                p.out_rgb[3 * ray] = o0; p.out_rgb[3 * ray + 1] = o1; p.out_rgb[3 * ray + 2] = o2;
                 p.out_acc[ray] = st.acc;
                 p.out_depth[ray] = st.depth;
             }
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
 
 void launch_render_pass(const uint32_t *num_visited, const float *dist, const float *bary, const uint32_t *verts, uint32_t M,
                         const uint32_t *ray_index, size_t r, uint32_t S, const float *edges, const float *fieldT,
-                        const float *dirs, const MlpPacks &w, float background, float *out_weights, float *out_rgb,
+                        const float *dirs, const MlpPacks &w, Background background, float *out_weights, float *out_rgb,
                         float *out_acc, float *out_depth, hipStream_t stream) {
     if (r == 0) return;
     if (S < 64) throw Error("render_pass needs at least 64 samples per ray");

@@ -37,6 +37,7 @@ above) and is tested with stand-ins of nerfstudio's MLP / FieldHead / RayBundle 
 """
 from __future__ import annotations
 
+import sys
 from typing import Dict, List, Tuple
 
 import torch
@@ -114,13 +115,39 @@ def fused_config_supported(config) -> Tuple[bool, str]:
         (g("num_color_layers", 1) == 1, "num_color_layers != 1"),
         (g("input_fourier_frequencies", 0) == 0, "input_fourier_frequencies > 0"),
         (g("appearance_embed_dim", 0) == 0, "appearance_embed_dim > 0"),
-        (g("background_color", "white") in ("white", "black"), "background_color is not a constant"),
+        (g("background_color", "white") not in ("random", "last_sample"), "background_color is not a constant"),
         (g("num_samples", 256) >= 1, "num_samples < 1"),
     )
     for ok, why in checks:
         if not ok:
             return False, why
     return True, ""
+
+
+def resolve_background(model):
+    """The colour nerfstudio's RGB renderer will blend with on THIS call, resolved the way the reference does it
+    (`get_background_color`, model.py:504-518; `RGBRenderer.combine_rgb`): `renderers.BACKGROUND_COLOR_OVERRIDE` when a
+    `background_color_override_context` is active (the viewer / exporters use it), else `renderer_rgb.background_color`,
+    else `config.background_color`.  Returns a grey level (float), an (r, g, b) tuple, or None when the colour is not a
+    constant ("random", "last_sample": the fused kernels do not implement them -> reference body)."""
+    renderers = sys.modules.get("nerfstudio.model_components.renderers")
+    bg = getattr(renderers, "BACKGROUND_COLOR_OVERRIDE", None) if renderers is not None else None
+    if bg is None:
+        bg = getattr(getattr(model, "renderer_rgb", None), "background_color", None)
+    if bg is None:
+        bg = getattr(model.config, "background_color", "white")
+    if isinstance(bg, str):
+        if bg in ("white", "black"):
+            return 1.0 if bg == "white" else 0.0
+        colors = sys.modules.get("nerfstudio.utils.colors")
+        if colors is None or bg not in getattr(colors, "COLORS_DICT", {}):
+            return None
+        bg = colors.COLORS_DICT[bg]
+    t = torch.as_tensor(bg).detach().to(dtype=torch.float32, device="cpu").reshape(-1)   # colours live on the host in nerfstudio
+    if t.numel() != 3:
+        return None
+    r, g, b = t.tolist()
+    return r if r == g == b else (r, g, b)
 
 
 def _renderer_for(model, tracer):
@@ -134,7 +161,7 @@ def _renderer_for(model, tracer):
         tracer, model.tetrahedra_field, ModelMLP(model), num_samples=int(cfg.num_samples),
         max_ray_triangles=int(cfg.max_intersected_triangles), fused=True, far_plane=float(model.collider.far_plane),
         num_fine_samples=int(getattr(cfg, "num_fine_samples", 0)), biased=bool(getattr(cfg, "use_biased_sampler", False)),
-        background={"white": 1.0, "black": 0.0}[getattr(cfg, "background_color", "white")])
+        background=1.0)     # every call passes the colour resolve_background() found
     # plain attribute (not a registered submodule / buffer): nothing of it enters the state dict
     object.__setattr__(model, "_tn_renderer", rd)
     return rd
@@ -146,6 +173,9 @@ def fused_get_outputs(model, ray_bundle) -> Dict[str, torch.Tensor]:
     ("rgb", "accumulation", "depth", "ray_mask").  Unsupported configurations run the reference implementation."""
     ok, _why = fused_config_supported(model.config)
     ref = getattr(type(model), "_tn_reference_get_outputs", None)
+    bg = resolve_background(model) if ok else None
+    if ok and bg is None:
+        ok, _why = False, "background colour is not a constant on this call"
     if not ok:
         if ref is None:
             raise RuntimeError(f"fused path unsupported ({_why}) and no reference get_outputs to fall back to")
@@ -156,9 +186,12 @@ def fused_get_outputs(model, ray_bundle) -> Dict[str, torch.Tensor]:
     rd = _renderer_for(model, tracer)
     o = ray_bundle.origins.reshape(-1, 3).contiguous()
     d = ray_bundle.directions.reshape(-1, 3).contiguous()
-    if model.training and torch.is_grad_enabled():
-        return rd.render_train(o, d, gradient_scaling=bool(getattr(model.config, "use_gradient_scaling", False)))
-    return rd.render(o, d)
+    if model.training:
+        # the reference's samplers stratify and its RGB renderer skips the clamp whenever `self.training` is set, with
+        # or without autograd (model.py:169; nerfstudio RGBRenderer.forward); render_train skips the activation saves
+        # when no graph is being recorded
+        return rd.render_train(o, d, gradient_scaling=bool(getattr(model.config, "use_gradient_scaling", False)), background=bg)
+    return rd.render(o, d, background=bg)
 
 
 def install(model_cls=None):

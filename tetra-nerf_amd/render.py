@@ -76,13 +76,30 @@ def stratified_bins(num_samples: int, t_rand: torch.Tensor) -> torch.Tensor:
     return lower + (upper - lower) * t_rand
 
 
+def spacing_bins(num_samples: int, t_rand: Optional[torch.Tensor], dtype, device) -> torch.Tensor:
+    """[1 or R, S+1] spacing bins of the coarse samplers before the map to distances (model.py:166-174): linspace in
+    evaluation mode, jittered with `t_rand` [R,S+1] in training mode."""
+    if t_rand is None:
+        return torch.linspace(0.0, 1.0, num_samples + 1, dtype=dtype, device=device)[None]
+    return stratified_bins(num_samples, t_rand)
+
+
 def uniform_sample_bins(nears: torch.Tensor, fars: torch.Tensor, num_samples: int, t_rand: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[R,S+1] euclidean bin edges of nerfstudio's UniformSampler (eval mode; train mode with `t_rand` [R,S+1])."""
-    if t_rand is None:
-        bins = torch.linspace(0.0, 1.0, num_samples + 1, dtype=nears.dtype, device=nears.device)[None]
-    else:
-        bins = stratified_bins(num_samples, t_rand)
+    bins = spacing_bins(num_samples, t_rand, nears.dtype, nears.device)
     return bins * fars + (1.0 - bins) * nears
+
+
+def coarse_samples(nears, fars, num_samples, biased=False, num_visited_cells=None, hit_distances=None, t_rand=None):
+    """(euclidean edges [R,S+1], spacing edges [R,S+1]) of the model's coarse sampler as the reference hands them on to
+    the PDF sampler and the GradientScaler (`spacing_starts / spacing_ends` of its RaySamples): the UniformSampler keeps
+    the spacing bins it drew, the TetrahedraSampler re-derives them from the re-mapped distances (model.py:182)."""
+    bins = spacing_bins(num_samples, t_rand, nears.dtype, nears.device)
+    edges = bins * fars + (1.0 - bins) * nears
+    if biased:
+        edges = map_to_biased(num_visited_cells, hit_distances, edges)
+        return edges, (edges - nears) / (fars - nears)
+    return edges, bins.expand(nears.shape[0], -1)
 
 
 def biased_sample_bins(nears: torch.Tensor, fars: torch.Tensor, num_samples: int, num_visited_cells: torch.Tensor,
@@ -110,7 +127,7 @@ def map_to_biased(num_visited_cells: torch.Tensor, hit_distances: torch.Tensor, 
 
 def pdf_sample_bins(spacing_edges: torch.Tensor, weights: torch.Tensor, num_fine: int, nears: torch.Tensor,
                     fars: torch.Tensor, histogram_padding: float = 0.01, eps: float = 1e-5,
-                    u_rand: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    u_rand: Optional[torch.Tensor] = None, return_spacing: bool = False):
     """[R, S + num_fine + 2] euclidean bin edges of nerfstudio's PDFSampler in eval mode with
     include_original=True (model.py:463,584): inverse-CDF samples of the padded coarse weights at the
     num_fine+1 bin-centred quantiles, merged with the coarse edges and sorted, then mapped back with
@@ -137,7 +154,8 @@ def pdf_sample_bins(spacing_edges: torch.Tensor, weights: torch.Tensor, num_fine
     t = torch.clip(torch.nan_to_num((u - cdf0) / (cdf1 - cdf0), 0), 0, 1)
     bins = b0 + t * (b1 - b0)
     bins, _ = torch.sort(torch.cat([spacing_edges, bins], -1), -1)
-    return bins * fars + (1.0 - bins) * nears
+    edges = bins * fars + (1.0 - bins) * nears
+    return (edges, bins) if return_spacing else edges
 
 
 def ray_weights(sigma: torch.Tensor, edges: torch.Tensor) -> torch.Tensor:
@@ -148,10 +166,22 @@ def ray_weights(sigma: torch.Tensor, edges: torch.Tensor) -> torch.Tensor:
     return torch.nan_to_num((1.0 - torch.exp(-dd)) * torch.exp(-trans))
 
 
+def background_tensor(background, device=None) -> torch.Tensor:
+    """[3] fp32 tensor of a grey level (float) or an (r, g, b) triple."""
+    if isinstance(background, torch.Tensor):
+        return background.detach().reshape(3).to(device=device, dtype=torch.float32)
+    if isinstance(background, (int, float)):
+        background = (background,) * 3
+    return torch.tensor([float(x) for x in background], dtype=torch.float32, device=device)
+
+
 def composite(sigma: torch.Tensor, rgb: torch.Tensor, starts: torch.Tensor, ends: torch.Tensor,
-              background: float = 1.0):
-    """RaySamples.get_weights + RGBRenderer(white) + AccumulationRenderer + DepthRenderer(median).
-    sigma [R,S,1], rgb [R,S,3], starts/ends [R,S,1]."""
+              background=1.0, clamp: bool = False):
+    """RaySamples.get_weights + RGBRenderer(background) + AccumulationRenderer + DepthRenderer(median).
+    sigma [R,S,1], rgb [R,S,3], starts/ends [R,S,1].  background: grey level or (r, g, b); clamp = the RGB renderer's
+    evaluation mode (nerfstudio RGBRenderer.forward when not training: nan_to_num of the colours, result clamped to [0, 1])."""
+    if clamp:
+        rgb = torch.nan_to_num(rgb)
     deltas = ends - starts
     dd = deltas * sigma
     alphas = 1.0 - torch.exp(-dd)
@@ -159,7 +189,9 @@ def composite(sigma: torch.Tensor, rgb: torch.Tensor, starts: torch.Tensor, ends
     trans = torch.cat([torch.zeros_like(trans[..., :1, :]), trans], dim=-2)
     weights = torch.nan_to_num(alphas * torch.exp(-trans))
     acc = weights.sum(-2)
-    out_rgb = (weights * rgb).sum(-2) + background * (1.0 - acc)
+    out_rgb = (weights * rgb).sum(-2) + background_tensor(background, rgb.device) * (1.0 - acc)
+    if clamp:
+        out_rgb = out_rgb.clamp(0.0, 1.0)
     steps = (starts + ends) / 2.0
     cum = torch.cumsum(weights[..., 0], dim=-1)
     split = torch.full_like(cum[..., :1], 0.5)
@@ -178,16 +210,18 @@ def median_margin(weights: torch.Tensor) -> torch.Tensor:
 def render_reference(tracer, interpolate_values, field: torch.Tensor, mlp: TetraMLP, origins: torch.Tensor,
                      directions: torch.Tensor, num_samples: int = 256, max_ray_triangles: int = 512,
                      far_plane: float = 1000.0, num_fine_samples: int = 0, biased: bool = False,
-                     background: float = 1.0) -> Dict[str, torch.Tensor]:
-    """Plain-PyTorch statement of the render path; `tracer` needs trace_rays /
-    find_visited_cells returning tensors, `interpolate_values(vi, bc, field)` the gather."""
+                     background=1.0) -> Dict[str, torch.Tensor]:
+    """Plain-PyTorch statement of the render path in EVALUATION mode (model.py:520-662 with `self.training == False`: the
+    samplers do not jitter, the RGB renderer sanitises and clamps); `tracer` needs trace_rays / find_visited_cells
+    returning tensors, `interpolate_values(vi, bc, field)` the gather.  Pinned by the reference's own `get_outputs`
+    executed from its file (tests/test_reference_model.py)."""
     out = tracer.trace_rays(origins.contiguous(), directions.contiguous(), max_ray_triangles)
     nv = out["num_visited_cells"]
     nears = out["hit_distances"][:, 0, 0][:, None]
     fars = torch.gather(out["hit_distances"][:, :, 1], 1, (nv[:, None].long() - 1).clamp_min(0))
     ray_mask = nv > 0
     R = origins.shape[0]
-    rgb = torch.full((R, 3), float(background), dtype=torch.float32, device=origins.device)
+    rgb = background_tensor(background, origins.device).expand(R, 3).contiguous()   # get_background_color (model.py:504-518,642)
     acc = torch.zeros((R, 1), dtype=torch.float32, device=origins.device)
     depth = torch.full((R, 1), far_plane, dtype=torch.float32, device=origins.device)
     margin = torch.full((R, 1), 0.5, dtype=torch.float32, device=origins.device)   # test aid: see median_margin
@@ -201,10 +235,7 @@ def render_reference(tracer, interpolate_values, field: torch.Tensor, mlp: Tetra
             traced = tracer.find_visited_cells(*lists, dist)
             return interpolate_values(traced["vertex_indices"], traced["barycentric_coordinates"], field)
 
-        if biased:
-            edges = biased_sample_bins(near_r, far_r, num_samples, lists[0], lists[3])
-        else:
-            edges = uniform_sample_bins(near_r, far_r, num_samples)
+        edges, spacing = coarse_samples(near_r, far_r, num_samples, biased, lists[0], lists[3])
         feats = features(edges)
         if num_fine_samples > 0:
             if hasattr(mlp, "coarse_sigma"):     # an adapter around other modules (nerfstudio_plugin.ModelMLP)
@@ -214,13 +245,12 @@ def render_reference(tracer, interpolate_values, field: torch.Tensor, mlp: Tetra
                 for lin in mlp.base:
                     x = torch.relu(lin(x))
                 sigma_c = torch.nn.functional.softplus(mlp.density(x))[..., 0]
-            spacing = (edges - near_r) / (far_r - near_r)
             edges = pdf_sample_bins(spacing, ray_weights(sigma_c, edges), num_fine_samples, near_r, far_r)
             feats = features(edges)
         starts, ends = edges[:, :-1, None], edges[:, 1:, None]
         dirs = directions[ray_mask][:, None, :].expand(-1, edges.shape[1] - 1, -1)
         sigma, col = mlp(feats, dirs)
-        rgb_r, acc_r, depth_r, w_r = composite(sigma, col, starts, ends, background=float(background))
+        rgb_r, acc_r, depth_r, w_r = composite(sigma, col, starts, ends, background=background, clamp=True)
         rgb[ray_mask] = rgb_r
         acc[ray_mask] = acc_r
         depth[ray_mask] = depth_r
@@ -283,7 +313,7 @@ class _FusedCompositeFunction(torch.autograd.Function):
         from . import tetranerf_cpp_extension as cpp
 
         ctx.save_for_backward(sigma, rgb, edges)
-        ctx.background = float(background)
+        ctx.background = background     # grey level or (r, g, b); training mode: the RGB renderer does not clamp
         out_rgb, acc, depth = cpp.composite(sigma.detach(), rgb.detach(), edges, ctx.background)
         ctx.mark_non_differentiable(depth)
         return out_rgb, acc, depth
@@ -315,17 +345,23 @@ class TetraRenderer:
     def __init__(self, tracer, field: torch.Tensor, mlp: TetraMLP, num_samples: int = 256,
                  max_ray_triangles: int = 512, fused: bool = True, far_plane: float = 1000.0,
                  num_fine_samples: int = 0, biased: bool = False, dense_tails: bool = False, fused_pass="auto",
-                 mlp_mode: str = "fp32", background: float = 1.0, cache_field: bool = True, device_samplers: bool = True):
+                 mlp_mode: str = "fp32", background=1.0, cache_field: bool = True, device_samplers: bool = True,
+                 interpolate_values=None):
         from . import tetranerf_cpp_extension as cpp
 
         self.cpp = cpp
         self.tracer, self.field, self.mlp = tracer, field, mlp
+        # the gather of the UNFUSED statement (render_train(fused=False)): default = the product's autograd op; the CPU
+        # tests pass the reference's einsum definition so that the statement runs next to the reference model's body
+        self._interpolate_values = interpolate_values
         # arithmetic of the fused forward kernels, per renderer (not process-wide): "fp32" = exact fp32 MFMA chain (what
         # the parity tests pin), "bf16x3" = split-operand bf16 MFMA (opt-in; inference only -- the training forward is
         # always fp32: tn_mlp_forward_gather_train has no bf16x3 mode)
         self.mlp_mode = mlp_mode
         self.train_node_samples = 1 << 22      # render_train: samples per autograd node of the fused MLP (see there)
-        self.background = float(background)    # RGBRenderer background: 1.0 white (default config), 0.0 black
+        # RGBRenderer background: grey level (1.0 white = default config, 0.0 black) or an (r, g, b) triple; render() /
+        # render_train() take a per-call override (nerfstudio's BACKGROUND_COLOR_OVERRIDE, model.py:504-518)
+        self.background = background if isinstance(background, (int, float)) else tuple(float(x) for x in background_tensor(background).tolist())
         # samplers as device kernels on the trace rows in place (tn_sample_coarse / tn_sample_pdf): a render is then
         # trace -> [sampler -> pass] x 2 with no PyTorch operator in between (False: the PyTorch statements above, ~15
         # small kernels per pass -- the parity definition, kept for tests and A/B)
@@ -349,27 +385,47 @@ class TetraRenderer:
         if not (self.S >= 64 and self.M <= 512):
             self.fused_pass = False
 
+    def _trace(self, origins, directions):
+        """trace_rays; compact rows (a PER-CALL flag of the op: the tracer may be shared with other threads) unless this
+        renderer was asked for the dense reference rows."""
+        o, d = origins.contiguous(), directions.contiguous()
+        if not self.dense_tails and getattr(self.tracer, "supports_compact_rows", False):
+            return self.tracer.trace_rays(o, d, self.M, compact_rows=True)
+        return self.tracer.trace_rays(o, d, self.M)
+
+    @staticmethod
+    def _background_rows(R, bg, dev):
+        """[R,3] rows of the background colour (get_background_color, model.py:504-518,642) without a host->device copy."""
+        if isinstance(bg, (int, float)):
+            return torch.full((R, 3), float(bg), dtype=torch.float32, device=dev)
+        rows = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        for c in range(3):
+            rows[:, c].fill_(float(bg[c]))
+        return rows
+
+    def _bg(self, background):
+        if background is None:
+            return self.background
+        return background if isinstance(background, (int, float)) else tuple(float(x) for x in background_tensor(background).tolist())
+
     @torch.no_grad()
-    def render(self, origins: torch.Tensor, directions: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def render(self, origins: torch.Tensor, directions: torch.Tensor, background=None) -> Dict[str, torch.Tensor]:
+        """Evaluation-mode render (model.py:520-662 with `self.training == False`: samplers without jitter, RGB renderer
+        with nan_to_num + clamp).  background: per-call override of the renderer's colour (grey level or (r, g, b))."""
         cpp, S = self.cpp, self.S
+        bg = self._bg(background)
         if not self.fused:
             return render_reference(self.tracer, cpp.interpolate_values, self.field, self.mlp, origins, directions,
-                                    S, self.M, self.far_plane, self.S_fine, self.biased, background=self.background)
-        if not self.dense_tails:
-            self.tracer.set_option("dense_tails", 0)
-        try:
-            out = self.tracer.trace_rays(origins.contiguous(), directions.contiguous(), self.M)
-        finally:
-            if not self.dense_tails:
-                self.tracer.set_option("dense_tails", 1)
+                                    S, self.M, self.far_plane, self.S_fine, self.biased, background=bg)
+        out = self._trace(origins, directions)
         nv = out["num_visited_cells"]
         ray_mask = nv > 0
         R, dev = origins.shape[0], origins.device
-        rgb = torch.full((R, 3), self.background, dtype=torch.float32, device=dev)
+        rgb = self._background_rows(R, bg, dev)
         acc = torch.zeros((R, 1), dtype=torch.float32, device=dev)
         depth = torch.full((R, 1), self.far_plane, dtype=torch.float32, device=dev)
         idx = torch.nonzero(ray_mask)[:, 0]
-        mode, bg = self.mlp_mode, self.background
+        mode = self.mlp_mode
         if idx.numel():
             # the 26 KB trace rows of the hitting rays are NOT compacted (model.py:546-567 copies them with boolean
             # indexing): samplers, find_visited_cells and the render pass read them in place through the ray index
@@ -408,7 +464,7 @@ class TetraRenderer:
                     weights_c = cpp.render_pass(lists, ridx, edges, self.field, None, w)
                     edges = fine_edges(edges, weights_c)
                 cpp.render_pass(lists, ridx, edges, self.field, directions[idx].contiguous(), w, out=(rgb, acc, depth),
-                                background=bg)
+                                background=bg, clamp=True)
                 return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
             traced = locate(edges)
             if self.S_fine > 0:
@@ -422,7 +478,7 @@ class TetraRenderer:
             # gather + MLP + heads in one kernel (no [64, n] feature buffer)
             sigma, col = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
                                                 directions[idx].contiguous(), w, S, mode=mode)
-            rgb_r, acc_r, depth_r = cpp.composite(sigma.view(-1, S), col.view(-1, S, 3), edges, background=bg)
+            rgb_r, acc_r, depth_r = cpp.composite(sigma.view(-1, S), col.view(-1, S, 3), edges, background=bg, clamp=True)
             rgb[idx] = rgb_r
             acc[idx] = acc_r
             depth[idx] = depth_r
@@ -430,29 +486,27 @@ class TetraRenderer:
 
     def render_train(self, origins: torch.Tensor, directions: torch.Tensor, gradient_scaling: bool = False,
                      generator: Optional[torch.Generator] = None, rand: Optional[Dict[str, torch.Tensor]] = None,
-                     fused: bool = True, capture: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+                     fused: bool = True, capture: Optional[dict] = None, background=None) -> Dict[str, torch.Tensor]:
         """One training forward (TetrahedraNerf.get_outputs in training mode, model.py:520-662): stratified coarse samples
         (uniform or biased), optional PDF fine pass on the detached coarse weights (nerfstudio's PDFSampler detaches
-        them), gather + MLP + heads, optional GradientScaler, weights and renderers -- differentiable w.r.t. the field
-        and the MLP parameters.  fused=True: the MLP and the composite are single autograd nodes backed by the HIP
-        forward / adjoint kernels; fused=False: the plain PyTorch statement (autograd through nn.Linear etc.), which is
-        what the parity tests compare against.  `rand` may carry the uniform draws ("coarse" [r,S+1], "fine"
-        [r,S_fine+1] over the hitting rays) so that two calls see the same samples."""
+        them), gather + MLP + heads, optional GradientScaler, weights and renderers (training mode: no clamp) --
+        differentiable w.r.t. the field and the MLP parameters.  fused=True: the MLP and the composite are single autograd
+        nodes backed by the HIP forward / adjoint kernels (without a graph being recorded -- `torch.no_grad()` -- the
+        non-saving forward kernels run instead); fused=False: the plain PyTorch statement (autograd through nn.Linear
+        etc.; with device_samplers=False not one HIP kernel above the tracer's ops), which is what the parity tests compare
+        against and what tests/test_reference_model.py pins with the reference's own get_outputs.  `rand` may carry the
+        uniform draws ("coarse" [r,S+1], "fine" [r,S_fine+1] over the hitting rays) so that two calls see the same
+        samples; without it they are drawn from `generator` / torch's global generator in the reference's order and
+        shapes (coarse first, then fine), so the same seed gives the reference body and this path the same draws."""
         cpp, S = self.cpp, self.S
         with torch.no_grad():
-            if not self.dense_tails:
-                self.tracer.set_option("dense_tails", 0)
-            try:
-                out = self.tracer.trace_rays(origins.contiguous(), directions.contiguous(), self.M)
-            finally:
-                if not self.dense_tails:
-                    self.tracer.set_option("dense_tails", 1)
+            out = self._trace(origins, directions)
             nv = out["num_visited_cells"]
             ray_mask = nv > 0
             idx = torch.nonzero(ray_mask)[:, 0]
         R, dev = origins.shape[0], origins.device
-        bg = self.background
-        rgb = torch.full((R, 3), bg, dtype=torch.float32, device=dev)
+        bg = self._bg(background)
+        rgb = self._background_rows(R, bg, dev)
         acc = torch.zeros((R, 1), dtype=torch.float32, device=dev)
         depth = torch.full((R, 1), self.far_plane, dtype=torch.float32, device=dev)
         if idx.numel() == 0:
@@ -462,6 +516,8 @@ class TetraRenderer:
         ridx = idx.to(torch.int32)
         r = idx.numel()
         rand = rand or {}
+        record = fused and torch.is_grad_enabled()
+        spacing = None            # spacing bins of the final samples (exact only on the PyTorch sampler path)
         with torch.no_grad():
             t_rand = rand.get("coarse")
             if t_rand is None:
@@ -473,10 +529,8 @@ class TetraRenderer:
                 near_r = out["hit_distances"][idx, 0, 0][:, None]
                 far_r = out["hit_distances"][idx, (nv[idx].long() - 1), 1][:, None]
                 near_far = torch.cat([near_r, far_r], 1).contiguous()
-                if self.biased:
-                    edges = biased_sample_bins(near_r, far_r, S, lists[0][idx], lists[3][idx], t_rand).contiguous()
-                else:
-                    edges = uniform_sample_bins(near_r, far_r, S, t_rand).contiguous()
+                edges, spacing = coarse_samples(near_r, far_r, S, self.biased, lists[0][idx], lists[3][idx], t_rand)
+                edges = edges.contiguous()
 
             def locate(e):
                 dist = ((e[:, 1:] + e[:, :-1]) / 2).contiguous()
@@ -485,17 +539,32 @@ class TetraRenderer:
             traced = locate(edges)
             w = mlp_weights(self.mlp)
             if self.S_fine > 0:
-                sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
-                                                 None, w, S)
-                weights_c = cpp.composite(sigma_c.view(-1, S), None, edges)
+                if fused:
+                    sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
+                                                     None, w, S).view(-1, S)
+                    weights_c = cpp.composite(sigma_c, None, edges)
+                else:       # model.py:577-582 in PyTorch
+                    gather = self._interpolate_values or cpp.interpolate_values
+                    feats_c = gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field)
+                    if hasattr(self.mlp, "coarse_sigma"):
+                        sigma_c = self.mlp.coarse_sigma(feats_c)
+                    else:
+                        x = feats_c
+                        for lin in self.mlp.base:
+                            x = torch.relu(lin(x))
+                        sigma_c = torch.nn.functional.softplus(self.mlp.density(x))[..., 0]
+                    weights_c = ray_weights(sigma_c, edges)
                 u_rand = rand.get("fine")
                 if u_rand is None:
                     u_rand = torch.rand((r, self.S_fine + 1), device=dev, generator=generator)
                 if self.device_samplers:
                     edges = cpp.sample_pdf(edges, weights_c, near_far, self.S_fine, u_rand=u_rand.contiguous())
+                    spacing = None
                 else:
-                    spacing = (edges - near_r) / (far_r - near_r)
-                    edges = pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r, u_rand=u_rand).contiguous()
+                    if spacing is None:
+                        spacing = (edges - near_r) / (far_r - near_r)
+                    edges, spacing = pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r, u_rand=u_rand, return_spacing=True)
+                    edges = edges.contiguous()
                 traced = locate(edges)
                 S = edges.shape[1] - 1
         dirs = directions[idx].contiguous()
@@ -503,7 +572,7 @@ class TetraRenderer:
         if capture is not None:   # the (non-differentiable) sample placement, for tests that restate the rest in float64
             capture.update(idx=idx, vertex_indices=vi, barycentric_coordinates=bc, edges=edges, dirs=dirs,
                            near=near_r, far=far_r, samples_per_ray=S)
-        if fused:
+        if record:
             # the node keeps 2.3 KB per sample from forward to backward (and its backward writes as much again): batches
             # beyond 2^22 samples (nerfstudio trains on 4096 rays) go through several nodes, one per block of rays
             rays_per_node = max(1, int(self.train_node_samples) // S)
@@ -514,19 +583,27 @@ class TetraRenderer:
                                                  dirs[a:a + rays_per_node], S, *w) for a in range(0, r, rays_per_node)]
                 sigma, col = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
             sigma, col = sigma.view(-1, S), col.view(-1, S, 3)
+        elif fused:               # no graph: the plain forward kernel, nothing saved
+            sigma, col = cpp.mlp_forward_gather(vi, bc, self.field, dirs, w, S)
+            sigma, col = sigma.view(-1, S), col.view(-1, S, 3)
         else:
-            from . import interpolate_values
+            interpolate_values = self._interpolate_values
+            if interpolate_values is None:
+                from . import interpolate_values
 
             feats = interpolate_values(vi, bc, self.field)
             sg, col = self.mlp(feats, dirs[:, None, :].expand(-1, S, -1))
             sigma = sg[..., 0]
-        if gradient_scaling:
-            spacing = (edges - near_r) / (far_r - near_r)
+        if gradient_scaling and torch.is_grad_enabled():
+            if spacing is None:
+                spacing = (edges - near_r) / (far_r - near_r)
             ray_dist = (spacing[:, 1:] + spacing[:, :-1])[..., None]      # model.py:625-630
             col, sg, _ = GradientScaler.apply(col, sigma[..., None], ray_dist)
             sigma = sg[..., 0]
-        if fused:
+        if record:
             rgb_r, acc_r, depth_r = _FusedCompositeFunction.apply(sigma, col, edges, bg)
+        elif fused:
+            rgb_r, acc_r, depth_r = cpp.composite(sigma.contiguous(), col.contiguous(), edges, background=bg)
         else:
             rgb_r, acc_r, depth_r, _ = composite(sigma[..., None], col, edges[:, :-1, None], edges[:, 1:, None], background=bg)
         rgb = rgb.index_copy(0, idx, rgb_r)

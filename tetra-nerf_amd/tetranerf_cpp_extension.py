@@ -119,7 +119,12 @@ class TetrahedraTracer:
         _lib.check(self._lib.tn_load_tetrahedra(
             self._h, xyz.numel() // 3, cells.numel() // 4, _ptr(xyz), _ptr(cells), _stream(self._device)))
 
-    def trace_rays(self, ray_origins, ray_directions, max_ray_triangles):
+    supports_compact_rows = True
+
+    def trace_rays(self, ray_origins, ray_directions, max_ray_triangles, compact_rows: bool = False):
+        """PyTetrahedraTracer::trace_rays (py_binding.cpp:41-76).  compact_rows (no reference counterpart; per call):
+        slots >= num_visited_cells are left unwritten (tn_trace_rays_ex + TN_TRACE_COMPACT_ROWS) for consumers that read
+        the rows only through num_visited_cells (the samplers, find_visited_cells(ray_index=...), render_pass)."""
         M = int(max_ray_triangles)
         if M <= 0 or (M & (M - 1)) != 0:
             raise RuntimeError("max_ray_triangles must be a power of 2.")
@@ -134,10 +139,10 @@ class TetrahedraTracer:
             barycentric_coordinates = _empty((R, M, 2, 3), dtype=torch.float32, device=dev)
             hit_distances = _empty((R, M, 2), dtype=torch.float32, device=dev)
             vertex_indices = _empty((R, M, 4), dtype=torch.int32, device=dev)
-            _lib.check(self._lib.tn_trace_rays(
+            _lib.check(self._lib.tn_trace_rays_ex(
                 self._h, R, M, _ptr(ray_origins), _ptr(ray_directions), _ptr(num_visited_cells),
                 _ptr(visited_cells), _ptr(barycentric_coordinates), _ptr(hit_distances),
-                _ptr(vertex_indices), _stream(dev)))
+                _ptr(vertex_indices), 1 if compact_rows else 0, _stream(dev)))
         return {
             "num_visited_cells": num_visited_cells,
             "visited_cells": visited_cells,
@@ -571,7 +576,22 @@ def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, wei
     return sigma if density_only else (sigma, rgb)
 
 
-def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, background=1.0):
+class _RgbBackground(C.Structure):   # tn_rgb_background
+    _fields_ = [("r", C.c_float), ("g", C.c_float), ("b", C.c_float), ("clamp", C.c_int)]
+
+
+def _background(background, clamp=False):
+    """tn_rgb_background from a grey level (float) or an (r, g, b) triple (sequence or HOST tensor; a device tensor would
+    force a sync here) + the RGB renderer's evaluation-mode flag."""
+    if isinstance(background, torch.Tensor):
+        background = background.detach().reshape(-1).tolist()
+    if isinstance(background, (int, float)):
+        background = (background,) * 3
+    r, g, b = (float(x) for x in background)
+    return C.byref(_RgbBackground(r, g, b, 1 if clamp else 0))
+
+
+def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, background=1.0, clamp=False):
     """One render pass as ONE launch (tn_render_pass): sample matching + barycentric gather + MLP + composite on the
     trace rows of the hitting rays in place.  trace_lists = (num_visited_cells [R], visited_cells, barycentric_coordinates
     [R,M,2,3], hit_distances [R,M,2], vertex_indices [R,M,4]) as returned by trace_rays; ray_index i32 [r]; edges f32
@@ -599,7 +619,7 @@ def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, b
         if density_only:
             w_out = _empty((r, S), dtype=torch.float32, device=dev)
             _lib.check(lib.tn_render_pass(m.handle, M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S,
-                                          _ptr(edges), _ptr(field_vm), None, float(background), _ptr(w_out), None, None, None,
+                                          _ptr(edges), _ptr(field_vm), None, None, _ptr(w_out), None, None, None,
                                           _stream(dev)))
         else:
             _check_input(dirs, "dirs")
@@ -609,7 +629,7 @@ def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, b
                 _check_input(x, name)
                 _check(x.dtype == torch.float32 and x.size(0) == nv.numel(), f"{name} must be f32 over all rays")
             _lib.check(lib.tn_render_pass(m.handle, M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S,
-                                          _ptr(edges), _ptr(field_vm), _ptr(dirs), float(background), None, _ptr(rgb), _ptr(acc),
+                                          _ptr(edges), _ptr(field_vm), _ptr(dirs), _background(background, clamp), None, _ptr(rgb), _ptr(acc),
                                           _ptr(depth), _stream(dev)))
     return w_out
 
@@ -677,7 +697,7 @@ def sample_pdf(edges, weights, near_far, num_fine, u_rand=None, histogram_paddin
     return out
 
 
-def composite(sigma, rgb, edges, background=1.0, return_weights=False):
+def composite(sigma, rgb, edges, background=1.0, return_weights=False, clamp=False):
     """RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers
     (model.py:632-638) in one kernel.  sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1].
     rgb=None: only the weights [R,S] are computed and returned (get_weights of the coarse pass, model.py:582)."""
@@ -690,7 +710,7 @@ def composite(sigma, rgb, edges, background=1.0, return_weights=False):
     if rgb is None:
         weights = _empty((R, S), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), None, _ptr(edges), float(background), None, None, None,
+            _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), None, _ptr(edges), None, None, None, None,
                                                 _ptr(weights), _stream(dev)))
         return weights
     out_rgb = _empty((R, 3), dtype=torch.float32, device=dev)
@@ -698,7 +718,7 @@ def composite(sigma, rgb, edges, background=1.0, return_weights=False):
     depth = _empty((R, 1), dtype=torch.float32, device=dev)
     weights = _empty((R, S), dtype=torch.float32, device=dev) if return_weights else None
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), _ptr(rgb), _ptr(edges), float(background), _ptr(out_rgb),
+        _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), _ptr(rgb), _ptr(edges), _background(background, clamp), _ptr(out_rgb),
                                             _ptr(acc), _ptr(depth), _ptr(weights), _stream(dev)))
     return (out_rgb, acc, depth, weights) if return_weights else (out_rgb, acc, depth)
 
@@ -798,7 +818,7 @@ def composite_backward(sigma, rgb, edges, d_out_rgb, d_out_acc, background=1.0):
     g_acc = None if d_out_acc is None else d_out_acc.contiguous().float()
     with torch.cuda.device(dev):
         _lib.check(_lib.load().tn_composite_backward(R, S, _ptr(sigma.contiguous()), _ptr(rgb.contiguous()), _ptr(edges.contiguous()),
-                                                     float(background), _ptr(g_rgb), _ptr(g_acc), _ptr(d_sigma), _ptr(d_rgb),
+                                                     _background(background), _ptr(g_rgb), _ptr(g_acc), _ptr(d_sigma), _ptr(d_rgb),
                                                      _stream(dev)))
     return d_sigma, d_rgb
 
