@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """Benchmark of the ray -> tetrahedra hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: re-executes itself under
+                                                           torch.distributed.run with N ranks, one per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W          (the driver's form; WORLD_SIZE must equal --gpus)
+
+Environment (tests on a one-GPU box): TETRANERF_BENCH_BACKEND=gloo + TETRANERF_BENCH_ONE_DEVICE=1 put all N ranks on
+cuda:0 with gloo collectives (RCCL refuses two ranks on one device), so that the N > 1 code runs on device tensors.
 
 A "step" is one pass of the hot path over one batch of synthetic input: trace_rays over one
 800x800 frame (640,000 rays, M = 512) through the 100k-tetrahedra stand-in of BASELINE.json's
@@ -40,6 +45,17 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (6290 GB/s measured copy ceiling), MI355X_MICROARCH.md:35
+
+
+def mesh_sha256(pts, cells) -> str:
+    """Fingerprint of a stand-in mesh: scipy / Qhull may triangulate the same points differently between images, so the
+    "same" configuration is only the same mesh where this hash agrees (also asserted-and-printed by the parity tests)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(pts, dtype=np.float32).tobytes())
+    h.update(np.ascontiguousarray(cells).astype(np.uint32).tobytes())
+    return h.hexdigest()[:16]
 
 
 def frame_rays(scenes, rank: int, width: int, height: int):
@@ -195,7 +211,8 @@ def config_legs(tn, scenes, dev, M):
                 (("C5_2^20_outside_in", scenes.outside_in_rays(1 << 20, 4), 3),))
         for name, (o, d), reps in sets:
             leg = trace_leg(tr, torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), M, reps)
-            leg.update(tets=int(len(cells)), load_tetrahedra_s=load_s, load_tetrahedra_host_build_s=loads["host_build"])
+            leg.update(tets=int(len(cells)), mesh_sha256=mesh_sha256(pts, cells), load_tetrahedra_s=load_s,
+                       load_tetrahedra_host_build_s=loads["host_build"])
             out[name] = leg
         if cfg == "C4":
             out["C4_train_4096"] = train_leg(tn, tr, len(pts), scenes, M, dev)
@@ -290,6 +307,91 @@ def sharded_render_leg(tn, tracer, num_vertices, scenes, width, height, M, dev, 
             "pass": "coarse only (uniform samples), fused MLP + composite"}
 
 
+def ddp_train_leg(tn, scenes, dev, M, rank, world, iters=5, mesh_points=45000, mesh_seed=2, rays=4096):
+    """The reference's only training-time collective (pipeline.py:53-58): the model replicated under
+    DistributedDataParallel(find_unused_parameters=True), every rank training on ITS OWN 4096-ray batch of the C4 mesh
+    (BASELINE.json configs[3]), gradients of tetrahedra_field (256 V bytes) + the MLP (245 KB) all-reduced over RCCL.
+    The model is render.TetraNerfModule: forward = the fused autograd nodes, so DDP's reducer hooks fire from the HIP
+    adjoint kernels' gradients.  Reported: ms per iteration (max over ranks) with the all-reduce and with
+    `no_sync()` (no collective: the difference is the exposed all-reduce time), whole-job rays/s."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    render = importlib.import_module("tetra-nerf_amd.render")
+    sharding = importlib.import_module("tetra-nerf_amd.sharding")
+    pts, cells = scenes.random_mesh(mesh_points, mesh_seed)
+    tr = tn.TetrahedraTracer(dev)
+    tr.load_tetrahedra(torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev))
+    o, d = scenes.outside_in_rays(rays, 100 + rank)          # a different batch per rank
+    o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    target = torch.rand(len(o), 3, device=dev)
+    out = {}
+    for name, (s_c, s_f, biased, scaling) in (("tetra-nerf-original", (256, 256, False, False)), ("tetra-nerf", (128, 128, True, True))):
+        torch.manual_seed(0)                                   # replicated initial parameters (DDP broadcasts rank 0's anyway)
+        module = render.TetraNerfModule(tr, len(pts), s_c, M, num_fine_samples=s_f, biased=biased, gradient_scaling=scaling).to(dev)
+        model = DDP(module, device_ids=[dev.index], find_unused_parameters=True)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+
+        def step(sync=True):
+            opt.zero_grad(set_to_none=True)
+            if sync:
+                res = model(o, d)
+                ((res["rgb"] - target) ** 2).mean().backward()
+            else:
+                with model.no_sync():
+                    res = model(o, d)
+                    ((res["rgb"] - target) ** 2).mean().backward()
+            opt.step()
+
+        res = {}
+        for what, sync in (("ddp", True), ("no_sync", False)):
+            step(sync)
+            step(sync)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                step(sync)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            res[what] = sharding.max_over_ranks((time.perf_counter() - t0) / iters, device=dev) * 1e3
+        grad_bytes = sum(p.numel() for p in module.parameters()) * 4
+        out[name] = {"ms_per_iteration": res["ddp"], "ms_per_iteration_no_sync": res["no_sync"],
+                     "exposed_all_reduce_ms": res["ddp"] - res["no_sync"], "rays_per_s": world * rays / (res["ddp"] * 1e-3),
+                     "rays_per_rank": rays, "all_reduced_bytes_per_iteration": grad_bytes}
+        del model, module, opt
+    out.update(n_gpus=world, backend=dist.get_backend(), mesh_tets=int(len(cells)),
+               wrapper="DistributedDataParallel(find_unused_parameters=True) as in pipeline.py:53-58",
+               step="trace_rays + render_train forward + backward (gradient all-reduce) + SGD step, one 4096-ray batch per rank")
+    return out
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: re-execute under torch.distributed.run, one rank
+    per GPU (the same command line the driver uses), and pass its exit code on."""
+    import subprocess
+
+    one_device = os.environ.get("TETRANERF_BENCH_ONE_DEVICE") == "1"
+    if not one_device and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible "
+                         "(TETRANERF_BENCH_ONE_DEVICE=1 + TETRANERF_BENCH_BACKEND=gloo run all ranks on cuda:0)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def cpu_baseline(pts, cells, o, d, M, target_s=30.0):
     """Oracle (BVH all-hits + sort + pairing, OpenMP) on a bounded sample of the bench rays."""
     from oracle import tn_oracle
@@ -329,22 +431,32 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true", help="skip the rendered-rays/s legs")
     ap.add_argument("--no-configs", action="store_true", help="skip the C4 / C5 legs")
+    ap.add_argument("--no-ddp", action="store_true", help="skip the DDP training leg of multi-rank runs")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)            # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: the two must agree")
+    one_device = os.environ.get("TETRANERF_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("TETRANERF_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", 0 if one_device else local_rank)
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     tn = importlib.import_module("tetra-nerf_amd")
     scenes = importlib.import_module("tetra-nerf_amd.scenes")
@@ -421,7 +533,7 @@ def main():
                 "workload": f"configs[1] stand-in: Delaunay of {args.mesh_points} uniform points seed {args.mesh_seed} "
                             f"({len(cells)} tets), {args.width}x{args.height} pinhole frame = {R} rays per GPU, "
                             f"trace_rays M={M}, dense reference outputs",
-                "tets": int(len(cells)), "rays_per_gpu": R, "max_ray_triangles": M,
+                "tets": int(len(cells)), "mesh_sha256": mesh_sha256(pts, cells), "rays_per_gpu": R, "max_ray_triangles": M,
                 "intersections_per_frame": inter, "sharding": f"rays/{world} ranks, no collective",
             },
             "roofline": {
@@ -440,30 +552,37 @@ def main():
         # secondary figure of SURVEY.md 8(d): the same launch without the constant tails of the dense
         # reference layout ("dense_tails" = 0; rows valid through num_visited only) -- what a
         # non-materialising consumer (find_visited_cells, the render path) needs
-        tracer.set_option("dense_tails", 0)
-        step()
+        def step_compact():
+            return tracer.trace_rays(o, d, M, compact_rows=True)["num_visited_cells"]
+
+        step_compact()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.steps):
-            step()
+            step_compact()
         e1.record()
         torch.cuda.synchronize()
-        tracer.set_option("dense_tails", 1)
         seg_ms = e0.elapsed_time(e1) / args.steps
         seg_bytes = 28 * R + 52 * inter
         line["segments_only"] = {"ms_per_step": seg_ms, "rays_per_s": R / (seg_ms * 1e-3),
                                  "intersections_per_s": inter / (seg_ms * 1e-3),
                                  "algorithmic_bytes_per_launch": seg_bytes,
                                  "achieved_GBps": seg_bytes / (seg_ms * 1e-3) / 1e9,
-                                 "note": "non-reference option dense_tails=0: 28 B/ray + 52 B/segment; instruction-issue-bound walk"}
+                                 "note": "per-call flag TN_TRACE_COMPACT_ROWS (no reference counterpart): 28 B/ray + 52 B/segment; instruction-issue-bound walk"}
         if not args.no_render and world == 1:   # secondary legs: single-GPU runs only (rank 0 alone would hold the job)
             line["render"] = render_leg(tn, tracer, len(pts), o, d, M, dev)
     # the sharded render: a collective leg, every rank takes part
     shr = None
     if not args.no_render:
         shr = sharded_render_leg(tn, tracer, len(pts), scenes, args.width, args.height, M, dev)
+    # the training collective: DDP gradient all-reduce, one 4096-ray batch per rank
+    ddp = None
+    if dist is not None and not args.no_ddp:
+        ddp = ddp_train_leg(tn, scenes, dev, M, rank, world)
     if rank == 0:
+        if ddp is not None:
+            line["ddp_train_4096"] = ddp
         if shr is not None:
             shr["n_gpus"] = world
             line["sharded_render"] = shr

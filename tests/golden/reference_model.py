@@ -62,8 +62,8 @@ def ray_bundle(ref, origins, directions, device=None, camera_indices=None):
     """A (stub-)nerfstudio RayBundle over [R,3] origins / directions."""
     from nerfstudio.cameras.rays import RayBundle
 
-    o = torch.as_tensor(np.asarray(origins), dtype=torch.float32)
-    d = torch.as_tensor(np.asarray(directions), dtype=torch.float32)
+    o = origins if isinstance(origins, torch.Tensor) else torch.as_tensor(np.asarray(origins), dtype=torch.float32)
+    d = directions if isinstance(directions, torch.Tensor) else torch.as_tensor(np.asarray(directions), dtype=torch.float32)
     ci = None if camera_indices is None else torch.as_tensor(camera_indices).reshape(-1, 1)
     if device is not None:
         o, d = o.to(device), d.to(device)

@@ -1,0 +1,144 @@
+"""The N > 1 code paths on the ONE GPU a test box has: N processes share cuda:0 and talk over "gloo" (RCCL refuses two ranks
+on one device; the one-rank "nccl" group is tests/test_sharding_gpu.py), so that rank > 0 code runs on device tensors:
+
+  * `bench.py --gpus 2` really starts two ranks (it used to ignore N), prints n_gpus = 2, runs the dealt-tile sharded
+    render and the DDP training leg;
+  * the reference's model (tests/golden/ref, stub nerfstudio) with nerfstudio_plugin installed, wrapped in
+    DistributedDataParallel(find_unused_parameters=True) exactly as pipeline.py:53-58 does: after one backward the
+    gradients are identical on both ranks and equal the mean of the two single-process gradients -- bit for bit for the
+    twelve weight tensors (their kernels are reproducible), to round-off for the atomically accumulated field;
+  * `render_sharded` over two ranks on device tensors == the single-process frame, bit for bit."""
+import importlib
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_gpus_2_starts_two_ranks(device):
+    env = dict(os.environ, TETRANERF_BENCH_BACKEND="gloo", TETRANERF_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-configs",
+                        "--no-cpu-baseline", "--width", "320", "--height", "200", "--mesh-points", "3000"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["rays_per_gpu"] == 320 * 200
+    assert line["rays_per_s"] * line["ms_per_step"] * 1e-3 == pytest.approx(2 * 320 * 200, rel=1e-6)   # units of BOTH ranks
+    shr = line["sharded_render"]
+    assert shr["n_gpus"] == 2 and len(shr["hitting_rays_per_rank"]) == 2 and sum(shr["hitting_rays_per_rank"]) == shr["hitting_rays"]
+    ddp = line["ddp_train_4096"]
+    assert ddp["n_gpus"] == 2 and ddp["backend"] == "gloo"
+    for name in ("tetra-nerf-original", "tetra-nerf"):
+        assert ddp[name]["ms_per_iteration"] > 0 and ddp[name]["all_reduced_bytes_per_iteration"] > 45000 * 64 * 4
+    # a launcher whose world size disagrees with --gpus is an error, not a silent one-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--no-configs", "--no-cpu-baseline", "--no-render"],
+                        cwd=ROOT, env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "must agree" in (r2.stdout + r2.stderr)
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests" / "golden"))
+    import reference_model as rm
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        ref = rm.load()
+        plugin = importlib.import_module("tetra-nerf_amd.nerfstudio_plugin")
+        sharding = importlib.import_module("tetra-nerf_amd.sharding")
+        scenes = importlib.import_module("tetra-nerf_amd.scenes")
+        plugin.install(ref.TetrahedraNerf)
+        pts, cells = scenes.random_mesh(3000, 11)
+        cfg = dict(num_samples=64, num_fine_samples=64, use_biased_sampler=True, use_gradient_scaling=True)
+        model = rm.build_model(ref, pts, cells, seed=1, **cfg).to(dev).train()      # same seed: replicated parameters
+        names = ["tetrahedra_field"] + list(plugin.STATE_DICT_KEYS)
+        params = dict(model.named_parameters())
+
+        def batch(k):
+            o, d = scenes.outside_in_rays(1024, 40 + k)
+            return rm.ray_bundle(ref, o, d, dev), torch.rand(len(o), 3, generator=torch.Generator().manual_seed(k)).to(dev)
+
+        def backward(m, k):
+            for p in model.parameters():
+                p.grad = None
+            rb, target = batch(k)
+            torch.manual_seed(100 + k)                  # the stratified draws of batch k
+            out = m(rb)
+            model.get_loss_dict(out, {"image": target})["rgb_loss"].backward()
+            return [params[n].grad.clone() for n in names]
+
+        single = [backward(model, k) for k in range(world)]                # no DDP: every rank computes every batch
+        ddp = DDP(model, device_ids=[0], find_unused_parameters=True)      # pipeline.py:53-58
+        got = backward(ddp, rank)                                          # this rank's batch; gradients all-reduced (mean)
+        assert model._tn_renderer is not None                              # the fused path ran under DDP
+        ok, worst = True, 0.0
+        for i, n in enumerate(names):
+            want = sum(g[i] for g in single) / world
+            if n == "tetrahedra_field":
+                err = float((got[i] - want).abs().max() / want.abs().max())
+                worst = max(worst, err)
+                ok = ok and err < 1e-5
+            else:
+                ok = ok and torch.equal(got[i], want)
+            # identical on every rank
+            mine = got[i].flatten()[:4096].double().cpu()
+            both = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            ok = ok and all(torch.equal(b, both[0]) for b in both)
+        # the sharded render of ONE frame over the two ranks, on device tensors, against the single-process frame
+        model.eval()
+        o, d = scenes.pinhole_rays(160, 120, eye=(0.5, 2.4, 0.6), lookat=(0.5, 0.5, 0.5))
+        rbf = rm.ray_bundle(ref, o, d, dev)
+        fn = lambda o_, d_: model.get_outputs(rm.ray_bundle(ref, o_, d_))      # noqa: E731
+        with torch.no_grad():
+            full = sharding.render_sharded(fn, rbf.origins, rbf.directions, chunk=4096, tile=1024)
+            whole = fn(rbf.origins, rbf.directions)
+        same = all(torch.equal(full[k], whole[k]) for k in ("rgb", "accumulation", "depth", "ray_mask"))
+        q.put((rank, bool(ok), worst, bool(same), int(whole["ray_mask"].sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_adapter_under_ddp_two_ranks_one_device(device):
+    import torch.multiprocessing as mp
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, worst, same, hits in res:
+        assert ok, (rank, worst)
+        assert same and hits > 3000, (rank, hits)

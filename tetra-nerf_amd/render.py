@@ -610,3 +610,39 @@ class TetraRenderer:
         acc = acc.index_copy(0, idx, acc_r.reshape(-1, 1))
         depth = depth.index_copy(0, idx, depth_r.reshape(-1, 1).detach())
         return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
+
+
+class TetraNerfModule(torch.nn.Module):
+    """The model's trainable state -- `tetrahedra_field` [64,V] + the MLP -- and its forward as ONE nn.Module, i.e. the
+    unit the reference wraps in `DistributedDataParallel(find_unused_parameters=True)` (pipeline.py:53-58: the model is
+    replicated, every rank trains on its own rays, the gradients of the field and the MLP are all-reduced).
+    `forward(origins, directions)` = TetraRenderer.render_train in training mode (the fused autograd nodes: their
+    gradients reach the parameters through the autograd engine, so DDP's reducer hooks see them like any other) and
+    TetraRenderer.render otherwise.  With a real nerfstudio the same role is played by the reference's TetrahedraNerf
+    after nerfstudio_plugin.install()."""
+
+    def __init__(self, tracer, num_vertices: int, num_samples: int = 256, max_ray_triangles: int = 512,
+                 num_fine_samples: int = 256, biased: bool = False, gradient_scaling: bool = False, **renderer_kw):
+        super().__init__()
+        field = (torch.rand(FIELD_DIM, num_vertices) * 2 - 1) * 1e-4      # model.py:269-271
+        field[1:4] = torch.rand(3, num_vertices) * 2 - 1                  # colours, model.py:379-386
+        self.tetrahedra_field = torch.nn.Parameter(field)
+        self.mlp = TetraMLP()
+        self.gradient_scaling = bool(gradient_scaling)
+        self._tracer = tracer
+        self._renderer_args = (int(num_samples), int(max_ray_triangles))
+        self._renderer_kw = dict(num_fine_samples=int(num_fine_samples), biased=bool(biased), **renderer_kw)
+        self._renderer = None
+
+    def renderer(self) -> "TetraRenderer":
+        rd = self._renderer
+        if rd is None or rd.field is not self.tetrahedra_field:      # (.to(device) replaces the parameter's storage)
+            rd = TetraRenderer(self._tracer, self.tetrahedra_field, self.mlp, *self._renderer_args, fused=True, **self._renderer_kw)
+            object.__setattr__(self, "_renderer", rd)
+        return rd
+
+    def forward(self, origins: torch.Tensor, directions: torch.Tensor) -> Dict[str, torch.Tensor]:
+        rd = self.renderer()
+        if self.training:
+            return rd.render_train(origins, directions, gradient_scaling=self.gradient_scaling)
+        return rd.render(origins, directions)

@@ -68,6 +68,30 @@ def undeal_index(num_rays: int, world_size: int, tile: int = TILE_RAYS) -> torch
     return pos
 
 
+def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
+    """dist.all_gather_into_tensor; device tensors on a "gloo" group (the one-GPU test mode of bench.py / the GPU tests:
+    N processes sharing one device, where RCCL refuses duplicate devices) are staged through the host."""
+    import torch.distributed as dist
+
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, inp.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def _all_reduce(t: torch.Tensor, op, group=None) -> torch.Tensor:
+    import torch.distributed as dist
+
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        return h
+    dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 def all_gather_dealt(local: torch.Tensor, num_rows_total: int, group=None, tile: int = TILE_RAYS) -> torch.Tensor:
     """All-gather rows partitioned by `deal_tiles` into the full [num_rows_total, ...] tensor in ray order on every
     rank: ONE all_gather_into_tensor of equal (padded) blocks + one index_select with the inverse permutation."""
@@ -86,7 +110,7 @@ def all_gather_dealt(local: torch.Tensor, num_rows_total: int, group=None, tile:
         padded = local.new_zeros((per,) + tuple(local.shape[1:]))
         padded[: local.shape[0]] = local
     out = local.new_empty((world * per,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    _all_gather_into(out, padded.contiguous(), group)
     return out.index_select(0, undeal_index(num_rows_total, world, tile).to(out.device))
 
 
@@ -112,7 +136,7 @@ def all_gather_rows(local: torch.Tensor, num_rows_total: int, group=None) -> tor
         padded = local.new_zeros((per,) + tail)
         padded[: local.shape[0]] = local
     out = local.new_empty((world * per,) + tail)
-    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    _all_gather_into(out, padded.contiguous(), group)
     if world * per == num_rows_total:
         return out
     pieces = []
@@ -153,14 +177,15 @@ def render_sharded(render_fn, origins: torch.Tensor, directions: torch.Tensor, g
     import torch.distributed as dist
 
     R = origins.shape[0]
-    if dist.is_available() and dist.is_initialized():
+    grouped = dist.is_available() and dist.is_initialized()
+    if grouped:
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     else:
         world, rank = 1, 0
     sync = (lambda: torch.cuda.synchronize(origins.device)) if origins.is_cuda else (lambda: None)
     sync()
     t0 = time.perf_counter()
-    if tile and world > 1:
+    if tile and grouped:   # (a one-rank group takes the same deal -> index_select -> all-gather -> un-deal path as N ranks)
         mine = deal_tiles(R, rank, world, tile).to(origins.device)
         o_mine, d_mine = origins.index_select(0, mine), directions.index_select(0, mine)
     else:
@@ -195,7 +220,7 @@ def gather_scalars(value: float, device=None, group=None):
         return [float(value)]
     world = dist.get_world_size(group)
     out = torch.zeros(world, dtype=torch.float64, device=device)
-    dist.all_gather_into_tensor(out, torch.tensor([value], dtype=torch.float64, device=device), group=group)
+    _all_gather_into(out, torch.tensor([value], dtype=torch.float64, device=device), group)
     return [float(x) for x in out.tolist()]
 
 
@@ -205,8 +230,7 @@ def max_over_ranks(value: float, device=None, group=None) -> float:
 
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    t = _all_reduce(torch.tensor([value], dtype=torch.float64, device=device), dist.ReduceOp.MAX, group)
     return float(t.item())
 
 
@@ -216,6 +240,5 @@ def sum_over_ranks(values, device=None, group=None):
 
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return [float(v) for v in values]
-    t = torch.tensor(list(values), dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t = _all_reduce(torch.tensor(list(values), dtype=torch.float64, device=device), dist.ReduceOp.SUM, group)
     return [float(x) for x in t.tolist()]
