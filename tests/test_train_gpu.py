@@ -148,7 +148,10 @@ def test_render_train_fused_equals_autograd_statement(tn, device, scenes):
             # adjoint is a different (equally cancelling) expression.  The ratio to float32 autograd's own error moves
             # between 0.5 and 6 with the target image (both are conditioning-limited: 1e-4 .. 2e-3 of the largest entry for
             # the field gradient of this loss), hence the absolute alternative
-            assert ours < max(5.0 * torch32, 2e-3 if name == "field" else 1e-4), ((S, S_fine, biased), name, ours, torch32, errs)
+            # (round 4, profiles/r04b_grad_diag.txt: float32 autograd itself is 1.0e-4 off for w1 and 5e-4 for wh on some
+            # mesh / draw combinations -- a ReLU pre-activation within rounding of 0 takes the other branch than in float64 --
+            # while on others it is 5e-7; the fused path flips different samples, so the absolute alternative is 3e-4)
+            assert ours < max(5.0 * torch32, 2e-3 if name == "field" else 3e-4), ((S, S_fine, biased), name, ours, torch32, errs)
 
 
 def test_render_train_in_several_autograd_nodes(tn, device, scenes):
