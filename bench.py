@@ -48,14 +48,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (6290 GB/s measured copy ceiling), MI355X_M
 
 
 def mesh_sha256(pts, cells) -> str:
-    """Fingerprint of a stand-in mesh: scipy / Qhull may triangulate the same points differently between images, so the
-    "same" configuration is only the same mesh where this hash agrees (also asserted-and-printed by the parity tests)."""
-    import hashlib
-
-    h = hashlib.sha256()
-    h.update(np.ascontiguousarray(pts, dtype=np.float32).tobytes())
-    h.update(np.ascontiguousarray(cells).astype(np.uint32).tobytes())
-    return h.hexdigest()[:16]
+    return importlib.import_module("tetra-nerf_amd.scenes").mesh_sha256(pts, cells)
 
 
 def frame_rays(scenes, rank: int, width: int, height: int):
@@ -162,6 +155,10 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
                                    "fp32 accumulate; same 1e-5 parity tests; not the default"}}
 
 
+def cross_check(reasons, stride=64):
+    return {"stride": stride, "checked": int(reasons.get("15", 0)), "mismatches": int(reasons.get("14", 0))}
+
+
 def trace_leg(tracer, o, d, M, reps):
     """ms per trace_rays call (HIP events on the launch stream), intersections, path statistics."""
     def run():
@@ -185,7 +182,8 @@ def trace_leg(tracer, o, d, M, reps):
     gbs = R * (28 + 52 * M) / (ms * 1e-3) / 1e9
     return {"rays": R, "ms": ms, "rays_per_s": R / (ms * 1e-3), "intersections_per_s": inter / (ms * 1e-3),
             "intersections": inter, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                 "frac": gbs / HBM_PEAK_GBS}, "paths": stats}
+                                                 "frac": gbs / HBM_PEAK_GBS}, "paths": stats,
+            "certification_cross_check": cross_check(stats["reasons"])}
 
 
 def config_legs(tn, scenes, dev, M):
@@ -547,6 +545,9 @@ def main():
             },
             "trace_path_stats": stats,
             "walk_hand_over_reasons": reasons,
+            # the always-on sampled cross-check of the walk's certification (count-only BVH traversal of every 64th ray,
+            # beside the writer and the fill): `mismatches` must be 0
+            "certification_cross_check": cross_check(reasons),
             "load_tetrahedra_s": load_s,
         }
         # secondary figure of SURVEY.md 8(d): the same launch without the constant tails of the dense

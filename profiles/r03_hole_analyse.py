@@ -11,7 +11,8 @@ import numpy as np
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 tn = importlib.import_module("tetra-nerf_amd"); scenes = importlib.import_module("tetra-nerf_amd.scenes")
-import r03_hole_fuzz_lib as lib   # noqa: E402  (generators shared with the fuzzer)
+sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))   # (round 4: the generators moved to tests/)
+import hole_fuzz_lib as lib   # noqa: E402  (generators shared with the fuzzer)
 dev = torch.device("cuda:0"); M = 256; B = 400_000
 KEYS = ("num_visited_cells", "visited_cells", "vertex_indices", "hit_distances", "barycentric_coordinates")
 rng = lib.rng

@@ -10,7 +10,8 @@ import numpy as np
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 tn = importlib.import_module("tetra-nerf_amd"); scenes = importlib.import_module("tetra-nerf_amd.scenes")
-import r03_hole_fuzz_lib as lib   # noqa: E402
+sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))   # (round 4: the generators moved to tests/)
+import hole_fuzz_lib as lib   # noqa: E402
 from oracle import tn_oracle      # noqa: E402
 from r03_hole_analyse import tet_stats  # noqa: E402  (imports run its module-level code? no: guarded below)
 dev = torch.device("cuda:0"); M = 256; B = 400_000

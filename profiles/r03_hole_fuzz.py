@@ -27,7 +27,8 @@ target_rays = int(float(sys.argv[1]) * 1e6) if len(sys.argv) > 1 else 50_000_000
 verify = int(sys.argv[2]) if len(sys.argv) > 2 else 1     # 0: the walk path as shipped (no count cross-check)
 
 
-import r03_hole_fuzz_lib as lib   # noqa: E402
+sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))   # (round 4: the generators moved to tests/)
+import hole_fuzz_lib as lib   # noqa: E402
 rng, MESHES, aimed_rays = lib.rng, lib.MESHES, lib.aimed_rays
 
 t0 = time.time(); total = 0; mism_rays = 0; oracle_rays = 0; oracle_bad = 0; reasons = {}; batches = 0

@@ -1,4 +1,5 @@
-"""Meshes and aimed-ray generators shared by profiles/r03_hole_fuzz.py and r03_hole_analyse.py."""
+"""Meshes and aimed-ray generators of the certification-hole fuzzer: used by tests/test_parity_configs_gpu.py (seeded
+sample) and by profiles/r03_hole_fuzz.py / r03_hole_analyse.py / r03_hole_classify.py (the long runs)."""
 import importlib, sys
 from pathlib import Path
 import numpy as np

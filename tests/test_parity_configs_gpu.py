@@ -2,8 +2,10 @@
 
  * C2: the bench workload itself -- 99,899 tets, the whole 800x800 frame (640,000 rays) traced in ONE call at
    M = 512, all five outputs including every tail byte;
- * C4: 301,874 tets -- the 800x800 frame and both 4096-ray training batches (outside-in / inside-out);
- * C5: 1,009,317 tets -- 2^20 outside-in rays traced in one call, 65,536 of them and a frame slice compared;
+ * C4: 301,769 tets with this image's Qhull (SURVEY.md quotes 301,874 from another image; the tests print the count and
+   the mesh fingerprint of what they built) -- the 800x800 frame and both 4096-ray training batches (outside-in / inside-out);
+ * C5: 1,009,442 tets -- 2^20 outside-in rays traced in one call: ALL of them against the BVH all-hits path on the GPU,
+   65,536 of them and a frame slice against the CPU oracle;
  * adversarial meshes: the reference's bottle under a multi-view orbit + inside-out rays, an exact lattice and a
    jittered one (cospherical points: Qhull slivers, zero-volume tets, exact ties in t), two thin shells,
    near-duplicate points (edges of ~1e-7, far below the pairing stage's 1e-6 window), a COLMAP-like clustered
@@ -68,6 +70,21 @@ def _trace(tr, device, o, d, M):
     return tr.trace_rays(torch.from_numpy(o).to(device), torch.from_numpy(d).to(device), M)
 
 
+def _cross_check_clean(tr, num_rays, ctx):
+    """The always-on sampled cross-check of the walk's certification (tracer option verify_stride, default 64: a count-only
+    BVH all-hits traversal of every 64th ray, beside the writer and the fill): it ran, and it never disagreed."""
+    why = tr.flag_reasons()
+    assert why.get(14, 0) == 0, (ctx, why)
+    assert why.get(15, 0) > 0.5 * num_rays / 64, (ctx, why)     # (literal / fallback rays among the sampled ones are skipped)
+
+
+def _mesh(scenes, n_points, seed, ctx):
+    """The stand-in mesh + its fingerprint on THIS box (scipy / Qhull differs between images: BASELINE.md section 4)."""
+    pts, cells = scenes.random_mesh(n_points, seed)
+    print(f"{ctx}: {len(cells)} tets, mesh sha256 {scenes.mesh_sha256(pts, cells)}")
+    return pts, cells
+
+
 def _frame(scenes, width=800, height=800):
     c = np.array([0.5, 0.5, 0.5], np.float32)
     return scenes.pinhole_rays(width, height, eye=tuple(c + np.array([0.0, 2.0, 0.0], np.float32)), lookat=tuple(c),
@@ -77,12 +94,13 @@ def _frame(scenes, width=800, height=800):
 # ------------------------------------------------------------------------------------------------ BASELINE configs
 def test_c2_full_bench_frame_bit_exact(tn, device, oracle, scenes):
     """configs[1]: the exact bench.py workload, all 640,000 rays, M = 512, default path selection."""
-    pts, cells = scenes.random_mesh(15000, 0)
+    pts, cells = _mesh(scenes, 15000, 0, "C2")
     o, d = _frame(scenes)
     tr = _tracer(tn, device, pts, cells, walk=1)
     out = _trace(tr, device, o, d, 512)
     st = tr.trace_stats()
     assert st["walk"] > 0.97 * len(o), st
+    _cross_check_clean(tr, len(o), "C2 frame")
     total = _compare(out, _oracle(oracle, pts, cells), o, d, 512, ctx="C2 frame")
     assert total == int(out["num_visited_cells"].sum()) and total > 25_000_000
 
@@ -90,7 +108,7 @@ def test_c2_full_bench_frame_bit_exact(tn, device, oracle, scenes):
 def test_c4_frame_and_training_batches_bit_exact(tn, device, oracle, scenes):
     """configs[3]: 300k-tet stand-in; the 800x800 frame and the two 4096-ray batches (default small-batch path AND
     the walk forced onto them)."""
-    pts, cells = scenes.random_mesh(45000, 2)
+    pts, cells = _mesh(scenes, 45000, 2, "C4")
     assert len(cells) > 300_000
     ot = _oracle(oracle, pts, cells)
     tr = _tracer(tn, device, pts, cells, walk=1)
@@ -98,6 +116,7 @@ def test_c4_frame_and_training_batches_bit_exact(tn, device, oracle, scenes):
     out = _trace(tr, device, o, d, 512)
     st = tr.trace_stats()
     assert st["walk"] > 0.93 * len(o), st
+    _cross_check_clean(tr, len(o), "C4 frame")
     _compare(out, ot, o, d, 512, ctx="C4 frame")
     del out
     for name, (bo, bd) in (("outside-in", scenes.outside_in_rays(4096, 1)), ("inside-out", scenes.inside_out_rays(4096, 2))):
@@ -109,7 +128,9 @@ def test_c4_frame_and_training_batches_bit_exact(tn, device, oracle, scenes):
 def test_c5_stress_sample_bit_exact(tn, device, oracle, scenes):
     """configs[4]: 1M tets; all 2^20 outside-in rays traced in one call (28 GB of rows), 65,536 of them compared
     (the first 32,768 and a random 32,768), plus 64 rows of the 800x800 frame."""
-    pts, cells = scenes.random_mesh(150000, 3)
+    import torch
+
+    pts, cells = _mesh(scenes, 150000, 3, "C5")
     assert len(cells) > 1_000_000
     ot = _oracle(oracle, pts, cells)
     tr = _tracer(tn, device, pts, cells, walk=1)
@@ -117,6 +138,14 @@ def test_c5_stress_sample_bit_exact(tn, device, oracle, scenes):
     out = _trace(tr, device, o, d, 512)
     st = tr.trace_stats()
     assert st["walk"] + st["general"] == len(o) and st["walk"] > 0.8 * len(o), st
+    _cross_check_clean(tr, len(o), "C5 2^20 rays")
+    # ALL 2^20 rays: the walk path (certified chains + literal pairing of the log + BVH fallbacks) against the BVH all-hits
+    # path alone, bit for bit over the five outputs (the oracle's CPU time only allows the 65,536-ray sample below)
+    tb = _tracer(tn, device, pts, cells, walk=0)
+    ref = _trace(tb, device, o, d, 512)
+    for k in KEYS:
+        assert torch.equal(out[k].view(torch.int32), ref[k].view(torch.int32)), f"C5 walk vs BVH path: {k}"
+    del ref, tb
     rows = np.concatenate([np.arange(32768), np.sort(np.random.default_rng(9).choice(np.arange(32768, 1 << 20), 32768, replace=False))])
     _compare(out, ot, o, d, 512, rows=rows, chunk=32768, ctx="C5 2^20 rays")
     del out
@@ -306,8 +335,8 @@ def test_aimed_rays_do_not_fall_into_the_certification_hole(tn, device, oracle, 
 
     import torch
 
-    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "profiles"))
-    import r03_hole_fuzz_lib as lib
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import hole_fuzz_lib as lib
 
     lib.rng = np.random.default_rng(5)
     pts, cells = dict(lib.MESHES)[mesh]()

@@ -42,7 +42,11 @@ struct tn_tracer {
     bool small_lds = true;               // small batches: LDS hit arrays sized for the mesh, overflow rays in a second launch
     unsigned lds_cap = 0;                // 0: from the mesh size; otherwise the entries of the small arrays (power of two; tests)
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
-    unsigned verify_stride = 0;          // > 0: every stride-th certified ray is cross-checked against a count-only BVH traversal
+    // every stride-th certified ray is cross-checked against a count-only BVH all-hits traversal (0: off).  On by default:
+    // the walk's certification has an unproved residue, and the check costs < 1 % of a frame because a
+    // one-chunk call runs it on the aux stream beside the writer and the fill (profiles/r04c_verify_ab.txt)
+    unsigned verify_stride = 64;
+    tn::DevBuf<uint32_t> verify_list;    // certified rays whose count differed: re-traced by the BVH kernel at the end of the call
     tn::DevBuf<tn::WalkVar> vars;        // the build's 64-byte records: split into the three tables below, then released
     tn::DevBuf<tn::WalkHot> hot;
     tn::DevBuf<tn::WalkCold> cold;
@@ -53,6 +57,7 @@ struct tn_tracer {
                                             // literal count, kmax (one memset clears them all)
     uint32_t *fallback_count() { return reinterpret_cast<uint32_t *>(stats.p + 24); }
     uint32_t *literal_count() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 1; }
+    uint32_t *verify_count() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 2; }
     size_t last_num_rays = 0;
     int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
     size_t walk_min_rays = 12288;        // measured crossover on the 300k-tet mesh after round 2b's faster BVH path
@@ -396,7 +401,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 w.hit_log = t->hit_log.p;
                 w.ray_base = base;
                 tn::launch_trace_walk(w, stream);
-                if (t->verify_stride)   // before anything that reads walk_n / the fallback list (same stream)
+                if (t->verify_stride && !single)   // chunked call: serially, before anything that reads walk_n / the fallback list
                     tn::launch_verify_counts(w.t, t->verify_stride, w.walk_n, w.fallback_list, w.fallback_count, base, stream);
             };
             auto launch_segments = [&](size_t base, size_t n) {
@@ -452,6 +457,13 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                     TN_HIP(hipStreamWaitEvent(stream, t->ev_pre, 0));
                 }
                 tn::launch_trace_general(p, t->aux);
+                if (t->verify_stride) {
+                    // the count cross-check beside the writer and the fill (late form): mismatching rays -> verify_list
+                    const size_t n_checks = (R + t->verify_stride - 1) / t->verify_stride;
+                    if (t->verify_list.n < n_checks) t->verify_list.alloc(n_checks);
+                    tn::launch_verify_counts(chunk_params(0, R), t->verify_stride, t->walk_n.p, t->verify_list.p, t->verify_count(), 0,
+                                             t->aux, true);
+                }
                 TN_HIP(hipEventRecord(t->ev_aux, t->aux));
                 // the segment writer is enqueued BEFORE the side stream's kernel: its grid is sized for the worst case (the
                 // count lives on the device) and would otherwise take every wave slot first
@@ -463,6 +475,14 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_aux, 0));
+                if (t->verify_stride) {
+                    // rows of the rays whose count differed (none, as far as anyone has seen): whole rows, after every other
+                    // writer of the call.  The count lives on the device: a small grid that finds it 0 and exits
+                    tn::TraceParams pv = make_params(t, 64, M, origins, directions, num_visited, visited, bary, dist, verts);
+                    pv.ray_list = t->verify_list.p;
+                    pv.item_count = t->verify_count();
+                    tn::launch_trace_general(pv, stream);
+                }
             } else {
                 for (size_t base = 0; base < R; base += chunk) {
                     const size_t n = R - base < chunk ? R - base : chunk;

@@ -553,9 +553,13 @@ __global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const Wal
 // BVH finds (count only: no sort, no pairing) must equal the number of hits the walk logged.  A mismatch is counted
 // (reason 14) and the ray is handed to the BVH kernel like any other fallback ray -- the kernels that write rows are
 // launched after this one.  reason 15 counts the rays checked.
+// LATE form (late != 0; the default schedule of a one-chunk call, tn_api.hip): the check runs on a side stream BESIDE
+// the segment writer and the tail fill instead of in front of them, so walk_n is left alone (the row of a mismatching ray is
+// written as certified) and the ray goes to a list of its own, which one more BVH launch re-traces -- whole rows -- after
+// everything else of the call has been joined.
 __global__ __launch_bounds__(64) void k_verify_counts(TraceParams p, uint32_t stride, uint32_t *__restrict__ walk_n,
                                                       uint32_t *__restrict__ fallback_list, uint32_t *__restrict__ fallback_count,
-                                                      size_t ray_base) {
+                                                      size_t ray_base, uint32_t late) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WaveSmem s = carve(smem, p.M);
     const int lane = threadIdx.x;
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(64) void k_verify_counts(TraceParams p, uint32_t st
         if (lane == 0) {
             if (p.stats) atomicAdd(&p.stats[4 + 15], 1ull);
             if (nh != wn || overflow) {
-                walk_n[ray] = TN_EMPTY;        // the segment writer and the fill skip the row: the BVH kernel writes it
+                if (!late) walk_n[ray] = TN_EMPTY;   // the segment writer and the fill skip the row: the BVH kernel writes it
                 fallback_list[atomicAdd(fallback_count, 1u)] = (uint32_t)(ray_base + ray);
                 if (p.stats) atomicAdd(&p.stats[4 + 14], 1ull);
             }
@@ -703,12 +707,12 @@ void launch_trace_general(const TraceParams &p, hipStream_t stream) {
 }
 
 void launch_verify_counts(const TraceParams &p, uint32_t stride, uint32_t *walk_n, uint32_t *fallback_list, uint32_t *fallback_count,
-                          size_t ray_base, hipStream_t stream) {
+                          size_t ray_base, hipStream_t stream, bool late) {
     if (p.num_items == 0 || stride == 0) return;
     const size_t smem = wave_smem(k_verify_counts, p.M);
     const size_t n_checks = (p.num_items + stride - 1) / stride, max_blocks = 256 * 16;
     hipLaunchKernelGGL(k_verify_counts, dim3((unsigned)(n_checks < max_blocks ? n_checks : max_blocks)), dim3(64), smem, stream, p, stride,
-                       walk_n, fallback_list, fallback_count, ray_base);
+                       walk_n, fallback_list, fallback_count, ray_base, late ? 1u : 0u);
 }
 
 void launch_postprocess_log(const TraceParams &p, const WalkFid *fidt, const uint4 *hit_log, const uint2 *literal_list,

@@ -218,3 +218,15 @@ def orbit_rays(width: int, height: int, views: int, center=(0.0, 0.0, 0.0), radi
         o, d = pinhole_rays(width, height, eye=eye, lookat=center, fov_y=fov_y)
         os_.append(o); ds_.append(d)
     return np.ascontiguousarray(np.concatenate(os_, 0)), np.ascontiguousarray(np.concatenate(ds_, 0))
+
+
+def mesh_sha256(points, cells) -> str:
+    """Fingerprint (first 16 hex digits of the sha256 of the float32 points + uint32 cells) of a stand-in mesh.  scipy /
+    Qhull may triangulate the same points differently between images, so "the same configuration" is only the same mesh
+    where this agrees: printed by bench.py and by the parity tests beside the tet count."""
+    import hashlib
+
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(points, dtype=np.float32).tobytes())
+    h.update(np.ascontiguousarray(cells).astype(np.uint32).tobytes())
+    return h.hexdigest()[:16]
