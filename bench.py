@@ -155,7 +155,7 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
                                    "fp32 accumulate; same 1e-5 parity tests; not the default"}}
 
 
-def cross_check(reasons, stride=64):
+def cross_check(reasons, stride=256):
     return {"stride": stride, "checked": int(reasons.get("15", 0)), "mismatches": int(reasons.get("14", 0))}
 
 
@@ -545,7 +545,7 @@ def main():
             },
             "trace_path_stats": stats,
             "walk_hand_over_reasons": reasons,
-            # the always-on sampled cross-check of the walk's certification (count-only BVH traversal of every 64th ray,
+            # the always-on sampled cross-check of the walk's certification (count-only BVH traversal of every 256th ray,
             # beside the writer and the fill): `mismatches` must be 0
             "certification_cross_check": cross_check(reasons),
             "load_tetrahedra_s": load_s,

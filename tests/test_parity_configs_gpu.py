@@ -71,11 +71,11 @@ def _trace(tr, device, o, d, M):
 
 
 def _cross_check_clean(tr, num_rays, ctx):
-    """The always-on sampled cross-check of the walk's certification (tracer option verify_stride, default 64: a count-only
-    BVH all-hits traversal of every 64th ray, beside the writer and the fill): it ran, and it never disagreed."""
+    """The always-on sampled cross-check of the walk's certification (tracer option verify_stride, default 256: a count-only
+    BVH all-hits traversal of every 256th ray, beside the writer and the fill): it ran, and it never disagreed."""
     why = tr.flag_reasons()
     assert why.get(14, 0) == 0, (ctx, why)
-    assert why.get(15, 0) > 0.5 * num_rays / 64, (ctx, why)     # (literal / fallback rays among the sampled ones are skipped)
+    assert why.get(15, 0) > 0.5 * num_rays / 256, (ctx, why)    # (literal / fallback rays among the sampled ones are skipped)
 
 
 def _mesh(scenes, n_points, seed, ctx):

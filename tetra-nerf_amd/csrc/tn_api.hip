@@ -43,9 +43,11 @@ struct tn_tracer {
     unsigned lds_cap = 0;                // 0: from the mesh size; otherwise the entries of the small arrays (power of two; tests)
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
     // every stride-th certified ray is cross-checked against a count-only BVH all-hits traversal (0: off).  On by default:
-    // the walk's certification has an unproved residue, and the check costs < 1 % of a frame because a
-    // one-chunk call runs it on the aux stream beside the writer and the fill (profiles/r04c_verify_ab.txt)
-    unsigned verify_stride = 64;
+    // the walk's certification has an unproved residue, and a one-chunk call runs the check on the aux
+    // stream beside the writer and the fill.  Measured (profiles/r04c_verify_ab.txt, interleaved in one process): stride 64
+    // costs +0.9 / +2.9 / +3.7 % on the C2 / C4 frame / the C5 rays, stride 16 +6 / +13 / +21 % -- linear in the rays
+    // checked -- so the default is 256: +0.2 / +0.7 / +0.9 %
+    unsigned verify_stride = 256;
     tn::DevBuf<uint32_t> verify_list;    // certified rays whose count differed: re-traced by the BVH kernel at the end of the call
     tn::DevBuf<tn::WalkVar> vars;        // the build's 64-byte records: split into the three tables below, then released
     tn::DevBuf<tn::WalkHot> hot;
