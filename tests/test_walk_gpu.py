@@ -185,6 +185,43 @@ def test_literal_pairing_of_the_log_equals_bvh_fallback(tn, device, oracle, scen
         assert _bits_equal(a[k][:30000], want[k]), k
 
 
+def test_writer_tables_agree(tn, device, scenes, bottle):
+    """The segment writer reads one record per (tet, entry face) on meshes whose table the L2s hold and one per TET on
+    larger ones (tn_common.h: WalkCold / WalkTet; option writer_table forces either): the same rows bit for bit -- also
+    with compact rows and on the reference's bottle (375 zero-volume tets) -- and the same re-assembled build records."""
+    import torch
+
+    meshes = [("random", scenes.random_mesh(5000, 21)), ("bottle", (bottle["vertices"], bottle["cells"])),
+              ("lattice", scenes.grid_mesh(9, 0.0)), ("near-duplicates", scenes.near_duplicates_mesh(2000, 1e-7))]
+    for name, (pts, cells) in meshes:
+        lo, hi = pts.min(0), pts.max(0)
+        o, d = scenes.outside_in_rays(30000, 17)            # for the unit cube: mapped onto the mesh's bounding box
+        t = o + d
+        o, t = lo + (hi - lo) * o, lo + (hi - lo) * t
+        d = t - o
+        o, d = o.astype(np.float32), (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        to, td = torch.from_numpy(np.ascontiguousarray(o)).to(device), torch.from_numpy(np.ascontiguousarray(d)).to(device)
+        outs, tables = [], []
+        for table in (1, 2):
+            tr = tn.TetrahedraTracer(device)
+            tr.set_option("walk", 2)
+            tr.set_option("writer_table", table)
+            tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+            outs.append((tr.trace_rays(to, td, 256), tr.trace_rays(to, td, 256, compact_rows=True)))
+            tables.append(tr.build_table(2))
+            assert tr.trace_stats()["walk"] > 0.5 * len(o), (name, tr.trace_stats())
+        assert torch.equal(tables[0], tables[1]), name
+        for k in KEYS:
+            assert torch.equal(outs[0][0][k].view(torch.int32), outs[1][0][k].view(torch.int32)), (name, k)
+        n = outs[0][1]["num_visited_cells"]
+        assert torch.equal(n, outs[1][1]["num_visited_cells"]) and torch.equal(n, outs[0][0]["num_visited_cells"])
+        valid = torch.arange(256, device=device)[None] < n[:, None]
+        for k in KEYS[1:]:
+            a, b, c = outs[0][1][k], outs[1][1][k], outs[0][0][k]
+            m = valid.reshape(valid.shape + (1,) * (a.dim() - 2)).expand_as(a)
+            assert torch.equal(a[m].view(torch.int32), b[m].view(torch.int32)) and torch.equal(a[m].view(torch.int32), c[m].view(torch.int32)), (name, k)
+
+
 def test_chunked_log_equals_single_launch(tn, device, scenes):
     """Calls whose hit log would exceed the cap are walked and written in ray chunks: same bits."""
     pts, cells = scenes.random_mesh(6000, 13)

@@ -8,8 +8,11 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+import os
+
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libtetranerf_hip.so"
+# TETRANERF_HIP_LIB: another build of the same library (profiling: interleaved A/B runs of two builds on one box)
+LIB_PATH = Path(os.environ["TETRANERF_HIP_LIB"]).resolve() if os.environ.get("TETRANERF_HIP_LIB") else _HERE / "libtetranerf_hip.so"
 
 # every symbol include/tetranerf_hip.h declares
 SYMBOLS = (

@@ -52,6 +52,8 @@ struct tn_tracer {
     tn::DevBuf<tn::WalkVar> vars;        // the build's 64-byte records: split into the three tables below, then released
     tn::DevBuf<tn::WalkHot> hot;
     tn::DevBuf<tn::WalkCold> cold;
+    tn::DevBuf<tn::WalkTet> tets;
+    int writer_table = 0;                // 0: by mesh size (WALK_TET_MIN_TETS), 1: per (tet, entry face), 2: per tet (tests, A/B)
     tn::DevBuf<tn::WalkFid> fidt;
     tn::DevBuf<float> hull_nodes, hull_tris;
     tn::DevWideBvh bvh;
@@ -235,14 +237,18 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
         m.V = (uint32_t)V; m.T = (uint32_t)T; m.F = (uint32_t)F;
         m.faces = t->faces.p; m.face_tets = t->face_tets.p;
         m.bvh = t->bvh.view;
-        {   // de-interleave the records by consumer (tn_common.h: WalkHot / WalkCold / WalkFid)
+        {   // de-interleave the records by consumer (tn_common.h: WalkHot / WalkTet / WalkFid)
             const size_t n4 = t->vars.n;
-            t->hot.alloc(n4); t->cold.alloc(n4); t->fidt.alloc(n4);
-            tn::launch_split_walk_records(n4, t->vars.p, t->hot.p, t->cold.p, t->fidt.p, stream);
+            const bool per_tet = t->writer_table ? t->writer_table == 2 : n4 / 4 >= tn::WALK_TET_MIN_TETS;
+            t->hot.alloc(n4); t->fidt.alloc(n4);
+            t->cold.release(); t->tets.release();
+            if (per_tet) t->tets.alloc(n4 / 4); else t->cold.alloc(n4);
+            tn::launch_split_walk_records(n4, t->vars.p, t->hot.p, per_tet ? nullptr : t->cold.p, per_tet ? t->tets.p : nullptr,
+                                          t->fidt.p, stream);
             TN_HIP(hipStreamSynchronize(stream));
             t->vars.release();
         }
-        m.hot = t->hot.p; m.cold = t->cold.p; m.fidt = t->fidt.p; m.n_hull = (uint32_t)n_hull;
+        m.hot = t->hot.p; m.cold = t->cold.n ? t->cold.p : nullptr; m.tets = t->tets.n ? t->tets.p : nullptr; m.fidt = t->fidt.p; m.n_hull = (uint32_t)n_hull;
         m.hull_nodes = reinterpret_cast<const float4 *>(t->hull_nodes.p);
         m.hull_tris = reinterpret_cast<const float4 *>(t->hull_tris.p);
         m.n_hull_nodes = (uint32_t)n_hull_nodes;
@@ -289,16 +295,19 @@ int tn_get_build_table(tn_tracer_t tracer, int which, void *dst, size_t *bytes) 
                 n = n4 * sizeof(tn::WalkVar);
                 if (bytes) *bytes = n;
                 if (dst && n4) {
-                    std::vector<tn::WalkHot> h(n4); std::vector<tn::WalkCold> c(n4); std::vector<tn::WalkFid> f(n4);
+                    std::vector<tn::WalkHot> h(n4); std::vector<tn::WalkTet> c(t->tets.n); std::vector<tn::WalkCold> cc(t->cold.n);
+                    std::vector<tn::WalkFid> f(n4);
                     TN_HIP(hipMemcpy(h.data(), t->hot.p, n4 * sizeof(tn::WalkHot), hipMemcpyDeviceToHost));
-                    TN_HIP(hipMemcpy(c.data(), t->cold.p, n4 * sizeof(tn::WalkCold), hipMemcpyDeviceToHost));
+                    if (!c.empty()) TN_HIP(hipMemcpy(c.data(), t->tets.p, c.size() * sizeof(tn::WalkTet), hipMemcpyDeviceToHost));
+                    if (!cc.empty()) TN_HIP(hipMemcpy(cc.data(), t->cold.p, cc.size() * sizeof(tn::WalkCold), hipMemcpyDeviceToHost));
                     TN_HIP(hipMemcpy(f.data(), t->fidt.p, n4 * sizeof(tn::WalkFid), hipMemcpyDeviceToHost));
                     tn::WalkVar *o = static_cast<tn::WalkVar *>(dst);
                     for (size_t i = 0; i < n4; ++i) {
                         tn::WalkVar v{};
                         for (int k = 0; k < 3; ++k) v.pn[k] = h[i].pn[k];
                         v.nb[0] = h[i].nb0; v.nb[1] = h[i].nb1; v.nb[2] = h[i].nb2; v.code_lo = h[i].code_lo; v.code_hi = h[i].code_hi;
-                        v.orig = c[i].orig; for (int k = 0; k < 4; ++k) v.vid[k] = c[i].vid[k];
+                        if (!c.empty()) { v.orig = c[i >> 2].orig; for (uint32_t k = 0; k < 4; ++k) v.vid[k] = c[i >> 2].vid((uint32_t)(i & 3), k); }
+                        else { v.orig = cc[i].orig; for (int k = 0; k < 4; ++k) v.vid[k] = cc[i].vid[k]; }
                         v.fid0 = f[i].fid[0]; v.fid1 = f[i].fid[1]; v.fid2 = f[i].fid[2];
                         o[i] = v;
                     }
@@ -411,7 +420,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 q.num_rays = n; q.M = M; q.dense_tails = dense_tails ? 1u : 0u;
                 q.walk_n = t->walk_n.p + base;
                 q.hit_log = t->hit_log.p;
-                q.vars = t->mesh.cold;
+                q.cold = t->mesh.cold; q.tets = t->mesh.tets;
                 q.out_cells = visited + base * M;
                 q.out_bary = bary + base * M * 6;
                 q.out_dist = dist + base * M * 2;
@@ -672,6 +681,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
             if (value < 0 || (value & (value - 1)) != 0 || (value && value < 8)) throw tn::Error("lds_cap must be 0 or a power of two >= 8");
             t->lds_cap = (unsigned)value;
         }
+        else if (k == "writer_table") t->writer_table = value;   // applies at the next load_tetrahedra
         else if (k == "verify_stride") t->verify_stride = value < 0 ? 0u : (unsigned)value;
         else if (k == "log_cap_mb") t->log_cap_bytes = value <= 0 ? 0 : (size_t)value << 20;
         else throw tn::Error("unknown option " + (name ? k : std::string("(null)")));

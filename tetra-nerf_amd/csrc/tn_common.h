@@ -120,12 +120,41 @@ static_assert(sizeof(WalkVar) == 64, "WalkVar must be 64 bytes");
 // random accesses fetch only bytes it uses (round 3: the walk read 48 and the segment writer 32 of every 64-byte record,
 // i.e. 37 % / 25 % of each 128-byte line; the tables are 2x / 2x / 4x smaller than the combined one for the XCD's 4 MiB L2):
 //   WalkHot  [4T] 32 B  walk:            position of n, the three neighbour variants, the 36-bit code + thin exponent
-//   WalkCold [4T] 32 B  segment writer:  vertex ids (n, a, b, c), the caller's tet id, the combine code of the 3 exits
+//   WalkCold [4T] 32 B  segment writer, meshes whose table fits the L2s (up to WALK_TET_MIN_TETS tets): vertex ids
+//                       (n, a, b, c), the caller's tet id, the combine code of the 3 exits -- nothing to derive per segment
+//   WalkTet  [T]  32 B  segment writer, larger meshes (round 4): ONE record per tet -- a quarter of the table, four
+//                       Morton-neighbouring tets per 128-byte line instead of one.  The tet's vertex ids in tet-local
+//                       order, the caller's tet id, and per entry face e what WalkCold bakes into the record of (tet, e):
+//                       the local indices of its a / b / c (6 bits at 6e of `perm`; n = local vertex e) and the combine code
+//                       of its three exits (18 bits at 18e of the 72-bit field cmb_lo | cmb_hi << 32 | perm[31:24] << 64);
+//                       the writer derives (n, a, b, c) and the code per segment (~40 VALU instructions).  Measured on one
+//                       box, interleaved (profiles/r04d_lib_ab.txt): 2^20 incoherent rays on 1M tets 18.96 -> 16.94 ms
+//                       (-10.7 %: the per-entry table is 129 MB there and every hit fetched a 64-byte sector beyond the L2
+//                       for 32 bytes), but +3 % on the 100k / 300k frames, whose tables the L2s hold -- hence both.
+//                       The log entry names (tet, e, exit) either way.
 //   WalkFid  [4T] 16 B  literal pairing: face id of exit 0 / 1 / 2 (total order (t, face id) of the sort)
 struct alignas(32) WalkHot { float pn[3]; uint32_t nb0; uint32_t nb1, nb2, code_lo, code_hi; };
 struct alignas(32) WalkCold { uint32_t vid[4]; uint32_t orig, cmb, pad0, pad1; };   // cmb: per exit x 6 bits at 6x (c0 c1 c2)
+constexpr uint32_t WALK_TET_MIN_TETS = 500000;   // from here on the writer reads the per-tet table (see above)
+struct alignas(32) WalkTet {
+    uint32_t vert[4]; uint32_t orig, perm, cmb_lo, cmb_hi;
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t cmb(uint32_t e) const {   // per exit x of entry face e: 6 bits at 6x (c0 c1 c2: position of a / b / c in the exit face's stored order)
+        const unsigned long long lo64 = (unsigned long long)cmb_lo | ((unsigned long long)cmb_hi << 32);
+        const uint32_t v = e == 3u ? ((uint32_t)(lo64 >> 54) | ((perm >> 24) << 10)) : (uint32_t)(lo64 >> (18u * e));
+        return v & 0x3FFFFu;
+    }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t vid(uint32_t e, uint32_t m) const {   // vertex ids (n, a, b, c) of a segment entered through face e, m = 0..3
+        return m == 0 ? vert[e & 3u] : vert[(perm >> (6u * e + 2u * (m - 1u))) & 3u];
+    }
+};
 struct alignas(16) WalkFid { uint32_t fid[3]; uint32_t pad; };
-static_assert(sizeof(WalkHot) == 32 && sizeof(WalkCold) == 32 && sizeof(WalkFid) == 16, "split walk records");
+static_assert(sizeof(WalkHot) == 32 && sizeof(WalkCold) == 32 && sizeof(WalkTet) == 32 && sizeof(WalkFid) == 16, "split walk records");
 
 struct DeviceMesh {
     const float *xyz = nullptr;       // borrowed [V,3]
@@ -136,7 +165,8 @@ struct DeviceMesh {
     WideBvh bvh{};                  // over all faces
     // adjacency walk
     const WalkHot *hot = nullptr;   // [4T] entry-face-specialised records, split by consumer (see WalkHot)
-    const WalkCold *cold = nullptr;
+    const WalkCold *cold = nullptr; // [4T] the writer's table of meshes below WALK_TET_MIN_TETS tets, else null
+    const WalkTet *tets = nullptr;  // [T] one record per tet (see WalkTet), else null
     const WalkFid *fidt = nullptr;
     const float4 *hull_nodes = nullptr;  // threaded binary BVH over the hull faces (2 float4 per node)
     const float4 *hull_tris = nullptr;   // 3 float4 per hull face

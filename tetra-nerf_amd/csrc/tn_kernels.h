@@ -36,7 +36,8 @@ void launch_find_tetrahedra(const TraceParams &p, const float *points, uint32_t 
                             uint32_t *out_verts, hipStream_t stream);
 
 // de-interleaves the 64-byte build records into the three consumer tables (tn_trace_walk.hip)
-void launch_split_walk_records(size_t n4, const WalkVar *vars, WalkHot *hot, WalkCold *cold, WalkFid *fidt, hipStream_t stream);
+// exactly one of cold / tets is non-null (tn_common.h: WALK_TET_MIN_TETS)
+void launch_split_walk_records(size_t n4, const WalkVar *vars, WalkHot *hot, WalkCold *cold, WalkTet *tets, WalkFid *fidt, hipStream_t stream);
 
 // adjacency walk, one lane per ray (tn_trace_walk.hip)
 struct WalkParams {
@@ -77,7 +78,8 @@ struct WriteParams {
     uint32_t dense_tails;      // 0: slots >= num_visited are left unwritten (non-reference option)
     const uint32_t *walk_n;    // hits in the log; TN_EMPTY: the row belongs to the literal / BVH kernels
     const uint4 *hit_log;
-    const WalkCold *vars;      // the segment writer's 32 bytes of the walk records
+    const WalkCold *cold;      // the segment writer's table: one 32-byte record per (tet, entry face) ...
+    const WalkTet *tets;       // ... or per tet (exactly one of the two is non-null)
     uint32_t *out_cells;
     float *out_bary;
     float *out_dist;

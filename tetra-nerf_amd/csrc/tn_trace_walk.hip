@@ -131,6 +131,11 @@ __device__ __forceinline__ Var load_var(const WalkHot *vars, uint32_t c) {   // 
     v.nb1 = q1.x; v.nb2 = q1.y; v.code_lo = q1.z; v.code_hi = q1.w;
     return v;
 }
+__device__ __forceinline__ uint32_t sel4u(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t i) {
+    const bool b0 = (i & 1u) != 0, b1 = (i & 2u) != 0;
+    const uint32_t lo = b0 ? b : a, hi = b0 ? d : c;
+    return b1 ? hi : lo;
+}
 __device__ __forceinline__ uint32_t sel3u(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t i) {  // i in 0..2 (3 -> v2)
     const bool b0 = (i & 1u) != 0, b1 = (i & 2u) != 0;
     const uint32_t lo = b0 ? v1 : v0;
@@ -388,8 +393,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
 // 8 full 128-byte lines of the log (entries of neighbouring rays are neighbours in the log).  For a certified ray
 // (header of this file) hits k-1 and k bound the tet recorded with hit k, and the pair is a segment unless it is
 // shorter than eps; emitted slots are numbered by a per-ray prefix count over the wave ballot.  The tet id /
-// vertex ids / combine_indices code come from the writer's 32-byte record of (tet, entry face) (WalkCold), two 16-byte
-// quads of one sector; bary_out is selected exactly as combine_indices does (optix_trace_rays.cu:39-75).  The slots between the
+// vertex ids / combine_indices code come from the writer's 32-byte record -- of (tet, entry face) (WalkCold: ready-made) on
+// meshes whose table the L2s hold, of the TET (WalkTet, round 4: a quarter of the table, (n, a, b, c) and the code derived
+// per segment) on larger ones (tn_common.h) -- two 16-byte quads; bary_out is selected exactly as combine_indices does (optix_trace_rays.cu:39-75).  The slots between the
 // last segment and the next multiple of 32 (where all four row arrays are on a 128-byte line boundary) get their
 // tail constants here, so that k_fill_range starts every row on a line boundary and no line is written by two kernels.
 //
@@ -432,7 +438,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 }  // namespace
 
-template <int U>
+template <int U, bool PER_TET>
 __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
     using W = SW<U>;
     __shared__ __attribute__((aligned(16))) uint32_t smem[4 * W::TOTAL];
@@ -521,15 +527,17 @@ __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
                 nseg += (uint32_t)__popcll(m);
             }
             if (any) {   // wave-uniform
-                // ---- the writer's records of the emitted segments (WalkCold, one 32-byte sector): vertex ids | tet id, combine code
+                // ---- the writer's records of the emitted segments (32 bytes: WalkCold or WalkTet): vertex ids | tet id, codes
                 uint4 qa[U], qv[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     qa[u] = make_uint4(0u, 0u, 0u, 0u); qv[u] = qa[u];
                     if (slot[u] != TN_EMPTY) {
-                        const uint32_t *rec = reinterpret_cast<const uint32_t *>(q.vars + (e[u].w & 0x3FFFFFFFu));
-                        qv[u] = *reinterpret_cast<const uint4 *>(rec);
-                        qa[u] = *reinterpret_cast<const uint4 *>(rec + 4);
+                        const uint32_t c = e[u].w & 0x3FFFFFFFu;
+                        const uint32_t *rec = PER_TET ? reinterpret_cast<const uint32_t *>(q.tets + (c >> 2))
+                                                      : reinterpret_cast<const uint32_t *>(q.cold + c);
+                        qv[u] = *reinterpret_cast<const uint4 *>(rec);       // PER_TET: vert[4]; else (n, a, b, c)
+                        qa[u] = *reinterpret_cast<const uint4 *>(rec + 4);   // PER_TET: orig, perm, cmb_lo, cmb_hi; else orig, cmb
                     }
                 }
                 // ---- segment records -> LDS [array][ray][slot]
@@ -537,8 +545,21 @@ __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
                 for (int u = 0; u < U; ++u) {
                     if (slot[u] != TN_EMPTY) {
                         const uint32_t at = a * W::STRIDE + slot[u];
-                        const uint32_t x = e[u].w >> 30;
-                        const uint32_t cmb = qa[u].y >> (6u * x);     // position of a / b / c in the exit face's stored order
+                        const uint32_t x = e[u].w >> 30, ent = e[u].w & 3u;
+                        uint32_t cmb;        // position of a / b / c in the exit face's stored order
+                        uint4 vids = qv[u];  // (n, a, b, c)
+                        if constexpr (PER_TET) {
+                            // what the record of (tet, entry face) holds ready-made, derived from the tet's record
+                            const unsigned long long lo64 = (unsigned long long)qa[u].z | ((unsigned long long)qa[u].w << 32);
+                            const uint32_t c18 = ent == 3u ? ((uint32_t)(lo64 >> 54) | ((qa[u].y >> 24) << 10)) : (uint32_t)(lo64 >> (18u * ent));
+                            cmb = c18 >> (6u * x);
+                            const uint32_t pm = qa[u].y >> (6u * ent);
+                            vids = make_uint4(sel4u(qv[u].x, qv[u].y, qv[u].z, qv[u].w, ent), sel4u(qv[u].x, qv[u].y, qv[u].z, qv[u].w, pm & 3u),
+                                              sel4u(qv[u].x, qv[u].y, qv[u].z, qv[u].w, (pm >> 2) & 3u),
+                                              sel4u(qv[u].x, qv[u].y, qv[u].z, qv[u].w, (pm >> 4) & 3u));
+                        } else {
+                            cmb = qa[u].y >> (6u * x);
+                        }
                         const float pt = __uint_as_float(pe[u].x), pu = __uint_as_float(pe[u].y), pv = __uint_as_float(pe[u].z);
                         const float ct = __uint_as_float(e[u].x), cu = __uint_as_float(e[u].y), cv = __uint_as_float(e[u].z);
                         const float r0f = 1.0f - cu - cv;
@@ -549,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
                         bp[0] = make_float2(1.0f - pu - pv, pu);
                         bp[1] = make_float2(pv, sel4f(r0f, cu, cv, 0.f, k0));
                         bp[2] = make_float2(sel4f(r0f, cu, cv, 0.f, k1), sel4f(r0f, cu, cv, 0.f, k2));
-                        *reinterpret_cast<uint4 *>(L + W::VERTS + 4 * at) = qv[u];   // (n, a, b, c)
+                        *reinterpret_cast<uint4 *>(L + W::VERTS + 4 * at) = vids;   // (n, a, b, c)
                     }
                 }
                 if (h == 0) *reinterpret_cast<uint2 *>(L + W::META + 2 * a) = make_uint2(nseg - base, base);
@@ -610,7 +631,8 @@ void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned ma
     // grid = what is resident at once (2 blocks per CU at 192 VGPRs): the groups are dealt round-robin over it
     const size_t cap = max_blocks ? max_blocks : (size_t)256 * 2;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_write_segments<4>, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    if (q.tets) hipLaunchKernelGGL((k_write_segments<4, true>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    else hipLaunchKernelGGL((k_write_segments<4, false>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
 }
 
 // Constant tails: pure streaming stores (16 B per lane, whole 128-byte lines), a contiguous span of rows per wave.
@@ -667,26 +689,58 @@ void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_
 
 // 64-byte build records -> the three consumer tables (tn_common.h: WalkHot / WalkCold / WalkFid)
 __global__ __launch_bounds__(256) void k_split_walk_records(size_t n4, const WalkVar *__restrict__ vars, WalkHot *__restrict__ hot,
-                                                            WalkCold *__restrict__ cold, WalkFid *__restrict__ fidt) {
+                                                            WalkCold *__restrict__ cold, WalkTet *__restrict__ tets,
+                                                            WalkFid *__restrict__ fidt) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const WalkVar v = vars[i];
     WalkHot h;
     h.pn[0] = v.pn[0]; h.pn[1] = v.pn[1]; h.pn[2] = v.pn[2];
     h.nb0 = v.nb[0]; h.nb1 = v.nb[1]; h.nb2 = v.nb[2]; h.code_lo = v.code_lo; h.code_hi = v.code_hi;
-    WalkCold c;
-    for (int k = 0; k < 4; ++k) c.vid[k] = v.vid[k];
-    c.orig = v.orig;
-    const unsigned long long code = (unsigned long long)v.code_lo | ((unsigned long long)(v.code_hi & 0xFu) << 32);
-    c.cmb = (uint32_t)((code >> 6) & 63u) | ((uint32_t)((code >> 18) & 63u) << 6) | ((uint32_t)((code >> 30) & 63u) << 12);
-    c.pad0 = 0; c.pad1 = 0;
     WalkFid f;
     f.fid[0] = v.fid0; f.fid[1] = v.fid1; f.fid[2] = v.fid2; f.pad = 0;
-    hot[i] = h; cold[i] = c; fidt[i] = f;
+    hot[i] = h; fidt[i] = f;
+    if (cold) {
+        WalkCold c;
+        for (int k = 0; k < 4; ++k) c.vid[k] = v.vid[k];
+        c.orig = v.orig;
+        const unsigned long long code = (unsigned long long)v.code_lo | ((unsigned long long)(v.code_hi & 0xFu) << 32);
+        c.cmb = (uint32_t)((code >> 6) & 63u) | ((uint32_t)((code >> 18) & 63u) << 6) | ((uint32_t)((code >> 30) & 63u) << 12);
+        c.pad0 = 0; c.pad1 = 0;
+        cold[i] = c;
+    }
+    if (tets && (i & 3u) == 0) {
+        // the tet's record from its four entry-face records: vert[e] = the vertex opposite face e (vid[0] of record e); the
+        // local index of a / b / c of entry e = any j with vert[j] == vid[m] (a degenerate tet may list a vertex twice: either
+        // index names the same vertex id, and only ids are ever read through it)
+        WalkTet tt;
+        WalkVar w[4];
+        w[0] = v; w[1] = vars[i + 1]; w[2] = vars[i + 2]; w[3] = vars[i + 3];
+        for (int e = 0; e < 4; ++e) tt.vert[e] = w[e].vid[0];
+        tt.orig = v.orig;
+        uint32_t perm = 0;
+        unsigned long long lo64 = 0;
+        uint32_t top = 0;
+        for (uint32_t e = 0; e < 4; ++e) {
+            for (uint32_t m = 0; m < 3; ++m) {
+                uint32_t j = 0;
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (tt.vert[3 - k] == w[e].vid[m + 1]) j = 3 - k;   // first match wins
+                perm |= j << (6 * e + 2 * m);
+            }
+            const unsigned long long code = (unsigned long long)w[e].code_lo | ((unsigned long long)(w[e].code_hi & 0xFu) << 32);
+            const unsigned long long c18 = ((code >> 6) & 63ull) | (((code >> 18) & 63ull) << 6) | (((code >> 30) & 63ull) << 12);
+            if (e < 3) lo64 |= c18 << (18 * e);
+            else { lo64 |= c18 << 54; top = (uint32_t)(c18 >> 10); }
+        }
+        tt.perm = perm | (top << 24);
+        tt.cmb_lo = (uint32_t)lo64; tt.cmb_hi = (uint32_t)(lo64 >> 32);
+        tets[i >> 2] = tt;
+    }
 }
-void launch_split_walk_records(size_t n4, const WalkVar *vars, WalkHot *hot, WalkCold *cold, WalkFid *fidt, hipStream_t stream) {
+void launch_split_walk_records(size_t n4, const WalkVar *vars, WalkHot *hot, WalkCold *cold, WalkTet *tets, WalkFid *fidt, hipStream_t stream) {
     if (n4 == 0) return;
-    hipLaunchKernelGGL(k_split_walk_records, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, n4, vars, hot, cold, fidt);
+    hipLaunchKernelGGL(k_split_walk_records, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, n4, vars, hot, cold, tets, fidt);
 }
 
 void launch_trace_walk(const WalkParams &p, hipStream_t stream) {

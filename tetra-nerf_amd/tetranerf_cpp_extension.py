@@ -787,7 +787,13 @@ def mlp_backward(saved, vertex_indices, barycentric_coordinates, field, dirs, we
     d_rgb = d_rgb.reshape(n, 3).contiguous().float()
     dirs = dirs.contiguous()
     lib = _lib.load()
-    grads = [torch.zeros(tuple(w.shape), dtype=torch.float32, device=dev) for w in keep]
+    # the twelve gradients as views of ONE zero-filled buffer (tn_mlp_param_grads accumulates): one fill launch, not twelve
+    sizes = [w.numel() for w in keep]
+    offs = [0]
+    for k in sizes:
+        offs.append(offs[-1] + (k + 3) // 4 * 4)       # 16-byte aligned pieces
+    flat = torch.zeros((offs[-1],), dtype=torch.float32, device=dev)
+    grads = [flat[o:o + k].view(tuple(w.shape)) for o, k, w in zip(offs, sizes, keep)]
     gs = _MlpWeightsStruct(*[g.data_ptr() for g in grads])
     grad_vm = torch.zeros((V, 64), dtype=torch.float32, device=dev)
     a = saved.acts
