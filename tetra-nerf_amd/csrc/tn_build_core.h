@@ -329,6 +329,13 @@ TN_HD WalkVar walk_var_of(uint32_t r, uint32_t e, const uint32_t *order, const u
 // bound of min h over the tets around its most suspicious edge (the ring of edge (a,b) lies in star(a) and star(b)).
 // Stored as the float's exponent byte (floor(log2) + 127) in bits 8..15 of WalkVar::code_hi; 0 = degenerate.
 TN_HD uint32_t tet_min_height_bits(const float p[4][3]) {
+    // The exponent byte of this value is compared across the host build, the device build and the CPU emulation (byte-equal
+    // walk records), so every product below must round once on all of them: the library is built with -ffp-contract=off;
+    // the pragma pins it for any other translation unit that includes this header (clang honours it per block, gcc's
+    // default for ISO C++ is already "off")
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     double q[4][3];
     for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) q[i][a] = (double)p[i][a];
     auto cross = [](const double *u, const double *v, double *w) {

@@ -322,7 +322,14 @@ def register_field(field):
 
     hit = _FIELD_VM.get(id(field))
     if hit is None or hit[0]() is not field:      # (a dead entry whose id() was reused is replaced)
-        _FIELD_VM[id(field)] = (weakref.ref(field), None, None, None, None)
+        key = id(field)
+
+        def _drop(ref, key=key):                  # the field died: its [V,64] shadow (V * 256 bytes of HBM) goes with it
+            cur = _FIELD_VM.get(key)
+            if cur is not None and cur[0] is ref:
+                del _FIELD_VM[key]
+
+        _FIELD_VM[key] = (weakref.ref(field, _drop), None, None, None, None)
     return field
 
 
@@ -483,6 +490,8 @@ class FusedMLP:
         key = tuple((w._version, w.data_ptr()) for w in weights)
         if (not force and self._key is not None and key == self._key[0]
                 and all(r() is w for r, w in zip(self._key[1], weights))):
+            # the packs were made on the stream that was current then: a consumer on another stream waits for them
+            torch.cuda.current_stream(self.device).wait_event(self._packed)
             return self
         st = _MlpWeightsStruct()
         keep = []
@@ -496,6 +505,8 @@ class FusedMLP:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.tn_mlp_set_weights(self._h, C.byref(st), _stream(self.device)))
         del keep
+        self._packed = torch.cuda.Event()
+        self._packed.record(torch.cuda.current_stream(self.device))
         self._key = (key, [weakref.ref(w) for w in weights])
         return self
 
@@ -504,21 +515,37 @@ class FusedMLP:
         return self._h
 
 
-_DEFAULT_MLP = {}    # device -> FusedMLP used by the module-level functions below
+_DEFAULT_MLP = {}    # id(first weight tensor) -> (weakref to it, FusedMLP): one handle (packed weights + scratch) per MODEL
+_MAX_HANDLES = 8     # (each holds ~1.5 MB of packs + 42 MB of gradient scratch once it has been trained with)
 
 
 def fused_mlp(weights) -> FusedMLP:
-    """The per-device default handle, synchronised with `weights` (re-packed only when they changed)."""
-    dev = weights[0].device
-    m = _DEFAULT_MLP.get(dev)
-    if m is None:
-        m = _DEFAULT_MLP[dev] = FusedMLP(dev)
-    return m.sync(weights)
+    """The handle of this weight set, synchronised with `weights` (re-packed only when they changed).  Handles are keyed
+    by the identity of the first weight tensor, so two models alternating on a device each keep their packs (a single
+    per-device handle re-packed four weight forms on every switch); a handle dies with its model, the oldest one is
+    dropped beyond _MAX_HANDLES.  Single-stream contract per handle: set_weights and the kernels are enqueued on the
+    caller's current stream; a call from another stream waits for the packing event (FusedMLP.sync), but two streams
+    must not run kernels of ONE handle concurrently (they share its per-call scratch)."""
+    import weakref
+
+    w0 = weights[0]
+    key = id(w0)
+    hit = _DEFAULT_MLP.get(key)
+    if hit is None or hit[0]() is not w0:
+        def _drop(ref, key=key):
+            cur = _DEFAULT_MLP.get(key)
+            if cur is not None and cur[0] is ref:
+                del _DEFAULT_MLP[key]
+
+        while len(_DEFAULT_MLP) >= _MAX_HANDLES:
+            _DEFAULT_MLP.pop(next(iter(_DEFAULT_MLP)))
+        hit = _DEFAULT_MLP[key] = (weakref.ref(w0, _drop), FusedMLP(w0.device))
+    return hit[1].sync(weights)
 
 
 def invalidate_weight_cache():
     """Needed only after writing MLP parameters through `.data` / a raw pointer."""
-    for m in _DEFAULT_MLP.values():
+    for _, m in _DEFAULT_MLP.values():
         m.invalidate()
 
 
