@@ -39,6 +39,14 @@ struct tn_tracer {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_start = nullptr, ev_pre = nullptr, ev_seg = nullptr, ev_aux = nullptr;
     int spec_fill = 1;                   // 1: the last quarter of every row is filled beside the walk where that is mesh-safe; 0 off
     unsigned spec_k0 = 0;                // override of the first speculatively filled slot (multiple of 32; tests)
+    // Round 4: the speculative fill used to be launched with 2048 blocks = 32 waves per CU -- every wave slot of the chip --
+    // in front of a walk that wants all 32 slots itself (64 VGPRs): the kernels shared the time instead of overlapping.  Now
+    // the fill holds 2 blocks = 8 waves per CU (enough for the write ceiling) and the walk is limited to 6 blocks = 24 waves
+    // per CU by a 26 KB dynamic-LDS reservation while a fill runs beside it, so both are resident for the walk's whole
+    // duration: -3.1 % on the C2 frame, -4.9 % on the C4 frame (interleaved sweep on one box, profiles/r04f_overlap_sweep.txt;
+    // 7 or 5 walk blocks, 1 or 4 fill blocks per CU are all worse).  Options for sweeps:
+    unsigned spec_blocks = 512;          // grid of the speculative fill
+    unsigned walk_lds_kb = 26;           // dynamic LDS reserved per walk block beside a speculative fill (0: no limit)
     bool small_lds = true;               // small batches: LDS hit arrays sized for the mesh, overflow rays in a second launch
     unsigned lds_cap = 0;                // 0: from the mesh size; otherwise the entries of the small arrays (power of two; tests)
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
@@ -396,6 +404,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 return make_params(t, n, M, origins + 3 * base, directions + 3 * base, num_visited + base, visited + base * M,
                                    bary + base * M * 6, dist + base * M * 2, verts ? verts + base * M * 4 : nullptr);
             };
+            size_t walk_reserve = 0;     // set by the one-chunk schedule when a speculative fill runs beside the walk
             auto launch_walk = [&](size_t base, size_t n) {
                 tn::WalkParams w{};
                 w.t = chunk_params(base, n);
@@ -411,7 +420,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 w.walk_n = t->walk_n.p + base;
                 w.hit_log = t->hit_log.p;
                 w.ray_base = base;
-                tn::launch_trace_walk(w, stream);
+                tn::launch_trace_walk(w, stream, walk_reserve);
                 if (t->verify_stride && !single)   // chunked call: serially, before anything that reads walk_n / the fallback list
                     tn::launch_verify_counts(w.t, t->verify_stride, w.walk_n, w.fallback_list, w.fallback_count, base, stream);
             };
@@ -449,16 +458,20 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 uint32_t K0 = 0;
                 if (t->spec_fill && dense_tails) {
                     K0 = (((uint32_t)(3.6 * std::cbrt((double)std::max<uint32_t>(t->mesh.T, 1u))) + 31u) & ~31u) + 32u;
-                    const uint32_t quarter = (3u * M / 4u) & ~31u;
-                    K0 = K0 <= quarter ? quarter : 0u;
+                    const uint32_t quarter = (3u * M / 4u) & ~31u, half = (M / 2u) & ~31u;
+                    // the longer the walk (the more faces per ray), the more bytes its duration hides: the last quarter of the
+                    // rows on small meshes (C2: 384), the last half where rays reach beyond M/2 - 64 slots (C4: 256 measured
+                    // best, 320 / 384: -3.6 / -0.6 % instead of -4.9 %); a row with more than K0 segments overwrites its slots
+                    K0 = K0 > quarter ? 0u : (K0 + 32u > half ? half : quarter);
                     if (t->spec_k0) K0 = t->spec_k0 & ~31u;
                     if (K0 + 32u > M) K0 = 0;
                 }
                 if (K0) {
                     TN_HIP(hipEventRecord(t->ev_start, stream));
                     TN_HIP(hipStreamWaitEvent(t->pre, t->ev_start, 0));
-                    tn::launch_fill_range(R, M, true, t->walk_n.p, num_visited, visited, bary, dist, verts, t->pre, K0, true);
+                    tn::launch_fill_range(R, M, true, t->walk_n.p, num_visited, visited, bary, dist, verts, t->pre, K0, true, t->spec_blocks);
                     TN_HIP(hipEventRecord(t->ev_pre, t->pre));
+                    walk_reserve = (size_t)t->walk_lds_kb * 1024;
                 }
                 launch_walk(0, R);
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
@@ -676,6 +689,8 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (k == "literal") t->literal = value != 0;
         else if (k == "spec_fill") t->spec_fill = value != 0;
         else if (k == "spec_k0") t->spec_k0 = (unsigned)value;
+        else if (k == "spec_blocks") t->spec_blocks = (unsigned)value;
+        else if (k == "walk_lds_kb") t->walk_lds_kb = (unsigned)value;
         else if (k == "small_lds") t->small_lds = value != 0;
         else if (k == "lds_cap") {
             if (value < 0 || (value & (value - 1)) != 0 || (value && value < 8)) throw tn::Error("lds_cap must be 0 or a power of two >= 8");

@@ -57,7 +57,8 @@ struct WalkParams {
                                // step); exit code 3 = entry hull face, its face id in the low 30 bits
     size_t ray_base;           // global index of item 0 (rays are traced in chunks when the log would be too large)
 };
-void launch_trace_walk(const WalkParams &p, hipStream_t stream);
+// lds_reserve: bytes of (unused) dynamic LDS per block = an occupancy limit (160 KB / lds_reserve blocks per CU), 0 = none
+void launch_trace_walk(const WalkParams &p, hipStream_t stream, size_t lds_reserve = 0);
 // literal sort + pairing of the logged hits of the rays in literal_list (tn_trace_general.hip); rows of launch item i
 // are p.out_*[i] (the TraceParams of the same walk launch)
 void launch_postprocess_log(const TraceParams &p, const WalkFid *fidt, const uint4 *hit_log, const uint2 *literal_list,
@@ -89,7 +90,7 @@ void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned ma
 // all_rows: slots [k_split, M) of every row; otherwise slots [ceil32(out_num[r]), k_split) of the certified rows
 void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *walk_n, const uint32_t *out_num,
                        uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
-                       uint32_t k_split, bool nontemporal);
+                       uint32_t k_split, bool nontemporal, unsigned max_blocks = 0);
 
 // sample -> segment matching (tn_match.hip)
 void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,

@@ -671,13 +671,13 @@ __global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M,
 
 void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *walk_n, const uint32_t *out_num,
                        uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
-                       uint32_t k_split, bool nontemporal) {
+                       uint32_t k_split, bool nontemporal, unsigned max_blocks) {
     if (num_rays == 0) return;
     size_t blocks = (num_rays + 3) / 4;           // >= one ray per wave
     // after the writer: 2 blocks (8 waves) per CU hold the write ceiling, and the latency-bound kernels running beside
     // the fill are less starved than with 8 per CU (profiles/r01_fill_grid.txt); beside the walk: 2048 blocks
     // (profiles/r02p_specfill2.txt)
-    const size_t cap = all_rows ? 2048 : 256 * 2;
+    const size_t cap = max_blocks ? max_blocks : (all_rows ? 2048 : 256 * 2);
     if (blocks > cap) blocks = cap;
     if (nontemporal)
         hipLaunchKernelGGL(k_fill_range<true>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split,
@@ -743,13 +743,14 @@ void launch_split_walk_records(size_t n4, const WalkVar *vars, WalkHot *hot, Wal
     hipLaunchKernelGGL(k_split_walk_records, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, n4, vars, hot, cold, tets, fidt);
 }
 
-void launch_trace_walk(const WalkParams &p, hipStream_t stream) {
+void launch_trace_walk(const WalkParams &p, hipStream_t stream, size_t lds_reserve) {
     if (p.t.num_items == 0) return;
     const uint32_t nblk = (uint32_t)((p.t.num_items + WALK_BLOCK - 1) / WALK_BLOCK);
     // grid padded so that the remap (runs of XCD_GROUP blocks per XCD) is a bijection
     const uint32_t unit = 8 * XCD_GROUP;
     const uint32_t grid = (nblk + unit - 1) / unit * unit;
-    hipLaunchKernelGGL(k_trace_walk, dim3(grid), dim3(WALK_BLOCK), 0, stream, p);
+    if (lds_reserve > 64 * 1024) lds_reserve = 64 * 1024;
+    hipLaunchKernelGGL(k_trace_walk, dim3(grid), dim3(WALK_BLOCK), lds_reserve, stream, p);
 }
 
 }  // namespace tn
