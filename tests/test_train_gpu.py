@@ -224,3 +224,77 @@ def test_training_iterations_do_not_leak(tn, device, scenes):
     finally:
         gc.enable()
     assert after - before < 8 << 20, f"{(after - before) / 2**20:.1f} MiB more allocated after 5 further iterations"
+
+
+def test_render_train_sync_free(tn, device, scenes):
+    """render_train's default form never synchronises the host with the device (torch.cuda.set_sync_debug_mode("error")
+    around forward + backward + an optimiser step): the batch is processed at its full size, hitting rays first, padded
+    entries masked out.  Against the compacting form (torch.nonzero): identical when every ray hits (same draws, same
+    kernels on the same rows); with a third of the rays missing -- and with ALL rays missing -- the outputs of the missing
+    rays are the miss values, the hitting rays' outputs are finite renders, and the gradients are finite (the padded
+    entries contribute exact zeros)."""
+    import torch
+
+    render = importlib.import_module("tetra-nerf_amd.render")
+    pts, cells = scenes.random_mesh(4000, 5)
+    tr = tn.TetrahedraTracer(device)
+    tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+    o, d = scenes.outside_in_rays(1024, 6)
+    for S, S_fine, biased, scaling in ((32, 32, False, False), (24, 24, True, True)):
+        torch.manual_seed(0)
+        mlp = render.TetraMLP().to(device)
+        field = ((torch.rand(64, len(pts), device=device) * 2 - 1) * 0.5).requires_grad_(True)
+        params = [field] + list(mlp.parameters())
+        opt = torch.optim.SGD(params, lr=1e-4)
+        free = render.TetraRenderer(tr, field, mlp, S, 256, fused=True, num_fine_samples=S_fine, biased=biased)
+        sync = render.TetraRenderer(tr, field, mlp, S, 256, fused=True, num_fine_samples=S_fine, biased=biased, sync_free_train=False)
+        assert free.sync_free_train and not sync.sync_free_train
+        for case in ("all hit", "a third misses", "all miss"):
+            dd = d.copy()
+            if case == "a third misses":
+                dd[::3] = -dd[::3]
+            elif case == "all miss":
+                dd = -dd
+            to, td = torch.from_numpy(o).to(device), torch.from_numpy(np.ascontiguousarray(dd)).to(device)
+            target = torch.rand(len(o), 3, device=device)
+
+            def step(rd, guard):
+                opt.zero_grad(set_to_none=True)
+                torch.manual_seed(3)
+                if guard:
+                    torch.cuda.set_sync_debug_mode("error")
+                try:
+                    out = rd.render_train(to, td, gradient_scaling=scaling)
+                    loss = ((out["rgb"] - target) ** 2).mean() + 0.1 * out["accumulation"].mean()
+                    loss.backward()
+                finally:
+                    torch.cuda.set_sync_debug_mode("default")
+                return out, [None if p.grad is None else p.grad.clone() for p in params]
+
+            step(free, False)                      # first call: allocations, weight packing
+            out_f, g_f = step(free, True)          # ... then not one synchronisation
+            out_s, g_s = step(sync, False)
+            assert torch.equal(out_f["ray_mask"], out_s["ray_mask"])
+            miss = ~out_f["ray_mask"]
+            assert bool((out_f["rgb"][miss] == 1.0).all()) and bool((out_f["accumulation"][miss] == 0.0).all())
+            assert bool((out_f["depth"][miss] == 1000.0).all())
+            assert bool(torch.isfinite(out_f["rgb"]).all())
+            if case == "all hit":
+                assert int(miss.sum()) == 0
+                for k in ("rgb", "accumulation", "depth"):
+                    assert torch.equal(out_f[k], out_s[k]), k
+                for a, b in zip(g_f[1:], g_s[1:]):        # the 12 weight gradients are reproducible; the field's is atomic
+                    assert torch.equal(a, b)
+                assert float((g_f[0] - g_s[0]).abs().max()) <= 1e-5 * float(g_s[0].abs().max())
+            elif case == "a third misses":
+                assert 0.25 < float(miss.float().mean()) < 0.45
+                hit = out_f["ray_mask"]
+                assert float(out_f["accumulation"][hit].mean()) > 0.05
+                for g in g_f:
+                    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+                # the same distribution, another random stream: the mean colour of the hitting rays agrees
+                assert abs(float(out_f["rgb"][hit].mean()) - float(out_s["rgb"][hit].mean())) < 0.02
+            else:
+                assert int(out_f["ray_mask"].sum()) == 0
+                for g in g_f:
+                    assert g is None or (bool(torch.isfinite(g).all()) and float(g.abs().max()) == 0.0)

@@ -74,8 +74,10 @@ __global__ __launch_bounds__(SB) void k_sample_coarse(size_t r, uint32_t S, uint
         const size_t ray = ray_index[q];
         const uint32_t nb = num_visited[ray];
         const float2 *row = reinterpret_cast<const float2 *>(hit_dist + ray * (size_t)M * 2);
-        const float near = row[0].x;
-        const float far = row[nb ? nb - 1 : 0].y;
+        // (a ray that misses the mesh has no row -- with compact rows not even a written one: the sync-free training path
+        // names such rays only when a whole batch misses; their samples are discarded, they just have to be finite)
+        const float near = nb ? row[0].x : 0.0f;
+        const float far = nb ? row[nb - 1].y : 1.0f;
         if (lane == 0) { near_far[2 * q] = near; near_far[2 * q + 1] = far; }
         if (biased) {
             // lengths (clamped at 0: the cell -1 closing segments) and their running sum from the first entry point
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(SB) void k_sample_coarse(size_t r, uint32_t S, uint
                 b = lower + (upper - lower) * t_rand[q * (size_t)(S + 1) + j];
             }
             float e = b * far + (1.0f - b) * near;
-            if (biased) {
+            if (biased && nb) {
                 float rest = (e - near) / (far - near) * fnb;
                 float iv = floorf(rest);
                 iv = fminf(iv, fnb - 1.0f);

@@ -346,8 +346,11 @@ class TetraRenderer:
                  max_ray_triangles: int = 512, fused: bool = True, far_plane: float = 1000.0,
                  num_fine_samples: int = 0, biased: bool = False, dense_tails: bool = False, fused_pass="auto",
                  mlp_mode: str = "fp32", background=1.0, cache_field: bool = True, device_samplers: bool = True,
-                 interpolate_values=None):
+                 interpolate_values=None, sync_free_train: bool = True):
         from . import tetranerf_cpp_extension as cpp
+
+        # render_train without a host synchronisation (see there); False: compact the hitting rays with torch.nonzero
+        self.sync_free_train = bool(sync_free_train)
 
         self.cpp = cpp
         self.tracer, self.field, self.mlp = tracer, field, mlp
@@ -499,12 +502,27 @@ class TetraRenderer:
         samples; without it they are drawn from `generator` / torch's global generator in the reference's order and
         shapes (coarse first, then fine), so the same seed gives the reference body and this path the same draws."""
         cpp, S = self.cpp, self.S
+        R, dev = origins.shape[0], origins.device
+        rand = rand or {}
+        # SYNC-FREE form (default for the fused path): the reference compacts the hitting rays with boolean indexing
+        # (model.py:540-567: a device -> host synchronisation per call, like torch.nonzero here).  Training batches are
+        # pixels of the object: nearly all of their rays hit, so the batch is processed at its full size R instead -- the
+        # hitting rays first, in ray order (stable argsort of the miss flag), the tail padded with copies of the first entry,
+        # whose (finite) results and gradients are masked out -- and nothing on the host ever waits for the ray count:
+        # no gap in the launch stream between the trace and the samplers.  When every ray hits (the bench batch, the
+        # parity tests) the stratified draws are the reference's, element for element; with misses they are the first
+        # `count` rows of an [R, S+1] draw instead of an [r, S+1] draw -- the same distribution, another stream.
+        sync_free = self.sync_free_train and fused and self.device_samplers and capture is None and not rand and R > 0
         with torch.no_grad():
             out = self._trace(origins, directions)
             nv = out["num_visited_cells"]
             ray_mask = nv > 0
-            idx = torch.nonzero(ray_mask)[:, 0]
-        R, dev = origins.shape[0], origins.device
+            if sync_free:
+                order = torch.argsort((~ray_mask).to(torch.uint8), stable=True)
+                valid = torch.arange(R, device=dev) < ray_mask.sum()
+                idx = torch.where(valid, order, order[:1])
+            else:
+                idx = torch.nonzero(ray_mask)[:, 0]
         bg = self._bg(background)
         rgb = self._background_rows(R, bg, dev)
         acc = torch.zeros((R, 1), dtype=torch.float32, device=dev)
@@ -515,7 +533,6 @@ class TetraRenderer:
                                   "vertex_indices")]
         ridx = idx.to(torch.int32)
         r = idx.numel()
-        rand = rand or {}
         record = fused and torch.is_grad_enabled()
         spacing = None            # spacing bins of the final samples (exact only on the PyTorch sampler path)
         with torch.no_grad():
@@ -606,6 +623,12 @@ class TetraRenderer:
             rgb_r, acc_r, depth_r = cpp.composite(sigma.contiguous(), col.contiguous(), edges, background=bg)
         else:
             rgb_r, acc_r, depth_r, _ = composite(sigma[..., None], col, edges[:, :-1, None], edges[:, 1:, None], background=bg)
+        if sync_free:     # `order` is a permutation of the rays: every row is written once, padded entries get the miss values
+            v = valid[:, None]
+            rgb = rgb.index_copy(0, order, torch.where(v, rgb_r, rgb))
+            acc = acc.index_copy(0, order, torch.where(v, acc_r.reshape(-1, 1), acc))
+            depth = depth.index_copy(0, order, torch.where(v, depth_r.reshape(-1, 1).detach(), depth))
+            return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
         rgb = rgb.index_copy(0, idx, rgb_r)
         acc = acc.index_copy(0, idx, acc_r.reshape(-1, 1))
         depth = depth.index_copy(0, idx, depth_r.reshape(-1, 1).detach())
