@@ -283,9 +283,14 @@ int tn_mlp_forward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const float
 /* the same with the barycentric gather fused in (tn_interpolate_values<4> + tn_mlp_forward without the
  * [64,n] intermediate): vertex_indices u32 [n,4], barycentric f32 [n,3], field_vm f32 [V,64] VERTEX-major
  * (tn_transpose_f32 of the [64,V] parameter, refreshed by the caller once per field version) */
+/* ray_head_bias f32 [n / samples_per_ray, 128] or NULL (here, in tn_render_pass and in tn_mlp_forward_gather_train): a
+ * per-RAY vector added to the pre-activation of mlp_head -- the reference's appearance embedding (model.py:437-447,
+ * 608-620: head input = cat[encoded_dir, base, embedded_appearance], the embedding constant along a ray), whose E columns
+ * of the head GEMM collapse to c_ray = Wh[:, 155:] emb(camera of the ray), an [rays, E] x [E, 128] product the caller
+ * makes (and differentiates: tn_mlp_ray_head_grad returns dL/dc_ray).  wh of tn_mlp_weights stays [128, 155]. */
 int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices,
                           const float *barycentric, const float *field_vm, const float *dirs, int mode, float *sigma,
-                          float *rgb, void *stream);
+                          float *rgb, const float *ray_head_bias, void *stream);
 
 /* One render PASS of TetrahedraNerf.get_outputs as ONE launch (reference span
  * tetranerf/nerfstudio/model.py:560-662 = find_visited_cells -> interpolate_values -> mlp_base + heads -> get_weights ->
@@ -305,7 +310,8 @@ typedef struct tn_rgb_background { float r, g, b; int clamp; } tn_rgb_background
 int tn_render_pass(tn_mlp_t mlp, uint32_t max_ray_triangles, const uint32_t *num_visited, const float *hit_distances,
                    const float *barycentric, const uint32_t *vertex_indices, const uint32_t *ray_index, size_t num_hit_rays,
                    uint32_t num_samples, const float *edges, const float *field_vm, const float *dirs,
-                   const tn_rgb_background *background, float *out_weights, float *out_rgb, float *out_acc, float *out_depth, void *stream);
+                   const tn_rgb_background *background, float *out_weights, float *out_rgb, float *out_acc, float *out_depth,
+                   const float *ray_head_bias /* f32 [num_hit_rays, 128] or NULL */, void *stream);
 
 /* ---- ray samplers between tn_trace_rays and the render passes (model.py:111-192, 549-557, 582-586; nerfstudio's
  * UniformSampler / PDFSampler for the parts the reference imports).  One wavefront per HITTING ray; the trace rows are
@@ -362,9 +368,13 @@ typedef struct tn_mlp_backward_buffers {
 } tn_mlp_backward_buffers;
 int tn_mlp_forward_gather_train(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices,
                                 const float *barycentric, const float *field_vm, const float *dirs, float *sigma, float *rgb,
-                                const tn_mlp_backward_buffers *buffers, void *stream);
+                                const tn_mlp_backward_buffers *buffers, const float *ray_head_bias, void *stream);
 int tn_mlp_backward(tn_mlp_t mlp, size_t n, const float *sigma, const float *rgb, const float *d_sigma, const float *d_rgb,
                     const tn_mlp_backward_buffers *buffers, void *stream);
+/* gradient of the per-ray head bias after tn_mlp_backward: d_ray_head_bias f32 [n / samples_per_ray, 128] = the sum over
+ * each ray's samples of d4 (bit-reproducible) */
+int tn_mlp_ray_head_grad(size_t n, uint32_t samples_per_ray, const tn_mlp_backward_buffers *buffers, float *d_ray_head_bias,
+                         void *stream);
 typedef struct tn_mlp_grads { /* same shapes as tn_mlp_weights */
     float *w1, *b1, *w2, *b2, *w3, *b3, *wd, *bd, *wh, *bh, *wr, *br;
 } tn_mlp_grads;

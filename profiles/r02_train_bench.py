@@ -26,7 +26,7 @@ for R, S in ((4096, 256), (4096, 513)):
     gs, gc = torch.randn(n, device=dev), torch.randn(n, 3, device=dev)
     def fused():
         field.grad = None; mlp.zero_grad()
-        s, c = render._FusedMlpFunction.apply(vi, bc, field, dirs, S, *w)
+        s, c = render._FusedMlpFunction.apply(vi, bc, field, dirs, S, None, *w)
         ((s * gs).sum() + (c * gc).sum()).backward()
     wd = [x.detach() for x in w]
     def fwd_only():

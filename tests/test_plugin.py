@@ -81,7 +81,8 @@ def test_fallback_rule(plugin, standins):
     ok = lambda **kw: plugin.fused_config_supported(standins.Config(**kw))[0]   # noqa: E731
     assert ok() and ok(num_samples=128, num_fine_samples=128, use_biased_sampler=True, use_gradient_scaling=True)
     assert ok(background_color="black") and ok(num_fine_samples=0) and ok(max_intersected_triangles=1024)
-    for bad in (dict(appearance_embed_dim=8), dict(input_fourier_frequencies=4), dict(hidden_size=256), dict(num_density_layers=2),
+    assert ok(appearance_embed_dim=8)            # round 4: the embedding acts through the kernels' per-ray head bias
+    for bad in (dict(input_fourier_frequencies=4), dict(hidden_size=256), dict(num_density_layers=2),
                 dict(num_color_layers=2), dict(field_dim=32), dict(background_color="random"), dict(background_color="last_sample")):
         supported, why = plugin.fused_config_supported(standins.Config(**bad))
         assert not supported and why, bad
@@ -101,7 +102,7 @@ def test_install_routes_unsupported_configs_to_the_reference(plugin, standins):
     import torch
 
     torch.manual_seed(0)
-    m = Model(standins.Config(appearance_embed_dim=8), torch.rand(20, 3), torch.randint(0, 20, (30, 4), dtype=torch.int32))
+    m = Model(standins.Config(input_fourier_frequencies=2), torch.rand(20, 3), torch.randint(0, 20, (30, 4), dtype=torch.int32))
     assert m.get_outputs("bundle") == {"rgb": "reference"} and calls == ["bundle"]
     plugin.uninstall(Model)
     assert Model.get_outputs is not plugin.fused_get_outputs

@@ -55,7 +55,8 @@ def test_state_dict_names_and_fallback_rule(ref, scenes):
     for a, b in zip(ws, plugin.weights_from_model(model)):
         assert a.data_ptr() == b.data_ptr()
     assert plugin.fused_config_supported(model.config) == (True, "")
-    for bad in (dict(appearance_embed_dim=8), dict(input_fourier_frequencies=2), dict(hidden_size=64),
+    assert plugin.fused_config_supported(rm.build_model(ref, pts, cells, appearance_embed_dim=8).config) == (True, "")
+    for bad in (dict(input_fourier_frequencies=2), dict(hidden_size=64),
                 dict(background_color="random"), dict(num_density_layers=2), dict(num_color_layers=2)):
         m2 = rm.build_model(ref, pts, cells, **bad)
         ok, why = plugin.fused_config_supported(m2.config)

@@ -68,7 +68,9 @@ def _compare_eval(got, want, bg=None):
 
 EVAL_CONFIGS = [dict(num_samples=256, num_fine_samples=256),                                                    # tetra-nerf-original
                 dict(num_samples=128, num_fine_samples=128, use_biased_sampler=True, use_gradient_scaling=True),  # tetra-nerf
-                dict(num_samples=96, num_fine_samples=0, background_color="black", max_intersected_triangles=256)]
+                dict(num_samples=96, num_fine_samples=0, background_color="black", max_intersected_triangles=256),
+                # per-image appearance embedding (model.py:437-447,608-620): evaluation = the mean embedding for every ray
+                dict(num_samples=128, num_fine_samples=128, use_biased_sampler=True, appearance_embed_dim=16)]
 
 
 @pytest.mark.parametrize("cfg", EVAL_CONFIGS)
@@ -78,9 +80,10 @@ def test_fused_adapter_eval_equals_the_reference_body(tn, device, scenes, ref, p
 
     model = _model(ref, scenes, device, **cfg).eval()
     o, d = _rays(scenes)
-    rb = rm.ray_bundle(ref, o, d, device)
+    rb = rm.ray_bundle(ref, o, d, device, camera_indices=np.arange(len(o)) % 3)
     reference_body = ref.TetrahedraNerf._tn_reference_get_outputs
     assert ref.TetrahedraNerf.get_outputs is plugin.fused_get_outputs and reference_body is not None
+    assert plugin.fused_config_supported(model.config) == (True, "")
     with torch.no_grad():
         want = reference_body(model, rb)
         got = model(rb)                          # Model.forward -> collider -> (patched) get_outputs
@@ -107,7 +110,10 @@ def test_fused_adapter_eval_equals_the_reference_body(tn, device, scenes, ref, p
 
 TRAIN_CONFIGS = [dict(num_samples=64, num_fine_samples=64),
                  dict(num_samples=48, num_fine_samples=48, use_biased_sampler=True, use_gradient_scaling=True),
-                 dict(num_samples=128, num_fine_samples=128, use_biased_sampler=True, use_gradient_scaling=True)]
+                 dict(num_samples=128, num_fine_samples=128, use_biased_sampler=True, use_gradient_scaling=True),
+                 # appearance embedding: training = the embedding of every ray's camera; gradients reach the embedding table
+                 # and all 155 + E columns of mlp_head
+                 dict(num_samples=64, num_fine_samples=64, use_gradient_scaling=True, appearance_embed_dim=8)]
 
 
 @pytest.mark.parametrize("cfg", TRAIN_CONFIGS)
@@ -116,9 +122,16 @@ def test_fused_adapter_training_equals_the_reference_body(tn, device, scenes, re
 
     model = _model(ref, scenes, device, **cfg).train()
     o, d = scenes.outside_in_rays(2048, 33)
-    rb = rm.ray_bundle(ref, o, d, device)
+    rb = rm.ray_bundle(ref, o, d, device, camera_indices=np.arange(len(o)) % 3)
     target = torch.rand(len(o), 3, device=device)
     params = [model.tetrahedra_field] + plugin.weights_from_model(model)
+    names = ["field", "w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd", "wh", "bh", "wr", "br"]
+    if cfg.get("appearance_embed_dim"):
+        with torch.no_grad():
+            model.appearance_embedding.weight.mul_(0.5)      # (N(0,1) init: keep the head pre-activation in a sane range)
+        params.append(model.appearance_embedding.weight)
+        names.append("appearance_embedding")
+        assert tuple(params[9].shape) == (128, 155 + cfg["appearance_embed_dim"])
     reference_body = ref.TetrahedraNerf._tn_reference_get_outputs
 
     def step(fn):
@@ -135,7 +148,6 @@ def test_fused_adapter_training_equals_the_reference_body(tn, device, scenes, re
     np.testing.assert_allclose(got["rgb"].cpu().numpy(), want["rgb"].cpu().numpy(), rtol=0, atol=1e-5)
     np.testing.assert_allclose(got["accumulation"].cpu().numpy(), want["accumulation"].cpu().numpy(), rtol=0, atol=1e-5)
     assert float(((got["depth"] - want["depth"]).abs() <= 1e-5).float().mean()) > 0.995
-    names = ["field", "w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd", "wh", "bh", "wr", "br"]
     for name, a, b in zip(names, g_got, g_want):
         assert b is not None and float(b.abs().max()) > 0, name
         # two fp32 evaluations of one gradient with differently split sums (sample-streaming GEMM slices + fixed-order
@@ -154,13 +166,13 @@ def test_fused_adapter_training_equals_the_reference_body(tn, device, scenes, re
     np.testing.assert_allclose(got["rgb"].cpu().numpy(), want["rgb"].cpu().numpy(), rtol=0, atol=1e-5)
 
 
-@pytest.mark.parametrize("cfg", [dict(appearance_embed_dim=8), dict(input_fourier_frequencies=2), dict(hidden_size=64),
+@pytest.mark.parametrize("cfg", [dict(input_fourier_frequencies=2), dict(hidden_size=64),
                                  dict(num_density_layers=2), dict(num_color_layers=2)])
 @pytest.mark.parametrize("train", [False, True])
 def test_unsupported_configurations_fall_back_to_the_reference_body(tn, device, scenes, ref, plugin, cfg, train):
     """The fallback rule under test: the patched get_outputs of a configuration the fused kernels do not implement IS the
     reference body (HIP tracer / matcher / gather under nerfstudio's PyTorch MLP): bit-identical outputs, and in training
-    mode gradients for every parameter including the appearance embedding."""
+    mode gradients for every parameter."""
     import torch
 
     model = _model(ref, scenes, device, num_samples=32, num_fine_samples=32, **cfg).train(train)

@@ -73,7 +73,7 @@ def test_mlp_backward_matches_autograd(tn, device, R, S, V):
     s64, c64, gf64, gw64 = reference(torch.float64)
     _, _, gf32, gw32 = reference(torch.float32)
     w = render.mlp_weights(mlp)
-    sigma, col = render._FusedMlpFunction.apply(vi, bc, field, dirs, S, *w)
+    sigma, col = render._FusedMlpFunction.apply(vi, bc, field, dirs, S, None, *w)
     np.testing.assert_allclose(sigma.detach().cpu().numpy(), s64.float().cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(col.detach().cpu().numpy(), c64.float().cpu().numpy(), rtol=0, atol=1e-5)
     ((sigma * g_sigma).sum() + (col * g_rgb).sum()).backward()

@@ -784,7 +784,7 @@ struct tn_mlp {
             enc.alloc(cap * tn::mlp_enc_floats_per_ray());
             nvh.alloc(cap);
         }
-        return tn::MlpPacks{pk_plain.p, pk_gather.p, pt.p, blob.p, enc.p, nvh.p, grad_scratch.p};
+        return tn::MlpPacks{pk_plain.p, pk_gather.p, pt.p, blob.p, enc.p, nullptr, nvh.p, grad_scratch.p};
     }
 };
 
@@ -866,7 +866,7 @@ int tn_mlp_forward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const float
 
 int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices,
                           const float *barycentric, const float *field_vm, const float *dirs, int mode, float *sigma,
-                          float *rgb, void *stream_) {
+                          float *rgb, const float *ray_head_bias, void *stream_) {
     return guarded([&] {
         tn_mlp *m = checked_mlp(mlp);
         check_mode(mode);
@@ -875,8 +875,10 @@ int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, cons
         if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
         DeviceGuard g(m->device);
         const size_t rays = n / samples_per_ray;
+        tn::MlpPacks pk = m->packs(rays);
+        pk.ray_bias = rgb ? ray_head_bias : nullptr;
         (mode ? tn::launch_mlp_forward_x3 : tn::launch_mlp_forward)(
-            n, samples_per_ray, rays, nullptr, vertex_indices, barycentric, field_vm, dirs, m->packs(rays), sigma, rgb,
+            n, samples_per_ray, rays, nullptr, vertex_indices, barycentric, field_vm, dirs, pk, sigma, rgb,
             (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
@@ -885,7 +887,8 @@ int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, cons
 int tn_render_pass(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const float *hit_distances, const float *barycentric,
                    const uint32_t *vertex_indices, const uint32_t *ray_index, size_t num_hit_rays, uint32_t num_samples,
                    const float *edges, const float *field_vm, const float *dirs, const tn_rgb_background *background,
-                   float *out_weights, float *out_rgb, float *out_acc, float *out_depth, void *stream_) {
+                   float *out_weights, float *out_rgb, float *out_acc, float *out_depth, const float *ray_head_bias,
+                   void *stream_) {
     return guarded([&] {
         tn_mlp *m = checked_mlp(mlp);
         if (num_hit_rays == 0) return;
@@ -893,8 +896,10 @@ int tn_render_pass(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const 
             throw tn::Error("null pointer");
         if (!dirs && !out_weights) throw tn::Error("density-only pass without out_weights");
         DeviceGuard g(m->device);
+        tn::MlpPacks pk = m->packs(num_hit_rays);
+        pk.ray_bias = ray_head_bias;
         tn::launch_render_pass(num_visited, hit_distances, barycentric, vertex_indices, M, ray_index, num_hit_rays, num_samples,
-                               edges, field_vm, dirs, m->packs(num_hit_rays), background_of(background), out_weights, out_rgb, out_acc, out_depth,
+                               edges, field_vm, dirs, pk, background_of(background), out_weights, out_rgb, out_acc, out_depth,
                                (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
@@ -909,7 +914,7 @@ tn::MlpBackwardBuffers training_buffers(const tn_mlp_backward_buffers *b) {
 
 int tn_mlp_forward_gather_train(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices,
                                 const float *barycentric, const float *field_vm, const float *dirs, float *sigma, float *rgb,
-                                const tn_mlp_backward_buffers *b, void *stream_) {
+                                const tn_mlp_backward_buffers *b, const float *ray_head_bias, void *stream_) {
     return guarded([&] {
         tn_mlp *m = checked_mlp(mlp);
         if (n == 0) return;
@@ -918,7 +923,9 @@ int tn_mlp_forward_gather_train(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray
         if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
         DeviceGuard g(m->device);
         const size_t rays = n / samples_per_ray;
-        tn::launch_mlp_forward_train(n, samples_per_ray, rays, vertex_indices, barycentric, field_vm, dirs, m->packs(rays), sigma, rgb,
+        tn::MlpPacks pk = m->packs(rays);
+        pk.ray_bias = ray_head_bias;
+        tn::launch_mlp_forward_train(n, samples_per_ray, rays, vertex_indices, barycentric, field_vm, dirs, pk, sigma, rgb,
                                      training_buffers(b), (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
@@ -933,6 +940,17 @@ int tn_mlp_backward(tn_mlp_t mlp, size_t n, const float *sigma, const float *rgb
         if (!b->masks || !b->d1 || !b->d2 || !b->d3 || !b->d4 || !b->dhead || !b->dx0) throw tn::Error("null pointer");
         DeviceGuard g(m->device);
         tn::launch_mlp_backward(n, sigma, rgb, m->packs(0), d_sigma, d_rgb, training_buffers(b), (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_mlp_ray_head_grad(size_t n, uint32_t samples_per_ray, const tn_mlp_backward_buffers *b, float *d_ray_head_bias,
+                         void *stream_) {
+    return guarded([&] {
+        if (n == 0) return;
+        if (!b || !b->d4 || !d_ray_head_bias) throw tn::Error("null pointer");
+        if (samples_per_ray == 0 || n % samples_per_ray != 0) throw tn::Error("n must be a multiple of samples_per_ray");
+        tn::launch_ray_head_grad(n, samples_per_ray, b->d4, d_ray_head_bias, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }

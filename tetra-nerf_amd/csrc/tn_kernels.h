@@ -130,6 +130,8 @@ struct MlpPacks {
     const float *pt;           // transposed weights in accumulator order (backward)
     const uint4 *blob;         // bf16x3 pieces (forward, mode 1)
     float *enc;                // [rays][mlp_enc_floats_per_ray()] direction encodings of the current call
+    const float *ray_bias;     // per CALL (set by the entry point, never stored): [rays][128] added to the head layer's
+                               // pre-activation (appearance embedding, tn_mlp_common.h: add_ray_bias), or null
     uint32_t *nvh;             // [rays] segment counts of the hitting rays (render pass)
     float *grad_scratch;       // [mlp_param_grad_scratch_floats()] per-block partial sums of the parameter gradients
 };
@@ -169,6 +171,9 @@ void launch_mlp_forward_train(size_t n, uint32_t samples_per_ray, size_t num_ray
 // sigmoid' = rgb (1 - rgb)); d_sigma [n], d_rgb [n, 3]; fills d1..d4, dhead, dx0
 void launch_mlp_backward(size_t n, const float *sigma, const float *rgb, const MlpPacks &w, const float *d_sigma, const float *d_rgb,
                          const MlpBackwardBuffers &b, hipStream_t stream);
+// gradient of the per-ray head bias: out [rays, 128] = sum over the ray's samples of d4 (the gradient w.r.t. the head
+// layer's pre-activation, left by launch_mlp_backward)
+void launch_ray_head_grad(size_t n, uint32_t samples_per_ray, const float *d4, float *out, hipStream_t stream);
 // parameter gradients (tn_mlp_grad.hip), ACCUMULATED into the twelve tensors (nn.Linear layout: w1 [128,64], b1, w2, b2, w3,
 // b3 [128..], wd [1,128], bd [1], wh [128,155], bh, wr [3,128], br [3]) from the buffers launch_mlp_backward left for the
 // same samples; bit-reproducible (no atomics).  dirs: the ray directions of the chunk.

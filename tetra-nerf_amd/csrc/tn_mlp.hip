@@ -105,7 +105,8 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
                                                            const uint32_t *__restrict__ vi, const float *__restrict__ bc,
                                                            const float *__restrict__ fieldT,
                                                            const float *__restrict__ enc, const float *__restrict__ pk,
-                                                           float *__restrict__ sigma, float *__restrict__ rgb, FwdSave sv) {
+                                                           float *__restrict__ sigma, float *__restrict__ rgb, FwdSave sv,
+                                                           const float *__restrict__ ray_bias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
             if constexpr (TRAIN) gemm_steps_store<KSH, KSE, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h3, n, sc, h), 2 * n);
             else gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
             bias_step<HEAD_KS, OT>(acc, lds, lane);
+            if (ray_bias) add_ray_bias(acc, ray_bias + (sc / samples_per_ray) * HID, h);   // wave-uniform test
             relu_to_bin(acc, bin);
         }
         if constexpr (TRAIN) store_bin(sv.h4, n, sc, bin, h);   // the last layer's output has no GEMM to hide under
@@ -341,7 +343,7 @@ void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, con
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
 #define TN_MLP_LAUNCH(G, D)                                                                                         \
     hipLaunchKernelGGL((k_mlp_forward<G, D>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc, \
-                       fieldT, enc, pk, sigma, rgb, FwdSave{})
+                       fieldT, enc, pk, sigma, rgb, FwdSave{}, w.ray_bias)
     if (gather && density_only) TN_MLP_LAUNCH(true, true);
     else if (gather) TN_MLP_LAUNCH(true, false);
     else if (density_only) TN_MLP_LAUNCH(false, true);
@@ -362,7 +364,7 @@ void launch_mlp_forward_train(size_t n, uint32_t samples_per_ray, size_t num_ray
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
     hipLaunchKernelGGL((k_mlp_forward<true, false, MLP_BLOCK, true>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray,
                        (const float *)nullptr, vi, bc, fieldT, w.enc, w.pk_gather, sigma, rgb,
-                       FwdSave{save.x0, save.h1, save.h2, save.h3, save.h4, save.masks});
+                       FwdSave{save.x0, save.h1, save.h2, save.h3, save.h4, save.masks}, w.ray_bias);
 }
 
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, Background background,

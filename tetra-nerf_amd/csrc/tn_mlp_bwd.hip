@@ -324,4 +324,33 @@ void launch_mlp_backward(size_t n, const float *sigma, const float *rgb, const M
                        BwdIn{b.masks, sigma, rgb, d_sigma, d_rgb}, w.pt, BwdOut{b.d1, b.d2, b.d3, b.d4, b.dhead, b.dx0});
 }
 
+// Gradient of the per-ray head bias (tn_mlp_common.h: add_ray_bias; the appearance embedding of model.py:608-620):
+// out[ray][f] = sum over the ray's S samples of d4[f][sample].  d4 is quad-major [32][n][4]: one 256-thread block per ray,
+// thread = (quad, one of 8 consecutive samples): every 8 threads read 128 contiguous bytes per step; the 8 partial sums are
+// combined by shuffles in a fixed order (bit-reproducible).
+__global__ __launch_bounds__(256) void k_ray_head_grad(size_t n, uint32_t S, const float *__restrict__ d4, float *__restrict__ out) {
+    const uint32_t quad = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const size_t rays = n / S;
+    const float4 *src = reinterpret_cast<const float4 *>(d4) + (size_t)quad * n;
+    for (size_t ray = blockIdx.x; ray < rays; ray += gridDim.x) {
+        const size_t s0 = ray * S;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t j = sub; j < S; j += 8) {
+            const float4 v = src[s0 + j];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            a.x += __shfl_xor(a.x, off); a.y += __shfl_xor(a.y, off); a.z += __shfl_xor(a.z, off); a.w += __shfl_xor(a.w, off);
+        }
+        if (sub == 0) *reinterpret_cast<float4 *>(out + ray * HID + 4 * quad) = a;
+    }
+}
+
+void launch_ray_head_grad(size_t n, uint32_t samples_per_ray, const float *d4, float *out, hipStream_t stream) {
+    if (n == 0 || samples_per_ray == 0) return;
+    const size_t rays = n / samples_per_ray;
+    hipLaunchKernelGGL(k_ray_head_grad, dim3((unsigned)(rays < 256 * 8 ? rays : 256 * 8)), dim3(256), 0, stream, n, samples_per_ray, d4, out);
+}
+
 }  // namespace tn

@@ -146,6 +146,22 @@ static __device__ __forceinline__ void bias_step(f32x16 (&acc)[TILES], const flo
     for (int t = 0; t < TILES; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], 1.0f, acc[t], 0, 0, 0);
 }
 
+// Per-RAY bias of the head layer (the appearance embedding of the reference's model, model.py:437-447,608-620: the head
+// input is cat[encoded_dir, base, embedded_appearance] and the embedding is constant along a ray, so its E columns of the
+// head GEMM collapse to one vector per ray, c = Wh[:, 155:] emb(camera of the ray), which the caller computes -- an
+// [rays, E] x [E, 128] product -- and the kernels add to the head pre-activation before the ReLU).  row = the ray's 128
+// floats; a lane adds the 64 features it holds: acc[t][4 q + j] is feature 32 t + 8 q + 4 h + j (acc_feature).
+template <int TILES>
+static __device__ __forceinline__ void add_ray_bias(f32x16 (&acc)[TILES], const float *__restrict__ row, int h) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + 32 * t + 8 * q + 4 * h);
+            acc[t][4 * q] += v.x; acc[t][4 * q + 1] += v.y; acc[t][4 * q + 2] += v.z; acc[t][4 * q + 3] += v.w;
+        }
+}
+
 template <int TILES>
 static __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TILES]) {
 #pragma unroll

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(X3_BLOCK) void k_mlp_forward_x3(size_t n, uint32_t 
                                                              const uint32_t *__restrict__ vi, const float *__restrict__ bc,
                                                              const float *__restrict__ fieldT, const float *__restrict__ enc,
                                                              const uint4 *__restrict__ blob, float *__restrict__ sigma,
-                                                             float *__restrict__ rgb) {
+                                                             float *__restrict__ rgb, const float *__restrict__ ray_bias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *lds = reinterpret_cast<uint4 *>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
@@ -357,6 +357,16 @@ __global__ __launch_bounds__(X3_BLOCK) void k_mlp_forward_x3(size_t n, uint32_t 
             }
             x3_steps<2, 4>(acc, lds, ev, lane);
             x3_steps<8, 4>(acc, lds + wu4(2, 4), bin, lane);
+            if (ray_bias) {   // per-ray head bias (appearance embedding; tn_mlp_common.h: add_ray_bias), wave-uniform test
+                const float *row = ray_bias + (sc / samples_per_ray) * HID;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4 *>(row + 32 * t + 8 * q + 4 * h);
+                        acc[t][4 * q] += v.x; acc[t][4 * q + 1] += v.y; acc[t][4 * q + 2] += v.z; acc[t][4 * q + 3] += v.w;
+                    }
+            }
             relu_to_bin(acc, bin);
         }
         {
@@ -404,7 +414,7 @@ void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, 
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
 #define TN_X3_LAUNCH(G, D)                                                                                            \
     hipLaunchKernelGGL((k_mlp_forward_x3<G, D>), dim3(grid), dim3(X3_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc, \
-                       fieldT, enc, blob, sigma, rgb)
+                       fieldT, enc, blob, sigma, rgb, w.ray_bias)
     if (gather && density_only) TN_X3_LAUNCH(true, true);
     else if (gather) TN_X3_LAUNCH(true, false);
     else if (density_only) TN_X3_LAUNCH(false, true);

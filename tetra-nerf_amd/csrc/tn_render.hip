@@ -46,6 +46,7 @@ struct RenderPassParams {
     const float *edges;            // [r, S + 1]
     const float *fieldT;           // [V, 64]
     const float *enc;              // [r, 28] or null (density only)
+    const float *ray_bias;         // [r, 128] per-ray head bias (appearance embedding) or null
     const float *pk;               // packed weights (k_mlp_pack, gather order)
     float *out_weights;            // [r, S] or null
     float *out_rgb, *out_acc, *out_depth;   // [R_all, 3], [R_all], [R_all] or null: written at ray_index[q]
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_render_pass(RenderPassParams p) {
                 }
                 gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
                 bias_step<HEAD_KS, OT>(acc, lds, lane);
+                if (p.ray_bias) add_ray_bias(acc, p.ray_bias + q * HID, h);
                 relu_to_bin(acc, bin);
             }
             const float *cv = lds + lfloats(HEAD_KS, OT);
@@ -461,7 +463,7 @@ void launch_render_pass(const uint32_t *num_visited, const float *dist, const fl
     if (!density_only) launch_dir_encoding(r, dirs, enc, stream);
     RenderPassParams p{};
     p.num_visited = num_visited; p.dist = dist; p.bary = bary; p.verts = verts; p.ray_index = ray_index; p.edges = edges;
-    p.nv_hit = nvh; p.fieldT = fieldT; p.enc = enc; p.pk = pk; p.out_weights = out_weights; p.out_rgb = out_rgb; p.out_acc = out_acc;
+    p.nv_hit = nvh; p.fieldT = fieldT; p.enc = enc; p.ray_bias = density_only ? nullptr : w.ray_bias; p.pk = pk; p.out_weights = out_weights; p.out_rgb = out_rgb; p.out_acc = out_acc;
     p.out_depth = out_depth; p.r = r; p.S = S; p.M = M; p.background = background;
     auto smem_for = [](size_t m) { return (MAX_STAGE_FLOATS + 2 * (size_t)RP_PIECES * m + 8 + 5 * RP_RING) * sizeof(float) + 2 * sizeof(RayState); };
     const size_t smem = smem_for(M);

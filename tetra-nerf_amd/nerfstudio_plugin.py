@@ -25,9 +25,14 @@ What is mapped (reference: /root/reference/tetranerf/nerfstudio/model.py):
     GradientScaler                                :195-205,625-630 -> render.GradientScaler
     state dict keys                               :273-300   -> weights_from_state_dict
 
-Fallback rule (the fused kernels hard-code the shipped architecture 64 -> 128^3 -> (27 + 128) -> 128 -> 3): any other
+    appearance_embedding (appearance_embed_dim = E > 0) :437-447,608-620 -> the E extra columns of mlp_head collapse to a
+                                                  per-RAY bias c = Wh[:, 155:] emb(camera) (training: the ray's camera; evaluation:
+                                                  the mean embedding), made here in PyTorch ([R,E] x [E,128], differentiable) and
+                                                  added by the kernels to the head pre-activation (`ray_head_bias`)
+
+Fallback rule (the fused kernels hard-code the shipped architecture 64 -> 128^3 -> (27 + 128 [+ E]) -> 128 -> 3): any other
 configuration -- `field_dim != 64`, `hidden_size != 128`, `num_density_layers != 3`, `num_color_layers != 1`,
-`input_fourier_frequencies > 0`, `appearance_embed_dim > 0`, `background_color` in {"random", "last_sample"} -- runs the
+`input_fourier_frequencies > 0`, a `background_color` that is not a constant on the call -- runs the
 REFERENCE `get_outputs` unchanged (i.e. the HIP tracer / matcher / gather under nerfstudio's PyTorch MLP): same results as
 the reference, just without the fused speed-up.  `fused_config_supported` states the rule; both method configs the
 reference registers (`tetra-nerf-original`, `tetra-nerf`) are supported.
@@ -90,7 +95,37 @@ class ModelMLP:
         self.model = model
 
     def fused_weights(self):
-        return weights_from_model(self.model)
+        """The 12 kernel tensors.  With an appearance embedding mlp_head's weight is [128, 155 + E]: the kernels take its
+        first 155 columns (a differentiable slice while a graph is recorded; cached per parameter version otherwise, so
+        that evaluation does not re-pack the weights on every call); the other E act through `ray_head_bias`."""
+        ws = weights_from_model(self.model)
+        wh = ws[8]
+        if wh.shape[1] != 155:
+            if torch.is_grad_enabled() and wh.requires_grad:
+                ws[8] = wh[:, :155].contiguous()
+            else:
+                hit = getattr(self, "_wh_main", None)
+                if hit is None or hit[0] != (wh._version, wh.data_ptr()):
+                    hit = self._wh_main = ((wh._version, wh.data_ptr()), wh.detach()[:, :155].contiguous())
+                ws[8] = hit[1]
+        return ws
+
+    def ray_head_bias(self, ray_bundle):
+        """[R, 128] per-ray bias of the head layer = Wh[:, 155:] applied to the ray's appearance embedding, exactly the
+        embedded_appearance of model.py:608-620 (training: the embedding of the ray's camera; evaluation: the mean
+        embedding for every ray); None without an appearance embedding."""
+        m = self.model
+        E = int(getattr(m.config, "appearance_embed_dim", 0))
+        if E <= 0:
+            return None
+        wa = m.mlp_head.layers[0].weight[:, 155:155 + E]
+        R = ray_bundle.origins.reshape(-1, 3).shape[0]
+        if m.training:
+            assert ray_bundle.camera_indices is not None
+            emb = m.appearance_embedding(ray_bundle.camera_indices.reshape(-1))       # [R, E]
+            return (emb @ wa.t()).contiguous()
+        mean = m.appearance_embedding.weight.mean(dim=0)                              # [E]
+        return (mean @ wa.t())[None, :].expand(R, -1).contiguous()
 
     def coarse_sigma(self, feats):
         """density of the coarse pass (model.py:577-581) -> [..., S]"""
@@ -114,7 +149,7 @@ def fused_config_supported(config) -> Tuple[bool, str]:
         (g("num_density_layers", 3) == 3, "num_density_layers != 3"),
         (g("num_color_layers", 1) == 1, "num_color_layers != 1"),
         (g("input_fourier_frequencies", 0) == 0, "input_fourier_frequencies > 0"),
-        (g("appearance_embed_dim", 0) == 0, "appearance_embed_dim > 0"),
+        (g("appearance_embed_dim", 0) >= 0, "appearance_embed_dim < 0"),
         (g("background_color", "white") not in ("random", "last_sample"), "background_color is not a constant"),
         (g("num_samples", 256) >= 1, "num_samples < 1"),
     )
@@ -186,12 +221,14 @@ def fused_get_outputs(model, ray_bundle) -> Dict[str, torch.Tensor]:
     rd = _renderer_for(model, tracer)
     o = ray_bundle.origins.reshape(-1, 3).contiguous()
     d = ray_bundle.directions.reshape(-1, 3).contiguous()
+    hb = rd.mlp.ray_head_bias(ray_bundle)       # appearance embedding -> per-ray head bias (None without one)
     if model.training:
         # the reference's samplers stratify and its RGB renderer skips the clamp whenever `self.training` is set, with
         # or without autograd (model.py:169; nerfstudio RGBRenderer.forward); render_train skips the activation saves
         # when no graph is being recorded
-        return rd.render_train(o, d, gradient_scaling=bool(getattr(model.config, "use_gradient_scaling", False)), background=bg)
-    return rd.render(o, d, background=bg)
+        return rd.render_train(o, d, gradient_scaling=bool(getattr(model.config, "use_gradient_scaling", False)), background=bg,
+                               ray_head_bias=hb)
+    return rd.render(o, d, background=bg, ray_head_bias=hb)
 
 
 def install(model_cls=None):

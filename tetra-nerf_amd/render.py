@@ -281,11 +281,12 @@ class _FusedMlpFunction(torch.autograd.Function):
     weight tensors."""
 
     @staticmethod
-    def forward(ctx, vertex_indices, barycentric_coordinates, field, dirs, samples_per_ray, *weights):
+    def forward(ctx, vertex_indices, barycentric_coordinates, field, dirs, samples_per_ray, ray_head_bias, *weights):
         from . import tetranerf_cpp_extension as cpp
 
+        ctx.has_bias = ray_head_bias is not None
         sigma, rgb, saved = cpp.mlp_forward_gather_train(vertex_indices, barycentric_coordinates, field, dirs, list(weights),
-                                                         int(samples_per_ray))
+                                                         int(samples_per_ray), ray_head_bias=ray_head_bias)
         # the outputs go through save_for_backward (which knows how to hold a node's own outputs); `saved` must not
         # reference them: node -> saved -> output -> grad_fn -> node is a cycle no collector sees through, i.e. 5 GB
         # leaked per iteration
@@ -300,9 +301,11 @@ class _FusedMlpFunction(torch.autograd.Function):
 
         vi, bc, field, dirs, sigma, rgb, *weights = ctx.saved_tensors
         saved = ctx.saved          # (kept: a second backward through a retained graph reads the same activations)
-        grad_field, grads = cpp.mlp_backward(saved, vi, bc, field, dirs, list(weights), sigma, rgb, d_sigma.contiguous(),
-                                             d_rgb.contiguous())
-        return (None, None, grad_field, None, None, *grads)
+        res = cpp.mlp_backward(saved, vi, bc, field, dirs, list(weights), sigma, rgb, d_sigma.contiguous(), d_rgb.contiguous(),
+                               want_ray_head_grad=ctx.has_bias)
+        grad_field, grads = res[0], res[1]
+        # the per-ray head bias (appearance embedding): its gradient = per-ray sums of the head pre-activation's gradient
+        return (None, None, grad_field, None, None, res[2] if ctx.has_bias else None, *grads)
 
 
 class _FusedCompositeFunction(torch.autograd.Function):
@@ -412,9 +415,11 @@ class TetraRenderer:
         return background if isinstance(background, (int, float)) else tuple(float(x) for x in background_tensor(background).tolist())
 
     @torch.no_grad()
-    def render(self, origins: torch.Tensor, directions: torch.Tensor, background=None) -> Dict[str, torch.Tensor]:
+    def render(self, origins: torch.Tensor, directions: torch.Tensor, background=None, ray_head_bias=None) -> Dict[str, torch.Tensor]:
         """Evaluation-mode render (model.py:520-662 with `self.training == False`: samplers without jitter, RGB renderer
-        with nan_to_num + clamp).  background: per-call override of the renderer's colour (grey level or (r, g, b))."""
+        with nan_to_num + clamp).  background: per-call override of the renderer's colour (grey level or (r, g, b)).
+        ray_head_bias f32 [R, 128] (fused path only): per-ray vector added to mlp_head's pre-activation -- the appearance
+        embedding's share of the head layer, Wh[:, 155:] emb (model.py:608-620), made by the caller."""
         cpp, S = self.cpp, self.S
         bg = self._bg(background)
         if not self.fused:
@@ -436,6 +441,7 @@ class TetraRenderer:
                                       "vertex_indices")]
             ridx = idx.to(torch.int32)
             w = mlp_weights(self.mlp)
+            hb = None if ray_head_bias is None else ray_head_bias.index_select(0, idx).contiguous()
 
             def locate(edges):
                 dist = ((edges[:, 1:] + edges[:, :-1]) / 2).contiguous()
@@ -467,7 +473,7 @@ class TetraRenderer:
                     weights_c = cpp.render_pass(lists, ridx, edges, self.field, None, w)
                     edges = fine_edges(edges, weights_c)
                 cpp.render_pass(lists, ridx, edges, self.field, directions[idx].contiguous(), w, out=(rgb, acc, depth),
-                                background=bg, clamp=True)
+                                background=bg, clamp=True, ray_head_bias=hb)
                 return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
             traced = locate(edges)
             if self.S_fine > 0:
@@ -480,7 +486,7 @@ class TetraRenderer:
                 S = edges.shape[1] - 1
             # gather + MLP + heads in one kernel (no [64, n] feature buffer)
             sigma, col = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
-                                                directions[idx].contiguous(), w, S, mode=mode)
+                                                directions[idx].contiguous(), w, S, mode=mode, ray_head_bias=hb)
             rgb_r, acc_r, depth_r = cpp.composite(sigma.view(-1, S), col.view(-1, S, 3), edges, background=bg, clamp=True)
             rgb[idx] = rgb_r
             acc[idx] = acc_r
@@ -489,7 +495,8 @@ class TetraRenderer:
 
     def render_train(self, origins: torch.Tensor, directions: torch.Tensor, gradient_scaling: bool = False,
                      generator: Optional[torch.Generator] = None, rand: Optional[Dict[str, torch.Tensor]] = None,
-                     fused: bool = True, capture: Optional[dict] = None, background=None) -> Dict[str, torch.Tensor]:
+                     fused: bool = True, capture: Optional[dict] = None, background=None,
+                     ray_head_bias: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """One training forward (TetrahedraNerf.get_outputs in training mode, model.py:520-662): stratified coarse samples
         (uniform or biased), optional PDF fine pass on the detached coarse weights (nerfstudio's PDFSampler detaches
         them), gather + MLP + heads, optional GradientScaler, weights and renderers (training mode: no clamp) --
@@ -585,6 +592,10 @@ class TetraRenderer:
                 traced = locate(edges)
                 S = edges.shape[1] - 1
         dirs = directions[idx].contiguous()
+        # per-ray bias of the head layer (appearance embedding; fused path only): differentiable w.r.t. the caller's tensor
+        hb = None if ray_head_bias is None else ray_head_bias.index_select(0, idx).contiguous()
+        if hb is not None and not fused:
+            raise RuntimeError("ray_head_bias is an input of the fused kernels; the PyTorch statement takes the model's own modules")
         vi, bc = traced["vertex_indices"], traced["barycentric_coordinates"]
         if capture is not None:   # the (non-differentiable) sample placement, for tests that restate the rest in float64
             capture.update(idx=idx, vertex_indices=vi, barycentric_coordinates=bc, edges=edges, dirs=dirs,
@@ -594,14 +605,15 @@ class TetraRenderer:
             # beyond 2^22 samples (nerfstudio trains on 4096 rays) go through several nodes, one per block of rays
             rays_per_node = max(1, int(self.train_node_samples) // S)
             if r <= rays_per_node:
-                sigma, col = _FusedMlpFunction.apply(vi, bc, self.field, dirs, S, *w)
+                sigma, col = _FusedMlpFunction.apply(vi, bc, self.field, dirs, S, hb, *w)
             else:
                 parts = [_FusedMlpFunction.apply(vi[a:a + rays_per_node], bc[a:a + rays_per_node], self.field,
-                                                 dirs[a:a + rays_per_node], S, *w) for a in range(0, r, rays_per_node)]
+                                                 dirs[a:a + rays_per_node], S, None if hb is None else hb[a:a + rays_per_node], *w)
+                         for a in range(0, r, rays_per_node)]
                 sigma, col = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
             sigma, col = sigma.view(-1, S), col.view(-1, S, 3)
         elif fused:               # no graph: the plain forward kernel, nothing saved
-            sigma, col = cpp.mlp_forward_gather(vi, bc, self.field, dirs, w, S)
+            sigma, col = cpp.mlp_forward_gather(vi, bc, self.field, dirs, w, S, ray_head_bias=hb)
             sigma, col = sigma.view(-1, S), col.view(-1, S, 3)
         else:
             interpolate_values = self._interpolate_values

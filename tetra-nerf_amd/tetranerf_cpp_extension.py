@@ -573,7 +573,18 @@ def mlp_forward(feats_fm, dirs, weights, samples_per_ray, mode="fp32"):
     return sigma, rgb
 
 
-def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray, mode="fp32"):
+def _ray_bias(ray_head_bias, rays, dev):
+    """f32 [rays, 128] per-ray bias of the head layer (appearance embedding: include/tetranerf_hip.h) or None"""
+    if ray_head_bias is None:
+        return None
+    _check_input(ray_head_bias, "ray_head_bias")
+    _check(ray_head_bias.dtype == torch.float32 and tuple(ray_head_bias.shape) == (rays, 128) and ray_head_bias.device == dev,
+           "ray_head_bias must be f32 [rays, 128] on the field's device")
+    return ray_head_bias
+
+
+def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray, mode="fp32",
+                       ray_head_bias=None):
     """interpolate_values + mlp_forward in ONE kernel: the wave gathers its samples' features from the
     (vertex-major shadow of the) field straight into MFMA operand registers; the [64, n] feature buffer is never
     written.  vertex_indices i32 [..., 4], barycentric_coordinates f32 [..., 3], field f32 [64, V].
@@ -599,6 +610,7 @@ def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, wei
     with torch.cuda.device(dev):
         _lib.check(_lib.load().tn_mlp_forward_gather(m.handle, n, S, _ptr(vertex_indices), _ptr(barycentric_coordinates),
                                                      _ptr(field_vm), _ptr(dirs), _mode(mode), _ptr(sigma), _ptr(rgb),
+                                                     _ptr(None if density_only else _ray_bias(ray_head_bias, n // S, dev)),
                                                      _stream(dev)))
     return sigma if density_only else (sigma, rgb)
 
@@ -618,7 +630,7 @@ def _background(background, clamp=False):
     return C.byref(_RgbBackground(r, g, b, 1 if clamp else 0))
 
 
-def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, background=1.0, clamp=False):
+def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, background=1.0, clamp=False, ray_head_bias=None):
     """One render pass as ONE launch (tn_render_pass): sample matching + barycentric gather + MLP + composite on the
     trace rows of the hitting rays in place.  trace_lists = (num_visited_cells [R], visited_cells, barycentric_coordinates
     [R,M,2,3], hit_distances [R,M,2], vertex_indices [R,M,4]) as returned by trace_rays; ray_index i32 [r]; edges f32
@@ -646,7 +658,7 @@ def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, b
         if density_only:
             w_out = _empty((r, S), dtype=torch.float32, device=dev)
             _lib.check(lib.tn_render_pass(m.handle, M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S,
-                                          _ptr(edges), _ptr(field_vm), None, None, _ptr(w_out), None, None, None,
+                                          _ptr(edges), _ptr(field_vm), None, None, _ptr(w_out), None, None, None, None,
                                           _stream(dev)))
         else:
             _check_input(dirs, "dirs")
@@ -657,7 +669,7 @@ def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, b
                 _check(x.dtype == torch.float32 and x.size(0) == nv.numel(), f"{name} must be f32 over all rays")
             _lib.check(lib.tn_render_pass(m.handle, M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S,
                                           _ptr(edges), _ptr(field_vm), _ptr(dirs), _background(background, clamp), None, _ptr(rgb), _ptr(acc),
-                                          _ptr(depth), _stream(dev)))
+                                          _ptr(depth), _ptr(_ray_bias(ray_head_bias, r, dev)), _stream(dev)))
     return w_out
 
 
@@ -761,7 +773,7 @@ class MlpSaved:
     __slots__ = ("acts", "masks", "sigma", "rgb", "n", "S")
 
 
-def mlp_forward_gather_train(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray):
+def mlp_forward_gather_train(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray, ray_head_bias=None):
     """mlp_forward_gather (fp32) for training: returns (sigma [n], rgb [n,3], saved) -- `saved` holds 2.3 KB per sample for
     mlp_backward, which then recomputes nothing."""
     for x, name in ((vertex_indices, "vertex_indices"), (barycentric_coordinates, "barycentric_coordinates"),
@@ -790,11 +802,12 @@ def mlp_forward_gather_train(vertex_indices, barycentric_coordinates, field, dir
     with torch.cuda.device(dev):
         _lib.check(_lib.load().tn_mlp_forward_gather_train(m.handle, n, S, _ptr(vertex_indices), _ptr(barycentric_coordinates),
                                                            _ptr(field_vm), _ptr(dirs.contiguous()), _ptr(sv.sigma), _ptr(sv.rgb),
-                                                           C.byref(bs), _stream(dev)))
+                                                           C.byref(bs), _ptr(_ray_bias(ray_head_bias, n // S, dev)), _stream(dev)))
     return sv.sigma, sv.rgb, sv
 
 
-def mlp_backward(saved, vertex_indices, barycentric_coordinates, field, dirs, weights, sigma, rgb, d_sigma, d_rgb):
+def mlp_backward(saved, vertex_indices, barycentric_coordinates, field, dirs, weights, sigma, rgb, d_sigma, d_rgb,
+                 want_ray_head_grad=False):
     """Adjoint of mlp_forward_gather_train (addition; the reference leaves this to PyTorch autograd, model.py:602-630):
     given the forward's outputs sigma [n] / rgb [n,3], dL/dsigma [n] and dL/drgb [n,3] returns (grad_field [64,V], [12 weight
     gradients in the order of `weights`]).
@@ -834,10 +847,16 @@ def mlp_backward(saved, vertex_indices, barycentric_coordinates, field, dirs, we
         _lib.check(lib.tn_mlp_backward(mh.handle, n, _ptr(sigma.contiguous()), _ptr(rgb.contiguous()), _ptr(d_sigma), _ptr(d_rgb),
                                        C.byref(bs), stream))
         _lib.check(lib.tn_mlp_param_grads(mh.handle, n, S, _ptr(dirs), C.byref(bs), C.byref(gs), stream))
+        d_ray_bias = None
+        if want_ray_head_grad:      # gradient of the per-ray head bias: per-ray sums of d4
+            d_ray_bias = _empty((n // S, 128), dtype=torch.float32, device=dev)
+            _lib.check(lib.tn_mlp_ray_head_grad(n, S, C.byref(bs), _ptr(d_ray_bias), stream))
         # gradient of the gathered features -> field (vertex-major accumulation)
         _lib.check(lib.tn_interpolate_values_backward_vm(4, n, 64, _ptr(vi), _ptr(bc), _ptr(rows), _ptr(grad_vm), stream))
         grad_field = _empty((64, V), dtype=torch.float32, device=dev)
         _lib.check(lib.tn_transpose_f32(V, 64, _ptr(grad_vm), _ptr(grad_field), stream))
+    if want_ray_head_grad:
+        return grad_field, grads, d_ray_bias
     return grad_field, grads
 
 
