@@ -542,6 +542,9 @@ class TetraRenderer:
         r = idx.numel()
         record = fused and torch.is_grad_enabled()
         spacing = None            # spacing bins of the final samples (exact only on the PyTorch sampler path)
+        # (outside the no_grad block below: an adapter may hand over differentiable VIEWS of its parameters -- the first
+        # 155 columns of an mlp_head widened by an appearance embedding, nerfstudio_plugin.ModelMLP.fused_weights)
+        w = mlp_weights(self.mlp)
         with torch.no_grad():
             t_rand = rand.get("coarse")
             if t_rand is None:
@@ -561,7 +564,6 @@ class TetraRenderer:
                 return self.tracer.find_visited_cells(*lists, dist, ray_index=ridx)
 
             traced = locate(edges)
-            w = mlp_weights(self.mlp)
             if self.S_fine > 0:
                 if fused:
                     sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
