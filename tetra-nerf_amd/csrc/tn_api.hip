@@ -70,8 +70,6 @@ struct tn_tracer {
     uint32_t *fallback_count() { return reinterpret_cast<uint32_t *>(stats.p + 24); }
     uint32_t *literal_count() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 1; }
     uint32_t *verify_count() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 2; }
-    uint32_t *fill_dispenser() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 3; }
-    unsigned fill_overlap_blocks = 0;    // > 0: a fill of this many blocks starts BESIDE the segment writer (sweeps)
     size_t last_num_rays = 0;
     int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
     size_t walk_min_rays = 12288;        // measured crossover on the 300k-tet mesh after round 2b's faster BVH path
@@ -493,25 +491,11 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 TN_HIP(hipEventRecord(t->ev_aux, t->aux));
                 // the segment writer is enqueued BEFORE the side stream's kernel: its grid is sized for the worst case (the
                 // count lives on the device) and would otherwise take every wave slot first
-                if (t->fill_overlap_blocks && dense_tails) {
-                    // a throttled share of the post-writer fill beside the (latency-bound) writer: both fills pull row chunks
-                    // from one dispenser (cleared by the memset of the counter block at the start of the call)
-                    TN_HIP(hipStreamWaitEvent(t->pre, t->ev_fork, 0));
-                    tn::launch_fill_range(R, M, false, t->walk_n.p, num_visited, visited, bary, dist, verts, t->pre, K0 ? K0 : M, false,
-                                          t->fill_overlap_blocks, t->fill_dispenser());
-                    TN_HIP(hipEventRecord(t->ev_pre, t->pre));
-                }
                 launch_segments(0, R);
                 TN_HIP(hipEventRecord(t->ev_seg, stream));
                 TN_HIP(hipStreamWaitEvent(t->side, t->ev_seg, 0));   // literal pairing beside the bandwidth-bound fill, not
                 launch_literal(0, R, t->side);                       // beside the latency-bound writer (r02f_sched_sweep.txt)
-                if (t->fill_overlap_blocks && dense_tails) {
-                    tn::launch_fill_range(R, M, false, t->walk_n.p, num_visited, visited, bary, dist, verts, stream, K0 ? K0 : M, false,
-                                          0, t->fill_dispenser());
-                    TN_HIP(hipStreamWaitEvent(stream, t->ev_pre, 0));
-                } else {
-                    launch_fill(0, R, K0 ? K0 : M);
-                }
+                launch_fill(0, R, K0 ? K0 : M);
                 TN_HIP(hipEventRecord(t->ev_join, t->side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_aux, 0));
@@ -706,7 +690,6 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (k == "spec_fill") t->spec_fill = value != 0;
         else if (k == "spec_k0") t->spec_k0 = (unsigned)value;
         else if (k == "spec_blocks") t->spec_blocks = (unsigned)value;
-        else if (k == "fill_overlap_blocks") t->fill_overlap_blocks = (unsigned)value;
         else if (k == "walk_lds_kb") t->walk_lds_kb = (unsigned)value;
         else if (k == "small_lds") t->small_lds = value != 0;
         else if (k == "lds_cap") {

@@ -90,7 +90,7 @@ void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned ma
 // all_rows: slots [k_split, M) of every row; otherwise slots [ceil32(out_num[r]), k_split) of the certified rows
 void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *walk_n, const uint32_t *out_num,
                        uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
-                       uint32_t k_split, bool nontemporal, unsigned max_blocks = 0, uint32_t *dispenser = nullptr);
+                       uint32_t k_split, bool nontemporal, unsigned max_blocks = 0);
 
 // sample -> segment matching (tn_match.hip)
 void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,

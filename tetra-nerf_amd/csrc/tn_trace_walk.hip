@@ -641,28 +641,17 @@ void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned ma
 //                 fill, tn_api.hip).  Rows of literal / fallback rays and rays with more than k_split segments are
 //                 included: the kernels that write those slots are ordered behind this one.
 //   all_rows = 0: slots [ceil32(n), k_split) of the certified rows (k_write_segments has written [0, ceil32(n))).
-//   dispenser != null: the rows are handed out in chunks of FILL_CHUNK through an atomic counter instead of one static
-//                 span per wave, so that SEVERAL launches can share one pass over the rows: a small grid started beside the
-//                 segment writer (throttled by its size) and the full grid after it both pull chunks until none is left.
-constexpr uint32_t FILL_CHUNK = 16;
 template <bool NT>
 __global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M, uint32_t all_rows, uint32_t k_split,
                                                     const uint32_t *__restrict__ walk_n, const uint32_t *__restrict__ out_num,
                                                     uint32_t *__restrict__ out_cells,
                                                     float *__restrict__ out_bary, float *__restrict__ out_dist,
-                                                    uint32_t *__restrict__ out_verts, uint32_t *__restrict__ dispenser) {
+                                                    uint32_t *__restrict__ out_verts) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // row span, row bases: scalar
     const size_t nwaves = (size_t)gridDim.x * 4;
-    const size_t span = dispenser ? FILL_CHUNK : (num_rays + nwaves - 1) / nwaves;   // consecutive rows are consecutive in memory
-    size_t r0 = ((size_t)blockIdx.x * 4 + wave) * span;
-    for (;;) {
-    if (dispenser) {
-        uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(dispenser, 1u);
-        r0 = (size_t)__builtin_amdgcn_readfirstlane((int)c) * FILL_CHUNK;
-        if (r0 >= num_rays) return;
-    }
+    const size_t span = (num_rays + nwaves - 1) / nwaves;   // consecutive rows are consecutive in memory
+    const size_t r0 = ((size_t)blockIdx.x * 4 + wave) * span;
     const size_t r1 = r0 + span < num_rays ? r0 + span : num_rays;
     for (size_t r = r0; r < r1; ++r) {
         uint32_t lo = k_split, hi = M;
@@ -678,13 +667,11 @@ __global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M,
         fill_dwords<NT>(reinterpret_cast<uint32_t *>(out_bary + r * M * 6), 6 * lo, 6 * hi, 0u, lane);
         if (out_verts) fill_dwords<NT>(out_verts + r * M * 4, 4 * lo, 4 * hi, TN_EMPTY, lane);
     }
-    if (!dispenser) return;
-    }
 }
 
 void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *walk_n, const uint32_t *out_num,
                        uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
-                       uint32_t k_split, bool nontemporal, unsigned max_blocks, uint32_t *dispenser) {
+                       uint32_t k_split, bool nontemporal, unsigned max_blocks) {
     if (num_rays == 0) return;
     size_t blocks = (num_rays + 3) / 4;           // >= one ray per wave
     // after the writer: 2 blocks (8 waves) per CU hold the write ceiling, and the latency-bound kernels running beside
@@ -694,10 +681,10 @@ void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_
     if (blocks > cap) blocks = cap;
     if (nontemporal)
         hipLaunchKernelGGL(k_fill_range<true>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split,
-                           walk_n, out_num, out_cells, out_bary, out_dist, out_verts, dispenser);
+                           walk_n, out_num, out_cells, out_bary, out_dist, out_verts);
     else
         hipLaunchKernelGGL(k_fill_range<false>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split,
-                           walk_n, out_num, out_cells, out_bary, out_dist, out_verts, dispenser);
+                           walk_n, out_num, out_cells, out_bary, out_dist, out_verts);
 }
 
 // 64-byte build records -> the three consumer tables (tn_common.h: WalkHot / WalkCold / WalkFid)
