@@ -222,6 +222,45 @@ def test_writer_tables_agree(tn, device, scenes, bottle):
             assert torch.equal(a[m].view(torch.int32), b[m].view(torch.int32)) and torch.equal(a[m].view(torch.int32), c[m].view(torch.int32)), (name, k)
 
 
+def test_cross_check_hand_over_paths(tn, device, scenes):
+    """The always-on count cross-check never finds a mismatch on its own, so its hand-over is exercised by injection
+    (option verify_inject: every checked ray counts as a mismatch): in the late form (one-chunk call: the check runs beside the
+    writer and the fill, the rays are re-traced through the BVH AFTER their rows were written as certified) and in the serial
+    form (chunked call: the rows are skipped by the writer and the fill) the rows must come out bit-identical, dense and
+    compact, and every checked ray must be counted as handed over."""
+    import torch
+
+    pts, cells = scenes.random_mesh(6000, 13)
+    o, d = scenes.outside_in_rays(60000, 14)
+    to, td = torch.from_numpy(o).to(device), torch.from_numpy(d).to(device)
+    tr = _tracer(tn, device, pts, cells, 1)
+    tr.set_option("verify_stride", 0)
+    ref = tr.trace_rays(to, td, 256)
+    for chunked in (False, True):
+        tr.set_option("log_cap_mb", 48 if chunked else 0)
+        for stride in (1, 7):
+            tr.set_option("verify_stride", stride)
+            tr.set_option("verify_inject", 1)
+            got = tr.trace_rays(to, td, 256)
+            why = tr.flag_reasons()
+            assert why.get(15, 0) > 0.8 * len(o) / stride and why.get(14, 0) == why.get(15, 0), (chunked, stride, why)
+            for k in KEYS:
+                assert torch.equal(ref[k].view(torch.int32), got[k].view(torch.int32)), (chunked, stride, k)
+            lean = tr.trace_rays(to, td, 256, compact_rows=True)
+            n = ref["num_visited_cells"]
+            assert torch.equal(n, lean["num_visited_cells"])
+            valid = torch.arange(256, device=device)[None] < n[:, None]
+            for k in KEYS[1:]:
+                a, b = ref[k], lean[k]
+                m = valid.reshape(valid.shape + (1,) * (a.dim() - 2)).expand_as(a)
+                assert torch.equal(a[m].view(torch.int32), b[m].view(torch.int32)), (chunked, stride, k)
+            tr.set_option("verify_inject", 0)
+            clean = tr.trace_rays(to, td, 256)
+            assert tr.flag_reasons().get(14, 0) == 0
+            for k in KEYS:
+                assert torch.equal(ref[k].view(torch.int32), clean[k].view(torch.int32)), (chunked, stride, k)
+
+
 def test_chunked_log_equals_single_launch(tn, device, scenes):
     """Calls whose hit log would exceed the cap are walked and written in ray chunks: same bits."""
     pts, cells = scenes.random_mesh(6000, 13)

@@ -56,6 +56,7 @@ struct tn_tracer {
     // costs +0.9 / +2.9 / +3.7 % on the C2 / C4 frame / the C5 rays, stride 16 +6 / +13 / +21 % -- linear in the rays
     // checked -- so the default is 256: +0.2 / +0.7 / +0.9 %
     unsigned verify_stride = 256;
+    bool verify_inject = false;          // tests: every cross-checked ray is treated as a mismatch (exercises the hand-over)
     tn::DevBuf<uint32_t> verify_list;    // certified rays whose count differed: re-traced by the BVH kernel at the end of the call
     tn::DevBuf<tn::WalkVar> vars;        // the build's 64-byte records: split into the three tables below, then released
     tn::DevBuf<tn::WalkHot> hot;
@@ -422,7 +423,8 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 w.ray_base = base;
                 tn::launch_trace_walk(w, stream, walk_reserve);
                 if (t->verify_stride && !single)   // chunked call: serially, before anything that reads walk_n / the fallback list
-                    tn::launch_verify_counts(w.t, t->verify_stride, w.walk_n, w.fallback_list, w.fallback_count, base, stream);
+                    tn::launch_verify_counts(w.t, t->verify_stride, w.walk_n, w.fallback_list, w.fallback_count, base, stream, false,
+                                             t->verify_inject);
             };
             auto launch_segments = [&](size_t base, size_t n) {
                 tn::WriteParams q{};
@@ -486,7 +488,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                     const size_t n_checks = (R + t->verify_stride - 1) / t->verify_stride;
                     if (t->verify_list.n < n_checks) t->verify_list.alloc(n_checks);
                     tn::launch_verify_counts(chunk_params(0, R), t->verify_stride, t->walk_n.p, t->verify_list.p, t->verify_count(), 0,
-                                             t->aux, true);
+                                             t->aux, true, t->verify_inject);
                 }
                 TN_HIP(hipEventRecord(t->ev_aux, t->aux));
                 // the segment writer is enqueued BEFORE the side stream's kernel: its grid is sized for the worst case (the
@@ -697,6 +699,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
             t->lds_cap = (unsigned)value;
         }
         else if (k == "writer_table") t->writer_table = value;   // applies at the next load_tetrahedra
+        else if (k == "verify_inject") t->verify_inject = value != 0;
         else if (k == "verify_stride") t->verify_stride = value < 0 ? 0u : (unsigned)value;
         else if (k == "log_cap_mb") t->log_cap_bytes = value <= 0 ? 0 : (size_t)value << 20;
         else throw tn::Error("unknown option " + (name ? k : std::string("(null)")));

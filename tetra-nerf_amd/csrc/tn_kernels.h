@@ -68,7 +68,7 @@ void launch_postprocess_log(const TraceParams &p, const WalkFid *fidt, const uin
 // TraceParams of the walk launch; mismatching rays are appended to the fallback list (global ids: ray_base + index)
 // late: mismatching rays only go to the list (their rows are re-traced at the end of the call), walk_n stays
 void launch_verify_counts(const TraceParams &p, uint32_t stride, uint32_t *walk_n, uint32_t *fallback_list, uint32_t *fallback_count,
-                          size_t ray_base, hipStream_t stream, bool late = false);
+                          size_t ray_base, hipStream_t stream, bool late = false, bool inject = false);
 
 // hit log -> rows of the rays the walk certified (walk_n[ray] != TN_EMPTY): k_write_segments writes the segment records
 // + the tail constants up to the next multiple of 32 slots (a 128-byte line boundary in all four row arrays);

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const Wal
 // everything else of the call has been joined.
 __global__ __launch_bounds__(64) void k_verify_counts(TraceParams p, uint32_t stride, uint32_t *__restrict__ walk_n,
                                                       uint32_t *__restrict__ fallback_list, uint32_t *__restrict__ fallback_count,
-                                                      size_t ray_base, uint32_t late) {
+                                                      size_t ray_base, uint32_t late, uint32_t inject) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WaveSmem s = carve(smem, p.M);
     const int lane = threadIdx.x;
@@ -573,7 +573,9 @@ __global__ __launch_bounds__(64) void k_verify_counts(TraceParams p, uint32_t st
                                          p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2], nullptr, lane, overflow);
         if (lane == 0) {
             if (p.stats) atomicAdd(&p.stats[4 + 15], 1ull);
-            if (nh != wn || overflow) {
+            // inject (tests): every checked ray is treated as a mismatch, so that the hand-over -- incl. the late form's
+            // re-trace of rows the writer and the fills have already written -- is exercised although no real mismatch exists
+            if (nh != wn || overflow || inject) {
                 if (!late) walk_n[ray] = TN_EMPTY;   // the segment writer and the fill skip the row: the BVH kernel writes it
                 fallback_list[atomicAdd(fallback_count, 1u)] = (uint32_t)(ray_base + ray);
                 if (p.stats) atomicAdd(&p.stats[4 + 14], 1ull);
@@ -707,12 +709,12 @@ void launch_trace_general(const TraceParams &p, hipStream_t stream) {
 }
 
 void launch_verify_counts(const TraceParams &p, uint32_t stride, uint32_t *walk_n, uint32_t *fallback_list, uint32_t *fallback_count,
-                          size_t ray_base, hipStream_t stream, bool late) {
+                          size_t ray_base, hipStream_t stream, bool late, bool inject) {
     if (p.num_items == 0 || stride == 0) return;
     const size_t smem = wave_smem(k_verify_counts, p.M);
     const size_t n_checks = (p.num_items + stride - 1) / stride, max_blocks = 256 * 16;
     hipLaunchKernelGGL(k_verify_counts, dim3((unsigned)(n_checks < max_blocks ? n_checks : max_blocks)), dim3(64), smem, stream, p, stride,
-                       walk_n, fallback_list, fallback_count, ray_base, late ? 1u : 0u);
+                       walk_n, fallback_list, fallback_count, ray_base, late ? 1u : 0u, inject ? 1u : 0u);
 }
 
 void launch_postprocess_log(const TraceParams &p, const WalkFid *fidt, const uint4 *hit_log, const uint2 *literal_list,
