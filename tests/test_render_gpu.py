@@ -313,3 +313,36 @@ def test_bf16x3_error_bound_per_layer(tn, device, render, scale_w, scale_x):
             err = (y - y64).abs()
             assert int(ok.sum()) > n // 4
             assert bool((err[ok] <= bound[ok] + 4e-7 * y64.abs()[ok]).all()), (mode, k, float((err[ok] / bound[ok]).max()))
+
+
+def test_ray_head_bias_on_every_forward_kernel(tn, device, scenes):
+    """The per-ray head bias (appearance embedding) is added by four kernels -- the one-launch render pass,
+    the fp32 gather + MLP kernel of the kernel chain, its bf16x3 form, and the training forward (against the reference body:
+    tests/test_reference_model_gpu.py) -- which must agree with each other, and a zero bias must reproduce the call without
+    one bit for bit."""
+    import torch
+
+    render = importlib.import_module("tetra-nerf_amd.render")
+    pts, cells = scenes.random_mesh(5000, 9)
+    tr = tn.TetrahedraTracer(device)
+    tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+    torch.manual_seed(2)
+    mlp = render.TetraMLP().to(device)
+    field = torch.randn(64, len(pts), device=device) * 0.5
+    o, d = scenes.outside_in_rays(3000, 4)
+    to, td = torch.from_numpy(o).to(device), torch.from_numpy(d).to(device)
+    bias = torch.randn(len(o), 128, device=device) * 0.7
+    outs = {}
+    for name, kw in (("one launch", dict(fused_pass=True)), ("chain fp32", dict(fused_pass=False)),
+                     ("chain bf16x3", dict(fused_pass=False, mlp_mode="bf16x3"))):
+        rd = render.TetraRenderer(tr, field, mlp, 64, 256, fused=True, num_fine_samples=64, **kw)
+        plain = rd.render(to, td)
+        zero = rd.render(to, td, ray_head_bias=torch.zeros_like(bias))
+        for k in ("rgb", "accumulation", "depth"):
+            assert torch.equal(plain[k], zero[k]), (name, k)
+        outs[name] = rd.render(to, td, ray_head_bias=bias)
+        assert float((outs[name]["rgb"] - plain["rgb"]).abs().max()) > 1e-2, name        # the bias acts
+        assert torch.equal(outs[name]["accumulation"], plain["accumulation"]), name      # ... on the colours only
+    ref = outs["chain fp32"]
+    np.testing.assert_allclose(outs["one launch"]["rgb"].cpu().numpy(), ref["rgb"].cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(outs["chain bf16x3"]["rgb"].cpu().numpy(), ref["rgb"].cpu().numpy(), rtol=0, atol=1e-5)
