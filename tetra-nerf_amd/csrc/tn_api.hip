@@ -774,16 +774,7 @@ int tn_interpolate_values_backward_vm(uint32_t D, uint32_t n, uint32_t Fd, const
 
 struct tn_mlp {
     int device = 0;
-    tn::DevBuf<float> pk_plain, pk_gather, pt, enc, grad_scratch, rgb_scratch;
-    // tn_mlp_param_grads: the bandwidth-bound rgb-head pass runs on `side` beside the MFMA-bound weight-gradient GEMMs
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool grad_overlap = true;            // TETRANERF_HIP_GRAD_OVERLAP=0: everything on the caller's stream (A/B)
-    ~tn_mlp() {
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side) (void)hipStreamDestroy(side);
-    }
+    tn::DevBuf<float> pk_plain, pk_gather, pt, enc, grad_scratch;
     tn::DevBuf<uint4> blob;
     tn::DevBuf<uint32_t> nvh;
     bool packed = false;
@@ -829,10 +820,6 @@ int tn_mlp_create(int device, tn_mlp_t *out) {
         m->pk_gather.alloc(tn::mlp_pack_floats());
         m->pt.alloc(tn::mlp_backward_pack_floats());
         m->blob.alloc(tn::mlp_x3_blob_u4());
-        TN_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-        TN_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-        TN_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
-        if (const char *e = std::getenv("TETRANERF_HIP_GRAD_OVERLAP")) m->grad_overlap = std::atoi(e) != 0;
         *out = m.release();
     });
 }
@@ -988,21 +975,10 @@ int tn_mlp_param_grads(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const f
         if (!m->grad_scratch.p) {   // first training call of this handle
             TN_HIP(hipDeviceSynchronize());
             m->grad_scratch.alloc(tn::mlp_param_grad_scratch_floats());
-            m->rgb_scratch.alloc(tn::mlp_rgb_head_grad_scratch_floats());
         }
         const tn::MlpBackwardBuffers bb = training_buffers(b);
         tn::MlpParamGrads pg{gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], gp[6], gp[7], gp[8], gp[9], gp[10], gp[11]};
-        hipStream_t stream = (hipStream_t)stream_;
-        if (m->grad_overlap) {
-            TN_HIP(hipEventRecord(m->ev_fork, stream));
-            TN_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-            tn::launch_mlp_rgb_head_grad(n, bb, pg, m->rgb_scratch.p, m->side);
-            TN_HIP(hipEventRecord(m->ev_join, m->side));
-            tn::launch_mlp_param_grads(n, samples_per_ray, dirs, m->packs(n / samples_per_ray), bb, pg, stream, false);
-            TN_HIP(hipStreamWaitEvent(stream, m->ev_join, 0));
-        } else {
-            tn::launch_mlp_param_grads(n, samples_per_ray, dirs, m->packs(n / samples_per_ray), bb, pg, stream);
-        }
+        tn::launch_mlp_param_grads(n, samples_per_ray, dirs, m->packs(n / samples_per_ray), bb, pg, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
 }

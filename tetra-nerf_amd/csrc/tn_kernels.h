@@ -180,10 +180,7 @@ void launch_ray_head_grad(size_t n, uint32_t samples_per_ray, const float *d4, f
 struct MlpParamGrads { float *w1, *b1, *w2, *b2, *w3, *b3, *wd, *bd, *wh, *bh, *wr, *br; };
 size_t mlp_param_grad_scratch_floats();
 void launch_mlp_param_grads(size_t n, uint32_t samples_per_ray, const float *dirs, const MlpPacks &w, const MlpBackwardBuffers &b,
-                            const MlpParamGrads &g, hipStream_t stream, bool with_rgb_head = true);
-// the rgb head's share of it alone (d wr, d bd, d br: one pass over h4), on its own scratch: runs beside the GEMMs
-size_t mlp_rgb_head_grad_scratch_floats();
-void launch_mlp_rgb_head_grad(size_t n, const MlpBackwardBuffers &b, const MlpParamGrads &g, float *scratch, hipStream_t stream);
+                            const MlpParamGrads &g, hipStream_t stream);
 // background colour of the RGB renderer (RGBRenderer.combine_rgb: comp + background (1 - accumulation)) and its evaluation-mode
 // behaviour (RGBRenderer.forward when not training: nan_to_num of the sample colours, result clamped to [0, 1])
 struct Background { float r, g, b; int clamp; };

@@ -300,19 +300,9 @@ void run_dw(size_t n, const DwArgs &g, ReduceArgs r, hipStream_t stream) {
 }  // namespace
 
 size_t mlp_param_grad_scratch_floats() { return (size_t)DW_GRID * (128 * 160 + 256); }
-size_t mlp_rgb_head_grad_scratch_floats() { return (size_t)DW_GRID * RGB_SLOT; }
-
-// d wr, d bd, d br: ONE bandwidth-bound pass over h4 (528 B per sample), independent of the four weight-gradient GEMMs -- the
-// entry point runs it on a side stream beside them (they are MFMA-bound), on a scratch of its own
-void launch_mlp_rgb_head_grad(size_t n, const MlpBackwardBuffers &b, const MlpParamGrads &g, float *scratch, hipStream_t stream) {
-    if (n == 0) return;
-    const Slicing sl = slicing(n, 128);
-    hipLaunchKernelGGL(k_rgb_head_grad, dim3(sl.grid), dim3(256), 0, stream, n, sl.slice, b.dhead, b.h4, scratch);
-    hipLaunchKernelGGL(k_reduce_rgb, dim3((RGB_SLOT + 63) / 64), dim3(256), 0, stream, scratch, sl.grid, g.wr, g.bd, g.br);
-}
 
 void launch_mlp_param_grads(size_t n, uint32_t samples_per_ray, const float *dirs, const MlpPacks &w, const MlpBackwardBuffers &b,
-                            const MlpParamGrads &g, hipStream_t stream, bool with_rgb_head) {
+                            const MlpParamGrads &g, hipStream_t stream) {
     if (n == 0) return;
     if (n > 0xFFFFFFFFull) throw Error("param_grads: more than 2^32 samples per call");
     launch_dir_encoding(n / samples_per_ray, dirs, w.enc, stream);
@@ -326,7 +316,9 @@ void launch_mlp_param_grads(size_t n, uint32_t samples_per_ray, const float *dir
                      ReduceArgs{nullptr, 0, 0, 0, g.w2, HID, nullptr, 0, g.b2, nullptr}, stream);
     run_dw<2, false>(n, DwArgs{b.d1, b.x0, nullptr, nullptr, 0, part},
                      ReduceArgs{nullptr, 0, 0, 0, g.w1, FD, nullptr, 0, g.b1, nullptr}, stream);
-    if (with_rgb_head) launch_mlp_rgb_head_grad(n, b, g, part, stream);
+    const Slicing sl = slicing(n, 128);
+    hipLaunchKernelGGL(k_rgb_head_grad, dim3(sl.grid), dim3(256), 0, stream, n, sl.slice, b.dhead, b.h4, part);
+    hipLaunchKernelGGL(k_reduce_rgb, dim3((RGB_SLOT + 63) / 64), dim3(256), 0, stream, part, sl.grid, g.wr, g.bd, g.br);
 }
 
 }  // namespace tn

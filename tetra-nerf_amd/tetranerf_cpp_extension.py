@@ -762,17 +762,6 @@ def composite(sigma, rgb, edges, background=1.0, return_weights=False, clamp=Fal
     return (out_rgb, acc, depth, weights) if return_weights else (out_rgb, acc, depth)
 
 
-_GRAD_OVERLAP = os.environ.get("TETRANERF_HIP_GRAD_OVERLAP", "1") != "0"    # (also read by the library: tn_mlp_param_grads)
-_SIDE_STREAMS = {}
-
-
-def _side_stream(dev):
-    s = _SIDE_STREAMS.get(dev)
-    if s is None:
-        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
-    return s
-
-
 class _MlpBackwardBuffers(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("x0", "h1", "h2", "h3", "h4", "masks", "d1", "d2", "d3", "d4", "dhead", "dx0")]
 
@@ -854,32 +843,18 @@ def mlp_backward(saved, vertex_indices, barycentric_coordinates, field, dirs, we
                              a[448:576].data_ptr(), saved.masks.data_ptr(), buf[0:128].data_ptr(), buf[128:256].data_ptr(),
                              buf[256:384].data_ptr(), buf[384:512].data_ptr(), buf[512:516].data_ptr(), rows.data_ptr())
     stream = _stream(dev)
-    grad_field = _empty((64, V), dtype=torch.float32, device=dev)
-    d_ray_bias = _empty((n // S, 128), dtype=torch.float32, device=dev) if want_ray_head_grad else None
     with torch.cuda.device(dev):
         _lib.check(lib.tn_mlp_backward(mh.handle, n, _ptr(sigma.contiguous()), _ptr(rgb.contiguous()), _ptr(d_sigma), _ptr(d_rgb),
                                        C.byref(bs), stream))
-
-        def gather_adjoint(st):     # gradient of the gathered features -> field (vertex-major atomic accumulation, transposed back)
-            _lib.check(lib.tn_interpolate_values_backward_vm(4, n, 64, _ptr(vi), _ptr(bc), _ptr(rows), _ptr(grad_vm), st))
-            _lib.check(lib.tn_transpose_f32(V, 64, _ptr(grad_vm), _ptr(grad_field), st))
-
-        if _GRAD_OVERLAP:
-            # the gather adjoint (atomics-bound, 0.25-0.3 ms per 4096-ray batch) needs only dx0 of the dX kernel: it runs on a
-            # side stream BESIDE the MFMA-bound weight-gradient GEMMs of tn_mlp_param_grads (which itself runs its
-            # bandwidth-bound rgb-head pass on a side stream of the handle).  Every buffer it touches was allocated on the
-            # caller's stream and stays referenced until the join below is enqueued.
-            main = torch.cuda.current_stream(dev)
-            side = _side_stream(dev)
-            side.wait_stream(main)
-            gather_adjoint(side.cuda_stream)
         _lib.check(lib.tn_mlp_param_grads(mh.handle, n, S, _ptr(dirs), C.byref(bs), C.byref(gs), stream))
+        d_ray_bias = None
         if want_ray_head_grad:      # gradient of the per-ray head bias: per-ray sums of d4
+            d_ray_bias = _empty((n // S, 128), dtype=torch.float32, device=dev)
             _lib.check(lib.tn_mlp_ray_head_grad(n, S, C.byref(bs), _ptr(d_ray_bias), stream))
-        if _GRAD_OVERLAP:
-            main.wait_stream(side)
-        else:
-            gather_adjoint(stream)
+        # gradient of the gathered features -> field (vertex-major accumulation)
+        _lib.check(lib.tn_interpolate_values_backward_vm(4, n, 64, _ptr(vi), _ptr(bc), _ptr(rows), _ptr(grad_vm), stream))
+        grad_field = _empty((64, V), dtype=torch.float32, device=dev)
+        _lib.check(lib.tn_transpose_f32(V, 64, _ptr(grad_vm), _ptr(grad_field), stream))
     if want_ray_head_grad:
         return grad_field, grads, d_ray_bias
     return grad_field, grads
