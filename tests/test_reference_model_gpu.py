@@ -113,15 +113,19 @@ TRAIN_CONFIGS = [dict(num_samples=64, num_fine_samples=64),
                  dict(num_samples=128, num_fine_samples=128, use_biased_sampler=True, use_gradient_scaling=True),
                  # appearance embedding: training = the embedding of every ray's camera; gradients reach the embedding table
                  # and all 155 + E columns of mlp_head
-                 dict(num_samples=64, num_fine_samples=64, use_gradient_scaling=True, appearance_embed_dim=8)]
+                 dict(num_samples=64, num_fine_samples=64, use_gradient_scaling=True, appearance_embed_dim=8),
+                 # the shipped `tetra-nerf-original` at the batch size nerfstudio trains with: 4096 rays x (256 + 513) samples
+                 dict(num_samples=256, num_fine_samples=256, _rays=4096)]
 
 
 @pytest.mark.parametrize("cfg", TRAIN_CONFIGS)
 def test_fused_adapter_training_equals_the_reference_body(tn, device, scenes, ref, plugin, cfg):
     import torch
 
+    cfg = dict(cfg)
+    n_rays = cfg.pop("_rays", 2048)
     model = _model(ref, scenes, device, **cfg).train()
-    o, d = scenes.outside_in_rays(2048, 33)
+    o, d = scenes.outside_in_rays(n_rays, 33)
     rb = rm.ray_bundle(ref, o, d, device, camera_indices=np.arange(len(o)) % 3)
     target = torch.rand(len(o), 3, device=device)
     params = [model.tetrahedra_field] + plugin.weights_from_model(model)
