@@ -145,3 +145,32 @@ def test_scatter_ema_uint32(tn, device):
         t2 = torch.rand((5, 3), device=device)
         tn.scatter_ema_uint32_(t2, 0, torch.randint(0, 3, (5, 8), dtype=torch.int32, device=device), 0.5,
                                torch.rand((5, 8), device=device))
+
+
+def test_stale_field_cache_is_caught_by_the_debug_check(tn, device):
+    """A registered field written through `.data` keeps its cached vertex-major shadow (no version counter moves): the
+    documented contract is invalidate_field_cache(); TETRANERF_HIP_CHECK_CACHES=1 turns the silent staleness into an error."""
+    import torch
+
+    cpp = tn.cpp
+    field = torch.randn(64, 500, device=device)
+    vi = torch.randint(0, 500, (1000, 4), dtype=torch.int32, device=device)
+    bc = torch.rand(1000, 3, device=device) * 0.3
+    cpp.register_field(field)
+    try:
+        a = cpp.interpolate_values(vi, bc, field).clone()
+        field.data[3] += 1.0                                    # no version bump
+        stale = cpp.interpolate_values(vi, bc, field)
+        assert torch.equal(a, stale)                            # the documented hazard
+        old = cpp._CHECK_CACHES
+        cpp._CHECK_CACHES = True
+        try:
+            with pytest.raises(RuntimeError, match="STALE"):
+                cpp.interpolate_values(vi, bc, field)
+            cpp.invalidate_field_cache(field)
+            fresh = cpp.interpolate_values(vi, bc, field)
+            assert not torch.equal(a, fresh)
+        finally:
+            cpp._CHECK_CACHES = old
+    finally:
+        cpp.unregister_field(field)

@@ -314,6 +314,9 @@ class TetrahedraTracer:
 # invalidate it from the model's initialisation hook; `TetrahedraTracer.load_tetrahedra` invalidates everything.
 # A cached shadow remembers the event that ends its transposition: a consumer on another stream waits for it.
 _FIELD_VM = {}        # id(tensor) -> (weakref, version, data_ptr, shadow, event)
+# TETRANERF_HIP_CHECK_CACHES=1 (debug): every use of a cached field shadow compares it with the field (a device-wide
+# comparison + synchronisation per call: for hunting stale caches, not for production)
+_CHECK_CACHES = os.environ.get("TETRANERF_HIP_CHECK_CACHES", "0") == "1"
 
 
 def register_field(field):
@@ -369,6 +372,10 @@ def field_vertex_major(field):
     if hit[1] == field._version and hit[2] == field.data_ptr() and hit[3] is not None:
         cur = torch.cuda.current_stream(field.device)
         cur.wait_event(hit[4])   # no-op on the producing stream; orders a consumer on another stream
+        if _CHECK_CACHES and not torch.equal(hit[3], field.detach().t()):
+            # (debug aid, TETRANERF_HIP_CHECK_CACHES=1: a write through `.data` / a raw pointer bumps no version counter)
+            raise RuntimeError("the cached vertex-major shadow of a registered field is STALE: the field was written through "
+                               ".data or a raw pointer without cpp.invalidate_field_cache(field)")
         return hit[3]
     ft = _transpose_field(field)
     ev = torch.cuda.Event()
