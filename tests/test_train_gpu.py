@@ -246,7 +246,8 @@ def test_render_train_sync_free(tn, device, scenes):
         field = ((torch.rand(64, len(pts), device=device) * 2 - 1) * 0.5).requires_grad_(True)
         params = [field] + list(mlp.parameters())
         opt = torch.optim.SGD(params, lr=1e-4)
-        free = render.TetraRenderer(tr, field, mlp, S, 256, fused=True, num_fine_samples=S_fine, biased=biased)
+        free = render.TetraRenderer(tr, field, mlp, S, 256, fused=True, num_fine_samples=S_fine, biased=biased,
+                                    sync_free_min_hits=0.0)     # (never fall back to compaction: see the adaptive test below)
         sync = render.TetraRenderer(tr, field, mlp, S, 256, fused=True, num_fine_samples=S_fine, biased=biased, sync_free_train=False)
         assert free.sync_free_train and not sync.sync_free_train
         for case in ("all hit", "a third misses", "all miss"):
@@ -302,3 +303,46 @@ def test_render_train_sync_free(tn, device, scenes):
                 assert int(out_f["ray_mask"].sum()) == 0
                 for g in g_f:
                     assert g is None or (bool(torch.isfinite(g).all()) and float(g.abs().max()) == 0.0)
+
+
+def test_render_train_falls_back_to_compaction_when_rays_miss(tn, device, scenes):
+    """The sync-free form computes (and discards) padded entries for the rays that miss, so it only pays while nearly all rays
+    hit: the hit fraction of a batch is read back asynchronously and a later batch whose last known fraction is below
+    SYNC_FREE_MIN_HITS (0.85) is compacted with torch.nonzero instead -- and the sync-free form resumes when it recovers."""
+    import torch
+
+    render = importlib.import_module("tetra-nerf_amd.render")
+    pts, cells = scenes.random_mesh(3000, 5)
+    tr = tn.TetrahedraTracer(device)
+    tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+    torch.manual_seed(0)
+    mlp = render.TetraMLP().to(device)
+    field = ((torch.rand(64, len(pts), device=device) * 2 - 1) * 0.5).requires_grad_(True)
+    rd = render.TetraRenderer(tr, field, mlp, 32, 256, fused=True, num_fine_samples=32)
+    o, d = scenes.outside_in_rays(512, 6)
+    dm = d.copy()
+    dm[::2] = -dm[::2]                                 # half of the rays miss
+    to = torch.from_numpy(o).to(device)
+    hit_all, hit_half = torch.from_numpy(d).to(device), torch.from_numpy(np.ascontiguousarray(dm)).to(device)
+
+    def call(dirs, guard):
+        torch.cuda.set_sync_debug_mode("error" if guard else "default")
+        try:
+            out = rd.render_train(to, dirs)
+            out["rgb"].mean().backward()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()                       # (the asynchronous read-back of this batch's hit count has landed)
+        return out
+
+    call(hit_all, False)
+    call(hit_all, True)                                # every ray hits: sync-free
+    assert rd._hit_fraction == 1.0
+    call(hit_half, True)                               # still decided on the previous batch: sync-free, with padded entries
+    call(hit_half, False)                              # now the 0.5 is known
+    assert 0.45 < rd._hit_fraction < 0.55
+    with pytest.raises(RuntimeError, match="synchroniz"):
+        call(hit_half, True)                           # compaction: torch.nonzero synchronises
+    call(hit_all, False)                               # (compacting call; its read-back says 1.0 again)
+    call(hit_all, False)
+    call(hit_all, True)                                # sync-free resumed

@@ -29,6 +29,7 @@ import torch
 
 FIELD_DIM = 64
 FUSED_PASS_MAX_RAYS = 16384   # TetraRenderer(fused_pass="auto"): one launch per pass up to this many hitting rays
+SYNC_FREE_MIN_HITS = 0.85     # render_train: below this (last known) fraction of hitting rays the batch is compacted instead
 HIDDEN = 128
 DIR_ENC = 27
 
@@ -349,11 +350,16 @@ class TetraRenderer:
                  max_ray_triangles: int = 512, fused: bool = True, far_plane: float = 1000.0,
                  num_fine_samples: int = 0, biased: bool = False, dense_tails: bool = False, fused_pass="auto",
                  mlp_mode: str = "fp32", background=1.0, cache_field: bool = True, device_samplers: bool = True,
-                 interpolate_values=None, sync_free_train: bool = True):
+                 interpolate_values=None, sync_free_train: bool = True, sync_free_min_hits: float = None):
         from . import tetranerf_cpp_extension as cpp
 
         # render_train without a host synchronisation (see there); False: compact the hitting rays with torch.nonzero
         self.sync_free_train = bool(sync_free_train)
+        # the sync-free form pays for rays that miss (padded entries are computed and discarded): the hit fraction of a batch
+        # is read back ASYNCHRONOUSLY (pinned buffer + event, never waited for) and, when the last known fraction is below
+        # SYNC_FREE_MIN_HITS, the next batches take the compacting form until it recovers
+        self._hits_pinned, self._hits_event, self._hit_fraction = None, None, 1.0
+        self.sync_free_min_hits = SYNC_FREE_MIN_HITS if sync_free_min_hits is None else float(sync_free_min_hits)
 
         self.cpp = cpp
         self.tracer, self.field, self.mlp = tracer, field, mlp
@@ -520,10 +526,22 @@ class TetraRenderer:
         # parity tests) the stratified draws are the reference's, element for element; with misses they are the first
         # `count` rows of an [R, S+1] draw instead of an [r, S+1] draw -- the same distribution, another stream.
         sync_free = self.sync_free_train and fused and self.device_samplers and capture is None and not rand and R > 0
+        if sync_free and self._hits_event is not None and self._hits_event.query():
+            self._hit_fraction = float(self._hits_pinned[0]) / max(float(self._hits_pinned[1]), 1.0)   # of an EARLIER batch
+        sync_free = sync_free and self._hit_fraction >= self.sync_free_min_hits
         with torch.no_grad():
             out = self._trace(origins, directions)
             nv = out["num_visited_cells"]
             ray_mask = nv > 0
+            if self.sync_free_train and origins.is_cuda:
+                # asynchronous read-back of (hits, rays) of this batch for the decision of a later one
+                if self._hits_pinned is None:
+                    self._hits_pinned = torch.zeros(2, dtype=torch.float32).pin_memory()
+                    self._hits_event = torch.cuda.Event()
+                if self._hits_event.query():       # (the previous copy has landed: the buffer is free again)
+                    stats = torch.stack([ray_mask.sum().float(), torch.full((), float(R), device=dev)])
+                    self._hits_pinned.copy_(stats, non_blocking=True)
+                    self._hits_event.record(torch.cuda.current_stream(dev))
             if sync_free:
                 order = torch.argsort((~ray_mask).to(torch.uint8), stable=True)
                 valid = torch.arange(R, device=dev) < ray_mask.sum()
