@@ -216,13 +216,16 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *             max_ray_triangles >= 4 (16-byte stores into the rows); 1 and 2 take the BVH path
  *   "dense_tails"  1 (default) = every slot of the [R,M] rows is written, as the reference does;
  *             0 = slots >= num_visited[r] of walked rows are left UNWRITTEN (non-reference: for callers
- *             that only read rows through num_visited, e.g. tn_find_matched_cells; saves ~88 % of the bytes)
+ *             that only read rows through num_visited, e.g. tn_find_matched_cells; saves ~88 % of the bytes).
+ *             Tracer-wide; prefer the per-call flag TN_TRACE_COMPACT_ROWS of tn_trace_rays_ex
  *   "literal" 1 (default) = rays whose order the walk cannot certify have their logged hits sorted and paired
  *             literally; 0 = they are re-traced through the BVH all-hits path (cross-check of the two paths)
- *   "spec_fill"  1 (default) = the last quarter of every row (slots no ray of this mesh is expected to reach) is
- *             filled beside the walk on a stream of its own; 0 = the whole tail fill after the segment writer.
- *             "spec_k0" = first speculatively filled slot (multiple of 32; 0 = the quarter rule) -- tests force it low
- *             so that rays of every class overwrite speculatively filled slots
+ *   "spec_fill"  1 (default) = the last quarter / half of every row (slots no ray, or hardly any ray, of this mesh reaches)
+ *             is filled beside the walk on a stream of its own; 0 = the whole tail fill after the segment writer.
+ *             "spec_k0" = first speculatively filled slot (multiple of 32; 0 = the rule of tn_api.hip) -- tests force it
+ *             low so that rays of every class overwrite speculatively filled slots; "spec_blocks" (512) = grid of that
+ *             fill, "walk_lds_kb" (26) = dynamic LDS reserved per walk block beside it (an occupancy limit that keeps both
+ *             kernels resident): sweeps
  *   "log_cap_mb"  cap of the hit log in MiB (0 = default: a quarter of the free device memory, at most 24 GiB);
  *             larger calls are processed in ray chunks
  *   "gpu_build"  1 (default) = load_tetrahedra builds its structures on the device; 0 = single-threaded host build
@@ -230,9 +233,13 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *             path tests 64 / leaf_width crossed leaves per wave instruction
  *   "small_lds"  1 (default) = batches below walk_min_rays use LDS hit arrays sized for the mesh (every ray resident at
  *             once) and re-trace the rays with more hits in a second launch; "lds_cap" forces their size (tests)
- *   "verify_stride"  k > 0: every k-th ray the walk certified is cross-checked before its row is written: a count-only
- *             BVH all-hits traversal must find exactly the faces the walk logged, otherwise the ray takes the BVH path
- *             (default 0 = off: the check costs a BVH traversal per checked ray; tests and the fuzzer run it at 1)
+ *   "verify_stride"  k > 0 (default 256): every k-th ray the walk certified is cross-checked: a count-only BVH all-hits
+ *             traversal must find exactly the faces the walk logged, otherwise the ray is re-traced through the BVH path and
+ *             counted in tn_trace_flag_reasons()[14].  A one-chunk call runs the check beside the row writers (< 1 % of the
+ *             call at 256; linear in the rays checked: tests and the fuzzer run it at 1); 0 = off.
+ *             "verify_inject" 1 = every checked ray counts as a mismatch (tests of the hand-over)
+ *   "writer_table"  0 (default) = the segment writer's record table by mesh size (one record per (tet, entry face) below
+ *             500k tets, one per tet above), 1 / 2 force either (applies at the next tn_load_tetrahedra; tests, A/B)
  * Unknown names are an error. */
 int tn_set_option(tn_tracer_t tracer, const char *name, int value);
 
