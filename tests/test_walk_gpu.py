@@ -261,6 +261,40 @@ def test_cross_check_hand_over_paths(tn, device, scenes):
                 assert torch.equal(ref[k].view(torch.int32), clean[k].view(torch.int32)), (chunked, stride, k)
 
 
+def test_compact_rows_on_the_small_batch_path(tn, device, scenes):
+    """TN_TRACE_COMPACT_ROWS on the BVH path (batches below walk_min_rays: nerfstudio's 4096-ray training batches): the
+    valid prefix of every row is bit-identical to the dense call, num_visited too, and the slots beyond are left alone
+    (a 4096-ray batch otherwise writes 109 MB of constants nobody reads)."""
+    import torch
+
+    pts, cells = scenes.random_mesh(6000, 13)
+    o, d = scenes.outside_in_rays(4096, 3)
+    d[::5] = -d[::5]                                  # some rays miss
+    to, td = torch.from_numpy(o).to(device), torch.from_numpy(np.ascontiguousarray(d)).to(device)
+    tr = _tracer(tn, device, pts, cells, 1)
+    M = 256
+    dense = tr.trace_rays(to, td, M)
+    assert tr.trace_stats()["walk"] == 0              # the BVH path
+    lean = tr.trace_rays(to, td, M, compact_rows=True)
+    n = dense["num_visited_cells"]
+    assert torch.equal(n, lean["num_visited_cells"]) and int((n == 0).sum()) > 500 and int(n.max()) > 50
+    valid = torch.arange(M, device=device)[None] < n[:, None]
+    for k in KEYS[1:]:
+        a, b = dense[k], lean[k]
+        m = valid.reshape(valid.shape + (1,) * (a.dim() - 2)).expand_as(a)
+        assert torch.equal(a[m].view(torch.int32), b[m].view(torch.int32)), k
+    # the tails of the compact call were not written: pre-set rows keep their sentinel
+    import ctypes as C
+    sent = {k: torch.full_like(dense[k], 0x5a5a5a5a if dense[k].dtype == torch.int32 else 12345.0) for k in KEYS}
+    lib = tn.cpp._lib.load()
+    tn.cpp._lib.check(lib.tn_trace_rays_ex(tr._h, len(o), M, C.c_void_p(to.data_ptr()), C.c_void_p(td.data_ptr()),
+                                            C.c_void_p(sent["num_visited_cells"].data_ptr()), C.c_void_p(sent["visited_cells"].data_ptr()),
+                                            C.c_void_p(sent["barycentric_coordinates"].data_ptr()), C.c_void_p(sent["hit_distances"].data_ptr()),
+                                            C.c_void_p(sent["vertex_indices"].data_ptr()), 1, C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+    assert bool((sent["visited_cells"][~valid] == 0x5a5a5a5a).all()) and bool((sent["hit_distances"][~valid] == 12345.0).all())
+    assert torch.equal(sent["visited_cells"][valid], dense["visited_cells"][valid])
+
+
 def test_chunked_log_equals_single_launch(tn, device, scenes):
     """Calls whose hit log would exceed the cap are walked and written in ray chunks: same bits."""
     pts, cells = scenes.random_mesh(6000, 13)

@@ -369,6 +369,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
         t->last_num_rays = R;
         TN_HIP(hipMemsetAsync(t->stats.p, 0, 26 * sizeof(unsigned long long), stream));
         tn::TraceParams p = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
+        p.compact_rows = dense_tails ? 0u : 1u;
         // Small batches are latency-bound: a lane walking ~180 dependent steps is slower than one
         // wavefront per ray through the wide BVH (measured: 4096 rays, 300k tets: 1.5 ms vs 0.75 ms),
         // so the walk is used from `walk_min_rays` on (use_walk == 2 forces it for any size).
@@ -402,8 +403,10 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
             if (t->hit_log.n < log_entries) t->hit_log.alloc(log_entries);
             const bool single = chunk >= R;
             auto chunk_params = [&](size_t base, size_t n) {
-                return make_params(t, n, M, origins + 3 * base, directions + 3 * base, num_visited + base, visited + base * M,
-                                   bary + base * M * 6, dist + base * M * 2, verts ? verts + base * M * 4 : nullptr);
+                tn::TraceParams q = make_params(t, n, M, origins + 3 * base, directions + 3 * base, num_visited + base, visited + base * M,
+                                                bary + base * M * 6, dist + base * M * 2, verts ? verts + base * M * 4 : nullptr);
+                q.compact_rows = dense_tails ? 0u : 1u;
+                return q;
             };
             size_t walk_reserve = 0;     // set by the one-chunk schedule when a speculative fill runs beside the walk
             auto launch_walk = [&](size_t base, size_t n) {
@@ -505,6 +508,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                     // rows of the rays whose count differed (none, as far as anyone has seen): whole rows, after every other
                     // writer of the call.  The count lives on the device: a small grid that finds it 0 and exits
                     tn::TraceParams pv = make_params(t, 64, M, origins, directions, num_visited, visited, bary, dist, verts);
+                    pv.compact_rows = dense_tails ? 0u : 1u;
                     pv.ray_list = t->verify_list.p;
                     pv.item_count = t->verify_count();
                     tn::launch_trace_general(pv, stream);

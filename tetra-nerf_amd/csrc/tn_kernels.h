@@ -23,6 +23,7 @@ struct TraceParams {
     uint32_t *overflow_list;   // [num_items] / [1]
     uint32_t *overflow_count;
     unsigned long long *stats; // [4] device counters or null
+    uint32_t compact_rows;     // 1: slots >= num_visited are left unwritten (TN_TRACE_COMPACT_ROWS); 0: every slot of a row
 };
 
 // general all-hits path, one wavefront per ray (tn_trace_general.hip)

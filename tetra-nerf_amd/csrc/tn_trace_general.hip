@@ -71,7 +71,7 @@ __device__ void postprocess_and_write(const WaveSmem &s, uint32_t nh, uint32_t M
                                       const uint32_t *__restrict__ face_tets, uint32_t *__restrict__ out_num,
                                       uint32_t *__restrict__ out_cells, float *__restrict__ out_bary,
                                       float *__restrict__ out_dist, uint32_t *__restrict__ out_verts,
-                                      unsigned long long *stats, int lane) {
+                                      unsigned long long *stats, int lane, bool compact = false) {
     // face -> tets of each sorted hit
     for (uint32_t j = lane; j < nh; j += 64) {
         const uint32_t id = (uint32_t)s.key[j];
@@ -267,8 +267,9 @@ __device__ void postprocess_and_write(const WaveSmem &s, uint32_t nh, uint32_t M
         nseg += __popcll(m);
     }
 
-    // tail fill: every remaining byte of the rows, coalesced
-    for (uint32_t j = nseg + lane; j < M; j += 64) {
+    // tail fill: every remaining byte of the rows, coalesced (compact rows: nothing beyond the segments -- a 4096-ray
+    // training batch otherwise writes 109 MB of constants that its consumers never read)
+    for (uint32_t j = nseg + lane; j < (compact ? nseg : M); j += 64) {
         out_cells[j] = TN_EMPTY;
         *reinterpret_cast<float2 *>(out_dist + 2 * (size_t)j) = make_float2(0.f, 0.f);
         float2 *bp = reinterpret_cast<float2 *>(out_bary + 6 * (size_t)j);
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
         sort_hits(s, nh, lane);
         postprocess_and_write(s, nh, M, p.faces, p.face_tets, p.out_num + ray, p.out_cells + ray * M,
                               p.out_bary + ray * M * 6, p.out_dist + ray * M * 2,
-                              p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane);
+                              p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane, p.compact_rows != 0);
         wave_sync();
     }
 }
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const Wal
         sort_hits(s, nh, lane);
         postprocess_and_write(s, nh, M, p.faces, p.face_tets, p.out_num + ray, p.out_cells + ray * M,
                               p.out_bary + ray * M * 6, p.out_dist + ray * M * 2,
-                              p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane);
+                              p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane, p.compact_rows != 0);
         if (lane == 0 && p.stats) atomicAdd(&p.stats[4 + 13], 1ull);
         wave_sync();
     }
