@@ -355,7 +355,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
         tn_tracer *t = checked(tracer);
         if (flags & ~(uint32_t)TN_TRACE_COMPACT_ROWS) throw tn::Error("unknown trace flag");
         // per CALL, not per tracer: a viewer thread and a trainer sharing one tracer may ask for different row forms
-        const bool dense_tails = dense_tails && !(flags & TN_TRACE_COMPACT_ROWS);
+        const bool dense_tails = t->dense_tails && !(flags & TN_TRACE_COMPACT_ROWS);
         if (M == 0 || (M & (M - 1)) != 0) throw tn::Error("max_ray_triangles must be a power of 2.");
         if (!t->loaded) throw tn::Error("load_tetrahedra must be called first");
         if (M > 4096) throw tn::Error("max_ray_triangles larger than 4096 is not supported");
