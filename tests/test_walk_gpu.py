@@ -261,6 +261,65 @@ def test_cross_check_hand_over_paths(tn, device, scenes):
                 assert torch.equal(ref[k].view(torch.int32), clean[k].view(torch.int32)), (chunked, stride, k)
 
 
+def _trace_into_sentinels(tn, tr, to, td, M, flags):
+    """tn_trace_rays_ex into buffers pre-set to sentinels: shows which bytes a call writes."""
+    import ctypes as C
+
+    import torch
+
+    dev = to.device
+    R = to.shape[0]
+    out = {"num_visited_cells": torch.full((R,), 0x5a5a5a5a, dtype=torch.int32, device=dev),
+           "visited_cells": torch.full((R, M), 0x5a5a5a5a, dtype=torch.int32, device=dev),
+           "barycentric_coordinates": torch.full((R, M, 2, 3), 12345.0, device=dev),
+           "hit_distances": torch.full((R, M, 2), 12345.0, device=dev),
+           "vertex_indices": torch.full((R, M, 4), 0x5a5a5a5a, dtype=torch.int32, device=dev)}
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    lib = tn.cpp._lib.load()
+    tn.cpp._lib.check(lib.tn_trace_rays_ex(tr._h, R, M, p(to), p(td), p(out["num_visited_cells"]), p(out["visited_cells"]),
+                                            p(out["barycentric_coordinates"]), p(out["hit_distances"]), p(out["vertex_indices"]),
+                                            flags, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out
+
+
+def test_which_bytes_a_call_writes(tn, device, scenes):
+    """Into sentinel-filled buffers: a default call writes EVERY slot of every row (ids -1, floats 0 beyond num_visited, as the
+    reference's torch::zeros + tail fill), on the walk path and on the BVH path; the per-call flag TN_TRACE_COMPACT_ROWS and
+    the tracer option dense_tails = 0 leave every slot beyond num_visited untouched.  (Round 4 shipped, for a few commits, a
+    flag that was initialised from itself: whether tails were written depended on the build.  This test pins it.)"""
+    import torch
+
+    pts, cells = scenes.random_mesh(6000, 13)
+    tr = _tracer(tn, device, pts, cells, 1)
+    M = 128
+    for n_rays in (40000, 3000):                      # walk path / wave-per-ray BVH path
+        o, d = scenes.outside_in_rays(n_rays, 3)
+        d[::7] = -d[::7]
+        to, td = torch.from_numpy(o).to(device), torch.from_numpy(np.ascontiguousarray(d)).to(device)
+        dense = _trace_into_sentinels(tn, tr, to, td, M, 0)
+        n = dense["num_visited_cells"]
+        assert int((n == 0).sum()) > n_rays // 10 and int(n.max()) > 40 and int(n.max()) < M
+        tail = torch.arange(M, device=device)[None] >= n[:, None]
+        assert bool((dense["visited_cells"][tail] == -1).all()) and bool((dense["vertex_indices"][tail] == -1).all())
+        assert bool((dense["hit_distances"][tail] == 0).all()) and bool((dense["barycentric_coordinates"][tail] == 0).all())
+        for how in ("flag", "option"):
+            if how == "option":
+                tr.set_option("dense_tails", 0)
+            lean = _trace_into_sentinels(tn, tr, to, td, M, 1 if how == "flag" else 0)
+            tr.set_option("dense_tails", 1)
+            assert torch.equal(lean["num_visited_cells"], n), how
+            for k in KEYS[1:]:
+                a, b = dense[k], lean[k]
+                t = tail.reshape(tail.shape + (1,) * (a.dim() - 2)).expand_as(a)
+                assert torch.equal(a[~t].view(torch.int32), b[~t].view(torch.int32)), (n_rays, how, k)
+                sent = 0x5a5a5a5a if b.dtype == torch.int32 else 12345.0
+                if n_rays == 40000 and how == "flag":
+                    # walked rows: the writer may pad a row's segments up to the next multiple of 32 slots -- it does not with
+                    # compact rows; literal / fallback rows are written by the BVH kernels: compact as well
+                    pass
+                assert bool((b[t] == sent).all()), (n_rays, how, k)
+
+
 def test_compact_rows_on_the_small_batch_path(tn, device, scenes):
     """TN_TRACE_COMPACT_ROWS on the BVH path (batches below walk_min_rays: nerfstudio's 4096-ray training batches): the
     valid prefix of every row is bit-identical to the dense call, num_visited too, and the slots beyond are left alone
