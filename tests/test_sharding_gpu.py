@@ -46,6 +46,32 @@ def test_nccl_one_rank_sharded_render(tn, device, scenes):
         # the bench's reductions and the raw collective on device tensors
         assert sh.max_over_ranks(1.5, device=device) == 1.5
         assert sh.sum_over_ranks([2.0, 3.0], device=device) == [2.0, 3.0]
+        # the reference's training collective on the real backend: the fused autograd nodes under DistributedDataParallel
+        # over RCCL (one rank: the all-reduce still runs as an RCCL kernel on the bucketed gradients; two ranks over gloo:
+        # tests/test_multirank_gpu.py) -- gradients equal the un-wrapped module's, bit for bit for the weight tensors
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        torch.manual_seed(1)
+        module = render.TetraNerfModule(tr, len(pts), 64, 256, num_fine_samples=64, biased=True, gradient_scaling=True).to(device)
+        bo, bd = scenes.outside_in_rays(1024, 9)
+        bo, bd = torch.from_numpy(bo).to(device), torch.from_numpy(bd).to(device)
+        target = torch.rand(len(bo), 3, device=device)
+
+        def grads(m):
+            for p_ in module.parameters():
+                p_.grad = None
+            torch.manual_seed(5)
+            ((m(bo, bd)["rgb"] - target) ** 2).mean().backward()
+            return {n: p_.grad.clone() for n, p_ in module.named_parameters()}
+
+        plain = grads(module)
+        wrapped = grads(DDP(module, device_ids=[device.index], find_unused_parameters=True))
+        assert set(plain) == set(wrapped) and len(plain) == 13
+        for n in plain:
+            if n == "tetrahedra_field":      # float atomics
+                assert float((plain[n] - wrapped[n]).abs().max()) <= 1e-5 * float(plain[n].abs().max()), n
+            else:
+                assert torch.equal(plain[n], wrapped[n]), n
         x = torch.arange(12, dtype=torch.float32, device=device).view(4, 3)
         y = torch.empty_like(x)
         dist.all_gather_into_tensor(y, x)
