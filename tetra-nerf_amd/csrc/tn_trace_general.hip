@@ -303,6 +303,32 @@ __device__ void sort_hits(const WaveSmem &s, uint32_t nh, int lane) {
     }
 }
 
+// The hits the walk logged come in chain order: sorted on (t, face id) except where a gap is below the resolution of t
+// (a tie, an inversion of a few ulps) -- which is why the ray is here.  Odd-even transposition passes until a whole pass
+// swaps nothing: one pass when the order is already right, a few when neighbours are exchanged; the keys are distinct (a
+// chain crosses a face once), so the result is the bitonic network's.  A chain that is still unsorted after 8 passes
+// gets the network.
+__device__ void sort_logged_hits(const WaveSmem &s, uint32_t nh, int lane) {
+    for (int pass = 0; pass < 8; ++pass) {
+        bool swapped = false;
+#pragma unroll
+        for (uint32_t par = 0; par < 2; ++par) {
+            for (uint32_t i = 2 * (uint32_t)lane + par; i + 1 < nh; i += 128) {
+                const uint64_t a = s.key[i], b = s.key[i + 1];
+                if (a > b) {
+                    s.key[i] = b; s.key[i + 1] = a;
+                    const float ua = s.hu[i], ub = s.hu[i + 1]; s.hu[i] = ub; s.hu[i + 1] = ua;
+                    const float va = s.hv[i], vb = s.hv[i + 1]; s.hv[i] = vb; s.hv[i + 1] = va;
+                    swapped = true;
+                }
+            }
+            wave_sync();
+        }
+        if (__ballot(swapped) == 0ull) return;
+    }
+    sort_hits(s, nh, lane);
+}
+
 }  // namespace
 
 // All faces of the mesh the ray (o, d) hits with 0 < t < 1e16, into the LDS hit arrays (unsorted).
@@ -537,7 +563,7 @@ __global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const Wal
             s.hv[j] = __uint_as_float(e.z);
         }
         wave_sync();
-        sort_hits(s, nh, lane);
+        sort_logged_hits(s, nh, lane);
         postprocess_and_write(s, nh, M, p.faces, p.face_tets, p.out_num + ray, p.out_cells + ray * M,
                               p.out_bary + ray * M * 6, p.out_dist + ray * M * 2,
                               p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane, p.compact_rows != 0);
