@@ -72,11 +72,19 @@ __device__ void postprocess_and_write(const WaveSmem &s, uint32_t nh, uint32_t M
                                       uint32_t *__restrict__ out_cells, float *__restrict__ out_bary,
                                       float *__restrict__ out_dist, uint32_t *__restrict__ out_verts,
                                       unsigned long long *stats, int lane, bool compact = false) {
-    // face -> tets of each sorted hit
-    for (uint32_t j = lane; j < nh; j += 64) {
-        const uint32_t id = (uint32_t)s.key[j];
-        s.hft[j] = *reinterpret_cast<const uint2 *>(face_tets + 2 * (size_t)id);
-        s.mark[j] = 0;
+    // face -> tets of each sorted hit: random 8-byte reads, all of a lane's requests (eight per 512 hits) in flight at once
+    for (uint32_t base = 0; base < nh; base += 512) {
+        uint2 ft[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t j = base + 64 * q + lane;
+            if (j < nh) ft[q] = *reinterpret_cast<const uint2 *>(face_tets + 2 * (size_t)(uint32_t)s.key[j]);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t j = base + 64 * q + lane;
+            if (j < nh) { s.hft[j] = ft[q]; s.mark[j] = 0; }
+        }
     }
     wave_sync();
 
@@ -240,9 +248,26 @@ __device__ void postprocess_and_write(const WaveSmem &s, uint32_t nh, uint32_t M
 
     // parallel emission of the flagged pairs (slot j, slot j+1), in slot order
     uint32_t nseg = 0;
+    struct FaceIds { uint32_t a[3], b[3]; bool emit; };
+    auto face_ids = [&](uint32_t base) {   // vertex ids (stored order) of the two faces of the segment slot base + lane emits
+        FaceIds r;
+        const uint32_t j = base + lane;
+        r.emit = j + 1 < nh && s.emitf[j] != 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) r.a[k] = r.b[k] = 0u;
+        if (r.emit) {
+            const uint32_t f0 = (uint32_t)s.key[j], f1 = (uint32_t)s.key[j + 1];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { r.a[k] = faces[3 * (size_t)f0 + k]; r.b[k] = faces[3 * (size_t)f1 + k]; }
+        }
+        return r;
+    };
+    FaceIds nxt = face_ids(0);
     for (uint32_t base = 0; base + 1 < nh; base += 64) {
         const uint32_t j = base + lane;
-        const bool emit = j + 1 < nh && s.emitf[j] != 0;
+        const FaceIds cur = nxt;
+        if (base + 65 < nh) nxt = face_ids(base + 64);   // requested before this iteration's rows are computed and stored
+        const bool emit = cur.emit;
         const uint64_t m = __ballot(emit);
         if (emit) {
             const uint32_t slot = nseg + __popcll(m & lanemask_lt());
@@ -250,9 +275,8 @@ __device__ void postprocess_and_write(const WaveSmem &s, uint32_t nh, uint32_t M
             const float t1 = __uint_as_float((uint32_t)(s.key[j + 1] >> 32));
             uint32_t cell = TN_EMPTY;
             common_tet(s.hft[j], s.hft[j + 1], cell);
-            const uint32_t f0 = (uint32_t)s.key[j], f1 = (uint32_t)s.key[j + 1];
-            const uint32_t id1[3] = {faces[3 * (size_t)f0], faces[3 * (size_t)f0 + 1], faces[3 * (size_t)f0 + 2]};
-            const uint32_t id2[3] = {faces[3 * (size_t)f1], faces[3 * (size_t)f1 + 1], faces[3 * (size_t)f1 + 2]};
+            const uint32_t id1[3] = {cur.a[0], cur.a[1], cur.a[2]};
+            const uint32_t id2[3] = {cur.b[0], cur.b[1], cur.b[2]};
             uint32_t vi[4];
             float b1[3], b2[3];
             combine_indices(id1, id2, s.hu[j], s.hv[j], s.hu[j + 1], s.hv[j + 1], vi, b1, b2);
@@ -554,13 +578,33 @@ __global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const Wal
         const size_t ray = ent.x;
         const uint32_t nh = ent.y < M ? ent.y : M - 1;
         const uint4 *lg = hit_log + (ray >> 6) * (size_t)M * 64 + (ray & 63);
-        for (uint32_t j = lane; j < nh; j += 64) {
-            const uint4 e = lg[(size_t)j * 64];
-            const uint32_t x = e.w >> 30, lo = e.w & 0x3FFFFFFFu;
-            const uint32_t fid = x == 3u ? lo : fidt[lo].fid[x];
-            s.key[j] = ((uint64_t)e.x << 32) | fid;
-            s.hu[j] = __uint_as_float(e.y);
-            s.hv[j] = __uint_as_float(e.z);
+        // two dependent random reads per hit (log entry -> face id of its variant): a lane's eight log entries are
+        // requested together, then its eight face ids, then everything goes to LDS
+        for (uint32_t base = 0; base < nh; base += 512) {
+            uint4 e[8];
+            uint32_t fid[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t j = base + 64 * q + lane;
+                if (j < nh) e[q] = lg[(size_t)j * 64];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t j = base + 64 * q + lane;
+                if (j < nh) {
+                    const uint32_t x = e[q].w >> 30, lo = e[q].w & 0x3FFFFFFFu;
+                    fid[q] = x == 3u ? lo : fidt[lo].fid[x];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t j = base + 64 * q + lane;
+                if (j < nh) {
+                    s.key[j] = ((uint64_t)e[q].x << 32) | fid[q];
+                    s.hu[j] = __uint_as_float(e[q].y);
+                    s.hv[j] = __uint_as_float(e[q].z);
+                }
+            }
         }
         wave_sync();
         sort_logged_hits(s, nh, lane);
