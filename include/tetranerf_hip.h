@@ -238,6 +238,8 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *             counted in tn_trace_flag_reasons()[14].  A one-chunk call runs the check beside the row writers (< 1 % of the
  *             call at 256; linear in the rays checked: tests and the fuzzer run it at 1); 0 = off.
  *             "verify_inject" 1 = every checked ray counts as a mismatch (tests of the hand-over)
+ *   "literal_sort_passes"  (default 8) odd-even transposition passes over the nearly sorted hits the walk logged for a ray
+ *             whose order it does not certify, before the bitonic network takes over (same result: distinct keys; tests run 0 and 1)
  *   "writer_table"  0 (default) = the segment writer's record table by mesh size (one record per (tet, entry face) below
  *             500k tets, one per tet above), 1 / 2 force either (applies at the next tn_load_tetrahedra; tests, A/B)
  * Unknown names are an error. */

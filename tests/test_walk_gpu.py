@@ -222,6 +222,41 @@ def test_writer_tables_agree(tn, device, scenes, bottle):
             assert torch.equal(a[m].view(torch.int32), b[m].view(torch.int32)) and torch.equal(a[m].view(torch.int32), c[m].view(torch.int32)), (name, k)
 
 
+def test_literal_sort_branches_agree(tn, device, scenes, bottle):
+    """The hits the walk logged for a ray whose order it does not certify are nearly sorted: the pairing kernel runs odd-even
+    transposition passes until one swaps nothing and hands chains that are still unsorted after "literal_sort_passes" (8) to
+    the bitonic network.  Natural rays never need the network, so both branches are forced: 0 passes (always the network, the
+    code of rounds 1-3), 1 pass (the network takes over half-sorted lists) and the default must write the same rows bit for
+    bit -- on meshes where most rays are literal (the bottle's zero-volume tets, a lattice, vertex twins) and against the BVH
+    path, which sorts unordered hits with the network alone."""
+    import torch
+
+    meshes = [("bottle", (bottle["vertices"], bottle["cells"])), ("lattice", scenes.grid_mesh(9, 0.0)),
+              ("near-duplicates", scenes.near_duplicates_mesh(2000, 1e-7)), ("random", scenes.random_mesh(5000, 22))]
+    literal_total = 0
+    for name, (pts, cells) in meshes:
+        lo, hi = pts.min(0), pts.max(0)
+        o, d = scenes.outside_in_rays(20000, 19)
+        t = o + d
+        o, t = lo + (hi - lo) * o, lo + (hi - lo) * t
+        d = t - o
+        o, d = o.astype(np.float32), (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        to, td = torch.from_numpy(np.ascontiguousarray(o)).to(device), torch.from_numpy(np.ascontiguousarray(d)).to(device)
+        tr = tn.TetrahedraTracer(device)
+        tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+        tr.set_option("walk", 0)
+        want = tr.trace_rays(to, td, 256)                    # BVH path
+        tr.set_option("walk", 2)
+        for passes in (8, 0, 1):
+            tr.set_option("literal_sort_passes", passes)
+            got = tr.trace_rays(to, td, 256)
+            reasons = tr.flag_reasons()
+            for k in KEYS:
+                assert torch.equal(got[k].view(torch.int32), want[k].view(torch.int32)), (name, passes, k)
+        literal_total += reasons.get(13, 0)
+    assert literal_total > 5000, literal_total               # rays that went through the literal pairing of the log
+
+
 def test_cross_check_hand_over_paths(tn, device, scenes):
     """The always-on count cross-check never finds a mismatch on its own, so its hand-over is exercised by injection
     (option verify_inject: every checked ray counts as a mismatch): in the late form (one-chunk call: the check runs beside the

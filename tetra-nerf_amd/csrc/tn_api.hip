@@ -56,6 +56,7 @@ struct tn_tracer {
     // costs +0.9 / +2.9 / +3.7 % on the C2 / C4 frame / the C5 rays, stride 16 +6 / +13 / +21 % -- linear in the rays
     // checked -- so the default is 256: +0.2 / +0.7 / +0.9 %
     unsigned verify_stride = 256;
+    unsigned literal_sort_passes = 8;    // odd-even passes over a literal ray's logged hits before the bitonic network (tests: 0, 1)
     bool verify_inject = false;          // tests: every cross-checked ray is treated as a mismatch (exercises the hand-over)
     tn::DevBuf<uint32_t> verify_list;    // certified rays whose count differed: re-traced by the BVH kernel at the end of the call
     tn::DevBuf<tn::WalkVar> vars;        // the build's 64-byte records: split into the three tables below, then released
@@ -406,6 +407,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 tn::TraceParams q = make_params(t, n, M, origins + 3 * base, directions + 3 * base, num_visited + base, visited + base * M,
                                                 bary + base * M * 6, dist + base * M * 2, verts ? verts + base * M * 4 : nullptr);
                 q.compact_rows = dense_tails ? 0u : 1u;
+                q.sort_passes = t->literal_sort_passes;
                 return q;
             };
             size_t walk_reserve = 0;     // set by the one-chunk schedule when a speculative fill runs beside the walk
@@ -704,6 +706,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         }
         else if (k == "writer_table") t->writer_table = value;   // applies at the next load_tetrahedra
         else if (k == "verify_inject") t->verify_inject = value != 0;
+        else if (k == "literal_sort_passes") t->literal_sort_passes = value < 0 ? 0u : (unsigned)value;
         else if (k == "verify_stride") t->verify_stride = value < 0 ? 0u : (unsigned)value;
         else if (k == "log_cap_mb") t->log_cap_bytes = value <= 0 ? 0 : (size_t)value << 20;
         else throw tn::Error("unknown option " + (name ? k : std::string("(null)")));

@@ -24,6 +24,7 @@ struct TraceParams {
     uint32_t *overflow_count;
     unsigned long long *stats; // [4] device counters or null
     uint32_t compact_rows;     // 1: slots >= num_visited are left unwritten (TN_TRACE_COMPACT_ROWS); 0: every slot of a row
+    uint32_t sort_passes;      // k_postprocess_log: odd-even passes over the logged hits before the bitonic network takes over
 };
 
 // general all-hits path, one wavefront per ray (tn_trace_general.hip)

@@ -331,9 +331,9 @@ __device__ void sort_hits(const WaveSmem &s, uint32_t nh, int lane) {
 // (a tie, an inversion of a few ulps) -- which is why the ray is here.  Odd-even transposition passes until a whole pass
 // swaps nothing: one pass when the order is already right, a few when neighbours are exchanged; the keys are distinct (a
 // chain crosses a face once), so the result is the bitonic network's.  A chain that is still unsorted after 8 passes
-// gets the network.
-__device__ void sort_logged_hits(const WaveSmem &s, uint32_t nh, int lane) {
-    for (int pass = 0; pass < 8; ++pass) {
+// gets the network (option "literal_sort_passes", default 8; tests run 0 = always the network and 1).
+__device__ void sort_logged_hits(const WaveSmem &s, uint32_t nh, int lane, uint32_t max_passes) {
+    for (uint32_t pass = 0; pass < max_passes; ++pass) {
         bool swapped = false;
 #pragma unroll
         for (uint32_t par = 0; par < 2; ++par) {
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const Wal
             }
         }
         wave_sync();
-        sort_logged_hits(s, nh, lane);
+        sort_logged_hits(s, nh, lane, p.sort_passes);
         postprocess_and_write(s, nh, M, p.faces, p.face_tets, p.out_num + ray, p.out_cells + ray * M,
                               p.out_bary + ray * M * 6, p.out_dist + ray * M * 2,
                               p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane, p.compact_rows != 0);
