@@ -469,7 +469,12 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                     // the longer the walk (the more faces per ray), the more bytes its duration hides: the last quarter of the
                     // rows on small meshes (C2: 384), the last half where rays reach beyond M/2 - 64 slots (C4: 256 measured
                     // best, 320 / 384: -3.6 / -0.6 % instead of -4.9 %); a row with more than K0 segments overwrites its slots
-                    K0 = K0 > quarter ? 0u : (K0 + 32u > half ? half : quarter);
+                    // meshes whose record tables the L2s no longer hold (the per-tet writer table's threshold): the walk waits
+                    // for HBM itself and hides less -- the last quarter where the estimate (which carries a 32-slot margin) still
+                    // allows it (C5, 1M tets: rays reach slot 346 of 384: -0.9 / -1.8 % in two runs, the last half +0.4 %,
+                    // profiles/r04w_c5_specfill*.txt; round 3 had measured the non-resident fill slower there)
+                    if (t->mesh.T >= WALK_TET_MIN_TETS) K0 = K0 > quarter + 32u ? 0u : quarter;
+                    else K0 = K0 > quarter ? 0u : (K0 + 32u > half ? half : quarter);
                     if (t->spec_k0) K0 = t->spec_k0 & ~31u;
                     if (K0 + 32u > M) K0 = 0;
                 }
