@@ -473,7 +473,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                     // for HBM itself and hides less -- the last quarter where the estimate (which carries a 32-slot margin) still
                     // allows it (C5, 1M tets: rays reach slot 346 of 384: -0.9 / -1.8 % in two runs, the last half +0.4 %,
                     // profiles/r04w_c5_specfill*.txt; round 3 had measured the non-resident fill slower there)
-                    if (t->mesh.T >= WALK_TET_MIN_TETS) K0 = K0 > quarter + 32u ? 0u : quarter;
+                    if (t->mesh.T >= tn::WALK_TET_MIN_TETS) K0 = K0 > quarter + 32u ? 0u : quarter;
                     else K0 = K0 > quarter ? 0u : (K0 + 32u > half ? half : quarter);
                     if (t->spec_k0) K0 = t->spec_k0 & ~31u;
                     if (K0 + 32u > M) K0 = 0;
