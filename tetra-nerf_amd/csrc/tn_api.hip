@@ -461,7 +461,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 // the walk (VALU-issue-bound, the fill HBM-write-bound).  The walk crawls beside a saturating write stream, so
                 // only as many bytes as its own duration buys are filled that way: the last quarter of every row (measured:
                 // profiles/r02p_specfill*.txt, r03a_sched.txt: +1..3 % per frame), and only where that quarter is mesh-safe
-                // (at 1M tets and M = 512 rays reach 346 of the 384 slots: measured -1..-6 %, off).
+                // (round 3, non-resident fill: at 1M tets and M = 512, where rays reach 346 of the 384 slots, it cost 1..6 %; see below).
                 uint32_t K0 = 0;
                 if (t->spec_fill && dense_tails) {
                     K0 = (((uint32_t)(3.6 * std::cbrt((double)std::max<uint32_t>(t->mesh.T, 1u))) + 31u) & ~31u) + 32u;
