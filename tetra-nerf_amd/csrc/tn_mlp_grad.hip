@@ -5,7 +5,7 @@
 // reductions).  All twelve gradients of a chunk of samples come from FIVE streaming kernels + their reductions:
 //
 //   k_dw_gemm<4, true>   A = d4, B = [h3 | enc(ray of the sample)]:  d Wh[:, 27:], d Wh[:, :27], d bh, and on the VALU
-//                        d wd[f] = sum_s d sigma_raw[s] h3[f][s]  (from the B operands wave f / 32 holds in registers)
+//                        d wd[f] = sum_s d sigma_raw[s] h3[f][s]  (h3's tile is in LDS anyway)
 //   k_dw_gemm<4, false>  A = d3, B = h2: d W3, d b3;   A = d2, B = h1: d W2, d b2
 //   k_dw_gemm<2, false>  A = d1, B = x0: d W1, d b1
 //   k_rgb_head_grad      d wr[c][f] = sum_s d rgb_raw[c][s] h4[f][s], d bd, d br   (bandwidth-bound: 528 B per sample)
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256, 2) void k_dw_gemm(DwArgs g, size_t n, uint32_t
         const int m = lane & 31, kk = lane >> 5;
         const float4 *arow = reinterpret_cast<const float4 *>(As + (32 * w + m) * LD + kk * 16);
         const float4 *brow = reinterpret_cast<const float4 *>(Bs + m * LD + kk * 16);
+        const int vf = tid >> 1, vh = tid & 1;             // d wd: feature row, sample parity
         for (size_t s0 = s_begin; s0 < s_end; s0 += 32) {
             __syncthreads();   // the previous step's reads of the tiles are done
 #pragma unroll
@@ -128,11 +129,6 @@ __global__ __launch_bounds__(256, 2) void k_dw_gemm(DwArgs g, size_t n, uint32_t
             __syncthreads();
             if (s0 + 32 < s_end) fetch(s0 + 32);
             float4 a4[4], b4[2][4];
-            float4 dq[EXTRA ? 4 : 1];
-            if constexpr (EXTRA) {   // d sigma_raw of this lane's 16 samples of the step (the k half its B operands cover)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dq[q] = reinterpret_cast<const float4 *>(dhs + kk * 16)[q];
-            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) a4[q] = arow[q];
 #pragma unroll
@@ -152,21 +148,19 @@ __global__ __launch_bounds__(256, 2) void k_dw_gemm(DwArgs g, size_t n, uint32_t
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[c], 0, 0, 0);
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[c], 0, 0, 0);
                 }
-                if constexpr (EXTRA) {
-                    // d wd[32 c + m] += sum over the step of d sigma_raw * h3: the B operands of tile c ARE h3's rows 32 c + m
-                    // (16 samples per lane), so wave c takes that tile from its registers -- no second pass over the LDS tile
-                    if (c < NBM && c == w) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float4 x = b4[c & 1][q], d = dq[q];
-                            dv += (x.x * d.x + x.y * d.y) + (x.z * d.z + x.w * d.w);
-                        }
-                    }
-                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) rsum += (a4[q].x + a4[q].y) + (a4[q].z + a4[q].w);
+            if (EXTRA) {
+                const float4 *hr = reinterpret_cast<const float4 *>(Bs + vf * LD + vh * 16);
+                const float4 *dr = reinterpret_cast<const float4 *>(dhs + vh * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 x = hr[q], d = dr[q];
+                    dv += (x.x * d.x + x.y * d.y) + (x.z * d.z + x.w * d.w);
+                }
+            }
         }
     }
     // partial sums of this block (zeros when the block had no samples: the reduction adds every slot)
@@ -179,8 +173,8 @@ __global__ __launch_bounds__(256, 2) void k_dw_gemm(DwArgs g, size_t n, uint32_t
     rsum += __shfl_xor(rsum, 32);
     if (lane < 32) part[RA * RB + 32 * w + lane] = rsum;
     if (EXTRA) {
-        dv += __shfl_xor(dv, 32);                           // the two k halves of row 32 w + m
-        if (lane < 32) part[RA * RB + 128 + 32 * w + lane] = dv;
+        dv += __shfl_xor(dv, 1);
+        if ((tid & 1) == 0) part[RA * RB + 128 + (tid >> 1)] = dv;
     } else if (tid < 128) {
         part[RA * RB + 128 + tid] = 0.f;
     }
