@@ -155,11 +155,47 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
                                    "fp32 accumulate; same 1e-5 parity tests; not the default"}}
 
 
+def box_write_ceiling(tn, out, reps=5):
+    """The write rate THIS box sustains, measured in this process: the product's own tail-fill kernel (k_fill_range,
+    tn_fill_rows) ALONE over every slot of the dense rows of one bench launch.  88 % of a trace_rays call's bytes are
+    these constant tails, so this is the ceiling of the call on this box (boxes of this pool differ by +-12 %: the
+    same kernel writes 5.1 TB/s on some and 6.6 TB/s on others)."""
+    cpp = tn.cpp
+    args = (out["visited_cells"], out["barycentric_coordinates"], out["hit_distances"], out["vertex_indices"])
+    R, M = out["visited_cells"].shape
+    cpp.fill_rows(*args)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        cpp.fill_rows(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = R * M * 52
+    return {"GBps": nbytes / (ms * 1e-3) / 1e9, "bytes": nbytes, "ms": ms,
+            "kernel": "k_fill_range (tn_fill_rows) alone, all slots of the bench launch's rows, same process"}
+
+
+def trace_breakdown(tracer, o, d, M):
+    """Per-kernel HIP-event milliseconds of ONE extra launch with the kernels serialised on the caller's stream (option
+    "timing"); the normal schedule overlaps them on four streams, so the parts do not add up to `ms`."""
+    tracer.set_option("timing", 1)
+    try:
+        out = tracer.trace_rays(o, d, M)
+        del out
+        bd = tracer.trace_timings()
+    finally:
+        tracer.set_option("timing", 0)
+    bd["sum_serialised"] = sum(bd.values())
+    return bd
+
+
 def cross_check(reasons, stride=256):
     return {"stride": stride, "checked": int(reasons.get("15", 0)), "mismatches": int(reasons.get("14", 0))}
 
 
-def trace_leg(tracer, o, d, M, reps):
+def trace_leg(tracer, o, d, M, reps, box_ceiling_gbps=None):
     """ms per trace_rays call (HIP events on the launch stream), intersections, path statistics."""
     def run():
         out = tracer.trace_rays(o, d, M)
@@ -180,13 +216,18 @@ def trace_leg(tracer, o, d, M, reps):
     ms = e0.elapsed_time(e1) / reps
     R = o.shape[0]
     gbs = R * (28 + 52 * M) / (ms * 1e-3) / 1e9
-    return {"rays": R, "ms": ms, "rays_per_s": R / (ms * 1e-3), "intersections_per_s": inter / (ms * 1e-3),
-            "intersections": inter, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                 "frac": gbs / HBM_PEAK_GBS}, "paths": stats,
-            "certification_cross_check": cross_check(stats["reasons"])}
+    roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+    if box_ceiling_gbps:
+        roof["frac_of_box_write_ceiling"] = gbs / box_ceiling_gbps
+    leg = {"rays": R, "ms": ms, "rays_per_s": R / (ms * 1e-3), "intersections_per_s": inter / (ms * 1e-3),
+           "intersections": inter, "roofline": roof, "paths": stats,
+           "certification_cross_check": cross_check(stats["reasons"])}
+    if stats.get("walk", 0) and R >= 12288:
+        leg["breakdown_ms_serialised"] = trace_breakdown(tracer, o, d, M)
+    return leg
 
 
-def config_legs(tn, scenes, dev, M):
+def config_legs(tn, scenes, dev, M, box_ceiling_gbps=None):
     """The other BASELINE.json sizes: C4 = 45,000 points seed 2 (~302k tets): the 800x800 frame and the
     two 4096-ray training batches; C5 = 150,000 points seed 3 (~1.01M tets): 2^20 outside-in rays seed 4."""
     out = {}
@@ -208,14 +249,120 @@ def config_legs(tn, scenes, dev, M):
                  ("C4_batch_4096_inside_out", scenes.inside_out_rays(4096, 2), 20)) if cfg == "C4" else
                 (("C5_2^20_outside_in", scenes.outside_in_rays(1 << 20, 4), 3),))
         for name, (o, d), reps in sets:
-            leg = trace_leg(tr, torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), M, reps)
+            leg = trace_leg(tr, torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), M, reps, box_ceiling_gbps)
             leg.update(tets=int(len(cells)), mesh_sha256=mesh_sha256(pts, cells), load_tetrahedra_s=load_s,
                        load_tetrahedra_host_build_s=loads["host_build"])
             out[name] = leg
         if cfg == "C4":
             out["C4_train_4096"] = train_leg(tn, tr, len(pts), scenes, M, dev)
+            out["C4_ops"] = ops_leg(tn, tr, pts, scenes, M, dev)
         del tr
         torch.cuda.empty_cache()
+    return out
+
+
+def _timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def ops_leg(tn, tracer, pts, scenes, M, dev, cpu=True):
+    """The three stand-alone ops the UNMODIFIED reference model calls every step (model.py:560-573 and autograd):
+    find_visited_cells (src/tetrahedra_tracer.cu:115-193; 37 algorithmic bytes per sample: 4 read + 33 written),
+    interpolate_values forward / backward (:195-290; 284 B per sample: 16 ids + 12 weights + 256 of features), on the C4
+    mesh at the two sizes SURVEY.md 8(d) names: a 4096-ray training batch with 513 fine samples, and a 65,536-ray
+    evaluation chunk with 256 coarse samples.  CPU baseline (rank 0, bounded): the oracle's port of the same three
+    functions (timing build, all host cores) and the MLP forward in torch on the CPU."""
+    cpp = tn.cpp
+    V = len(pts)
+    torch.manual_seed(0)
+    field = torch.randn(64, V, device=dev)
+    res = {}
+    keep = None
+    fo, fd = frame_rays(scenes, 0, 800, 800)
+    bo, bd = scenes.outside_in_rays(4096, 1)
+    for name, (o_np, d_np), S, want in (("4096x513", (bo, bd), 513, 4096), ("65536x256", (fo, fd), 256, 65536)):
+        o, d = torch.from_numpy(o_np).to(dev), torch.from_numpy(d_np).to(dev)
+        out = tracer.trace_rays(o, d, M, compact_rows=True)
+        idx = torch.nonzero(out["num_visited_cells"] > 0)[:, 0][:want]
+        lists = [out[k][idx].contiguous() for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates",
+                                                      "hit_distances", "vertex_indices")]
+        del out
+        R = int(idx.numel())
+        nv = lists[0].long()
+        near = lists[3][:, 0, 0][:, None]
+        far = torch.gather(lists[3][:, :, 1], 1, (nv[:, None] - 1).clamp_min(0))
+        ts = torch.linspace(0.0, 1.0, S, device=dev)[None]
+        dist = (near * (1 - ts) + far * ts).contiguous()
+        n = R * S
+        traced = tracer.find_visited_cells(*lists, dist)
+        vi, bc = traced["vertex_indices"], traced["barycentric_coordinates"]
+        ms_match = _timed(lambda: tracer.find_visited_cells(*lists, dist), 10)
+        ms_fwd = _timed(lambda: cpp.interpolate_values(vi, bc, field), 10)
+        g = torch.randn(R, S, 64, device=dev)
+        ms_bwd = _timed(lambda: cpp.interpolate_values_backward(vi, bc, field, g), 10)
+
+        def roof(ms, bytes_per_sample):
+            gbs = n * bytes_per_sample / (ms * 1e-3) / 1e9
+            return {"ms": ms, "samples_per_s": n / (ms * 1e-3), "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                                                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                                                                "algorithmic_bytes_per_sample": bytes_per_sample}}
+        res[name] = {"rays": R, "samples_per_ray": S, "matched_fraction": float(traced["mask"].float().mean()),
+                     "find_visited_cells": roof(ms_match, 37), "interpolate_values": roof(ms_fwd, 284),
+                     "interpolate_values_backward": roof(ms_bwd, 284)}
+        if name == "4096x513":
+            keep = ([x.cpu().numpy() for x in lists], dist.cpu().numpy(), vi.cpu().numpy(), bc.cpu().numpy(),
+                    field.cpu().numpy(), R, S)
+        del lists, traced, vi, bc, g, dist
+        torch.cuda.empty_cache()
+    if cpu and keep is not None:
+        res["cpu_baseline"] = cpu_ops_baseline(*keep)
+    return res
+
+
+def cpu_ops_baseline(lists, dist, vi, bc, field, R, S):
+    """the oracle's find_matched_cells / interpolate_values (+ adjoint), timing build (-O3 -march=native
+    -fopenmp), all host cores, on the 4096 x 513 batch; the shallow MLP forward in torch on the CPU on a bounded sample."""
+    from oracle import tn_oracle
+
+    n = R * S
+    out = {"cores": tn_oracle.num_threads(), "kind": "port", "sample": f"{R} rays x {S} samples of the C4 mesh (the 4096x513 leg)"}
+    tn_oracle.find_visited_cells(*[x[:64] for x in lists], dist[:64], fast=True)          # loads / builds the timing library
+    t0 = time.perf_counter()
+    tn_oracle.find_visited_cells(*lists, dist, fast=True)
+    dt = time.perf_counter() - t0
+    out["find_visited_cells"] = {"s": dt, "samples_per_s": n / dt}
+    t0 = time.perf_counter()
+    feats = tn_oracle.interpolate_values(vi, bc, field, fast=True)
+    dt = time.perf_counter() - t0
+    out["interpolate_values"] = {"s": dt, "samples_per_s": n / dt}
+    g = np.ones((R, S, 64), np.float32)
+    t0 = time.perf_counter()
+    tn_oracle.interpolate_values_backward(vi, bc, field, g, fast=True)
+    dt = time.perf_counter() - t0
+    out["interpolate_values_backward"] = {"s": dt, "samples_per_s": n / dt}
+    # the shallow MLP + heads (model.py:414-455, 602-621) as plain torch on the host cores
+    render = importlib.import_module("tetra-nerf_amd.render")
+    torch.manual_seed(0)
+    mlp = render.TetraMLP()
+    m = min(n, 1 << 18)
+    x = torch.from_numpy(np.ascontiguousarray(feats.reshape(-1, 64)[:m]))
+    dirs = torch.nn.functional.normalize(torch.randn(m, 3), dim=-1)
+    with torch.no_grad():
+        mlp(x[:4096], dirs[:4096])
+        t0 = time.perf_counter()
+        mlp(x, dirs)
+        dt = time.perf_counter() - t0
+    flop = 2 * (64 * 128 + 128 * 128 * 2 + 128 + 155 * 128 + 128 * 3)
+    out["mlp_forward_torch_cpu"] = {"s": dt, "samples_per_s": m / dt, "TFLOPs": m * flop / dt / 1e12, "samples": m,
+                                    "threads": torch.get_num_threads()}
     return out
 
 
@@ -305,7 +452,7 @@ def sharded_render_leg(tn, tracer, num_vertices, scenes, width, height, M, dev, 
             "pass": "coarse only (uniform samples), fused MLP + composite"}
 
 
-def ddp_train_leg(tn, scenes, dev, M, rank, world, iters=5, mesh_points=45000, mesh_seed=2, rays=4096):
+def ddp_train_leg(tn, scenes, dev, M, rank, world, iters=5, mesh_points=45000, mesh_seed=2, rays=4096, warm=6):
     """The reference's only training-time collective (pipeline.py:53-58): the model replicated under
     DistributedDataParallel(find_unused_parameters=True), every rank training on ITS OWN 4096-ray batch of the C4 mesh
     (BASELINE.json configs[3]), gradients of tetrahedra_field (256 V bytes) + the MLP (245 KB) all-reduced over RCCL.
@@ -343,8 +490,8 @@ def ddp_train_leg(tn, scenes, dev, M, rank, world, iters=5, mesh_points=45000, m
 
         res = {}
         for what, sync in (("ddp", True), ("no_sync", False)):
-            step(sync)
-            step(sync)
+            for _ in range(warm):     # DDP rebuilds its buckets after the first iteration (find_unused_parameters=True): not timed
+                step(sync)
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -356,7 +503,7 @@ def ddp_train_leg(tn, scenes, dev, M, rank, world, iters=5, mesh_points=45000, m
             torch.cuda.synchronize()
             res[what] = sharding.max_over_ranks((time.perf_counter() - t0) / iters, device=dev) * 1e3
         grad_bytes = sum(p.numel() for p in module.parameters()) * 4
-        out[name] = {"ms_per_iteration": res["ddp"], "ms_per_iteration_no_sync": res["no_sync"],
+        out[name] = {"ms_per_iteration": res["ddp"], "ms_per_iteration_no_sync": res["no_sync"], "warmup_iterations": warm,
                      "exposed_all_reduce_ms": res["ddp"] - res["no_sync"], "rays_per_s": world * rays / (res["ddp"] * 1e-3),
                      "rays_per_rank": rays, "all_reduced_bytes_per_iteration": grad_bytes}
         del model, module, opt
@@ -506,9 +653,18 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     tot_inter = float(inter)
     sharding = importlib.import_module("tetra-nerf_amd.sharding")
+    per_rank_ms = [x / args.steps * 1e3 for x in sharding.gather_scalars(elapsed, device=dev)]   # a straggler shows here
+    per_rank_kern_ms = sharding.gather_scalars(kern_ms, device=dev)
     elapsed = sharding.max_over_ranks(elapsed, device=dev)           # MAX over ranks
     tot_inter, tot_rays = sharding.sum_over_ranks([tot_inter, float(R)], device=dev)  # whole-job units
 
+    # the write rate this box sustains, measured in this process (every rank: its own GPU), and the serialised per-kernel
+    # breakdown of one extra launch
+    full = tracer.trace_rays(o, d, M)
+    ceiling = box_write_ceiling(tn, full)
+    del full
+    breakdown = trace_breakdown(tracer, o, d, M) if stats.get("walk", 0) else None
+    per_rank_ceiling = sharding.gather_scalars(ceiling["GBps"], device=dev)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         alg_bytes = R * (28 + 52 * M)  # o,d + count + dense rows, SURVEY.md 8(d)
@@ -538,11 +694,20 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, R, M),
                 "traffic_source": "committed rocprofv3 PMC passes of this command (profiles/traffic.json), not read in this run",
-                "kernel": "trace_rays launch (walk + general fallback)",
+                # `achieved` / `frac` are LAUNCH figures (conservative): the whole trace_rays call -- walk, segment writer, tail
+                # fills, literal pairing, BVH fallback, cross-check -- over the HIP-event duration of the call.  The dominant
+                # kernel by time and bytes is k_fill_range (the constant tails, 88 % of the bytes): its own rate is
+                # `box_write_ceiling_GBps`, measured in this process on this box
+                "kernel": "trace_rays launch = k_trace_walk + k_write_segments + 2 x k_fill_range (dominant) + k_postprocess_log + "
+                          "k_trace_general + k_verify_counts",
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
+                "box_write_ceiling_GBps": ceiling["GBps"], "box_write_ceiling": ceiling,
+                "frac_of_box_write_ceiling": achieved / ceiling["GBps"],
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
-                "frac_of_measured_write_ceiling_5500": achieved / 5500.0,  # torch fill_ of 15 GB, profiles/r01_overlap_sweep.txt
+                "breakdown_ms_serialised": breakdown,
             },
+            "ms_per_step_per_rank": per_rank_ms, "kernel_ms_per_rank": per_rank_kern_ms,
+            "box_write_ceiling_GBps_per_rank": per_rank_ceiling,
             "trace_path_stats": stats,
             "walk_hand_over_reasons": reasons,
             # the always-on sampled cross-check of the walk's certification (count-only BVH traversal of every 256th ray,
@@ -590,14 +755,22 @@ def main():
         if not args.no_configs and world == 1:
             del tracer
             torch.cuda.empty_cache()
-            line["configs"] = config_legs(tn, scenes, dev, M)
+            line["configs"] = config_legs(tn, scenes, dev, M, ceiling["GBps"])
             line["configs"]["C2_frame_800x800"] = {"rays": R, "ms": kern_ms, "rays_per_s": R / (kern_ms * 1e-3),
                                                    "intersections_per_s": inter / (kern_ms * 1e-3), "intersections": inter,
                                                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                                                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS},
+                                                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                                                "frac_of_box_write_ceiling": achieved / ceiling["GBps"]},
+                                                   "breakdown_ms_serialised": breakdown,
                                                    "paths": stats, "tets": int(len(cells)), "note": "the headline workload"}
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(pts, cells, o_np, d_np, M)
+        if world > 1:
+            line["configs"] = "single-GPU legs (C4 / C5 / training / stand-alone ops): see the --gpus 1 line"
+        if not args.no_cpu_baseline:
+            # rank 0's host cores (the other ranks are idle by now); a shorter sample in multi-rank runs
+            line["cpu_baseline"] = cpu_baseline(pts, cells, o_np, d_np, M, target_s=30.0 if world == 1 else 10.0)
+            ops = line.get("configs", {}).get("C4_ops") if isinstance(line.get("configs"), dict) else None
+            if ops and "cpu_baseline" in ops:
+                line["cpu_baseline"]["ops"] = ops["cpu_baseline"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -89,7 +89,8 @@ int tn_trace_rays(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_triangle
  * for num_visited[r] = 0) -- for consumers that read the rows only through num_visited (tn_sample_*, tn_render_pass,
  * tn_find_matched_cells_indexed): 52 B per segment instead of 52*M B per ray.  A per-call argument rather than a tracer
  * option, so that threads sharing a tracer (nerfstudio's viewer and trainer share the model) cannot see each other's
- * choice. */
+ * choice.  Calls on ONE tracer handle are serialised inside the library (a per-tracer mutex around the host section: the
+ * tracer's scratch buffers, counters, side streams and events are shared state); their kernels queue on the streams. */
 #define TN_TRACE_COMPACT_ROWS 1u
 int tn_trace_rays_ex(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_triangles,
                      const float *origins, const float *directions, uint32_t *num_visited,
@@ -131,7 +132,21 @@ int tn_find_matched_cells_indexed(size_t num_rays, size_t num_samples, size_t ma
                                   const uint32_t *ray_index, const uint32_t *num_visited, const uint32_t *visited,
                                   const float *dist, const float *bary, const float *distances,
                                   const uint32_t *verts, uint32_t *cells_out, uint32_t *verts_out,
-                                  uint8_t *mask_out, float *bary_out, void *stream);
+                                  uint8_t *mask_out, float *bary_out, const uint32_t *count /* see tn_compact_hits */,
+                                  void *stream);
+
+/* Compaction of the hitting rays ON THE DEVICE (addition; the reference compacts with boolean indexing, model.py:540-567 --
+ * a device -> host synchronisation per call).  A stable partition of the rays of a trace call by num_visited > 0:
+ * order u32 [R]: order[0 .. *count) = the rays that hit the mesh, in ray order, order[*count .. R) = the others, in ray order;
+ * count u32 [1] stays in DEVICE memory; padded u32 [R] (nullable) = order with the entries from *count on replaced by
+ * order[0] (a full-size index whose tail names a valid ray: what a padded, sync-free batch is gathered with).
+ * scratch: 2 * ceil(R / 2048) uint32 of device memory (scratch_len = its length).
+ * `count` ARGUMENTS of the entry points below (tn_sample_coarse, tn_sample_pdf, tn_find_matched_cells_indexed,
+ * tn_mlp_forward_gather, tn_composite, tn_render_rays): a nullable device pointer to the number of rays to process; when it is
+ * given, the size argument (num_hit_rays / num_rays / n) is only the UPPER BOUND the launch is sized for and the outputs are
+ * allocated for -- rows from *count on are left unwritten -- so that nothing on the host ever waits for the ray count. */
+int tn_compact_hits(size_t num_rays, const uint32_t *num_visited, uint32_t *order, uint32_t *count, uint32_t *padded,
+                    uint32_t *scratch, size_t scratch_len, void *stream);
 
 /* interpolate_values<D>                                src/tetrahedra_tracer.h:395-402,
  *                                                       src/tetrahedra_tracer.cu:195-221,250-266
@@ -208,6 +223,20 @@ int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]);
  * (re-traced through the BVH path; never observed). */
 int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
 
+/* Per-kernel breakdown of the last one-chunk walk call traced with option "timing" = 1 (measurement aid; bench.py prints it):
+ * with that option the kernels of a call are enqueued on the CALLER's stream in program order with a timing event after each
+ * (a normal call overlaps them on four streams, so its parts do not add up to its duration).  ms[0..7] = speculative tail fill,
+ * adjacency walk, BVH re-trace of the fallback rays, count cross-check, segment writer, literal pairing of the logged hits,
+ * tail fill, re-trace of cross-check mismatches.  Waits for the call to finish. */
+int tn_trace_timings(tn_tracer_t tracer, float ms[8]);
+
+/* The constant tails of the dense reference rows (py_binding.cpp:53-57: torch::zeros / full(-1) of the five outputs) for slots
+ * [first_slot & ~31, M) of EVERY row: visited / verts = 0xFFFFFFFF, bary / dist = 0.  The tracer's own tail-fill kernel as a
+ * stand-alone op: what a caller that traced with TN_TRACE_COMPACT_ROWS runs if it later needs dense rows, and what bench.py
+ * times to learn the write rate THIS box sustains (the ceiling of a trace_rays call, whose bytes are 88 % constant tails). */
+int tn_fill_rows(size_t num_rays, uint32_t max_ray_triangles, uint32_t first_slot, uint32_t *visited, float *bary, float *dist,
+                 uint32_t *verts, void *stream);
+
 /* knobs ("walk" and "gpu_build" also through the environment: TETRANERF_HIP_WALK, TETRANERF_HIP_GPU_BUILD):
  *   "walk"    1 = adjacency-walk fast path with general-path fallback (default),
  *             0 = general all-hits path for every ray, 2 = walk for any batch size
@@ -240,6 +269,8 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
  *             "verify_inject" 1 = every checked ray counts as a mismatch (tests of the hand-over)
  *   "literal_sort_passes"  (default 8) odd-even transposition passes over the nearly sorted hits the walk logged for a ray
  *             whose order it does not certify, before the bitonic network takes over (same result: distinct keys; tests run 0 and 1)
+ *   "timing"  1 = serialise the kernels of a one-chunk walk call on the caller's stream with timing events (tn_trace_timings);
+ *             0 (default) = the overlapped four-stream schedule
  *   "writer_table"  0 (default) = the segment writer's record table by mesh size (one record per (tet, entry face) below
  *             500k tets, one per tet above), 1 / 2 force either (applies at the next tn_load_tetrahedra; tests, A/B)
  * Unknown names are an error. */
@@ -299,7 +330,8 @@ int tn_mlp_forward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const float
  * makes (and differentiates: tn_mlp_ray_head_grad returns dL/dc_ray).  wh of tn_mlp_weights stays [128, 155]. */
 int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices,
                           const float *barycentric, const float *field_vm, const float *dirs, int mode, float *sigma,
-                          float *rgb, const float *ray_head_bias, void *stream);
+                          float *rgb, const float *ray_head_bias, const uint32_t *count /* device-side number of RAYS, nullable */,
+                          void *stream);
 
 /* One render PASS of TetrahedraNerf.get_outputs as ONE launch (reference span
  * tetranerf/nerfstudio/model.py:560-662 = find_visited_cells -> interpolate_values -> mlp_base + heads -> get_weights ->
@@ -337,18 +369,20 @@ int tn_render_pass(tn_mlp_t mlp, uint32_t max_ray_triangles, const uint32_t *num
  *   merged with the coarse edges: edges_out f32 [r, S + num_fine + 2], sorted, euclidean. */
 int tn_sample_coarse(size_t num_hit_rays, uint32_t num_samples, uint32_t max_ray_triangles, const uint32_t *ray_index,
                      const uint32_t *num_visited, const float *hit_distances, const float *linspace, const float *t_rand,
-                     int biased, float *edges, float *near_far, void *stream);
+                     int biased, float *edges, float *near_far, const uint32_t *count, void *stream);
 int tn_sample_pdf(size_t num_hit_rays, uint32_t num_samples, uint32_t num_fine, const float *edges, const float *weights,
                   const float *near_far, const float *u_table, const float *u_rand, float histogram_padding, float eps,
-                  float *edges_out, void *stream);
+                  float *edges_out, const uint32_t *count, void *stream);
 
 /* RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers.
  * sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1] (bin edges: starts = edges[:, :-1], ends = edges[:, 1:]);
  * out_rgb f32 [R,3], out_acc f32 [R], out_depth f32 [R], out_weights f32 [R,S] (nullable).
- * rgb == NULL and out_rgb == NULL: only out_weights is written (get_weights of the coarse pass, model.py:582). */
+ * rgb == NULL and out_rgb == NULL: only out_weights is written (get_weights of the coarse pass, model.py:582).
+ * ray_index u32 [R] (nullable): out_rgb / out_acc / out_depth are then arrays over ALL rays of the trace call and row q is
+ * written at ray_index[q] (the scatter of model.py:640-662 into the frame, without an index_put pass). */
 int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, const float *rgb, const float *edges,
                  const tn_rgb_background *background, float *out_rgb, float *out_acc, float *out_depth,
-                 float *out_weights, void *stream);
+                 float *out_weights, const uint32_t *ray_index, const uint32_t *count, void *stream);
 
 /* ---- training: the MLP node and the composite node (PyTorch autograd in the reference: the trainer
  * back-propagates through nerfstudio's MLP / renderers, model.py:602-638).  Three calls per batch of n samples, all on

@@ -211,7 +211,8 @@ def postprocess(faces, face_tets, hit_count, hit_ids, hit_t, hit_uv):
 
 
 def find_visited_cells(num_visited_cells, visited_cells, barycentric_coordinates, hit_distances,
-                       vertex_indices, distances):
+                       vertex_indices, distances, fast: bool = False):
+    """fast = the timing-only build (bench.py's cpu_baseline; never used as a checker)."""
     nv = _u32(num_visited_cells)
     vc = _u32(visited_cells)
     R, M = vc.shape
@@ -222,7 +223,7 @@ def find_visited_cells(num_visited_cells, visited_cells, barycentric_coordinates
     verts = np.empty((R, S, 4), np.uint32)
     mask = np.empty((R, S), np.uint8)
     bary = np.empty((R, S, 3), np.float32)
-    rc = lib().tno_find_matched_cells(
+    rc = (lib_fast() if fast else lib()).tno_find_matched_cells(
         C.c_uint64(R), C.c_uint64(S), C.c_uint64(M), _p(nv), _p(vc), _p(_f32(hit_distances)),
         _p(_f32(barycentric_coordinates)), _p(dist), _p(_u32(vertex_indices)),
         _p(cells), _p(verts), _p(mask), _p(bary))
@@ -232,7 +233,7 @@ def find_visited_cells(num_visited_cells, visited_cells, barycentric_coordinates
             "mask": mask.astype(bool), "barycentric_coordinates": bary}
 
 
-def interpolate_values(vertex_indices, barycentric_coordinates, field):
+def interpolate_values(vertex_indices, barycentric_coordinates, field, fast: bool = False):
     vi = _u32(vertex_indices)
     bc = _f32(barycentric_coordinates)
     field = _f32(field)
@@ -241,14 +242,14 @@ def interpolate_values(vertex_indices, barycentric_coordinates, field):
     n = vi.size // D
     Fd, V = field.shape
     out = np.empty((Fd, n), np.float32)
-    rc = lib().tno_interpolate_values(C.c_uint32(D), C.c_uint32(V), C.c_uint32(n), C.c_uint32(Fd),
+    rc = (lib_fast() if fast else lib()).tno_interpolate_values(C.c_uint32(D), C.c_uint32(V), C.c_uint32(n), C.c_uint32(Fd),
                                       _p(vi), _p(bc), _p(field), _p(out))
     if rc:
         raise RuntimeError(f"Unsupported interpolation dimension with value {D}")
     return np.moveaxis(out.reshape((Fd,) + vi.shape[:-1]), 0, -1)
 
 
-def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, grad_in):
+def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, grad_in, fast: bool = False):
     vi = _u32(vertex_indices)
     bc = _f32(barycentric_coordinates)
     field = _f32(field)
@@ -257,7 +258,7 @@ def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, 
     Fd, V = field.shape
     g = np.ascontiguousarray(np.moveaxis(_f32(grad_in), -1, 0)).reshape(Fd, n)
     out = np.empty((Fd, V), np.float32)
-    rc = lib().tno_interpolate_values_backward(C.c_uint32(D), C.c_uint32(V), C.c_uint32(n),
+    rc = (lib_fast() if fast else lib()).tno_interpolate_values_backward(C.c_uint32(D), C.c_uint32(V), C.c_uint32(n),
                                                C.c_uint32(Fd), _p(vi), _p(bc), _p(g), _p(out))
     if rc:
         raise RuntimeError(f"Unsupported interpolation dimension with value {D}")

@@ -80,6 +80,17 @@ struct tn_tracer {
     bool last_walk = false;
     bool loaded = false;
     hipStream_t last_stream = nullptr;
+    // One tracer = one set of scratch buffers, counters, side streams and events: calls on the SAME handle are serialised
+    // here (host section only: the kernels of two calls still queue behind each other on their streams).  ctypes releases
+    // the GIL, so a viewer thread and a trainer sharing a tracer can be inside tn_trace_rays* at the same time.
+    std::mutex mu;
+    // option "timing" = 1: every kernel of a one-chunk walk call is enqueued on the CALLER's stream, in program order,
+    // with a timing event after each -- the per-kernel breakdown bench.py prints (tn_trace_timings); the schedule of a
+    // normal call overlaps them on four streams, so the parts do not add up to a call's duration
+    bool timing = false;
+    static constexpr int N_TEV = 9;
+    hipEvent_t tev[N_TEV] = {};
+    bool tev_valid = false;
 };
 
 namespace {
@@ -168,6 +179,8 @@ int tn_tracer_destroy(tn_tracer_t tracer) {
             if (st) (void)hipStreamDestroy(st);
         for (hipEvent_t e : {tracer->ev_fork, tracer->ev_join, tracer->ev_start, tracer->ev_pre, tracer->ev_seg, tracer->ev_aux})
             if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : tracer->tev)
+            if (e) (void)hipEventDestroy(e);
         delete tracer;
     });
 }
@@ -176,6 +189,7 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
                        void *stream_) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);
+        std::lock_guard<std::mutex> lock(t->mu);
         DeviceGuard g(t->device);
         hipStream_t stream = (hipStream_t)stream_;
         if ((V && !xyz) || (T && !cells)) throw tn::Error("xyz / cells must not be null");
@@ -354,6 +368,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                              uint32_t flags, void *stream_) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);
+        std::lock_guard<std::mutex> lock(t->mu);
         if (flags & ~(uint32_t)TN_TRACE_COMPACT_ROWS) throw tn::Error("unknown trace flag");
         // per CALL, not per tracer: a viewer thread and a trainer sharing one tracer may ask for different row forms
         const bool dense_tails = t->dense_tails && !(flags & TN_TRACE_COMPACT_ROWS);
@@ -388,6 +403,12 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
             // (or a literal / fallback row) simply overwrites its slots.  The log holds 16 B per hit slot; calls whose log
             // would exceed the cap are processed in ray chunks (multiples of 4096 rays, the walk's XCD run), serially.
             if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); }
+            if (t->verify_stride) {
+                // sized with the other scratch buffers, BEFORE the first launch of the call: an allocation in the middle of
+                // the overlapped schedule would synchronise the device there (hipFree / hipMalloc)
+                const size_t n_checks = (R + t->verify_stride - 1) / t->verify_stride;
+                if (t->verify_list.n < n_checks) t->verify_list.alloc(n_checks);
+            }
             size_t cap_bytes = t->log_cap_bytes;
             if (!cap_bytes) {
                 // the log lives for the tracer's lifetime: at most a quarter of what is free now (plus what it already
@@ -478,37 +499,50 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                     if (t->spec_k0) K0 = t->spec_k0 & ~31u;
                     if (K0 + 32u > M) K0 = 0;
                 }
+                // option "timing": the same kernels, serialised on the caller's stream with a timing event after each
+                const bool timing = t->timing;
+                hipStream_t s_pre = timing ? stream : t->pre, s_aux = timing ? stream : t->aux, s_side = timing ? stream : t->side;
+                if (timing && !t->tev[0])
+                    for (hipEvent_t &e : t->tev) TN_HIP(hipEventCreate(&e));
+                int mark_i = 0;
+                auto mark = [&] { if (timing) TN_HIP(hipEventRecord(t->tev[mark_i++], stream)); };
+                mark();                                                   // 0: start
                 if (K0) {
                     TN_HIP(hipEventRecord(t->ev_start, stream));
-                    TN_HIP(hipStreamWaitEvent(t->pre, t->ev_start, 0));
-                    tn::launch_fill_range(R, M, true, t->walk_n.p, num_visited, visited, bary, dist, verts, t->pre, K0, true, t->spec_blocks);
-                    TN_HIP(hipEventRecord(t->ev_pre, t->pre));
-                    walk_reserve = (size_t)t->walk_lds_kb * 1024;
+                    TN_HIP(hipStreamWaitEvent(s_pre, t->ev_start, 0));
+                    tn::launch_fill_range(R, M, true, t->walk_n.p, num_visited, visited, bary, dist, verts, s_pre, K0, true, t->spec_blocks);
+                    TN_HIP(hipEventRecord(t->ev_pre, s_pre));
+                    walk_reserve = timing ? 0 : (size_t)t->walk_lds_kb * 1024;
                 }
+                mark();                                                   // 1: speculative fill
                 launch_walk(0, R);
+                mark();                                                   // 2: walk
                 TN_HIP(hipEventRecord(t->ev_fork, stream));
-                TN_HIP(hipStreamWaitEvent(t->aux, t->ev_fork, 0));
+                TN_HIP(hipStreamWaitEvent(s_aux, t->ev_fork, 0));
                 if (K0) {   // everything that writes rows comes after the speculative fill
-                    TN_HIP(hipStreamWaitEvent(t->aux, t->ev_pre, 0));
+                    TN_HIP(hipStreamWaitEvent(s_aux, t->ev_pre, 0));
                     TN_HIP(hipStreamWaitEvent(stream, t->ev_pre, 0));
                 }
-                tn::launch_trace_general(p, t->aux);
+                tn::launch_trace_general(p, s_aux);
+                mark();                                                   // 3: BVH re-trace of the fallback rays
                 if (t->verify_stride) {
                     // the count cross-check beside the writer and the fill (late form): mismatching rays -> verify_list
-                    const size_t n_checks = (R + t->verify_stride - 1) / t->verify_stride;
-                    if (t->verify_list.n < n_checks) t->verify_list.alloc(n_checks);
                     tn::launch_verify_counts(chunk_params(0, R), t->verify_stride, t->walk_n.p, t->verify_list.p, t->verify_count(), 0,
-                                             t->aux, true, t->verify_inject);
+                                             s_aux, true, t->verify_inject);
                 }
-                TN_HIP(hipEventRecord(t->ev_aux, t->aux));
+                mark();                                                   // 4: count cross-check
+                TN_HIP(hipEventRecord(t->ev_aux, s_aux));
                 // the segment writer is enqueued BEFORE the side stream's kernel: its grid is sized for the worst case (the
                 // count lives on the device) and would otherwise take every wave slot first
                 launch_segments(0, R);
+                mark();                                                   // 5: segment writer
                 TN_HIP(hipEventRecord(t->ev_seg, stream));
-                TN_HIP(hipStreamWaitEvent(t->side, t->ev_seg, 0));   // literal pairing beside the bandwidth-bound fill, not
-                launch_literal(0, R, t->side);                       // beside the latency-bound writer (r02f_sched_sweep.txt)
+                TN_HIP(hipStreamWaitEvent(s_side, t->ev_seg, 0));    // literal pairing beside the bandwidth-bound fill, not
+                launch_literal(0, R, s_side);                        // beside the latency-bound writer (r02f_sched_sweep.txt)
+                mark();                                                   // 6: literal pairing of the logged hits
                 launch_fill(0, R, K0 ? K0 : M);
-                TN_HIP(hipEventRecord(t->ev_join, t->side));
+                mark();                                                   // 7: tail fill
+                TN_HIP(hipEventRecord(t->ev_join, s_side));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_join, 0));
                 TN_HIP(hipStreamWaitEvent(stream, t->ev_aux, 0));
                 if (t->verify_stride) {
@@ -520,6 +554,8 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                     pv.item_count = t->verify_count();
                     tn::launch_trace_general(pv, stream);
                 }
+                mark();                                                   // 8: end
+                t->tev_valid = timing;
             } else {
                 for (size_t base = 0; base < R; base += chunk) {
                     const size_t n = R - base < chunk ? R - base : chunk;
@@ -569,14 +605,14 @@ int tn_trace_rays_ex(tn_tracer_t tracer, size_t R, uint32_t M, const float *orig
 int tn_find_matched_cells_indexed(size_t R, size_t S, size_t M, const uint32_t *ray_index, const uint32_t *num_visited,
                                   const uint32_t *visited, const float *dist, const float *bary, const float *distances,
                                   const uint32_t *verts, uint32_t *cells_out, uint32_t *verts_out, uint8_t *mask_out,
-                                  float *bary_out, void *stream_) {
+                                  float *bary_out, const uint32_t *count, void *stream_) {
     return guarded([&] {
         if (R == 0 || S == 0) return;
         if (!ray_index) throw tn::Error("ray_index is null");
         if (S >= 0xFFFFFFFFull || M >= 0xFFFFFFFFull) throw tn::Error("num_samples / max_visited_cells too large");
         if (M * 2 * sizeof(float) > 64 * 1024) throw tn::Error("max_visited_cells larger than 8192 is not supported");
         tn::launch_find_matched_cells(R, S, M, num_visited, visited, dist, bary, distances, verts, cells_out,
-                                      verts_out, mask_out, bary_out, (hipStream_t)stream_, ray_index);
+                                      verts_out, mask_out, bary_out, (hipStream_t)stream_, ray_index, count);
         TN_HIP(hipGetLastError());
     });
 }
@@ -657,6 +693,7 @@ int tn_find_tetrahedra(tn_tracer_t tracer, size_t N, const float *positions, uin
 int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);
+        std::lock_guard<std::mutex> lock(t->mu);
         DeviceGuard g(t->device);
         TN_HIP(hipStreamSynchronize(t->last_stream));
         unsigned long long h[24];
@@ -679,6 +716,7 @@ int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]) {
 int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);
+        std::lock_guard<std::mutex> lock(t->mu);
         DeviceGuard g(t->device);
         TN_HIP(hipStreamSynchronize(t->last_stream));
         unsigned long long h[20];
@@ -687,11 +725,39 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]) {
     });
 }
 
+int tn_trace_timings(tn_tracer_t tracer, float ms[8]) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        std::lock_guard<std::mutex> lock(t->mu);
+        if (!ms) throw tn::Error("ms is null");
+        if (!t->tev_valid) throw tn::Error("no timed call: set option \"timing\" = 1 and trace a one-chunk walk call first");
+        DeviceGuard g(t->device);
+        TN_HIP(hipEventSynchronize(t->tev[tn_tracer::N_TEV - 1]));
+        for (int i = 0; i + 1 < tn_tracer::N_TEV; ++i) TN_HIP(hipEventElapsedTime(&ms[i], t->tev[i], t->tev[i + 1]));
+    });
+}
+
+int tn_fill_rows(size_t R, uint32_t M, uint32_t first_slot, uint32_t *visited, float *bary, float *dist, uint32_t *verts,
+                 void *stream_) {
+    return guarded([&] {
+        if (R == 0) return;
+        if (!visited || !bary || !dist) throw tn::Error("null output pointer");
+        if (M < 4 || (M & (M - 1)) != 0) throw tn::Error("max_ray_triangles must be a power of 2.");
+        if (first_slot >= M) return;
+        // rows are written from a 128-byte line boundary of all four arrays on (multiples of 32 slots), like the tracer's own fill
+        tn::launch_fill_range(R, M, true, nullptr, nullptr, visited, bary, dist, verts, (hipStream_t)stream_, first_slot & ~31u, false,
+                              512);
+        TN_HIP(hipGetLastError());
+    });
+}
+
 int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);
+        std::lock_guard<std::mutex> lock(t->mu);
         const std::string k = name ? name : "";
         if (k == "gpu_build") t->gpu_build = value != 0;
+        else if (k == "timing") { t->timing = value != 0; t->tev_valid = false; }
         else if (k == "leaf_width") {
             if (value != 16 && value != 32 && value != 64) throw tn::Error("leaf_width must be 16, 32 or 64");
             t->leaf_width = (unsigned)value;
@@ -874,14 +940,14 @@ int tn_mlp_forward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const float
         DeviceGuard g(m->device);
         const size_t rays = n / samples_per_ray;
         (mode ? tn::launch_mlp_forward_x3 : tn::launch_mlp_forward)(
-            n, samples_per_ray, rays, feats, nullptr, nullptr, nullptr, dirs, m->packs(rays), sigma, rgb, (hipStream_t)stream_);
+            n, samples_per_ray, rays, feats, nullptr, nullptr, nullptr, dirs, m->packs(rays), sigma, rgb, (hipStream_t)stream_, nullptr);
         TN_HIP(hipGetLastError());
     });
 }
 
 int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const uint32_t *vertex_indices,
                           const float *barycentric, const float *field_vm, const float *dirs, int mode, float *sigma,
-                          float *rgb, const float *ray_head_bias, void *stream_) {
+                          float *rgb, const float *ray_head_bias, const uint32_t *count, void *stream_) {
     return guarded([&] {
         tn_mlp *m = checked_mlp(mlp);
         check_mode(mode);
@@ -894,7 +960,7 @@ int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, cons
         pk.ray_bias = rgb ? ray_head_bias : nullptr;
         (mode ? tn::launch_mlp_forward_x3 : tn::launch_mlp_forward)(
             n, samples_per_ray, rays, nullptr, vertex_indices, barycentric, field_vm, dirs, pk, sigma, rgb,
-            (hipStream_t)stream_);
+            (hipStream_t)stream_, count);
         TN_HIP(hipGetLastError());
     });
 }
@@ -995,28 +1061,39 @@ int tn_mlp_param_grads(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const f
     });
 }
 
+int tn_compact_hits(size_t num_rays, const uint32_t *num_visited, uint32_t *order, uint32_t *count, uint32_t *padded,
+                    uint32_t *scratch, size_t scratch_len, void *stream_) {
+    return guarded([&] {
+        if (!num_visited || !order || !count || !scratch) throw tn::Error("null pointer");
+        if (num_rays >= 0xFFFFFFFFull) throw tn::Error("too many rays for one call");
+        if (scratch_len < tn::compact_scratch_u32(num_rays)) throw tn::Error("compact_hits: scratch too small (2 * ceil(num_rays / 2048) uint32)");
+        tn::launch_compact_hits(num_rays, num_visited, order, count, padded, scratch, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
 int tn_sample_coarse(size_t num_hit_rays, uint32_t num_samples, uint32_t M, const uint32_t *ray_index, const uint32_t *num_visited,
                      const float *hit_distances, const float *linspace, const float *t_rand, int biased, float *edges,
-                     float *near_far, void *stream_) {
+                     float *near_far, const uint32_t *count, void *stream_) {
     return guarded([&] {
         if (num_hit_rays == 0) return;
         if (!ray_index || !num_visited || !hit_distances || !linspace || !edges || !near_far) throw tn::Error("null pointer");
         if (num_samples == 0) throw tn::Error("num_samples must be positive");
         tn::launch_sample_coarse(num_hit_rays, num_samples, M, ray_index, num_visited, hit_distances, linspace, t_rand, biased != 0,
-                                 edges, near_far, (hipStream_t)stream_);
+                                 edges, near_far, (hipStream_t)stream_, count);
         TN_HIP(hipGetLastError());
     });
 }
 
 int tn_sample_pdf(size_t num_hit_rays, uint32_t num_samples, uint32_t num_fine, const float *edges, const float *weights,
                   const float *near_far, const float *u_table, const float *u_rand, float histogram_padding, float eps,
-                  float *edges_out, void *stream_) {
+                  float *edges_out, const uint32_t *count, void *stream_) {
     return guarded([&] {
         if (num_hit_rays == 0) return;
         if (!edges || !weights || !near_far || !u_table || !edges_out) throw tn::Error("null pointer");
         if (num_samples == 0) throw tn::Error("num_samples must be positive");
         tn::launch_sample_pdf(num_hit_rays, num_samples, num_fine, edges, weights, near_far, u_table, u_rand, histogram_padding, eps,
-                              edges_out, (hipStream_t)stream_);
+                              edges_out, (hipStream_t)stream_, count);
         TN_HIP(hipGetLastError());
     });
 }
@@ -1033,10 +1110,10 @@ int tn_composite_backward(size_t num_rays, uint32_t num_samples, const float *si
 
 int tn_composite(size_t num_rays, uint32_t num_samples, const float *sigma, const float *rgb, const float *edges,
                  const tn_rgb_background *background, float *out_rgb, float *out_acc, float *out_depth, float *out_weights,
-                 void *stream_) {
+                 const uint32_t *ray_index, const uint32_t *count, void *stream_) {
     return guarded([&] {
         tn::launch_composite(num_rays, num_samples, sigma, rgb, edges, background_of(background), out_rgb, out_acc, out_depth,
-                             out_weights, (hipStream_t)stream_);
+                             out_weights, (hipStream_t)stream_, ray_index, count);
         TN_HIP(hipGetLastError());
     });
 }

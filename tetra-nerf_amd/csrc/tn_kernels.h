@@ -99,7 +99,7 @@ void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num
                                const uint32_t *visited, const float *dist, const float *bary,
                                const float *distances, const uint32_t *verts, uint32_t *cells_out,
                                uint32_t *verts_out, uint8_t *mask_out, float *bary_out, hipStream_t stream,
-                               const uint32_t *ray_index = nullptr);
+                               const uint32_t *ray_index = nullptr, const uint32_t *count = nullptr);
 
 // barycentric gather and its adjoint (tn_interp.hip); throws on unsupported D
 void launch_interpolate_values(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi,
@@ -146,13 +146,14 @@ void launch_mlp_pack_t(const MlpWeights &w, float *pt, hipStream_t stream);
 void launch_mlp_pack_x3(const MlpWeights &w, uint4 *blob, hipStream_t stream);
 // feats != null: input is the [64, n] feature buffer; feats == null: the kernel gathers the features itself from
 // (vi [n,4], bc [n,3], fieldT [V, 64] VERTEX-major)
+// count (nullable): device-side number of RAYS (n, num_rays are then upper bounds the grid is sized for)
 void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
                         const float *bc, const float *fieldT, const float *dirs, const MlpPacks &w, float *sigma, float *rgb,
-                        hipStream_t stream);
+                        hipStream_t stream, const uint32_t *count = nullptr);
 // the same on the bf16 matrix cores with 3-way operand splitting (tn_mlp_x3.hip)
 void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
                            const float *bc, const float *fieldT, const float *dirs, const MlpPacks &w, float *sigma, float *rgb,
-                           hipStream_t stream);
+                           hipStream_t stream, const uint32_t *count = nullptr);
 // Training (tn_mlp.hip: TRAIN variant of the forward kernel, tn_mlp_bwd.hip, tn_mlp_grad.hip).  The training forward SAVES
 // the layer inputs and the ReLU masks; the backward kernel runs the reverse network from the masks alone (no recompute);
 // the parameter-gradient GEMMs contract the saved inputs with the gradients it leaves.  Device memory owned by the caller;
@@ -201,12 +202,22 @@ void launch_render_pass(const uint32_t *num_visited, const float *dist, const fl
                         const float *dirs, const MlpPacks &w, Background background, float *out_weights, float *out_rgb,
                         float *out_acc, float *out_depth, hipStream_t stream);
 // ray samplers (tn_samplers.hip): one wavefront per hitting ray, trace rows read in place through ray_index
+// count (nullable, every launcher below): the number of hitting rays lives on the device; r / R is the upper bound the grid is sized for
 void launch_sample_coarse(size_t r, uint32_t S, uint32_t M, const uint32_t *ray_index, const uint32_t *num_visited, const float *hit_dist,
-                          const float *lin, const float *t_rand, bool biased, float *edges, float *near_far, hipStream_t stream);
+                          const float *lin, const float *t_rand, bool biased, float *edges, float *near_far, hipStream_t stream,
+                          const uint32_t *count = nullptr);
 void launch_sample_pdf(size_t r, uint32_t S, uint32_t num_fine, const float *edges, const float *weights, const float *near_far,
-                       const float *u_table, const float *u_rand, float histogram_padding, float eps, float *out, hipStream_t stream);
+                       const float *u_table, const float *u_rand, float histogram_padding, float eps, float *out, hipStream_t stream,
+                       const uint32_t *count = nullptr);
+// ray_index (nullable): out_rgb / out_acc / out_depth are arrays over ALL rays of the call and row q is written at ray_index[q]
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, Background background,
-                      float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream);
+                      float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream,
+                      const uint32_t *ray_index = nullptr, const uint32_t *count = nullptr);
+// stable partition of the rays by num_visited > 0 (tn_samplers.hip): order [R], *count, padded [R] (nullable: order with the
+// entries beyond count replaced by order[0]); scratch: compact_scratch_u32(R) uint32
+size_t compact_scratch_u32(size_t R);
+void launch_compact_hits(size_t R, const uint32_t *num_visited, uint32_t *order, uint32_t *count, uint32_t *padded, uint32_t *scratch,
+                         hipStream_t stream);
 
 // uint32-indexed gather / EMA scatter (tn_uint32.hip); elem_size 4 = f32, 8 = f64
 void launch_gather_uint32(int elem_size, uint32_t num_values, uint32_t num_indices, const uint32_t *indices,

@@ -25,8 +25,9 @@ __global__ __launch_bounds__(64) void k_find_matched(size_t R, uint32_t S, uint3
                                                      uint32_t *__restrict__ verts_out,
                                                      uint8_t *__restrict__ mask_out,
                                                      float *__restrict__ bary_out,
-                                                     const uint32_t *__restrict__ ray_index) {
+                                                     const uint32_t *__restrict__ ray_index, const uint32_t *__restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (count) R = *count;      // device-side number of (hitting) rays; the grid was sized for an upper bound
     float *tin = reinterpret_cast<float *>(smem);  // [M]
     float *pmax = tin + M;                         // [M] running max of t_out
     const int lane = threadIdx.x;
@@ -158,13 +159,13 @@ void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num
                                const uint32_t *visited, const float *dist, const float *bary,
                                const float *distances, const uint32_t *verts, uint32_t *cells_out,
                                uint32_t *verts_out, uint8_t *mask_out, float *bary_out, hipStream_t stream,
-                               const uint32_t *ray_index) {
+                               const uint32_t *ray_index, const uint32_t *count) {
     if (R == 0 || S == 0) return;
     const size_t smem = 2 * M * sizeof(float);
     const size_t max_blocks = 256 * 32;
     const unsigned grid = (unsigned)(R < max_blocks ? R : max_blocks);
     hipLaunchKernelGGL(k_find_matched, dim3(grid), dim3(64), smem, stream, R, (uint32_t)S, (uint32_t)M,
-                       num_visited, visited, dist, bary, distances, verts, cells_out, verts_out, mask_out, bary_out, ray_index);
+                       num_visited, visited, dist, bary, distances, verts, cells_out, verts_out, mask_out, bary_out, ray_index, count);
 }
 
 }  // namespace tn

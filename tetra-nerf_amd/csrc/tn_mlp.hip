@@ -21,7 +21,8 @@
 // layers: no LDS round trip, no cross-lane shuffles, no HBM traffic besides the [64,n] input and the
 // 16 B/sample output.  Weights are staged per layer in LDS (<= 80 KB) and shared by the 4 waves of a
 // block; every MFMA reads its A operand as one conflict-free 256-B ds_read_b32.
-#include "tn_mlp_common.h"
+#include "tn_mlp_fwd.h"
+#include "tn_ray_ops.h"
 
 namespace tn {
 
@@ -95,144 +96,24 @@ __global__ void k_dir_encoding(size_t R, const float *__restrict__ dirs, float *
 
 // 8 waves (BLOCK = 512) share each staged layer, one block per CU, two waves per SIMD: while one waits for a weight copy, at
 // a barrier or in an epilogue the other one's MFMAs run.  (Round 2's 4-wave / two-blocks-per-CU variant with the head layer
-// staged in two halves measured neutral, profiles/r02o_mlp_block.txt, and is gone.)
-// TRAIN: the layer inputs x0, h1..h4 (quad-major [F/4][n][4], what the weight-gradient GEMMs contract) and the ReLU masks (all the
-// dX kernel needs) are saved on the way -- the backward pass recomputes nothing (round 3a recomputed the whole forward
-// inside the dX kernel: 2.2 of its 5 ms).
-struct FwdSave { float *x0, *h1, *h2, *h3, *h4; unsigned long long *masks; };
+// staged in two halves measured neutral, profiles/r02o_mlp_block.txt, and is gone.)  The loop body lives in tn_mlp_fwd.h
+// (mlp_forward_group): the persistent render kernel (tn_render_rays.hip) runs the same code on its tiles.
 template <bool GATHER, bool DENSITY_ONLY, int BLOCK = MLP_BLOCK, bool TRAIN = false>
 __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t samples_per_ray, const float *__restrict__ feats,
                                                            const uint32_t *__restrict__ vi, const float *__restrict__ bc,
                                                            const float *__restrict__ fieldT,
                                                            const float *__restrict__ enc, const float *__restrict__ pk,
                                                            float *__restrict__ sigma, float *__restrict__ rgb, FwdSave sv,
-                                                           const float *__restrict__ ray_bias) {
+                                                           const float *__restrict__ ray_bias, const uint32_t *__restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    // count (nullable): the number of RAYS lives on the device (sync-free callers launch over an upper bound)
+    if (count) n = (size_t)*count * samples_per_ray;
     constexpr size_t GROUP = (BLOCK / 64) * 32;
     const size_t ngroups = (n + GROUP - 1) / GROUP;
-
-    for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const size_t s = g * GROUP + (size_t)wave * 32 + (lane & 31);
-        const size_t sc = s < n ? s : n - 1;  // clamped: out-of-range lanes compute a duplicate, store nothing
-        float bin[KSH];
-
-        // ---- layer 1: 64 -> 128, B operands straight from the feature-major input [64, n]
-        __syncthreads();
-        stage_weights<BLOCK>(lds, pk + OFF_W1, lfloats(KS1, OT));
-        if constexpr (!GATHER) {
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) bin[ks] = feats[(size_t)(2 * ks + h) * n + sc];
-        } else {
-            // fused barycentric gather (interpolate_values<4>, same summation order => same bits as the
-            // stand-alone op): this lane produces features 32h .. 32h+31 of its sample straight into the
-            // B-operand registers; the [64, n] feature buffer never exists.
-            const uint4 v4 = *reinterpret_cast<const uint4 *>(vi + 4 * sc);
-            const float b0 = bc[3 * sc], b1 = bc[3 * sc + 1], b2 = bc[3 * sc + 2];
-            const float w0 = 1.0f - ((b0 + b1) + b2);
-            const uint32_t vv[4] = {v4.y, v4.z, v4.w, v4.x};
-            const float ww[4] = {b0, b1, b2, w0};
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) bin[ks] = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (vv[k] != TN_EMPTY) {
-                    const float4 *row = reinterpret_cast<const float4 *>(fieldT + (size_t)vv[k] * FD + 32 * h);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float4 x = row[q];
-                        bin[4 * q] += ww[k] * x.x; bin[4 * q + 1] += ww[k] * x.y;
-                        bin[4 * q + 2] += ww[k] * x.z; bin[4 * q + 3] += ww[k] * x.w;
-                    }
-                }
-            }
-        }
-        stage_wait();
-        {
-            f32x16 acc[OT];
-            zero_acc(acc);
-            // TRAIN: every GEMM's input leaves for HBM under the GEMM's own MFMAs (lanes beyond the end store their
-            // duplicate of sample n - 1 where its owner stores it)
-            if constexpr (TRAIN) gemm_steps_store<KS1, 0, OT, KS1>(acc, bin, lds, lane, quad_ptr_x0(sv.x0, n, sc, h), n);
-            else gemm_steps<KS1, 0, OT>(acc, bin, lds, lane);
-            bias_step<KS1, OT>(acc, lds, lane);
-            relu_to_bin(acc, bin);
-        }
-        auto save_mask = [&](int layer) {
-            if constexpr (TRAIN) sv.masks[((size_t)layer * n + sc) * 2 + h] = mask_of(bin);
-        };
-        save_mask(0);
-        // ---- layers 2, 3: 128 -> 128, accumulators fed back as B operands
-        __syncthreads();
-        stage_weights<BLOCK>(lds, pk + OFF_W2, lfloats(KSH, OT));
-        stage_wait();
-        {
-            f32x16 acc[OT];
-            zero_acc(acc);
-            if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h1, n, sc, h), 2 * n);
-            else gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
-            bias_step<KSH, OT>(acc, lds, lane);
-            relu_to_bin(acc, bin);
-        }
-        save_mask(1);
-        __syncthreads();
-        stage_weights<BLOCK>(lds, pk + OFF_W3, N_W3);
-        stage_wait();
-        {
-            f32x16 acc[OT];
-            zero_acc(acc);
-            if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h2, n, sc, h), 2 * n);
-            else gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
-            bias_step<KSH, OT>(acc, lds, lane);
-            relu_to_bin(acc, bin);  // mlp_base out_activation = ReLU
-        }
-        save_mask(2);
-        {
-            // density head 128 -> 1 + softplus on the VALU (the vector rides behind layer 3's weights)
-            const float *dv = lds + lfloats(KSH, OT);
-            const float raw = head_dot(dv + 64 * h, bin) + dv[128];
-            const float sp = raw > 20.0f ? raw : log1pf(expf(raw));  // torch softplus(beta=1, threshold=20)
-            if (h == 0 && s < n) sigma[s] = sp;
-        }
-        if constexpr (DENSITY_ONLY) continue;  // coarse pass of the model (model.py:577-581)
-        // ---- head [enc(27) | base(128)] -> 128 ReLU
-        __syncthreads();
-        stage_weights<BLOCK>(lds, pk + OFF_WHEAD, N_WHEAD);
-        stage_wait();
-        {
-            f32x16 acc[OT];
-            zero_acc(acc);
-            const float *e = enc + (sc / samples_per_ray) * ENC_PAD;
-#pragma unroll
-            for (int ks = 0; ks < KSE; ++ks) {
-                const float b = e[2 * ks + h];
-                const float *wrow = lds + (size_t)ks * OT * 64 + lane;
-#pragma unroll
-                for (int t = 0; t < OT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], b, acc[t], 0, 0, 0);
-            }
-            if constexpr (TRAIN) gemm_steps_store<KSH, KSE, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h3, n, sc, h), 2 * n);
-            else gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
-            bias_step<HEAD_KS, OT>(acc, lds, lane);
-            if (ray_bias) add_ray_bias(acc, ray_bias + (sc / samples_per_ray) * HID, h);   // wave-uniform test
-            relu_to_bin(acc, bin);
-        }
-        if constexpr (TRAIN) store_bin(sv.h4, n, sc, bin, h);   // the last layer's output has no GEMM to hide under
-        save_mask(3);
-        {
-            // rgb head 128 -> 3 + sigmoid on the VALU
-            const float *cv = lds + lfloats(HEAD_KS, OT);
-            const float c0 = head_dot(cv + 64 * h, bin) + cv[384];
-            const float c1 = head_dot(cv + 128 + 64 * h, bin) + cv[385];
-            const float c2 = head_dot(cv + 256 + 64 * h, bin) + cv[386];
-            if (h == 0 && s < n) {
-                rgb[3 * s] = 1.0f / (1.0f + expf(-c0));
-                rgb[3 * s + 1] = 1.0f / (1.0f + expf(-c1));
-                rgb[3 * s + 2] = 1.0f / (1.0f + expf(-c2));
-            }
-        }
-    }
+    for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x)
+        mlp_forward_group<GATHER, DENSITY_ONLY, BLOCK, TRAIN>(lds, g, n, samples_per_ray, feats, vi, bc, fieldT, enc, pk, sigma, rgb, sv,
+                                                              ray_bias);
 }
 
 // Per-ray composite: one wavefront per ray, lanes stride the samples; exclusive scan of sigma*delta.
@@ -240,67 +121,15 @@ __global__ __launch_bounds__(64) void k_composite(size_t R, uint32_t S, const fl
                                                   const float *__restrict__ rgb, const float *__restrict__ edges,
                                                   Background background, float *__restrict__ out_rgb,
                                                   float *__restrict__ out_acc, float *__restrict__ out_depth,
-                                                  float *__restrict__ out_weights) {
+                                                  float *__restrict__ out_weights, const uint32_t *__restrict__ ray_index,
+                                                  const uint32_t *__restrict__ count) {
     const int lane = threadIdx.x;
+    if (count) R = *count;
     for (size_t ray = blockIdx.x; ray < R; ray += gridDim.x) {
-        const float *e = edges + ray * (S + 1);
-        float carry = 0.f;       // sum of sigma*delta of all previous samples
-        float cw = 0.f;          // running sum of weights (for the median depth)
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f, accw = 0.f;
-        float depth = 0.f;
-        bool found = false;
-        for (uint32_t base = 0; base < S; base += 64) {
-            const uint32_t j = base + lane;
-            const bool ok = j < S;
-            const size_t q = ray * S + (ok ? j : S - 1);
-            const float st = e[ok ? j : S - 1], en = e[(ok ? j : S - 1) + 1];
-            const float dd = ok ? (en - st) * sigma[q] : 0.f;
-            // inclusive scan of dd over the wave
-            float inc = dd;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float o = __shfl_up(inc, off);
-                if (lane >= off) inc += o;
-            }
-            const float excl = carry + (inc - dd);
-            float w = (1.0f - expf(-dd)) * expf(-excl);
-            if (!(w == w) || !ok) w = 0.f;  // nan_to_num
-            if (out_weights && ok) out_weights[q] = w;
-            if (rgb) {
-                float c0 = rgb[3 * q], c1 = rgb[3 * q + 1], c2 = rgb[3 * q + 2];
-                if (background.clamp) { c0 = nan_to_num(c0); c1 = nan_to_num(c1); c2 = nan_to_num(c2); }
-                r0 += w * c0; r1 += w * c1; r2 += w * c2;
-            }
-            accw += w;
-            // median depth: first sample whose cumulative weight reaches 0.5
-            float winc = w;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float o = __shfl_up(winc, off);
-                if (lane >= off) winc += o;
-            }
-            const float cum = cw + winc;
-            const uint64_t m = __ballot(ok && cum >= 0.5f);
-            if (!found && m) {
-                const int src = __ffsll((unsigned long long)m) - 1;
-                depth = __shfl(0.5f * (st + en), src);
-                found = true;
-            }
-            carry += __shfl(inc, 63);
-            cw += __shfl(winc, 63);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            r0 += __shfl_xor(r0, off); r1 += __shfl_xor(r1, off); r2 += __shfl_xor(r2, off); accw += __shfl_xor(accw, off);
-        }
-        if (!found) depth = 0.5f * (e[S - 1] + e[S]);  // searchsorted clamps to the last sample
-        if (lane == 0 && out_rgb) {
-            float o0 = r0 + background.r * (1.0f - accw), o1 = r1 + background.g * (1.0f - accw), o2 = r2 + background.b * (1.0f - accw);
-            if (background.clamp) { o0 = fminf(fmaxf(o0, 0.f), 1.f); o1 = fminf(fmaxf(o1, 0.f), 1.f); o2 = fminf(fmaxf(o2, 0.f), 1.f); }
-            out_rgb[3 * ray] = o0; out_rgb[3 * ray + 1] = o1; out_rgb[3 * ray + 2] = o2;
-            out_acc[ray] = accw;
-            out_depth[ray] = depth;
-        }
+        const size_t dst = ray_index ? (size_t)ray_index[ray] : ray;   // (scatter into the frame buffers of all rays)
+        rayops::ray_composite(S, sigma + ray * S, rgb ? rgb + 3 * ray * S : nullptr, edges + ray * (S + 1), background,
+                              out_rgb ? out_rgb + 3 * dst : nullptr, out_acc ? out_acc + dst : nullptr,
+                              out_depth ? out_depth + dst : nullptr, out_weights ? out_weights + ray * S : nullptr, lane);
     }
 }
 
@@ -320,7 +149,7 @@ size_t mlp_enc_floats_per_ray() { return 32; }
 
 void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
                         const float *bc, const float *fieldT, const float *dirs, const MlpPacks &w, float *sigma, float *rgb,
-                        hipStream_t stream) {
+                        hipStream_t stream, const uint32_t *count) {
     if (n == 0) return;
     const bool gather = feats == nullptr;
     const bool density_only = rgb == nullptr;  // coarse pass: no colour head, no direction encoding
@@ -343,7 +172,7 @@ void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, con
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
 #define TN_MLP_LAUNCH(G, D)                                                                                         \
     hipLaunchKernelGGL((k_mlp_forward<G, D>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc, \
-                       fieldT, enc, pk, sigma, rgb, FwdSave{}, w.ray_bias)
+                       fieldT, enc, pk, sigma, rgb, FwdSave{}, w.ray_bias, count)
     if (gather && density_only) TN_MLP_LAUNCH(true, true);
     else if (gather) TN_MLP_LAUNCH(true, false);
     else if (density_only) TN_MLP_LAUNCH(false, true);
@@ -364,15 +193,16 @@ void launch_mlp_forward_train(size_t n, uint32_t samples_per_ray, size_t num_ray
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
     hipLaunchKernelGGL((k_mlp_forward<true, false, MLP_BLOCK, true>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray,
                        (const float *)nullptr, vi, bc, fieldT, w.enc, w.pk_gather, sigma, rgb,
-                       FwdSave{save.x0, save.h1, save.h2, save.h3, save.h4, save.masks}, w.ray_bias);
+                       FwdSave{save.x0, save.h1, save.h2, save.h3, save.h4, save.masks}, w.ray_bias, (const uint32_t *)nullptr);
 }
 
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, Background background,
-                      float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream) {
+                      float *out_rgb, float *out_acc, float *out_depth, float *out_weights, hipStream_t stream,
+                      const uint32_t *ray_index, const uint32_t *count) {
     if (R == 0 || S == 0) return;
     const unsigned grid = (unsigned)(R < 256u * 32u ? R : 256u * 32u);
     hipLaunchKernelGGL(k_composite, dim3(grid), dim3(64), 0, stream, R, S, sigma, rgb, edges, background, out_rgb, out_acc,
-                       out_depth, out_weights);
+                       out_depth, out_weights, ray_index, count);
 }
 
 }  // namespace tn

@@ -1,0 +1,148 @@
+// tn_mlp_fwd.h -- one 256-sample group of the fused forward MLP (gather + mlp_base + density head [+ mlp_head + rgb head]) as a
+// device function: the loop body of k_mlp_forward (tn_mlp.hip), shared with the persistent render kernel (tn_render_rays.hip),
+// which runs the SAME instruction stream on its tiles -- results are bit-identical by construction.  See tn_mlp.hip's header
+// for the dataflow.
+#pragma once
+#include "tn_mlp_common.h"
+
+namespace tn {
+namespace mlp {
+
+// TRAIN: the layer inputs x0, h1..h4 (quad-major [F/4][n][4], what the weight-gradient GEMMs contract) and the ReLU masks (all the
+// dX kernel needs) are saved on the way -- the backward pass recomputes nothing (round 3a recomputed the whole forward
+// inside the dX kernel: 2.2 of its 5 ms).
+struct FwdSave { float *x0, *h1, *h2, *h3, *h4; unsigned long long *masks; };
+
+// group g = samples [g * GROUP, (g + 1) * GROUP) of n; every thread of the block calls it (it contains the block barriers of
+// the weight stages).  lds: MAX_STAGE_FLOATS floats.
+template <bool GATHER, bool DENSITY_ONLY, int BLOCK, bool TRAIN>
+static __device__ __forceinline__ void mlp_forward_group(float *lds, size_t g, size_t n, uint32_t samples_per_ray,
+                                                         const float *__restrict__ feats, const uint32_t *__restrict__ vi,
+                                                         const float *__restrict__ bc, const float *__restrict__ fieldT,
+                                                         const float *__restrict__ enc, const float *__restrict__ pk,
+                                                         float *__restrict__ sigma, float *__restrict__ rgb, const FwdSave &sv,
+                                                         const float *__restrict__ ray_bias) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    constexpr size_t GROUP = (BLOCK / 64) * 32;
+    const size_t s = g * GROUP + (size_t)wave * 32 + (lane & 31);
+    const size_t sc = s < n ? s : n - 1;  // clamped: out-of-range lanes compute a duplicate, store nothing
+    float bin[KSH];
+
+    // ---- layer 1: 64 -> 128, B operands straight from the feature-major input [64, n]
+    __syncthreads();
+    stage_weights<BLOCK>(lds, pk + OFF_W1, lfloats(KS1, OT));
+    if constexpr (!GATHER) {
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) bin[ks] = feats[(size_t)(2 * ks + h) * n + sc];
+    } else {
+        // fused barycentric gather (interpolate_values<4>, same summation order => same bits as the
+        // stand-alone op): this lane produces features 32h .. 32h+31 of its sample straight into the
+        // B-operand registers; the [64, n] feature buffer never exists.
+        const uint4 v4 = *reinterpret_cast<const uint4 *>(vi + 4 * sc);
+        const float b0 = bc[3 * sc], b1 = bc[3 * sc + 1], b2 = bc[3 * sc + 2];
+        const float w0 = 1.0f - ((b0 + b1) + b2);
+        const uint32_t vv[4] = {v4.y, v4.z, v4.w, v4.x};
+        const float ww[4] = {b0, b1, b2, w0};
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) bin[ks] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (vv[k] != TN_EMPTY) {
+                const float4 *row = reinterpret_cast<const float4 *>(fieldT + (size_t)vv[k] * FD + 32 * h);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 x = row[q];
+                    bin[4 * q] += ww[k] * x.x; bin[4 * q + 1] += ww[k] * x.y;
+                    bin[4 * q + 2] += ww[k] * x.z; bin[4 * q + 3] += ww[k] * x.w;
+                }
+            }
+        }
+    }
+    stage_wait();
+    {
+        f32x16 acc[OT];
+        zero_acc(acc);
+        // TRAIN: every GEMM's input leaves for HBM under the GEMM's own MFMAs (lanes beyond the end store their
+        // duplicate of sample n - 1 where its owner stores it)
+        if constexpr (TRAIN) gemm_steps_store<KS1, 0, OT, KS1>(acc, bin, lds, lane, quad_ptr_x0(sv.x0, n, sc, h), n);
+        else gemm_steps<KS1, 0, OT>(acc, bin, lds, lane);
+        bias_step<KS1, OT>(acc, lds, lane);
+        relu_to_bin(acc, bin);
+    }
+    auto save_mask = [&](int layer) {
+        if constexpr (TRAIN) sv.masks[((size_t)layer * n + sc) * 2 + h] = mask_of(bin);
+    };
+    save_mask(0);
+    // ---- layers 2, 3: 128 -> 128, accumulators fed back as B operands
+    __syncthreads();
+    stage_weights<BLOCK>(lds, pk + OFF_W2, lfloats(KSH, OT));
+    stage_wait();
+    {
+        f32x16 acc[OT];
+        zero_acc(acc);
+        if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h1, n, sc, h), 2 * n);
+        else gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
+        bias_step<KSH, OT>(acc, lds, lane);
+        relu_to_bin(acc, bin);
+    }
+    save_mask(1);
+    __syncthreads();
+    stage_weights<BLOCK>(lds, pk + OFF_W3, N_W3);
+    stage_wait();
+    {
+        f32x16 acc[OT];
+        zero_acc(acc);
+        if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h2, n, sc, h), 2 * n);
+        else gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
+        bias_step<KSH, OT>(acc, lds, lane);
+        relu_to_bin(acc, bin);  // mlp_base out_activation = ReLU
+    }
+    save_mask(2);
+    {
+        // density head 128 -> 1 + softplus on the VALU (the vector rides behind layer 3's weights)
+        const float *dv = lds + lfloats(KSH, OT);
+        const float raw = head_dot(dv + 64 * h, bin) + dv[128];
+        const float sp = raw > 20.0f ? raw : log1pf(expf(raw));  // torch softplus(beta=1, threshold=20)
+        if (h == 0 && s < n) sigma[s] = sp;
+    }
+    if constexpr (DENSITY_ONLY) return;  // coarse pass of the model (model.py:577-581)
+    // ---- head [enc(27) | base(128)] -> 128 ReLU
+    __syncthreads();
+    stage_weights<BLOCK>(lds, pk + OFF_WHEAD, N_WHEAD);
+    stage_wait();
+    {
+        f32x16 acc[OT];
+        zero_acc(acc);
+        const float *e = enc + (sc / samples_per_ray) * ENC_PAD;
+#pragma unroll
+        for (int ks = 0; ks < KSE; ++ks) {
+            const float b = e[2 * ks + h];
+            const float *wrow = lds + (size_t)ks * OT * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < OT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], b, acc[t], 0, 0, 0);
+        }
+        if constexpr (TRAIN) gemm_steps_store<KSH, KSE, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h3, n, sc, h), 2 * n);
+        else gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
+        bias_step<HEAD_KS, OT>(acc, lds, lane);
+        if (ray_bias) add_ray_bias(acc, ray_bias + (sc / samples_per_ray) * HID, h);   // wave-uniform test
+        relu_to_bin(acc, bin);
+    }
+    if constexpr (TRAIN) store_bin(sv.h4, n, sc, bin, h);   // the last layer's output has no GEMM to hide under
+    save_mask(3);
+    {
+        // rgb head 128 -> 3 + sigmoid on the VALU
+        const float *cv = lds + lfloats(HEAD_KS, OT);
+        const float c0 = head_dot(cv + 64 * h, bin) + cv[384];
+        const float c1 = head_dot(cv + 128 + 64 * h, bin) + cv[385];
+        const float c2 = head_dot(cv + 256 + 64 * h, bin) + cv[386];
+        if (h == 0 && s < n) {
+            rgb[3 * s] = 1.0f / (1.0f + expf(-c0));
+            rgb[3 * s + 1] = 1.0f / (1.0f + expf(-c1));
+            rgb[3 * s + 2] = 1.0f / (1.0f + expf(-c2));
+        }
+    }
+}
+
+}  // namespace mlp
+}  // namespace tn

@@ -274,10 +274,12 @@ __global__ __launch_bounds__(X3_BLOCK) void k_mlp_forward_x3(size_t n, uint32_t 
                                                              const uint32_t *__restrict__ vi, const float *__restrict__ bc,
                                                              const float *__restrict__ fieldT, const float *__restrict__ enc,
                                                              const uint4 *__restrict__ blob, float *__restrict__ sigma,
-                                                             float *__restrict__ rgb, const float *__restrict__ ray_bias) {
+                                                             float *__restrict__ rgb, const float *__restrict__ ray_bias,
+                                                             const uint32_t *__restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *lds = reinterpret_cast<uint4 *>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    if (count) n = (size_t)*count * samples_per_ray;   // device-side ray count (sync-free callers: n = the upper bound)
     constexpr size_t GROUP = (X3_BLOCK / 64) * 32;
     const size_t ngroups = (n + GROUP - 1) / GROUP;
 
@@ -392,7 +394,7 @@ void launch_mlp_pack_x3(const MlpWeights &w, uint4 *blob, hipStream_t stream) {
 
 void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
                            const float *bc, const float *fieldT, const float *dirs, const MlpPacks &w, float *sigma, float *rgb,
-                           hipStream_t stream) {
+                           hipStream_t stream, const uint32_t *count) {
     if (n == 0) return;
     const bool gather = feats == nullptr;
     const bool density_only = rgb == nullptr;
@@ -414,7 +416,7 @@ void launch_mlp_forward_x3(size_t n, uint32_t samples_per_ray, size_t num_rays, 
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
 #define TN_X3_LAUNCH(G, D)                                                                                            \
     hipLaunchKernelGGL((k_mlp_forward_x3<G, D>), dim3(grid), dim3(X3_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc, \
-                       fieldT, enc, blob, sigma, rgb, w.ray_bias)
+                       fieldT, enc, blob, sigma, rgb, w.ray_bias, count)
     if (gather && density_only) TN_X3_LAUNCH(true, true);
     else if (gather) TN_X3_LAUNCH(true, false);
     else if (density_only) TN_X3_LAUNCH(false, true);

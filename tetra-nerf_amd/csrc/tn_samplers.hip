@@ -14,48 +14,13 @@
 //   k_sample_pdf     inverse-CDF samples of the padded coarse weights at num_fine + 1 quantiles, merged with the coarse
 //                    edges (two sorted lists: merge by rank instead of a sort) and mapped to euclidean distances
 // so that a render is trace -> [sampler -> pass] x 2 with no PyTorch operator in between.
-#include "tn_device.h"
-#include "tn_kernels.h"
+#include "tn_ray_ops.h"
 
 namespace tn {
 
-namespace {
+using namespace rayops;
 
-__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_up(v, off);
-        if (lane >= off) v += o;
-    }
-    return v;
-}
-// running maximum over an LDS array of n floats (wave-cooperative): makes a list that is sorted up to rounding
-// (an inversion of an ulp between neighbours) non-decreasing, so that the merge by rank below is a permutation
-__device__ __forceinline__ void lds_running_max(float *a, uint32_t n, int lane) {
-    float carry = -INFINITY;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t k = base + lane;
-        float v = k < n ? a[k] : -INFINITY;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float o = __shfl_up(v, off);
-            if (lane >= off) v = fmaxf(v, o);
-        }
-        v = fmaxf(v, carry);
-        if (k < n) a[k] = v;
-        carry = __shfl(v, 63);
-    }
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-__device__ __forceinline__ void lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+namespace {
 
 constexpr int SB = 256;   // 4 rays per block
 
@@ -66,56 +31,15 @@ constexpr int SB = 256;   // 4 rays per block
 __global__ __launch_bounds__(SB) void k_sample_coarse(size_t r, uint32_t S, uint32_t M, const uint32_t *__restrict__ ray_index,
                                                       const uint32_t *__restrict__ num_visited, const float *__restrict__ hit_dist,
                                                       const float *__restrict__ lin, const float *__restrict__ t_rand, int biased,
-                                                      float *__restrict__ edges, float *__restrict__ near_far) {
+                                                      float *__restrict__ edges, float *__restrict__ near_far,
+                                                      const uint32_t *__restrict__ count) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (count) r = *count;      // device-side number of hitting rays (the grid was sized for an upper bound)
     float *cum = smem + (size_t)wave * (M + 1);          // biased: cum[i] = start + sum of the first i segment lengths
-    for (size_t q = (size_t)blockIdx.x * (SB / 64) + wave; q < r; q += (size_t)gridDim.x * (SB / 64)) {
-        const size_t ray = ray_index[q];
-        const uint32_t nb = num_visited[ray];
-        const float2 *row = reinterpret_cast<const float2 *>(hit_dist + ray * (size_t)M * 2);
-        // (a ray that misses the mesh has no row -- with compact rows not even a written one: the sync-free training path
-        // names such rays only when a whole batch misses; their samples are discarded, they just have to be finite)
-        const float near = nb ? row[0].x : 0.0f;
-        const float far = nb ? row[nb - 1].y : 1.0f;
-        if (lane == 0) { near_far[2 * q] = near; near_far[2 * q + 1] = far; }
-        if (biased) {
-            // lengths (clamped at 0: the cell -1 closing segments) and their running sum from the first entry point
-            float carry = near;   // bounds_start = hit_distances[..., 0, 0]
-            if (lane == 0) cum[0] = carry;
-            for (uint32_t base = 0; base < nb; base += 64) {
-                const uint32_t k = base + lane;
-                float len = 0.f;
-                if (k < nb) { const float2 s = row[k]; len = fmaxf(s.y - s.x, 0.f); }
-                const float inc = wave_incl_scan(len, lane);
-                if (k < nb) cum[k + 1] = carry + inc;
-                carry += __shfl(inc, 63);
-            }
-            lds_sync();
-        }
-        const float fnb = (float)nb;
-        for (uint32_t j = lane; j <= S; j += 64) {
-            float b = lin[j];
-            if (t_rand) {   // stratified: every edge jittered between the centres of its two neighbouring bins
-                const float lower = j == 0 ? lin[0] : (lin[j] + lin[j - 1]) / 2.0f;
-                const float upper = j == S ? lin[S] : (lin[j + 1] + lin[j]) / 2.0f;
-                b = lower + (upper - lower) * t_rand[q * (size_t)(S + 1) + j];
-            }
-            float e = b * far + (1.0f - b) * near;
-            if (biased && nb) {
-                float rest = (e - near) / (far - near) * fnb;
-                float iv = floorf(rest);
-                iv = fminf(iv, fnb - 1.0f);
-                iv = fmaxf(iv, 0.0f);
-                rest = rest - iv;
-                const uint32_t i = (uint32_t)iv;
-                const float2 s = row[i];
-                e = cum[i] + fmaxf(s.y - s.x, 0.f) * rest;
-            }
-            edges[q * (size_t)(S + 1) + j] = e;
-        }
-        if (biased) lds_sync();
-    }
+    for (size_t q = (size_t)blockIdx.x * (SB / 64) + wave; q < r; q += (size_t)gridDim.x * (SB / 64))
+        ray_sample_coarse(S, M, ray_index[q], num_visited, hit_dist, lin, t_rand ? t_rand + q * (size_t)(S + 1) : nullptr, biased,
+                          edges + q * (size_t)(S + 1), near_far + 2 * q, cum, lane);
 }
 
 // edges [r, S+1] euclidean coarse edges, weights [r, S] coarse weights, near_far [r, 2];
@@ -124,96 +48,146 @@ __global__ __launch_bounds__(SB) void k_sample_coarse(size_t r, uint32_t S, uint
 __global__ __launch_bounds__(SB) void k_sample_pdf(size_t r, uint32_t S, uint32_t nb, const float *__restrict__ edges,
                                                    const float *__restrict__ weights, const float *__restrict__ near_far,
                                                    const float *__restrict__ u_table, const float *__restrict__ u_rand,
-                                                   float histogram_padding, float eps, float *__restrict__ out) {
+                                                   float histogram_padding, float eps, float *__restrict__ out,
+                                                   const uint32_t *__restrict__ count) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t per = (S + 1) + (S + 1) + nb;
-    float *cdf = smem + (size_t)wave * per;      // [S+1]
-    float *sp = cdf + (S + 1);                   // [S+1] spacing edges
-    float *nw = sp + (S + 1);                    // [nb]  new bins
-    for (size_t q = (size_t)blockIdx.x * (SB / 64) + wave; q < r; q += (size_t)gridDim.x * (SB / 64)) {
-        const float near = near_far[2 * q], far = near_far[2 * q + 1];
-        const float *w = weights + q * (size_t)S;
-        const float *e = edges + q * (size_t)(S + 1);
-        for (uint32_t j = lane; j <= S; j += 64) sp[j] = (e[j] - near) / (far - near);
-        // padded weights -> pdf -> cdf
-        float part = 0.f;
-        for (uint32_t j = lane; j < S; j += 64) part += w[j] + histogram_padding;
-        float wsum = wave_sum(part);
-        const float padding = fmaxf(eps - wsum, 0.f);
-        const float add = padding / (float)S;
-        wsum = wsum + padding;
-        float carry = 0.f;
-        if (lane == 0) cdf[0] = 0.f;
-        for (uint32_t base = 0; base < S; base += 64) {
-            const uint32_t j = base + lane;
-            const float pdf = j < S ? ((w[j] + histogram_padding) + add) / wsum : 0.f;
-            const float inc = wave_incl_scan(pdf, lane);
-            if (j < S) cdf[j + 1] = fminf(1.0f, carry + inc);
-            carry += __shfl(inc, 63);
-        }
-        lds_sync();
-        // inverse CDF at the quantiles
-        for (uint32_t k = lane; k < nb; k += 64) {
-            float u = u_table[k];
-            if (u_rand) u = u + u_rand[q * (size_t)nb + k] / (float)nb;
-            // searchsorted(cdf, u, side = "right"): number of entries <= u
-            uint32_t lo = 0, hi = S + 1;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
-            }
-            const uint32_t below = lo == 0 ? 0u : (lo - 1 > S ? S : lo - 1), above = lo > S ? S : lo;
-            const float c0 = cdf[below], c1 = cdf[above], b0 = sp[below], b1 = sp[above];
-            float t = (u - c0) / (c1 - c0);
-            if (!(t == t)) t = 0.f;                                   // nan_to_num(., 0)
-            if (t == INFINITY) t = 3.4028234663852886e38f;            // nan_to_num maps +-inf to the finite extremes
-            if (t == -INFINITY) t = -3.4028234663852886e38f;
-            t = fminf(fmaxf(t, 0.f), 1.f);
-            nw[k] = b0 + t * (b1 - b0);
-        }
-        lds_sync();
-        // both lists are sorted up to rounding (the biased mapping and the inverse CDF are monotone functions evaluated
-        // in fp32): enforce it, then merge by rank (coarse edges first on ties) and map back to euclidean distances
-        lds_running_max(sp, S + 1, lane);
-        lds_running_max(nw, nb, lane);
-        lds_sync();
-        float *o = out + q * (size_t)(S + 1 + nb);
-        for (uint32_t j = lane; j <= S; j += 64) {
-            const float v = sp[j];
-            uint32_t lo = 0, hi = nb;                                 // new bins strictly below v
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (nw[mid] < v) lo = mid + 1; else hi = mid; }
-            o[j + lo] = v * far + (1.0f - v) * near;
-        }
-        for (uint32_t k = lane; k < nb; k += 64) {
-            const float v = nw[k];
-            uint32_t lo = 0, hi = S + 1;                              // coarse edges <= v
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sp[mid] <= v) lo = mid + 1; else hi = mid; }
-            o[k + lo] = v * far + (1.0f - v) * near;
-        }
-        lds_sync();
+    if (count) r = *count;
+    float *lds = smem + (size_t)wave * pdf_lds_floats(S, nb);
+    for (size_t q = (size_t)blockIdx.x * (SB / 64) + wave; q < r; q += (size_t)gridDim.x * (SB / 64))
+        ray_sample_pdf(S, nb, edges + q * (size_t)(S + 1), weights + q * (size_t)S, near_far[2 * q], near_far[2 * q + 1], u_table,
+                       u_rand ? u_rand + q * (size_t)nb : nullptr, histogram_padding, eps, out + q * (size_t)(S + 1 + nb), lds, lane);
+}
+
+// ---- compaction of the hitting rays on the device (replaces torch.nonzero / boolean indexing, model.py:540-567: no host
+// synchronisation).  A stable partition of the rays by num_visited > 0: order[0 .. count) = the rays that hit the mesh, in ray
+// order, order[count .. R) = the others, in ray order; *count stays in device memory -- the samplers, the matcher, the MLP
+// and the composite kernels take its address and are launched over R.  Two small launches: per-block hit counts, then every
+// block sums the counts before it (a few hundred values) and writes its rays.
+namespace {
+constexpr int CP_BLOCK = 256, CP_PER = 8, CP_RAYS = CP_BLOCK * CP_PER;   // 2048 consecutive rays per block, 8 per thread
+
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *sm /*[CP_BLOCK / 64 + 1]*/, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) sm[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < CP_BLOCK / 64; ++w) {
+        const uint32_t x = sm[w];
+        before += w < wave ? x : 0u;
+        tot += x;
+    }
+    total = tot;
+    __syncthreads();
+    return before + inc - v;
+}
+}  // namespace
+
+__global__ __launch_bounds__(CP_BLOCK) void k_count_hits(size_t R, const uint32_t *__restrict__ num_visited, uint32_t *__restrict__ block_hits,
+                                                         uint32_t *__restrict__ block_first) {
+    __shared__ uint32_t sm[CP_BLOCK / 64 + 1];
+    __shared__ uint32_t first;
+    if (threadIdx.x == 0) first = TN_EMPTY;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * CP_RAYS + (size_t)threadIdx.x * CP_PER;
+    uint32_t c = 0, mine = TN_EMPTY;
+#pragma unroll
+    for (int i = 0; i < CP_PER; ++i) {
+        const size_t ray = base + i;
+        const bool hit = ray < R && num_visited[ray] > 0;
+        if (hit && mine == TN_EMPTY) mine = (uint32_t)ray;
+        c += hit ? 1u : 0u;
+    }
+    if (mine != TN_EMPTY) atomicMin(&first, mine);
+    uint32_t total;
+    block_excl_scan(c, sm, total);
+    if (threadIdx.x == 0) { block_hits[blockIdx.x] = total; block_first[blockIdx.x] = first; }
+}
+
+__global__ __launch_bounds__(CP_BLOCK) void k_write_order(size_t R, const uint32_t *__restrict__ num_visited, const uint32_t *__restrict__ block_hits,
+                                                          const uint32_t *__restrict__ block_first, uint32_t *__restrict__ order,
+                                                          uint32_t *__restrict__ count, uint32_t *__restrict__ padded) {
+    __shared__ uint32_t sm[CP_BLOCK / 64 + 1];
+    __shared__ uint32_t s_first;
+    if (threadIdx.x == 0) s_first = TN_EMPTY;
+    __syncthreads();
+    // hits in the blocks before this one, hits in all blocks, the first hitting ray of the call
+    uint32_t before = 0, all = 0, first = TN_EMPTY;
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += CP_BLOCK) {
+        const uint32_t x = block_hits[b];
+        before += b < blockIdx.x ? x : 0u;
+        all += x;
+        const uint32_t f = block_first[b];
+        first = f < first ? f : first;
+    }
+    if (first != TN_EMPTY) atomicMin(&s_first, first);
+    uint32_t t0, t1;
+    block_excl_scan(before, sm, t0);
+    block_excl_scan(all, sm, t1);
+    const uint32_t hits_before = t0, total = t1;
+    const uint32_t pad_ray = s_first == TN_EMPTY ? 0u : s_first;   // (no ray hits: every entry is padding and names ray 0)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count = total;
+    const size_t base = (size_t)blockIdx.x * CP_RAYS + (size_t)threadIdx.x * CP_PER;
+    bool hit[CP_PER];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < CP_PER; ++i) {
+        const size_t ray = base + i;
+        hit[i] = ray < R && num_visited[ray] > 0;
+        c += hit[i] ? 1u : 0u;
+    }
+    uint32_t tot_block;
+    uint32_t h = hits_before + block_excl_scan(c, sm, tot_block);   // hitting rays before this thread's first ray
+#pragma unroll
+    for (int i = 0; i < CP_PER; ++i) {
+        const size_t ray = base + i;
+        if (ray >= R) break;
+        const size_t pos = hit[i] ? (size_t)h : (size_t)total + (ray - h);   // misses: rank among the misses = ray - hits before it
+        order[pos] = (uint32_t)ray;
+        if (padded) padded[pos] = hit[i] ? (uint32_t)ray : pad_ray;
+        h += hit[i] ? 1u : 0u;
     }
 }
 
+size_t compact_scratch_u32(size_t R) { return 2 * ((R + CP_RAYS - 1) / CP_RAYS); }
+
+void launch_compact_hits(size_t R, const uint32_t *num_visited, uint32_t *order, uint32_t *count, uint32_t *padded, uint32_t *scratch,
+                         hipStream_t stream) {
+    const size_t blocks = (R + CP_RAYS - 1) / CP_RAYS;
+    if (R == 0) { (void)hipMemsetAsync(count, 0, sizeof(uint32_t), stream); return; }
+    hipLaunchKernelGGL(k_count_hits, dim3((unsigned)blocks), dim3(CP_BLOCK), 0, stream, R, num_visited, scratch, scratch + blocks);
+    hipLaunchKernelGGL(k_write_order, dim3((unsigned)blocks), dim3(CP_BLOCK), 0, stream, R, num_visited, scratch, scratch + blocks, order,
+                       count, padded);
+}
+
 void launch_sample_coarse(size_t r, uint32_t S, uint32_t M, const uint32_t *ray_index, const uint32_t *num_visited, const float *hit_dist,
-                          const float *lin, const float *t_rand, bool biased, float *edges, float *near_far, hipStream_t stream) {
+                          const float *lin, const float *t_rand, bool biased, float *edges, float *near_far, hipStream_t stream,
+                          const uint32_t *count) {
     if (r == 0) return;
     const size_t smem = biased ? (size_t)(SB / 64) * (M + 1) * sizeof(float) : 0;
     if (smem > 64 * 1024) throw Error("sample_coarse: max_ray_triangles too large for the biased sampler");
     const size_t blocks = (r + SB / 64 - 1) / (SB / 64);
     hipLaunchKernelGGL(k_sample_coarse, dim3((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16)), dim3(SB), smem, stream, r, S, M, ray_index,
-                       num_visited, hit_dist, lin, t_rand, biased ? 1 : 0, edges, near_far);
+                       num_visited, hit_dist, lin, t_rand, biased ? 1 : 0, edges, near_far, count);
 }
 
 void launch_sample_pdf(size_t r, uint32_t S, uint32_t num_fine, const float *edges, const float *weights, const float *near_far,
-                       const float *u_table, const float *u_rand, float histogram_padding, float eps, float *out, hipStream_t stream) {
+                       const float *u_table, const float *u_rand, float histogram_padding, float eps, float *out, hipStream_t stream,
+                       const uint32_t *count) {
     if (r == 0) return;
     const uint32_t nb = num_fine + 1;
     const size_t smem = (size_t)(SB / 64) * (2 * (S + 1) + nb) * sizeof(float);
     if (smem > 64 * 1024) throw Error("sample_pdf: too many samples per ray");
     const size_t blocks = (r + SB / 64 - 1) / (SB / 64);
     hipLaunchKernelGGL(k_sample_pdf, dim3((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16)), dim3(SB), smem, stream, r, S, nb, edges, weights,
-                       near_far, u_table, u_rand, histogram_padding, eps, out);
+                       near_far, u_table, u_rand, histogram_padding, eps, out, count);
 }
 
 }  // namespace tn

@@ -187,9 +187,10 @@ class TetrahedraTracer:
         return {"tetrahedra": tets, "barycentric_coordinates": bary, "vertex_indices": verts, "valid_mask": tets != -1}
 
     def find_visited_cells(self, num_visited_cells, visited_cells, barycentric_coordinates,
-                           hit_distances, vertex_indices, distances, ray_index=None):
+                           hit_distances, vertex_indices, distances, ray_index=None, count=None):
         """py_binding.cpp:163-216.  Addition: `ray_index` (int32 [r]) matches a SUBSET of the traced rays without
-        compacting their rows first -- `distances` and the results are [r, S...], the trace tensors stay [R, M...]."""
+        compacting their rows first -- `distances` and the results are [r, S...], the trace tensors stay [R, M...];
+        `count` (int32 [1] device tensor, with ray_index): only the first count[0] rows are matched (compact_hits)."""
         for x, name in ((num_visited_cells, "num_visited_cells"), (visited_cells, "visited_cells"),
                         (barycentric_coordinates, "barycentric_coordinates"),
                         (hit_distances, "hit_distances"), (distances, "distances"),
@@ -229,7 +230,7 @@ class TetrahedraTracer:
                 _lib.check(self._lib.tn_find_matched_cells_indexed(
                     R, S, M, _ptr(ray_index), _ptr(num_visited_cells), _ptr(visited_cells), _ptr(hit_distances),
                     _ptr(barycentric_coordinates), _ptr(distances), _ptr(vertex_indices), _ptr(matched_cells),
-                    _ptr(vertex_indices_out), _ptr(mask), _ptr(barycentric_coordinates_out), _stream(dev)))
+                    _ptr(vertex_indices_out), _ptr(mask), _ptr(barycentric_coordinates_out), _ptr(count), _stream(dev)))
         return {
             "cell_indices": matched_cells,
             "vertex_indices": vertex_indices_out,
@@ -256,6 +257,16 @@ class TetrahedraTracer:
 
     def set_option(self, name: str, value: int):
         _lib.check(self._lib.tn_set_option(self._h, name.encode(), int(value)))
+
+    TIMING_KEYS = ("speculative_fill", "walk", "bvh_fallback", "cross_check", "segment_writer", "literal_pairing", "tail_fill",
+                   "cross_check_retrace")
+
+    def trace_timings(self):
+        """Per-kernel milliseconds of the last one-chunk walk call traced with set_option("timing", 1) (the kernels then run
+        serialised on the caller's stream; tn_trace_timings)."""
+        arr = (C.c_float * 8)()
+        _lib.check(self._lib.tn_trace_timings(self._h, C.byref(arr)))
+        return {k: float(arr[i]) for i, k in enumerate(self.TIMING_KEYS)}
 
     def face_tables(self):
         """(faces [F,3], face_tets [F,2]) int64 CPU tensors of the loaded mesh (debug aid)."""
@@ -300,6 +311,18 @@ class TetrahedraTracer:
             _ptr(out["num_visited_cells"]), _ptr(out["visited_cells"]), _ptr(out["barycentric_coordinates"]),
             _ptr(out["hit_distances"]), _ptr(out["vertex_indices"]), _stream(dev)))
         return out
+
+
+def fill_rows(visited_cells, barycentric_coordinates, hit_distances, vertex_indices=None, first_slot=0):
+    """The constant tails of trace_rays' dense rows (tn_fill_rows) from slot `first_slot & ~31` on, in place, for every row."""
+    for x, name in ((visited_cells, "visited_cells"), (barycentric_coordinates, "barycentric_coordinates"),
+                    (hit_distances, "hit_distances")) + (() if vertex_indices is None else ((vertex_indices, "vertex_indices"),)):
+        _check_input(x, name)
+    R, M = visited_cells.shape
+    dev = visited_cells.device
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tn_fill_rows(R, M, int(first_slot), _ptr(visited_cells), _ptr(barycentric_coordinates),
+                                            _ptr(hit_distances), _ptr(vertex_indices), _stream(dev)))
 
 
 # Vertex-major shadow copies [V, F] of feature-major fields [F, V] (the checkpoint layout, model.py:269-271).
@@ -591,7 +614,7 @@ def _ray_bias(ray_head_bias, rays, dev):
 
 
 def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, weights, samples_per_ray, mode="fp32",
-                       ray_head_bias=None):
+                       ray_head_bias=None, count=None):
     """interpolate_values + mlp_forward in ONE kernel: the wave gathers its samples' features from the
     (vertex-major shadow of the) field straight into MFMA operand registers; the [64, n] feature buffer is never
     written.  vertex_indices i32 [..., 4], barycentric_coordinates f32 [..., 3], field f32 [64, V].
@@ -618,7 +641,7 @@ def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, wei
         _lib.check(_lib.load().tn_mlp_forward_gather(m.handle, n, S, _ptr(vertex_indices), _ptr(barycentric_coordinates),
                                                      _ptr(field_vm), _ptr(dirs), _mode(mode), _ptr(sigma), _ptr(rgb),
                                                      _ptr(None if density_only else _ray_bias(ray_head_bias, n // S, dev)),
-                                                     _stream(dev)))
+                                                     _ptr(count), _stream(dev)))
     return sigma if density_only else (sigma, rgb)
 
 
@@ -698,7 +721,26 @@ def _quantile_table(num_bins, centred, device):
     return _TABLES[key]
 
 
-def sample_coarse(num_visited_cells, hit_distances, ray_index, num_samples, biased=False, t_rand=None):
+def compact_hits(num_visited_cells, want_padded=False):
+    """Stable partition of the rays of a trace call by num_visited_cells > 0, on the device (tn_compact_hits; replaces
+    torch.nonzero / boolean indexing: no host synchronisation).  Returns (order i32 [R], count i32 [1] on the device[,
+    padded i32 [R]]): order[:count] = the hitting rays in ray order, order[count:] = the others; padded = order with the tail
+    replaced by order[0]."""
+    _check_input(num_visited_cells, "num_visited_cells")
+    _check(num_visited_cells.dtype == torch.int32 and num_visited_cells.dim() == 1, "num_visited_cells must be i32 [R]")
+    R, dev = num_visited_cells.numel(), num_visited_cells.device
+    order = _empty((R,), dtype=torch.int32, device=dev)
+    count = _empty((1,), dtype=torch.int32, device=dev)
+    padded = _empty((R,), dtype=torch.int32, device=dev) if want_padded else None
+    n_scratch = 2 * ((R + 2047) // 2048)
+    scratch = _empty((max(n_scratch, 1),), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tn_compact_hits(R, _ptr(num_visited_cells), _ptr(order), _ptr(count), _ptr(padded), _ptr(scratch),
+                                               scratch.numel(), _stream(dev)))
+    return (order, count, padded) if want_padded else (order, count)
+
+
+def sample_coarse(num_visited_cells, hit_distances, ray_index, num_samples, biased=False, t_rand=None, count=None):
     """Coarse sampler as ONE kernel on the trace rows in place (tn_sample_coarse; model.py:531-557, 111-192): returns
     (edges f32 [r, S+1] euclidean bin edges, near_far f32 [r, 2]) for the hitting rays ray_index i32 [r].  t_rand
     [r, S+1]: training-mode stratified bins; biased: the TetrahedraSampler mapping.  Same values as
@@ -717,11 +759,11 @@ def sample_coarse(num_visited_cells, hit_distances, ray_index, num_samples, bias
     with torch.cuda.device(dev):
         _lib.check(_lib.load().tn_sample_coarse(r, S, M, _ptr(ray_index), _ptr(num_visited_cells), _ptr(hit_distances),
                                                 _ptr(_linspace_table(S, dev)), _ptr(t_rand), 1 if biased else 0, _ptr(edges),
-                                                _ptr(near_far), _stream(dev)))
+                                                _ptr(near_far), _ptr(count), _stream(dev)))
     return edges, near_far
 
 
-def sample_pdf(edges, weights, near_far, num_fine, u_rand=None, histogram_padding=0.01, eps=1e-5):
+def sample_pdf(edges, weights, near_far, num_fine, u_rand=None, histogram_padding=0.01, eps=1e-5, count=None):
     """nerfstudio's PDFSampler (include_original) as ONE kernel (tn_sample_pdf; model.py:582-586): edges f32 [r, S+1]
     euclidean coarse edges, weights f32 [r, S], near_far f32 [r, 2] -> f32 [r, S + num_fine + 2] merged, sorted euclidean
     edges.  u_rand [r, num_fine+1]: training-mode stratified quantiles."""
@@ -739,14 +781,16 @@ def sample_pdf(edges, weights, near_far, num_fine, u_rand=None, histogram_paddin
     with torch.cuda.device(dev):
         _lib.check(_lib.load().tn_sample_pdf(r, S, int(num_fine), _ptr(edges), _ptr(weights), _ptr(near_far),
                                              _ptr(_quantile_table(nb, u_rand is None, dev)), _ptr(u_rand), float(histogram_padding),
-                                             float(eps), _ptr(out), _stream(dev)))
+                                             float(eps), _ptr(out), _ptr(count), _stream(dev)))
     return out
 
 
-def composite(sigma, rgb, edges, background=1.0, return_weights=False, clamp=False):
+def composite(sigma, rgb, edges, background=1.0, return_weights=False, clamp=False, out=None, ray_index=None, count=None):
     """RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers
     (model.py:632-638) in one kernel.  sigma f32 [R,S], rgb f32 [R,S,3], edges f32 [R,S+1].
-    rgb=None: only the weights [R,S] are computed and returned (get_weights of the coarse pass, model.py:582)."""
+    rgb=None: only the weights [R,S] are computed and returned (get_weights of the coarse pass, model.py:582).
+    out = (rgb [R_all,3], accumulation, depth over ALL rays of the trace call) + ray_index i32 [R]: row q is written at
+    ray_index[q] (returns None); count i32 [1] on the device: only the first count[0] rows are processed (compact_hits)."""
     for x, name in ((sigma, "sigma"), (edges, "edges")) + (() if rgb is None else ((rgb, "rgb"),)):
         _check_input(x, name)
         _check(x.dtype == torch.float32, f"{name} must have float32 type")
@@ -757,8 +801,18 @@ def composite(sigma, rgb, edges, background=1.0, return_weights=False, clamp=Fal
         weights = _empty((R, S), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), None, _ptr(edges), None, None, None, None,
-                                                _ptr(weights), _stream(dev)))
+                                                _ptr(weights), None, _ptr(count), _stream(dev)))
         return weights
+    if out is not None:
+        _check(ray_index is not None and ray_index.dtype == torch.int32 and ray_index.numel() == R, "out= needs ray_index i32 [R]")
+        o_rgb, o_acc, o_depth = out
+        for x, name in ((o_rgb, "rgb"), (o_acc, "accumulation"), (o_depth, "depth")):
+            _check_input(x, name)
+            _check(x.dtype == torch.float32, f"{name} must have float32 type")
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), _ptr(rgb), _ptr(edges), _background(background, clamp), _ptr(o_rgb),
+                                                _ptr(o_acc), _ptr(o_depth), None, _ptr(ray_index), _ptr(count), _stream(dev)))
+        return None
     out_rgb = _empty((R, 3), dtype=torch.float32, device=dev)
     acc = _empty((R, 1), dtype=torch.float32, device=dev)
     depth = _empty((R, 1), dtype=torch.float32, device=dev)
