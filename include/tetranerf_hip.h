@@ -223,6 +223,15 @@ int tn_trace_stats(tn_tracer_t tracer, uint64_t stats[4]);
  * (re-traced through the BVH path; never observed). */
 int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
 
+/* The cross-check of the walk's certification in the last tn_trace_rays (host values; forces a stream sync).  Two populations of
+ * CERTIFIED rays are re-counted by a count-only BVH all-hits traversal (a differing count re-traces the ray through the BVH path):
+ *   the blind sample   every verify_stride-th ray:                      out[0] = stride, out[1] = checked, out[2] = mismatches
+ *   the risk classes   EVERY ray inside the wide band (64 rounding distances; the guards that hand a ray over act at 8) of
+ *                      a hull edge (out[3] = rays of that class) or of an edge of a thin-neighbourhood tet (out[4]):
+ *                      out[5] = checked (those not already in the blind sample), out[6] = mismatches
+ * See csrc/tn_trace_walk.hip (edge_band) and DESIGN.md section 2.  Option "verify_risk" = 0 switches the risk classes off. */
+int tn_trace_cross_check(tn_tracer_t tracer, uint64_t out[8]);
+
 /* Per-kernel breakdown of the last one-chunk walk call traced with option "timing" = 1 (measurement aid; bench.py prints it):
  * with that option the kernels of a call are enqueued on the CALLER's stream in program order with a timing event after each
  * (a normal call overlaps them on four streams, so its parts do not add up to its duration).  ms[0..7] = speculative tail fill,
@@ -269,6 +278,8 @@ int tn_fill_rows(size_t num_rays, uint32_t max_ray_triangles, uint32_t first_slo
  *             "verify_inject" 1 = every checked ray counts as a mismatch (tests of the hand-over)
  *   "literal_sort_passes"  (default 8) odd-even transposition passes over the nearly sorted hits the walk logged for a ray
  *             whose order it does not certify, before the bitonic network takes over (same result: distinct keys; tests run 0 and 1)
+ *   "verify_risk"  1 (default) = every certified ray of the RISK classes is cross-checked as well (tn_trace_cross_check); 0 = only
+ *             the blind sample
  *   "timing"  1 = serialise the kernels of a one-chunk walk call on the caller's stream with timing events (tn_trace_timings);
  *             0 (default) = the overlapped four-stream schedule
  *   "writer_table"  0 (default) = the segment writer's record table by mesh size (one record per (tet, entry face) below
@@ -353,6 +364,26 @@ int tn_render_pass(tn_mlp_t mlp, uint32_t max_ray_triangles, const uint32_t *num
                    uint32_t num_samples, const float *edges, const float *field_vm, const float *dirs,
                    const tn_rgb_background *background, float *out_weights, float *out_rgb, float *out_acc, float *out_depth,
                    const float *ray_head_bias /* f32 [num_hit_rays, 128] or NULL */, void *stream);
+
+/* EVERYTHING between tn_trace_rays and the frame as ONE persistent launch (reference span
+ * tetranerf/nerfstudio/model.py:531-662 in evaluation mode): coarse sampler (uniform or biased) -> find_visited_cells ->
+ * interpolate_values + mlp_base + density head -> get_weights -> PDFSampler (include_original) -> find_visited_cells ->
+ * interpolate_values + mlp_base + heads -> get_weights + RGB / accumulation / median-depth renderers, written into the frame.
+ * The ray set is ray_index u32 [num_hit_rays_max] = tn_compact_hits' `order` and its SIZE lives on the device (count u32 [1];
+ * NULL: all num_hit_rays_max entries) -- nothing on the host waits for the trace.  The trace rows are read in place; dirs f32
+ * [R,3] and ray_head_bias f32 [R,128] (nullable) are arrays over ALL rays, indexed by ray; out_rgb f32 [R,3], out_acc f32 [R],
+ * out_depth f32 [R] are written at the hitting rays' own rows (pre-fill them with the background values).
+ * num_fine = 0: one pass over the coarse samples.  linspace f32 [S+1], u_table f32 [num_fine+1] (bin-centred quantiles),
+ * histogram_padding / eps as in tn_sample_coarse / tn_sample_pdf.  fp32 MFMA arithmetic; every stage runs the same device
+ * function as the stand-alone entry points, so the frame is bit-identical to tn_sample_coarse -> tn_find_matched_cells_indexed
+ * -> tn_mlp_forward_gather -> tn_composite -> tn_sample_pdf -> ... (csrc/tn_render_rays.hip).
+ * Needs max(2 M, 3 S + num_fine + 3) * 32 B <= 160 KB of LDS (M <= 2048 at the shipped sample counts). */
+int tn_render_rays(tn_mlp_t mlp, uint32_t max_ray_triangles, const uint32_t *num_visited, const float *hit_distances,
+                   const float *barycentric, const uint32_t *vertex_indices, const uint32_t *ray_index, const uint32_t *count,
+                   size_t num_hit_rays_max, uint32_t num_samples, uint32_t num_fine, int biased, const float *linspace,
+                   const float *u_table, float histogram_padding, float eps, const float *field_vm, const float *dirs,
+                   const tn_rgb_background *background, float *out_rgb, float *out_acc, float *out_depth,
+                   const float *ray_head_bias, void *stream);
 
 /* ---- ray samplers between tn_trace_rays and the render passes (model.py:111-192, 549-557, 582-586; nerfstudio's
  * UniformSampler / PDFSampler for the parts the reference imports).  One wavefront per HITTING ray; the trace rows are

@@ -76,6 +76,15 @@ def _cross_check_clean(tr, num_rays, ctx):
     why = tr.flag_reasons()
     assert why.get(14, 0) == 0, (ctx, why)
     assert why.get(15, 0) > 0.5 * num_rays / 256, (ctx, why)    # (literal / fallback rays among the sampled ones are skipped)
+    # round 5: EVERY certified ray of the risk classes (inside the 64-delta band of a guard that hands over at 8 delta) is
+    # re-counted as well: it ran on all of them (but those the blind sample already holds), and it never disagreed
+    xc = tr.cross_check()
+    risk = xc["risk"]
+    print(f"{ctx}: cross-check {xc}")
+    assert xc["checked"] == why.get(15, 0) and xc["mismatches"] == 0 and risk["mismatches"] == 0, (ctx, xc)
+    listed = risk["hull_near_miss_rays"] + risk["thin_neighbourhood_rays"]
+    assert listed - listed // 128 - 8 <= risk["checked"] <= listed, (ctx, xc)
+    assert listed < 0.05 * num_rays, (ctx, xc)     # a class of a few per mille of the rays on well-shaped meshes
 
 
 def _mesh(scenes, n_points, seed, ctx):
@@ -153,6 +162,60 @@ def test_c5_stress_sample_bit_exact(tn, device, oracle, scenes):
     sl = slice(368 * 800, 432 * 800)  # 64 image rows through the middle of the frame (51,200 rays)
     fo, fd = np.ascontiguousarray(fo[sl]), np.ascontiguousarray(fd[sl])
     _compare(_trace(tr, device, fo, fd, 512), ot, fo, fd, 512, ctx="C5 frame slice")
+
+
+def _cached_delaunay(scenes, n_points, seed):
+    """Delaunay cells of `n_points` uniform points (seed), cached under ~/.cache/tetranerf_tests (or $TETRANERF_TEST_CACHE; outside
+    the repository: 108 MB at 1M points; ~80-110 s of Qhull when absent)."""
+    import os
+    from pathlib import Path
+
+    rng = np.random.default_rng(seed)
+    pts = rng.random((n_points, 3)).astype(np.float32)
+    f = Path(os.environ.get("TETRANERF_TEST_CACHE", str(Path.home() / ".cache" / "tetranerf_tests"))) / f"delaunay_{n_points}_seed{seed}.npy"
+    if f.exists():
+        cells = np.load(f)
+    else:
+        cells = scenes.delaunay_cells(pts)
+        try:
+            f.parent.mkdir(parents=True, exist_ok=True)
+            np.save(f, cells)
+        except OSError:
+            pass
+    return pts, cells
+
+
+def test_reference_scale_mesh_one_million_points(tn, device, oracle, scenes):
+    """The reference triangulates up to 1,000,000 points (tetranerf/scripts/triangulate.py:15): a Delaunay of 1M uniform points =
+    6.7M tets, 13.5M faces -- walk tables of 0.9 GB (six times the 256 MiB Infinity Cache), 27M walk records (the log entry holds
+    30 bits of record index), rays crossing 500-650 faces (M = 1024).  load_tetrahedra builds it on the device; 204,800 frame
+    rays + 16,384 incoherent rays: the walk path (certified chains, literal pairing, BVH fallbacks) against the BVH all-hits
+    path, bit for bit over the five outputs; 8,192 of them against the CPU oracle; the sampled cross-check clean."""
+    import torch
+
+    pts, cells = _cached_delaunay(scenes, 1_000_000, 7)
+    assert len(cells) > 5_000_000, len(cells)
+    print(f"reference scale: {len(cells)} tets, mesh sha256 {scenes.mesh_sha256(pts, cells)}")
+    M = 1024
+    tr = _tracer(tn, device, pts, cells, walk=1)
+    assert tr._lib.tn_num_faces(tr._h) > 2 * len(cells)
+    fo, fd = _frame(scenes, 512, 400)
+    ro, rd = scenes.outside_in_rays(16384, 31)
+    o, d = np.concatenate([fo, ro]), np.concatenate([fd, rd])
+    out = _trace(tr, device, o, d, M)
+    st, why = tr.trace_stats(), tr.flag_reasons()
+    assert st["walk"] + st["general"] == len(o) and st["walk"] > 0.7 * len(o), (st, why)
+    assert st["overflow"] == 0, st
+    _cross_check_clean(tr, len(o), "1M points")
+    nv = out["num_visited_cells"]
+    assert int(nv.max()) > 400 and int((nv > 0).sum()) > 0.5 * len(o), (int(nv.max()), int((nv > 0).sum()))
+    tb = _tracer(tn, device, pts, cells, walk=0)
+    ref = _trace(tb, device, o, d, M)
+    for k in KEYS:
+        assert torch.equal(out[k].view(torch.int32), ref[k].view(torch.int32)), f"1M points, walk vs BVH path: {k}"
+    del ref, tb
+    rows = np.sort(np.concatenate([np.random.default_rng(3).choice(len(fo), 6144, replace=False), len(fo) + np.arange(2048)]))
+    _compare(out, _oracle(oracle, pts, cells), o, d, M, rows=rows, chunk=8192, ctx="1M points")
 
 
 # ------------------------------------------------------------------------------------------------ adversarial geometry

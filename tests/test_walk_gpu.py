@@ -296,6 +296,43 @@ def test_cross_check_hand_over_paths(tn, device, scenes):
                 assert torch.equal(ref[k].view(torch.int32), clean[k].view(torch.int32)), (chunked, stride, k)
 
 
+def test_risk_classes_of_the_certification_are_cross_checked(tn, device, scenes):
+    """Round 5: a certified ray inside the WIDE band (64 rounding distances) of a guard that hands rays over at 8 -- a hull edge,
+    an edge of a thin-neighbourhood tet -- is re-counted by the BVH cross-check, every one of them (the blind sample takes one
+    ray in 256).  On meshes with thin tets and with rays aimed at vertices the classes are populated; the check runs on all
+    their rays, finds no mismatch, changes no output; option verify_risk = 0 switches it off; the chunked schedule does the same."""
+    import torch
+
+    for name, (pts, cells) in (("near_duplicates", scenes.near_duplicates_mesh()), ("shells", scenes.shells_mesh()),
+                               ("random", scenes.random_mesh(5000, 3))):
+        lo, hi = pts.min(0), pts.max(0)
+        ext = float((hi - lo).max())
+        vo, vd = scenes.vertex_to_vertex_rays(pts, 20000, 5, extend=1.2 * ext)
+        oo, od = scenes.outside_in_rays(20000, 6)
+        oo = ((oo - 0.5) * ext + 0.5 * (lo + hi)).astype(np.float32)
+        o, d = np.concatenate([vo, oo]), np.concatenate([vd, od])
+        to, td = torch.from_numpy(np.ascontiguousarray(o)).to(device), torch.from_numpy(np.ascontiguousarray(d)).to(device)
+        tr = _tracer(tn, device, pts, cells, 2)
+        tr.set_option("verify_risk", 0)
+        ref = tr.trace_rays(to, td, 512)
+        off = tr.cross_check()
+        assert off["risk"] == {"hull_near_miss_rays": 0, "thin_neighbourhood_rays": 0, "checked": 0, "mismatches": 0}, off
+        tr.set_option("verify_risk", 1)
+        for chunked in (False, True):
+            tr.set_option("log_cap_mb", 96 if chunked else 0)
+            got = tr.trace_rays(to, td, 512)
+            xc = tr.cross_check()
+            risk = xc["risk"]
+            listed = risk["hull_near_miss_rays"] + risk["thin_neighbourhood_rays"]
+            print(name, "chunked" if chunked else "one chunk", xc, tr.trace_stats())
+            assert xc["mismatches"] == 0 and risk["mismatches"] == 0, (name, xc)
+            assert listed - listed // 128 - 8 <= risk["checked"] <= listed, (name, xc)   # all but those the blind sample holds
+            if name != "random":
+                assert listed > 20, (name, xc)
+            for k in KEYS:
+                assert torch.equal(ref[k].view(torch.int32), got[k].view(torch.int32)), (name, chunked, k)
+
+
 def _trace_into_sentinels(tn, tr, to, td, M, flags):
     """tn_trace_rays_ex into buffers pre-set to sentinels: shows which bytes a call writes."""
     import ctypes as C

@@ -1,6 +1,7 @@
 // tn_api.hip -- the C-ABI of libtetranerf_hip.so (see include/tetranerf_hip.h).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -67,11 +68,16 @@ struct tn_tracer {
     tn::DevBuf<tn::WalkFid> fidt;
     tn::DevBuf<float> hull_nodes, hull_tris;
     tn::DevWideBvh bvh;
-    tn::DevBuf<unsigned long long> stats;   // [24] counters of the last call + [24..26) three uint32: fallback count,
+    static constexpr int N_STATS = 32;      // 64-bit counters of the last call: [0..4) path statistics, [4..20) walk hand-over reasons,
+                                            // [20..24) diagnostics, [24..28) risk classes of the certification (tn_trace_cross_check)
+    tn::DevBuf<unsigned long long> stats;   // [N_STATS] counters + [N_STATS .. N_STATS + 2) four uint32: fallback count,
                                             // literal count, kmax (one memset clears them all)
-    uint32_t *fallback_count() { return reinterpret_cast<uint32_t *>(stats.p + 24); }
-    uint32_t *literal_count() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 1; }
-    uint32_t *verify_count() { return reinterpret_cast<uint32_t *>(stats.p + 24) + 2; }
+    uint32_t *fallback_count() { return reinterpret_cast<uint32_t *>(stats.p + N_STATS); }
+    uint32_t *literal_count() { return reinterpret_cast<uint32_t *>(stats.p + N_STATS) + 1; }
+    uint32_t *verify_count() { return reinterpret_cast<uint32_t *>(stats.p + N_STATS) + 2; }
+    uint32_t *risk_count() { return reinterpret_cast<uint32_t *>(stats.p + N_STATS) + 3; }
+    tn::DevBuf<uint32_t> risk_list;      // certified rays inside the wide band of a certification guard (all cross-checked)
+    bool verify_risk = true;             // option "verify_risk"
     size_t last_num_rays = 0;
     int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
     size_t walk_min_rays = 12288;        // measured crossover on the 300k-tet mesh after round 2b's faster BVH path
@@ -153,8 +159,8 @@ int tn_tracer_create(int device, tn_tracer_t *out) {
         t->device = device;
         t->use_walk = env_flag("TETRANERF_HIP_WALK", true) ? 1 : 0;
         t->gpu_build = env_flag("TETRANERF_HIP_GPU_BUILD", true);
-        t->stats.alloc(26);
-        TN_HIP(hipMemset(t->stats.p, 0, 26 * sizeof(unsigned long long)));
+        t->stats.alloc(tn_tracer::N_STATS + 2);
+        TN_HIP(hipMemset(t->stats.p, 0, (tn_tracer::N_STATS + 2) * sizeof(unsigned long long)));
         {
             // the side streams carry the few rays the walk does not certify: lowest priority, so that the dispatcher
             // hands wave slots to the main stream's kernels first when both have blocks waiting
@@ -383,7 +389,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
         hipStream_t stream = (hipStream_t)stream_;
         t->last_stream = stream;
         t->last_num_rays = R;
-        TN_HIP(hipMemsetAsync(t->stats.p, 0, 26 * sizeof(unsigned long long), stream));
+        TN_HIP(hipMemsetAsync(t->stats.p, 0, (tn_tracer::N_STATS + 2) * sizeof(unsigned long long), stream));
         tn::TraceParams p = make_params(t, R, M, origins, directions, num_visited, visited, bary, dist, verts);
         p.compact_rows = dense_tails ? 0u : 1u;
         // Small batches are latency-bound: a lane walking ~180 dependent steps is slower than one
@@ -403,11 +409,13 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
             // (or a literal / fallback row) simply overwrites its slots.  The log holds 16 B per hit slot; calls whose log
             // would exceed the cap are processed in ray chunks (multiples of 4096 rays, the walk's XCD run), serially.
             if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); }
+            const bool verify_risk = t->verify_risk && t->verify_stride;
             if (t->verify_stride) {
                 // sized with the other scratch buffers, BEFORE the first launch of the call: an allocation in the middle of
-                // the overlapped schedule would synchronise the device there (hipFree / hipMalloc)
-                const size_t n_checks = (R + t->verify_stride - 1) / t->verify_stride;
-                if (t->verify_list.n < n_checks) t->verify_list.alloc(n_checks);
+                // the overlapped schedule would synchronise the device there (hipFree / hipMalloc).  (R entries: the blind
+                // sample + the risk classes can, on a degenerate mesh, name every ray)
+                if (t->verify_list.n < R) t->verify_list.alloc(R);
+                if (verify_risk && t->risk_list.n < R) t->risk_list.alloc(R);
             }
             size_t cap_bytes = t->log_cap_bytes;
             if (!cap_bytes) {
@@ -447,10 +455,16 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 w.walk_n = t->walk_n.p + base;
                 w.hit_log = t->hit_log.p;
                 w.ray_base = base;
+                w.risk_list = verify_risk ? t->risk_list.p : nullptr;
+                w.risk_count = t->risk_count();
                 tn::launch_trace_walk(w, stream, walk_reserve);
-                if (t->verify_stride && !single)   // chunked call: serially, before anything that reads walk_n / the fallback list
+                if (t->verify_stride && !single) {  // chunked call: serially, before anything that reads walk_n / the fallback list
                     tn::launch_verify_counts(w.t, t->verify_stride, w.walk_n, w.fallback_list, w.fallback_count, base, stream, false,
                                              t->verify_inject);
+                    if (verify_risk)
+                        tn::launch_verify_counts(w.t, t->verify_stride, w.walk_n, w.fallback_list, w.fallback_count, base, stream, false,
+                                                 false, t->risk_list.p, t->risk_count(), n);
+                }
             };
             auto launch_segments = [&](size_t base, size_t n) {
                 tn::WriteParams q{};
@@ -529,6 +543,10 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                     // the count cross-check beside the writer and the fill (late form): mismatching rays -> verify_list
                     tn::launch_verify_counts(chunk_params(0, R), t->verify_stride, t->walk_n.p, t->verify_list.p, t->verify_count(), 0,
                                              s_aux, true, t->verify_inject);
+                    // ... and EVERY certified ray of the risk classes (inside the wide band of a guard: DESIGN.md section 2)
+                    if (verify_risk)
+                        tn::launch_verify_counts(chunk_params(0, R), t->verify_stride, t->walk_n.p, t->verify_list.p, t->verify_count(), 0,
+                                                 s_aux, true, false, t->risk_list.p, t->risk_count(), R);
                 }
                 mark();                                                   // 4: count cross-check
                 TN_HIP(hipEventRecord(t->ev_aux, s_aux));
@@ -560,6 +578,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 for (size_t base = 0; base < R; base += chunk) {
                     const size_t n = R - base < chunk ? R - base : chunk;
                     TN_HIP(hipMemsetAsync(t->literal_count(), 0, sizeof(uint32_t), stream));
+                    TN_HIP(hipMemsetAsync(t->risk_count(), 0, sizeof(uint32_t), stream));
                     launch_walk(base, n);
                     launch_segments(base, n);
                     launch_fill(base, n, M);
@@ -725,6 +744,20 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]) {
     });
 }
 
+int tn_trace_cross_check(tn_tracer_t tracer, uint64_t out[8]) {
+    return guarded([&] {
+        tn_tracer *t = checked(tracer);
+        std::lock_guard<std::mutex> lock(t->mu);
+        if (!out) throw tn::Error("out is null");
+        DeviceGuard g(t->device);
+        TN_HIP(hipStreamSynchronize(t->last_stream));
+        unsigned long long h[tn_tracer::N_STATS];
+        TN_HIP(hipMemcpy(h, t->stats.p, sizeof h, hipMemcpyDeviceToHost));
+        out[0] = t->verify_stride; out[1] = h[4 + 15]; out[2] = h[4 + 14];
+        out[3] = h[24]; out[4] = h[25]; out[5] = h[26]; out[6] = h[27]; out[7] = 0;
+    });
+}
+
 int tn_trace_timings(tn_tracer_t tracer, float ms[8]) {
     return guarded([&] {
         tn_tracer *t = checked(tracer);
@@ -779,6 +812,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (k == "verify_inject") t->verify_inject = value != 0;
         else if (k == "literal_sort_passes") t->literal_sort_passes = value < 0 ? 0u : (unsigned)value;
         else if (k == "verify_stride") t->verify_stride = value < 0 ? 0u : (unsigned)value;
+        else if (k == "verify_risk") t->verify_risk = value != 0;
         else if (k == "log_cap_mb") t->log_cap_bytes = value <= 0 ? 0 : (size_t)value << 20;
         else throw tn::Error("unknown option " + (name ? k : std::string("(null)")));
     });
@@ -855,6 +889,8 @@ struct tn_mlp {
     tn::DevBuf<float> pk_plain, pk_gather, pt, enc, grad_scratch;
     tn::DevBuf<uint4> blob;
     tn::DevBuf<uint32_t> nvh;
+    tn::DevBuf<float> render_scratch;    // per-block hand-over area of tn_render_rays (grown on demand, never shrunk)
+    tn::DevBuf<unsigned long long> render_prof;   // TETRANERF_HIP_RENDER_PROFILE=1 (debug): phase ticks of tn_render_rays
     bool packed = false;
     // per-call scratch: grown on demand (blocking hipMalloc, rare), never shrunk; one handle serves one stream at a time
     tn::MlpPacks packs(size_t rays) {
@@ -983,6 +1019,54 @@ int tn_render_pass(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const 
                                edges, field_vm, dirs, pk, background_of(background), out_weights, out_rgb, out_acc, out_depth,
                                (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
+    });
+}
+
+int tn_render_rays(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const float *hit_distances, const float *barycentric,
+                   const uint32_t *vertex_indices, const uint32_t *ray_index, const uint32_t *count, size_t num_hit_rays_max,
+                   uint32_t num_samples, uint32_t num_fine, int biased, const float *linspace, const float *u_table,
+                   float histogram_padding, float eps, const float *field_vm, const float *dirs,
+                   const tn_rgb_background *background, float *out_rgb, float *out_acc, float *out_depth,
+                   const float *ray_head_bias, void *stream_) {
+    return guarded([&] {
+        tn_mlp *m = checked_mlp(mlp);
+        if (num_hit_rays_max == 0) return;
+        if (!num_visited || !hit_distances || !barycentric || !vertex_indices || !ray_index || !linspace || !field_vm || !dirs ||
+            !out_rgb || !out_acc || !out_depth || (num_fine && !u_table))
+            throw tn::Error("null pointer");
+        if (num_samples == 0) throw tn::Error("num_samples must be positive");
+        if (num_hit_rays_max >= 0xFFFFFFFFull) throw tn::Error("too many rays for one call");
+        if ((size_t)num_samples + num_fine + 2 > 8192) throw tn::Error("render_rays: too many samples per ray");
+        DeviceGuard g(m->device);
+        if (!m->packed) throw tn::Error("tn_mlp_set_weights must be called first");
+        const unsigned grid = 256;   // one persistent 8-wave block per CU
+        tn::RenderRaysLayout L{};
+        const size_t need = tn::render_rays_scratch_floats(num_hit_rays_max, num_samples, num_fine, ray_head_bias != nullptr, grid, L);
+        if (m->render_scratch.n < need) {
+            TN_HIP(hipDeviceSynchronize());   // the old scratch may still be in use by queued kernels
+            m->render_scratch.alloc(need + need / 8);
+        }
+        // debug aid: TETRANERF_HIP_RENDER_PROFILE=1 prints where the persistent kernel's blocks spent their time, per call
+        // (a stream synchronisation per call: for profiling runs only)
+        static const bool profile = env_flag("TETRANERF_HIP_RENDER_PROFILE", false);
+        if (profile) {
+            if (!m->render_prof.p) m->render_prof.alloc(8);
+            TN_HIP(hipMemsetAsync(m->render_prof.p, 0, 8 * sizeof(unsigned long long), (hipStream_t)stream_));
+        }
+        tn::launch_render_rays(num_visited, hit_distances, barycentric, vertex_indices, M, ray_index, count, num_hit_rays_max, num_samples,
+                               num_fine, biased != 0, linspace, u_table, histogram_padding, eps, field_vm, dirs, ray_head_bias, m->packs(0),
+                               background_of(background), out_rgb, out_acc, out_depth, m->render_scratch.p, L, grid, (hipStream_t)stream_,
+                               profile ? m->render_prof.p : nullptr);
+        TN_HIP(hipGetLastError());
+        if (profile) {
+            unsigned long long h[8];
+            TN_HIP(hipStreamSynchronize((hipStream_t)stream_));
+            TN_HIP(hipMemcpy(h, m->render_prof.p, sizeof h, hipMemcpyDeviceToHost));
+            const double nb = h[5] ? (double)h[5] : 1.0, us = 0.01;   // 100 MHz ticks -> microseconds, mean per working block
+            fprintf(stderr, "[tn_render_rays] S=%u fine=%u rays<=%zu blocks=%llu  mean us per block: sample+match %.1f | mlp density %.1f | "
+                            "weights+pdf+match %.1f | mlp full %.1f | composite %.1f\n", num_samples, num_fine, num_hit_rays_max,
+                    h[5], h[0] * us / nb, h[1] * us / nb, h[2] * us / nb, h[3] * us / nb, h[4] * us / nb);
+        }
     });
 }
 

@@ -58,6 +58,8 @@ struct WalkParams {
                                // ((r / 64) * M + k) * 64 + r % 64 (a wave's 64 lanes store 1 KB of consecutive bytes per
                                // step); exit code 3 = entry hull face, its face id in the low 30 bits
     size_t ray_base;           // global index of item 0 (rays are traced in chunks when the log would be too large)
+    uint32_t *risk_list;       // [num_items] certified rays inside the WIDE band (64 delta) of a certification guard: every one of
+    uint32_t *risk_count;      // [1]          them is cross-checked (k_verify_counts); null: not collected
 };
 // lds_reserve: bytes of (unused) dynamic LDS per block = an occupancy limit (160 KB / lds_reserve blocks per CU), 0 = none
 void launch_trace_walk(const WalkParams &p, hipStream_t stream, size_t lds_reserve = 0);
@@ -69,8 +71,11 @@ void launch_postprocess_log(const TraceParams &p, const WalkFid *fidt, const uin
 // count-only BVH cross-check of every stride-th certified ray (tn_trace_general.hip: k_verify_counts); p = the
 // TraceParams of the walk launch; mismatching rays are appended to the fallback list (global ids: ray_base + index)
 // late: mismatching rays only go to the list (their rows are re-traced at the end of the call), walk_n stays
+// ray_list / list_count (nullable): check exactly those rays (indices within this launch; the count lives on the device; the grid is
+// sized for max_list) instead of every stride-th one -- the walk's risk list
 void launch_verify_counts(const TraceParams &p, uint32_t stride, uint32_t *walk_n, uint32_t *fallback_list, uint32_t *fallback_count,
-                          size_t ray_base, hipStream_t stream, bool late = false, bool inject = false);
+                          size_t ray_base, hipStream_t stream, bool late = false, bool inject = false, const uint32_t *ray_list = nullptr,
+                          const uint32_t *list_count = nullptr, size_t max_list = 0);
 
 // hit log -> rows of the rays the walk certified (walk_n[ray] != TN_EMPTY): k_write_segments writes the segment records
 // + the tail constants up to the next multiple of 32 slots (a 128-byte line boundary in all four row arrays);
@@ -201,6 +206,18 @@ void launch_render_pass(const uint32_t *num_visited, const float *dist, const fl
                         const uint32_t *ray_index, size_t r, uint32_t S, const float *edges, const float *fieldT,
                         const float *dirs, const MlpPacks &w, Background background, float *out_weights, float *out_rgb,
                         float *out_acc, float *out_depth, hipStream_t stream);
+// everything between trace_rays and the frame as ONE persistent launch (tn_render_rays.hip): coarse sampler -> match -> gather +
+// MLP (density) -> weights -> PDF sampler -> match -> gather + MLP + heads -> composite, scattered into out_* (arrays over ALL rays)
+// at the hitting rays ray_index[0 .. *count) (count null: r_max); S_fine = 0: one pass.  dirs [R_all, 3], ray_bias [R_all, 128] or
+// null are indexed by ray.  scratch: render_rays_scratch_floats(...) floats, laid out by the RenderRaysLayout it fills.
+struct RenderRaysLayout { uint32_t T; size_t per_block, o_nf, o_wc, o_edges_f, o_enc, o_bias, o_vi, o_bc, o_sigma, o_rgb; };
+size_t render_rays_scratch_floats(size_t r_max, uint32_t S, uint32_t S_fine, bool has_bias, unsigned grid, RenderRaysLayout &L);
+void launch_render_rays(const uint32_t *num_visited, const float *dist, const float *bary, const uint32_t *verts, uint32_t M,
+                        const uint32_t *ray_index, const uint32_t *count, size_t r_max, uint32_t S, uint32_t S_fine, bool biased,
+                        const float *lin, const float *u_table, float hist_pad, float eps, const float *fieldT, const float *dirs,
+                        const float *ray_bias, const MlpPacks &w, Background background, float *out_rgb, float *out_acc, float *out_depth,
+                        float *scratch, const RenderRaysLayout &L, unsigned grid, hipStream_t stream,
+                        unsigned long long *prof = nullptr /* [8] debug: 100 MHz ticks per phase kind, summed over blocks */);
 // ray samplers (tn_samplers.hip): one wavefront per hitting ray, trace rows read in place through ray_index
 // count (nullable, every launcher below): the number of hitting rays lives on the device; r / R is the upper bound the grid is sized for
 void launch_sample_coarse(size_t r, uint32_t S, uint32_t M, const uint32_t *ray_index, const uint32_t *num_visited, const float *hit_dist,

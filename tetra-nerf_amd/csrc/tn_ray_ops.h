@@ -112,22 +112,65 @@ __device__ __forceinline__ void ray_sample_pdf(uint32_t S, uint32_t nb, const fl
     float *cdf = lds;                // [S+1]
     float *sp = cdf + (S + 1);       // [S+1] spacing edges
     float *nw = sp + (S + 1);        // [nb]  new bins
-    for (uint32_t j = lane; j <= S; j += 64) sp[j] = (e[j] - near) / (far - near);
-    // padded weights -> pdf -> cdf
-    float part = 0.f;
-    for (uint32_t j = lane; j < S; j += 64) part += w[j] + histogram_padding;
-    float wsum = wave_sum(part);
-    const float padding = fmaxf(eps - wsum, 0.f);
-    const float add = padding / (float)S;
-    wsum = wsum + padding;
-    float carry = 0.f;
-    if (lane == 0) cdf[0] = 0.f;
-    for (uint32_t base = 0; base < S; base += 64) {
-        const uint32_t j = base + lane;
-        const float pdf = j < S ? ((w[j] + histogram_padding) + add) / wsum : 0.f;
-        const float inc = wave_incl_scan(pdf, lane);
-        if (j < S) cdf[j + 1] = fminf(1.0f, carry + inc);
-        carry += __shfl(inc, 63);
+    // the ray's edges and weights: every load requested before the first use (one round trip instead of one per chunk and
+    // pass); WCH chunks of 64 cover S <= 576, longer rays take the generic loops
+    constexpr int WCH = 9;
+    if (S <= 64 * WCH) {
+        float ev[WCH], wv[WCH];
+#pragma unroll
+        for (int c = 0; c < WCH; ++c) {
+            ev[c] = wv[c] = 0.f;
+            if (64u * c <= S) {                 // wave-uniform
+                const uint32_t j = 64u * c + lane;
+                if (j <= S) ev[c] = e[j];
+                if (j < S) wv[c] = w[j];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < WCH; ++c) {
+            const uint32_t j = 64u * c + lane;
+            if (64u * c <= S && j <= S) sp[j] = (ev[c] - near) / (far - near);
+        }
+        // padded weights -> pdf -> cdf
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < WCH; ++c) {
+            const uint32_t j = 64u * c + lane;
+            if (64u * c < S && j < S) part += wv[c] + histogram_padding;
+        }
+        float wsum = wave_sum(part);
+        const float padding = fmaxf(eps - wsum, 0.f);
+        const float add = padding / (float)S;
+        wsum = wsum + padding;
+        float carry = 0.f;
+        if (lane == 0) cdf[0] = 0.f;
+#pragma unroll
+        for (int c = 0; c < WCH; ++c) {
+            if (64u * c >= S) break;            // wave-uniform
+            const uint32_t j = 64u * c + lane;
+            const float pdf = j < S ? ((wv[c] + histogram_padding) + add) / wsum : 0.f;
+            const float inc = wave_incl_scan(pdf, lane);
+            if (j < S) cdf[j + 1] = fminf(1.0f, carry + inc);
+            carry += __shfl(inc, 63);
+        }
+    } else {
+        for (uint32_t j = lane; j <= S; j += 64) sp[j] = (e[j] - near) / (far - near);
+        // padded weights -> pdf -> cdf
+        float part = 0.f;
+        for (uint32_t j = lane; j < S; j += 64) part += w[j] + histogram_padding;
+        float wsum = wave_sum(part);
+        const float padding = fmaxf(eps - wsum, 0.f);
+        const float add = padding / (float)S;
+        wsum = wsum + padding;
+        float carry = 0.f;
+        if (lane == 0) cdf[0] = 0.f;
+        for (uint32_t base = 0; base < S; base += 64) {
+            const uint32_t j = base + lane;
+            const float pdf = j < S ? ((w[j] + histogram_padding) + add) / wsum : 0.f;
+            const float inc = wave_incl_scan(pdf, lane);
+            if (j < S) cdf[j + 1] = fminf(1.0f, carry + inc);
+            carry += __shfl(inc, 63);
+        }
     }
     lds_sync();
     // inverse CDF at the quantiles
@@ -182,45 +225,64 @@ __device__ __forceinline__ void ray_composite(uint32_t S, const float *__restric
     float r0 = 0.f, r1 = 0.f, r2 = 0.f, accw = 0.f;
     float depth = 0.f;
     bool found = false;
-    for (uint32_t base = 0; base < S; base += 64) {
-        const uint32_t j = base + lane;
-        const bool ok = j < S;
-        const size_t q = ok ? j : S - 1;
-        const float st = e[q], en = e[q + 1];
-        const float dd = ok ? (en - st) * sigma[q] : 0.f;
-        // inclusive scan of dd over the wave
-        float inc = dd;
+    // The chunks of 64 samples are a serial chain (two wave scans each, carried sums), their LOADS are not: a wave that owns
+    // a ray alone (8 waves per CU in the persistent render kernel) would pay one memory round trip per chunk, so the values of
+    // up to CH chunks (576 samples: both shipped configurations in one go) are requested before the first scan.
+    constexpr int CH = 9;
+    for (uint32_t base0 = 0; base0 < S; base0 += 64 * CH) {
+        float stv[CH], env[CH], sgv[CH], k0[CH], k1[CH], k2[CH];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float o = __shfl_up(inc, off);
-            if (lane >= off) inc += o;
+        for (int c = 0; c < CH; ++c) {
+            stv[c] = env[c] = sgv[c] = k0[c] = k1[c] = k2[c] = 0.f;
+            if (base0 + 64u * c < S) {          // wave-uniform
+                const uint32_t j = base0 + 64u * c + lane;
+                const size_t q = j < S ? j : S - 1;
+                stv[c] = e[q]; env[c] = e[q + 1]; sgv[c] = sigma[q];
+                if (rgb) { k0[c] = rgb[3 * q]; k1[c] = rgb[3 * q + 1]; k2[c] = rgb[3 * q + 2]; }
+            }
         }
-        const float excl = carry + (inc - dd);
-        float w = (1.0f - expf(-dd)) * expf(-excl);
-        if (!(w == w) || !ok) w = 0.f;  // nan_to_num
-        if (out_w && ok) out_w[q] = w;
-        if (rgb) {
-            float c0 = rgb[3 * q], c1 = rgb[3 * q + 1], c2 = rgb[3 * q + 2];
-            if (background.clamp) { c0 = nan_to_num(c0); c1 = nan_to_num(c1); c2 = nan_to_num(c2); }
-            r0 += w * c0; r1 += w * c1; r2 += w * c2;
-        }
-        accw += w;
-        // median depth: first sample whose cumulative weight reaches 0.5
-        float winc = w;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float o = __shfl_up(winc, off);
-            if (lane >= off) winc += o;
+        for (int c = 0; c < CH; ++c) {
+            if (base0 + 64u * c >= S) break;    // wave-uniform
+            const uint32_t j = base0 + 64u * c + lane;
+            const bool ok = j < S;
+            const size_t q = ok ? j : S - 1;
+            const float st = stv[c], en = env[c];
+            const float dd = ok ? (en - st) * sgv[c] : 0.f;
+            // inclusive scan of dd over the wave
+            float inc = dd;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+            }
+            const float excl = carry + (inc - dd);
+            float w = (1.0f - expf(-dd)) * expf(-excl);
+            if (!(w == w) || !ok) w = 0.f;  // nan_to_num
+            if (out_w && ok) out_w[q] = w;
+            if (rgb) {
+                float c0 = k0[c], c1 = k1[c], c2 = k2[c];
+                if (background.clamp) { c0 = nan_to_num(c0); c1 = nan_to_num(c1); c2 = nan_to_num(c2); }
+                r0 += w * c0; r1 += w * c1; r2 += w * c2;
+            }
+            accw += w;
+            // median depth: first sample whose cumulative weight reaches 0.5
+            float winc = w;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float o = __shfl_up(winc, off);
+                if (lane >= off) winc += o;
+            }
+            const float cum = cw + winc;
+            const uint64_t m = __ballot(ok && cum >= 0.5f);
+            if (!found && m) {
+                const int src = __ffsll((unsigned long long)m) - 1;
+                depth = __shfl(0.5f * (st + en), src);
+                found = true;
+            }
+            carry += __shfl(inc, 63);
+            cw += __shfl(winc, 63);
         }
-        const float cum = cw + winc;
-        const uint64_t m = __ballot(ok && cum >= 0.5f);
-        if (!found && m) {
-            const int src = __ffsll((unsigned long long)m) - 1;
-            depth = __shfl(0.5f * (st + en), src);
-            found = true;
-        }
-        carry += __shfl(inc, 63);
-        cw += __shfl(winc, 63);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

@@ -630,26 +630,30 @@ __global__ __launch_bounds__(64) void k_postprocess_log(TraceParams p, const Wal
 // everything else of the call has been joined.
 __global__ __launch_bounds__(64) void k_verify_counts(TraceParams p, uint32_t stride, uint32_t *__restrict__ walk_n,
                                                       uint32_t *__restrict__ fallback_list, uint32_t *__restrict__ fallback_count,
-                                                      size_t ray_base, uint32_t late, uint32_t inject) {
+                                                      size_t ray_base, uint32_t late, uint32_t inject,
+                                                      const uint32_t *__restrict__ ray_list, const uint32_t *__restrict__ list_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WaveSmem s = carve(smem, p.M);
     const int lane = threadIdx.x;
-    const size_t n_checks = (p.num_items + stride - 1) / stride;
+    // every stride-th ray (the blind sample), or exactly the rays of a list (the walk's risk list: its count lives on the device)
+    const size_t n_checks = ray_list ? (size_t)*list_count : (p.num_items + stride - 1) / stride;
+    const int c_checked = ray_list ? 26 : 4 + 15, c_bad = ray_list ? 27 : 4 + 14;
     for (size_t it = blockIdx.x; it < n_checks; it += gridDim.x) {
-        const size_t ray = it * stride;
+        const size_t ray = ray_list ? (size_t)ray_list[it] : it * stride;
+        if (ray_list && stride && ray % stride == 0) continue;   // the blind sample checks (and counts) this one
         const uint32_t wn = walk_n[ray];
         if (wn == TN_EMPTY) continue;          // literal / fallback ray: not certified, nothing to verify
         bool overflow = false;
         const uint32_t nh = collect_hits(p.bvh, s, p.M, p.M - 1, p.origins[3 * ray], p.origins[3 * ray + 1], p.origins[3 * ray + 2],
                                          p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2], nullptr, lane, overflow);
         if (lane == 0) {
-            if (p.stats) atomicAdd(&p.stats[4 + 15], 1ull);
+            if (p.stats) atomicAdd(&p.stats[c_checked], 1ull);
             // inject (tests): every checked ray is treated as a mismatch, so that the hand-over -- incl. the late form's
             // re-trace of rows the writer and the fills have already written -- is exercised although no real mismatch exists
             if (nh != wn || overflow || inject) {
                 if (!late) walk_n[ray] = TN_EMPTY;   // the segment writer and the fill skip the row: the BVH kernel writes it
                 fallback_list[atomicAdd(fallback_count, 1u)] = (uint32_t)(ray_base + ray);
-                if (p.stats) atomicAdd(&p.stats[4 + 14], 1ull);
+                if (p.stats) atomicAdd(&p.stats[c_bad], 1ull);
             }
         }
         wave_sync();
@@ -780,12 +784,16 @@ void launch_trace_general(const TraceParams &p, hipStream_t stream) {
 }
 
 void launch_verify_counts(const TraceParams &p, uint32_t stride, uint32_t *walk_n, uint32_t *fallback_list, uint32_t *fallback_count,
-                          size_t ray_base, hipStream_t stream, bool late, bool inject) {
-    if (p.num_items == 0 || stride == 0) return;
+                          size_t ray_base, hipStream_t stream, bool late, bool inject, const uint32_t *ray_list,
+                          const uint32_t *list_count, size_t max_list) {
+    if (p.num_items == 0 || (stride == 0 && !ray_list)) return;
     const size_t smem = wave_smem(k_verify_counts, p.M);
-    const size_t n_checks = (p.num_items + stride - 1) / stride, max_blocks = 256 * 16;
+    // (the risk list is short -- a fraction of a per cent of the rays -- but its length is only known on the device: a grid of
+    //  at most 1024 waves strides over it)
+    const size_t n_checks = ray_list ? std::min<size_t>(max_list, 1024) : (p.num_items + stride - 1) / stride, max_blocks = 256 * 16;
+    if (n_checks == 0) return;
     hipLaunchKernelGGL(k_verify_counts, dim3((unsigned)(n_checks < max_blocks ? n_checks : max_blocks)), dim3(64), smem, stream, p, stride,
-                       walk_n, fallback_list, fallback_count, ray_base, late ? 1u : 0u, inject ? 1u : 0u);
+                       walk_n, fallback_list, fallback_count, ray_base, late ? 1u : 0u, inject ? 1u : 0u, ray_list, list_count);
 }
 
 void launch_postprocess_log(const TraceParams &p, const WalkFid *fidt, const uint4 *hit_log, const uint2 *literal_list,

@@ -190,7 +190,17 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     const float delta = 0.21875f * pad;               // 7/32 of the box padding
     const float kappa = 8.0f * delta;
     const uint32_t thin_exp = (__float_as_uint(32.0f * delta) >> 23) & 0xFFu;
-    auto near_edge = [&](float e, const SV &X, const SV &Y) { return fabsf(e) <= kappa * (fabsf(X.x - Y.x) + fabsf(X.y - Y.y)); };
+    // RISK classes of the certification (round 5): the two guards above hand a ray over when it passes
+    // within 8 delta of a hull edge / of an edge of a thin-neighbourhood tet.  What is not proved is that the degenerate
+    // feature always lies THAT close to a tested edge, so the same tests with an 8 times wider band (64 delta) mark a certified
+    // ray as "at risk": every such ray -- not one in 256 -- is re-counted by the BVH cross-check (k_verify_counts).
+    // bit 0: within 8 delta (hand over), bit 1: within 64 delta (verify)
+    const float kappa2 = 8.0f * kappa;
+    auto edge_band = [&](float e, const SV &X, const SV &Y) -> uint32_t {
+        const float len = fabsf(X.x - Y.x) + fabsf(X.y - Y.y), ae = fabsf(e);
+        return (ae <= kappa * len ? 1u : 0u) | (ae <= kappa2 * len ? 2u : 0u);
+    };
+    uint32_t risk = 0;   // bit 0: hull near-miss, bit 1: thin-neighbourhood near-miss
     uint32_t nhull = 0;
     uint32_t hf0 = TN_EMPTY, hf1 = TN_EMPTY, hc0 = 0, hc1 = 0, he0 = 0, he1 = 0, hs0 = 0, hs1 = 0;
     float ht0 = 0.f, ht1 = 0.f;
@@ -205,7 +215,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         // that grazes the hull can have crossed faces in the rounded projection -- a closed cycle around the grazed
         // edge / vertex -- although it crosses no hull face at all (nhull == 0: the walk would certify a miss); round 3's
         // fuzzer found exactly these after rule 8 had removed the interior cycles (profiles/r03g_hole_classify.txt)
-        if (near_edge(U, B, C) || near_edge(V, C, A) || near_edge(W, A, B)) { flag = true; why = why ? why : 2u; }
+        const uint32_t hb = edge_band(U, B, C) | edge_band(V, C, A) | edge_band(W, A, B);
+        if (hb & 1u) { flag = true; why = why ? why : 2u; }
+        risk |= (hb >> 1) & 1u;
         const float T = (U * A.z + V * B.z) + W * C.z;
         const float tt = T / det;
         const bool s0 = !mixed && nhull == 0, s1 = !mixed && nhull == 1;
@@ -272,8 +284,11 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     uint32_t nhits = 0, nshort = 0;
     uint32_t steps = 0;
     Var cur = load_var(p.vars, c);
-    if (alive && ((cur.code_hi >> 8) & 0xFFu) <= thin_exp &&
-        (near_edge(Uc, B, C) || near_edge(Vc, C, A) || near_edge(Wc, A, B))) { flag = true; why = 8; alive = false; }
+    if (alive && ((cur.code_hi >> 8) & 0xFFu) <= thin_exp) {
+        const uint32_t eb0 = edge_band(Uc, B, C) | edge_band(Vc, C, A) | edge_band(Wc, A, B);
+        if (eb0 & 1u) { flag = true; why = 8; alive = false; }
+        risk |= eb0 & 2u;
+    }
     if (alive) {
         // the entry hull face itself may be the first recorded hit (exit code 3 = "hull face id in the low bits")
         float tt, uu, vv;
@@ -294,7 +309,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         // fold guard: a thin neighbourhood and one of the tet's NEW edges (n-a, n-b, n-c; the others were new edges of
         // a tet visited earlier, which carries the same flag when both end points of the edge have thin stars)
         const bool thin = ((cur.code_hi >> 8) & 0xFFu) <= thin_exp;
-        bad = (!bad && thin && (near_edge(ea, P, A) || near_edge(eb, P, B) || near_edge(ec, P, C))) ? 8u : bad;
+        const uint32_t band = edge_band(ea, P, A) | edge_band(eb, P, B) | edge_band(ec, P, C);
+        bad = (!bad && thin && (band & 1u)) ? 8u : bad;
+        risk |= thin ? (band & 2u) : 0u;
         // exit candidates: the faces opposite a {n,b,c}, b {n,c,a}, c {n,a,b}; a face is crossed iff its three
         // cyclic edge functions agree in sign: E(n,b), E(b,c) = Uc, E(c,n) = -ec, and cyclically
         const bool sa = ea > 0.0f, sb = eb > 0.0f, sc = ec > 0.0f;
@@ -383,6 +400,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         } else {
             p.walk_n[ray] = nhits;      // hits in the log (0 for a miss)
             t.out_num[ray] = nseg;
+            if (risk && p.risk_list) {  // certified, but inside the wide band of a guard: cross-checked, every one of them
+                p.risk_list[atomicAdd(p.risk_count, 1u)] = (uint32_t)ray;
+                if (t.stats) atomicAdd(&t.stats[24 + ((risk >> 1) & 1u)], 1ull);   // 24: hull near-miss (only), 25: thin neighbourhood
+            }
         }
     }
 }

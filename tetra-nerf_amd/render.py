@@ -28,7 +28,6 @@ from typing import Dict, Optional
 import torch
 
 FIELD_DIM = 64
-FUSED_PASS_MAX_RAYS = 16384   # TetraRenderer(fused_pass="auto"): one launch per pass up to this many hitting rays
 SYNC_FREE_MIN_HITS = 0.85     # render_train: below this (last known) fraction of hitting rays the batch is compacted instead
 HIDDEN = 128
 DIR_ENC = 27
@@ -387,15 +386,14 @@ class TetraRenderer:
         # the render path only reads the trace rows through num_visited_cells, so the constant tails of the
         # dense reference layout need not be written (non-materialising trace: 52 B per segment, not 52*M per ray)
         self.dense_tails = bool(dense_tails)
-        # match + gather + MLP + composite of a pass as ONE launch (tn_render_pass) when its preconditions hold.
-        # True / False / "auto": measured (profiles/r02j_render_bench.txt) the one-launch pass ties with or beats the
-        # separate match / gather+MLP / composite kernels on nerfstudio-sized batches (4096 rays: launch-bound, and it
-        # moves no per-sample intermediates through HBM) and is 3-4 % slower on 65,536-ray chunks (the match and the
-        # composite then run inside an MFMA-bound kernel at 2 waves per SIMD instead of as cheap, fully parallel kernels
-        # of their own), so "auto" uses it up to FUSED_PASS_MAX_RAYS hitting rays per call.
+        # Everything after the trace as ONE persistent launch (tn_render_rays: samplers + match + gather + MLP + composite of both
+        # passes; round 5) whenever its preconditions hold (fp32 arithmetic, device samplers, the per-wave LDS regions fit:
+        # max_ray_triangles <= 2048).  True / "auto": use it; False: the chain of separate kernels (sampler, matcher, gather + MLP,
+        # composite per pass), which takes the same device-side ray count -- neither form synchronises with the host.  Round 2-4's
+        # per-pass fusion (tn_render_pass) interleaved match / composite with the MFMA layers and lost 4-6 % to the chain on
+        # 65,536-ray chunks; the persistent kernel separates the stages in time inside one launch and runs the chain's own device
+        # functions, so its frame is bit-identical to the chain's.
         self.fused_pass = fused_pass if fused_pass == "auto" else bool(fused_pass)
-        if not (self.S >= 64 and self.M <= 512):
-            self.fused_pass = False
 
     def _trace(self, origins, directions):
         """trace_rays; compact rows (a PER-CALL flag of the op: the tracer may be shared with other threads) unless this
@@ -420,17 +418,85 @@ class TetraRenderer:
             return self.background
         return background if isinstance(background, (int, float)) else tuple(float(x) for x in background_tensor(background).tolist())
 
+    def _one_launch_ok(self, mode):
+        """tn_render_rays' preconditions: fp32 arithmetic, device samplers, max(2 M, 3 S + S_fine + 3) floats of LDS per wave."""
+        region = max(2 * self.M, (3 * self.S + self.S_fine + 3) if self.S_fine else 0)
+        return (self.fused_pass is not False and mode == "fp32" and self.device_samplers and 8 * 4 * region <= 160 * 1024
+                and self.S + self.S_fine + 2 <= 8192)
+
     @torch.no_grad()
     def render(self, origins: torch.Tensor, directions: torch.Tensor, background=None, ray_head_bias=None) -> Dict[str, torch.Tensor]:
         """Evaluation-mode render (model.py:520-662 with `self.training == False`: samplers without jitter, RGB renderer
         with nan_to_num + clamp).  background: per-call override of the renderer's colour (grey level or (r, g, b)).
         ray_head_bias f32 [R, 128] (fused path only): per-ray vector added to mlp_head's pre-activation -- the appearance
-        embedding's share of the head layer, Wh[:, 155:] emb (model.py:608-620), made by the caller."""
+        embedding's share of the head layer, Wh[:, 155:] emb (model.py:608-620), made by the caller.
+        NO HOST SYNCHRONISATION (round 5): the reference compacts the hitting rays with boolean indexing (model.py:540-567),
+        rounds 2-4 with torch.nonzero -- a device -> host round trip per chunk during which the GPU idles.  Here the hitting
+        rays are compacted on the device (tn_compact_hits: their number stays there) and every kernel after the trace takes the
+        address of that count."""
         cpp, S = self.cpp, self.S
         bg = self._bg(background)
         if not self.fused:
+            if ray_head_bias is not None:
+                raise RuntimeError("ray_head_bias is an input of the fused kernels; the PyTorch statement takes the model's own modules")
             return render_reference(self.tracer, cpp.interpolate_values, self.field, self.mlp, origins, directions,
                                     S, self.M, self.far_plane, self.S_fine, self.biased, background=bg)
+        if not self.device_samplers:
+            return self._render_host_compaction(origins, directions, bg, ray_head_bias)
+        out = self._trace(origins, directions)
+        nv = out["num_visited_cells"]
+        ray_mask = nv > 0
+        R, dev = origins.shape[0], origins.device
+        rgb = self._background_rows(R, bg, dev)
+        acc = torch.zeros((R, 1), dtype=torch.float32, device=dev)
+        depth = torch.full((R, 1), self.far_plane, dtype=torch.float32, device=dev)
+        res = {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
+        if R == 0:
+            return res
+        # the 26 KB trace rows of the hitting rays are NOT compacted (model.py:546-567 copies them with boolean indexing):
+        # samplers, matcher and composite read them in place through the ray index
+        lists = [out[k] for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates", "hit_distances",
+                                  "vertex_indices")]
+        order, count = cpp.compact_hits(nv)          # hitting rays first, in ray order; their number stays on the device
+        w = mlp_weights(self.mlp)
+        mode = self.mlp_mode
+        d = directions.contiguous()
+        if self._one_launch_ok(mode):
+            cpp.render_rays(lists, order, count, self.field, d, w, S, self.S_fine, self.biased, out=(rgb, acc, depth), background=bg,
+                            clamp=True, ray_head_bias=ray_head_bias)
+            return res
+        # the chain of separate kernels: each is launched over R rows and processes the first `count` of them
+        order_l = order.long()
+        dirs_o = d.index_select(0, order_l)
+        hb = None if ray_head_bias is None else ray_head_bias.index_select(0, order_l).contiguous()
+
+        def locate(edges):
+            dist = ((edges[:, 1:] + edges[:, :-1]) / 2).contiguous()
+            return self.tracer.find_visited_cells(*lists, dist, ray_index=order, count=count)
+
+        edges, near_far = cpp.sample_coarse(lists[0], lists[3], order, S, biased=self.biased, count=count)
+        traced = locate(edges)
+        if self.S_fine > 0:
+            # coarse pass: gather + mlp_base + density head in one kernel, weights in one more
+            sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
+                                             None, w, S, mode=mode, count=count)
+            weights_c = cpp.composite(sigma_c.view(-1, S), None, edges, count=count)
+            edges = cpp.sample_pdf(edges, weights_c, near_far, self.S_fine, count=count)
+            traced = locate(edges)
+            S = edges.shape[1] - 1
+        # gather + MLP + heads in one kernel (no [64, n] feature buffer)
+        sigma, col = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
+                                            dirs_o, w, S, mode=mode, ray_head_bias=hb, count=count)
+        cpp.composite(sigma.view(-1, S), col.view(-1, S, 3), edges, background=bg, clamp=True, out=(rgb, acc, depth), ray_index=order,
+                      count=count)
+        return res
+
+    @torch.no_grad()
+    def _render_host_compaction(self, origins, directions, bg, ray_head_bias=None):
+        """render() with the PyTorch SAMPLER statements (device_samplers=False: the parity definition of tn_sample_coarse /
+        tn_sample_pdf, ~15 small operators per pass) between the HIP kernels.  Sizes its work on the host (torch.nonzero), as
+        the reference does; not the production path."""
+        cpp, S = self.cpp, self.S
         out = self._trace(origins, directions)
         nv = out["num_visited_cells"]
         ray_mask = nv > 0
@@ -441,8 +507,6 @@ class TetraRenderer:
         idx = torch.nonzero(ray_mask)[:, 0]
         mode = self.mlp_mode
         if idx.numel():
-            # the 26 KB trace rows of the hitting rays are NOT compacted (model.py:546-567 copies them with boolean
-            # indexing): samplers, find_visited_cells and the render pass read them in place through the ray index
             lists = [out[k] for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates", "hit_distances",
                                       "vertex_indices")]
             ridx = idx.to(torch.int32)
@@ -453,44 +517,22 @@ class TetraRenderer:
                 dist = ((edges[:, 1:] + edges[:, :-1]) / 2).contiguous()
                 return self.tracer.find_visited_cells(*lists, dist, ray_index=ridx)
 
-            if self.device_samplers:
-                edges, near_far = cpp.sample_coarse(lists[0], lists[3], ridx, S, biased=self.biased)
-                near_r, far_r = near_far[:, 0:1], near_far[:, 1:2]
+            # (rows of empty rays are unwritten without dense tails: nears / fars only of the hitting rays)
+            near_r = out["hit_distances"][idx, 0, 0][:, None]
+            far_r = out["hit_distances"][idx, (nv[idx].long() - 1), 1][:, None]
+            if self.biased:
+                edges = biased_sample_bins(near_r, far_r, S, lists[0][idx], lists[3][idx]).contiguous()
             else:
-                # (rows of empty rays are unwritten without dense tails: nears / fars only of the hitting rays)
-                near_r = out["hit_distances"][idx, 0, 0][:, None]
-                far_r = out["hit_distances"][idx, (nv[idx].long() - 1), 1][:, None]
-                near_far = torch.cat([near_r, far_r], 1).contiguous()
-                if self.biased:
-                    edges = biased_sample_bins(near_r, far_r, S, lists[0][idx], lists[3][idx]).contiguous()
-                else:
-                    edges = uniform_sample_bins(near_r, far_r, S).contiguous()
-
-            def fine_edges(edges, weights_c):
-                if self.device_samplers:
-                    return cpp.sample_pdf(edges, weights_c, near_far, self.S_fine)
-                spacing = (edges - near_r) / (far_r - near_r)
-                return pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r).contiguous()
-
-            if (self.fused_pass is True or (self.fused_pass == "auto" and idx.numel() <= FUSED_PASS_MAX_RAYS)) and mode == "fp32":
-                # every pass is ONE launch: match + gather + MLP + composite (tn_render.hip); per sample only the coarse
-                # weights go through HBM; the finished rays are written straight into the frame buffers
-                if self.S_fine > 0:
-                    weights_c = cpp.render_pass(lists, ridx, edges, self.field, None, w)
-                    edges = fine_edges(edges, weights_c)
-                cpp.render_pass(lists, ridx, edges, self.field, directions[idx].contiguous(), w, out=(rgb, acc, depth),
-                                background=bg, clamp=True, ray_head_bias=hb)
-                return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
+                edges = uniform_sample_bins(near_r, far_r, S).contiguous()
             traced = locate(edges)
             if self.S_fine > 0:
-                # coarse pass: gather + mlp_base + density head in one kernel, weights in one more
                 sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
                                                  None, w, S, mode=mode)
                 weights_c = cpp.composite(sigma_c.view(-1, S), None, edges)
-                edges = fine_edges(edges, weights_c)
+                spacing = (edges - near_r) / (far_r - near_r)
+                edges = pdf_sample_bins(spacing, weights_c, self.S_fine, near_r, far_r).contiguous()
                 traced = locate(edges)
                 S = edges.shape[1] - 1
-            # gather + MLP + heads in one kernel (no [64, n] feature buffer)
             sigma, col = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], self.field,
                                                 directions[idx].contiguous(), w, S, mode=mode, ray_head_bias=hb)
             rgb_r, acc_r, depth_r = cpp.composite(sigma.view(-1, S), col.view(-1, S, 3), edges, background=bg, clamp=True)
@@ -526,7 +568,9 @@ class TetraRenderer:
         # parity tests) the stratified draws are the reference's, element for element; with misses they are the first
         # `count` rows of an [R, S+1] draw instead of an [r, S+1] draw -- the same distribution, another stream.
         sync_free = self.sync_free_train and fused and self.device_samplers and capture is None and not rand and R > 0
-        if sync_free and self._hits_event is not None and self._hits_event.query():
+        if self._hits_event is not None and self._hits_event.query():
+            # (whenever the copy has landed, whatever form THIS call takes: a renderer that alternates between forms must not
+            #  decide on a stale fraction)
             self._hit_fraction = float(self._hits_pinned[0]) / max(float(self._hits_pinned[1]), 1.0)   # of an EARLIER batch
         sync_free = sync_free and self._hit_fraction >= self.sync_free_min_hits
         with torch.no_grad():
@@ -543,9 +587,12 @@ class TetraRenderer:
                     self._hits_pinned.copy_(stats, non_blocking=True)
                     self._hits_event.record(torch.cuda.current_stream(dev))
             if sync_free:
-                order = torch.argsort((~ray_mask).to(torch.uint8), stable=True)
-                valid = torch.arange(R, device=dev) < ray_mask.sum()
-                idx = torch.where(valid, order, order[:1])
+                # ONE small kernel pair (tn_compact_hits) instead of a stable argsort of the miss flag (13 rocprim launches) +
+                # where: order = the hitting rays in ray order, then the others; padded = order with the tail naming order[0]
+                order32, count, padded = self.cpp.compact_hits(nv, want_padded=True)
+                order = order32.long()
+                valid = torch.arange(R, device=dev) < count     # (count is a one-element device tensor: no read-back)
+                idx = padded.long()
             else:
                 idx = torch.nonzero(ray_mask)[:, 0]
         bg = self._bg(background)

@@ -258,6 +258,15 @@ class TetrahedraTracer:
     def set_option(self, name: str, value: int):
         _lib.check(self._lib.tn_set_option(self._h, name.encode(), int(value)))
 
+    def cross_check(self):
+        """The cross-check of the walk's certification in the last trace_rays call (tn_trace_cross_check): the blind sample
+        (every stride-th certified ray) and the risk classes (EVERY certified ray inside the wide band of a guard)."""
+        arr = (C.c_uint64 * 8)()
+        _lib.check(self._lib.tn_trace_cross_check(self._h, C.byref(arr)))
+        return {"stride": int(arr[0]), "checked": int(arr[1]), "mismatches": int(arr[2]),
+                "risk": {"hull_near_miss_rays": int(arr[3]), "thin_neighbourhood_rays": int(arr[4]), "checked": int(arr[5]),
+                         "mismatches": int(arr[6])}}
+
     TIMING_KEYS = ("speculative_fill", "walk", "bvh_fallback", "cross_check", "segment_writer", "literal_pairing", "tail_fill",
                    "cross_check_retrace")
 
@@ -703,6 +712,39 @@ def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, b
     return w_out
 
 
+def render_rays(trace_lists, order, count, field, directions, weights, num_samples, num_fine=0, biased=False, out=None,
+                background=1.0, clamp=True, ray_head_bias=None, histogram_padding=0.01, eps=1e-5):
+    """Everything between trace_rays and the frame as ONE persistent launch (tn_render_rays): coarse sampler -> match -> gather
+    + MLP -> weights -> PDF sampler -> match -> gather + MLP + heads -> composite, for the hitting rays order[:count] (compact_hits)
+    whose number stays on the device.  trace_lists as returned by trace_rays; directions f32 [R,3] and ray_head_bias f32 [R,128]
+    over ALL rays; out = (rgb [R,3], accumulation [R,1] or [R], depth) pre-filled with the background values."""
+    nv, _cells, bary, dist, verts = trace_lists
+    for x, name in ((nv, "num_visited_cells"), (bary, "barycentric_coordinates"), (dist, "hit_distances"), (verts, "vertex_indices"),
+                    (order, "order"), (field, "field"), (directions, "directions")):
+        _check_input(x, name)
+    R, M = dist.size(0), dist.size(1)
+    _check(order.dtype == torch.int32 and order.dim() == 1 and order.numel() <= R, "order must be i32 [<= R]")
+    _check(count is None or (count.dtype == torch.int32 and count.numel() >= 1 and count.is_cuda), "count must be an i32 device tensor")
+    _check(directions.dtype == torch.float32 and tuple(directions.shape) == (R, 3), "directions must be f32 [R, 3]")
+    _check(field.dtype == torch.float32 and field.dim() == 2 and field.size(0) == 64, "field must be f32 [64, V]")
+    S, Sf = int(num_samples), int(num_fine)
+    m = fused_mlp(weights)
+    dev = field.device
+    field_vm = field_vertex_major(field)
+    rgb, acc, depth = out
+    for x, name in ((rgb, "rgb"), (acc, "accumulation"), (depth, "depth")):
+        _check_input(x, name)
+        _check(x.dtype == torch.float32 and x.size(0) == R, f"{name} must be f32 over all rays")
+    hb = None
+    if ray_head_bias is not None:
+        hb = _ray_bias(ray_head_bias, R, dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tn_render_rays(
+            m.handle, M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(order), _ptr(count), order.numel(), S, Sf, 1 if biased else 0,
+            _ptr(_linspace_table(S, dev)), _ptr(_quantile_table(Sf + 1, True, dev)) if Sf else None, float(histogram_padding), float(eps),
+            _ptr(field_vm), _ptr(directions), _background(background, clamp), _ptr(rgb), _ptr(acc), _ptr(depth), _ptr(hb), _stream(dev)))
+
+
 _TABLES = {}    # (kind, n, device) -> small constant tables of the samplers (the values the PyTorch statements use)
 
 
@@ -819,7 +861,7 @@ def composite(sigma, rgb, edges, background=1.0, return_weights=False, clamp=Fal
     weights = _empty((R, S), dtype=torch.float32, device=dev) if return_weights else None
     with torch.cuda.device(dev):
         _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), _ptr(rgb), _ptr(edges), _background(background, clamp), _ptr(out_rgb),
-                                            _ptr(acc), _ptr(depth), _ptr(weights), _stream(dev)))
+                                            _ptr(acc), _ptr(depth), _ptr(weights), None, _ptr(count), _stream(dev)))
     return (out_rgb, acc, depth, weights) if return_weights else (out_rgb, acc, depth)
 
 
