@@ -707,8 +707,8 @@ def main():
             "box_write_ceiling_GBps_per_rank": per_rank_ceiling,
             "trace_path_stats": stats,
             "walk_hand_over_reasons": reasons,
-            # the always-on sampled cross-check of the walk's certification (count-only BVH traversal of every 256th ray,
-            # beside the writer and the fill): `mismatches` must be 0
+            # the always-on cross-check of the walk's certification (count-only BVH traversal beside the writer and the fill) of
+            # every certified ray of the risk classes + a blind sample of 1 in `stride`: all `mismatches` must be 0
             "certification_cross_check": xcheck,
             "load_tetrahedra_s": load_s,
         }

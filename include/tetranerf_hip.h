@@ -226,7 +226,7 @@ int tn_trace_flag_reasons(tn_tracer_t tracer, uint64_t reasons[16]);
 /* The cross-check of the walk's certification in the last tn_trace_rays (host values; forces a stream sync).  Two populations of
  * CERTIFIED rays are re-counted by a count-only BVH all-hits traversal (a differing count re-traces the ray through the BVH path):
  *   the blind sample   every verify_stride-th ray:                      out[0] = stride, out[1] = checked, out[2] = mismatches
- *   the risk classes   EVERY ray inside the wide band (64 rounding distances; the guards that hand a ray over act at 8) of
+ *   the risk classes   EVERY ray inside the wide band (16 rounding distances by default; the guards that hand a ray over act at 8) of
  *                      a hull edge (out[3] = rays of that class) or of an edge of a thin-neighbourhood tet (out[4]):
  *                      out[5] = checked (those not already in the blind sample), out[6] = mismatches
  * See csrc/tn_trace_walk.hip (edge_band) and DESIGN.md section 2.  Option "verify_risk" = 0 switches the risk classes off. */
@@ -271,15 +271,17 @@ int tn_fill_rows(size_t num_rays, uint32_t max_ray_triangles, uint32_t first_slo
  *             path tests 64 / leaf_width crossed leaves per wave instruction
  *   "small_lds"  1 (default) = batches below walk_min_rays use LDS hit arrays sized for the mesh (every ray resident at
  *             once) and re-trace the rays with more hits in a second launch; "lds_cap" forces their size (tests)
- *   "verify_stride"  k > 0 (default 256): every k-th ray the walk certified is cross-checked: a count-only BVH all-hits
+ *   "verify_stride"  k > 0 (default 1024; 256 until round 5, when the risk classes below took over most of the work): every k-th ray
+ *             the walk certified is cross-checked: a count-only BVH all-hits
  *             traversal must find exactly the faces the walk logged, otherwise the ray is re-traced through the BVH path and
  *             counted in tn_trace_flag_reasons()[14].  A one-chunk call runs the check beside the row writers (< 1 % of the
- *             call at 256; linear in the rays checked: tests and the fuzzer run it at 1); 0 = off.
+ *             call; linear in the rays checked: tests and the fuzzer run it at 1); 0 = off.
  *             "verify_inject" 1 = every checked ray counts as a mismatch (tests of the hand-over)
  *   "literal_sort_passes"  (default 8) odd-even transposition passes over the nearly sorted hits the walk logged for a ray
  *             whose order it does not certify, before the bitonic network takes over (same result: distinct keys; tests run 0 and 1)
  *   "verify_risk"  1 (default) = every certified ray of the RISK classes is cross-checked as well (tn_trace_cross_check); 0 = only
- *             the blind sample
+ *             the blind sample.  "risk_band" (default 2) = width of the classes' band in units of the guards' own 8 rounding
+ *             distances (2: rays between 8 and 16; measured cost in DESIGN.md section 2)
  *   "timing"  1 = serialise the kernels of a one-chunk walk call on the caller's stream with timing events (tn_trace_timings);
  *             0 (default) = the overlapped four-stream schedule
  *   "writer_table"  0 (default) = the segment writer's record table by mesh size (one record per (tet, entry face) below

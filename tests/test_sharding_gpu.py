@@ -43,9 +43,24 @@ def test_nccl_one_rank_sharded_render(tn, device, scenes):
             assert torch.allclose(full[k], ref[k], rtol=0, atol=0, equal_nan=True), k
         assert torch.equal(full["ray_mask"], ref["ray_mask"])
         assert int(ref["ray_mask"].sum()) > 5000 and tm["all_gather"] > 0
-        # the bench's reductions and the raw collective on device tensors
-        assert sh.max_over_ranks(1.5, device=device) == 1.5
-        assert sh.sum_over_ranks([2.0, 3.0], device=device) == [2.0, 3.0]
+        # the bench's reductions and the raw collective on device tensors: since round 5 a one-rank group runs the RCCL
+        # all-reduce / all-gather too (the non-staging branch of sharding._all_reduce / _all_gather_into)
+        calls = []
+        real_ar, real_ag = dist.all_reduce, dist.all_gather_into_tensor
+        dist.all_reduce = lambda t, *a, **k: (calls.append(("all_reduce", t.is_cuda)), real_ar(t, *a, **k))[1]
+        dist.all_gather_into_tensor = lambda o_, i_, *a, **k: (calls.append(("all_gather", i_.is_cuda)), real_ag(o_, i_, *a, **k))[1]
+        try:
+            assert sh.max_over_ranks(1.5, device=device) == 1.5
+            assert sh.sum_over_ranks([2.0, 3.0], device=device) == [2.0, 3.0]
+            assert sh.gather_scalars(4.25, device=device) == [4.25]
+            # dealt tiles with a short last tile (R not a multiple of the tile): deal -> all-gather -> un-deal on device rows
+            rows = torch.arange(10000 * 6, dtype=torch.float32, device=device).view(10000, 6)
+            mine = sh.deal_tiles(10000, 0, 1, 4096).to(device)
+            back = sh.all_gather_dealt(rows.index_select(0, mine), 10000, tile=4096)
+            assert torch.equal(back, rows)
+        finally:
+            dist.all_reduce, dist.all_gather_into_tensor = real_ar, real_ag
+        assert calls == [("all_reduce", True), ("all_reduce", True), ("all_gather", True), ("all_gather", True)], calls
         # the reference's training collective on the real backend: the fused autograd nodes under DistributedDataParallel
         # over RCCL (one rank: the all-reduce still runs as an RCCL kernel on the bucketed gradients; two ranks over gloo:
         # tests/test_multirank_gpu.py) -- gradients equal the un-wrapped module's, bit for bit for the weight tensors

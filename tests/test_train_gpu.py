@@ -150,8 +150,112 @@ def test_render_train_fused_equals_autograd_statement(tn, device, scenes):
             # the field gradient of this loss), hence the absolute alternative
             # (round 4, profiles/r04b_grad_diag.txt: float32 autograd itself is 1.0e-4 off for w1 and 5e-4 for wh on some
             # mesh / draw combinations -- a ReLU pre-activation within rounding of 0 takes the other branch than in float64 --
-            # while on others it is 5e-7; the fused path flips different samples, so the absolute alternative is 3e-4)
+            # while on others it is 5e-7; the fused path flips different samples, so the absolute alternative is 3e-4.
+            # Round 5 SHOWS it: test_training_gradients_match_float64_under_the_saved_relu_masks below compares under the
+            # masks the fused forward saved -- every tensor within 5e-6 there, 1-5 flipped bits where this comparison is off)
             assert ours < max(5.0 * torch32, 2e-3 if name == "field" else 3e-4), ((S, S_fine, biased), name, ours, torch32, errs)
+
+
+def _decode_relu_masks(masks, n):
+    """[4, n, 2] int64 as saved by tn_mlp_forward_gather_train -> bool [4, n, 128] in nn.Linear feature order: bit j of word
+    (layer, sample, half h) = accumulator slot j = feature 32 (j >> 4) + (j & 3) + 8 ((j & 15) >> 2) + 4 h (tn_mlp_common.h)."""
+    import torch
+
+    j = torch.arange(64, device=masks.device)
+    bits = ((masks[..., None] >> j) & 1).bool()
+    out = torch.empty(4, n, 128, dtype=torch.bool, device=masks.device)
+    for h in range(2):
+        out[:, :, 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * h] = bits[:, :, h, :]
+    return out
+
+
+@pytest.mark.parametrize("mesh_seed", [5, 6])
+def test_training_gradients_match_float64_under_the_saved_relu_masks(tn, device, scenes, mesh_seed):
+    """WHY the gradients of the tensors upstream of a hidden layer can sit 1e-4 .. 1e-3 (of the largest entry) away from float64
+    autograd while the kernels are exact to 1e-7: a handful of ReLU units (1-5 of 3-4 million) whose pre-activation rounds to the
+    other side of 0 in fp32 than in float64 -- float32 autograd flips as many, not always the same ones.  Shown, not asserted
+    (profiles/r05e_grad_masks.txt): the float64 statement evaluated WITH THE MASKS THE FUSED FORWARD SAVED
+    (read back from tn_mlp_forward_gather_train's buffer), on the same sample placement and upstream gradients, leaves only the
+    arithmetic of k_mlp_backward / k_dw_gemm / k_interp_bwd -- and there the fused gradients are within 5e-6 on EVERY tensor incl.
+    the field (measured: <= 2.3e-7 field, <= 1.4e-6 wh, at or below float32 autograd under the same masks), for all four
+    configurations of the round-4 diagnostic on both mesh seeds.  The number of flipped bits is reported and bounded; a deviation
+    from the unmasked float64 gradient beyond 1e-5 may only occur where bits flipped."""
+    import torch
+
+    render = importlib.import_module("tetra-nerf_amd.render")
+    cpp = tn.cpp
+    pts, cells = scenes.random_mesh(4000, mesh_seed)
+    tr = tn.TetrahedraTracer(device)
+    tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+    o, d = scenes.outside_in_rays(512, 6)
+    to, td = torch.from_numpy(o).to(device), torch.from_numpy(d).to(device)
+    torch.manual_seed(123)
+    target = torch.rand(len(o), 3, device=device)
+    names = ["field", "w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd", "wh", "bh", "wr", "br"]
+
+    def statement(mlp, field, vi, bc, dirs, S, masks, dtype):
+        m = render.TetraMLP().to(device).to(dtype)
+        m.load_state_dict({k: v.to(dtype) for k, v in mlp.state_dict().items()})
+        f = field.detach().to(dtype).requires_grad_(True)
+        b = bc.to(dtype)
+        wts = torch.cat([1 - b.sum(-1, keepdim=True), b], -1)
+        wts = torch.where(vi < 0, torch.zeros_like(wts), wts)
+        x = (f.t()[vi.long().clamp_min(0)] * wts[..., None]).sum(-2)
+        natural = []
+        for l, lin in enumerate(m.base):
+            pre = lin(x)
+            natural.append(pre > 0)
+            x = pre * (masks[l] if masks is not None else natural[-1]).to(dtype)
+        sigma = torch.nn.functional.softplus(m.density(x))[..., 0]
+        enc = render.direction_encoding(dirs.to(dtype))[:, None, :].expand(-1, S, -1).reshape(-1, 27)
+        pre = m.head(torch.cat([enc, x], -1))
+        natural.append(pre > 0)
+        rgb = torch.sigmoid(m.rgb(pre * (masks[3] if masks is not None else natural[-1]).to(dtype)))
+        return sigma, rgb, [f] + render.mlp_weights(m), torch.stack(natural)
+
+    for S, S_fine, biased, scaling in ((24, 24, True, True), (24, 24, True, False), (24, 24, False, True), (32, 32, False, False)):
+        torch.manual_seed(0)
+        mlp = render.TetraMLP().to(device)
+        field = ((torch.rand(64, len(pts), device=device) * 2 - 1) * 0.5)
+        rd = render.TetraRenderer(tr, field, mlp, S, 256, fused=True, num_fine_samples=S_fine, biased=biased)
+        hit = int((tr.trace_rays(to, td, 256)["num_visited_cells"] > 0).sum())
+        rand = {"coarse": torch.rand(hit, S + 1, device=device), "fine": torch.rand(hit, S_fine + 1, device=device)}
+        cap = {}
+        with torch.no_grad():
+            rd.render_train(to, td, gradient_scaling=scaling, rand=rand, fused=True, capture=cap)
+        vi, bc, edges, S2, dirs = cap["vertex_indices"], cap["barycentric_coordinates"], cap["edges"], cap["samples_per_ray"], cap["dirs"]
+        n = vi.numel() // 4
+        w = [x.detach() for x in render.mlp_weights(mlp)]
+        sigma, rgb, saved = cpp.mlp_forward_gather_train(vi, bc, field, dirs, w, S2)
+        masks = _decode_relu_masks(saved.masks.clone(), n)
+        # upstream gradients: the float64 composite + loss at the fused forward's outputs
+        dt = torch.float64
+        sg = sigma.detach().to(dt).view(-1, S2, 1).requires_grad_(True)
+        cl = rgb.detach().to(dt).view(-1, S2, 3).requires_grad_(True)
+        e64, sg2, cl2 = edges.to(dt), sg, cl
+        if scaling:
+            spacing = (e64 - cap["near"].to(dt)) / (cap["far"].to(dt) - cap["near"].to(dt))
+            cl2, sg2, _ = render.GradientScaler.apply(cl, sg, (spacing[:, 1:] + spacing[:, :-1])[..., None])
+        rgb_r, acc_r, _, _ = render.composite(sg2, cl2, e64[:, :-1, None], e64[:, 1:, None])
+        full_rgb = torch.ones(len(o), 3, dtype=dt, device=device).index_copy(0, cap["idx"], rgb_r)
+        full_acc = torch.zeros(len(o), 1, dtype=dt, device=device).index_copy(0, cap["idx"], acc_r)
+        (((full_rgb - target.to(dt)) ** 2).mean() + 0.1 * full_acc.mean()).backward()
+        d_sigma, d_rgb = sg.grad.reshape(-1), cl.grad.reshape(-1, 3)
+        gf, gw = cpp.mlp_backward(saved, vi, bc, field, dirs, w, sigma, rgb, d_sigma.float().contiguous(), d_rgb.float().contiguous())
+        fused = [gf] + list(gw)
+        res = {}
+        for label, dtype, mk in (("f64 masked", torch.float64, masks), ("f32 masked", torch.float32, masks), ("f64 own", torch.float64, None)):
+            s_, c_, leaves, natural = statement(mlp, field, vi.reshape(n, 4), bc.reshape(n, 3), dirs, S2, mk, dtype)
+            ((s_ * d_sigma.to(dtype)).sum() + (c_ * d_rgb.to(dtype)).sum()).backward()
+            res[label] = ([x.grad for x in leaves], natural)
+        flipped = (masks != res["f64 own"][1]).sum(dim=(1, 2)).tolist()
+        print(f"mesh seed {mesh_seed} config {(S, S_fine, biased, scaling)}: {n} samples, flipped ReLU bits per layer (of {n * 128}): {flipped}")
+        assert max(flipped) <= 32, flipped                      # a handful of 3-4 million
+        for k, name in enumerate(names):
+            ours, t32 = _rel(fused[k], res["f64 masked"][0][k]), _rel(res["f32 masked"][0][k], res["f64 masked"][0][k])
+            assert ours < max(5.0 * t32, 5e-6), ((S, S_fine, biased, scaling), name, ours, t32)
+            unmasked = _rel(fused[k], res["f64 own"][0][k])
+            assert unmasked < 1e-5 or sum(flipped) > 0, ((S, S_fine, biased, scaling), name, unmasked, flipped)
 
 
 def test_render_train_in_several_autograd_nodes(tn, device, scenes):

@@ -297,9 +297,9 @@ def test_cross_check_hand_over_paths(tn, device, scenes):
 
 
 def test_risk_classes_of_the_certification_are_cross_checked(tn, device, scenes):
-    """Round 5: a certified ray inside the WIDE band (64 rounding distances) of a guard that hands rays over at 8 -- a hull edge,
+    """Round 5: a certified ray inside the WIDE band (16 rounding distances) of a guard that hands rays over at 8 -- a hull edge,
     an edge of a thin-neighbourhood tet -- is re-counted by the BVH cross-check, every one of them (the blind sample takes one
-    ray in 256).  On meshes with thin tets and with rays aimed at vertices the classes are populated; the check runs on all
+    ray in 1024).  On meshes with thin tets and with rays aimed at vertices the classes are populated; the check runs on all
     their rays, finds no mismatch, changes no output; option verify_risk = 0 switches it off; the chunked schedule does the same."""
     import torch
 

@@ -51,12 +51,16 @@ struct tn_tracer {
     bool small_lds = true;               // small batches: LDS hit arrays sized for the mesh, overflow rays in a second launch
     unsigned lds_cap = 0;                // 0: from the mesh size; otherwise the entries of the small arrays (power of two; tests)
     bool dense_tails = true;             // false: slots >= num_visited stay unwritten on walked rows (non-reference, compact use)
-    // every stride-th certified ray is cross-checked against a count-only BVH all-hits traversal (0: off).  On by default:
-    // the walk's certification has an unproved residue, and a one-chunk call runs the check on the aux
-    // stream beside the writer and the fill.  Measured (profiles/r04c_verify_ab.txt, interleaved in one process): stride 64
-    // costs +0.9 / +2.9 / +3.7 % on the C2 / C4 frame / the C5 rays, stride 16 +6 / +13 / +21 % -- linear in the rays
-    // checked -- so the default is 256: +0.2 / +0.7 / +0.9 %
-    unsigned verify_stride = 256;
+    // The walk's certification has an unproved residue, so certified rays are cross-checked against a
+    // count-only BVH all-hits traversal, on the aux stream beside the writer and the fill (one-chunk calls).  Two populations:
+    //   * the RISK classes (round 5): every certified ray inside the wide band of a guard (walk: edge_band; option "risk_band" = 2:
+    //     between 8 and 16 rounding distances of a hull edge / of an edge of a thin-neighbourhood tet) -- 0.3-0.5 % of the rays;
+    //   * a blind sample: every verify_stride-th certified ray.
+    // Measured interleaved in one process (profiles/r05e_risk_sweep.txt; C2 frame / C4 frame / C5 rays): round 4's blind sample
+    // of 1 in 256 cost +0.8 / +0.9 / +0.0 % over no check at all; the risk classes at band 2 + a blind 1 in 1024 cost the same
+    // (+0.8 / +1.3 / -0.0 %) while checking EVERY ray of the classes (1,850 / 2,705 / 5,176 rays) and 618 / 609 / 924 blind ones;
+    // band 4 costs +1.1 / +5.3 / +4.1 %, band 8 +5.5 / +13 / +15 % (three to seven times as many rays).  Hence 1024 and 2.
+    unsigned verify_stride = 1024;
     unsigned literal_sort_passes = 8;    // odd-even passes over a literal ray's logged hits before the bitonic network (tests: 0, 1)
     bool verify_inject = false;          // tests: every cross-checked ray is treated as a mismatch (exercises the hand-over)
     tn::DevBuf<uint32_t> verify_list;    // certified rays whose count differed: re-traced by the BVH kernel at the end of the call
@@ -78,6 +82,7 @@ struct tn_tracer {
     uint32_t *risk_count() { return reinterpret_cast<uint32_t *>(stats.p + N_STATS) + 3; }
     tn::DevBuf<uint32_t> risk_list;      // certified rays inside the wide band of a certification guard (all cross-checked)
     bool verify_risk = true;             // option "verify_risk"
+    unsigned risk_band = 2;              // option "risk_band": width of the risk classes' band, in units of the guards' 8 delta
     size_t last_num_rays = 0;
     int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
     size_t walk_min_rays = 12288;        // measured crossover on the 300k-tet mesh after round 2b's faster BVH path
@@ -457,6 +462,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 w.ray_base = base;
                 w.risk_list = verify_risk ? t->risk_list.p : nullptr;
                 w.risk_count = t->risk_count();
+                w.risk_band = (float)t->risk_band;
                 tn::launch_trace_walk(w, stream, walk_reserve);
                 if (t->verify_stride && !single) {  // chunked call: serially, before anything that reads walk_n / the fallback list
                     tn::launch_verify_counts(w.t, t->verify_stride, w.walk_n, w.fallback_list, w.fallback_count, base, stream, false,
@@ -813,6 +819,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (k == "literal_sort_passes") t->literal_sort_passes = value < 0 ? 0u : (unsigned)value;
         else if (k == "verify_stride") t->verify_stride = value < 0 ? 0u : (unsigned)value;
         else if (k == "verify_risk") t->verify_risk = value != 0;
+        else if (k == "risk_band") t->risk_band = value < 1 ? 1u : (unsigned)value;
         else if (k == "log_cap_mb") t->log_cap_bytes = value <= 0 ? 0 : (size_t)value << 20;
         else throw tn::Error("unknown option " + (name ? k : std::string("(null)")));
     });

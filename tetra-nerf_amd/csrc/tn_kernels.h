@@ -60,6 +60,7 @@ struct WalkParams {
     size_t ray_base;           // global index of item 0 (rays are traced in chunks when the log would be too large)
     uint32_t *risk_list;       // [num_items] certified rays inside the WIDE band (64 delta) of a certification guard: every one of
     uint32_t *risk_count;      // [1]          them is cross-checked (k_verify_counts); null: not collected
+    float risk_band;           // width of that band in units of the guards' own 8 delta (tn option "risk_band")
 };
 // lds_reserve: bytes of (unused) dynamic LDS per block = an occupancy limit (160 KB / lds_reserve blocks per CU), 0 = none
 void launch_trace_walk(const WalkParams &p, hipStream_t stream, size_t lds_reserve = 0);
@@ -210,7 +211,7 @@ void launch_render_pass(const uint32_t *num_visited, const float *dist, const fl
 // MLP (density) -> weights -> PDF sampler -> match -> gather + MLP + heads -> composite, scattered into out_* (arrays over ALL rays)
 // at the hitting rays ray_index[0 .. *count) (count null: r_max); S_fine = 0: one pass.  dirs [R_all, 3], ray_bias [R_all, 128] or
 // null are indexed by ray.  scratch: render_rays_scratch_floats(...) floats, laid out by the RenderRaysLayout it fills.
-struct RenderRaysLayout { uint32_t T; size_t per_block, o_nf, o_wc, o_edges_f, o_enc, o_bias, o_vi, o_bc, o_sigma, o_rgb; };
+struct RenderRaysLayout { uint32_t T; size_t per_block, o_edges_f, o_enc, o_bias, o_vi, o_bc, o_sigma, o_rgb; };
 size_t render_rays_scratch_floats(size_t r_max, uint32_t S, uint32_t S_fine, bool has_bias, unsigned grid, RenderRaysLayout &L);
 void launch_render_rays(const uint32_t *num_visited, const float *dist, const float *bary, const uint32_t *verts, uint32_t M,
                         const uint32_t *ray_index, const uint32_t *count, size_t r_max, uint32_t S, uint32_t S_fine, bool biased,

@@ -127,7 +127,9 @@ __global__ __launch_bounds__(64) void k_composite(size_t R, uint32_t S, const fl
     if (count) R = *count;
     for (size_t ray = blockIdx.x; ray < R; ray += gridDim.x) {
         const size_t dst = ray_index ? (size_t)ray_index[ray] : ray;   // (scatter into the frame buffers of all rays)
-        rayops::ray_composite(S, sigma + ray * S, rgb ? rgb + 3 * ray * S : nullptr, edges + ray * (S + 1), background,
+        // (one chunk at a time: 39 registers, 8 waves per SIMD hide the scans' latency here; the persistent render kernel, 8 waves
+        //  per CU, interleaves up to 9 chunks -- same bits for any grouping, tn_ray_ops.h)
+        rayops::ray_composite_chunks<1>(S, sigma + ray * S, rgb ? rgb + 3 * ray * S : nullptr, edges + ray * (S + 1), background,
                               out_rgb ? out_rgb + 3 * dst : nullptr, out_acc ? out_acc + dst : nullptr,
                               out_depth ? out_depth + dst : nullptr, out_weights ? out_weights + ray * S : nullptr, lane);
     }

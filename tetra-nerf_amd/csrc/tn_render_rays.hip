@@ -55,7 +55,7 @@ struct RenderRaysParams {
     float *scratch;
     size_t per_block;
     uint32_t T;                    // tile capacity in rays
-    size_t o_nf, o_wc, o_edges_f, o_enc, o_bias, o_vi, o_bc, o_sigma, o_rgb;   // (edges_c at 0)
+    size_t o_edges_f, o_enc, o_bias, o_vi, o_bc, o_sigma, o_rgb;   // (edges_c at 0)
     uint32_t region;               // floats of LDS per wave for the ray phases
     unsigned long long *prof;      // [8] debug (TETRANERF_HIP_RENDER_PROFILE=1): 100 MHz ticks per phase kind, summed over blocks
 };
@@ -63,10 +63,10 @@ struct RenderRaysParams {
 // one ray's samples (the bin centres of e[0 .. S]) against its segments: vi [S] x 4 ids, bc [S] x 3 weights.  The expressions
 // are k_find_matched's (tn_match.hip); only vertex ids and barycentrics are produced (the MLP kernel reads nothing else).
 // tin / pmax: 2 M floats of LDS owned by the wave.
+// n = num_visited[src] (the kernel loads the counts of a whole tile at once: no dependent load here).
 template <int UM>
-__device__ __forceinline__ void ray_match(uint32_t S, uint32_t M, size_t src, const RenderRaysParams &p, const float *__restrict__ e,
+__device__ __forceinline__ void ray_match(uint32_t S, uint32_t M, size_t src, uint32_t n, const RenderRaysParams &p, const float *__restrict__ e,
                                           uint32_t *__restrict__ vi_out, float *__restrict__ bc_out, float *tin, float *pmax, int lane) {
-    uint32_t n = p.num_visited[src];
     if (n > M) n = M;
     const float2 *drow = reinterpret_cast<const float2 *>(p.dist) + src * M;
     // do the sample distances ascend?  (distance j = centre of bin j, as the callers of find_visited_cells compute it.)  The
@@ -87,27 +87,24 @@ __device__ __forceinline__ void ray_match(uint32_t S, uint32_t M, size_t src, co
             if (j + 1 < S) bad |= !((a1[u] + a0[u]) / 2.0f <= (a2[u] + a1[u]) / 2.0f);
         }
     }
-    // stage bounds + inclusive running max of t_out (wave scan, chunks of 64; the rows of up to 8 chunks requested at once)
+    // stage bounds + inclusive running max of t_out (wave scans over chunks of 64; the rows of up to 8 chunks requested at once,
+    // their scans interleaved: rayops::wave_incl_max_multi)
     float carry = -INFINITY;
     for (uint32_t base0 = 0; base0 < n; base0 += 512) {
         float2 dv[8];
+        float mx[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t j = base0 + 64u * c + lane;
             dv[c] = make_float2(0.f, -INFINITY);
             if (j < n) dv[c] = drow[j];
+            mx[c] = dv[c].y;
         }
+        wave_incl_max_multi<8>(mx, lane);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            if (base0 + 64u * c >= n) break;    // wave-uniform
             const uint32_t j = base0 + 64u * c + lane;
-            float m = dv[c].y;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float o = __shfl_up(m, off);
-                if (lane >= off) m = fmaxf(m, o);
-            }
-            m = fmaxf(m, carry);
+            const float m = fmaxf(mx[c], carry);
             if (j < n) { tin[j] = dv[c].x; pmax[j] = m; }
             carry = __shfl(m, 63);
         }
@@ -128,25 +125,32 @@ __device__ __forceinline__ void ray_match(uint32_t S, uint32_t M, size_t src, co
                 cur[u] = j < S ? (e[j + 1] + e[j]) / 2.0f : 0.f;
                 pp[u] = 0;
             }
-            // pp = number of segments whose running-max t_out is below the sample = first pp with pmax[pp] >= cur
+            // pp = number of segments whose running-max t_out is below the sample = first pp with pmax[pp] >= cur.  Straight-line
+            // (clamped reads + selects): the UM reads of a step are issued together
+            const uint32_t nlast = n ? n - 1 : 0;
             for (uint32_t bit = top; bit > 0; bit >>= 1) {
+                float pv[UM];
 #pragma unroll
-                for (int u = 0; u < UM; ++u)
-                    if (pp[u] + bit <= n && pmax[pp[u] + bit - 1] < cur[u]) pp[u] += bit;
+                for (int u = 0; u < UM; ++u) { const uint32_t k = pp[u] + bit - 1; pv[u] = pmax[k < nlast ? k : nlast]; }
+#pragma unroll
+                for (int u = 0; u < UM; ++u) pp[u] = (pp[u] + bit <= n && pv[u] < cur[u]) ? pp[u] + bit : pp[u];
             }
             bool mk[UM];
             uint4 vv[UM];
             float t_in[UM], t_out[UM];
             float2 q0[UM], q1[UM], q2[UM];
+            float tv[UM];
+#pragma unroll
+            for (int u = 0; u < UM; ++u) tv[u] = tin[pp[u] < nlast ? pp[u] : nlast];
 #pragma unroll
             for (int u = 0; u < UM; ++u) {
                 const uint32_t j = base + 64 * u + lane;
                 mk[u] = false; vv[u] = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
                 t_in[u] = 0.f; t_out[u] = 1.f; q0[u] = q1[u] = q2[u] = make_float2(0.f, 0.f);
-                if (j < S && pp[u] < n && tin[pp[u]] <= cur[u]) {
+                if (j < S && pp[u] < n && tv[u] <= cur[u]) {
                     const size_t g = src * M + pp[u];
                     mk[u] = true;
-                    t_in[u] = tin[pp[u]]; t_out[u] = drow[pp[u]].y;
+                    t_in[u] = tv[u]; t_out[u] = drow[pp[u]].y;
                     vv[u] = *reinterpret_cast<const uint4 *>(p.verts + 4 * g);
                     const float2 *bp = reinterpret_cast<const float2 *>(p.bary + 6 * g);
                     q0[u] = bp[0]; q1[u] = bp[1]; q2[u] = bp[2];  // c1.xyz = q0.x q0.y q1.x ; c2.xyz = q1.y q2.x q2.y
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void k_render_rays(RenderRaysParams p
     const uint32_t nb = p.S_fine + 1;
     const uint32_t Sf = FINE ? S + nb : S;                  // samples of the final pass
     float *sc = p.scratch + (size_t)blockIdx.x * p.per_block;
-    float *edges_c = sc, *nf = sc + p.o_nf, *wc = sc + p.o_wc, *edges_f = sc + p.o_edges_f, *enc = sc + p.o_enc;
+    float *edges_c = sc, *edges_f = sc + p.o_edges_f, *enc = sc + p.o_enc;
     float *bias = p.ray_bias ? sc + p.o_bias : nullptr;
     uint32_t *vi = reinterpret_cast<uint32_t *>(sc + p.o_vi);
     float *bc = sc + p.o_bc, *sigma = sc + p.o_sigma, *rgb = sc + p.o_rgb;
@@ -248,13 +252,27 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void k_render_rays(RenderRaysParams p
     auto tick = [&](int k) {      // phase k ends here (block-uniform branch; nothing but a null test when profiling is off)
         if (p.prof) { const unsigned long long t = wall_clock64(); acc_t[k] += t - t_prev; t_prev = t; }
     };
+    // per-wave LDS for ray phase 2: [coarse weights: S floats][PDF sampler], re-used by the matcher afterwards
+    const uint32_t w_floats = (S + 3u) & ~3u;
     for (size_t tq = q0; tq < q1; tq += tile) {
         const uint32_t nt = (uint32_t)(q1 - tq < tile ? q1 - tq : tile);
+        // This wave's rays of the tile are t = wave + NW i, i = 0, 1, ...: lane i holds ray i's row index, segment count and --
+        // after phase 1 -- near / far, for all three ray phases (T <= 64 NW): a ray phase starts without a dependent load chain
+        // (ray id -> count -> rows), which a wave that owns its ray alone would pay in full, three times per ray.
+        uint32_t l_ray = 0, l_nv = 0;
+        float l_near = 0.f, l_far = 1.f;
+        if ((uint32_t)wave + (uint32_t)NW * lane < nt) {
+            l_ray = p.ray_index[tq + wave + (size_t)NW * lane];
+            l_nv = p.num_visited[l_ray];
+        }
         // ---- ray phase 1: coarse sampler -> matcher (+ direction encoding, head bias row) of this wave's rays
-        for (uint32_t t = wave; t < nt; t += NW) {
-            const size_t ray = p.ray_index[tq + t];
+        for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
+            const size_t ray = (uint32_t)__builtin_amdgcn_readlane((int)l_ray, (int)i);
+            const uint32_t nv = (uint32_t)__builtin_amdgcn_readlane((int)l_nv, (int)i);
             float *e = edges_c + (size_t)t * (S + 1);
-            ray_sample_coarse(S, M, ray, p.num_visited, p.dist, p.lin, nullptr, p.biased, e, nf + 2 * (size_t)t, wl, lane);
+            float near, far;
+            ray_sample_coarse(S, M, ray, nv, p.dist, p.lin, nullptr, p.biased, e, nullptr, wl, lane, near, far);
+            if (lane == (int)i) { l_near = near; l_far = far; }
             ray_dir_encoding(p.dirs + 3 * ray, enc + (size_t)t * ENC_PAD, lane);
             if (bias) {
                 const float *src = p.ray_bias + ray * HID;
@@ -262,8 +280,8 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void k_render_rays(RenderRaysParams p
                 bias[(size_t)t * HID + 64 + lane] = src[64 + lane];
             }
             wave_global_sync();
-            if (S <= 256) ray_match<4>(S, M, ray, p, e, vi + 4 * (size_t)t * S, bc + 3 * (size_t)t * S, wl, wl + M, lane);
-            else ray_match<9>(S, M, ray, p, e, vi + 4 * (size_t)t * S, bc + 3 * (size_t)t * S, wl, wl + M, lane);
+            if (S <= 256) ray_match<4>(S, M, ray, nv, p, e, vi + 4 * (size_t)t * S, bc + 3 * (size_t)t * S, wl, wl + M, lane);
+            else ray_match<9>(S, M, ray, nv, p, e, vi + 4 * (size_t)t * S, bc + 3 * (size_t)t * S, wl, wl + M, lane);
         }
         __syncthreads();
         tick(0);
@@ -277,18 +295,20 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void k_render_rays(RenderRaysParams p
             }
             __syncthreads();
             tick(1);
-            // ---- ray phase 2: get_weights -> PDF sampler -> matcher of the fine samples
-            for (uint32_t t = wave; t < nt; t += NW) {
-                const size_t ray = p.ray_index[tq + t];
+            // ---- ray phase 2: get_weights -> PDF sampler -> matcher of the fine samples.  The coarse weights go from the
+            //      composite to the sampler through the wave's LDS (the kernel chain writes and re-reads them in HBM)
+            for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
+                const size_t ray = (uint32_t)__builtin_amdgcn_readlane((int)l_ray, (int)i);
+                const uint32_t nv = (uint32_t)__builtin_amdgcn_readlane((int)l_nv, (int)i);
+                const float near = __shfl(l_near, (int)i), far = __shfl(l_far, (int)i);
                 const float *e = edges_c + (size_t)t * (S + 1);
-                float *w = wc + (size_t)t * S;
-                ray_composite(S, sigma + (size_t)t * S, nullptr, e, p.bg, nullptr, nullptr, nullptr, w, lane);
-                wave_global_sync();
+                ray_composite(S, sigma + (size_t)t * S, nullptr, e, p.bg, nullptr, nullptr, nullptr, wl, lane);
+                lds_sync();
                 float *ef = edges_f + (size_t)t * (Sf + 1);
-                ray_sample_pdf(S, nb, e, w, nf[2 * (size_t)t], nf[2 * (size_t)t + 1], p.u_table, nullptr, p.hist_pad, p.eps, ef, wl, lane);
+                ray_sample_pdf(S, nb, e, wl, near, far, p.u_table, nullptr, p.hist_pad, p.eps, ef, wl + w_floats, lane);
                 wave_global_sync();
-                if (Sf <= 256) ray_match<4>(Sf, M, ray, p, ef, vi + 4 * (size_t)t * Sf, bc + 3 * (size_t)t * Sf, wl, wl + M, lane);
-                else ray_match<9>(Sf, M, ray, p, ef, vi + 4 * (size_t)t * Sf, bc + 3 * (size_t)t * Sf, wl, wl + M, lane);
+                if (Sf <= 256) ray_match<4>(Sf, M, ray, nv, p, ef, vi + 4 * (size_t)t * Sf, bc + 3 * (size_t)t * Sf, wl, wl + M, lane);
+                else ray_match<9>(Sf, M, ray, nv, p, ef, vi + 4 * (size_t)t * Sf, bc + 3 * (size_t)t * Sf, wl, wl + M, lane);
             }
             __syncthreads();
             tick(2);
@@ -304,8 +324,8 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void k_render_rays(RenderRaysParams p
         tick(3);
         // ---- ray phase 3: weights + renderers, scattered into the frame
         const float *ee = FINE ? edges_f : edges_c;
-        for (uint32_t t = wave; t < nt; t += NW) {
-            const size_t ray = p.ray_index[tq + t];
+        for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
+            const size_t ray = (uint32_t)__builtin_amdgcn_readlane((int)l_ray, (int)i);
             ray_composite(Sf, sigma + (size_t)t * Sf, rgb + 3 * (size_t)t * Sf, ee + (size_t)t * (Sf + 1), p.bg, p.out_rgb + 3 * ray,
                           p.out_acc + ray, p.out_depth + ray, nullptr, lane);
         }
@@ -323,16 +343,15 @@ size_t render_rays_scratch_floats(size_t r_max, uint32_t S, uint32_t S_fine, boo
     auto al = [](size_t x) { return (x + 3) & ~(size_t)3; };   // 16-byte aligned pieces
     const uint32_t nb = S_fine + 1;
     const uint32_t Sf = S_fine ? S + nb : S;
-    const size_t per_ray = (size_t)(S + 1) + 2 + (S_fine ? (size_t)S + (Sf + 1) : 0) + ENC_PAD + (has_bias ? HID : 0) + (size_t)Sf * 11;
+    const size_t per_ray = (size_t)(S + 1) + (S_fine ? (size_t)(Sf + 1) : 0) + ENC_PAD + (has_bias ? HID : 0) + (size_t)Sf * 11;
     const size_t rays_per_block = (r_max + grid - 1) / grid;
     size_t T = ((size_t)4 << 20) / (per_ray * sizeof(float));      // <= 4 MB of scratch per block
     if (T < 8) T = 8;
+    if (T > 64 * (MLP_BLOCK / 64)) T = 64 * (MLP_BLOCK / 64);      // a wave keeps its rays' ids in one register, lane i = ray i
     if (T > rays_per_block) T = rays_per_block;
     if (T < 1) T = 1;
     L.T = (uint32_t)T;
     size_t o = al(T * (S + 1));
-    L.o_nf = o; o = al(o + T * 2);
-    L.o_wc = o; o = al(o + (S_fine ? T * S : 0));
     L.o_edges_f = o; o = al(o + (S_fine ? T * (Sf + 1) : 0));
     L.o_enc = o; o = al(o + T * ENC_PAD);
     L.o_bias = o; o = al(o + (has_bias ? T * HID : 0));
@@ -351,7 +370,8 @@ void launch_render_rays(const uint32_t *num_visited, const float *dist, const fl
                         float *scratch, const RenderRaysLayout &L, unsigned grid, hipStream_t stream, unsigned long long *prof) {
     if (r_max == 0) return;
     const uint32_t nb = S_fine + 1;
-    const size_t region = std::max<size_t>(std::max<size_t>(2 * (size_t)M, (size_t)M + 1), S_fine ? pdf_lds_floats(S, nb) : 0);
+    const size_t region = std::max<size_t>(std::max<size_t>(2 * (size_t)M, (size_t)M + 1),
+                                           S_fine ? (((size_t)S + 3) & ~(size_t)3) + pdf_lds_floats(S, nb) : 0);
     const size_t lds_floats = std::max<size_t>(MAX_STAGE_FLOATS, (MLP_BLOCK / 64) * region);
     const size_t smem = lds_floats * sizeof(float);
     if (smem > 160 * 1024) throw Error("render_rays: max_ray_triangles / samples per ray too large for the per-wave LDS regions");
@@ -363,7 +383,7 @@ void launch_render_rays(const uint32_t *num_visited, const float *dist, const fl
     p.fieldT = fieldT; p.dirs = dirs; p.ray_bias = ray_bias; p.pk = w.pk_gather; p.bg = background;
     p.out_rgb = out_rgb; p.out_acc = out_acc; p.out_depth = out_depth;
     p.scratch = scratch; p.per_block = L.per_block; p.T = L.T;
-    p.o_nf = L.o_nf; p.o_wc = L.o_wc; p.o_edges_f = L.o_edges_f; p.o_enc = L.o_enc; p.o_bias = L.o_bias; p.o_vi = L.o_vi; p.o_bc = L.o_bc;
+    p.o_edges_f = L.o_edges_f; p.o_enc = L.o_enc; p.o_bias = L.o_bias; p.o_vi = L.o_vi; p.o_bc = L.o_bc;
     p.o_sigma = L.o_sigma; p.o_rgb = L.o_rgb;
     p.region = (uint32_t)region;
     p.prof = prof;

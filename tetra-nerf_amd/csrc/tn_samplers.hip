@@ -37,9 +37,12 @@ __global__ __launch_bounds__(SB) void k_sample_coarse(size_t r, uint32_t S, uint
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (count) r = *count;      // device-side number of hitting rays (the grid was sized for an upper bound)
     float *cum = smem + (size_t)wave * (M + 1);          // biased: cum[i] = start + sum of the first i segment lengths
-    for (size_t q = (size_t)blockIdx.x * (SB / 64) + wave; q < r; q += (size_t)gridDim.x * (SB / 64))
-        ray_sample_coarse(S, M, ray_index[q], num_visited, hit_dist, lin, t_rand ? t_rand + q * (size_t)(S + 1) : nullptr, biased,
-                          edges + q * (size_t)(S + 1), near_far + 2 * q, cum, lane);
+    for (size_t q = (size_t)blockIdx.x * (SB / 64) + wave; q < r; q += (size_t)gridDim.x * (SB / 64)) {
+        const size_t ray = ray_index[q];
+        float near, far;
+        ray_sample_coarse(S, M, ray, num_visited[ray], hit_dist, lin, t_rand ? t_rand + q * (size_t)(S + 1) : nullptr, biased,
+                          edges + q * (size_t)(S + 1), near_far + 2 * q, cum, lane, near, far);
+    }
 }
 
 // edges [r, S+1] euclidean coarse edges, weights [r, S] coarse weights, near_far [r, 2];

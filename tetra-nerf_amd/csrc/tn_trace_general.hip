@@ -788,9 +788,9 @@ void launch_verify_counts(const TraceParams &p, uint32_t stride, uint32_t *walk_
                           const uint32_t *list_count, size_t max_list) {
     if (p.num_items == 0 || (stride == 0 && !ray_list)) return;
     const size_t smem = wave_smem(k_verify_counts, p.M);
-    // (the risk list is short -- a fraction of a per cent of the rays -- but its length is only known on the device: a grid of
-    //  at most 1024 waves strides over it)
-    const size_t n_checks = ray_list ? std::min<size_t>(max_list, 1024) : (p.num_items + stride - 1) / stride, max_blocks = 256 * 16;
+    // (the risk list is short -- a fraction of a per cent of the rays -- but its length is only known on the device: the grid
+    //  of the blind sample strides over it; blocks beyond the list exit at once)
+    const size_t n_checks = ray_list ? std::min<size_t>(max_list, 256 * 16) : (p.num_items + stride - 1) / stride, max_blocks = 256 * 16;
     if (n_checks == 0) return;
     hipLaunchKernelGGL(k_verify_counts, dim3((unsigned)(n_checks < max_blocks ? n_checks : max_blocks)), dim3(64), smem, stream, p, stride,
                        walk_n, fallback_list, fallback_count, ray_base, late ? 1u : 0u, inject ? 1u : 0u, ray_list, list_count);

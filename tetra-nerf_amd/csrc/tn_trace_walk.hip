@@ -192,10 +192,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     const uint32_t thin_exp = (__float_as_uint(32.0f * delta) >> 23) & 0xFFu;
     // RISK classes of the certification (round 5): the two guards above hand a ray over when it passes
     // within 8 delta of a hull edge / of an edge of a thin-neighbourhood tet.  What is not proved is that the degenerate
-    // feature always lies THAT close to a tested edge, so the same tests with an 8 times wider band (64 delta) mark a certified
-    // ray as "at risk": every such ray -- not one in 256 -- is re-counted by the BVH cross-check (k_verify_counts).
-    // bit 0: within 8 delta (hand over), bit 1: within 64 delta (verify)
-    const float kappa2 = 8.0f * kappa;
+    // feature always lies THAT close to a tested edge, so the same tests with a wider band (option "risk_band": twice as wide
+    // = 16 delta by default) mark a certified ray as "at risk": every such ray -- not one in 256 -- is re-counted by the BVH
+    // cross-check (k_verify_counts).  bit 0: within 8 delta (hand over), bit 1: within the wide band (verify)
+    const float kappa2 = p.risk_band * kappa;
     auto edge_band = [&](float e, const SV &X, const SV &Y) -> uint32_t {
         const float len = fabsf(X.x - Y.x) + fabsf(X.y - Y.y), ae = fabsf(e);
         return (ae <= kappa * len ? 1u : 0u) | (ae <= kappa2 * len ? 2u : 0u);

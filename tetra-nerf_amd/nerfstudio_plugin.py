@@ -178,11 +178,26 @@ def resolve_background(model):
         if colors is None or bg not in getattr(colors, "COLORS_DICT", {}):
             return None
         bg = colors.COLORS_DICT[bg]
+    # A colour TENSOR is read back once per (object, version, storage): get_outputs runs per batch, and a device tensor
+    # (nerfstudio keeps its colours on the host, an override may not) would cost a host synchronisation every time -- in the
+    # middle of the sync-free training path.  The key changes when the tensor is replaced or written in place.
+    key = (id(bg), getattr(bg, "_version", None), bg.data_ptr()) if isinstance(bg, torch.Tensor) else None
+    if key is not None and _BG_CACHE.get("key") == key and _BG_CACHE.get("ref", lambda: None)() is bg:
+        return _BG_CACHE["value"]
     t = torch.as_tensor(bg).detach().to(dtype=torch.float32, device="cpu").reshape(-1)   # colours live on the host in nerfstudio
     if t.numel() != 3:
-        return None
-    r, g, b = t.tolist()
-    return r if r == g == b else (r, g, b)
+        value = None
+    else:
+        r, g, b = t.tolist()
+        value = r if r == g == b else (r, g, b)
+    if key is not None:
+        import weakref
+
+        _BG_CACHE.update(key=key, value=value, ref=weakref.ref(bg))
+    return value
+
+
+_BG_CACHE: dict = {}
 
 
 def _renderer_for(model, tracer):

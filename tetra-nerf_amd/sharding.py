@@ -216,7 +216,9 @@ def gather_scalars(value: float, device=None, group=None):
     """[world_size] list of one host scalar per rank (per-rank render times / hitting rays in the bench line)."""
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    # (a ONE-rank group still runs the collective: on backend "nccl" that is an RCCL kernel -- the GPU suite's only way to
+    #  execute this code on the real backend; without a process group there is nothing to reduce over)
+    if not dist.is_available() or not dist.is_initialized():
         return [float(value)]
     world = dist.get_world_size(group)
     out = torch.zeros(world, dtype=torch.float64, device=device)
@@ -228,7 +230,7 @@ def max_over_ranks(value: float, device=None, group=None) -> float:
     """MAX-reduce a host scalar (the bench's elapsed time) over all ranks."""
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return float(value)
     t = _all_reduce(torch.tensor([value], dtype=torch.float64, device=device), dist.ReduceOp.MAX, group)
     return float(t.item())
@@ -238,7 +240,7 @@ def sum_over_ranks(values, device=None, group=None):
     """SUM-reduce a list of host scalars over all ranks (units processed by the whole job)."""
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return [float(v) for v in values]
     t = _all_reduce(torch.tensor(list(values), dtype=torch.float64, device=device), dist.ReduceOp.SUM, group)
     return [float(x) for x in t.tolist()]
