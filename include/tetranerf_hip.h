@@ -86,7 +86,7 @@ int tn_trace_rays(tn_tracer_t tracer, size_t num_rays, uint32_t max_ray_triangle
 
 /* tn_trace_rays with per-call flags (no reference counterpart: the reference always materialises the dense rows).
  * TN_TRACE_COMPACT_ROWS: slots >= num_visited[r] are left UNWRITTEN (and rows of rays that miss the mesh untouched but
- * for num_visited[r] = 0) -- for consumers that read the rows only through num_visited (tn_sample_*, tn_render_pass,
+ * for num_visited[r] = 0) -- for consumers that read the rows only through num_visited (tn_sample_*, tn_render_rays,
  * tn_find_matched_cells_indexed): 52 B per segment instead of 52*M B per ray.  A per-call argument rather than a tracer
  * option, so that threads sharing a tracer (nerfstudio's viewer and trainer share the model) cannot see each other's
  * choice.  Calls on ONE tracer handle are serialised inside the library (a per-tracer mutex around the host section: the
@@ -336,7 +336,7 @@ int tn_mlp_forward(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, const float
 /* the same with the barycentric gather fused in (tn_interpolate_values<4> + tn_mlp_forward without the
  * [64,n] intermediate): vertex_indices u32 [n,4], barycentric f32 [n,3], field_vm f32 [V,64] VERTEX-major
  * (tn_transpose_f32 of the [64,V] parameter, refreshed by the caller once per field version) */
-/* ray_head_bias f32 [n / samples_per_ray, 128] or NULL (here, in tn_render_pass and in tn_mlp_forward_gather_train): a
+/* ray_head_bias f32 [n / samples_per_ray, 128] or NULL (here and in tn_mlp_forward_gather_train; tn_render_rays takes rows over ALL rays): a
  * per-RAY vector added to the pre-activation of mlp_head -- the reference's appearance embedding (model.py:437-447,
  * 608-620: head input = cat[encoded_dir, base, embedded_appearance], the embedding constant along a ray), whose E columns
  * of the head GEMM collapse to c_ray = Wh[:, 155:] emb(camera of the ray), an [rays, E] x [E, 128] product the caller
@@ -346,27 +346,11 @@ int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, cons
                           float *rgb, const float *ray_head_bias, const uint32_t *count /* device-side number of RAYS, nullable */,
                           void *stream);
 
-/* One render PASS of TetrahedraNerf.get_outputs as ONE launch (reference span
- * tetranerf/nerfstudio/model.py:560-662 = find_visited_cells -> interpolate_values -> mlp_base + heads -> get_weights ->
- * renderers): sample matching, barycentric gather, MLP and composite fused; nothing per sample goes through HBM but the
- * coarse weights.  The trace rows (outputs of tn_trace_rays, rows of M slots, M <= 512) are read IN PLACE:
- * ray_index u32 [r] names the row of hitting ray q.  edges f32 [r, S+1] = the sampler's bin edges (non-decreasing per
- * ray, S >= 64); field_vm f32 [V,64] vertex-major (tn_transpose_f32).
- *   dirs == NULL : density-only coarse pass (model.py:577-582): out_weights f32 [r, S] = get_weights.
- *   dirs f32 [r,3]: full pass: out_rgb f32 [R,3], out_acc f32 [R], out_depth f32 [R] (arrays over ALL rays of the trace
- *                  call, written at ray_index[q]; pre-fill them with the background values); out_weights optional.
- * Always the fp32 MFMA arithmetic. */
 /* background colour of nerfstudio's RGBRenderer as the reference model configures / overrides it (model.py:466,504-518;
  * `renderers.BACKGROUND_COLOR_OVERRIDE`): comp_rgb + background (1 - accumulation).  clamp != 0 = the renderer's
  * evaluation mode (RGBRenderer.forward when not training): nan_to_num of the sample colours, result clamped to [0, 1].
  * A NULL pointer means white without clamp (the shipped configurations in training mode). */
 typedef struct tn_rgb_background { float r, g, b; int clamp; } tn_rgb_background;
-int tn_render_pass(tn_mlp_t mlp, uint32_t max_ray_triangles, const uint32_t *num_visited, const float *hit_distances,
-                   const float *barycentric, const uint32_t *vertex_indices, const uint32_t *ray_index, size_t num_hit_rays,
-                   uint32_t num_samples, const float *edges, const float *field_vm, const float *dirs,
-                   const tn_rgb_background *background, float *out_weights, float *out_rgb, float *out_acc, float *out_depth,
-                   const float *ray_head_bias /* f32 [num_hit_rays, 128] or NULL */, void *stream);
-
 /* EVERYTHING between tn_trace_rays and the frame as ONE persistent launch (reference span
  * tetranerf/nerfstudio/model.py:531-662 in evaluation mode): coarse sampler (uniform or biased) -> find_visited_cells ->
  * interpolate_values + mlp_base + density head -> get_weights -> PDFSampler (include_original) -> find_visited_cells ->
@@ -389,7 +373,7 @@ int tn_render_rays(tn_mlp_t mlp, uint32_t max_ray_triangles, const uint32_t *num
 
 /* ---- ray samplers between tn_trace_rays and the render passes (model.py:111-192, 549-557, 582-586; nerfstudio's
  * UniformSampler / PDFSampler for the parts the reference imports).  One wavefront per HITTING ray; the trace rows are
- * read in place through ray_index u32 [r] (as in tn_render_pass).
+ * read in place through ray_index u32 [r] (as in tn_render_rays).
  * tn_sample_coarse: near / far of every hitting ray (near_far f32 [r,2]: first t_in, last t_out, model.py:531-544) and
  *   its num_samples + 1 coarse bin edges (edges f32 [r, S+1], euclidean): linspace f32 [S+1] = the spacing bins
  *   (torch.linspace(0, 1, S+1): the caller's table, so that both sides use the same values); t_rand f32 [r, S+1] uniform

@@ -195,7 +195,7 @@ def test_render_c3(tn, device, oracle, scenes, render, cfg, mlp_mode):
     gm = render.TetraMLP()
     gm.load_state_dict(mlp.state_dict())
     gm = gm.to(device)
-    # fused_pass: every pass ONE launch (tn_render_pass: match + gather + MLP + composite); fused without it: separate
+    # fused_pass: everything after the trace ONE persistent launch (tn_render_rays); fused without it: separate
     # match / fused gather+MLP / composite kernels; fused=False: the HIP ops + the PyTorch MLP
     for fused, fused_pass in ((True, True), (True, False), (False, False)):
         rd = render.TetraRenderer(tr, field.to(device), gm, S, M, fused=fused, num_fine_samples=S_fine, biased=biased,
@@ -217,61 +217,6 @@ def test_render_c3(tn, device, oracle, scenes, render, cfg, mlp_mode):
         assert np.isclose(got["depth"].cpu().numpy(), want["depth"].numpy(), rtol=0, atol=1e-4).mean() > 0.98
         np.testing.assert_allclose(got["depth"].cpu().numpy()[decided], want["depth"].numpy()[decided], rtol=0, atol=1e-5,
                                    err_msg=f"depth fused={fused} fused_pass={fused_pass}")
-
-
-@pytest.mark.parametrize("S", [64, 100, 256, 513])
-def test_render_pass_equals_unfused_kernels(tn, device, scenes, render, S):
-    """tn_render_pass against the chain it replaces (find_visited_cells -> mlp_forward_gather -> composite) on the same
-    trace rows and bin edges: the weights of a density-only pass and the rgb / accumulation / depth of a full pass,
-    for sample counts that put 1..4 rays into a step of 256 samples (incl. rays straddling steps and blocks)."""
-    import torch
-
-    cpp = tn.cpp
-    pts, cells = scenes.random_mesh(4000, 11)
-    torch.manual_seed(3)
-    gm = render.TetraMLP().to(device)
-    field = (torch.rand(64, len(pts), device=device) * 2 - 1)
-    w = render.mlp_weights(gm)
-    tr = tn.TetrahedraTracer(device)
-    tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
-    o, d = scenes.outside_in_rays(3001, 12)
-    o, d = torch.from_numpy(o).to(device), torch.from_numpy(d).to(device)
-    M = 256
-    out = tr.trace_rays(o, d, M)
-    nv = out["num_visited_cells"]
-    idx = torch.nonzero(nv > 0)[:, 0]
-    ridx = idx.to(torch.int32)
-    lists = [out[k] for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates", "hit_distances", "vertex_indices")]
-    near = out["hit_distances"][idx, 0, 0][:, None]
-    far = torch.gather(out["hit_distances"][idx][:, :, 1], 1, (nv[idx, None].long() - 1))
-    # uneven, sorted edges that stick out of the mesh on both sides (unmatched samples at the ends)
-    u = torch.sort(torch.rand(len(idx), S + 1, device=device), dim=1).values
-    edges = (near - 0.05 + u * (far - near + 0.1)).contiguous()
-    dist = ((edges[:, 1:] + edges[:, :-1]) / 2).contiguous()
-    traced = tr.find_visited_cells(*lists, dist, ray_index=ridx)
-    assert 0.5 < float(traced["mask"].float().mean()) < 1.0
-    dirs = d[idx].contiguous()
-    # density-only pass
-    sigma_c = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], field, None, w, S)
-    want_w = cpp.composite(sigma_c.view(-1, S), None, edges)
-    got_w = cpp.render_pass(lists, ridx, edges, field, None, w)
-    torch.testing.assert_close(got_w, want_w, rtol=0, atol=2e-6)
-    # full pass
-    sigma, col = cpp.mlp_forward_gather(traced["vertex_indices"], traced["barycentric_coordinates"], field, dirs, w, S)
-    want_rgb, want_acc, want_depth, want_wf = cpp.composite(sigma.view(-1, S), col.view(-1, S, 3), edges, return_weights=True)
-    R = o.shape[0]
-    rgb = torch.ones((R, 3), device=device); acc = torch.zeros((R, 1), device=device); depth = torch.full((R, 1), 1000.0, device=device)
-    cpp.render_pass(lists, ridx, edges, field, dirs, w, out=(rgb, acc, depth))
-    torch.testing.assert_close(rgb[idx], want_rgb, rtol=0, atol=2e-6)
-    torch.testing.assert_close(acc[idx].reshape(-1), want_acc.reshape(-1), rtol=0, atol=2e-6)
-    miss = torch.ones(R, dtype=torch.bool, device=device); miss[idx] = False
-    assert bool((rgb[miss] == 1).all()) and bool((acc[miss] == 0).all()) and bool((depth[miss] == 1000.0).all())
-    # median depth at 1e-5 on every decided ray (cumulative weights further from the threshold at every sample than the
-    # two evaluations -- 2e-6 apart per weight -- can drift over the ray)
-    decided = render.median_margin(want_wf)[:, 0] > 4e-6 * S
-    assert int(decided.sum()) > 100
-    assert float(torch.isclose(depth[idx].reshape(-1), want_depth.reshape(-1), rtol=0, atol=1e-6).float().mean()) > 0.99
-    torch.testing.assert_close(depth[idx].reshape(-1)[decided], want_depth.reshape(-1)[decided], rtol=0, atol=1e-5)
 
 
 @pytest.mark.parametrize("scale_w,scale_x", [(1.0, 1.0), (1e-4, 1e4), (1e4, 1e-4), (1e-3, 1e-3), (30.0, 30.0)])

@@ -23,7 +23,7 @@ SYMBOLS = (
     "tn_transpose_f32", "tn_interpolate_values_vm", "tn_interpolate_values_backward_vm",
     "tn_postprocess_hits", "tn_postprocess_hits_tables",
     "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_create", "tn_mlp_destroy", "tn_mlp_set_weights",
-    "tn_mlp_forward", "tn_mlp_forward_gather", "tn_render_pass", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
+    "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
     "tn_mlp_forward_gather_train", "tn_mlp_backward", "tn_mlp_ray_head_grad", "tn_mlp_param_grads", "tn_composite_backward", "tn_sample_coarse", "tn_sample_pdf",
     "tn_trace_timings", "tn_trace_cross_check", "tn_fill_rows", "tn_compact_hits", "tn_render_rays",
 )
@@ -78,7 +78,6 @@ def load():
     lib.tn_mlp_set_weights.argtypes = [vp, vp, vp]
     lib.tn_mlp_forward.argtypes = [vp, sz, u32, vp, vp, i32, vp, vp, vp]
     lib.tn_mlp_forward_gather.argtypes = [vp, sz, u32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
-    lib.tn_render_pass.argtypes = [vp, u32, vp, vp, vp, vp, vp, sz, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tn_gather_uint32.argtypes = [i32, u32, u32, vp, vp, vp, vp]
     lib.tn_scatter_ema_uint32.argtypes = [i32, u32, u32, vp, C.c_double, vp, vp, vp]
     lib.tn_composite.argtypes = [sz, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]

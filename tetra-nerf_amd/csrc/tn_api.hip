@@ -893,22 +893,21 @@ int tn_interpolate_values_backward_vm(uint32_t D, uint32_t n, uint32_t Fd, const
 
 struct tn_mlp {
     int device = 0;
-    tn::DevBuf<float> pk_plain, pk_gather, pt, enc, grad_scratch;
+    tn::DevBuf<float> pk_plain, pk_gather, pt, enc, grad_scratch, wenc, hterm;
     tn::DevBuf<uint4> blob;
-    tn::DevBuf<uint32_t> nvh;
     tn::DevBuf<float> render_scratch;    // per-block hand-over area of tn_render_rays (grown on demand, never shrunk)
     tn::DevBuf<unsigned long long> render_prof;   // TETRANERF_HIP_RENDER_PROFILE=1 (debug): phase ticks of tn_render_rays
     bool packed = false;
     // per-call scratch: grown on demand (blocking hipMalloc, rare), never shrunk; one handle serves one stream at a time
     tn::MlpPacks packs(size_t rays) {
         if (!packed) throw tn::Error("tn_mlp_set_weights must be called first");
-        if (enc.n < rays * tn::mlp_enc_floats_per_ray() || nvh.n < rays) {
+        if (enc.n < rays * tn::mlp_enc_floats_per_ray() || hterm.n < rays * 128) {
             const size_t cap = std::max<size_t>(rays + rays / 4, 4096);
             TN_HIP(hipDeviceSynchronize());   // the old scratch may still be in use by queued kernels
             enc.alloc(cap * tn::mlp_enc_floats_per_ray());
-            nvh.alloc(cap);
+            hterm.alloc(cap * 128);
         }
-        return tn::MlpPacks{pk_plain.p, pk_gather.p, pt.p, blob.p, enc.p, nullptr, nvh.p, grad_scratch.p};
+        return tn::MlpPacks{pk_plain.p, pk_gather.p, pt.p, blob.p, wenc.p, hterm.p, enc.p, nullptr, grad_scratch.p};
     }
 };
 
@@ -941,6 +940,7 @@ int tn_mlp_create(int device, tn_mlp_t *out) {
         m->pk_gather.alloc(tn::mlp_pack_floats());
         m->pt.alloc(tn::mlp_backward_pack_floats());
         m->blob.alloc(tn::mlp_x3_blob_u4());
+        m->wenc.alloc(128 * 28);
         *out = m.release();
     });
 }
@@ -967,6 +967,7 @@ int tn_mlp_set_weights(tn_mlp_t mlp, const tn_mlp_weights *w, void *stream_) {
         tn::launch_mlp_pack(mw, m->pk_gather.p, true, stream);
         tn::launch_mlp_pack_t(mw, m->pt.p, stream);
         tn::launch_mlp_pack_x3(mw, m->blob.p, stream);
+        tn::launch_pack_wenc(mw, m->wenc.p, stream);
         TN_HIP(hipGetLastError());
         m->packed = true;
     });
@@ -1008,27 +1009,6 @@ int tn_mlp_forward_gather(tn_mlp_t mlp, size_t n, uint32_t samples_per_ray, cons
     });
 }
 
-int tn_render_pass(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const float *hit_distances, const float *barycentric,
-                   const uint32_t *vertex_indices, const uint32_t *ray_index, size_t num_hit_rays, uint32_t num_samples,
-                   const float *edges, const float *field_vm, const float *dirs, const tn_rgb_background *background,
-                   float *out_weights, float *out_rgb, float *out_acc, float *out_depth, const float *ray_head_bias,
-                   void *stream_) {
-    return guarded([&] {
-        tn_mlp *m = checked_mlp(mlp);
-        if (num_hit_rays == 0) return;
-        if (!num_visited || !hit_distances || !barycentric || !vertex_indices || !ray_index || !edges || !field_vm)
-            throw tn::Error("null pointer");
-        if (!dirs && !out_weights) throw tn::Error("density-only pass without out_weights");
-        DeviceGuard g(m->device);
-        tn::MlpPacks pk = m->packs(num_hit_rays);
-        pk.ray_bias = ray_head_bias;
-        tn::launch_render_pass(num_visited, hit_distances, barycentric, vertex_indices, M, ray_index, num_hit_rays, num_samples,
-                               edges, field_vm, dirs, pk, background_of(background), out_weights, out_rgb, out_acc, out_depth,
-                               (hipStream_t)stream_);
-        TN_HIP(hipGetLastError());
-    });
-}
-
 int tn_render_rays(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const float *hit_distances, const float *barycentric,
                    const uint32_t *vertex_indices, const uint32_t *ray_index, const uint32_t *count, size_t num_hit_rays_max,
                    uint32_t num_samples, uint32_t num_fine, int biased, const float *linspace, const float *u_table,
@@ -1046,7 +1026,7 @@ int tn_render_rays(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const 
         if ((size_t)num_samples + num_fine + 2 > 8192) throw tn::Error("render_rays: too many samples per ray");
         DeviceGuard g(m->device);
         if (!m->packed) throw tn::Error("tn_mlp_set_weights must be called first");
-        const unsigned grid = 256;   // one persistent 8-wave block per CU
+        const unsigned grid = 512;   // two persistent 4-wave blocks per CU (tn_render_rays.hip)
         tn::RenderRaysLayout L{};
         const size_t need = tn::render_rays_scratch_floats(num_hit_rays_max, num_samples, num_fine, ray_head_bias != nullptr, grid, L);
         if (m->render_scratch.n < need) {

@@ -137,10 +137,11 @@ struct MlpPacks {
     const float *pk_gather;    // the same with layer-1 K order of the fused gather (forward, render pass, backward)
     const float *pt;           // transposed weights in accumulator order (backward)
     const uint4 *blob;         // bf16x3 pieces (forward, mode 1)
+    const float *wenc;         // [128][28] the direction encoding's columns of mlp_head (head_ray_term)
+    float *hterm;              // [rays][128] the head layer's per-ray term of the current call: Wh[:, :27] enc(dir) + ray_bias
     float *enc;                // [rays][mlp_enc_floats_per_ray()] direction encodings of the current call
     const float *ray_bias;     // per CALL (set by the entry point, never stored): [rays][128] added to the head layer's
                                // pre-activation (appearance embedding, tn_mlp_common.h: add_ray_bias), or null
-    uint32_t *nvh;             // [rays] segment counts of the hitting rays (render pass)
     float *grad_scratch;       // [mlp_param_grad_scratch_floats()] per-block partial sums of the parameter gradients
 };
 size_t mlp_pack_floats();              // tn_mlp.hip
@@ -148,6 +149,7 @@ size_t mlp_backward_pack_floats();     // tn_mlp_bwd.hip
 size_t mlp_x3_blob_u4();               // tn_mlp_x3.hip
 size_t mlp_enc_floats_per_ray();       // 32: covers the fp32 kernels' 28 and the bf16x3 kernel's 32
 void launch_mlp_pack(const MlpWeights &w, float *pk, bool gather_l1, hipStream_t stream);
+void launch_pack_wenc(const MlpWeights &w, float *wenc, hipStream_t stream);   // [128 * 28] floats
 void launch_mlp_pack_t(const MlpWeights &w, float *pt, hipStream_t stream);
 void launch_mlp_pack_x3(const MlpWeights &w, uint4 *blob, hipStream_t stream);
 // feats != null: input is the [64, n] feature buffer; feats == null: the kernel gathers the features itself from
@@ -200,18 +202,11 @@ __host__ __device__ __forceinline__ float nan_to_num(float x) {
 void launch_composite_backward(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, Background background,
                                const float *d_out_rgb, const float *d_out_acc, float *d_sigma, float *d_rgb, hipStream_t stream);
 void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols, hipStream_t stream);
-// one render pass as one launch (tn_render.hip): match -> gather -> MLP -> composite on the trace rows of the hitting
-// rays (ray_index [r]) from the bin edges [r, S + 1]; dirs == nullptr: density only, out_weights [r, S] written;
-// otherwise out_rgb / out_acc / out_depth (arrays over ALL rays) are written at ray_index[q]
-void launch_render_pass(const uint32_t *num_visited, const float *dist, const float *bary, const uint32_t *verts, uint32_t M,
-                        const uint32_t *ray_index, size_t r, uint32_t S, const float *edges, const float *fieldT,
-                        const float *dirs, const MlpPacks &w, Background background, float *out_weights, float *out_rgb,
-                        float *out_acc, float *out_depth, hipStream_t stream);
 // everything between trace_rays and the frame as ONE persistent launch (tn_render_rays.hip): coarse sampler -> match -> gather +
 // MLP (density) -> weights -> PDF sampler -> match -> gather + MLP + heads -> composite, scattered into out_* (arrays over ALL rays)
 // at the hitting rays ray_index[0 .. *count) (count null: r_max); S_fine = 0: one pass.  dirs [R_all, 3], ray_bias [R_all, 128] or
 // null are indexed by ray.  scratch: render_rays_scratch_floats(...) floats, laid out by the RenderRaysLayout it fills.
-struct RenderRaysLayout { uint32_t T; size_t per_block, o_edges_f, o_enc, o_bias, o_vi, o_bc, o_sigma, o_rgb; };
+struct RenderRaysLayout { uint32_t T; size_t per_block, o_edges_f, o_hterm, o_vi, o_bc, o_sigma, o_rgb; };
 size_t render_rays_scratch_floats(size_t r_max, uint32_t S, uint32_t S_fine, bool has_bias, unsigned grid, RenderRaysLayout &L);
 void launch_render_rays(const uint32_t *num_visited, const float *dist, const float *bary, const uint32_t *verts, uint32_t M,
                         const uint32_t *ray_index, const uint32_t *count, size_t r_max, uint32_t S, uint32_t S_fine, bool biased,

@@ -9,11 +9,17 @@
 // consecutive lanes (coalesced), including the defaults the reference gets from
 // torch::full/zeros (src/py_binding.cpp:188-191).  Rays whose distances do not ascend take a
 // literal serial branch on lane 0.
-#include "tn_device.h"
-#include "tn_kernels.h"
+#include "tn_ray_ops.h"
 
 namespace tn {
 
+// Round 5: the per-ray chain of dependent round trips (row index -> count -> bounds, chunk by chunk -> distances, twice ->
+// per 256 samples: search -> gather -> store) is what the op waits for at every size.  Now: the NEXT
+// ray's row index and count are requested while this one is matched; the bounds rows of up to 8 chunks and the distances of a
+// whole group of 64 UM samples (with the neighbours the ascending test needs) are requested together; the chunks' running-max
+// scans run interleaved (rayops::wave_incl_max_multi); the binary lifting reads LDS through clamped indices and selects, so
+// the UM reads of a step overlap.  Same expressions, same outputs.
+template <int UM>
 __global__ __launch_bounds__(64) void k_find_matched(size_t R, uint32_t S, uint32_t M,
                                                      const uint32_t *__restrict__ num_visited,
                                                      const uint32_t *__restrict__ visited,
@@ -32,43 +38,72 @@ __global__ __launch_bounds__(64) void k_find_matched(size_t R, uint32_t S, uint3
     float *pmax = tin + M;                         // [M] running max of t_out
     const int lane = threadIdx.x;
 
-    for (size_t ray = blockIdx.x; ray < R; ray += gridDim.x) {
-        // row of the trace outputs this sample row belongs to (ray_index: the caller kept the trace rows of ALL
-        // rays and matches a subset -- no compacted copy of the 26 KB rows)
-        const size_t src = ray_index ? (size_t)ray_index[ray] : ray;
-        uint32_t n = num_visited[src];
+    // row of the trace outputs a sample row belongs to (ray_index: the caller kept the trace rows of ALL rays and matches a
+    // subset -- no compacted copy of the 26 KB rows) and its segment count, one ray ahead
+    size_t ray = blockIdx.x;
+    size_t src_next = 0;
+    uint32_t n_next = 0;
+    if (ray < R) {
+        src_next = ray_index ? (size_t)ray_index[ray] : ray;
+        n_next = num_visited[src_next];
+    }
+    for (; ray < R; ray += gridDim.x) {
+        const size_t src = src_next;
+        uint32_t n = n_next;
+        if (ray + gridDim.x < R) {
+            src_next = ray_index ? (size_t)ray_index[ray + gridDim.x] : ray + gridDim.x;
+            n_next = num_visited[src_next];
+        }
         if (n > M) n = M;
         const float2 *drow = reinterpret_cast<const float2 *>(dist) + src * M;
-        // stage bounds + inclusive running max of t_out (wave scan, chunks of 64)
-        float carry = -INFINITY;
-        for (uint32_t base = 0; base < n; base += 64) {
-            const uint32_t j = base + lane;
-            float2 d = make_float2(0.f, -INFINITY);
-            if (j < n) d = drow[j];
-            float m = d.y;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float o = __shfl_up(m, off);
-                if (lane >= off) m = fmaxf(m, o);
-            }
-            m = fmaxf(m, carry);
-            if (j < n) { tin[j] = d.x; pmax[j] = m; }
-            carry = __shfl(m, 63);
-        }
-        // do the sample distances ascend?
         const float *srow = distances + ray * S;
+        // do the sample distances ascend?
         bool bad = false;
-        for (uint32_t j = lane; j + 1 < S; j += 64) bad |= !(srow[j] <= srow[j + 1]);
+        for (uint32_t base = 0; base + 1 < S; base += 64 * UM) {
+            float a0[UM], a1[UM];
+#pragma unroll
+            for (int u = 0; u < UM; ++u) {
+                const uint32_t j = base + 64 * u + lane;
+                a0[u] = a1[u] = 0.f;
+                if (j + 1 < S) { a0[u] = srow[j]; a1[u] = srow[j + 1]; }
+            }
+#pragma unroll
+            for (int u = 0; u < UM; ++u) {
+                const uint32_t j = base + 64 * u + lane;
+                if (j + 1 < S) bad |= !(a0[u] <= a1[u]);
+            }
+        }
+        // stage bounds + inclusive running max of t_out (wave scans, chunks of 64)
+        float carry = -INFINITY;
+        for (uint32_t base0 = 0; base0 < n; base0 += 512) {
+            float2 dv[8];
+            float mx[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t j = base0 + 64u * c + lane;
+                dv[c] = make_float2(0.f, -INFINITY);
+                if (j < n) dv[c] = drow[j];
+                mx[c] = dv[c].y;
+            }
+            rayops::wave_incl_max_multi<8>(mx, lane);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t j = base0 + 64u * c + lane;
+                const float m = fmaxf(mx[c], carry);
+                if (j < n) { tin[j] = dv[c].x; pmax[j] = m; }
+                carry = __shfl(m, 63);
+            }
+        }
         const bool ascending = (__ballot(bad) == 0ull);
         __syncthreads();
 
         if (ascending) {
-            // four sample chunks of 64 per iteration: their searches (LDS) and segment gathers (global) are
-            // independent, so the dependent chain search -> gather -> store is paid once per 256 samples
-            constexpr int UM = 4;
+            // UM sample chunks of 64 per iteration: their searches (LDS) and segment gathers (global) are
+            // independent, so the dependent chain search -> gather -> store is paid once per 64 UM samples
             uint32_t top = 1;                       // largest power of two <= n (0 for n == 0)
             while ((top << 1) <= n && (top << 1) != 0) top <<= 1;
             if (n == 0) top = 0;
+            const uint32_t nlast = n ? n - 1 : 0;
             for (uint32_t base = 0; base < S; base += 64 * UM) {
                 float cur[UM];
                 uint32_t p[UM];
@@ -80,24 +115,28 @@ __global__ __launch_bounds__(64) void k_find_matched(size_t R, uint32_t S, uint3
                 }
                 // p = number of segments whose running-max t_out is below the sample = first p with pmax[p] >= cur
                 for (uint32_t bit = top; bit > 0; bit >>= 1) {
+                    float pv[UM];
 #pragma unroll
-                    for (int u = 0; u < UM; ++u)
-                        if (p[u] + bit <= n && pmax[p[u] + bit - 1] < cur[u]) p[u] += bit;
+                    for (int u = 0; u < UM; ++u) { const uint32_t k = p[u] + bit - 1; pv[u] = pmax[k < nlast ? k : nlast]; }
+#pragma unroll
+                    for (int u = 0; u < UM; ++u) p[u] = (p[u] + bit <= n && pv[u] < cur[u]) ? p[u] + bit : p[u];
                 }
                 uint8_t mk[UM];
                 uint32_t cell[UM];
                 uint4 vv[UM];
-                float t_in[UM], t_out[UM];
+                float t_in[UM], t_out[UM], tv[UM];
                 float2 q0[UM], q1[UM], q2[UM];
+#pragma unroll
+                for (int u = 0; u < UM; ++u) tv[u] = tin[p[u] < nlast ? p[u] : nlast];
 #pragma unroll
                 for (int u = 0; u < UM; ++u) {
                     const uint32_t j = base + 64 * u + lane;
                     mk[u] = 0; cell[u] = TN_EMPTY; vv[u] = make_uint4(TN_EMPTY, TN_EMPTY, TN_EMPTY, TN_EMPTY);
                     t_in[u] = 0.f; t_out[u] = 1.f; q0[u] = q1[u] = q2[u] = make_float2(0.f, 0.f);
-                    if (j < S && p[u] < n && tin[p[u]] <= cur[u]) {
+                    if (j < S && p[u] < n && tv[u] <= cur[u]) {
                         const size_t g = src * M + p[u];
                         mk[u] = 1;
-                        t_in[u] = tin[p[u]]; t_out[u] = drow[p[u]].y;
+                        t_in[u] = tv[u]; t_out[u] = drow[p[u]].y;
                         cell[u] = visited[g];
                         vv[u] = *reinterpret_cast<const uint4 *>(verts + 4 * g);
                         const float2 *bp = reinterpret_cast<const float2 *>(bary + 6 * g);
@@ -164,8 +203,13 @@ void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num
     const size_t smem = 2 * M * sizeof(float);
     const size_t max_blocks = 256 * 32;
     const unsigned grid = (unsigned)(R < max_blocks ? R : max_blocks);
-    hipLaunchKernelGGL(k_find_matched, dim3(grid), dim3(64), smem, stream, R, (uint32_t)S, (uint32_t)M,
-                       num_visited, visited, dist, bary, distances, verts, cells_out, verts_out, mask_out, bary_out, ray_index, count);
+    // the samples of a ray in ONE group where they fit: 64 UM per iteration of the search / gather / store chain
+    if (S <= 256)
+        hipLaunchKernelGGL(k_find_matched<4>, dim3(grid), dim3(64), smem, stream, R, (uint32_t)S, (uint32_t)M,
+                           num_visited, visited, dist, bary, distances, verts, cells_out, verts_out, mask_out, bary_out, ray_index, count);
+    else
+        hipLaunchKernelGGL(k_find_matched<5>, dim3(grid), dim3(64), smem, stream, R, (uint32_t)S, (uint32_t)M,
+                           num_visited, visited, dist, bary, distances, verts, cells_out, verts_out, mask_out, bary_out, ray_index, count);
 }
 
 }  // namespace tn

@@ -57,13 +57,12 @@ __global__ void k_mlp_pack(MlpWeights w, float *__restrict__ pk, int gather_l1) 
         const int j = (int)(i - OFF_W3 - lfloats(KSH, OT));
         if (j < 128) v = w.wd[acc_k(j & 63, j >> 6)];
         else if (j == 128) v = w.bd[0];
-    } else if (i < OFF_WHEAD + lfloats(HEAD_KS, OT)) {  // head [enc(27) | base(128)] -> 128
+    } else if (i < OFF_WHEAD + lfloats(HEAD_KS, OT)) {  // head: the 128 base columns of [enc(27) | base(128)] -> 128
         split(i - OFF_WHEAD, OT, ks, ot, lane);
         const int row = lane & 31, h = lane >> 5;
         const int o = 32 * ot + row;
         const size_t base = (size_t)o * (ENC + HID);
-        if (ks < KSE) { const int k = 2 * ks + h; v = k < ENC ? w.wh[base + k] : 0.f; }
-        else if (ks < HEAD_KS) v = w.wh[base + ENC + acc_k(ks - KSE, h)];
+        if (ks < HEAD_KS) v = w.wh[base + ENC + acc_k(ks, h)];
         else v = h == 0 ? w.bh[o] : 0.f;
     } else {                                // rgb head vectors behind the head layer
         const int j = (int)(i - OFF_WHEAD - lfloats(HEAD_KS, OT));
@@ -92,6 +91,26 @@ __global__ void k_dir_encoding(size_t R, const float *__restrict__ dirs, float *
     e[27] = 0.f;
 }
 
+// the encoding's 27 columns of mlp_head, [128][ENC_PAD] (column 27 zero): the operand of head_ray_term
+__global__ void k_pack_wenc(MlpWeights w, float *__restrict__ wenc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HID * ENC_PAD) return;
+    const int o = i / ENC_PAD, k = i % ENC_PAD;
+    wenc[i] = k < ENC ? w.wh[(size_t)o * (ENC + HID) + k] : 0.f;
+}
+
+// hterm[r][o] = Wh[o, :27] . enc(dir_r) (+ the caller's per-ray bias: the appearance embedding): what the head layer adds per RAY
+__global__ __launch_bounds__(256) void k_head_ray_term(size_t R, const float *__restrict__ enc, const float *__restrict__ wenc,
+                                                       const float *__restrict__ ray_bias, float *__restrict__ hterm) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * HID) return;
+    const size_t r = i / HID;
+    const int o = (int)(i % HID);
+    float t = head_ray_term(wenc + o * ENC_PAD, enc + r * ENC_PAD);
+    if (ray_bias) t += ray_bias[i];
+    hterm[i] = t;
+}
+
 }  // namespace
 
 // 8 waves (BLOCK = 512) share each staged layer, one block per CU, two waves per SIMD: while one waits for a weight copy, at
@@ -102,9 +121,9 @@ template <bool GATHER, bool DENSITY_ONLY, int BLOCK = MLP_BLOCK, bool TRAIN = fa
 __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t samples_per_ray, const float *__restrict__ feats,
                                                            const uint32_t *__restrict__ vi, const float *__restrict__ bc,
                                                            const float *__restrict__ fieldT,
-                                                           const float *__restrict__ enc, const float *__restrict__ pk,
+                                                           const float *__restrict__ hterm, const float *__restrict__ pk,
                                                            float *__restrict__ sigma, float *__restrict__ rgb, FwdSave sv,
-                                                           const float *__restrict__ ray_bias, const uint32_t *__restrict__ count) {
+                                                           const uint32_t *__restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
     // count (nullable): the number of RAYS lives on the device (sync-free callers launch over an upper bound)
@@ -112,8 +131,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
     constexpr size_t GROUP = (BLOCK / 64) * 32;
     const size_t ngroups = (n + GROUP - 1) / GROUP;
     for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x)
-        mlp_forward_group<GATHER, DENSITY_ONLY, BLOCK, TRAIN>(lds, g, n, samples_per_ray, feats, vi, bc, fieldT, enc, pk, sigma, rgb, sv,
-                                                              ray_bias);
+        mlp_forward_group<GATHER, DENSITY_ONLY, BLOCK, TRAIN>(lds, g, n, samples_per_ray, feats, vi, bc, fieldT, hterm, pk, sigma, rgb, sv);
 }
 
 // Per-ray composite: one wavefront per ray, lanes stride the samples; exclusive scan of sigma*delta.
@@ -147,6 +165,18 @@ void launch_dir_encoding(size_t num_rays, const float *dirs, float *enc, hipStre
     hipLaunchKernelGGL(k_dir_encoding, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, stream, num_rays, dirs, enc);
 }
 
+void launch_pack_wenc(const MlpWeights &w, float *wenc, hipStream_t stream) {
+    hipLaunchKernelGGL(k_pack_wenc, dim3((HID * ENC_PAD + 255) / 256), dim3(256), 0, stream, w, wenc);
+}
+
+// the head layer's per-ray term of a call: direction encodings (w.enc) -> w.hterm (+ w.ray_bias)
+void launch_head_ray_term(size_t num_rays, const float *dirs, const MlpPacks &w, hipStream_t stream) {
+    if (num_rays == 0) return;
+    hipLaunchKernelGGL(k_dir_encoding, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, stream, num_rays, dirs, w.enc);
+    hipLaunchKernelGGL(k_head_ray_term, dim3((unsigned)((num_rays * HID + 255) / 256)), dim3(256), 0, stream, num_rays, w.enc, w.wenc,
+                       w.ray_bias, w.hterm);
+}
+
 size_t mlp_enc_floats_per_ray() { return 32; }
 
 void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, const float *feats, const uint32_t *vi,
@@ -157,9 +187,7 @@ void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, con
     const bool density_only = rgb == nullptr;  // coarse pass: no colour head, no direction encoding
     if (density_only) num_rays = 0;
     const float *pk = gather ? w.pk_gather : w.pk_plain;
-    float *enc = w.enc;
-    if (num_rays)
-        hipLaunchKernelGGL(k_dir_encoding, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, stream, num_rays, dirs, enc);
+    launch_head_ray_term(num_rays, dirs, w, stream);
     // one 8-wave block per CU (4-wave blocks, two per CU, measured neutral: profiles/r02o_mlp_block.txt)
     const size_t smem = MAX_STAGE_FLOATS * sizeof(float);  // the largest staged layer
     static PerDeviceOnce lds_attr;
@@ -174,7 +202,7 @@ void launch_mlp_forward(size_t n, uint32_t samples_per_ray, size_t num_rays, con
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
 #define TN_MLP_LAUNCH(G, D)                                                                                         \
     hipLaunchKernelGGL((k_mlp_forward<G, D>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray, feats, vi, bc, \
-                       fieldT, enc, pk, sigma, rgb, FwdSave{}, w.ray_bias, count)
+                       fieldT, w.hterm, pk, sigma, rgb, FwdSave{}, count)
     if (gather && density_only) TN_MLP_LAUNCH(true, true);
     else if (gather) TN_MLP_LAUNCH(true, false);
     else if (density_only) TN_MLP_LAUNCH(false, true);
@@ -186,7 +214,7 @@ void launch_mlp_forward_train(size_t n, uint32_t samples_per_ray, size_t num_ray
                               const float *fieldT, const float *dirs, const MlpPacks &w, float *sigma, float *rgb,
                               const MlpBackwardBuffers &save, hipStream_t stream) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_dir_encoding, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, stream, num_rays, dirs, w.enc);
+    launch_head_ray_term(num_rays, dirs, w, stream);
     const size_t smem = MAX_STAGE_FLOATS * sizeof(float);
     static PerDeviceOnce lds_attr;
     lds_attr.run([&] { allow_dynamic_lds(reinterpret_cast<const void *>(k_mlp_forward<true, false, MLP_BLOCK, true>), smem); });
@@ -194,8 +222,8 @@ void launch_mlp_forward_train(size_t n, uint32_t samples_per_ray, size_t num_ray
     const size_t ngroups = (n + group - 1) / group;
     const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);
     hipLaunchKernelGGL((k_mlp_forward<true, false, MLP_BLOCK, true>), dim3(grid), dim3(MLP_BLOCK), smem, stream, n, samples_per_ray,
-                       (const float *)nullptr, vi, bc, fieldT, w.enc, w.pk_gather, sigma, rgb,
-                       FwdSave{save.x0, save.h1, save.h2, save.h3, save.h4, save.masks}, w.ray_bias, (const uint32_t *)nullptr);
+                       (const float *)nullptr, vi, bc, fieldT, w.hterm, w.pk_gather, sigma, rgb,
+                       FwdSave{save.x0, save.h1, save.h2, save.h3, save.h4, save.masks}, (const uint32_t *)nullptr);
 }
 
 void launch_composite(size_t R, uint32_t S, const float *sigma, const float *rgb, const float *edges, Background background,

@@ -25,7 +25,12 @@ constexpr int MLP_BLOCK = 512;    // 8 waves share one staged layer: 256 samples
 // operands, the mlp_base output); the rgb head is a 1-tile layer (rows 0..2).
 struct LayerGeom { int ksteps, tiles; size_t off; };
 constexpr size_t lfloats(int ksteps, int tiles) { return (size_t)(ksteps + 1) * tiles * 64; }
-constexpr int HEAD_KS = KSE + KSH;
+// The head layer (mlp_head: [enc(27) | base(128)] -> 128) as an MFMA GEMM covers only its 128 base columns (round 5): the
+// direction encoding is constant along a ray, so its 27 columns collapse to ONE vector per ray, t_ray = Wh[:, :27] enc(dir)
+// -- 27 multiply-adds per output and ray instead of 14 MFMA k-steps (of 242 in the network) per 32 samples -- which is
+// added to the accumulators together with the appearance embedding's per-ray bias (add_ray_bias).  head_ray_term below is
+// the one expression both the stand-alone kernel (k_head_ray_term, tn_mlp.hip) and the persistent render kernel evaluate.
+constexpr int HEAD_KS = KSH;
 // The two narrow heads (density 128 -> 1 on the mlp_base output, rgb 128 -> 3 on the head output) are NOT
 // MFMA layers: as 32-row tiles they would spend 130 of 1098 MFMAs per 32 samples on 4 useful rows.  Their
 // weights ride behind the layer that produces their input ([half][64] floats in the lane's K order + bias)
@@ -160,6 +165,14 @@ static __device__ __forceinline__ void add_ray_bias(f32x16 (&acc)[TILES], const 
             const float4 v = *reinterpret_cast<const float4 *>(row + 32 * t + 8 * q + 4 * h);
             acc[t][4 * q] += v.x; acc[t][4 * q + 1] += v.y; acc[t][4 * q + 2] += v.z; acc[t][4 * q + 3] += v.w;
         }
+}
+
+// t[o] = sum_k wenc[o][k] enc[k], k = 0 .. 26 in this order (wenc: [128][ENC_PAD] = Wh[:, :27], column 27 zero)
+static __device__ __forceinline__ float head_ray_term(const float *__restrict__ wenc_row, const float *enc) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < ENC; ++k) a = a + wenc_row[k] * enc[k];
+    return a;
 }
 
 template <int TILES>

@@ -14,14 +14,13 @@ namespace mlp {
 struct FwdSave { float *x0, *h1, *h2, *h3, *h4; unsigned long long *masks; };
 
 // group g = samples [g * GROUP, (g + 1) * GROUP) of n; every thread of the block calls it (it contains the block barriers of
-// the weight stages).  lds: MAX_STAGE_FLOATS floats.
+// the weight stages).  lds: MAX_STAGE_FLOATS floats.  hterm [rays][128]: the head layer's per-ray term (unused when DENSITY_ONLY).
 template <bool GATHER, bool DENSITY_ONLY, int BLOCK, bool TRAIN>
 static __device__ __forceinline__ void mlp_forward_group(float *lds, size_t g, size_t n, uint32_t samples_per_ray,
                                                          const float *__restrict__ feats, const uint32_t *__restrict__ vi,
                                                          const float *__restrict__ bc, const float *__restrict__ fieldT,
-                                                         const float *__restrict__ enc, const float *__restrict__ pk,
-                                                         float *__restrict__ sigma, float *__restrict__ rgb, const FwdSave &sv,
-                                                         const float *__restrict__ ray_bias) {
+                                                         const float *__restrict__ hterm, const float *__restrict__ pk,
+                                                         float *__restrict__ sigma, float *__restrict__ rgb, const FwdSave &sv) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     constexpr size_t GROUP = (BLOCK / 64) * 32;
     const size_t s = g * GROUP + (size_t)wave * 32 + (lane & 31);
@@ -106,26 +105,18 @@ static __device__ __forceinline__ void mlp_forward_group(float *lds, size_t g, s
         if (h == 0 && s < n) sigma[s] = sp;
     }
     if constexpr (DENSITY_ONLY) return;  // coarse pass of the model (model.py:577-581)
-    // ---- head [enc(27) | base(128)] -> 128 ReLU
+    // ---- head [enc(27) | base(128)] -> 128 ReLU: the 128 base columns as a GEMM, the encoding's 27 columns (constant along a
+    //      ray) as the per-ray vector the caller made (hterm = Wh[:, :27] enc(dir) + the appearance embedding's bias, if any)
     __syncthreads();
     stage_weights<BLOCK>(lds, pk + OFF_WHEAD, N_WHEAD);
     stage_wait();
     {
         f32x16 acc[OT];
         zero_acc(acc);
-        const float *e = enc + (sc / samples_per_ray) * ENC_PAD;
-#pragma unroll
-        for (int ks = 0; ks < KSE; ++ks) {
-            const float b = e[2 * ks + h];
-            const float *wrow = lds + (size_t)ks * OT * 64 + lane;
-#pragma unroll
-            for (int t = 0; t < OT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[t * 64], b, acc[t], 0, 0, 0);
-        }
-        if constexpr (TRAIN) gemm_steps_store<KSH, KSE, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h3, n, sc, h), 2 * n);
-        else gemm_steps<KSH, KSE, OT>(acc, bin, lds, lane);
+        if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h3, n, sc, h), 2 * n);
+        else gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
         bias_step<HEAD_KS, OT>(acc, lds, lane);
-        if (ray_bias) add_ray_bias(acc, ray_bias + (sc / samples_per_ray) * HID, h);   // wave-uniform test
+        add_ray_bias(acc, hterm + (sc / samples_per_ray) * HID, h);
         relu_to_bin(acc, bin);
     }
     if constexpr (TRAIN) store_bin(sv.h4, n, sc, bin, h);   // the last layer's output has no GEMM to hide under

@@ -48,6 +48,7 @@ struct RenderRaysParams {
     const float *fieldT;           // [V, 64]
     const float *dirs;             // [R_all, 3]
     const float *ray_bias;         // [R_all, 128] or null
+    const float *wenc;             // [128][28] the direction encoding's columns of mlp_head (head_ray_term)
     const float *pk;               // packed weights (gather order)
     Background bg;
     float *out_rgb, *out_acc, *out_depth;   // [R_all, 3], [R_all], [R_all]: written at the ray's own row
@@ -55,7 +56,7 @@ struct RenderRaysParams {
     float *scratch;
     size_t per_block;
     uint32_t T;                    // tile capacity in rays
-    size_t o_edges_f, o_enc, o_bias, o_vi, o_bc, o_sigma, o_rgb;   // (edges_c at 0)
+    size_t o_edges_f, o_hterm, o_vi, o_bc, o_sigma, o_rgb;   // (edges_c at 0)
     uint32_t region;               // floats of LDS per wave for the ray phases
     unsigned long long *prof;      // [8] debug (TETRANERF_HIP_RENDER_PROFILE=1): 100 MHz ticks per phase kind, summed over blocks
 };
@@ -224,12 +225,18 @@ __device__ __forceinline__ void wave_global_sync() {
 
 }  // namespace
 
+// 4-wave blocks, TWO per CU (the staged head layer is 68 KB since the encoding's columns left it): while one block of a CU is in
+// a ray phase -- latency-bound wave-per-ray work that leaves the matrix cores idle -- the other one's MLP phase has them to
+// itself.  Blocks of a CU would run in lockstep (same work), so the blocks of one of the two residency classes start with a
+// half tile (see `stagger`).
+constexpr int RR_BLOCK = 256;
+
 template <bool FINE>
-__global__ __launch_bounds__(MLP_BLOCK, 2) void k_render_rays(RenderRaysParams p) {
+__global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = MLP_BLOCK / 64;
+    constexpr int NW = RR_BLOCK / 64;
     const size_t r = p.count ? (size_t)*p.count : p.r_max;
     const size_t q0 = r * blockIdx.x / gridDim.x, q1 = r * (blockIdx.x + 1) / gridDim.x;   // r < 2^32, gridDim <= 2^10
     if (q0 >= q1) return;                                   // block-uniform
@@ -237,15 +244,19 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void k_render_rays(RenderRaysParams p
     const uint32_t nb = p.S_fine + 1;
     const uint32_t Sf = FINE ? S + nb : S;                  // samples of the final pass
     float *sc = p.scratch + (size_t)blockIdx.x * p.per_block;
-    float *edges_c = sc, *edges_f = sc + p.o_edges_f, *enc = sc + p.o_enc;
-    float *bias = p.ray_bias ? sc + p.o_bias : nullptr;
+    float *edges_c = sc, *edges_f = sc + p.o_edges_f, *hterm = sc + p.o_hterm;
     uint32_t *vi = reinterpret_cast<uint32_t *>(sc + p.o_vi);
     float *bc = sc + p.o_bc, *sigma = sc + p.o_sigma, *rgb = sc + p.o_rgb;
     float *wl = lds + (size_t)wave * p.region;              // this wave's LDS for the ray phases (aliases the weight stage)
 
     const uint32_t nrays = (uint32_t)(q1 - q0);
-    const uint32_t ntiles = (nrays + p.T - 1) / p.T;
-    const uint32_t tile = (nrays + ntiles - 1) / ntiles;    // even tiles: one partial MLP group per tile at most
+    // at least two tiles per block (where it has the rays), even ones: one partial MLP group per tile at most
+    uint32_t ntiles = (nrays + p.T - 1) / p.T;
+    if (ntiles < 2 && nrays >= 8) ntiles = 2;
+    const uint32_t tile = (nrays + ntiles - 1) / ntiles;
+    // which two blocks share a CU is the dispatcher's business (b and b + 1, or b and b + gridDim / 2): the blocks whose
+    // index differs in bit 0 XOR the top bit start with half a tile, so that either pairing puts the two out of phase
+    const bool stagger = (((blockIdx.x & 1u) ^ ((2u * blockIdx.x / gridDim.x) & 1u)) != 0u) && tile >= 4;
     constexpr size_t GROUP = (size_t)NW * 32;
 
     unsigned long long t_prev = p.prof ? wall_clock64() : 0ull, acc_t[6] = {0, 0, 0, 0, 0, 0};
@@ -254,8 +265,9 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void k_render_rays(RenderRaysParams p
     };
     // per-wave LDS for ray phase 2: [coarse weights: S floats][PDF sampler], re-used by the matcher afterwards
     const uint32_t w_floats = (S + 3u) & ~3u;
-    for (size_t tq = q0; tq < q1; tq += tile) {
-        const uint32_t nt = (uint32_t)(q1 - tq < tile ? q1 - tq : tile);
+    for (size_t tq = q0, first = 1; tq < q1; first = 0) {
+        uint32_t nt = (first && stagger) ? tile / 2 : tile;
+        if (q1 - tq < nt) nt = (uint32_t)(q1 - tq);
         // This wave's rays of the tile are t = wave + NW i, i = 0, 1, ...: lane i holds ray i's row index, segment count and --
         // after phase 1 -- near / far, for all three ray phases (T <= 64 NW): a ray phase starts without a dependent load chain
         // (ray id -> count -> rows), which a wave that owns its ray alone would pay in full, three times per ray.
@@ -273,11 +285,15 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void k_render_rays(RenderRaysParams p
             float near, far;
             ray_sample_coarse(S, M, ray, nv, p.dist, p.lin, nullptr, p.biased, e, nullptr, wl, lane, near, far);
             if (lane == (int)i) { l_near = near; l_far = far; }
-            ray_dir_encoding(p.dirs + 3 * ray, enc + (size_t)t * ENC_PAD, lane);
-            if (bias) {
-                const float *src = p.ray_bias + ray * HID;
-                bias[(size_t)t * HID + lane] = src[lane];
-                bias[(size_t)t * HID + 64 + lane] = src[64 + lane];
+            // the head layer's per-ray term: Wh[:, :27] enc(dir) + the appearance embedding's bias (k_head_ray_term's expression)
+            ray_dir_encoding(p.dirs + 3 * ray, wl, lane);           // (28 floats of the wave's LDS: the sampler is done with it)
+            lds_sync();
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int o = lane + 64 * half;
+                float tv = head_ray_term(p.wenc + o * ENC_PAD, wl);
+                if (p.ray_bias) tv += p.ray_bias[ray * HID + o];
+                hterm[(size_t)t * HID + o] = tv;
             }
             wave_global_sync();
             if (S <= 256) ray_match<4>(S, M, ray, nv, p, e, vi + 4 * (size_t)t * S, bc + 3 * (size_t)t * S, wl, wl + M, lane);
@@ -290,8 +306,8 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void k_render_rays(RenderRaysParams p
             {
                 const size_t n = (size_t)nt * S, ngroups = (n + GROUP - 1) / GROUP;
                 for (size_t g = 0; g < ngroups; ++g)
-                    mlp_forward_group<true, true, MLP_BLOCK, false>(lds, g, n, S, nullptr, vi, bc, p.fieldT, nullptr, p.pk, sigma, nullptr,
-                                                                    FwdSave{}, nullptr);
+                    mlp_forward_group<true, true, RR_BLOCK, false>(lds, g, n, S, nullptr, vi, bc, p.fieldT, nullptr, p.pk, sigma, nullptr,
+                                                                   FwdSave{});
             }
             __syncthreads();
             tick(1);
@@ -317,8 +333,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void k_render_rays(RenderRaysParams p
         {
             const size_t n = (size_t)nt * Sf, ngroups = (n + GROUP - 1) / GROUP;
             for (size_t g = 0; g < ngroups; ++g)
-                mlp_forward_group<true, false, MLP_BLOCK, false>(lds, g, n, Sf, nullptr, vi, bc, p.fieldT, enc, p.pk, sigma, rgb, FwdSave{},
-                                                                 bias);
+                mlp_forward_group<true, false, RR_BLOCK, false>(lds, g, n, Sf, nullptr, vi, bc, p.fieldT, hterm, p.pk, sigma, rgb, FwdSave{});
         }
         __syncthreads();
         tick(3);
@@ -330,7 +345,8 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void k_render_rays(RenderRaysParams p
                           p.out_acc + ray, p.out_depth + ray, nullptr, lane);
         }
         tick(4);
-        // (the next tile's first ray phase writes edges_c / enc / vi / bc: all of them last read before the barrier above;
+        tq += nt;
+        // (the next tile's first ray phase writes edges_c / hterm / vi / bc: all of them last read before the barrier above;
         //  its LDS use starts after this wave's own composite; sigma / rgb are next written after two more barriers)
     }
     if (p.prof && threadIdx.x == 0) {
@@ -343,18 +359,17 @@ size_t render_rays_scratch_floats(size_t r_max, uint32_t S, uint32_t S_fine, boo
     auto al = [](size_t x) { return (x + 3) & ~(size_t)3; };   // 16-byte aligned pieces
     const uint32_t nb = S_fine + 1;
     const uint32_t Sf = S_fine ? S + nb : S;
-    const size_t per_ray = (size_t)(S + 1) + (S_fine ? (size_t)(Sf + 1) : 0) + ENC_PAD + (has_bias ? HID : 0) + (size_t)Sf * 11;
+    const size_t per_ray = (size_t)(S + 1) + (S_fine ? (size_t)(Sf + 1) : 0) + HID + (size_t)Sf * 11;
     const size_t rays_per_block = (r_max + grid - 1) / grid;
-    size_t T = ((size_t)4 << 20) / (per_ray * sizeof(float));      // <= 4 MB of scratch per block
+    size_t T = ((size_t)2 << 20) / (per_ray * sizeof(float));      // <= 2 MB of scratch per block
     if (T < 8) T = 8;
-    if (T > 64 * (MLP_BLOCK / 64)) T = 64 * (MLP_BLOCK / 64);      // a wave keeps its rays' ids in one register, lane i = ray i
+    if (T > 64 * (RR_BLOCK / 64)) T = 64 * (RR_BLOCK / 64);        // a wave keeps its rays' ids in one register, lane i = ray i
     if (T > rays_per_block) T = rays_per_block;
     if (T < 1) T = 1;
     L.T = (uint32_t)T;
     size_t o = al(T * (S + 1));
     L.o_edges_f = o; o = al(o + (S_fine ? T * (Sf + 1) : 0));
-    L.o_enc = o; o = al(o + T * ENC_PAD);
-    L.o_bias = o; o = al(o + (has_bias ? T * HID : 0));
+    L.o_hterm = o; o = al(o + T * HID);
     L.o_vi = o; o = al(o + T * Sf * 4);
     L.o_bc = o; o = al(o + T * Sf * 3);
     L.o_sigma = o; o = al(o + T * Sf);
@@ -372,28 +387,28 @@ void launch_render_rays(const uint32_t *num_visited, const float *dist, const fl
     const uint32_t nb = S_fine + 1;
     const size_t region = std::max<size_t>(std::max<size_t>(2 * (size_t)M, (size_t)M + 1),
                                            S_fine ? (((size_t)S + 3) & ~(size_t)3) + pdf_lds_floats(S, nb) : 0);
-    const size_t lds_floats = std::max<size_t>(MAX_STAGE_FLOATS, (MLP_BLOCK / 64) * region);
+    const size_t lds_floats = std::max<size_t>(MAX_STAGE_FLOATS, (RR_BLOCK / 64) * region);
     const size_t smem = lds_floats * sizeof(float);
-    if (smem > 160 * 1024) throw Error("render_rays: max_ray_triangles / samples per ray too large for the per-wave LDS regions");
+    if (smem > 80 * 1024) throw Error("render_rays: max_ray_triangles / samples per ray too large for the per-wave LDS regions");
     RenderRaysParams p{};
     p.num_visited = num_visited; p.dist = dist; p.bary = bary; p.verts = verts; p.M = M;
     p.ray_index = ray_index; p.count = count; p.r_max = r_max;
     p.S = S; p.S_fine = S_fine; p.biased = biased ? 1 : 0;
     p.lin = lin; p.u_table = u_table; p.hist_pad = hist_pad; p.eps = eps;
-    p.fieldT = fieldT; p.dirs = dirs; p.ray_bias = ray_bias; p.pk = w.pk_gather; p.bg = background;
+    p.fieldT = fieldT; p.dirs = dirs; p.ray_bias = ray_bias; p.wenc = w.wenc; p.pk = w.pk_gather; p.bg = background;
     p.out_rgb = out_rgb; p.out_acc = out_acc; p.out_depth = out_depth;
     p.scratch = scratch; p.per_block = L.per_block; p.T = L.T;
-    p.o_edges_f = L.o_edges_f; p.o_enc = L.o_enc; p.o_bias = L.o_bias; p.o_vi = L.o_vi; p.o_bc = L.o_bc;
+    p.o_edges_f = L.o_edges_f; p.o_hterm = L.o_hterm; p.o_vi = L.o_vi; p.o_bc = L.o_bc;
     p.o_sigma = L.o_sigma; p.o_rgb = L.o_rgb;
     p.region = (uint32_t)region;
     p.prof = prof;
     static PerDeviceOnce lds_attr;
     lds_attr.run([&] {
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<false>), 160 * 1024);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<true>), 160 * 1024);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<false>), 80 * 1024);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<true>), 80 * 1024);
     });
-    if (S_fine) hipLaunchKernelGGL(k_render_rays<true>, dim3(grid), dim3(MLP_BLOCK), smem, stream, p);
-    else hipLaunchKernelGGL(k_render_rays<false>, dim3(grid), dim3(MLP_BLOCK), smem, stream, p);
+    if (S_fine) hipLaunchKernelGGL(k_render_rays<true>, dim3(grid), dim3(RR_BLOCK), smem, stream, p);
+    else hipLaunchKernelGGL(k_render_rays<false>, dim3(grid), dim3(RR_BLOCK), smem, stream, p);
 }
 
 }  // namespace tn

@@ -2,7 +2,7 @@
 
 With only the `tetranerf_cpp_extension` shim `ns-train tetra-nerf` runs the HIP tracer, matcher
 and gather, but the MLP, the samplers and the renderers stay nerfstudio's PyTorch modules -- the fp32-MFMA MLP
-(`tn_mlp_forward_gather`), the one-launch render pass (`tn_render_pass`) and the training adjoints (`tn_mlp_backward`,
+(`tn_mlp_forward_gather`), the one-launch render (`tn_render_rays`) and the training adjoints (`tn_mlp_backward`,
 `tn_composite_backward`) are never reached.  This module closes that gap without touching the reference's files:
 
     import tetranerf.nerfstudio.model as ref_model

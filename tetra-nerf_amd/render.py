@@ -421,7 +421,7 @@ class TetraRenderer:
     def _one_launch_ok(self, mode):
         """tn_render_rays' preconditions: fp32 arithmetic, device samplers, max(2 M, 3 S + S_fine + 6) floats of LDS per wave."""
         region = max(2 * self.M, (3 * self.S + self.S_fine + 6) if self.S_fine else 0)
-        return (self.fused_pass is not False and mode == "fp32" and self.device_samplers and 8 * 4 * region <= 160 * 1024
+        return (self.fused_pass is not False and mode == "fp32" and self.device_samplers and 4 * 4 * region <= 80 * 1024
                 and self.S + self.S_fine + 2 <= 8192)
 
     @torch.no_grad()

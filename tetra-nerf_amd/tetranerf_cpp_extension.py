@@ -124,7 +124,7 @@ class TetrahedraTracer:
     def trace_rays(self, ray_origins, ray_directions, max_ray_triangles, compact_rows: bool = False):
         """PyTetrahedraTracer::trace_rays (py_binding.cpp:41-76).  compact_rows (no reference counterpart; per call):
         slots >= num_visited_cells are left unwritten (tn_trace_rays_ex + TN_TRACE_COMPACT_ROWS) for consumers that read
-        the rows only through num_visited_cells (the samplers, find_visited_cells(ray_index=...), render_pass)."""
+        the rows only through num_visited_cells (the samplers, find_visited_cells(ray_index=...), render_rays)."""
         M = int(max_ray_triangles)
         if M <= 0 or (M & (M - 1)) != 0:
             raise RuntimeError("max_ray_triangles must be a power of 2.")
@@ -667,49 +667,6 @@ def _background(background, clamp=False):
         background = (background,) * 3
     r, g, b = (float(x) for x in background)
     return C.byref(_RgbBackground(r, g, b, 1 if clamp else 0))
-
-
-def render_pass(trace_lists, ray_index, edges, field, dirs, weights, out=None, background=1.0, clamp=False, ray_head_bias=None):
-    """One render pass as ONE launch (tn_render_pass): sample matching + barycentric gather + MLP + composite on the
-    trace rows of the hitting rays in place.  trace_lists = (num_visited_cells [R], visited_cells, barycentric_coordinates
-    [R,M,2,3], hit_distances [R,M,2], vertex_indices [R,M,4]) as returned by trace_rays; ray_index i32 [r]; edges f32
-    [r, S+1].  dirs=None: density-only coarse pass -> weights f32 [r, S].  Otherwise dirs f32 [r, 3] and
-    out = (rgb [R,3], accumulation [R,1] or [R], depth [R,1] or [R]) pre-filled with the background values: the rows at
-    ray_index are overwritten; returns None."""
-    nv, _cells, bary, dist, verts = trace_lists
-    for x, name in ((nv, "num_visited_cells"), (bary, "barycentric_coordinates"), (dist, "hit_distances"),
-                    (verts, "vertex_indices"), (ray_index, "ray_index"), (edges, "edges"), (field, "field")):
-        _check_input(x, name)
-    M = dist.size(1)
-    _check(dist.dim() == 3 and dist.size(2) == 2 and verts.size(1) == M and bary.size(1) == M, "trace rows must share M")
-    _check(ray_index.dtype == torch.int32 and ray_index.dim() == 1, "ray_index must be i32 [r]")
-    r, S = ray_index.numel(), edges.size(-1) - 1
-    _check(edges.dtype == torch.float32 and tuple(edges.shape) == (r, S + 1), "edges must be f32 [r, S+1]")
-    _check(S >= 64 and M <= 512, "render_pass needs S >= 64 samples per ray and max_ray_triangles <= 512")
-    _check(field.dtype == torch.float32 and field.dim() == 2 and field.size(0) == 64, "field must be f32 [64, V]")
-    m = fused_mlp(weights)
-    dev = field.device
-    field_vm = field_vertex_major(field)
-    density_only = dirs is None
-    w_out = None
-    lib = _lib.load()
-    with torch.cuda.device(dev):
-        if density_only:
-            w_out = _empty((r, S), dtype=torch.float32, device=dev)
-            _lib.check(lib.tn_render_pass(m.handle, M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S,
-                                          _ptr(edges), _ptr(field_vm), None, None, _ptr(w_out), None, None, None, None,
-                                          _stream(dev)))
-        else:
-            _check_input(dirs, "dirs")
-            _check(dirs.dtype == torch.float32 and tuple(dirs.shape) == (r, 3), "dirs must be f32 [r, 3]")
-            rgb, acc, depth = out
-            for x, name in ((rgb, "rgb"), (acc, "accumulation"), (depth, "depth")):
-                _check_input(x, name)
-                _check(x.dtype == torch.float32 and x.size(0) == nv.numel(), f"{name} must be f32 over all rays")
-            _lib.check(lib.tn_render_pass(m.handle, M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(ray_index), r, S,
-                                          _ptr(edges), _ptr(field_vm), _ptr(dirs), _background(background, clamp), None, _ptr(rgb), _ptr(acc),
-                                          _ptr(depth), _ptr(_ray_bias(ray_head_bias, r, dev)), _stream(dev)))
-    return w_out
 
 
 def render_rays(trace_lists, order, count, field, directions, weights, num_samples, num_fine=0, biased=False, out=None,
