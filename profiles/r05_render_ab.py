@@ -27,7 +27,9 @@ torch.manual_seed(0)
 mlp = render.TetraMLP().to(dev)
 field = ((torch.rand(64, len(pts), device=dev) * 2 - 1) * 1e-4)
 field[1:4] = torch.rand(3, len(pts), device=dev) * 2 - 1
-R, chunk, M = o.shape[0], 65536, 512
+R, M = o.shape[0], 512
+chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 65536      # rays per render() call (nerfstudio's eval default: 4096)
+print(f"chunks of {chunk} rays")
 
 
 def frame(rd):

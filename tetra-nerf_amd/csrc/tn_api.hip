@@ -1026,7 +1026,7 @@ int tn_render_rays(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const 
         if ((size_t)num_samples + num_fine + 2 > 8192) throw tn::Error("render_rays: too many samples per ray");
         DeviceGuard g(m->device);
         if (!m->packed) throw tn::Error("tn_mlp_set_weights must be called first");
-        const unsigned grid = 512;   // two persistent 4-wave blocks per CU (tn_render_rays.hip)
+        const unsigned grid = 256;   // one persistent 8-wave block per CU (tn_render_rays.hip)
         tn::RenderRaysLayout L{};
         const size_t need = tn::render_rays_scratch_floats(num_hit_rays_max, num_samples, num_fine, ray_head_bias != nullptr, grid, L);
         if (m->render_scratch.n < need) {

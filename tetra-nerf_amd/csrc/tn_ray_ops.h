@@ -95,19 +95,13 @@ __device__ __forceinline__ void lds_sync() {
 // Coarse sampler of one hitting ray (model.py:531-557, 111-122, 166-177): near / far + the S + 1 bin edges.
 // `ray` = its row in the trace outputs; lin [S+1] = linspace(0, 1, S+1); t_row [S+1] uniform draws of THIS ray or null
 // (evaluation); cum: M + 1 floats of LDS owned by the wave (biased only); edges [S+1], near_far [2] of THIS ray.
-// nb = num_visited[ray] (the caller has it: the persistent kernel loads the counts of a whole tile at once); near_far (nullable)
-// [2] of THIS ray; near / far are returned as well.
-__device__ __forceinline__ void ray_sample_coarse(uint32_t S, uint32_t M, size_t ray, uint32_t nb,
-                                                  const float *__restrict__ hit_dist, const float *__restrict__ lin,
-                                                  const float *__restrict__ t_row, int biased, float *__restrict__ edges,
-                                                  float *__restrict__ near_far, float *cum, int lane, float &near_out, float &far_out) {
+// ray_sample_coarse_nf: nb = num_visited[ray] and the ray's near / far are the CALLER's (the persistent kernel loads them for a
+// whole tile at once); edges2 (nullable): a second copy of the edges, e.g. in the wave's LDS for the matcher that follows.
+__device__ __forceinline__ void ray_sample_coarse_nf(uint32_t S, uint32_t M, size_t ray, uint32_t nb, float near, float far,
+                                                     const float *__restrict__ hit_dist, const float *__restrict__ lin,
+                                                     const float *__restrict__ t_row, int biased, float *__restrict__ edges,
+                                                     float *edges2, float *cum, int lane) {
     const float2 *row = reinterpret_cast<const float2 *>(hit_dist + ray * (size_t)M * 2);
-    // (a ray that misses the mesh has no row -- with compact rows not even a written one: the sync-free training path
-    // names such rays only when a whole batch misses; their samples are discarded, they just have to be finite)
-    const float near = nb ? row[0].x : 0.0f;
-    const float far = nb ? row[nb - 1].y : 1.0f;
-    near_out = near; far_out = far;
-    if (lane == 0 && near_far) { near_far[0] = near; near_far[1] = far; }
     if (biased) {
         // lengths (clamped at 0: the cell -1 closing segments) and their running sum from the first entry point
         float carry = near;   // bounds_start = hit_distances[..., 0, 0]
@@ -142,8 +136,23 @@ __device__ __forceinline__ void ray_sample_coarse(uint32_t S, uint32_t M, size_t
             e = cum[i] + fmaxf(s.y - s.x, 0.f) * rest;
         }
         edges[j] = e;
+        if (edges2) edges2[j] = e;
     }
-    if (biased) lds_sync();
+    if (biased || edges2) lds_sync();
+}
+
+// the same with near / far read from the ray's row (the stand-alone kernel); near_far [2] of THIS ray
+__device__ __forceinline__ void ray_sample_coarse(uint32_t S, uint32_t M, size_t ray, uint32_t nb,
+                                                  const float *__restrict__ hit_dist, const float *__restrict__ lin,
+                                                  const float *__restrict__ t_row, int biased, float *__restrict__ edges,
+                                                  float *__restrict__ near_far, float *cum, int lane) {
+    const float2 *row = reinterpret_cast<const float2 *>(hit_dist + ray * (size_t)M * 2);
+    // (a ray that misses the mesh has no row -- with compact rows not even a written one: the sync-free training path
+    // names such rays only when a whole batch misses; their samples are discarded, they just have to be finite)
+    const float near = nb ? row[0].x : 0.0f;
+    const float far = nb ? row[nb - 1].y : 1.0f;
+    if (lane == 0) { near_far[0] = near; near_far[1] = far; }
+    ray_sample_coarse_nf(S, M, ray, nb, near, far, hit_dist, lin, t_row, biased, edges, nullptr, cum, lane);
 }
 
 // The binary searches of searchsorted / the merge by rank, for the CH items a lane owns AT ONCE: the classic lo / hi / mid loop
@@ -189,7 +198,7 @@ template <int CH>
 __device__ __forceinline__ void ray_sample_pdf_chunks(uint32_t S, uint32_t nb, const float *__restrict__ e, const float *__restrict__ w,
                                                       float near, float far, const float *__restrict__ u_table,
                                                       const float *__restrict__ u_row, float histogram_padding, float eps,
-                                                      float *__restrict__ o, float *lds, int lane) {
+                                                      float *__restrict__ o, float *lds, int lane, float *o2 = nullptr) {
     float *cdf = lds;                // [S+1]
     float *sp = cdf + (S + 1);       // [S+1] spacing edges
     float *nw = sp + (S + 1);        // [nb]  new bins
@@ -270,13 +279,21 @@ __device__ __forceinline__ void ray_sample_pdf_chunks(uint32_t S, uint32_t nb, c
     multi_search<CH, false>(nw, nb, vv, on2, rk);            // new bins strictly below v
 #pragma unroll
     for (int c = 0; c < CH; ++c)
-        if (on2[c]) o[64u * c + lane + rk[c]] = vv[c] * far + (1.0f - vv[c]) * near;
+        if (on2[c]) {
+            const float ev2 = vv[c] * far + (1.0f - vv[c]) * near;
+            o[64u * c + lane + rk[c]] = ev2;
+            if (o2) o2[64u * c + lane + rk[c]] = ev2;
+        }
 #pragma unroll
     for (int c = 0; c < CH; ++c) { const uint32_t k = 64u * c + lane; on2[c] = k < nb; vv[c] = on2[c] ? nw[k] : 0.f; }
     multi_search<CH, true>(sp, S + 1, vv, on2, rk);          // coarse edges <= v
 #pragma unroll
     for (int c = 0; c < CH; ++c)
-        if (on2[c]) o[64u * c + lane + rk[c]] = vv[c] * far + (1.0f - vv[c]) * near;
+        if (on2[c]) {
+            const float ev2 = vv[c] * far + (1.0f - vv[c]) * near;
+            o[64u * c + lane + rk[c]] = ev2;
+            if (o2) o2[64u * c + lane + rk[c]] = ev2;
+        }
     lds_sync();
 }
 
@@ -346,12 +363,15 @@ __device__ __forceinline__ void ray_sample_pdf_loops(uint32_t S, uint32_t nb, co
 __device__ __forceinline__ void ray_sample_pdf(uint32_t S, uint32_t nb, const float *__restrict__ e, const float *__restrict__ w,
                                                float near, float far, const float *__restrict__ u_table,
                                                const float *__restrict__ u_row, float histogram_padding, float eps,
-                                               float *__restrict__ o, float *lds, int lane) {
+                                               float *__restrict__ o, float *lds, int lane, float *o2 = nullptr) {
+    // o2 (nullable): a second copy of the merged edges (the wave's LDS, for the matcher that follows); returns through *o2
+    // only in the chunk forms -- the caller falls back to `o` otherwise (pdf_writes_second_copy)
     const uint32_t big = S + 1 > nb ? S + 1 : nb;       // wave-uniform dispatch on the chunks a lane owns
-    if (big <= 64 * 3) ray_sample_pdf_chunks<3>(S, nb, e, w, near, far, u_table, u_row, histogram_padding, eps, o, lds, lane);
-    else if (big <= 64 * 5) ray_sample_pdf_chunks<5>(S, nb, e, w, near, far, u_table, u_row, histogram_padding, eps, o, lds, lane);
+    if (big <= 64 * 3) ray_sample_pdf_chunks<3>(S, nb, e, w, near, far, u_table, u_row, histogram_padding, eps, o, lds, lane, o2);
+    else if (big <= 64 * 5) ray_sample_pdf_chunks<5>(S, nb, e, w, near, far, u_table, u_row, histogram_padding, eps, o, lds, lane, o2);
     else ray_sample_pdf_loops(S, nb, e, w, near, far, u_table, u_row, histogram_padding, eps, o, lds, lane);
 }
+__host__ __device__ constexpr bool pdf_writes_second_copy(uint32_t S, uint32_t nb) { return (S + 1 > nb ? S + 1 : nb) <= 64 * 5; }
 
 // RaySamples.get_weights + RGB (background blend) / accumulation / median-depth renderers of one ray (model.py:632-662):
 // sigma [S], rgb [S,3] (null: weights only), e [S+1]; out_rgb3 / out_acc / out_depth: where THIS ray's results go (null: not

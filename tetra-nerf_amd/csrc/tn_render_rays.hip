@@ -64,10 +64,24 @@ struct RenderRaysParams {
 // one ray's samples (the bin centres of e[0 .. S]) against its segments: vi [S] x 4 ids, bc [S] x 3 weights.  The expressions
 // are k_find_matched's (tn_match.hip); only vertex ids and barycentrics are produced (the MLP kernel reads nothing else).
 // tin / pmax: 2 M floats of LDS owned by the wave.
-// n = num_visited[src] (the kernel loads the counts of a whole tile at once: no dependent load here).
+// n = num_visited[src] (the kernel loads the counts of a whole tile at once: no dependent load here); dv0: the ray's first 512
+// segment bounds as load_bounds() requested them (the caller issues that ahead of the sampler / composite of the same ray, so
+// that the rows are back when the matcher starts); e: global or LDS.
+__device__ __forceinline__ void load_bounds(uint32_t M, size_t src, uint32_t n, const RenderRaysParams &p, float2 (&dv)[8], int lane) {
+    if (n > M) n = M;
+    const float2 *drow = reinterpret_cast<const float2 *>(p.dist) + src * M;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t j = 64u * c + lane;
+        dv[c] = make_float2(0.f, -INFINITY);
+        if (j < n) dv[c] = drow[j];
+    }
+}
+
 template <int UM>
-__device__ __forceinline__ void ray_match(uint32_t S, uint32_t M, size_t src, uint32_t n, const RenderRaysParams &p, const float *__restrict__ e,
-                                          uint32_t *__restrict__ vi_out, float *__restrict__ bc_out, float *tin, float *pmax, int lane) {
+__device__ __forceinline__ void ray_match(uint32_t S, uint32_t M, size_t src, uint32_t n, const RenderRaysParams &p, const float *e,
+                                          uint32_t *__restrict__ vi_out, float *__restrict__ bc_out, float *tin, float *pmax, int lane,
+                                          const float2 (&dv0)[8]) {
     if (n > M) n = M;
     const float2 *drow = reinterpret_cast<const float2 *>(p.dist) + src * M;
     // do the sample distances ascend?  (distance j = centre of bin j, as the callers of find_visited_cells compute it.)  The
@@ -97,8 +111,8 @@ __device__ __forceinline__ void ray_match(uint32_t S, uint32_t M, size_t src, ui
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t j = base0 + 64u * c + lane;
-            dv[c] = make_float2(0.f, -INFINITY);
-            if (j < n) dv[c] = drow[j];
+            dv[c] = dv0[c];
+            if (base0) { dv[c] = make_float2(0.f, -INFINITY); if (j < n) dv[c] = drow[j]; }   // (rays with more than 512 segments)
             mx[c] = dv[c].y;
         }
         wave_incl_max_multi<8>(mx, lane);
@@ -225,11 +239,11 @@ __device__ __forceinline__ void wave_global_sync() {
 
 }  // namespace
 
-// 4-wave blocks, TWO per CU (the staged head layer is 68 KB since the encoding's columns left it): while one block of a CU is in
-// a ray phase -- latency-bound wave-per-ray work that leaves the matrix cores idle -- the other one's MLP phase has them to
-// itself.  Blocks of a CU would run in lockstep (same work), so the blocks of one of the two residency classes start with a
-// half tile (see `stagger`).
-constexpr int RR_BLOCK = 256;
+// One 8-wave block per CU, like k_mlp_forward.  Measured and dropped (profiles/r05h_render_ab.txt): 4-wave blocks, two per CU
+// (the staged head layer is 68 KB since the encoding's columns left it), started half a tile apart so that one block's ray
+// phases fall into the other one's MLP phases -- the MLP phases of 4-wave blocks (128-sample groups: twice the weight staging
+// and barriers per sample) lost more than the overlap gained: 3.6 % behind the kernel chain instead of 1.3 %.
+constexpr int RR_BLOCK = MLP_BLOCK;
 
 template <bool FINE>
 __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p) {
@@ -250,13 +264,8 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
     float *wl = lds + (size_t)wave * p.region;              // this wave's LDS for the ray phases (aliases the weight stage)
 
     const uint32_t nrays = (uint32_t)(q1 - q0);
-    // at least two tiles per block (where it has the rays), even ones: one partial MLP group per tile at most
-    uint32_t ntiles = (nrays + p.T - 1) / p.T;
-    if (ntiles < 2 && nrays >= 8) ntiles = 2;
-    const uint32_t tile = (nrays + ntiles - 1) / ntiles;
-    // which two blocks share a CU is the dispatcher's business (b and b + 1, or b and b + gridDim / 2): the blocks whose
-    // index differs in bit 0 XOR the top bit start with half a tile, so that either pairing puts the two out of phase
-    const bool stagger = (((blockIdx.x & 1u) ^ ((2u * blockIdx.x / gridDim.x) & 1u)) != 0u) && tile >= 4;
+    const uint32_t ntiles = (nrays + p.T - 1) / p.T;
+    const uint32_t tile = (nrays + ntiles - 1) / ntiles;    // even tiles: one partial MLP group per tile at most
     constexpr size_t GROUP = (size_t)NW * 32;
 
     unsigned long long t_prev = p.prof ? wall_clock64() : 0ull, acc_t[6] = {0, 0, 0, 0, 0, 0};
@@ -265,9 +274,8 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
     };
     // per-wave LDS for ray phase 2: [coarse weights: S floats][PDF sampler], re-used by the matcher afterwards
     const uint32_t w_floats = (S + 3u) & ~3u;
-    for (size_t tq = q0, first = 1; tq < q1; first = 0) {
-        uint32_t nt = (first && stagger) ? tile / 2 : tile;
-        if (q1 - tq < nt) nt = (uint32_t)(q1 - tq);
+    for (size_t tq = q0; tq < q1;) {
+        const uint32_t nt = (uint32_t)(q1 - tq < tile ? q1 - tq : tile);
         // This wave's rays of the tile are t = wave + NW i, i = 0, 1, ...: lane i holds ray i's row index, segment count and --
         // after phase 1 -- near / far, for all three ray phases (T <= 64 NW): a ray phase starts without a dependent load chain
         // (ray id -> count -> rows), which a wave that owns its ray alone would pay in full, three times per ray.
@@ -277,16 +285,24 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
             l_ray = p.ray_index[tq + wave + (size_t)NW * lane];
             l_nv = p.num_visited[l_ray];
         }
-        // ---- ray phase 1: coarse sampler -> matcher (+ direction encoding, head bias row) of this wave's rays
+        if ((uint32_t)wave + (uint32_t)NW * lane < nt) {     // (after l_nv: near / far as ray_sample_coarse reads them)
+            const float2 *row = reinterpret_cast<const float2 *>(p.dist) + (size_t)l_ray * M;
+            l_near = l_nv ? row[0].x : 0.0f;
+            l_far = l_nv ? row[l_nv - 1].y : 1.0f;
+        }
+        // ---- ray phase 1: coarse sampler -> matcher (+ the head layer's per-ray term) of this wave's rays.  The edges reach
+        //      the matcher through the wave's LDS (and global memory for the later phases): no store -> load round trip
+        float *el = wl + 2 * (size_t)M;                      // [S + 1] behind the matcher's tin / pmax
         for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
             const size_t ray = (uint32_t)__builtin_amdgcn_readlane((int)l_ray, (int)i);
             const uint32_t nv = (uint32_t)__builtin_amdgcn_readlane((int)l_nv, (int)i);
+            const float near = __shfl(l_near, (int)i), far = __shfl(l_far, (int)i);
+            float2 dv[8];
+            load_bounds(M, ray, nv, p, dv, lane);            // back by the time the matcher wants them
             float *e = edges_c + (size_t)t * (S + 1);
-            float near, far;
-            ray_sample_coarse(S, M, ray, nv, p.dist, p.lin, nullptr, p.biased, e, nullptr, wl, lane, near, far);
-            if (lane == (int)i) { l_near = near; l_far = far; }
+            ray_sample_coarse_nf(S, M, ray, nv, near, far, p.dist, p.lin, nullptr, p.biased, e, el, wl, lane);
             // the head layer's per-ray term: Wh[:, :27] enc(dir) + the appearance embedding's bias (k_head_ray_term's expression)
-            ray_dir_encoding(p.dirs + 3 * ray, wl, lane);           // (28 floats of the wave's LDS: the sampler is done with it)
+            ray_dir_encoding(p.dirs + 3 * ray, wl, lane);   // (28 floats of the wave's LDS: the sampler is done with `cum`)
             lds_sync();
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -295,9 +311,9 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
                 if (p.ray_bias) tv += p.ray_bias[ray * HID + o];
                 hterm[(size_t)t * HID + o] = tv;
             }
-            wave_global_sync();
-            if (S <= 256) ray_match<4>(S, M, ray, nv, p, e, vi + 4 * (size_t)t * S, bc + 3 * (size_t)t * S, wl, wl + M, lane);
-            else ray_match<9>(S, M, ray, nv, p, e, vi + 4 * (size_t)t * S, bc + 3 * (size_t)t * S, wl, wl + M, lane);
+            lds_sync();
+            if (S <= 256) ray_match<4>(S, M, ray, nv, p, el, vi + 4 * (size_t)t * S, bc + 3 * (size_t)t * S, wl, wl + M, lane, dv);
+            else ray_match<9>(S, M, ray, nv, p, el, vi + 4 * (size_t)t * S, bc + 3 * (size_t)t * S, wl, wl + M, lane, dv);
         }
         __syncthreads();
         tick(0);
@@ -313,18 +329,26 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
             tick(1);
             // ---- ray phase 2: get_weights -> PDF sampler -> matcher of the fine samples.  The coarse weights go from the
             //      composite to the sampler through the wave's LDS (the kernel chain writes and re-reads them in HBM)
+            // LDS of the wave: [coarse weights S | PDF sampler] then -- the matcher re-uses that part for tin / pmax -- the merged
+            // fine edges behind both
+            const size_t o_merged = std::max<size_t>(2 * (size_t)M, w_floats + pdf_lds_floats(S, nb));
+            const bool lds_edges = pdf_writes_second_copy(S, nb);
             for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
                 const size_t ray = (uint32_t)__builtin_amdgcn_readlane((int)l_ray, (int)i);
                 const uint32_t nv = (uint32_t)__builtin_amdgcn_readlane((int)l_nv, (int)i);
                 const float near = __shfl(l_near, (int)i), far = __shfl(l_far, (int)i);
+                float2 dv[8];
+                load_bounds(M, ray, nv, p, dv, lane);        // in flight during the composite and the sampler
                 const float *e = edges_c + (size_t)t * (S + 1);
                 ray_composite(S, sigma + (size_t)t * S, nullptr, e, p.bg, nullptr, nullptr, nullptr, wl, lane);
                 lds_sync();
                 float *ef = edges_f + (size_t)t * (Sf + 1);
-                ray_sample_pdf(S, nb, e, wl, near, far, p.u_table, nullptr, p.hist_pad, p.eps, ef, wl + w_floats, lane);
-                wave_global_sync();
-                if (Sf <= 256) ray_match<4>(Sf, M, ray, nv, p, ef, vi + 4 * (size_t)t * Sf, bc + 3 * (size_t)t * Sf, wl, wl + M, lane);
-                else ray_match<9>(Sf, M, ray, nv, p, ef, vi + 4 * (size_t)t * Sf, bc + 3 * (size_t)t * Sf, wl, wl + M, lane);
+                float *efl = wl + o_merged;
+                ray_sample_pdf(S, nb, e, wl, near, far, p.u_table, nullptr, p.hist_pad, p.eps, ef, wl + w_floats, lane, efl);
+                const float *em = efl;
+                if (!lds_edges) { wave_global_sync(); em = ef; }
+                if (Sf <= 256) ray_match<4>(Sf, M, ray, nv, p, em, vi + 4 * (size_t)t * Sf, bc + 3 * (size_t)t * Sf, wl, wl + M, lane, dv);
+                else ray_match<9>(Sf, M, ray, nv, p, em, vi + 4 * (size_t)t * Sf, bc + 3 * (size_t)t * Sf, wl, wl + M, lane, dv);
             }
             __syncthreads();
             tick(2);
@@ -361,7 +385,7 @@ size_t render_rays_scratch_floats(size_t r_max, uint32_t S, uint32_t S_fine, boo
     const uint32_t Sf = S_fine ? S + nb : S;
     const size_t per_ray = (size_t)(S + 1) + (S_fine ? (size_t)(Sf + 1) : 0) + HID + (size_t)Sf * 11;
     const size_t rays_per_block = (r_max + grid - 1) / grid;
-    size_t T = ((size_t)2 << 20) / (per_ray * sizeof(float));      // <= 2 MB of scratch per block
+    size_t T = ((size_t)4 << 20) / (per_ray * sizeof(float));      // <= 4 MB of scratch per block
     if (T < 8) T = 8;
     if (T > 64 * (RR_BLOCK / 64)) T = 64 * (RR_BLOCK / 64);        // a wave keeps its rays' ids in one register, lane i = ray i
     if (T > rays_per_block) T = rays_per_block;
@@ -385,11 +409,14 @@ void launch_render_rays(const uint32_t *num_visited, const float *dist, const fl
                         float *scratch, const RenderRaysLayout &L, unsigned grid, hipStream_t stream, unsigned long long *prof) {
     if (r_max == 0) return;
     const uint32_t nb = S_fine + 1;
-    const size_t region = std::max<size_t>(std::max<size_t>(2 * (size_t)M, (size_t)M + 1),
-                                           S_fine ? (((size_t)S + 3) & ~(size_t)3) + pdf_lds_floats(S, nb) : 0);
+    // per wave: phase 1 = [tin / pmax (or the biased sampler's cum): 2 M][coarse edges: S + 1]; phase 2 = [coarse weights |
+    // PDF sampler, re-used as tin / pmax][merged fine edges: S + nb + 1]
+    const size_t w_fl = ((size_t)S + 3) & ~(size_t)3;
+    const size_t region = (std::max<size_t>(2 * (size_t)M + (S + 1), S_fine ? std::max<size_t>(2 * (size_t)M, w_fl + pdf_lds_floats(S, nb)) +
+                                                                                  (size_t)S + nb + 1 : 0) + 3) & ~(size_t)3;
     const size_t lds_floats = std::max<size_t>(MAX_STAGE_FLOATS, (RR_BLOCK / 64) * region);
     const size_t smem = lds_floats * sizeof(float);
-    if (smem > 80 * 1024) throw Error("render_rays: max_ray_triangles / samples per ray too large for the per-wave LDS regions");
+    if (smem > 160 * 1024) throw Error("render_rays: max_ray_triangles / samples per ray too large for the per-wave LDS regions");
     RenderRaysParams p{};
     p.num_visited = num_visited; p.dist = dist; p.bary = bary; p.verts = verts; p.M = M;
     p.ray_index = ray_index; p.count = count; p.r_max = r_max;
@@ -404,8 +431,8 @@ void launch_render_rays(const uint32_t *num_visited, const float *dist, const fl
     p.prof = prof;
     static PerDeviceOnce lds_attr;
     lds_attr.run([&] {
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<false>), 80 * 1024);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<true>), 80 * 1024);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<false>), 160 * 1024);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<true>), 160 * 1024);
     });
     if (S_fine) hipLaunchKernelGGL(k_render_rays<true>, dim3(grid), dim3(RR_BLOCK), smem, stream, p);
     else hipLaunchKernelGGL(k_render_rays<false>, dim3(grid), dim3(RR_BLOCK), smem, stream, p);

@@ -39,9 +39,8 @@ __global__ __launch_bounds__(SB) void k_sample_coarse(size_t r, uint32_t S, uint
     float *cum = smem + (size_t)wave * (M + 1);          // biased: cum[i] = start + sum of the first i segment lengths
     for (size_t q = (size_t)blockIdx.x * (SB / 64) + wave; q < r; q += (size_t)gridDim.x * (SB / 64)) {
         const size_t ray = ray_index[q];
-        float near, far;
         ray_sample_coarse(S, M, ray, num_visited[ray], hit_dist, lin, t_rand ? t_rand + q * (size_t)(S + 1) : nullptr, biased,
-                          edges + q * (size_t)(S + 1), near_far + 2 * q, cum, lane, near, far);
+                          edges + q * (size_t)(S + 1), near_far + 2 * q, cum, lane);
     }
 }
 

@@ -419,9 +419,9 @@ class TetraRenderer:
         return background if isinstance(background, (int, float)) else tuple(float(x) for x in background_tensor(background).tolist())
 
     def _one_launch_ok(self, mode):
-        """tn_render_rays' preconditions: fp32 arithmetic, device samplers, max(2 M, 3 S + S_fine + 6) floats of LDS per wave."""
-        region = max(2 * self.M, (3 * self.S + self.S_fine + 6) if self.S_fine else 0)
-        return (self.fused_pass is not False and mode == "fp32" and self.device_samplers and 4 * 4 * region <= 80 * 1024
+        """tn_render_rays' preconditions: fp32 arithmetic, device samplers, the per-wave LDS regions of its ray phases fit."""
+        region = max(2 * self.M + self.S + 1, (max(2 * self.M, 3 * self.S + self.S_fine + 6) + 2 * self.S + self.S_fine + 2) if self.S_fine else 0) + 4
+        return (self.fused_pass is not False and mode == "fp32" and self.device_samplers and 8 * 4 * region <= 160 * 1024
                 and self.S + self.S_fine + 2 <= 8192)
 
     @torch.no_grad()
