@@ -573,6 +573,8 @@ def main():
     ap.add_argument("--no-render", action="store_true", help="skip the rendered-rays/s legs")
     ap.add_argument("--no-configs", action="store_true", help="skip the C4 / C5 legs")
     ap.add_argument("--no-ddp", action="store_true", help="skip the DDP training leg of multi-rank runs")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="skip the box write-ceiling measurement and the serialised breakdown (rocprofv3 PMC passes: only the bench launches)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -657,10 +659,13 @@ def main():
 
     # the write rate this box sustains, measured in this process (every rank: its own GPU), and the serialised per-kernel
     # breakdown of one extra launch
-    full = tracer.trace_rays(o, d, M)
-    ceiling = box_write_ceiling(tn, full)
-    del full
-    breakdown = trace_breakdown(tracer, o, d, M) if stats.get("walk", 0) else None
+    if args.no_calibration:
+        ceiling, breakdown = {"GBps": float("nan"), "note": "--no-calibration"}, None
+    else:
+        full = tracer.trace_rays(o, d, M)
+        ceiling = box_write_ceiling(tn, full)
+        del full
+        breakdown = trace_breakdown(tracer, o, d, M) if stats.get("walk", 0) else None
     per_rank_ceiling = sharding.gather_scalars(ceiling["GBps"], device=dev)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
