@@ -20,6 +20,8 @@
 // kernel chain pays the same stages as separate launches over the whole chunk plus its intermediates' allocations.
 // Every stage is the SAME device function the stand-alone kernels call (tn_ray_ops.h, tn_mlp_fwd.h; the matcher restates
 // k_find_matched's expressions), so the frame is bit-identical to the kernel chain's (tests/test_render_gpu.py).
+#include <cstdlib>
+
 #include "tn_mlp_fwd.h"
 #include "tn_ray_ops.h"
 
@@ -252,8 +254,15 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = RR_BLOCK / 64;
     const size_t r = p.count ? (size_t)*p.count : p.r_max;
-    const size_t q0 = r * blockIdx.x / gridDim.x, q1 = r * (blockIdx.x + 1) / gridDim.x;   // r < 2^32, gridDim <= 2^10
-    if (q0 >= q1) return;                                   // block-uniform
+    // Block b owns the hitting rays b, b + G, b + 2 G, ... (G = gridDim.x), its i-th ray = entry i G + b of the list: the
+    // blocks advance at the same pace, so at any moment the whole chip works on a window of ~G consecutive hitting rays -- the
+    // neighbouring image pixels whose tetrahedra share vertices -- and the XCDs' L2s hold the field rows they gather.  With
+    // contiguous per-block ranges (first version) every CU sat in a different part of the image and the MLP phases ran 3.6 %
+    // slower than k_mlp_forward, whose grid-stride over 256-sample groups has exactly this interleaving
+    // (profiles/r05end_render_kernel_stats.txt).
+    const size_t G = gridDim.x, blk = blockIdx.x;
+    if (r <= blk) return;                                   // block-uniform
+    const size_t q0 = 0, q1 = (r - blk + G - 1) / G;        // local ray indices of this block
     const uint32_t S = p.S, M = p.M;
     const uint32_t nb = p.S_fine + 1;
     const uint32_t Sf = FINE ? S + nb : S;                  // samples of the final pass
@@ -268,9 +277,12 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
     const uint32_t tile = (nrays + ntiles - 1) / ntiles;    // even tiles: one partial MLP group per tile at most
     constexpr size_t GROUP = (size_t)NW * 32;
 
-    unsigned long long t_prev = p.prof ? wall_clock64() : 0ull, acc_t[6] = {0, 0, 0, 0, 0, 0};
-    auto tick = [&](int k) {      // phase k ends here (block-uniform branch; nothing but a null test when profiling is off)
-        if (p.prof) { const unsigned long long t = wall_clock64(); acc_t[k] += t - t_prev; t_prev = t; }
+    // phase profile (debug): thread 0 adds the ticks of a phase straight to the global counters when it ends; nothing is kept
+    // in registers across the MLP phases (per-thread accumulators cost 14 VGPRs alive through the whole kernel: spills)
+    unsigned long long t_prev = 0;
+    if (p.prof && threadIdx.x == 0) { t_prev = wall_clock64(); atomicAdd(&p.prof[5], 1ull); }
+    auto tick = [&](int k) {      // phase k ends here (a null test when profiling is off)
+        if (p.prof && threadIdx.x == 0) { const unsigned long long t = wall_clock64(); atomicAdd(&p.prof[k], t - t_prev); t_prev = t; }
     };
     // per-wave LDS for ray phase 2: [coarse weights: S floats][PDF sampler], re-used by the matcher afterwards
     const uint32_t w_floats = (S + 3u) & ~3u;
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
         uint32_t l_ray = 0, l_nv = 0;
         float l_near = 0.f, l_far = 1.f;
         if ((uint32_t)wave + (uint32_t)NW * lane < nt) {
-            l_ray = p.ray_index[tq + wave + (size_t)NW * lane];
+            l_ray = p.ray_index[(tq + wave + (size_t)NW * lane) * G + blk];
             l_nv = p.num_visited[l_ray];
         }
         if ((uint32_t)wave + (uint32_t)NW * lane < nt) {     // (after l_nv: near / far as ray_sample_coarse reads them)
@@ -373,10 +385,6 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
         // (the next tile's first ray phase writes edges_c / hterm / vi / bc: all of them last read before the barrier above;
         //  its LDS use starts after this wave's own composite; sigma / rgb are next written after two more barriers)
     }
-    if (p.prof && threadIdx.x == 0) {
-        for (int k = 0; k < 5; ++k) atomicAdd(&p.prof[k], acc_t[k]);
-        atomicAdd(&p.prof[5], 1ull);
-    }
 }
 
 size_t render_rays_scratch_floats(size_t r_max, uint32_t S, uint32_t S_fine, bool has_bias, unsigned grid, RenderRaysLayout &L) {
@@ -385,7 +393,14 @@ size_t render_rays_scratch_floats(size_t r_max, uint32_t S, uint32_t S_fine, boo
     const uint32_t Sf = S_fine ? S + nb : S;
     const size_t per_ray = (size_t)(S + 1) + (S_fine ? (size_t)(Sf + 1) : 0) + HID + (size_t)Sf * 11;
     const size_t rays_per_block = (r_max + grid - 1) / grid;
-    size_t T = ((size_t)4 << 20) / (per_ray * sizeof(float));      // <= 4 MB of scratch per block
+    // Scratch budget per block = tile size.  Measured (profiles/r05k_scratch_sweep.txt): a chip-wide working set of 256 x 4 MB
+    // costs the coarse-only render 1.4 % against 256 x 0.5 MB (address translation: 256 private windows), but small tiles end in
+    // a partial MLP group each -- free when the samples per ray are a multiple of the group (256: the coarse-only pass), 0.4 % at
+    // 78 rays x 513 samples, 1.1 % at 39: hence 512 KB where tiles cannot end in a partial group, 4 MB otherwise.
+    // TETRANERF_HIP_RENDER_SCRATCH_KB overrides (sweeps).
+    static const size_t env_kb = [] { const char *v = std::getenv("TETRANERF_HIP_RENDER_SCRATCH_KB"); return v && *v ? (size_t)std::atol(v) : (size_t)0; }();
+    const size_t budget_kb = env_kb ? env_kb : ((Sf % 256u == 0 && (!S_fine || S % 256u == 0)) ? (size_t)512 : (size_t)4096);
+    size_t T = (budget_kb << 10) / (per_ray * sizeof(float));
     if (T < 8) T = 8;
     if (T > 64 * (RR_BLOCK / 64)) T = 64 * (RR_BLOCK / 64);        // a wave keeps its rays' ids in one register, lane i = ray i
     if (T > rays_per_block) T = rays_per_block;
