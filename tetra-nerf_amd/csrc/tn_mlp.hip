@@ -130,8 +130,18 @@ __global__ __launch_bounds__(BLOCK, 2) void k_mlp_forward(size_t n, uint32_t sam
     if (count) n = (size_t)*count * samples_per_ray;
     constexpr size_t GROUP = (BLOCK / 64) * 32;
     const size_t ngroups = (n + GROUP - 1) / GROUP;
-    for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x)
-        mlp_forward_group<GATHER, DENSITY_ONLY, BLOCK, TRAIN>(lds, g, n, samples_per_ray, feats, vi, bc, fieldT, hterm, pk, sigma, rgb, sv);
+    if constexpr (TRAIN) {
+        FwdCarry cy;
+#pragma unroll
+        for (int j = 0; j < KSH; ++j) cy.h4[j] = 0.f;
+        cy.p = nullptr; cy.m = nullptr;
+        for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x)
+            mlp_forward_group<GATHER, DENSITY_ONLY, BLOCK, TRAIN>(lds, g, n, samples_per_ray, feats, vi, bc, fieldT, hterm, pk, sigma, rgb, sv, &cy);
+        flush_carry(cy, n);
+    } else {
+        for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x)
+            mlp_forward_group<GATHER, DENSITY_ONLY, BLOCK, TRAIN>(lds, g, n, samples_per_ray, feats, vi, bc, fieldT, hterm, pk, sigma, rgb, sv);
+    }
 }
 
 // Per-ray composite: one wavefront per ray, lanes stride the samples; exclusive scan of sigma*delta.

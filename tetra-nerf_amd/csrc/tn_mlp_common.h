@@ -109,10 +109,20 @@ static __device__ __forceinline__ void gemm_steps(f32x16 (&acc)[TILES], const fl
 // gemm_steps + the stores of the B operand (the training kernels save every GEMM's input): one quad after every second
 // k-step of the first NST / 2, i.e. in the shadow of MFMAs and drained long before the GEMM ends.  p: this lane's first
 // quad; qstride: distance of consecutive quads in float4 units (2 n in accumulator order, n for x0).
-template <int KS, int KS0, int TILES, int NST>
+// MASK: the operand is a ReLU output whose mask the dX kernel wants (slot j: bit j, stored as masks[(layer * n + sample) * 2 +
+// half]); its two VALU operations per value ride under the MFMAs of k-step j as well (round 5's ablation, profiles/
+// r05m_save_ablate.txt: computed between two GEMMs, where the matrix pipe of BOTH waves of a SIMD idles -- the stage
+// barriers keep them in phase -- the four masks cost 0.10 of the 0.30 ms the saves add to a 2.1 M-sample forward).
+static __device__ __forceinline__ uint32_t relu_bit(float v, int j) {
+    const uint32_t b = __float_as_uint(v);      // a ReLU output is >= +0: "positive" = "bit pattern not zero"
+    return (b < 1u ? b : 1u) << (j & 31);
+}
+template <int KS, int KS0, int TILES, int NST, bool MASK = false>
 static __device__ __forceinline__ void gemm_steps_store(f32x16 (&acc)[TILES], const float (&bin)[KSH], const float *lds, int lane,
-                                                        float4 *__restrict__ p, size_t qstride) {
+                                                        float4 *__restrict__ p, size_t qstride,
+                                                        unsigned long long *__restrict__ mask_out = nullptr) {
     float a[TILES], an[TILES];
+    uint32_t lo = 0, hi = 0;
     const float *w0 = lds + (size_t)KS0 * TILES * 64 + lane;
 #pragma unroll
     for (int t = 0; t < TILES; ++t) a[t] = w0[t * 64];
@@ -131,10 +141,58 @@ static __device__ __forceinline__ void gemm_steps_store(f32x16 (&acc)[TILES], co
             *p = make_float4(bin[2 * ks], bin[2 * ks + 1], bin[2 * ks + 2], bin[2 * ks + 3]);
             p += qstride;
         }
+        if constexpr (MASK) {
+            if (ks < 32) lo |= relu_bit(bin[ks], ks);
+            else hi |= relu_bit(bin[ks], ks);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < TILES; ++t) a[t] = an[t];
     }
+    if constexpr (MASK) *mask_out = ((unsigned long long)hi << 32) | lo;
+}
+// The training forward's LAST saved tensor, h4 (the head layer's ReLU output), and its mask have no GEMM of their own group
+// to leave under (the rgb head runs on the VALU): stored right away they cost as much as h1..h3 together (0.09 ms of the same
+// 0.30).  They are carried in registers into the NEXT group's layer-1 GEMM instead, whose 32 k-steps have room beside the 8 quads
+// of x0: one quad of the carried h4 after every odd k-step, two of its mask bits per k-step.
+struct FwdCarry { float h4[KSH]; float4 *p; unsigned long long *m; };
+template <int KS, int TILES>
+static __device__ __forceinline__ void gemm_steps_store_carry(f32x16 (&acc)[TILES], const float (&bin)[KSH], const float *lds, int lane,
+                                                              float4 *__restrict__ p, size_t qstride, const FwdCarry &cy, size_t cstride) {
+    static_assert(KS == 32 && KSH == 64, "16 carried quads on the odd k-steps, two mask bits per k-step");
+    float a[TILES], an[TILES];
+    uint32_t lo = 0, hi = 0;
+    float4 *cp = cy.p;
+    const float *w0 = lds + lane;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) a[t] = w0[t * 64];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+            const float *wrow = lds + (size_t)(ks + 1) * TILES * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) an[t] = wrow[t * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bin[ks], acc[t], 0, 0, 0);
+        if ((ks & 1) == 0 && 2 * ks < KS) {
+            *p = make_float4(bin[2 * ks], bin[2 * ks + 1], bin[2 * ks + 2], bin[2 * ks + 3]);
+            p += qstride;
+        }
+        if (ks & 1) {
+            const int q = ks >> 1;
+            *cp = make_float4(cy.h4[4 * q], cy.h4[4 * q + 1], cy.h4[4 * q + 2], cy.h4[4 * q + 3]);
+            cp += cstride;
+        }
+        if (ks < 16) lo |= relu_bit(cy.h4[2 * ks], 2 * ks) | relu_bit(cy.h4[2 * ks + 1], 2 * ks + 1);
+        else hi |= relu_bit(cy.h4[2 * ks], 2 * ks) | relu_bit(cy.h4[2 * ks + 1], 2 * ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) a[t] = an[t];
+    }
+    *cy.m = ((unsigned long long)hi << 32) | lo;
 }
 // this lane's first quad of a [128 / 4][n][4] tensor in accumulator order / of the [64 / 4][n][4] gathered features
 static __device__ __forceinline__ float4 *quad_ptr(float *base, size_t n, size_t s, int h) {

@@ -14,13 +14,15 @@ namespace mlp {
 struct FwdSave { float *x0, *h1, *h2, *h3, *h4; unsigned long long *masks; };
 
 // group g = samples [g * GROUP, (g + 1) * GROUP) of n; every thread of the block calls it (it contains the block barriers of
-// the weight stages).  lds: MAX_STAGE_FLOATS floats.  hterm [rays][128]: the head layer's per-ray term (unused when DENSITY_ONLY).
+// the weight stages).  TRAIN: cy carries h4 and the place of its mask from one group of the block to the next (FwdCarry,
+// tn_mlp_common.h: cy->p == nullptr before the first group; the caller stores the last group's with flush_carry).  lds: MAX_STAGE_FLOATS floats.  hterm [rays][128]: the head layer's per-ray term (unused when DENSITY_ONLY).
 template <bool GATHER, bool DENSITY_ONLY, int BLOCK, bool TRAIN>
 static __device__ __forceinline__ void mlp_forward_group(float *lds, size_t g, size_t n, uint32_t samples_per_ray,
                                                          const float *__restrict__ feats, const uint32_t *__restrict__ vi,
                                                          const float *__restrict__ bc, const float *__restrict__ fieldT,
                                                          const float *__restrict__ hterm, const float *__restrict__ pk,
-                                                         float *__restrict__ sigma, float *__restrict__ rgb, const FwdSave &sv) {
+                                                         float *__restrict__ sigma, float *__restrict__ rgb, const FwdSave &sv,
+                                                         FwdCarry *cy = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     constexpr size_t GROUP = (BLOCK / 64) * 32;
     const size_t s = g * GROUP + (size_t)wave * 32 + (lane & 31);
@@ -63,15 +65,16 @@ static __device__ __forceinline__ void mlp_forward_group(float *lds, size_t g, s
         zero_acc(acc);
         // TRAIN: every GEMM's input leaves for HBM under the GEMM's own MFMAs (lanes beyond the end store their
         // duplicate of sample n - 1 where its owner stores it)
-        if constexpr (TRAIN) gemm_steps_store<KS1, 0, OT, KS1>(acc, bin, lds, lane, quad_ptr_x0(sv.x0, n, sc, h), n);
-        else gemm_steps<KS1, 0, OT>(acc, bin, lds, lane);
+        if constexpr (TRAIN) {
+            // (the first group of a block has nothing to carry: it stores zeros where its own h4 and mask go -- the same lane
+            //  stores the values there later, and a wave's stores to one address land in program order)
+            if (!cy->p) { cy->p = quad_ptr(sv.h4, n, sc, h); cy->m = sv.masks + ((size_t)3 * n + sc) * 2 + h; }
+            gemm_steps_store_carry<KS1, OT>(acc, bin, lds, lane, quad_ptr_x0(sv.x0, n, sc, h), n, *cy, 2 * n);
+        } else gemm_steps<KS1, 0, OT>(acc, bin, lds, lane);
         bias_step<KS1, OT>(acc, lds, lane);
         relu_to_bin(acc, bin);
     }
-    auto save_mask = [&](int layer) {
-        if constexpr (TRAIN) sv.masks[((size_t)layer * n + sc) * 2 + h] = mask_of(bin);
-    };
-    save_mask(0);
+    auto mask_ptr = [&](int layer) { return sv.masks + ((size_t)layer * n + sc) * 2 + h; };   // TRAIN only
     // ---- layers 2, 3: 128 -> 128, accumulators fed back as B operands
     __syncthreads();
     stage_weights<BLOCK>(lds, pk + OFF_W2, lfloats(KSH, OT));
@@ -79,24 +82,22 @@ static __device__ __forceinline__ void mlp_forward_group(float *lds, size_t g, s
     {
         f32x16 acc[OT];
         zero_acc(acc);
-        if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h1, n, sc, h), 2 * n);
+        if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH, true>(acc, bin, lds, lane, quad_ptr(sv.h1, n, sc, h), 2 * n, mask_ptr(0));
         else gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
         bias_step<KSH, OT>(acc, lds, lane);
         relu_to_bin(acc, bin);
     }
-    save_mask(1);
     __syncthreads();
     stage_weights<BLOCK>(lds, pk + OFF_W3, N_W3);
     stage_wait();
     {
         f32x16 acc[OT];
         zero_acc(acc);
-        if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h2, n, sc, h), 2 * n);
+        if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH, true>(acc, bin, lds, lane, quad_ptr(sv.h2, n, sc, h), 2 * n, mask_ptr(1));
         else gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
         bias_step<KSH, OT>(acc, lds, lane);
         relu_to_bin(acc, bin);  // mlp_base out_activation = ReLU
     }
-    save_mask(2);
     {
         // density head 128 -> 1 + softplus on the VALU (the vector rides behind layer 3's weights)
         const float *dv = lds + lfloats(KSH, OT);
@@ -113,14 +114,18 @@ static __device__ __forceinline__ void mlp_forward_group(float *lds, size_t g, s
     {
         f32x16 acc[OT];
         zero_acc(acc);
-        if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH>(acc, bin, lds, lane, quad_ptr(sv.h3, n, sc, h), 2 * n);
+        if constexpr (TRAIN) gemm_steps_store<KSH, 0, OT, KSH, true>(acc, bin, lds, lane, quad_ptr(sv.h3, n, sc, h), 2 * n, mask_ptr(2));
         else gemm_steps<KSH, 0, OT>(acc, bin, lds, lane);
         bias_step<HEAD_KS, OT>(acc, lds, lane);
         add_ray_bias(acc, hterm + (sc / samples_per_ray) * HID, h);
         relu_to_bin(acc, bin);
     }
-    if constexpr (TRAIN) store_bin(sv.h4, n, sc, bin, h);   // the last layer's output has no GEMM to hide under
-    save_mask(3);
+    if constexpr (TRAIN) {   // h4 and its mask leave under the next group's first GEMM (or with flush_carry)
+#pragma unroll
+        for (int j = 0; j < KSH; ++j) cy->h4[j] = bin[j];
+        cy->p = quad_ptr(sv.h4, n, sc, h);
+        cy->m = mask_ptr(3);
+    }
     {
         // rgb head 128 -> 3 + sigmoid on the VALU
         const float *cv = lds + lfloats(HEAD_KS, OT);
@@ -133,6 +138,18 @@ static __device__ __forceinline__ void mlp_forward_group(float *lds, size_t g, s
             rgb[3 * s + 2] = 1.0f / (1.0f + expf(-c2));
         }
     }
+}
+
+// after a block's last group: the carried h4 and its mask
+static __device__ __forceinline__ void flush_carry(const FwdCarry &cy, size_t n) {
+    if (!cy.p) return;
+    float4 *p = cy.p;
+#pragma unroll
+    for (int g = 0; g < KSH / 4; ++g) {
+        *p = make_float4(cy.h4[4 * g], cy.h4[4 * g + 1], cy.h4[4 * g + 2], cy.h4[4 * g + 3]);
+        p += 2 * n;
+    }
+    *cy.m = mask_of(cy.h4);
 }
 
 }  // namespace mlp
