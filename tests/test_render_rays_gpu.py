@@ -94,6 +94,27 @@ def test_one_launch_render_is_bit_identical_to_the_kernel_chain(tn, device, scen
     assert bool((a["rgb"][~a["ray_mask"]] == torch.tensor([0.1, 0.5, 0.9], device=device)).all())
 
 
+def test_one_launch_render_of_a_whole_frame_in_one_call(tn, device, scenes, render):
+    """No chunking: 307,200 rays in ONE render call (every block works through dozens of tiles, the hitting-ray count is far
+    beyond a 65,536-ray chunk's) -- still bit-identical to the kernel chain, for both shipped sample configurations."""
+    import torch
+
+    tr, mlp, field = _setup(tn, scenes, render, device, n_pts=6000, seed=9)
+    o, d = _frame(scenes, device, 640, 480)
+    for S, S_fine, biased in ((256, 256, False), (128, 128, True)):
+        one = render.TetraRenderer(tr, field, mlp, S, 512, fused=True, num_fine_samples=S_fine, biased=biased, fused_pass=True)
+        chain = render.TetraRenderer(tr, field, mlp, S, 512, fused=True, num_fine_samples=S_fine, biased=biased, fused_pass=False)
+        a, b = one.render(o, d), chain.render(o, d)
+        hits = int(a["ray_mask"].sum())
+        assert hits > 100000, hits
+        assert torch.equal(a["ray_mask"], b["ray_mask"])
+        for k in ("rgb", "accumulation", "depth"):
+            assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), (S, k, float((a[k] - b[k]).abs().max()))
+        assert bool(torch.isfinite(a["rgb"]).all())
+        del a, b, one, chain
+        torch.cuda.empty_cache()
+
+
 def test_one_launch_render_matches_the_host_compacting_form(tn, device, scenes, render):
     """... and the form that sizes its work on the host (PyTorch sampler statements + torch.nonzero, the parity definition of
     the sampler kernels): same frame at the samplers' tolerance."""
