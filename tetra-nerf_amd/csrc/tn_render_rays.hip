@@ -33,6 +33,9 @@ using namespace rayops;
 namespace {
 
 struct RenderRaysParams {
+    uint32_t skip;   // diagnostic (TETRANERF_HIP_RENDER_SKIP): bit 0 / 1 / 2 = leave out ray phase 1 / 2 / 3 -- the MLP phases then run on the
+                     // sample placement the previous launch left in the scratch: their time alone (profiles/r05q_mlp_phase_only.py)
+
     // trace rows (outputs of tn_trace_rays, read in place)
     const uint32_t *num_visited;   // [R_all]
     const float *dist;             // [R_all, M, 2]
@@ -256,10 +259,9 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
     const size_t r = p.count ? (size_t)*p.count : p.r_max;
     // Block b owns the hitting rays b, b + G, b + 2 G, ... (G = gridDim.x), its i-th ray = entry i G + b of the list: the
     // blocks advance at the same pace, so at any moment the whole chip works on a window of ~G consecutive hitting rays -- the
-    // neighbouring image pixels whose tetrahedra share vertices -- and the XCDs' L2s hold the field rows they gather.  With
-    // contiguous per-block ranges (first version) every CU sat in a different part of the image and the MLP phases ran 3.6 %
-    // slower than k_mlp_forward, whose grid-stride over 256-sample groups has exactly this interleaving
-    // (profiles/r05end_render_kernel_stats.txt).
+    // neighbouring image pixels whose tetrahedra share vertices -- as k_mlp_forward's grid-stride over 256-sample groups does.
+    // (Measured against contiguous per-block ranges, the first version: no difference on the bench frame, whose 3.8 MB field
+    // every XCD's L2 holds; kept for meshes beyond the L2s.)
     const size_t G = gridDim.x, blk = blockIdx.x;
     if (r <= blk) return;                                   // block-uniform
     const size_t q0 = 0, q1 = (r - blk + G - 1) / G;        // local ray indices of this block
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
         // ---- ray phase 1: coarse sampler -> matcher (+ the head layer's per-ray term) of this wave's rays.  The edges reach
         //      the matcher through the wave's LDS (and global memory for the later phases): no store -> load round trip
         float *el = wl + 2 * (size_t)M;                      // [S + 1] behind the matcher's tin / pmax
-        for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
+        if (!(p.skip & 1u)) for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
             const size_t ray = (uint32_t)__builtin_amdgcn_readlane((int)l_ray, (int)i);
             const uint32_t nv = (uint32_t)__builtin_amdgcn_readlane((int)l_nv, (int)i);
             const float near = __shfl(l_near, (int)i), far = __shfl(l_far, (int)i);
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
             // fine edges behind both
             const size_t o_merged = std::max<size_t>(2 * (size_t)M, w_floats + pdf_lds_floats(S, nb));
             const bool lds_edges = pdf_writes_second_copy(S, nb);
-            for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
+            if (!(p.skip & 2u)) for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
                 const size_t ray = (uint32_t)__builtin_amdgcn_readlane((int)l_ray, (int)i);
                 const uint32_t nv = (uint32_t)__builtin_amdgcn_readlane((int)l_nv, (int)i);
                 const float near = __shfl(l_near, (int)i), far = __shfl(l_far, (int)i);
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
         tick(3);
         // ---- ray phase 3: weights + renderers, scattered into the frame
         const float *ee = FINE ? edges_f : edges_c;
-        for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
+        if (!(p.skip & 4u)) for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
             const size_t ray = (uint32_t)__builtin_amdgcn_readlane((int)l_ray, (int)i);
             ray_composite(Sf, sigma + (size_t)t * Sf, rgb + 3 * (size_t)t * Sf, ee + (size_t)t * (Sf + 1), p.bg, p.out_rgb + 3 * ray,
                           p.out_acc + ray, p.out_depth + ray, nullptr, lane);
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
 }
 
 size_t render_rays_scratch_floats(size_t r_max, uint32_t S, uint32_t S_fine, bool has_bias, unsigned grid, RenderRaysLayout &L) {
-    auto al = [](size_t x) { return (x + 3) & ~(size_t)3; };   // 16-byte aligned pieces
+    auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };   // 256-byte aligned pieces (and blocks): a group's 4 KB of vertex ids start on a line
     const uint32_t nb = S_fine + 1;
     const uint32_t Sf = S_fine ? S + nb : S;
     const size_t per_ray = (size_t)(S + 1) + (S_fine ? (size_t)(Sf + 1) : 0) + HID + (size_t)Sf * 11;
@@ -433,6 +435,7 @@ void launch_render_rays(const uint32_t *num_visited, const float *dist, const fl
     const size_t smem = lds_floats * sizeof(float);
     if (smem > 160 * 1024) throw Error("render_rays: max_ray_triangles / samples per ray too large for the per-wave LDS regions");
     RenderRaysParams p{};
+    { const char *v = std::getenv("TETRANERF_HIP_RENDER_SKIP"); p.skip = v && *v ? (uint32_t)std::atoi(v) : 0u; }
     p.num_visited = num_visited; p.dist = dist; p.bary = bary; p.verts = verts; p.M = M;
     p.ray_index = ray_index; p.count = count; p.r_max = r_max;
     p.S = S; p.S_fine = S_fine; p.biased = biased ? 1 : 0;
