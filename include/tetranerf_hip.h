@@ -188,6 +188,12 @@ int tn_interpolate_values_vm(uint32_t interpolation_dim, uint32_t num_values, ui
 int tn_interpolate_values_backward_vm(uint32_t interpolation_dim, uint32_t num_values, uint32_t field_dim,
                                       const uint32_t *vertex_indices, const float *barycentric,
                                       const float *grad_rows, float *field_grad_vm, void *stream);
+/* The same WITHOUT float atomics (addition; the reference's kernel, tetrahedra_tracer.cu:223-247, adds with atomicAdd and so
+ * does tn_interpolate_values_backward_vm): the (sample, vertex) pairs are sorted by vertex and every gradient element is
+ * summed by one writer in a fixed order -- bit-identical from run to run, 3-5x the time.  Needs num_vertices. */
+int tn_interpolate_values_backward_vm_det(uint32_t interpolation_dim, uint32_t num_vertices, uint32_t num_values,
+                                          uint32_t field_dim, const uint32_t *vertex_indices, const float *barycentric,
+                                          const float *grad_rows, float *field_grad_vm, void *stream);
 
 /* Test aid: run only the dedupe / pairing / tail-fill stage
  * (post_process_tetrahedra, src/optix/optix_trace_rays.cu:110-266) on caller-supplied

@@ -91,6 +91,46 @@ def test_backward_vs_oracle(tn, device, oracle, D):
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("D,Fd", [(4, 64), (3, 64), (4, 37), (2, 130)])
+def test_backward_without_atomics_is_reproducible_and_agrees(tn, device, oracle, D, Fd):
+    """tn_interpolate_values_backward_vm_det (cpp.DETERMINISTIC_FIELD_GRADIENT / torch.use_deterministic_algorithms): one writer
+    per gradient element, fixed summation order -- the same bits on every run (the atomic kernel's sums depend on the order
+    the hardware retires its atomics in), the oracle's values, EMPTY slots skipped, vertices nobody samples left at zero."""
+    import torch
+
+    rng = np.random.default_rng(23 + D + Fd)
+    V = 501
+    vi, bc = _inputs(rng, V, (6000,), D)
+    vi[200:900] = vi[200]; bc[200:900] = bc[200]          # a long run of one tuple: vertices with hundreds of pairs
+    vi[vi == 77] = 78                                      # a vertex nobody samples
+    vi[1000:1100, 0] = -1                                  # unmatched slots (TN_EMPTY)
+    field = rng.standard_normal((Fd, V)).astype(np.float32)
+    g = rng.standard_normal((6000, Fd)).astype(np.float32)
+    want = oracle.interpolate_values_backward(vi, bc, field, g)
+    args = (torch.from_numpy(vi).to(device), torch.from_numpy(bc).to(device), torch.from_numpy(field).to(device),
+            torch.from_numpy(g).to(device))
+    atomic = tn.cpp.interpolate_values_backward(*args)
+    assert not tn.cpp.deterministic_gradients()
+    tn.cpp.DETERMINISTIC_FIELD_GRADIENT = True
+    try:
+        assert tn.cpp.deterministic_gradients()
+        runs = [tn.cpp.interpolate_values_backward(*args) for _ in range(3)]
+    finally:
+        tn.cpp.DETERMINISTIC_FIELD_GRADIENT = False
+    for r in runs[1:]:
+        assert torch.equal(r.view(torch.int32), runs[0].view(torch.int32))
+    np.testing.assert_allclose(runs[0].cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(runs[0].cpu().numpy(), atomic.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    assert float(runs[0][:, 77].abs().max()) == 0.0
+    # PyTorch's own switch selects it too
+    prev = torch.are_deterministic_algorithms_enabled()
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        assert tn.cpp.deterministic_gradients()
+    finally:
+        torch.use_deterministic_algorithms(prev)
+
+
 def test_gather_errors(tn, device):
     import torch
 

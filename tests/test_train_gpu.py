@@ -258,6 +258,49 @@ def test_training_gradients_match_float64_under_the_saved_relu_masks(tn, device,
             assert unmasked < 1e-5 or sum(flipped) > 0, ((S, S_fine, biased, scaling), name, unmasked, flipped)
 
 
+def test_training_gradients_are_bit_reproducible_without_atomics(tn, device, scenes):
+    """With cpp.DETERMINISTIC_FIELD_GRADIENT (or torch.use_deterministic_algorithms) the gather's adjoint runs without float
+    atomics: ALL thirteen gradients of a training step -- the field's included -- are the same bits run after run (4096-ray
+    batch of the 300k-tet mesh, both shipped configurations); against the atomic form the field gradient differs by rounding."""
+    import torch
+
+    render = importlib.import_module("tetra-nerf_amd.render")
+    pts, cells = scenes.random_mesh(45000, 2)
+    tr = tn.TetrahedraTracer(device)
+    tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+    o, d = scenes.outside_in_rays(4096, 1)
+    to, td = torch.from_numpy(o).to(device), torch.from_numpy(d).to(device)
+    torch.manual_seed(5)
+    target = torch.rand(len(o), 3, device=device)
+    for S, S_fine, biased, scaling in ((256, 256, False, False), (128, 128, True, True)):
+        torch.manual_seed(1)
+        mlp = render.TetraMLP().to(device)
+        field = ((torch.rand(64, len(pts), device=device) * 2 - 1) * 0.5).requires_grad_(True)
+        rd = render.TetraRenderer(tr, field, mlp, S, 512, fused=True, num_fine_samples=S_fine, biased=biased)
+
+        def grads():
+            field.grad = None
+            mlp.zero_grad()
+            torch.manual_seed(9)
+            out = rd.render_train(to, td, gradient_scaling=scaling)
+            ((out["rgb"] - target) ** 2).mean().backward()
+            return [field.grad.clone()] + [p.grad.clone() for p in render.mlp_weights(mlp)]
+
+        atomic = grads()
+        tn.cpp.DETERMINISTIC_FIELD_GRADIENT = True
+        try:
+            a, b = grads(), grads()
+        finally:
+            tn.cpp.DETERMINISTIC_FIELD_GRADIENT = False
+        assert len(a) == 13
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+        for x, y in zip(a[1:], atomic[1:]):                     # the weight gradients never came from atomics
+            assert torch.equal(x, y)
+        assert float(a[0].abs().max()) > 0
+        assert float((a[0] - atomic[0]).abs().max()) <= 2e-5 * float(atomic[0].abs().max())
+
+
 def test_render_train_in_several_autograd_nodes(tn, device, scenes):
     """Batches beyond `train_node_samples` go through several fused-MLP nodes (one per block of rays): outputs identical,
     gradients equal up to the order in which the blocks' parameter gradients are summed."""

@@ -20,7 +20,7 @@ SYMBOLS = (
     "tn_num_faces", "tn_get_faces", "tn_get_build_table", "tn_trace_rays", "tn_trace_rays_ex", "tn_trace_rays_triangles", "tn_find_tetrahedra",
     "tn_find_matched_cells", "tn_find_matched_cells_indexed",
     "tn_interpolate_values", "tn_interpolate_values_backward", "tn_interpolate_values_backward_rows",
-    "tn_transpose_f32", "tn_interpolate_values_vm", "tn_interpolate_values_backward_vm",
+    "tn_transpose_f32", "tn_interpolate_values_vm", "tn_interpolate_values_backward_vm", "tn_interpolate_values_backward_vm_det",
     "tn_postprocess_hits", "tn_postprocess_hits_tables",
     "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_create", "tn_mlp_destroy", "tn_mlp_set_weights",
     "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
@@ -65,6 +65,7 @@ def load():
     lib.tn_transpose_f32.argtypes = [u32, u32, vp, vp, vp]
     lib.tn_interpolate_values_vm.argtypes = [u32, u32, u32, vp, vp, vp, vp, vp]
     lib.tn_interpolate_values_backward_vm.argtypes = [u32, u32, u32, vp, vp, vp, vp, vp]
+    lib.tn_interpolate_values_backward_vm_det.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp]
     lib.tn_postprocess_hits.argtypes = [vp, sz, u32] + [vp] * 10
     lib.tn_postprocess_hits_tables.argtypes = [i32, sz, u32] + [vp] * 12
     lib.tn_trace_stats.argtypes = [vp, C.POINTER(C.c_uint64 * 4)]

@@ -888,6 +888,14 @@ int tn_interpolate_values_backward_vm(uint32_t D, uint32_t n, uint32_t Fd, const
     });
 }
 
+int tn_interpolate_values_backward_vm_det(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
+                                          const float *grad_rows, float *field_grad_vm, void *stream_) {
+    return guarded([&] {
+        tn::launch_interpolate_values_backward_vm_det(D, V, n, Fd, vi, bc, grad_rows, field_grad_vm, (hipStream_t)stream_);
+        TN_HIP(hipGetLastError());
+    });
+}
+
 /* ---- shallow MLP: a handle owns the packed forms of one set of weights and the per-call scratch ---- */
 }  // extern "C" (the handle type is C++)
 

@@ -16,6 +16,11 @@
 // Backward: LANE = FEATURE; 64 lanes add to 64 consecutive floats of a vertex-major gradient (one
 // cache line per atomic instruction), with run-length combining of consecutive samples that hit the
 // same vertex tuple; the result is transposed back to [Fd, V].
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
 #include "tn_device.h"
 #include "tn_kernels.h"
 
@@ -328,7 +333,103 @@ void run_bwd(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const floa
     launch_transpose(gradT.p, field_grad, V, Fd, stream);
 }
 
+// ---- the adjoint WITHOUT float atomics (opt-in: bit-reproducible field gradients) -------------------------------------
+// The (sample, vertex slot) pairs are sorted by vertex (stable radix sort: inside a vertex they stay in sample order), then
+// one block per vertex adds its pairs' weighted gradient rows in a FIXED order: wave w of the block takes the w-th quarter
+// of the vertex's run, lane = feature, sequential over the run; the four partial sums are combined as (p0 + p1) + (p2 + p3).
+// One writer per gradient element: the result does not depend on scheduling.  ~3-5x the time of the atomic kernel.
+__global__ void k_iota(uint32_t n, uint32_t *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+__global__ void k_run_bounds(uint32_t n, const uint32_t *__restrict__ keys, uint32_t V, uint32_t *__restrict__ start,
+                             uint32_t *__restrict__ end) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys[i];
+    if (k >= V) return;                                   // TN_EMPTY (unmatched slot) sorts last
+    if (i == 0 || keys[i - 1] != k) start[k] = i;
+    if (i + 1 == n || keys[i + 1] != k) end[k] = i + 1;
+}
+template <int D>
+__global__ __launch_bounds__(256) void k_interp_bwd_det(uint32_t V, uint32_t Fd, const uint32_t *__restrict__ start,
+                                                        const uint32_t *__restrict__ end, const uint32_t *__restrict__ pairs,
+                                                        const float *__restrict__ bc, const float *__restrict__ grad_rows,
+                                                        float *__restrict__ gradT) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (uint32_t v = blockIdx.x; v < V; v += gridDim.x) {
+        const uint32_t st = start[v], en = end[v];
+        if (en <= st) continue;                            // block-uniform
+        const uint32_t len = en - st;
+        const uint32_t a = st + (uint32_t)(((uint64_t)len * wave) / 4), b = st + (uint32_t)(((uint64_t)len * (wave + 1)) / 4);
+        for (uint32_t f0 = 0; f0 < Fd; f0 += 64) {
+            const uint32_t f = f0 + lane;
+            const bool fok = f < Fd;
+            float acc = 0.f;
+            for (uint32_t i0 = a; i0 < b; i0 += 8) {
+                float g[8], w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    g[j] = 0.f; w[j] = 0.f;
+                    if (i0 + j < b) {
+                        const uint32_t p = pairs[i0 + j];           // wave-uniform
+                        const uint32_t smp = p / D, k = p % D;
+                        if (k == 0) {
+                            float t = 0.f;
+#pragma unroll
+                            for (int c = 0; c < D - 1; ++c) t += bc[(size_t)smp * (D - 1) + c];
+                            w[j] = 1.0f - t;
+                        } else {
+                            w[j] = bc[(size_t)smp * (D - 1) + (k - 1)];
+                        }
+                        if (fok) g[j] = grad_rows[(size_t)smp * Fd + f];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += w[j] * g[j];   // (slots beyond the run add w = 0 times g = 0)
+            }
+            part[wave][lane] = acc;
+            __syncthreads();
+            if (wave == 0 && fok) gradT[(size_t)v * Fd + f] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+            __syncthreads();
+        }
+    }
+}
+
+template <int D>
+void run_bwd_det(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc, const float *grad_rows, float *gradT,
+                 hipStream_t stream) {
+    const size_t np = (size_t)n * D;
+    if (np > 0xFFFFFFFFull) throw Error("interpolate_values backward (deterministic): too many samples");
+    AsyncBuf keys(np, stream), vals(np, stream), iota(np, stream), bounds(2 * (size_t)V, stream);
+    uint32_t *ks = reinterpret_cast<uint32_t *>(keys.p), *vs = reinterpret_cast<uint32_t *>(vals.p), *io = reinterpret_cast<uint32_t *>(iota.p);
+    uint32_t *st = reinterpret_cast<uint32_t *>(bounds.p), *en = st + V;
+    hipLaunchKernelGGL(k_iota, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, (uint32_t)np, io);
+    size_t bytes = 0;
+    TN_HIP(rocprim::radix_sort_pairs(nullptr, bytes, vi, ks, io, vs, np, 0u, 32u, stream));
+    AsyncBuf tmp((bytes + 3) / 4 + 64, stream);
+    TN_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, vi, ks, io, vs, np, 0u, 32u, stream));
+    TN_HIP(hipMemsetAsync(st, 0, 2 * (size_t)V * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_run_bounds, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, (uint32_t)np, ks, V, st, en);
+    const unsigned grid = V < 256u * 64u ? V : 256u * 64u;
+    hipLaunchKernelGGL(k_interp_bwd_det<D>, dim3(grid), dim3(256), 0, stream, V, Fd, st, en, vs, bc, grad_rows, gradT);
+}
+
 }  // namespace
+
+void launch_interpolate_values_backward_vm_det(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
+                                               const float *grad_rows, float *gradT, hipStream_t stream) {
+    if (n == 0 || Fd == 0 || V == 0) return;
+    switch (D) {
+        case 2: run_bwd_det<2>(V, n, Fd, vi, bc, grad_rows, gradT, stream); break;
+        case 3: run_bwd_det<3>(V, n, Fd, vi, bc, grad_rows, gradT, stream); break;
+        case 4: run_bwd_det<4>(V, n, Fd, vi, bc, grad_rows, gradT, stream); break;
+        case 6: run_bwd_det<6>(V, n, Fd, vi, bc, grad_rows, gradT, stream); break;
+        default: throw Error("Unsupported interpolation dimension with value " + std::to_string(D));
+    }
+}
 
 void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols, hipStream_t stream) {
     if (rows == 0 || cols == 0) return;

@@ -118,6 +118,8 @@ void launch_interpolate_values_backward(uint32_t D, uint32_t V, uint32_t n, uint
 // per-call transposition and no temporaries -- what a caller that keeps a vertex-major shadow of the field uses
 void launch_interpolate_values_vm(uint32_t D, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
                                   const float *fieldT, float *result, hipStream_t stream);
+void launch_interpolate_values_backward_vm_det(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
+                                               const float *grad_rows, float *gradT, hipStream_t stream);
 void launch_interpolate_values_backward_vm(uint32_t D, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
                                            const float *grad_rows, float *gradT, hipStream_t stream);
 

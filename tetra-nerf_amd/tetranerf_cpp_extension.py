@@ -439,6 +439,23 @@ def interpolate_values(vertex_indices, barycentric_coordinates, field):
     return result.moveaxis(0, -1)
 
 
+def deterministic_gradients() -> bool:
+    """Whether the field gradient (the gather's adjoint) is summed without float atomics: bit-identical from run to run, 3-5x
+    the time of the atomic kernel (the twelve weight gradients are bit-reproducible either way).  On when the caller asked
+    PyTorch for deterministic algorithms (`torch.use_deterministic_algorithms(True)`) or set DETERMINISTIC_FIELD_GRADIENT."""
+    return bool(DETERMINISTIC_FIELD_GRADIENT) or torch.are_deterministic_algorithms_enabled()
+
+
+DETERMINISTIC_FIELD_GRADIENT = False
+
+
+def _gather_adjoint_vm(lib, D, V, n, Fd, vi, bc, rows, grad_vm, stream):
+    if deterministic_gradients():
+        _lib.check(lib.tn_interpolate_values_backward_vm_det(D, V, n, Fd, _ptr(vi), _ptr(bc), _ptr(rows), _ptr(grad_vm), stream))
+    else:
+        _lib.check(lib.tn_interpolate_values_backward_vm(D, n, Fd, _ptr(vi), _ptr(bc), _ptr(rows), _ptr(grad_vm), stream))
+
+
 def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, grad_in):
     """py_interpolate_values_backward (py_binding.cpp:341-372)."""
     for x, name in ((vertex_indices, "vertex_indices"), (barycentric_coordinates, "barycentric_coordinates"),
@@ -457,7 +474,7 @@ def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, 
     _check(grad_in.size(-1) == Fd, "grad_in must have shape [..., field_dim]")
     grad_field_out = _empty((Fd, V), dtype=grad_in.dtype, device=grad_in.device)
     lib = _lib.load()
-    if grad_in.moveaxis(-1, 0).is_contiguous() and Fd > 1:
+    if grad_in.moveaxis(-1, 0).is_contiguous() and Fd > 1 and not deterministic_gradients():
         # the reference's layout: a [Fd, n] buffer viewed as [..., Fd] (what py_binding.cpp:369 produces)
         with torch.cuda.device(field.device):
             _lib.check(lib.tn_interpolate_values_backward(D, V, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates),
@@ -468,8 +485,7 @@ def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, 
     g = grad_in.contiguous()
     grad_vm = torch.zeros((V, Fd), dtype=torch.float32, device=grad_in.device)
     with torch.cuda.device(field.device):
-        _lib.check(lib.tn_interpolate_values_backward_vm(D, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates),
-                                                         _ptr(g), _ptr(grad_vm), _stream(field.device)))
+        _gather_adjoint_vm(lib, D, V, n, Fd, vertex_indices, barycentric_coordinates, g, grad_vm, _stream(field.device))
         _lib.check(lib.tn_transpose_f32(V, Fd, _ptr(grad_vm), _ptr(grad_field_out), _stream(field.device)))
     return grad_field_out
 
@@ -912,7 +928,7 @@ def mlp_backward(saved, vertex_indices, barycentric_coordinates, field, dirs, we
             d_ray_bias = _empty((n // S, 128), dtype=torch.float32, device=dev)
             _lib.check(lib.tn_mlp_ray_head_grad(n, S, C.byref(bs), _ptr(d_ray_bias), stream))
         # gradient of the gathered features -> field (vertex-major accumulation)
-        _lib.check(lib.tn_interpolate_values_backward_vm(4, n, 64, _ptr(vi), _ptr(bc), _ptr(rows), _ptr(grad_vm), stream))
+        _gather_adjoint_vm(lib, 4, V, n, 64, vi, bc, rows, grad_vm, stream)
         grad_field = _empty((64, V), dtype=torch.float32, device=dev)
         _lib.check(lib.tn_transpose_f32(V, 64, _ptr(grad_vm), _ptr(grad_field), stream))
     if want_ray_head_grad:
