@@ -358,6 +358,7 @@ class TetraRenderer:
         # is read back ASYNCHRONOUSLY (pinned buffer + event, never waited for) and, when the last known fraction is below
         # SYNC_FREE_MIN_HITS, the next batches take the compacting form until it recovers
         self._hits_pinned, self._hits_event, self._hit_fraction = None, None, 1.0
+        self._hits_pending, self._hits_host_id, self._batch_id = None, 0, 0
         self.sync_free_min_hits = SYNC_FREE_MIN_HITS if sync_free_min_hits is None else float(sync_free_min_hits)
 
         self.cpp = cpp
@@ -568,33 +569,40 @@ class TetraRenderer:
         # parity tests) the stratified draws are the reference's, element for element; with misses they are the first
         # `count` rows of an [R, S+1] draw instead of an [r, S+1] draw -- the same distribution, another stream.
         sync_free = self.sync_free_train and fused and self.device_samplers and capture is None and not rand and R > 0
-        if self._hits_event is not None and self._hits_event.query():
+        self._batch_id += 1
+        if self._hits_pending is not None and self._hits_event.query():
             # (whenever the copy has landed, whatever form THIS call takes: a renderer that alternates between forms must not
-            #  decide on a stale fraction)
-            self._hit_fraction = float(self._hits_pinned[0]) / max(float(self._hits_pinned[1]), 1.0)   # of an EARLIER batch
+            #  decide on a stale fraction -- nor let the count of an older batch override one the host has seen since)
+            issued, rays = self._hits_pending
+            self._hits_pending = None
+            if issued > self._hits_host_id:
+                self._hit_fraction = float(self._hits_pinned[0]) / max(float(rays), 1.0)   # of an EARLIER batch
         sync_free = sync_free and self._hit_fraction >= self.sync_free_min_hits
+        ridx = None
         with torch.no_grad():
             out = self._trace(origins, directions)
             nv = out["num_visited_cells"]
             ray_mask = nv > 0
-            if self.sync_free_train and origins.is_cuda:
-                # asynchronous read-back of (hits, rays) of this batch for the decision of a later one
-                if self._hits_pinned is None:
-                    self._hits_pinned = torch.zeros(2, dtype=torch.float32).pin_memory()
-                    self._hits_event = torch.cuda.Event()
-                if self._hits_event.query():       # (the previous copy has landed: the buffer is free again)
-                    stats = torch.stack([ray_mask.sum().float(), torch.full((), float(R), device=dev)])
-                    self._hits_pinned.copy_(stats, non_blocking=True)
-                    self._hits_event.record(torch.cuda.current_stream(dev))
             if sync_free:
                 # ONE small kernel pair (tn_compact_hits) instead of a stable argsort of the miss flag (13 rocprim launches) +
                 # where: order = the hitting rays in ray order, then the others; padded = order with the tail naming order[0]
                 order32, count, padded = self.cpp.compact_hits(nv, want_padded=True)
                 order = order32.long()
                 valid = torch.arange(R, device=dev) < count     # (count is a one-element device tensor: no read-back)
-                idx = padded.long()
+                idx, ridx = padded.long(), padded
+                # asynchronous read-back of this batch's hit count for the decision of a later one: the count the compaction
+                # left on the device goes to pinned memory as it is (one copy; rounds 4's form built it from five small kernels)
+                if self._hits_pinned is None:
+                    self._hits_pinned = torch.zeros(1, dtype=torch.int32).pin_memory()
+                    self._hits_event = torch.cuda.Event()
+                if self._hits_pending is None:     # (no copy in flight: the buffer is free)
+                    self._hits_pinned.copy_(count, non_blocking=True)
+                    self._hits_event.record(torch.cuda.current_stream(dev))
+                    self._hits_pending = (self._batch_id, R)
             else:
                 idx = torch.nonzero(ray_mask)[:, 0]
+                if self.sync_free_train:           # this form knows its count on the host anyway
+                    self._hit_fraction, self._hits_host_id = idx.numel() / max(R, 1), self._batch_id
         bg = self._bg(background)
         rgb = self._background_rows(R, bg, dev)
         acc = torch.zeros((R, 1), dtype=torch.float32, device=dev)
@@ -603,7 +611,8 @@ class TetraRenderer:
             return {"rgb": rgb, "accumulation": acc, "depth": depth, "ray_mask": ray_mask}
         lists = [out[k] for k in ("num_visited_cells", "visited_cells", "barycentric_coordinates", "hit_distances",
                                   "vertex_indices")]
-        ridx = idx.to(torch.int32)
+        if ridx is None:
+            ridx = idx.to(torch.int32)
         r = idx.numel()
         record = fused and torch.is_grad_enabled()
         spacing = None            # spacing bins of the final samples (exact only on the PyTorch sampler path)
