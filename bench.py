@@ -186,7 +186,8 @@ def trace_breakdown(tracer, o, d, M):
 
 
 def cross_check(tracer):
-    """blind sample (every 256th certified ray) + risk classes (every certified ray inside the wide band of a guard)"""
+    """blind sample (every verify_stride-th certified ray: 1 in 1024 by default) + risk classes (every certified ray inside the
+    wide band of a guard)"""
     return tracer.cross_check()
 
 
@@ -254,6 +255,65 @@ def config_legs(tn, scenes, dev, M, box_ceiling_gbps=None):
             out["C4_ops"] = ops_leg(tn, tr, pts, scenes, M, dev)
         del tr
         torch.cuda.empty_cache()
+    return out
+
+
+def start_c6_mesh(n_points=1_000_000, seed=7):
+    """C6 = the reference's own upper size (tetranerf/scripts/triangulate.py:15 keeps up to 1,000,000 points): the Delaunay of
+    1M uniform points = 6.7M tets.  Qhull needs 60-110 s on one host core, so it runs in a child process from the start of
+    the bench, beside every other leg; `finish_c6_mesh` collects the cells."""
+    import subprocess
+    import tempfile
+
+    f = Path(tempfile.gettempdir()) / f"tetranerf_bench_delaunay_{n_points}_{seed}_{os.getpid()}.npy"
+    code = ("import numpy as np, sys; from scipy.spatial import Delaunay; "
+            f"p = np.random.default_rng({seed}).random(({n_points}, 3)).astype(np.float32); "
+            "np.save(sys.argv[1], np.ascontiguousarray(Delaunay(p.astype(np.float64)).simplices.astype(np.int32)))")
+    t0 = time.perf_counter()
+    proc = subprocess.Popen([sys.executable, "-c", code, str(f)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return {"proc": proc, "file": f, "n": n_points, "seed": seed, "t0": t0}
+
+
+def finish_c6_mesh(h, timeout_s=400.0):
+    try:
+        rc = h["proc"].wait(timeout=timeout_s)
+    except Exception:
+        h["proc"].kill()
+        return None
+    if rc != 0 or not h["file"].exists():
+        return None
+    cells = np.load(h["file"])
+    try:
+        h["file"].unlink()
+    except OSError:
+        pass
+    pts = np.random.default_rng(h["seed"]).random((h["n"], 3)).astype(np.float32)
+    return pts, cells, time.perf_counter() - h["t0"]
+
+
+def c6_legs(tn, scenes, dev, mesh, box_ceiling_gbps=None, M=1024):
+    """C6_ref_scale: 1M points / 6.7M tets (walk tables of 0.9 GB: 3.5x the 256 MiB Infinity Cache); rays cross 500-650 faces,
+    so M = 1024.  A 512x400 frame (204,800 rays) and one 4096-ray outside-in batch, each with its dense-row roofline, and the
+    time of load_tetrahedra (every structure built on the device)."""
+    pts, cells, qhull_s = mesh
+    tr = tn.TetrahedraTracer(dev)
+    x_dev, c_dev = torch.from_numpy(pts).to(dev), torch.from_numpy(cells).to(dev)
+    load_s = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.load_tetrahedra(x_dev, c_dev)
+        torch.cuda.synchronize()
+        load_s.append(time.perf_counter() - t0)
+    out = {}
+    for name, (o, d), reps in (("C6_frame_512x400", frame_rays(scenes, 0, 512, 400), 3),
+                                ("C6_batch_4096_outside_in", scenes.outside_in_rays(4096, 31), 10)):
+        leg = trace_leg(tr, torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), M, reps, box_ceiling_gbps)
+        leg.update(tets=int(len(cells)), points=int(len(pts)), max_ray_triangles=M, load_tetrahedra_s=load_s[1],
+                   load_tetrahedra_first_call_s=load_s[0], qhull_s_host=qhull_s)
+        out[name] = leg
+    del tr
+    torch.cuda.empty_cache()
     return out
 
 
@@ -559,6 +619,85 @@ def cpu_baseline(pts, cells, o, d, M, target_s=30.0):
             "sample": f"{n} random rays of the same frame, M={M}, oracle BVH path, {dt:.1f} s"}
 
 
+def _get(dct, *path):
+    for k in path:
+        if not isinstance(dct, dict) or k not in dct:
+            return None
+        dct = dct[k]
+    return dct
+
+
+def _r(x, nd=4):
+    return round(float(x), nd) if isinstance(x, (int, float)) and x == x else x
+
+
+def secondary_summary(line):
+    """Every graded secondary figure of the run in one small object (`roofline.secondary` of the printed line): the driver
+    keeps `roofline` whole, while the complete result is tens of KB (file named by --full-json)."""
+    cfg = line.get("configs") if isinstance(line.get("configs"), dict) else {}
+    sec = {}
+    for key, name in (("C4_frame", "C4_frame_800x800"), ("C4_batch_4096_oi", "C4_batch_4096_outside_in"),
+                      ("C4_batch_4096_io", "C4_batch_4096_inside_out"), ("C5", "C5_2^20_outside_in"),
+                      ("C6_frame", "C6_frame_512x400"), ("C6_batch_4096", "C6_batch_4096_outside_in")):
+        leg = cfg.get(name)
+        if isinstance(leg, dict):
+            e = {"frac": _r(_get(leg, "roofline", "frac")), "ms": _r(leg.get("ms")), "tets": leg.get("tets"),
+                 "frac_of_box_write_ceiling": _r(_get(leg, "roofline", "frac_of_box_write_ceiling"))}
+            if "load_tetrahedra_s" in leg:
+                e["load_tetrahedra_s"] = _r(leg["load_tetrahedra_s"])
+            sec[key] = e
+    tr = cfg.get("C4_train_4096")
+    if isinstance(tr, dict):
+        sec["train"] = {k: {"frac": _r(_get(v, "fused", "frac_of_fp32_mfma_peak_157.3")), "ms": _r(_get(v, "fused", "ms_per_iteration")),
+                            "pytorch_autograd_ms": _r(_get(v, "pytorch_autograd", "ms_per_iteration"))}
+                        for k, v in tr.items() if isinstance(v, dict)}
+    ops = cfg.get("C4_ops")
+    if isinstance(ops, dict):
+        sec["ops"] = {shape: {op: _r(_get(v, op, "roofline", "frac")) for op in ("find_visited_cells", "interpolate_values",
+                                                                                "interpolate_values_backward")}
+                      for shape, v in ops.items() if shape != "cpu_baseline" and isinstance(v, dict)}
+    rn = line.get("render")
+    if isinstance(rn, dict):
+        sec["render"] = {"coarse_only_ms": _r(rn.get("ms_per_frame"), 2), "mlp_forward_frac": _r(_get(rn, "roofline_mlp", "frac"))}
+        for k, v in (rn.get("eval_configs") or {}).items():
+            sec["render"][k] = {"one_launch_ms": _r(_get(v, "fp32", "ms_per_frame"), 2), "chain_ms": _r(_get(v, "fp32_kernel_chain", "ms_per_frame"), 2),
+                                "bf16x3_ms": _r(_get(v, "bf16x3", "ms_per_frame"), 2), "one_launch_over_chain": _r(v.get("one_launch_over_chain"))}
+    if isinstance(line.get("sharded_render"), dict):
+        sec["sharded_render"] = {"ms_per_frame": _r(line["sharded_render"].get("ms_per_frame"), 2),
+                                 "all_gather_ms": _r(line["sharded_render"].get("all_gather_ms"))}
+    if isinstance(line.get("ddp_train_4096"), dict):
+        sec["ddp_train_4096"] = {k: {"ms": _r(v.get("ms_per_iteration")), "exposed_all_reduce_ms": _r(v.get("exposed_all_reduce_ms"))}
+                                 for k, v in line["ddp_train_4096"].items() if isinstance(v, dict)}
+    return sec
+
+
+SHORT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "rays_per_s", "config", "roofline", "cpu_baseline")
+
+
+def emit(line, args):
+    """The complete result -> a file (and stderr); ONE short JSON line (<= 4 KB) -> stdout, the last thing printed."""
+    line["roofline"]["secondary"] = secondary_summary(line)
+    full = json.dumps(line)
+    target = Path(args.full_json) if args.full_json else ROOT / "gpurun_out" / "bench_full.json"
+    try:
+        target.parent.mkdir(parents=True, exist_ok=True)
+        target.write_text(full + "\n")
+        where = str(target)
+    except OSError:
+        where = "stderr only"
+    print(full, file=sys.stderr, flush=True)
+    short = {k: line[k] for k in SHORT_KEYS if k in line}
+    roof = dict(short["roofline"])
+    roof.pop("box_write_ceiling", None)          # the scalar box_write_ceiling_GBps stays
+    short["roofline"] = roof
+    if isinstance(short.get("cpu_baseline"), dict):
+        short["cpu_baseline"] = {k: v for k, v in short["cpu_baseline"].items() if k != "ops"}
+    short["certification_mismatches"] = _get(line, "certification_cross_check", "mismatches")
+    short["full_result"] = where
+    print(json.dumps(short), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -573,6 +712,10 @@ def main():
     ap.add_argument("--no-render", action="store_true", help="skip the rendered-rays/s legs")
     ap.add_argument("--no-configs", action="store_true", help="skip the C4 / C5 legs")
     ap.add_argument("--no-ddp", action="store_true", help="skip the DDP training leg of multi-rank runs")
+    ap.add_argument("--no-c6", action="store_true", help="skip the reference-scale leg (1M points / 6.7M tets; 60-110 s of Qhull beside the other legs)")
+    ap.add_argument("--full-json", default=None,
+                    help="file for the complete result (default: gpurun_out/bench_full.json under the repository); stdout carries the "
+                         "short line (<= 4 KB) whose `roofline.secondary` holds every graded fraction")
     ap.add_argument("--no-calibration", action="store_true",
                     help="skip the box write-ceiling measurement and the serialised breakdown (rocprofv3 PMC passes: only the bench launches)")
     args = ap.parse_args()
@@ -604,6 +747,7 @@ def main():
     tn = importlib.import_module("tetra-nerf_amd")
     scenes = importlib.import_module("tetra-nerf_amd.scenes")
 
+    c6 = start_c6_mesh() if (world == 1 and rank == 0 and not args.no_configs and not args.no_c6) else None
     pts, cells = scenes.random_mesh(args.mesh_points, args.mesh_seed)
     o_np, d_np = frame_rays(scenes, rank, args.width, args.height)
     R, M = len(o_np), args.max_ray_triangles
@@ -686,9 +830,8 @@ def main():
             "data": "synthetic",
             "rays_per_s": tot_rays * args.steps / elapsed,
             "config": {
-                "workload": f"configs[1] stand-in: Delaunay of {args.mesh_points} uniform points seed {args.mesh_seed} "
-                            f"({len(cells)} tets), {args.width}x{args.height} pinhole frame = {R} rays per GPU, "
-                            f"trace_rays M={M}, dense reference outputs",
+                "workload": f"configs[1] stand-in: {len(cells)}-tet Delaunay ({args.mesh_points} uniform points, seed {args.mesh_seed}), "
+                            f"{args.width}x{args.height} frame = {R} rays/GPU, trace_rays M={M}, dense reference rows",
                 "tets": int(len(cells)), "mesh_sha256": mesh_sha256(pts, cells), "rays_per_gpu": R, "max_ray_triangles": M,
                 "intersections_per_frame": inter, "sharding": f"rays/{world} ranks, no collective",
             },
@@ -700,12 +843,11 @@ def main():
                 # fills, literal pairing, BVH fallback, cross-check -- over the HIP-event duration of the call.  The dominant
                 # kernel by time and bytes is k_fill_range (the constant tails, 88 % of the bytes): its own rate is
                 # `box_write_ceiling_GBps`, measured in this process on this box
-                "kernel": "trace_rays launch = k_trace_walk + k_write_segments + 2 x k_fill_range (dominant) + k_postprocess_log + "
-                          "k_trace_general + k_verify_counts",
+                "kernel": "trace_rays launch: k_trace_walk, k_write_segments, 2 x k_fill_range (dominant), k_postprocess_log, "
+                          "k_trace_general, k_verify_counts",
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                 "box_write_ceiling_GBps": ceiling["GBps"], "box_write_ceiling": ceiling,
                 "frac_of_box_write_ceiling": achieved / ceiling["GBps"],
-                "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
                 "breakdown_ms_serialised": breakdown,
             },
             "ms_per_step_per_rank": per_rank_ms, "kernel_ms_per_rank": per_rank_kern_ms,
@@ -758,6 +900,13 @@ def main():
             del tracer
             torch.cuda.empty_cache()
             line["configs"] = config_legs(tn, scenes, dev, M, ceiling["GBps"])
+            if c6 is not None:
+                mesh6 = finish_c6_mesh(c6)
+                if mesh6 is not None:
+                    line["configs"].update(c6_legs(tn, scenes, dev, mesh6, ceiling["GBps"]))
+                    del mesh6
+                else:
+                    line["configs"]["C6_ref_scale"] = "Qhull child process failed or timed out"
             line["configs"]["C2_frame_800x800"] = {"rays": R, "ms": kern_ms, "rays_per_s": R / (kern_ms * 1e-3),
                                                    "intersections_per_s": inter / (kern_ms * 1e-3), "intersections": inter,
                                                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -773,7 +922,7 @@ def main():
             ops = line.get("configs", {}).get("C4_ops") if isinstance(line.get("configs"), dict) else None
             if ops and "cpu_baseline" in ops:
                 line["cpu_baseline"]["ops"] = ops["cpu_baseline"]
-        print(json.dumps(line), flush=True)
+        emit(line, args)
     if dist is not None:
         dist.destroy_process_group()
 

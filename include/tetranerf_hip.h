@@ -37,8 +37,15 @@ typedef struct tn_tracer *tn_tracer_t;
 /* thread-local text of the last error raised on this thread ("" if none) */
 const char *tn_last_error(void);
 
-/* library / build identification: "tetranerf_hip <version> gfx950" */
+/* library / build identification: "tetranerf_hip <version> abi <TN_ABI_VERSION> gfx950" */
 const char *tn_version(void);
+
+/* Number of this header's binary interface: raised whenever an exported signature changes (round 5 added count / ray_index
+ * pointers to tn_find_matched_cells_indexed, tn_mlp_forward_gather, tn_composite, tn_sample_coarse, tn_sample_pdf and removed
+ * tn_render_pass).  A binding compares tn_abi_version() of the library it loaded with the TN_ABI_VERSION it was written
+ * against and refuses a mismatch (tetra-nerf_amd/_lib.py does) instead of calling through shifted arguments. */
+#define TN_ABI_VERSION 6
+int tn_abi_version(void);
 
 /* TetrahedraTracer::TetrahedraTracer(int8_t device)   src/tetrahedra_tracer.h:284-378,
  *                                                       src/tetrahedra_tracer.cpp:90-135

@@ -29,16 +29,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_bench_gpus_2_starts_two_ranks(device):
+def test_bench_gpus_2_starts_two_ranks(device, tmp_path):
     env = dict(os.environ, TETRANERF_BENCH_BACKEND="gloo", TETRANERF_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-configs",
-                        "--no-cpu-baseline", "--width", "320", "--height", "200", "--mesh-points", "3000"],
+                        "--no-cpu-baseline", "--width", "320", "--height", "200", "--mesh-points", "3000",
+                        "--full-json", str(tmp_path / "full.json")],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]          # rank 0 alone prints
-    line = json.loads(lines[0])
+    # stdout: the SHORT line (the driver keeps 8 KB of stdout): the contract keys + roofline.secondary; the complete result: the file
+    assert len(lines[0]) <= 4096, len(lines[0])
+    short = json.loads(lines[0])
+    assert short["n_gpus"] == 2 and short["value"] > 0 and short["full_result"] == str(tmp_path / "full.json")
+    sec = short["roofline"]["secondary"]
+    assert sec["sharded_render"]["ms_per_frame"] > 0 and set(sec["ddp_train_4096"]) == {"tetra-nerf-original", "tetra-nerf"}
+    line = json.loads((tmp_path / "full.json").read_text())
+    assert all(line[k] == short[k] for k in ("metric", "value", "ms_per_step", "n_gpus", "config"))
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["rays_per_gpu"] == 320 * 200
     assert line["rays_per_s"] * line["ms_per_step"] * 1e-3 == pytest.approx(2 * 320 * 200, rel=1e-6)   # units of BOTH ranks

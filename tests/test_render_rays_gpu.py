@@ -94,6 +94,32 @@ def test_one_launch_render_is_bit_identical_to_the_kernel_chain(tn, device, scen
     assert bool((a["rgb"][~a["ray_mask"]] == torch.tensor([0.1, 0.5, 0.9], device=device)).all())
 
 
+@pytest.mark.parametrize("M", [4, 8, 16])
+def test_one_launch_render_small_max_ray_triangles(tn, device, scenes, render, M):
+    """max_ray_triangles of 4 / 8 (both accepted by trace_rays): 2 M < 28, so the 28 floats of the direction encoding at the start
+    of a wave's LDS region reached into the coarse edges kept at offset 2 M (the matcher then read corrupted edges
+    and the default render differed from the kernel chain).  The edges now sit behind max(2 M, 28) floats."""
+    import torch
+
+    pts, cells = scenes.cube_mesh()                      # 12 tets: rays cross at most a handful of faces
+    tr = tn.TetrahedraTracer(device)
+    tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+    torch.manual_seed(5)
+    mlp = render.TetraMLP().to(device)
+    field = torch.randn(64, len(pts), device=device) * 0.5
+    o, d = _frame(scenes, device, 96, 64, dist=2.5)
+    for S, S_fine, biased in ((64, 0, False), (48, 32, False), (32, 32, True)):
+        one = render.TetraRenderer(tr, field, mlp, S, M, fused=True, num_fine_samples=S_fine, biased=biased, fused_pass=True)
+        chain = render.TetraRenderer(tr, field, mlp, S, M, fused=True, num_fine_samples=S_fine, biased=biased, fused_pass=False)
+        assert one._one_launch_ok("fp32")
+        a, b = one.render(o, d), chain.render(o, d)
+        assert int(a["ray_mask"].sum()) > 500
+        assert torch.equal(a["ray_mask"], b["ray_mask"])
+        for k in ("rgb", "accumulation", "depth"):
+            assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), (M, S, k, float((a[k] - b[k]).abs().max()))
+        assert float(a["accumulation"].max()) > 0.05 and bool(torch.isfinite(a["rgb"]).all())
+
+
 def test_one_launch_render_of_a_whole_frame_in_one_call(tn, device, scenes, render):
     """No chunking: 307,200 rays in ONE render call (every block works through dozens of tiles, the hitting-ray count is far
     beyond a 65,536-ray chunk's) -- still bit-identical to the kernel chain, for both shipped sample configurations."""

@@ -16,7 +16,7 @@ LIB_PATH = Path(os.environ["TETRANERF_HIP_LIB"]).resolve() if os.environ.get("TE
 
 # every symbol include/tetranerf_hip.h declares
 SYMBOLS = (
-    "tn_last_error", "tn_version", "tn_tracer_create", "tn_tracer_destroy", "tn_load_tetrahedra",
+    "tn_last_error", "tn_version", "tn_abi_version", "tn_tracer_create", "tn_tracer_destroy", "tn_load_tetrahedra",
     "tn_num_faces", "tn_get_faces", "tn_get_build_table", "tn_trace_rays", "tn_trace_rays_ex", "tn_trace_rays_triangles", "tn_find_tetrahedra",
     "tn_find_matched_cells", "tn_find_matched_cells_indexed",
     "tn_interpolate_values", "tn_interpolate_values_backward", "tn_interpolate_values_backward_rows",
@@ -27,6 +27,8 @@ SYMBOLS = (
     "tn_mlp_forward_gather_train", "tn_mlp_backward", "tn_mlp_ray_head_grad", "tn_mlp_param_grads", "tn_composite_backward", "tn_sample_coarse", "tn_sample_pdf",
     "tn_trace_timings", "tn_trace_cross_check", "tn_fill_rows", "tn_compact_hits", "tn_render_rays",
 )
+
+ABI_VERSION = 6          # include/tetranerf_hip.h: TN_ABI_VERSION this binding was written against
 
 _lib = None
 
@@ -46,6 +48,11 @@ def load():
     lib.tn_last_error.argtypes = []
     lib.tn_version.restype = C.c_char_p
     lib.tn_version.argtypes = []
+    if not hasattr(lib, "tn_abi_version") or lib.tn_abi_version() != ABI_VERSION:
+        got = lib.tn_abi_version() if hasattr(lib, "tn_abi_version") else "none (a build older than ABI 6)"
+        raise RuntimeError(f"ERROR: {LIB_PATH} exports ABI {got}, this binding needs ABI {ABI_VERSION} "
+                           "(include/tetranerf_hip.h: TN_ABI_VERSION). Rebuild it: python __graft_entry__.py")
+    lib.tn_abi_version.argtypes = []
     lib.tn_tracer_create.argtypes = [i32, C.POINTER(vp)]
     lib.tn_tracer_destroy.argtypes = [vp]
     lib.tn_load_tetrahedra.argtypes = [vp, sz, sz, vp, vp, vp]
@@ -93,7 +100,7 @@ def load():
     lib.tn_render_rays.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, sz, u32, u32, i32, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("tn_last_error", "tn_version", "tn_num_faces"):
+        if fn.restype is C.c_int and name not in ("tn_last_error", "tn_version", "tn_abi_version", "tn_num_faces"):
             fn.restype = C.c_int
     _lib = lib
     return lib

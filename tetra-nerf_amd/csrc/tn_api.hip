@@ -151,7 +151,10 @@ extern "C" {
 
 const char *tn_last_error(void) { return tn::g_last_error.c_str(); }
 
-const char *tn_version(void) { return "tetranerf_hip 0.1.0 gfx950"; }
+#define TN_STR2(x) #x
+#define TN_STR(x) TN_STR2(x)
+const char *tn_version(void) { return "tetranerf_hip 0.6.0 abi " TN_STR(TN_ABI_VERSION) " gfx950"; }
+int tn_abi_version(void) { return TN_ABI_VERSION; }
 
 int tn_tracer_create(int device, tn_tracer_t *out) {
     return guarded([&] {
@@ -783,9 +786,10 @@ int tn_fill_rows(size_t R, uint32_t M, uint32_t first_slot, uint32_t *visited, f
         if (!visited || !bary || !dist) throw tn::Error("null output pointer");
         if (M < 4 || (M & (M - 1)) != 0) throw tn::Error("max_ray_triangles must be a power of 2.");
         if (first_slot >= M) return;
-        // rows are written from a 128-byte line boundary of all four arrays on (multiples of 32 slots), like the tracer's own fill
-        tn::launch_fill_range(R, M, true, nullptr, nullptr, visited, bary, dist, verts, (hipStream_t)stream_, first_slot & ~31u, false,
-                              512);
+        // rows are written from a 128-byte line boundary of all four arrays on (multiples of 32 slots), like the tracer's own fill;
+        // any other first slot is refused rather than rounded: rounding down would overwrite up to 31 written segments
+        if (first_slot & 31u) throw tn::Error("tn_fill_rows: first_slot must be a multiple of 32");
+        tn::launch_fill_range(R, M, true, nullptr, nullptr, visited, bary, dist, verts, (hipStream_t)stream_, first_slot, false, 512);
         TN_HIP(hipGetLastError());
     });
 }
@@ -891,6 +895,11 @@ int tn_interpolate_values_backward_vm(uint32_t D, uint32_t n, uint32_t Fd, const
 int tn_interpolate_values_backward_vm_det(uint32_t D, uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc,
                                           const float *grad_rows, float *field_grad_vm, void *stream_) {
     return guarded([&] {
+        if (n == 0 || Fd == 0) return;
+        if (!vi || !bc || !grad_rows || !field_grad_vm) throw tn::Error("null pointer");
+        if (V == 0) throw tn::Error("interpolate_values backward (deterministic): the vertex count is 0");
+        // vertex ids >= V (TN_EMPTY = an unmatched slot, and any other out-of-range id) sort behind every vertex's run and are
+        // skipped; the atomic entry point would write through such an id (the reference does not check either, py_binding.cpp:309-311)
         tn::launch_interpolate_values_backward_vm_det(D, V, n, Fd, vi, bc, grad_rows, field_grad_vm, (hipStream_t)stream_);
         TN_HIP(hipGetLastError());
     });
@@ -1043,7 +1052,11 @@ int tn_render_rays(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const 
         }
         // debug aid: TETRANERF_HIP_RENDER_PROFILE=1 prints where the persistent kernel's blocks spent their time, per call
         // (a stream synchronisation per call: for profiling runs only)
-        static const bool profile = env_flag("TETRANERF_HIP_RENDER_PROFILE", false);
+#if defined(TN_RENDER_DIAG) && TN_RENDER_DIAG
+        static const bool profile = env_flag("TETRANERF_HIP_RENDER_PROFILE", false);   // diagnostic builds only (tn_render_rays.hip)
+#else
+        constexpr bool profile = false;
+#endif
         if (profile) {
             if (!m->render_prof.p) m->render_prof.alloc(8);
             TN_HIP(hipMemsetAsync(m->render_prof.p, 0, 8 * sizeof(unsigned long long), (hipStream_t)stream_));

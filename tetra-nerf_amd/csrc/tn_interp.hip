@@ -403,14 +403,17 @@ void run_bwd_det(uint32_t V, uint32_t n, uint32_t Fd, const uint32_t *vi, const 
                  hipStream_t stream) {
     const size_t np = (size_t)n * D;
     if (np > 0xFFFFFFFFull) throw Error("interpolate_values backward (deterministic): too many samples");
-    AsyncBuf keys(np, stream), vals(np, stream), iota(np, stream), bounds(2 * (size_t)V, stream);
-    uint32_t *ks = reinterpret_cast<uint32_t *>(keys.p), *vs = reinterpret_cast<uint32_t *>(vals.p), *io = reinterpret_cast<uint32_t *>(iota.p);
-    uint32_t *st = reinterpret_cast<uint32_t *>(bounds.p), *en = st + V;
-    hipLaunchKernelGGL(k_iota, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, (uint32_t)np, io);
+    // ONE stream-ordered allocation per call (keys | values | iota | run bounds | rocprim's scratch); the pool keeps it cached
+    // between calls, so a training step that takes this path every iteration does not touch the allocator after the first
     size_t bytes = 0;
-    TN_HIP(rocprim::radix_sort_pairs(nullptr, bytes, vi, ks, io, vs, np, 0u, 32u, stream));
-    AsyncBuf tmp((bytes + 3) / 4 + 64, stream);
-    TN_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, vi, ks, io, vs, np, 0u, 32u, stream));
+    TN_HIP(rocprim::radix_sort_pairs(nullptr, bytes, vi, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, np, 0u, 32u, stream));
+    const size_t npa = (np + 63) & ~(size_t)63, nb = (2 * (size_t)V + 63) & ~(size_t)63;
+    AsyncBuf all(3 * npa + nb + (bytes + 3) / 4 + 64, stream);
+    uint32_t *ks = reinterpret_cast<uint32_t *>(all.p), *vs = ks + npa, *io = vs + npa;
+    uint32_t *st = io + npa, *en = st + V;
+    void *tmp = st + nb;
+    hipLaunchKernelGGL(k_iota, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, (uint32_t)np, io);
+    TN_HIP(rocprim::radix_sort_pairs(tmp, bytes, vi, ks, io, vs, np, 0u, 32u, stream));
     TN_HIP(hipMemsetAsync(st, 0, 2 * (size_t)V * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(k_run_bounds, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, (uint32_t)np, ks, V, st, en);
     const unsigned grid = V < 256u * 64u ? V : 256u * 64u;

@@ -58,7 +58,7 @@ struct WalkParams {
                                // ((r / 64) * M + k) * 64 + r % 64 (a wave's 64 lanes store 1 KB of consecutive bytes per
                                // step); exit code 3 = entry hull face, its face id in the low 30 bits
     size_t ray_base;           // global index of item 0 (rays are traced in chunks when the log would be too large)
-    uint32_t *risk_list;       // [num_items] certified rays inside the WIDE band (64 delta) of a certification guard: every one of
+    uint32_t *risk_list;       // [num_items] certified rays inside the WIDE band (risk_band x 8 delta: 16 delta by default) of a certification guard: every one of
     uint32_t *risk_count;      // [1]          them is cross-checked (k_verify_counts); null: not collected
     float risk_band;           // width of that band in units of the guards' own 8 delta (tn option "risk_band")
 };

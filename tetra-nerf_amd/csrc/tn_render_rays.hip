@@ -32,8 +32,19 @@ using namespace rayops;
 
 namespace {
 
+// Run-time diagnostics that CHANGE RESULTS (phase skipping) or add work (phase clocks) exist only in a diagnostic build
+// (make CXXFLAGS+=-DTN_RENDER_DIAG=1, as profiles/r05q_mlp_phase_only.py / r05n_prof_overlap.sh need): the product kernel
+// carries neither the tests nor the environment variables.
+#ifndef TN_RENDER_DIAG
+#define TN_RENDER_DIAG 0
+#endif
+constexpr bool DIAG = TN_RENDER_DIAG != 0;
+// first float of the coarse edges in a wave's LDS region during ray phase 1: behind the matcher's tin / pmax [2 M] AND behind the
+// 28 floats ray_dir_encoding writes at the start of the region (M = 4 / 8: 2 M < 28 -- the encoding used to overwrite the edges)
+__host__ __device__ inline size_t phase1_edges_offset(uint32_t M) { return 2 * (size_t)M > 28 ? 2 * (size_t)M : 28; }
+
 struct RenderRaysParams {
-    uint32_t skip;   // diagnostic (TETRANERF_HIP_RENDER_SKIP): bit 0 / 1 / 2 = leave out ray phase 1 / 2 / 3 -- the MLP phases then run on the
+    uint32_t skip;   // DIAG builds only (TETRANERF_HIP_RENDER_SKIP): bit 0 / 1 / 2 = leave out ray phase 1 / 2 / 3 -- the MLP phases then run on the
                      // sample placement the previous launch left in the scratch: their time alone (profiles/r05q_mlp_phase_only.py)
 
     // trace rows (outputs of tn_trace_rays, read in place)
@@ -63,7 +74,7 @@ struct RenderRaysParams {
     uint32_t T;                    // tile capacity in rays
     size_t o_edges_f, o_hterm, o_vi, o_bc, o_sigma, o_rgb;   // (edges_c at 0)
     uint32_t region;               // floats of LDS per wave for the ray phases
-    unsigned long long *prof;      // [8] debug (TETRANERF_HIP_RENDER_PROFILE=1): 100 MHz ticks per phase kind, summed over blocks
+    unsigned long long *prof;      // [8] DIAG builds only (TETRANERF_HIP_RENDER_PROFILE=1): 100 MHz ticks per phase kind, summed over blocks
 };
 
 // one ray's samples (the bin centres of e[0 .. S]) against its segments: vi [S] x 4 ids, bc [S] x 3 weights.  The expressions
@@ -282,10 +293,11 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
     // phase profile (debug): thread 0 adds the ticks of a phase straight to the global counters when it ends; nothing is kept
     // in registers across the MLP phases (per-thread accumulators cost 14 VGPRs alive through the whole kernel: spills)
     unsigned long long t_prev = 0;
-    if (p.prof && threadIdx.x == 0) { t_prev = wall_clock64(); atomicAdd(&p.prof[5], 1ull); }
-    auto tick = [&](int k) {      // phase k ends here (a null test when profiling is off)
-        if (p.prof && threadIdx.x == 0) { const unsigned long long t = wall_clock64(); atomicAdd(&p.prof[k], t - t_prev); t_prev = t; }
+    if constexpr (DIAG) if (p.prof && threadIdx.x == 0) { t_prev = wall_clock64(); atomicAdd(&p.prof[5], 1ull); }
+    auto tick = [&](int k) {      // phase k ends here (nothing in the product build)
+        if constexpr (DIAG) if (p.prof && threadIdx.x == 0) { const unsigned long long t = wall_clock64(); atomicAdd(&p.prof[k], t - t_prev); t_prev = t; }
     };
+    const uint32_t skip = DIAG ? p.skip : 0u;
     // per-wave LDS for ray phase 2: [coarse weights: S floats][PDF sampler], re-used by the matcher afterwards
     const uint32_t w_floats = (S + 3u) & ~3u;
     for (size_t tq = q0; tq < q1;) {
@@ -306,8 +318,8 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
         }
         // ---- ray phase 1: coarse sampler -> matcher (+ the head layer's per-ray term) of this wave's rays.  The edges reach
         //      the matcher through the wave's LDS (and global memory for the later phases): no store -> load round trip
-        float *el = wl + 2 * (size_t)M;                      // [S + 1] behind the matcher's tin / pmax
-        if (!(p.skip & 1u)) for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
+        float *el = wl + phase1_edges_offset(M);             // [S + 1] behind the matcher's tin / pmax and the direction encoding
+        if (!(skip & 1u)) for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
             const size_t ray = (uint32_t)__builtin_amdgcn_readlane((int)l_ray, (int)i);
             const uint32_t nv = (uint32_t)__builtin_amdgcn_readlane((int)l_nv, (int)i);
             const float near = __shfl(l_near, (int)i), far = __shfl(l_far, (int)i);
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
             // fine edges behind both
             const size_t o_merged = std::max<size_t>(2 * (size_t)M, w_floats + pdf_lds_floats(S, nb));
             const bool lds_edges = pdf_writes_second_copy(S, nb);
-            if (!(p.skip & 2u)) for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
+            if (!(skip & 2u)) for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
                 const size_t ray = (uint32_t)__builtin_amdgcn_readlane((int)l_ray, (int)i);
                 const uint32_t nv = (uint32_t)__builtin_amdgcn_readlane((int)l_nv, (int)i);
                 const float near = __shfl(l_near, (int)i), far = __shfl(l_far, (int)i);
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
         tick(3);
         // ---- ray phase 3: weights + renderers, scattered into the frame
         const float *ee = FINE ? edges_f : edges_c;
-        if (!(p.skip & 4u)) for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
+        if (!(skip & 4u)) for (uint32_t t = wave, i = 0; t < nt; t += NW, ++i) {
             const size_t ray = (uint32_t)__builtin_amdgcn_readlane((int)l_ray, (int)i);
             ray_composite(Sf, sigma + (size_t)t * Sf, rgb + 3 * (size_t)t * Sf, ee + (size_t)t * (Sf + 1), p.bg, p.out_rgb + 3 * ray,
                           p.out_acc + ray, p.out_depth + ray, nullptr, lane);
@@ -429,13 +441,13 @@ void launch_render_rays(const uint32_t *num_visited, const float *dist, const fl
     // per wave: phase 1 = [tin / pmax (or the biased sampler's cum): 2 M][coarse edges: S + 1]; phase 2 = [coarse weights |
     // PDF sampler, re-used as tin / pmax][merged fine edges: S + nb + 1]
     const size_t w_fl = ((size_t)S + 3) & ~(size_t)3;
-    const size_t region = (std::max<size_t>(2 * (size_t)M + (S + 1), S_fine ? std::max<size_t>(2 * (size_t)M, w_fl + pdf_lds_floats(S, nb)) +
+    const size_t region = (std::max<size_t>(phase1_edges_offset(M) + (S + 1), S_fine ? std::max<size_t>(2 * (size_t)M, w_fl + pdf_lds_floats(S, nb)) +
                                                                                   (size_t)S + nb + 1 : 0) + 3) & ~(size_t)3;
     const size_t lds_floats = std::max<size_t>(MAX_STAGE_FLOATS, (RR_BLOCK / 64) * region);
     const size_t smem = lds_floats * sizeof(float);
     if (smem > 160 * 1024) throw Error("render_rays: max_ray_triangles / samples per ray too large for the per-wave LDS regions");
     RenderRaysParams p{};
-    { const char *v = std::getenv("TETRANERF_HIP_RENDER_SKIP"); p.skip = v && *v ? (uint32_t)std::atoi(v) : 0u; }
+    if constexpr (DIAG) { const char *v = std::getenv("TETRANERF_HIP_RENDER_SKIP"); p.skip = v && *v ? (uint32_t)std::atoi(v) : 0u; }
     p.num_visited = num_visited; p.dist = dist; p.bary = bary; p.verts = verts; p.M = M;
     p.ray_index = ray_index; p.count = count; p.r_max = r_max;
     p.S = S; p.S_fine = S_fine; p.biased = biased ? 1 : 0;
@@ -446,7 +458,7 @@ void launch_render_rays(const uint32_t *num_visited, const float *dist, const fl
     p.o_edges_f = L.o_edges_f; p.o_hterm = L.o_hterm; p.o_vi = L.o_vi; p.o_bc = L.o_bc;
     p.o_sigma = L.o_sigma; p.o_rgb = L.o_rgb;
     p.region = (uint32_t)region;
-    p.prof = prof;
+    p.prof = DIAG ? prof : nullptr;
     static PerDeviceOnce lds_attr;
     lds_attr.run([&] {
         allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<false>), 160 * 1024);

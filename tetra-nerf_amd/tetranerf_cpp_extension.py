@@ -199,6 +199,7 @@ class TetrahedraTracer:
             _check(x.device == self._device, f"{name} must be on the same device")
         _check(distances.dtype == torch.float32, "distances must have float32 type")
         R = num_visited_cells.size(0)
+        _check(count is None or ray_index is not None, "find_visited_cells: `count` needs `ray_index` (it counts rows of that list)")
         if ray_index is not None:
             _check_input(ray_index, "ray_index")
             _check(ray_index.dtype == torch.int32 and ray_index.dim() == 1, "ray_index must be int32 [r]")
@@ -323,7 +324,8 @@ class TetrahedraTracer:
 
 
 def fill_rows(visited_cells, barycentric_coordinates, hit_distances, vertex_indices=None, first_slot=0):
-    """The constant tails of trace_rays' dense rows (tn_fill_rows) from slot `first_slot & ~31` on, in place, for every row."""
+    """The constant tails of trace_rays' dense rows (tn_fill_rows) from slot `first_slot` (a multiple of 32: a 128-byte line
+    boundary of all four arrays; anything else raises) on, in place, for every row."""
     for x, name in ((visited_cells, "visited_cells"), (barycentric_coordinates, "barycentric_coordinates"),
                     (hit_distances, "hit_distances")) + (() if vertex_indices is None else ((vertex_indices, "vertex_indices"),)):
         _check_input(x, name)
