@@ -78,6 +78,20 @@
 #include "tn_device.h"
 #include "tn_kernels.h"
 
+// Diagnostic builds only (make CXXFLAGS+=-DTN_WALK_DIAG=1; profiles/r06b_literal_reasons.py): which rule of the order test made
+// a ray "literal" -- the FIRST violated one per ray, counted in g_walk_diag[1..8]; [0] = literal rays, [9..15] see below.
+#ifndef TN_WALK_DIAG
+#define TN_WALK_DIAG 0
+#endif
+#if TN_WALK_DIAG
+__device__ unsigned long long g_walk_diag[16];
+extern "C" int tn_debug_walk_diag(unsigned long long out[16], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_diag), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_walk_diag), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
 namespace tn {
 
 namespace {
@@ -283,6 +297,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     float pt = 0.f, ppt = 0.f;  // t of the previous recorded hit and of the one before
     uint32_t nhits = 0, nshort = 0;
     uint32_t steps = 0;
+#if TN_WALK_DIAG
+    uint32_t lit_why = 0, n_viol = 0, n_inv_long = 0;
+#endif
     Var cur = load_var(p.vars, c);
     if (alive && ((cur.code_hi >> 8) & 0xFFu) <= thin_exp) {
         const uint32_t eb0 = edge_band(Uc, B, C) | edge_band(Vc, C, A) | edge_band(Wc, A, B);
@@ -353,15 +370,33 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
                                             : (!prev_short && have_pp && clear2))
                                      : (asc && (!prev_inv || clear2));
             order_ok = order_ok && (!vp || ok);
+#if TN_WALK_DIAG
+            if (vp && !ok) {
+                // 1 short asc after an inverted pair | 2 two short gaps at the entry face | 3 short inverted after a short gap
+                // 4 short inverted as the first pair | 5 short inverted, the face before within eps | 6 inverted by eps or more
+                // 7 long asc after an inverted pair, not clear of it
+                const uint32_t r = is_short ? (asc ? (prev_inv ? 1u : 2u) : (prev_short ? 3u : (!have_pp ? 4u : 5u))) : (asc ? 7u : 6u);
+                lit_why = lit_why ? lit_why : r;
+                n_viol++;
+                n_inv_long += r == 6u ? 1u : 0u;
+            }
+#endif
             nshort += (vp && is_short) ? 1u : 0u;
             prev_inv = vp ? (is_short && !asc) : prev_inv;
             prev_short = vp ? is_short : prev_short;
         }
         bad = (!bad && !valid && have_prev) ? 10u : bad;        // the hit list is not a suffix of the chain
         bad = (!bad && valid && nhits >= M - 1) ? 9u : bad;     // more than M-1 faces
-        if (valid && nhits < M - 1) {
-            // hit `nhits` of this ray: (t, u, v) in the face's stored order + the tet it closes (variant, exit)
-            mylog[(size_t)nhits * 64] = make_uint4(__float_as_uint(ct), __float_as_uint(cu), __float_as_uint(cv), c | (x << 30));
+        {
+            // hit `nhits` of this ray: (t, u, v) in the face's stored order + the tet it closes (variant, exit).  The store is
+            // UNCONDITIONAL (round 6): behind a branch the compiler ends every step with s_waitcnt vmcnt(0) -- the step then waits
+            // for the acknowledgement of its own log store, which under the write stream of the fill running beside the walk takes
+            // several times the record load's latency -- while a straight-line store leaves vmcnt(1) at the top of the loop (only
+            // the next record must be back).  A step without a valid hit writes a dummy entry into slot `nhits`, which the next
+            // valid hit overwrites and no reader looks at (readers stop at the ray's hit count); slot M - 1 takes the entries of
+            // a ray that overflows (reason 9: its row comes from the BVH path).
+            const uint32_t slot_k = nhits < M - 1 ? nhits : M - 1;
+            mylog[(size_t)slot_k * 64] = make_uint4(__float_as_uint(ct), __float_as_uint(cu), __float_as_uint(cv), c | (x << 30));
         }
         nhits += valid ? 1u : 0u;
         have_pp = valid ? have_prev : have_pp;
@@ -393,6 +428,14 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             if (t.stats) atomicAdd(&t.stats[4 + (flag ? why : 7u)], 1ull);
             p.walk_n[ray] = TN_EMPTY;   // the BVH kernel writes the whole row
         } else if (!order_ok) {
+#if TN_WALK_DIAG
+            atomicAdd(&g_walk_diag[0], 1ull);
+            atomicAdd(&g_walk_diag[lit_why ? lit_why : 8u], 1ull);                 // 8: a pair inverted at the very end
+            atomicAdd(&g_walk_diag[9], n_viol == 1 ? 1ull : 0ull);                 // rays with exactly one violation
+            atomicAdd(&g_walk_diag[10], (unsigned long long)n_viol);               // violations in total
+            atomicAdd(&g_walk_diag[11], n_inv_long ? 1ull : 0ull);                 // rays with an inversion by eps or more
+            atomicAdd(&g_walk_diag[12], (unsigned long long)nhits);               // hits of literal rays
+#endif
             if (t.stats) atomicAdd(&t.stats[4 + 7], 1ull);
             const uint32_t slot = atomicAdd(p.literal_count, 1u);
             p.literal_list[slot] = make_uint2((uint32_t)ray, nhits);   // index within this walk launch (= log row)
