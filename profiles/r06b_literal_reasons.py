@@ -14,9 +14,11 @@ tn = importlib.import_module("tetra-nerf_amd")
 scenes = importlib.import_module("tetra-nerf_amd.scenes")
 lib = importlib.import_module("tetra-nerf_amd._lib").load()
 dev = torch.device("cuda:0")
-NAMES = ["literal rays", "short asc after an inverted pair", "two short gaps at the entry face", "short inverted after a short gap",
-         "short inverted as the first pair", "short inverted, face before within eps", "inverted by eps or more",
-         "long asc after an inverted pair, not clear", "inverted pair at the very end", "rays with exactly one violation",
+# (first run of the round, rules of round 5: gpurun_out/r06b_literal_reasons.txt had [2] = two short gaps at the entry face, [4] = short
+#  inverted as the first pair, [8] = inverted pair at the very end -- the three patterns rules A-C of round 6 certify)
+NAMES = ["literal rays", "short asc after an inverted pair", "short gap while an entry look-ahead is pending", "short inverted after a short gap",
+         "entry look-ahead unsettled at the end of the chain", "short inverted, face before within eps", "inverted by eps or more",
+         "long asc after an inverted pair, not clear", "inverted last pair of a 3-hit chain", "rays with exactly one violation",
          "violations in total", "rays with an inversion >= eps", "hits of literal rays"]
 for name, npts, seed in (("C2", 15000, 0), ("C4", 45000, 2), ("C5", 150000, 3)):
     pts, cells = scenes.random_mesh(npts, seed)

@@ -342,9 +342,12 @@ def test_speculative_fill_is_overwritten_by_every_ray_class(tn, device, oracle, 
     tr = _tracer(tn, device, pts, cells, walk=2)
     _trace(tr, device, np.ascontiguousarray(o[long_rays]), np.ascontiguousarray(d[long_rays]), M)
     st, why = tr.trace_stats(), tr.flag_reasons()
-    assert st["walk"] > 1000 and why.get(13, 0) > 50 and sum(v for k, v in why.items() if k in (1, 2, 3, 4, 5, 6, 9, 10, 11)) > 50, (st, why)
-    for k0 in (0, 64, 32):
+    # (round 6: rules A-C of the order test certify most of what used to be literal here -- 45 rays are left; the second pass runs
+    #  round 5's rules, under which 200+ of these rays go through the literal kernel)
+    assert st["walk"] > 1000 and why.get(13, 0) > 20 and sum(v for k, v in why.items() if k in (1, 2, 3, 4, 5, 6, 9, 10, 11)) > 50, (st, why)
+    for k0, ends in ((0, 1), (64, 1), (32, 1), (0, 0), (32, 0)):
         tr.set_option("spec_k0", k0)
+        tr.set_option("cert_ends", ends)
         out = _trace(tr, device, o, d, M)
         for k in KEYS:
             g = out[k].cpu().numpy()

@@ -185,6 +185,55 @@ def test_literal_pairing_of_the_log_equals_bvh_fallback(tn, device, oracle, scen
         assert _bits_equal(a[k][:30000], want[k]), k
 
 
+def test_pipelined_writer_matches_the_classic_writer(tn, device, scenes, bottle):
+    """Round 6's segment writer (k_write_segments_pipe: a three-stage software pipeline over the walk's list of non-empty
+    groups, unconditional memory instructions, unused store lanes into a sink line of the log, padding left to the tail fill)
+    against rounds 2-5's k_write_segments: identical dense rows -- every tail byte -- for both writer tables, with both sets of
+    order rules (cert_ends: the rays rules A-C certify come from the writer instead of the literal kernel -- two independent
+    implementations of the same rows), identical valid slots with compact rows, on meshes with
+    many literal / fallback rows in between (bottle, lattice, vertex twins), ray counts that are not multiples of 8 / 64 / 256,
+    and a poisoned output buffer (nothing relies on what the rows held before)."""
+    import torch
+
+    meshes = [("random", scenes.random_mesh(5000, 21)), ("bottle", (bottle["vertices"], bottle["cells"])),
+              ("lattice", scenes.grid_mesh(9, 0.0)), ("near-duplicates", scenes.near_duplicates_mesh(2000, 1e-7))]
+    for name, (pts, cells) in meshes:
+        lo, hi = pts.min(0), pts.max(0)
+        o, d = scenes.outside_in_rays(30011, 23)
+        t = o + d
+        o, t = lo + (hi - lo) * o, lo + (hi - lo) * t
+        d = t - o
+        o, d = o.astype(np.float32), (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        o[5000:5600] += 100.0                               # a stretch of rays that miss: all-miss groups inside the batch
+        to, td = torch.from_numpy(np.ascontiguousarray(o)).to(device), torch.from_numpy(np.ascontiguousarray(d)).to(device)
+        for table in (1, 2):
+            res = {}
+            for key, (pipe, ends) in (("classic", (0, 0)), ("pipe", (1, 0)), ("pipe+ends", (1, 1)), ("classic+ends", (0, 1))):
+                tr = tn.TetrahedraTracer(device)
+                tr.set_option("walk", 2)
+                tr.set_option("writer_table", table)
+                tr.set_option("writer_pipe", pipe)
+                tr.set_option("cert_ends", ends)
+                tr.load_tetrahedra(torch.from_numpy(pts).to(device), torch.from_numpy(cells).to(device))
+                junk = torch.full((64 << 20,), 0x7FC12345, dtype=torch.int32, device=device)   # poison what the allocator hands out next
+                del junk
+                res[key] = (tr.trace_rays(to, td, 256), tr.trace_rays(to, td, 256, compact_rows=True), tr.trace_stats())
+                assert res[key][2]["walk"] > 0.2 * len(o), (name, res[key][2])
+            want, want_c, _ = res["classic"]
+            n = want["num_visited_cells"]
+            valid = torch.arange(256, device=device)[None] < n[:, None]
+            assert res["pipe+ends"][2]["general"] <= res["pipe"][2]["general"], (name, res["pipe+ends"][2], res["pipe"][2])
+            for key in ("pipe", "pipe+ends", "classic+ends"):
+                got, got_c, _ = res[key]
+                for k in KEYS:
+                    assert torch.equal(got[k].view(torch.int32), want[k].view(torch.int32)), (name, table, key, k)
+                assert torch.equal(got_c["num_visited_cells"], n)
+                for k in KEYS[1:]:
+                    a, b = got_c[k], want_c[k]
+                    m = valid.reshape(valid.shape + (1,) * (a.dim() - 2)).expand_as(a)
+                    assert torch.equal(a[m].view(torch.int32), b[m].view(torch.int32)), (name, table, key, k, "compact")
+
+
 def test_writer_tables_agree(tn, device, scenes, bottle):
     """The segment writer reads one record per (tet, entry face) on meshes whose table the L2s hold and one per TET on
     larger ones (tn_common.h: WalkCold / WalkTet; option writer_table forces either): the same rows bit for bit -- also

@@ -641,8 +641,9 @@ __global__ __launch_bounds__(64) void k_verify_counts(TraceParams p, uint32_t st
     for (size_t it = blockIdx.x; it < n_checks; it += gridDim.x) {
         const size_t ray = ray_list ? (size_t)ray_list[it] : it * stride;
         if (ray_list && stride && ray % stride == 0) continue;   // the blind sample checks (and counts) this one
-        const uint32_t wn = walk_n[ray];
-        if (wn == TN_EMPTY) continue;          // literal / fallback ray: not certified, nothing to verify
+        const uint32_t wn_raw = walk_n[ray];
+        if (wn_raw == TN_EMPTY) continue;      // literal / fallback ray: not certified, nothing to verify
+        const uint32_t wn = wn_raw & 0x3FFFFFFFu;   // (bit 30: the walk's rule C flag for the segment writer)
         bool overflow = false;
         const uint32_t nh = collect_hits(p.bvh, s, p.M, p.M - 1, p.origins[3 * ray], p.origins[3 * ray + 1], p.origins[3 * ray + 2],
                                          p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2], nullptr, lane, overflow);

@@ -38,13 +38,25 @@
 //                 rays are not certified (the lattice meshes of tests/test_parity_configs_gpu.py hit this).
 //               * an isolated inverted pair: phase 1 only marks, phase 2 finds the partner of the face before
 //                 the pair in the second slot it examines and the swap restores chain order.
+//               * round 6, the ENDS of the chain (the hull is where slivers are: profiles/r06b_literal_reasons.txt -- 73-91 % of
+//                 the literal rays of the bench meshes had their first violation there).  Stated in tests/cert_model.py, checked
+//                 against the literal algorithm on crafted chains in tests/test_certification_rules.py:
+//                 A  an isolated inverted pair at the very END of a chain of >= 4 hits: the face before the pair finds its
+//                    partner in the second slot it examines and the swap restores chain order, nothing follows that could need
+//                    clearing.  (3 hits: the entry hull face would examine the exit hull face first -> EMPTY == EMPTY.)
+//                 B  a run of >= 2 short ascending gaps AT THE ENTRY face: phase 1 clears the run's interior; the entry face's
+//                    look-ahead examines the run's last face and the face after it -- neither shares a tet with it -- and stops
+//                    there iff the gap behind that face is long, which is required (two long ascending gaps after the run).
+//                 C  the FIRST pair inverted by less than eps: after the sort hit 1 pairs with hit 0 (short: no segment) and hit 0
+//                    then finds no partner, so the reference emits NO segment for hit 2 although it is long: the ray is
+//                    certified with a flag that makes the segment writer drop that one segment (hit 2 clear of both by eps,
+//                    then two more long ascending gaps: the same look-ahead bound).
 //               Runs that contain an inversion are NOT certified: a face whose two chain neighbours both sort
 //               after it survives phase 1 inside the run, and the look-ahead of the run's last face can then
 //               stop short of its partner (worked example in DESIGN.md section 2).
 //   literal     the chain is sound but its order is not clean (an inversion inside a run of short gaps, an
-//               inversion by eps or more, an inverted pair at the very end, two short gaps right at the entry
-//               face): the hits of the log go through the literal sort + pairing (k_postprocess_log,
-//               tn_trace_general.hip).
+//               inversion by eps or more, an end-of-chain pattern whose look-ahead bound is not met): the hits of
+//               the log go through the literal sort + pairing (k_postprocess_log, tn_trace_general.hip).
 //   fallback    anything else -> re-traced by the BVH all-hits kernel.
 // The chain is the connected component of the hull faces in the set of crossed faces.  Every tet has 0 or 2 crossed
 // faces for ANY rounded 2-D vertex positions (its boundary is a closed surface; edge functions are shared, so faces
@@ -75,6 +87,8 @@
 // VALU issue, the fill by HBM writes), slots [ceil32(n), 3M/4) of the certified rows after the segment writer.
 // blockIdx is remapped so each XCD owns runs of 16 consecutive blocks (4096 neighbouring rays) and its L2 keeps
 // the tets they cross.
+#include <type_traits>
+
 #include "tn_device.h"
 #include "tn_kernels.h"
 
@@ -109,7 +123,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool NT = false>
 __device__ __forceinline__ void fill_dwords(uint32_t *__restrict__ base, uint32_t start, uint32_t end, uint32_t value, int lane) {
-    const uint32_t a0 = (start + 3u) & ~3u;  // first 16-B aligned dword
+    // head: dword stores up to the next 128-BYTE LINE (not just the next 16 bytes): a wave's vector stores below then cover whole
+    // lines.  With a start that is only 16-byte aligned every 1 KB store instruction straddles nine lines, two of them partial
+    // (round 6: the tail fill behind the pipelined writer starts at the ray's segment count -- +12 % of the fill's time before this)
+    const uint32_t a0 = (start + 31u) & ~31u;
     const uint32_t head_end = a0 < end ? a0 : end;
     if (start + lane < head_end) base[start + lane] = value;
     if (a0 >= end) return;
@@ -294,6 +311,11 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     bool have_prev = false, have_pp = false;  // one / two valid hits have been recorded
     bool order_ok = true;     // the order of the hits so far is "clean" (header)
     bool prev_short = false, prev_inv = false;  // the previous pair was closer than eps / and inverted
+    // round 6 (rules A-C of the header; tests/cert_model.py states them, tests/test_certification_rules.py checks them against
+    // the literal algorithm): look-ahead state of the ENTRY face -- 0 none | 1 inside a run of short gaps at the entry | 2 one more
+    // long gap needed | 3 first pair inverted, hit 2 pending | 4 two more long gaps needed -- and "the segment of hit 2 is lost"
+    uint32_t pend = 0;
+    bool drop2 = false;
     float pt = 0.f, ppt = 0.f;  // t of the previous recorded hit and of the one before
     uint32_t nhits = 0, nshort = 0;
     uint32_t steps = 0;
@@ -363,19 +385,27 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             // this tet's entry face, and "id of exit x > id of the entry face" is bit 16 + x of the record's code_hi
             const bool asc = (ct > pt) || (ct == pt && ((cur.code_hi >> (16u + x)) & 1u) != 0);
             const bool clear2 = ct - ppt >= TN_EPS;
-            // short + ascending: any run of them is fine (header), except a run that starts at the entry hull face
-            // (pairs 1 and 2 both short: nhits == 2 here); short + inverted: isolated and clear of the face before;
-            // after an inverted pair: a long gap, clear of both of its members
-            const bool ok = is_short ? (asc ? (!prev_inv && !(prev_short && nhits == 2))
-                                            : (!prev_short && have_pp && clear2))
-                                     : (asc && (!prev_inv || clear2));
+            // short + ascending: any run of them is fine (header) -- a run that starts at the entry face (pairs 1 and 2 both
+            // short: nhits == 2 here) only if two long gaps follow it (rule B); short + inverted: isolated and clear of the face
+            // before -- as the FIRST pair: the segment of hit 2 is lost, three clear long gaps must follow (rule C); after an
+            // inverted pair: a long gap, clear of both of its members
+            const bool pend_wait = pend >= 2u;
+            const bool first_inv = is_short && !asc && !have_pp;
+            const bool entry_run = is_short && asc && prev_short && nhits == 2u;
+            const bool ok = (is_short ? (!pend_wait && (asc ? !prev_inv : (!have_pp || (!prev_short && clear2))))
+                                      : (asc && (!prev_inv || clear2))) &&
+                            (p.cert_ends || !(entry_run || first_inv));            // (cert_ends = 0: round 5's rules)
+            const uint32_t pend_long = (0x2810u >> (3u * pend)) & 7u;               // on a long gap: 0 2 0 4 2
+            const uint32_t pend_next = is_short ? (entry_run ? 1u : (first_inv ? 3u : pend)) : pend_long;
+            pend = vp ? pend_next : pend;
+            drop2 = drop2 || (vp && first_inv);
             order_ok = order_ok && (!vp || ok);
 #if TN_WALK_DIAG
             if (vp && !ok) {
-                // 1 short asc after an inverted pair | 2 two short gaps at the entry face | 3 short inverted after a short gap
-                // 4 short inverted as the first pair | 5 short inverted, the face before within eps | 6 inverted by eps or more
-                // 7 long asc after an inverted pair, not clear of it
-                const uint32_t r = is_short ? (asc ? (prev_inv ? 1u : 2u) : (prev_short ? 3u : (!have_pp ? 4u : 5u))) : (asc ? 7u : 6u);
+                // 1 short asc after an inverted pair | 2 short gap while an entry look-ahead is pending | 3 short inverted after a
+                // short gap | 5 short inverted, the face before within eps | 6 inverted by eps or more | 7 long asc after an
+                // inverted pair, not clear of it
+                const uint32_t r = is_short ? (pend_wait ? 2u : (asc ? 1u : (prev_short ? 3u : 5u))) : (asc ? 7u : 6u);
                 lit_why = lit_why ? lit_why : r;
                 n_viol++;
                 n_inv_long += r == 6u ? 1u : 0u;
@@ -419,8 +449,33 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     }
 
     // ------------------------------------------------------------------ classes, hand-over lists, hit counts
-    order_ok = order_ok && !prev_inv;   // a pair inverted at the very end has no following face to clear it
-    const uint32_t nseg = nhits ? nhits - 1 - nshort : 0;   // every consecutive pair that is not short
+    // rule A: an isolated inverted pair at the very end of a chain of >= 4 hits needs no following face (with 3 hits the entry hull
+    // face would look ahead straight at the exit hull face); rules B / C: the entry face's look-ahead must have been settled
+    order_ok = order_ok && pend == 0u && !(prev_inv && (nhits < 4u || !p.cert_ends));
+    // every consecutive pair that is not short (rule C: minus the segment of hit 2, which the reference loses)
+    const uint32_t nseg = nhits ? nhits - 1 - nshort - (drop2 ? 1u : 0u) : 0;
+    const uint32_t wflag = drop2 ? 1u : 0u;
+    if (p.group_list) {
+        // Work list of the pipelined segment writer: one entry per group of 8 consecutive rays (= 8 lanes) in which a certified
+        // ray logged a hit.  All lanes of the wave are here (the walk loop has reconverged; padding lanes count 0).
+        const bool mine = active && !flag && order_ok;
+        const uint32_t wn = mine ? (nhits | (wflag << 15)) : 0u;             // hits <= M - 1 <= 4095; bit 15: rule C (drop hit 2's segment)
+        uint32_t gm = mine ? nhits : 0u;
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)gm, off); gm = o > gm ? o : gm; }
+        const uint32_t p01 = wn | ((uint32_t)__shfl_down((int)wn, 1) << 16);   // (rays a, a + 1) on even lanes
+        const uint32_t q1 = (uint32_t)__shfl_down((int)p01, 2), q2 = (uint32_t)__shfl_down((int)p01, 4), q3 = (uint32_t)__shfl_down((int)p01, 6);
+        const bool lead = (lane & 7) == 0 && gm > 0;
+        const unsigned long long lm = __ballot(lead);
+        uint32_t base = 0;
+        if (lane == 0 && lm) base = atomicAdd(p.group_count, (uint32_t)__popcll(lm));
+        base = (uint32_t)__shfl((int)base, 0);
+        if (lead) {
+            const uint32_t at = base + (uint32_t)__popcll(lm & lanemask_lt());
+            p.group_list[2 * (size_t)at] = make_uint4((uint32_t)(ray >> 3), gm, p01, q1);
+            p.group_list[2 * (size_t)at + 1] = make_uint4(q2, q3, 0u, 0u);
+        }
+    }
     if (active) {
         if (flag || (!order_ok && !p.literal_list)) {
             const uint32_t slot = atomicAdd(p.fallback_count, 1u);
@@ -430,7 +485,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         } else if (!order_ok) {
 #if TN_WALK_DIAG
             atomicAdd(&g_walk_diag[0], 1ull);
-            atomicAdd(&g_walk_diag[lit_why ? lit_why : 8u], 1ull);                 // 8: a pair inverted at the very end
+            atomicAdd(&g_walk_diag[lit_why ? lit_why : (pend ? 4u : 8u)], 1ull);   // 4: entry look-ahead unsettled at the end | 8: inverted last pair of a 3-hit chain
             atomicAdd(&g_walk_diag[9], n_viol == 1 ? 1ull : 0ull);                 // rays with exactly one violation
             atomicAdd(&g_walk_diag[10], (unsigned long long)n_viol);               // violations in total
             atomicAdd(&g_walk_diag[11], n_inv_long ? 1ull : 0ull);                 // rays with an inversion by eps or more
@@ -441,7 +496,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             p.literal_list[slot] = make_uint2((uint32_t)ray, nhits);   // index within this walk launch (= log row)
             p.walk_n[ray] = TN_EMPTY;   // k_postprocess_log writes the whole row
         } else {
-            p.walk_n[ray] = nhits;      // hits in the log (0 for a miss)
+            p.walk_n[ray] = nhits | (wflag << 30);   // hits in the log (0 for a miss); bit 30: rule C (drop hit 2's segment)
             t.out_num[ray] = nseg;
             if (risk && p.risk_list) {  // certified, but inside the wide band of a guard: cross-checked, every one of them
                 p.risk_list[atomicAdd(p.risk_count, 1u)] = (uint32_t)ray;
@@ -538,10 +593,11 @@ __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
     uint32_t nh_raw = hits_of(g);
     uint32_t nh_next_raw = hits_of(g_next);                // in flight during the whole first group
     uint4 e[U];
-    load_entries(e, log_of(g), nh_raw == TN_EMPTY ? 0u : nh_raw, 0);
+    load_entries(e, log_of(g), nh_raw == TN_EMPTY ? 0u : (nh_raw & 0x3FFFFFFFu), 0);
     for (; g < G; g = g_next, g_next = g_next2) {
         const bool skip = nh_raw == TN_EMPTY;   // literal / fallback ray (or padding): the row belongs to another kernel
-        const uint32_t nh = skip ? 0u : nh_raw;
+        const uint32_t nh = skip ? 0u : (nh_raw & 0x3FFFFFFFu);
+        const bool drop2 = !skip && (nh_raw >> 30) != 0u;   // rule C of the walk's order test: the reference loses hit 2's segment
         uint32_t mx = nh;                       // max over the 8 rays (the value is replicated over h)
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {
@@ -559,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
         const uint32_t row = a * M;
         // the group after the next: its hit counts are requested now, needed one group later
         g_next2 = g_next + nwaves;
-        const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : nh_next_raw;
+        const uint32_t nh_next = nh_next_raw == TN_EMPTY ? 0u : (nh_next_raw & 0x3FFFFFFFu);
         const uint32_t nh_next2_raw = hits_of(g_next2);
         uint32_t nseg = 0;
         uint4 carry = make_uint4(0u, 0u, 0u, 0u);   // hit c0 - 1 of ray a
@@ -583,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
                 if (h == 0) pe[u] = carry;
                 carry.x = (uint32_t)__shfl((int)e[u].x, (int)a + 56); carry.y = (uint32_t)__shfl((int)e[u].y, (int)a + 56);
                 carry.z = (uint32_t)__shfl((int)e[u].z, (int)a + 56);
-                const bool emit = k >= 1 && k < nh && !(fabsf(__uint_as_float(pe[u].x) - __uint_as_float(e[u].x)) < TN_EPS);
+                const bool emit = k >= 1 && k < nh && !(fabsf(__uint_as_float(pe[u].x) - __uint_as_float(e[u].x)) < TN_EPS) && !(drop2 && k == 2u);
                 const unsigned long long mall = __ballot(emit);
                 const unsigned long long m = mall & raymask;
                 any |= mall;
@@ -639,33 +695,49 @@ __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
                 }
                 if (h == 0) *reinterpret_cast<uint2 *>(L + W::META + 2 * a) = make_uint2(nseg - base, base);
                 wave_lds_fence();
-                // ---- LDS -> rows: lane = (ray a2, unit d of that ray's run of this iteration)
+                // ---- LDS -> rows: lane = (ray a2, unit d of that ray's run of this iteration).  ALL units are read back into
+                //      registers first, then ALL stores are issued back to back (round 6): with a store group per read group the
+                //      compiler put an s_waitcnt vmcnt(0) in front of every group's ds_read -- ~20 serialised store round trips
+                //      per iteration
                 constexpr uint32_t RPI = 64 / W::SLOTS;       // rays per instruction for the one-unit-per-slot arrays
+                constexpr uint32_t NQ = 8 / RPI;
+                uint32_t s_sl[NQ], s_cell[NQ];
+                float2 s_dist[NQ];
+                uint4 s_vert[NQ];
 #pragma unroll
-                for (uint32_t qd = 0; qd < 8 / RPI; ++qd) {   // cell ids (4 B), distances (8 B), vertex ids (16 B) per slot
+                for (uint32_t qd = 0; qd < NQ; ++qd) {        // cell ids (4 B), distances (8 B), vertex ids (16 B) per slot
                     const uint32_t a2 = RPI * qd + (uint32_t)lane / W::SLOTS, d = (uint32_t)lane % W::SLOTS;
                     const uint2 meta = *reinterpret_cast<const uint2 *>(L + W::META + 2 * a2);
-                    if (d < meta.x) {
-                        const uint32_t at = a2 * W::STRIDE + d;
-                        const uint32_t sl = a2 * M + meta.y + d;
-                        g_cells[sl] = L[W::CELLS + at];
-                        *reinterpret_cast<float2 *>(g_dist + 2u * sl) = *reinterpret_cast<const float2 *>(L + W::DIST + 2 * at);
-                        if (g_verts) *reinterpret_cast<uint4 *>(g_verts + 4u * sl) = *reinterpret_cast<const uint4 *>(L + W::VERTS + 4 * at);
-                    }
+                    const uint32_t at = a2 * W::STRIDE + d;
+                    s_sl[qd] = d < meta.x ? a2 * M + meta.y + d : TN_EMPTY;
+                    s_cell[qd] = L[W::CELLS + at];
+                    s_dist[qd] = *reinterpret_cast<const float2 *>(L + W::DIST + 2 * at);
+                    s_vert[qd] = *reinterpret_cast<const uint4 *>(L + W::VERTS + 4 * at);
                 }
                 constexpr uint32_t UB = 3 * W::SLOTS;         // barycentrics: 3 x 8 B per slot
+                constexpr uint32_t NB = 8 * UB / 64;
+                uint32_t b_off[NB];
+                float2 b_val[NB];
 #pragma unroll
-                for (uint32_t qd = 0; qd < 8 * UB / 64; ++qd) {
+                for (uint32_t qd = 0; qd < NB; ++qd) {
                     const uint32_t gi = 64u * qd + (uint32_t)lane;
                     const uint32_t a2 = gi / UB, d = gi - UB * a2;
                     const uint2 meta = *reinterpret_cast<const uint2 *>(L + W::META + 2 * a2);
-                    if (d < 3u * meta.x) {
-                        const uint32_t sl = a2 * M + meta.y;
-                        *reinterpret_cast<float2 *>(g_bary + (6u * sl + 2u * d)) =
-                            *reinterpret_cast<const float2 *>(L + W::BARY + 6 * (a2 * W::STRIDE) + 2 * d);
+                    b_off[qd] = d < 3u * meta.x ? 6u * (a2 * M + meta.y) + 2u * d : TN_EMPTY;
+                    b_val[qd] = *reinterpret_cast<const float2 *>(L + W::BARY + 6 * (a2 * W::STRIDE) + 2 * d);
+                }
+                wave_lds_fence();                             // the staging region is free for the next iteration
+#pragma unroll
+                for (uint32_t qd = 0; qd < NQ; ++qd) {
+                    if (s_sl[qd] != TN_EMPTY) {
+                        g_cells[s_sl[qd]] = s_cell[qd];
+                        *reinterpret_cast<float2 *>(g_dist + 2u * s_sl[qd]) = s_dist[qd];
+                        if (g_verts) *reinterpret_cast<uint4 *>(g_verts + 4u * s_sl[qd]) = s_vert[qd];
                     }
                 }
-                wave_lds_fence();
+#pragma unroll
+                for (uint32_t qd = 0; qd < NB; ++qd)
+                    if (b_off[qd] != TN_EMPTY) *reinterpret_cast<float2 *>(g_bary + b_off[qd]) = b_val[qd];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) e[u] = en[u];
@@ -689,12 +761,259 @@ __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
     }
 }
 
+// ---- round 6: the segment writer as a SOFTWARE PIPELINE with straight-line memory instructions ----------------------------
+// What bounded k_write_segments above was not bandwidth but the compiler's s_waitcnt placement (read off the ISA): every
+// predicated load / store sits behind an s_cbranch_execz, the wait-count pass cannot count instructions a branch may skip, so
+// it falls back to s_waitcnt vmcnt(0) -- a full drain of the wave's memory queue, stores included -- in front of the LDS
+// read-back of every store group (~20 per iteration), at the top of every iteration and before the record gathers.  gfx950
+// retires a wave's loads and stores in issue order, so each drain costs a store round trip under the writer's own write
+// traffic.  Here EVERY vector memory instruction of the loop is unconditional:
+//   * loads take a clamped (always valid) address and the value is discarded by a select;
+//   * stores of lanes without a unit go to a SINK: log slot M - 1 of the group's 8 rays, one 128-byte line that no reader
+//     ever looks at (a ray logs at most M - 1 hits);
+//   * all-miss groups never arrive: the walk compacts the non-empty groups into a list whose 32-byte entries also carry the
+//     8 rays' hit counts (a group change = one sequential load, no dependent walk_n read);
+//   * the padding up to the next line boundary is left to the tail fill (exact_start), so the loop has no second store path.
+// With a static instruction count per iteration (4 entry loads + 2 descriptor loads + 8 record loads + 24 stores) the pass
+// emits COUNTED waits, and the loop is a three-stage pipeline over "items" (group, chunk of 8U hits per ray):
+//   E  request the log entries of item i + 2          B  pair / number the segments of item i + 1, request their records
+//   C  stage item i's 52-byte records in LDS, read them back by (ray, run), store
+// so a record gather has a whole iteration to arrive and no wait ever covers the stores of the current iteration.  Same
+// arithmetic, same LDS layout, same row bytes as k_write_segments (tests/test_walk_gpu.py: bit-identical rows).
+template <int U, bool PER_TET>
+__global__ __launch_bounds__(256, 2) void k_write_segments_pipe(WriteParams q) {
+    using W = SW<U>;
+    __shared__ __attribute__((aligned(16))) uint32_t smem[4 * W::TOTAL];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *L = smem + wave * W::TOTAL;
+    const uint32_t a = (uint32_t)lane & 7u, h = (uint32_t)lane >> 3;
+    const uint32_t M = q.M;
+    const uint32_t nwaves = gridDim.x * 4u;
+    const uint32_t n_groups = *q.group_count;
+    const unsigned long long raymask = 0x0101010101010101ull << a;
+    constexpr uint32_t CH = 8 * U;                              // hits per ray per item
+
+    struct Item { uint32_t g, c0, nh; bool live; };             // g, c0, live: wave-uniform; nh: hits of ray 8 g + a | rule C flag << 15
+    auto log_of = [&](uint32_t g) -> const uint4 * {            // entry k of ray 8 g + a at [k * 64 + a]
+        const size_t r0 = 8 * (size_t)g;
+        return q.hit_log + (r0 >> 6) * (size_t)M * 64 + (r0 & 63);
+    };
+    // (every load fetches exactly the dwords that are used: the compiler recycles the dead lanes of a wider in-flight load as
+    //  temporaries and then has to wait for that load -- an s_waitcnt vmcnt(1) right behind the request)
+    auto load_desc = [&](uint32_t li, uint4 &d0, uint2 &d1) {    // unconditional: clamped index (entry 0 exists even for an empty list)
+        const uint32_t i = li < n_groups ? li : (n_groups ? n_groups - 1u : 0u);
+        d0 = q.group_list[2 * (size_t)i];
+        d1 = *reinterpret_cast<const uint2 *>(q.group_list + 2 * (size_t)i + 1);
+    };
+    auto nh_of = [&](const uint4 &d0, const uint2 &d1) -> uint32_t {
+        const uint32_t w = sel4u(d0.z, d0.w, d1.x, d1.y, a >> 1);
+        return (a & 1u) ? (w >> 16) : (w & 0xFFFFu);
+    };
+
+    // ---- cursor of stage E over (list entry, chunk); the next entry's descriptor is resident, the one after is requested
+    //      anew in every iteration (an unconditional load: redundant until the cursor moves on, then it has had an iteration)
+    uint32_t li = (uint32_t)blockIdx.x * 4u + (uint32_t)wave;
+    uint4 c_d0, n_d0, f_d0;
+    uint2 c_d1, n_d1, f_d1;
+    load_desc(li, c_d0, c_d1);
+    load_desc(li + nwaves, n_d0, n_d1);
+    load_desc(li + 2u * nwaves, f_d0, f_d1);
+    uint32_t c0 = 0;
+
+    // pipeline registers
+    Item it1{0u, 0u, 0u, false};                                // E -> B
+    uint4 e1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) e1[u] = make_uint4(0u, 0u, 0u, 0u);
+    Item it0{0u, 0u, 0u, false};                                // B -> C
+    using QA = typename std::conditional<PER_TET, uint4, uint2>::type;   // per tet: orig, perm, cmb_lo, cmb_hi; per (tet, entry): orig, cmb
+    uint4 e0[U], qv0[U];
+    float pe0[U][3];
+    QA qa0[U];
+    uint32_t slot0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        e0[u] = qv0[u] = make_uint4(0u, 0u, 0u, 0u); qa0[u] = QA{}; slot0[u] = TN_EMPTY;
+        pe0[u][0] = pe0[u][1] = pe0[u][2] = 0.f;
+    }
+    uint32_t base0 = 0, cnt0 = 0;                               // first slot / segments of item 0 (of ray a)
+    // stage B's running state of the current group
+    uint32_t nsegB = 0;
+    uint4 carryB = make_uint4(0u, 0u, 0u, 0u);
+
+    bool curs_live = li < n_groups;
+    while (curs_live || it1.live || it0.live) {                 // wave-uniform
+        // ================= stage E: request the entries of the cursor's item, move the cursor
+        Item it2;
+        it2.g = __builtin_amdgcn_readfirstlane((int)c_d0.x);
+        it2.c0 = c0;
+        it2.live = curs_live;
+        it2.nh = curs_live ? nh_of(c_d0, c_d1) : 0u;
+        if (!curs_live) it2.g = 0u;
+        uint4 e2[U];
+        {
+            const uint4 *lg = log_of(it2.g);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t k = it2.c0 + 8u * (uint32_t)u + h;
+                e2[u] = lg[(k < (it2.nh & 0x7FFFu) ? k : 0u) * 64u + a];    // (slot 0 of a valid log column when there is no such hit)
+            }
+        }
+        {
+            const uint32_t mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_d0.y);
+            c0 += CH;
+            if (!(curs_live && c0 < mx)) {                      // next list entry (wave-uniform; no memory instruction inside)
+                c0 = 0;
+                li += nwaves;
+                curs_live = li < n_groups;
+                c_d0 = n_d0; c_d1 = n_d1; n_d0 = f_d0; n_d1 = f_d1;
+            }
+            load_desc(li + 2u * nwaves, f_d0, f_d1);
+        }
+
+        // ================= stage B: item 1 -- previous hit of every lane, emission, slots, record requests
+        uint4 qv1[U];
+        float pe1[U][3];
+        QA qa1[U];
+        uint32_t slot1[U];
+        uint32_t base1, cnt1;
+        {
+            if (it1.c0 == 0u) { nsegB = 0u; carryB = make_uint4(0u, 0u, 0u, 0u); }   // (selects: wave-uniform condition)
+            base1 = nsegB;
+            const uint32_t nh1 = it1.nh & 0x7FFFu;
+            const bool drop2 = (it1.nh >> 15) != 0u;                // rule C of the walk's order test: the reference loses hit 2's segment
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t k = it1.c0 + 8u * (uint32_t)u + h;
+                if (!(k < nh1)) e1[u] = make_uint4(0u, 0u, 0u, 0u);
+                pe1[u][0] = __uint_as_float((uint32_t)__shfl_up((int)e1[u].x, 8)); pe1[u][1] = __uint_as_float((uint32_t)__shfl_up((int)e1[u].y, 8));
+                pe1[u][2] = __uint_as_float((uint32_t)__shfl_up((int)e1[u].z, 8));
+                if (h == 0) { pe1[u][0] = __uint_as_float(carryB.x); pe1[u][1] = __uint_as_float(carryB.y); pe1[u][2] = __uint_as_float(carryB.z); }
+                carryB.x = (uint32_t)__shfl((int)e1[u].x, (int)a + 56); carryB.y = (uint32_t)__shfl((int)e1[u].y, (int)a + 56);
+                carryB.z = (uint32_t)__shfl((int)e1[u].z, (int)a + 56);
+                const bool emit = k >= 1 && k < nh1 && !(fabsf(pe1[u][0] - __uint_as_float(e1[u].x)) < TN_EPS) && !(drop2 && k == 2u);
+                const unsigned long long m = __ballot(emit) & raymask;
+                slot1[u] = emit ? (nsegB - base1) + (uint32_t)__popcll(m & lanemask_lt()) : TN_EMPTY;
+                nsegB += (uint32_t)__popcll(m);
+            }
+            cnt1 = nsegB - base1;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t c = slot1[u] != TN_EMPTY ? (e1[u].w & 0x3FFFFFFFu) : 0u;      // record 0 for lanes without a segment
+                const uint32_t *rec = PER_TET ? reinterpret_cast<const uint32_t *>(q.tets + (c >> 2))
+                                              : reinterpret_cast<const uint32_t *>(q.cold + c);
+                qv1[u] = *reinterpret_cast<const uint4 *>(rec);
+                qa1[u] = *reinterpret_cast<const QA *>(rec + 4);
+            }
+        }
+
+        // ================= stage C: item 0 -- segment records -> LDS [array][ray][slot] -> rows
+        {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (slot0[u] != TN_EMPTY) {                     // (LDS instructions only)
+                    const uint32_t at = a * W::STRIDE + slot0[u];
+                    const uint32_t x = e0[u].w >> 30, ent = e0[u].w & 3u;
+                    uint32_t cmb;
+                    uint4 vids = qv0[u];
+                    if constexpr (PER_TET) {
+                        const unsigned long long lo64 = (unsigned long long)qa0[u].z | ((unsigned long long)qa0[u].w << 32);
+                        const uint32_t c18 = ent == 3u ? ((uint32_t)(lo64 >> 54) | ((qa0[u].y >> 24) << 10)) : (uint32_t)(lo64 >> (18u * ent));
+                        cmb = c18 >> (6u * x);
+                        const uint32_t pm = qa0[u].y >> (6u * ent);
+                        vids = make_uint4(sel4u(qv0[u].x, qv0[u].y, qv0[u].z, qv0[u].w, ent), sel4u(qv0[u].x, qv0[u].y, qv0[u].z, qv0[u].w, pm & 3u),
+                                          sel4u(qv0[u].x, qv0[u].y, qv0[u].z, qv0[u].w, (pm >> 2) & 3u),
+                                          sel4u(qv0[u].x, qv0[u].y, qv0[u].z, qv0[u].w, (pm >> 4) & 3u));
+                    } else {
+                        cmb = qa0[u].y >> (6u * x);
+                    }
+                    const float pt = pe0[u][0], pu = pe0[u][1], pv = pe0[u][2];
+                    const float ct = __uint_as_float(e0[u].x), cu = __uint_as_float(e0[u].y), cv = __uint_as_float(e0[u].z);
+                    const float r0f = 1.0f - cu - cv;
+                    const uint32_t k0 = cmb & 3u, k1 = (cmb >> 2) & 3u, k2 = (cmb >> 4) & 3u;
+                    L[W::CELLS + at] = qa0[u].x;
+                    *reinterpret_cast<float2 *>(L + W::DIST + 2 * at) = make_float2(pt, ct);
+                    float2 *bp = reinterpret_cast<float2 *>(L + W::BARY + 6 * at);
+                    bp[0] = make_float2(1.0f - pu - pv, pu);
+                    bp[1] = make_float2(pv, sel4f(r0f, cu, cv, 0.f, k0));
+                    bp[2] = make_float2(sel4f(r0f, cu, cv, 0.f, k1), sel4f(r0f, cu, cv, 0.f, k2));
+                    *reinterpret_cast<uint4 *>(L + W::VERTS + 4 * at) = vids;
+                }
+            }
+            if (h == 0) *reinterpret_cast<uint2 *>(L + W::META + 2 * a) = make_uint2(cnt0, base0);
+            wave_lds_fence();
+            // rows of the group: scalar bases + 32-bit lane offsets; the sink: log slot M - 1 of the group's 8 rays (16 B per ray)
+            const size_t row0 = 8 * (size_t)it0.g * (size_t)M;
+            uint32_t *const g_cells = q.out_cells + row0;
+            float *const g_dist = q.out_dist + 2 * row0;
+            float *const g_bary = q.out_bary + 6 * row0;
+            uint32_t *const g_verts = q.out_verts ? q.out_verts + 4 * row0 : nullptr;
+            uint32_t *const sink = reinterpret_cast<uint32_t *>(const_cast<uint4 *>(log_of(it0.g)) + (size_t)(M - 1u) * 64u) + 4u * a;
+            constexpr uint32_t RPI = 64 / W::SLOTS;
+            constexpr uint32_t NQ = 8 / RPI;
+            uint32_t s_sl[NQ], s_cell[NQ];
+            float2 s_dist[NQ];
+            uint4 s_vert[NQ];
+#pragma unroll
+            for (uint32_t qd = 0; qd < NQ; ++qd) {
+                const uint32_t a2 = RPI * qd + (uint32_t)lane / W::SLOTS, d = (uint32_t)lane % W::SLOTS;
+                const uint2 meta = *reinterpret_cast<const uint2 *>(L + W::META + 2 * a2);
+                const uint32_t at = a2 * W::STRIDE + d;
+                s_sl[qd] = d < meta.x ? a2 * M + meta.y + d : TN_EMPTY;
+                s_cell[qd] = L[W::CELLS + at];
+                s_dist[qd] = *reinterpret_cast<const float2 *>(L + W::DIST + 2 * at);
+                s_vert[qd] = *reinterpret_cast<const uint4 *>(L + W::VERTS + 4 * at);
+            }
+            constexpr uint32_t UB = 3 * W::SLOTS;
+            constexpr uint32_t NB = 8 * UB / 64;
+            uint32_t b_off[NB];
+            float2 b_val[NB];
+#pragma unroll
+            for (uint32_t qd = 0; qd < NB; ++qd) {
+                const uint32_t gi = 64u * qd + (uint32_t)lane;
+                const uint32_t a2 = gi / UB, d = gi - UB * a2;
+                const uint2 meta = *reinterpret_cast<const uint2 *>(L + W::META + 2 * a2);
+                b_off[qd] = d < 3u * meta.x ? 6u * (a2 * M + meta.y) + 2u * d : TN_EMPTY;
+                b_val[qd] = *reinterpret_cast<const float2 *>(L + W::BARY + 6 * (a2 * W::STRIDE) + 2 * d);
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (uint32_t qd = 0; qd < NQ; ++qd) {
+                const bool on = s_sl[qd] != TN_EMPTY;
+                *(on ? g_cells + s_sl[qd] : sink) = s_cell[qd];
+                *reinterpret_cast<float2 *>(on ? g_dist + 2u * s_sl[qd] : reinterpret_cast<float *>(sink)) = s_dist[qd];
+                *reinterpret_cast<uint4 *>((on && g_verts) ? g_verts + 4u * s_sl[qd] : sink) = s_vert[qd];
+            }
+#pragma unroll
+            for (uint32_t qd = 0; qd < NB; ++qd) {
+                const bool on = b_off[qd] != TN_EMPTY;
+                *reinterpret_cast<float2 *>(on ? g_bary + b_off[qd] : reinterpret_cast<float *>(sink)) = b_val[qd];
+            }
+        }
+
+        // ================= rotate
+        it0 = it1; base0 = base1; cnt0 = cnt1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            e0[u] = e1[u]; pe0[u][0] = pe1[u][0]; pe0[u][1] = pe1[u][1]; pe0[u][2] = pe1[u][2];
+            qa0[u] = qa1[u]; qv0[u] = qv1[u]; slot0[u] = slot1[u]; e1[u] = e2[u];
+        }
+        it1 = it2;
+    }
+}
+
 void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned max_blocks) {
     if (q.num_rays == 0) return;
     size_t blocks = (q.num_rays + 31) / 32;        // one group of 8 rays per wave
     // grid = what is resident at once (2 blocks per CU at 192 VGPRs): the groups are dealt round-robin over it
     const size_t cap = max_blocks ? max_blocks : (size_t)256 * 2;
     if (blocks > cap) blocks = cap;
+    if (q.group_list) {
+        if (q.tets) hipLaunchKernelGGL((k_write_segments_pipe<4, true>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL((k_write_segments_pipe<4, false>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
+        return;
+    }
     if (q.tets) hipLaunchKernelGGL((k_write_segments<4, true>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
     else hipLaunchKernelGGL((k_write_segments<4, false>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
 }
@@ -706,7 +1025,7 @@ void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned ma
 //                 included: the kernels that write those slots are ordered behind this one.
 //   all_rows = 0: slots [ceil32(n), k_split) of the certified rows (k_write_segments has written [0, ceil32(n))).
 template <bool NT>
-__global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M, uint32_t all_rows, uint32_t k_split,
+__global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M, uint32_t all_rows, uint32_t k_split, uint32_t exact_start,
                                                     const uint32_t *__restrict__ walk_n, const uint32_t *__restrict__ out_num,
                                                     uint32_t *__restrict__ out_cells,
                                                     float *__restrict__ out_bary, float *__restrict__ out_dist,
@@ -721,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M,
         uint32_t lo = k_split, hi = M;
         if (!all_rows) {
             if (walk_n[r] == TN_EMPTY) continue;  // literal / fallback ray: those kernels write the whole row
-            lo = (out_num[r] + 31u) & ~31u;
+            lo = exact_start ? out_num[r] : (out_num[r] + 31u) & ~31u;   // exact: the pipelined writer leaves the padding to this kernel
             if (lo > M) lo = M;
             hi = k_split;
         }
@@ -735,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M,
 
 void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *walk_n, const uint32_t *out_num,
                        uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
-                       uint32_t k_split, bool nontemporal, unsigned max_blocks) {
+                       uint32_t k_split, bool nontemporal, unsigned max_blocks, bool exact_start) {
     if (num_rays == 0) return;
     size_t blocks = (num_rays + 3) / 4;           // >= one ray per wave
     // after the writer: 2 blocks (8 waves) per CU hold the write ceiling, and the latency-bound kernels running beside
@@ -744,10 +1063,10 @@ void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_
     const size_t cap = max_blocks ? max_blocks : (all_rows ? 2048 : 256 * 2);
     if (blocks > cap) blocks = cap;
     if (nontemporal)
-        hipLaunchKernelGGL(k_fill_range<true>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split,
+        hipLaunchKernelGGL(k_fill_range<true>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split, exact_start ? 1u : 0u,
                            walk_n, out_num, out_cells, out_bary, out_dist, out_verts);
     else
-        hipLaunchKernelGGL(k_fill_range<false>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split,
+        hipLaunchKernelGGL(k_fill_range<false>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split, exact_start ? 1u : 0u,
                            walk_n, out_num, out_cells, out_bary, out_dist, out_verts);
 }
 
