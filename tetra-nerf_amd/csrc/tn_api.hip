@@ -74,21 +74,18 @@ struct tn_tracer {
     tn::DevWideBvh bvh;
     static constexpr int N_STATS = 32;      // 64-bit counters of the last call: [0..4) path statistics, [4..20) walk hand-over reasons,
                                             // [20..24) diagnostics, [24..28) risk classes of the certification (tn_trace_cross_check)
-    static constexpr int N_CTR = 3;         // 64-bit words behind the statistics: six uint32 device-side counters
+    static constexpr int N_CTR = 2;         // 64-bit words behind the statistics: four uint32 device-side counters
     tn::DevBuf<unsigned long long> stats;   // [N_STATS] counters + [N_STATS .. N_STATS + N_CTR) uint32: fallback count,
                                             // literal count, kmax (one memset clears them all)
     uint32_t *fallback_count() { return reinterpret_cast<uint32_t *>(stats.p + N_STATS); }
     uint32_t *literal_count() { return reinterpret_cast<uint32_t *>(stats.p + N_STATS) + 1; }
     uint32_t *verify_count() { return reinterpret_cast<uint32_t *>(stats.p + N_STATS) + 2; }
     uint32_t *risk_count() { return reinterpret_cast<uint32_t *>(stats.p + N_STATS) + 3; }
-    uint32_t *group_count() { return reinterpret_cast<uint32_t *>(stats.p + N_STATS) + 4; }
-    tn::DevBuf<uint4> group_list;        // the pipelined segment writer's work list (the walk appends one 32-byte entry per non-empty group of 8 rays)
-    // Round 6: the segment writer as a software pipeline with straight-line memory instructions (tn_trace_walk.hip:
-    // k_write_segments_pipe).  1 = on (default), 0 = round 2-5's k_write_segments (kept: the two must write identical rows,
-    // tests/test_walk_gpu.py).  Measured and dropped with it: the tail fill of the certified rows (it needs the walk's counts
-    // only) on a stream of its own BESIDE the pipelined writer: +17 % / +3.4 % / -0.5..+6 % on the C2 / C4 frames / C5 rays
-    // (profiles/r06e_sweep.txt: the two kernels together take longer than one after the other)
-    int writer_pipe = 1;
+    // Round 6, measured and dropped (profiles/r06d_lib_ab.txt, r06e_sweep.txt, r06f_sweep.txt; the code is in the history:
+    // commit "wip: pipelined segment writer"): the segment writer as a three-stage software pipeline with unconditional memory
+    // instructions over a walk-built list of non-empty groups.  Alone it equals the grouped-store writer below (0.62 ms on the C2
+    // frame), in the schedule it costs +3..6 %: it leaves the padding [n, ceil32(n)) to the tail fill, and a line written in part
+    // by two kernels costs the fill 12-18 % (partial-line writes).  The tail fill BESIDE that writer: +17 % / +3 % / +0..6 %.
     int cert_ends = 1;                   // rules A-C of the walk's order test (tn_trace_walk.hip header); 0: round 5's rules
 
     tn::DevBuf<uint32_t> risk_list;      // certified rays inside the wide band of a certification guard (all cross-checked)
@@ -428,8 +425,6 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
             // (or a literal / fallback row) simply overwrites its slots.  The log holds 16 B per hit slot; calls whose log
             // would exceed the cap are processed in ray chunks (multiples of 4096 rays, the walk's XCD run), serially.
             if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); }
-            const bool pipe = t->writer_pipe != 0;
-            if (pipe && t->group_list.n < 2 * ((R + 7) / 8) + 2) t->group_list.alloc(2 * ((R + 7) / 8) + 2);
             const bool verify_risk = t->verify_risk && t->verify_stride;
             if (t->verify_stride) {
                 // sized with the other scratch buffers, BEFORE the first launch of the call: an allocation in the middle of
@@ -480,8 +475,6 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 w.risk_count = t->risk_count();
                 w.risk_band = (float)t->risk_band;
                 w.cert_ends = t->cert_ends ? 1u : 0u;
-                w.group_list = pipe ? t->group_list.p : nullptr;
-                w.group_count = t->group_count();
                 tn::launch_trace_walk(w, stream, walk_reserve);
                 if (t->verify_stride && !single) {  // chunked call: serially, before anything that reads walk_n / the fallback list
                     tn::launch_verify_counts(w.t, t->verify_stride, w.walk_n, w.fallback_list, w.fallback_count, base, stream, false,
@@ -501,15 +494,12 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 q.out_bary = bary + base * M * 6;
                 q.out_dist = dist + base * M * 2;
                 q.out_verts = verts ? verts + base * M * 4 : nullptr;
-                q.group_list = pipe ? t->group_list.p : nullptr;
-                q.group_count = t->group_count();
                 tn::launch_write_segments(q, stream);
             };
-            // [ceil32(n_r), k_hi) of the certified rows; behind the pipelined writer: [n_r, k_hi) (it writes segments only)
-            auto launch_fill = [&](size_t base, size_t n, uint32_t k_hi, hipStream_t st) {
+            auto launch_fill = [&](size_t base, size_t n, uint32_t k_hi, hipStream_t st) {   // [ceil32(n_r), k_hi) of the certified rows
                 if (!dense_tails) return;
                 tn::launch_fill_range(n, M, false, t->walk_n.p + base, num_visited + base, visited + base * M, bary + base * M * 6,
-                                      dist + base * M * 2, verts ? verts + base * M * 4 : nullptr, st, k_hi, false, 0, pipe);
+                                      dist + base * M * 2, verts ? verts + base * M * 4 : nullptr, st, k_hi, false);
             };
             auto launch_literal = [&](size_t base, size_t n, hipStream_t st) {
                 if (!t->literal) return;
@@ -606,7 +596,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 for (size_t base = 0; base < R; base += chunk) {
                     const size_t n = R - base < chunk ? R - base : chunk;
                     TN_HIP(hipMemsetAsync(t->literal_count(), 0, sizeof(uint32_t), stream));
-                    TN_HIP(hipMemsetAsync(t->risk_count(), 0, 2 * sizeof(uint32_t), stream));   // + the group count behind it
+                    TN_HIP(hipMemsetAsync(t->risk_count(), 0, sizeof(uint32_t), stream));
                     launch_walk(base, n);
                     launch_segments(base, n);
                     launch_fill(base, n, M, stream);
@@ -838,7 +828,6 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
             t->lds_cap = (unsigned)value;
         }
         else if (k == "writer_table") t->writer_table = value;   // applies at the next load_tetrahedra
-        else if (k == "writer_pipe") t->writer_pipe = value;
         else if (k == "cert_ends") t->cert_ends = value;
         else if (k == "verify_inject") t->verify_inject = value != 0;
         else if (k == "literal_sort_passes") t->literal_sort_passes = value < 0 ? 0u : (unsigned)value;

@@ -197,89 +197,13 @@ __global__ __launch_bounds__(256) void k_interp_fwd64(uint32_t n, const uint32_t
     }
 }
 
-// Round 6: the same tile (lane (q, s) = features {4q..4q+3, 32+4q..32+4q+3} of the 8 consecutive samples base + 8 s + it) as
-// STRAIGHT-LINE code.  k_interp_fwd64 above takes a vertex row from the previous sample's registers when the vertex repeats
-// and loads it otherwise: 16 compare-and-move blocks and 4 "register or load" selects per sample, which hipcc turns into 558
-// branches with 41 s_waitcnt vmcnt(0) in the 64-sample tile (read off the ISA; the guide's de-pipelining trap (c)): every
-// sample's rows are a dependent L2 round trip of their own, 8 in a row per lane.  Here EVERY load is unconditional -- sample
-// indices clamped, EMPTY ids read row 0 and are discarded by selects -- and independent of loaded data, so all of a lane's
-// requests (8 x ids + weights, then 8 x 4 rows x 2 quads) can be in flight together; the rows that repeat from sample to sample
-// hit the CU's L1 instead of registers.  Same summation order as the reference -> bit-identical to the oracle and to the
-// kernel above (tests/test_gather_gpu.py).
-template <int D>
-__global__ __launch_bounds__(256, 2) void k_interp_fwd64s(uint32_t n, const uint32_t *__restrict__ vi,
-                                                          const float *__restrict__ bc, const float *__restrict__ fieldT,
-                                                          float *__restrict__ result) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t q = (uint32_t)lane & 7u, sg = (uint32_t)lane >> 3;
-    const uint32_t ntiles = (n + 63) / 64;
-    const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    struct Rows { float4 x0[D], x1[D]; };
-    for (uint32_t tix = wave0; tix < ntiles; tix += nwaves) {
-        const uint32_t base = tix * 64 + 8 * sg;
-        uint32_t v[8][D];
-        float b[8][D - 1];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const uint32_t smp = base + it < n ? base + it : n - 1;     // clamped: the stores below are masked
-#pragma unroll
-            for (int k = 0; k < D; ++k) v[it][k] = vi[(size_t)smp * D + k];
-#pragma unroll
-            for (int k = 0; k < D - 1; ++k) b[it][k] = bc[(size_t)smp * (D - 1) + k];
-        }
-        auto load_rows = [&](int it) {
-            Rows r;
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const uint32_t vk = v[it][k] != TN_EMPTY ? v[it][k] : 0u;
-                const float4 *row = reinterpret_cast<const float4 *>(fieldT + (size_t)vk * 64);
-                r.x0[k] = row[q]; r.x1[k] = row[8 + q];
-            }
-            return r;
-        };
-        float acc[8][8];
-        Rows nxt = load_rows(0);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const Rows cur = nxt;
-            if (it < 7) nxt = load_rows(it + 1);            // the next sample's rows are requested before this one's arithmetic
-            __builtin_amdgcn_sched_barrier(0);
-            float w = 0.f;
-#pragma unroll
-            for (int k = 0; k < D - 1; ++k) w += b[it][k];
-            const float w0 = 1.0f - w;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
-            // reference order: the D-1 weighted vertices first, the implicit-weight vertex last; EMPTY ids contribute nothing
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const int kk = k < D - 1 ? k + 1 : 0;
-                const float wk = k < D - 1 ? b[it][k < D - 1 ? k : 0] : w0;
-                const bool on = v[it][kk] != TN_EMPTY;
-                const float t0 = a0 + wk * cur.x0[kk].x, t1 = a1 + wk * cur.x0[kk].y, t2 = a2 + wk * cur.x0[kk].z, t3 = a3 + wk * cur.x0[kk].w;
-                const float t4 = a4 + wk * cur.x1[kk].x, t5 = a5 + wk * cur.x1[kk].y, t6 = a6 + wk * cur.x1[kk].z, t7 = a7 + wk * cur.x1[kk].w;
-                a0 = on ? t0 : a0; a1 = on ? t1 : a1; a2 = on ? t2 : a2; a3 = on ? t3 : a3;
-                a4 = on ? t4 : a4; a5 = on ? t5 : a5; a6 = on ? t6 : a6; a7 = on ? t7 : a7;
-            }
-            acc[it][0] = a0; acc[it][1] = a1; acc[it][2] = a2; acc[it][3] = a3;
-            acc[it][4] = a4; acc[it][5] = a5; acc[it][6] = a6; acc[it][7] = a7;
-        }
-        const bool wide = (n & 3u) == 0 && base + 8 <= n;   // 16-byte aligned rows, all 8 samples valid
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t f = (j < 4 ? 4 * q + j : 32 + 4 * q + (j - 4));
-            float *dst = result + (size_t)f * n + base;
-            if (wide) {
-                reinterpret_cast<float4 *>(dst)[0] = make_float4(acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
-                reinterpret_cast<float4 *>(dst)[1] = make_float4(acc[4][j], acc[5][j], acc[6][j], acc[7][j]);
-            } else {
-#pragma unroll
-                for (int it = 0; it < 8; ++it)
-                    if (base + it < n) dst[it] = acc[it][j];
-            }
-        }
-    }
-}
+// Round 6, measured and dropped (profiles/r06g_ops_ab.txt; the kernel is in the history, commit "wip: ... straight-line gather
+// kernel draft"): the ISA of k_interp_fwd64 above has 558 branches and 41 s_waitcnt vmcnt(0) per 64-sample tile (the "register
+// or load" selects of the carry become branches around loads), so a STRAIGHT-LINE form was tried: every load unconditional (clamped
+// index, EMPTY ids read row 0 and are discarded by selects), no carry, all 64 row requests of a tile in flight (324 registers,
+// 7 drains).  In-process A/B, bit-identical: 250 -> 278 us (4096 x 513 samples), 1927 -> 2300 us (65,536 x 256): 11-19 % SLOWER.
+// The carry's saved L2 -> L1 row traffic (1 KB per sample without it) is worth more than the drains cost: round 3's reading of the
+// counters (this op sits on the L2 -> L1 return path) stands.
 
 // Backward: one wavefront = 64 consecutive samples, LANE = FEATURE.  The incoming gradient is read
 // sample-major ([n, Fd] rows: one coalesced 256-B load per sample at Fd = 64); vertex ids and weights
@@ -374,10 +298,7 @@ void run_fwd_vm(uint32_t n, uint32_t Fd, const uint32_t *vi, const float *bc, co
     if (Fd == 64) {
         const uint32_t nblocks = ((n + 63) / 64 + 3) / 4;  // 4 waves (256 samples) per block
         const unsigned grid = nblocks < 256u * 16u ? nblocks : 256u * 16u;
-        // TETRANERF_HIP_GATHER=carry: round 3-5's kernel with the register carry (A/B, tests/test_gather_gpu.py)
-        static const bool carry = [] { const char *e = std::getenv("TETRANERF_HIP_GATHER"); return e && std::strcmp(e, "carry") == 0; }();
-        if (carry) hipLaunchKernelGGL(k_interp_fwd64<D>, dim3(grid), dim3(256), 0, stream, n, vi, bc, fieldT, result);
-        else hipLaunchKernelGGL(k_interp_fwd64s<D>, dim3(grid), dim3(256), 0, stream, n, vi, bc, fieldT, result);
+        hipLaunchKernelGGL(k_interp_fwd64<D>, dim3(grid), dim3(256), 0, stream, n, vi, bc, fieldT, result);
         return;
     }
     const uint32_t nblocks = ((n + 31) / 32 + 3) / 4;  // 4 waves (128 samples) per block

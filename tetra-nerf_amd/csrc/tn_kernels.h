@@ -62,9 +62,6 @@ struct WalkParams {
     uint32_t *risk_count;      // [1]          them is cross-checked (k_verify_counts); null: not collected
     float risk_band;           // width of that band in units of the guards' own 8 delta (tn option "risk_band")
     uint32_t cert_ends;        // 1: rules A-C of the order test (round 6: end-of-chain patterns certified); 0: round 5's rules (A/B, tests)
-    uint4 *group_list;         // [2 x ceil(num_items / 8)] the pipelined segment writer's work list (round 6): one 32-byte entry per group
-    uint32_t *group_count;     // [1]   of 8 consecutive rays with at least one certified hit: {group, max hits, the 8 rays' hit counts
-                               //       as 16-bit halves} -- all-miss groups never reach the writer, a group change costs it ONE load
 };
 // lds_reserve: bytes of (unused) dynamic LDS per block = an occupancy limit (160 KB / lds_reserve blocks per CU), 0 = none
 void launch_trace_walk(const WalkParams &p, hipStream_t stream, size_t lds_reserve = 0);
@@ -97,15 +94,12 @@ struct WriteParams {
     float *out_bary;
     float *out_dist;
     uint32_t *out_verts;       // nullable
-    const uint4 *group_list;   // the walk's list of non-empty groups (WalkParams::group_list): non-null = the pipelined writer
-    const uint32_t *group_count;
 };
 void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned max_blocks = 0);
-// all_rows: slots [k_split, M) of every row; otherwise slots [ceil32(out_num[r]), k_split) of the certified rows -- from
-// out_num[r] itself with exact_start (the pipelined writer writes segments only, no padding up to the line boundary)
+// all_rows: slots [k_split, M) of every row; otherwise slots [ceil32(out_num[r]), k_split) of the certified rows
 void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *walk_n, const uint32_t *out_num,
                        uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
-                       uint32_t k_split, bool nontemporal, unsigned max_blocks = 0, bool exact_start = false);
+                       uint32_t k_split, bool nontemporal, unsigned max_blocks = 0);
 
 // sample -> segment matching (tn_match.hip)
 void launch_find_matched_cells(size_t R, size_t S, size_t M, const uint32_t *num_visited,

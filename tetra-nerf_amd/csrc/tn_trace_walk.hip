@@ -87,8 +87,6 @@
 // VALU issue, the fill by HBM writes), slots [ceil32(n), 3M/4) of the certified rows after the segment writer.
 // blockIdx is remapped so each XCD owns runs of 16 consecutive blocks (4096 neighbouring rays) and its L2 keeps
 // the tets they cross.
-#include <type_traits>
-
 #include "tn_device.h"
 #include "tn_kernels.h"
 
@@ -123,10 +121,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool NT = false>
 __device__ __forceinline__ void fill_dwords(uint32_t *__restrict__ base, uint32_t start, uint32_t end, uint32_t value, int lane) {
-    // head: dword stores up to the next 128-BYTE LINE (not just the next 16 bytes): a wave's vector stores below then cover whole
-    // lines.  With a start that is only 16-byte aligned every 1 KB store instruction straddles nine lines, two of them partial
-    // (round 6: the tail fill behind the pipelined writer starts at the ray's segment count -- +12 % of the fill's time before this)
-    const uint32_t a0 = (start + 31u) & ~31u;
+    const uint32_t a0 = (start + 3u) & ~3u;  // first 16-B aligned dword
     const uint32_t head_end = a0 < end ? a0 : end;
     if (start + lane < head_end) base[start + lane] = value;
     if (a0 >= end) return;
@@ -455,27 +450,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     // every consecutive pair that is not short (rule C: minus the segment of hit 2, which the reference loses)
     const uint32_t nseg = nhits ? nhits - 1 - nshort - (drop2 ? 1u : 0u) : 0;
     const uint32_t wflag = drop2 ? 1u : 0u;
-    if (p.group_list) {
-        // Work list of the pipelined segment writer: one entry per group of 8 consecutive rays (= 8 lanes) in which a certified
-        // ray logged a hit.  All lanes of the wave are here (the walk loop has reconverged; padding lanes count 0).
-        const bool mine = active && !flag && order_ok;
-        const uint32_t wn = mine ? (nhits | (wflag << 15)) : 0u;             // hits <= M - 1 <= 4095; bit 15: rule C (drop hit 2's segment)
-        uint32_t gm = mine ? nhits : 0u;
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)gm, off); gm = o > gm ? o : gm; }
-        const uint32_t p01 = wn | ((uint32_t)__shfl_down((int)wn, 1) << 16);   // (rays a, a + 1) on even lanes
-        const uint32_t q1 = (uint32_t)__shfl_down((int)p01, 2), q2 = (uint32_t)__shfl_down((int)p01, 4), q3 = (uint32_t)__shfl_down((int)p01, 6);
-        const bool lead = (lane & 7) == 0 && gm > 0;
-        const unsigned long long lm = __ballot(lead);
-        uint32_t base = 0;
-        if (lane == 0 && lm) base = atomicAdd(p.group_count, (uint32_t)__popcll(lm));
-        base = (uint32_t)__shfl((int)base, 0);
-        if (lead) {
-            const uint32_t at = base + (uint32_t)__popcll(lm & lanemask_lt());
-            p.group_list[2 * (size_t)at] = make_uint4((uint32_t)(ray >> 3), gm, p01, q1);
-            p.group_list[2 * (size_t)at + 1] = make_uint4(q2, q3, 0u, 0u);
-        }
-    }
     if (active) {
         if (flag || (!order_ok && !p.literal_list)) {
             const uint32_t slot = atomicAdd(p.fallback_count, 1u);
@@ -697,8 +671,9 @@ __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
                 wave_lds_fence();
                 // ---- LDS -> rows: lane = (ray a2, unit d of that ray's run of this iteration).  ALL units are read back into
                 //      registers first, then ALL stores are issued back to back (round 6): with a store group per read group the
-                //      compiler put an s_waitcnt vmcnt(0) in front of every group's ds_read -- ~20 serialised store round trips
-                //      per iteration
+                //      compiler put an s_waitcnt vmcnt(0) in front of every group's ds_read (read off the ISA: 24 full drains of
+                //      the wave's memory queue per iteration, 8 now) -- ~20 serialised store round trips per iteration.  Kernel
+                //      alone -15 % (C2 0.72 -> 0.61 ms, C4 0.95 -> 0.80 ms: profiles/r06c_lib_ab.txt)
                 constexpr uint32_t RPI = 64 / W::SLOTS;       // rays per instruction for the one-unit-per-slot arrays
                 constexpr uint32_t NQ = 8 / RPI;
                 uint32_t s_sl[NQ], s_cell[NQ];
@@ -761,259 +736,12 @@ __global__ __launch_bounds__(256, 2) void k_write_segments(WriteParams q) {
     }
 }
 
-// ---- round 6: the segment writer as a SOFTWARE PIPELINE with straight-line memory instructions ----------------------------
-// What bounded k_write_segments above was not bandwidth but the compiler's s_waitcnt placement (read off the ISA): every
-// predicated load / store sits behind an s_cbranch_execz, the wait-count pass cannot count instructions a branch may skip, so
-// it falls back to s_waitcnt vmcnt(0) -- a full drain of the wave's memory queue, stores included -- in front of the LDS
-// read-back of every store group (~20 per iteration), at the top of every iteration and before the record gathers.  gfx950
-// retires a wave's loads and stores in issue order, so each drain costs a store round trip under the writer's own write
-// traffic.  Here EVERY vector memory instruction of the loop is unconditional:
-//   * loads take a clamped (always valid) address and the value is discarded by a select;
-//   * stores of lanes without a unit go to a SINK: log slot M - 1 of the group's 8 rays, one 128-byte line that no reader
-//     ever looks at (a ray logs at most M - 1 hits);
-//   * all-miss groups never arrive: the walk compacts the non-empty groups into a list whose 32-byte entries also carry the
-//     8 rays' hit counts (a group change = one sequential load, no dependent walk_n read);
-//   * the padding up to the next line boundary is left to the tail fill (exact_start), so the loop has no second store path.
-// With a static instruction count per iteration (4 entry loads + 2 descriptor loads + 8 record loads + 24 stores) the pass
-// emits COUNTED waits, and the loop is a three-stage pipeline over "items" (group, chunk of 8U hits per ray):
-//   E  request the log entries of item i + 2          B  pair / number the segments of item i + 1, request their records
-//   C  stage item i's 52-byte records in LDS, read them back by (ray, run), store
-// so a record gather has a whole iteration to arrive and no wait ever covers the stores of the current iteration.  Same
-// arithmetic, same LDS layout, same row bytes as k_write_segments (tests/test_walk_gpu.py: bit-identical rows).
-template <int U, bool PER_TET>
-__global__ __launch_bounds__(256, 2) void k_write_segments_pipe(WriteParams q) {
-    using W = SW<U>;
-    __shared__ __attribute__((aligned(16))) uint32_t smem[4 * W::TOTAL];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t *L = smem + wave * W::TOTAL;
-    const uint32_t a = (uint32_t)lane & 7u, h = (uint32_t)lane >> 3;
-    const uint32_t M = q.M;
-    const uint32_t nwaves = gridDim.x * 4u;
-    const uint32_t n_groups = *q.group_count;
-    const unsigned long long raymask = 0x0101010101010101ull << a;
-    constexpr uint32_t CH = 8 * U;                              // hits per ray per item
-
-    struct Item { uint32_t g, c0, nh; bool live; };             // g, c0, live: wave-uniform; nh: hits of ray 8 g + a | rule C flag << 15
-    auto log_of = [&](uint32_t g) -> const uint4 * {            // entry k of ray 8 g + a at [k * 64 + a]
-        const size_t r0 = 8 * (size_t)g;
-        return q.hit_log + (r0 >> 6) * (size_t)M * 64 + (r0 & 63);
-    };
-    // (every load fetches exactly the dwords that are used: the compiler recycles the dead lanes of a wider in-flight load as
-    //  temporaries and then has to wait for that load -- an s_waitcnt vmcnt(1) right behind the request)
-    auto load_desc = [&](uint32_t li, uint4 &d0, uint2 &d1) {    // unconditional: clamped index (entry 0 exists even for an empty list)
-        const uint32_t i = li < n_groups ? li : (n_groups ? n_groups - 1u : 0u);
-        d0 = q.group_list[2 * (size_t)i];
-        d1 = *reinterpret_cast<const uint2 *>(q.group_list + 2 * (size_t)i + 1);
-    };
-    auto nh_of = [&](const uint4 &d0, const uint2 &d1) -> uint32_t {
-        const uint32_t w = sel4u(d0.z, d0.w, d1.x, d1.y, a >> 1);
-        return (a & 1u) ? (w >> 16) : (w & 0xFFFFu);
-    };
-
-    // ---- cursor of stage E over (list entry, chunk); the next entry's descriptor is resident, the one after is requested
-    //      anew in every iteration (an unconditional load: redundant until the cursor moves on, then it has had an iteration)
-    uint32_t li = (uint32_t)blockIdx.x * 4u + (uint32_t)wave;
-    uint4 c_d0, n_d0, f_d0;
-    uint2 c_d1, n_d1, f_d1;
-    load_desc(li, c_d0, c_d1);
-    load_desc(li + nwaves, n_d0, n_d1);
-    load_desc(li + 2u * nwaves, f_d0, f_d1);
-    uint32_t c0 = 0;
-
-    // pipeline registers
-    Item it1{0u, 0u, 0u, false};                                // E -> B
-    uint4 e1[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) e1[u] = make_uint4(0u, 0u, 0u, 0u);
-    Item it0{0u, 0u, 0u, false};                                // B -> C
-    using QA = typename std::conditional<PER_TET, uint4, uint2>::type;   // per tet: orig, perm, cmb_lo, cmb_hi; per (tet, entry): orig, cmb
-    uint4 e0[U], qv0[U];
-    float pe0[U][3];
-    QA qa0[U];
-    uint32_t slot0[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        e0[u] = qv0[u] = make_uint4(0u, 0u, 0u, 0u); qa0[u] = QA{}; slot0[u] = TN_EMPTY;
-        pe0[u][0] = pe0[u][1] = pe0[u][2] = 0.f;
-    }
-    uint32_t base0 = 0, cnt0 = 0;                               // first slot / segments of item 0 (of ray a)
-    // stage B's running state of the current group
-    uint32_t nsegB = 0;
-    uint4 carryB = make_uint4(0u, 0u, 0u, 0u);
-
-    bool curs_live = li < n_groups;
-    while (curs_live || it1.live || it0.live) {                 // wave-uniform
-        // ================= stage E: request the entries of the cursor's item, move the cursor
-        Item it2;
-        it2.g = __builtin_amdgcn_readfirstlane((int)c_d0.x);
-        it2.c0 = c0;
-        it2.live = curs_live;
-        it2.nh = curs_live ? nh_of(c_d0, c_d1) : 0u;
-        if (!curs_live) it2.g = 0u;
-        uint4 e2[U];
-        {
-            const uint4 *lg = log_of(it2.g);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t k = it2.c0 + 8u * (uint32_t)u + h;
-                e2[u] = lg[(k < (it2.nh & 0x7FFFu) ? k : 0u) * 64u + a];    // (slot 0 of a valid log column when there is no such hit)
-            }
-        }
-        {
-            const uint32_t mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_d0.y);
-            c0 += CH;
-            if (!(curs_live && c0 < mx)) {                      // next list entry (wave-uniform; no memory instruction inside)
-                c0 = 0;
-                li += nwaves;
-                curs_live = li < n_groups;
-                c_d0 = n_d0; c_d1 = n_d1; n_d0 = f_d0; n_d1 = f_d1;
-            }
-            load_desc(li + 2u * nwaves, f_d0, f_d1);
-        }
-
-        // ================= stage B: item 1 -- previous hit of every lane, emission, slots, record requests
-        uint4 qv1[U];
-        float pe1[U][3];
-        QA qa1[U];
-        uint32_t slot1[U];
-        uint32_t base1, cnt1;
-        {
-            if (it1.c0 == 0u) { nsegB = 0u; carryB = make_uint4(0u, 0u, 0u, 0u); }   // (selects: wave-uniform condition)
-            base1 = nsegB;
-            const uint32_t nh1 = it1.nh & 0x7FFFu;
-            const bool drop2 = (it1.nh >> 15) != 0u;                // rule C of the walk's order test: the reference loses hit 2's segment
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t k = it1.c0 + 8u * (uint32_t)u + h;
-                if (!(k < nh1)) e1[u] = make_uint4(0u, 0u, 0u, 0u);
-                pe1[u][0] = __uint_as_float((uint32_t)__shfl_up((int)e1[u].x, 8)); pe1[u][1] = __uint_as_float((uint32_t)__shfl_up((int)e1[u].y, 8));
-                pe1[u][2] = __uint_as_float((uint32_t)__shfl_up((int)e1[u].z, 8));
-                if (h == 0) { pe1[u][0] = __uint_as_float(carryB.x); pe1[u][1] = __uint_as_float(carryB.y); pe1[u][2] = __uint_as_float(carryB.z); }
-                carryB.x = (uint32_t)__shfl((int)e1[u].x, (int)a + 56); carryB.y = (uint32_t)__shfl((int)e1[u].y, (int)a + 56);
-                carryB.z = (uint32_t)__shfl((int)e1[u].z, (int)a + 56);
-                const bool emit = k >= 1 && k < nh1 && !(fabsf(pe1[u][0] - __uint_as_float(e1[u].x)) < TN_EPS) && !(drop2 && k == 2u);
-                const unsigned long long m = __ballot(emit) & raymask;
-                slot1[u] = emit ? (nsegB - base1) + (uint32_t)__popcll(m & lanemask_lt()) : TN_EMPTY;
-                nsegB += (uint32_t)__popcll(m);
-            }
-            cnt1 = nsegB - base1;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t c = slot1[u] != TN_EMPTY ? (e1[u].w & 0x3FFFFFFFu) : 0u;      // record 0 for lanes without a segment
-                const uint32_t *rec = PER_TET ? reinterpret_cast<const uint32_t *>(q.tets + (c >> 2))
-                                              : reinterpret_cast<const uint32_t *>(q.cold + c);
-                qv1[u] = *reinterpret_cast<const uint4 *>(rec);
-                qa1[u] = *reinterpret_cast<const QA *>(rec + 4);
-            }
-        }
-
-        // ================= stage C: item 0 -- segment records -> LDS [array][ray][slot] -> rows
-        {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (slot0[u] != TN_EMPTY) {                     // (LDS instructions only)
-                    const uint32_t at = a * W::STRIDE + slot0[u];
-                    const uint32_t x = e0[u].w >> 30, ent = e0[u].w & 3u;
-                    uint32_t cmb;
-                    uint4 vids = qv0[u];
-                    if constexpr (PER_TET) {
-                        const unsigned long long lo64 = (unsigned long long)qa0[u].z | ((unsigned long long)qa0[u].w << 32);
-                        const uint32_t c18 = ent == 3u ? ((uint32_t)(lo64 >> 54) | ((qa0[u].y >> 24) << 10)) : (uint32_t)(lo64 >> (18u * ent));
-                        cmb = c18 >> (6u * x);
-                        const uint32_t pm = qa0[u].y >> (6u * ent);
-                        vids = make_uint4(sel4u(qv0[u].x, qv0[u].y, qv0[u].z, qv0[u].w, ent), sel4u(qv0[u].x, qv0[u].y, qv0[u].z, qv0[u].w, pm & 3u),
-                                          sel4u(qv0[u].x, qv0[u].y, qv0[u].z, qv0[u].w, (pm >> 2) & 3u),
-                                          sel4u(qv0[u].x, qv0[u].y, qv0[u].z, qv0[u].w, (pm >> 4) & 3u));
-                    } else {
-                        cmb = qa0[u].y >> (6u * x);
-                    }
-                    const float pt = pe0[u][0], pu = pe0[u][1], pv = pe0[u][2];
-                    const float ct = __uint_as_float(e0[u].x), cu = __uint_as_float(e0[u].y), cv = __uint_as_float(e0[u].z);
-                    const float r0f = 1.0f - cu - cv;
-                    const uint32_t k0 = cmb & 3u, k1 = (cmb >> 2) & 3u, k2 = (cmb >> 4) & 3u;
-                    L[W::CELLS + at] = qa0[u].x;
-                    *reinterpret_cast<float2 *>(L + W::DIST + 2 * at) = make_float2(pt, ct);
-                    float2 *bp = reinterpret_cast<float2 *>(L + W::BARY + 6 * at);
-                    bp[0] = make_float2(1.0f - pu - pv, pu);
-                    bp[1] = make_float2(pv, sel4f(r0f, cu, cv, 0.f, k0));
-                    bp[2] = make_float2(sel4f(r0f, cu, cv, 0.f, k1), sel4f(r0f, cu, cv, 0.f, k2));
-                    *reinterpret_cast<uint4 *>(L + W::VERTS + 4 * at) = vids;
-                }
-            }
-            if (h == 0) *reinterpret_cast<uint2 *>(L + W::META + 2 * a) = make_uint2(cnt0, base0);
-            wave_lds_fence();
-            // rows of the group: scalar bases + 32-bit lane offsets; the sink: log slot M - 1 of the group's 8 rays (16 B per ray)
-            const size_t row0 = 8 * (size_t)it0.g * (size_t)M;
-            uint32_t *const g_cells = q.out_cells + row0;
-            float *const g_dist = q.out_dist + 2 * row0;
-            float *const g_bary = q.out_bary + 6 * row0;
-            uint32_t *const g_verts = q.out_verts ? q.out_verts + 4 * row0 : nullptr;
-            uint32_t *const sink = reinterpret_cast<uint32_t *>(const_cast<uint4 *>(log_of(it0.g)) + (size_t)(M - 1u) * 64u) + 4u * a;
-            constexpr uint32_t RPI = 64 / W::SLOTS;
-            constexpr uint32_t NQ = 8 / RPI;
-            uint32_t s_sl[NQ], s_cell[NQ];
-            float2 s_dist[NQ];
-            uint4 s_vert[NQ];
-#pragma unroll
-            for (uint32_t qd = 0; qd < NQ; ++qd) {
-                const uint32_t a2 = RPI * qd + (uint32_t)lane / W::SLOTS, d = (uint32_t)lane % W::SLOTS;
-                const uint2 meta = *reinterpret_cast<const uint2 *>(L + W::META + 2 * a2);
-                const uint32_t at = a2 * W::STRIDE + d;
-                s_sl[qd] = d < meta.x ? a2 * M + meta.y + d : TN_EMPTY;
-                s_cell[qd] = L[W::CELLS + at];
-                s_dist[qd] = *reinterpret_cast<const float2 *>(L + W::DIST + 2 * at);
-                s_vert[qd] = *reinterpret_cast<const uint4 *>(L + W::VERTS + 4 * at);
-            }
-            constexpr uint32_t UB = 3 * W::SLOTS;
-            constexpr uint32_t NB = 8 * UB / 64;
-            uint32_t b_off[NB];
-            float2 b_val[NB];
-#pragma unroll
-            for (uint32_t qd = 0; qd < NB; ++qd) {
-                const uint32_t gi = 64u * qd + (uint32_t)lane;
-                const uint32_t a2 = gi / UB, d = gi - UB * a2;
-                const uint2 meta = *reinterpret_cast<const uint2 *>(L + W::META + 2 * a2);
-                b_off[qd] = d < 3u * meta.x ? 6u * (a2 * M + meta.y) + 2u * d : TN_EMPTY;
-                b_val[qd] = *reinterpret_cast<const float2 *>(L + W::BARY + 6 * (a2 * W::STRIDE) + 2 * d);
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (uint32_t qd = 0; qd < NQ; ++qd) {
-                const bool on = s_sl[qd] != TN_EMPTY;
-                *(on ? g_cells + s_sl[qd] : sink) = s_cell[qd];
-                *reinterpret_cast<float2 *>(on ? g_dist + 2u * s_sl[qd] : reinterpret_cast<float *>(sink)) = s_dist[qd];
-                *reinterpret_cast<uint4 *>((on && g_verts) ? g_verts + 4u * s_sl[qd] : sink) = s_vert[qd];
-            }
-#pragma unroll
-            for (uint32_t qd = 0; qd < NB; ++qd) {
-                const bool on = b_off[qd] != TN_EMPTY;
-                *reinterpret_cast<float2 *>(on ? g_bary + b_off[qd] : reinterpret_cast<float *>(sink)) = b_val[qd];
-            }
-        }
-
-        // ================= rotate
-        it0 = it1; base0 = base1; cnt0 = cnt1;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            e0[u] = e1[u]; pe0[u][0] = pe1[u][0]; pe0[u][1] = pe1[u][1]; pe0[u][2] = pe1[u][2];
-            qa0[u] = qa1[u]; qv0[u] = qv1[u]; slot0[u] = slot1[u]; e1[u] = e2[u];
-        }
-        it1 = it2;
-    }
-}
-
 void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned max_blocks) {
     if (q.num_rays == 0) return;
     size_t blocks = (q.num_rays + 31) / 32;        // one group of 8 rays per wave
     // grid = what is resident at once (2 blocks per CU at 192 VGPRs): the groups are dealt round-robin over it
     const size_t cap = max_blocks ? max_blocks : (size_t)256 * 2;
     if (blocks > cap) blocks = cap;
-    if (q.group_list) {
-        if (q.tets) hipLaunchKernelGGL((k_write_segments_pipe<4, true>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
-        else hipLaunchKernelGGL((k_write_segments_pipe<4, false>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
-        return;
-    }
     if (q.tets) hipLaunchKernelGGL((k_write_segments<4, true>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
     else hipLaunchKernelGGL((k_write_segments<4, false>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
 }
@@ -1025,7 +753,7 @@ void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned ma
 //                 included: the kernels that write those slots are ordered behind this one.
 //   all_rows = 0: slots [ceil32(n), k_split) of the certified rows (k_write_segments has written [0, ceil32(n))).
 template <bool NT>
-__global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M, uint32_t all_rows, uint32_t k_split, uint32_t exact_start,
+__global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M, uint32_t all_rows, uint32_t k_split,
                                                     const uint32_t *__restrict__ walk_n, const uint32_t *__restrict__ out_num,
                                                     uint32_t *__restrict__ out_cells,
                                                     float *__restrict__ out_bary, float *__restrict__ out_dist,
@@ -1040,7 +768,7 @@ __global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M,
         uint32_t lo = k_split, hi = M;
         if (!all_rows) {
             if (walk_n[r] == TN_EMPTY) continue;  // literal / fallback ray: those kernels write the whole row
-            lo = exact_start ? out_num[r] : (out_num[r] + 31u) & ~31u;   // exact: the pipelined writer leaves the padding to this kernel
+            lo = (out_num[r] + 31u) & ~31u;
             if (lo > M) lo = M;
             hi = k_split;
         }
@@ -1054,7 +782,7 @@ __global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M,
 
 void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *walk_n, const uint32_t *out_num,
                        uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
-                       uint32_t k_split, bool nontemporal, unsigned max_blocks, bool exact_start) {
+                       uint32_t k_split, bool nontemporal, unsigned max_blocks) {
     if (num_rays == 0) return;
     size_t blocks = (num_rays + 3) / 4;           // >= one ray per wave
     // after the writer: 2 blocks (8 waves) per CU hold the write ceiling, and the latency-bound kernels running beside
@@ -1063,10 +791,10 @@ void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_
     const size_t cap = max_blocks ? max_blocks : (all_rows ? 2048 : 256 * 2);
     if (blocks > cap) blocks = cap;
     if (nontemporal)
-        hipLaunchKernelGGL(k_fill_range<true>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split, exact_start ? 1u : 0u,
+        hipLaunchKernelGGL(k_fill_range<true>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split,
                            walk_n, out_num, out_cells, out_bary, out_dist, out_verts);
     else
-        hipLaunchKernelGGL(k_fill_range<false>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split, exact_start ? 1u : 0u,
+        hipLaunchKernelGGL(k_fill_range<false>, dim3((unsigned)blocks), dim3(256), 0, stream, num_rays, M, all_rows ? 1u : 0u, k_split,
                            walk_n, out_num, out_cells, out_bary, out_dist, out_verts);
 }
 
