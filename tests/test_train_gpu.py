@@ -112,65 +112,66 @@ def test_render_train_fused_equals_autograd_statement(tn, device, scenes):
         rd = render.TetraRenderer(tr, field, mlp, S, 256, fused=True, num_fine_samples=S_fine, biased=biased)
         hit = int((tr.trace_rays(to, td, 256)["num_visited_cells"] > 0).sum())
         rand = {"coarse": torch.rand(hit, S + 1, device=device), "fine": torch.rand(hit, S_fine + 1, device=device)}
-        grads, cap = [], {}
+        # Each path is compared with float64 autograd of the plain statement ON ITS OWN SAMPLE PLACEMENT (round 6).  Until round 5
+        # one capture dictionary served both runs, so the fused gradients were compared with float64 on the UNFUSED run's
+        # placement: the two placements differ by an ulp of the bin edges (5e-5 in the barycentrics of short segments), which
+        # moves samples across ReLU boundaries -- that, not the kernels, was most of the 1e-4 .. 2e-3 this test used to allow
+        # (profiles/r06h_grad_bisect.txt: on its own placement the fused path is within 5e-7 of float64 on every tensor
+        # whenever no ReLU decision differs).
+        def float64_statement(cap):
+            dt = torch.float64
+            m64 = render.TetraMLP().to(device).to(dt)
+            m64.load_state_dict({k: v.to(dt) for k, v in mlp.state_dict().items()})
+            f64 = field.detach().to(dt).requires_grad_(True)
+            vi, bc, edges, S2 = cap["vertex_indices"], cap["barycentric_coordinates"].to(dt), cap["edges"].to(dt), cap["samples_per_ray"]
+            wts = torch.cat([1 - bc.sum(-1, keepdim=True), bc], -1)
+            wts = torch.where(vi < 0, torch.zeros_like(wts), wts)
+            feats = (f64.t()[vi.long().clamp_min(0)] * wts[..., None]).sum(-2)
+            sg, col = m64(feats, cap["dirs"].to(dt)[:, None, :].expand(-1, S2, -1))
+            if scaling:
+                spacing = (edges - cap["near"].to(dt)) / (cap["far"].to(dt) - cap["near"].to(dt))
+                col, sg, _ = render.GradientScaler.apply(col, sg, (spacing[:, 1:] + spacing[:, :-1])[..., None])
+            rgb_r, acc_r, _, _ = render.composite(sg, col, edges[:, :-1, None], edges[:, 1:, None])
+            rgb = torch.ones(len(o), 3, dtype=dt, device=device).index_copy(0, cap["idx"], rgb_r)
+            acc = torch.zeros(len(o), 1, dtype=dt, device=device).index_copy(0, cap["idx"], acc_r)
+            loss_of(rgb, acc).backward()
+            assert float(f64.grad.abs().max()) > 0
+            return rgb.detach().float(), [f64.grad] + [p.grad for p in render.mlp_weights(m64)]
+
+        def flipped_decisions(cap, fused):
+            """ReLU decisions of the fp32 forward on this placement (fused: the masks tn_mlp_forward_gather_train saves; unfused:
+            the float32 statement's own signs) that differ from float64's, per layer"""
+            vi, bc, S2 = cap["vertex_indices"], cap["barycentric_coordinates"], cap["samples_per_ray"]
+            n_s = vi.numel() // 4
+            with torch.no_grad():
+                natural64 = _statement(render, device, mlp, field, vi.reshape(n_s, 4), bc.reshape(n_s, 3), cap["dirs"], S2, None, torch.float64)[3]
+                if fused:
+                    _, _, saved = tn.cpp.mlp_forward_gather_train(vi, bc, field.detach(), cap["dirs"], [x.detach() for x in render.mlp_weights(mlp)], S2)
+                    ours = _decode_relu_masks(saved.masks.clone(), n_s)
+                else:
+                    ours = _statement(render, device, mlp, field, vi.reshape(n_s, 4), bc.reshape(n_s, 3), cap["dirs"], S2, None, torch.float32)[3]
+            return n_s, (ours != natural64).sum(dim=(1, 2)).tolist()
+
+        names = ["field", "w1", "b1", "w2", "b2", "w3", "b3", "wd", "bd", "wh", "bh", "wr", "br"]
         for fused in (True, False):
             field.grad = None
             mlp.zero_grad()
+            cap = {}
             out = rd.render_train(to, td, gradient_scaling=scaling, rand=rand, fused=fused, capture=cap)
             loss_of(out["rgb"], out["accumulation"]).backward()
-            grads.append((out["rgb"].detach().clone(), field.grad.clone(), [p.grad.clone() for p in render.mlp_weights(mlp)]))
-        # float64 statement on the captured sample placement
-        dt = torch.float64
-        m64 = render.TetraMLP().to(device).to(dt)
-        m64.load_state_dict({k: v.to(dt) for k, v in mlp.state_dict().items()})
-        f64 = field.detach().to(dt).requires_grad_(True)
-        vi, bc, edges, S2 = cap["vertex_indices"], cap["barycentric_coordinates"].to(dt), cap["edges"].to(dt), cap["samples_per_ray"]
-        wts = torch.cat([1 - bc.sum(-1, keepdim=True), bc], -1)
-        wts = torch.where(vi < 0, torch.zeros_like(wts), wts)
-        feats = (f64.t()[vi.long().clamp_min(0)] * wts[..., None]).sum(-2)
-        sg, col = m64(feats, cap["dirs"].to(dt)[:, None, :].expand(-1, S2, -1))
-        if scaling:
-            spacing = (edges - cap["near"].to(dt)) / (cap["far"].to(dt) - cap["near"].to(dt))
-            col, sg, _ = render.GradientScaler.apply(col, sg, (spacing[:, 1:] + spacing[:, :-1])[..., None])
-        rgb_r, acc_r, _, _ = render.composite(sg, col, edges[:, :-1, None], edges[:, 1:, None])
-        rgb = torch.ones(len(o), 3, dtype=dt, device=device).index_copy(0, cap["idx"], rgb_r)
-        acc = torch.zeros(len(o), 1, dtype=dt, device=device).index_copy(0, cap["idx"], acc_r)
-        loss_of(rgb, acc).backward()
-        want_f, want_w = f64.grad, [p.grad for p in render.mlp_weights(m64)]
-        (rgb_a, gf_a, gw_a), (rgb_b, gf_b, gw_b) = grads
-        np.testing.assert_allclose(rgb_a.cpu().numpy(), rgb.detach().float().cpu().numpy(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(rgb_b.cpu().numpy(), rgb.detach().float().cpu().numpy(), rtol=0, atol=1e-5)
-        assert float(want_f.abs().max()) > 0
-        # ReLU decisions of the fused forward (the masks tn_mlp_forward_gather_train saves, on the captured sample placement)
-        # against float64's own
-        n_s = vi.numel() // 4
-        _, _, saved = tn.cpp.mlp_forward_gather_train(vi, cap["barycentric_coordinates"], field.detach(), cap["dirs"],
-                                                      [x.detach() for x in render.mlp_weights(mlp)], S2)
-        with torch.no_grad():
-            natural64 = _statement(render, device, mlp, field, vi.reshape(n_s, 4), cap["barycentric_coordinates"].reshape(n_s, 3), cap["dirs"], S2,
-                                   None, torch.float64)[3]
-        flipped = int((_decode_relu_masks(saved.masks.clone(), n_s) != natural64).sum())
-        errs = [("field", _rel(gf_a, want_f), _rel(gf_b, want_f))] + [(f"w{i}", _rel(a, w), _rel(b, w)) for i, (a, b, w) in enumerate(zip(gw_a, gw_b, want_w))]
-        print(f"config {(S, S_fine, biased, scaling)}: {n_s} samples, {flipped} ReLU decisions differ from float64; (tensor, fused, float32 autograd) "
-              + ", ".join(f"({nm} {a:.1e} {b:.1e})" for nm, a, b in errs))
-        for name, ours, torch32 in errs:
-            # the fused path must be as close to float64 as the float32 autograd statement is, up to a factor: the sums
-            # over the samples are split differently (4096-sample slices + float atomics here) and the composite
-            # adjoint is a different (equally cancelling) expression.  The ratio to float32 autograd's own error moves
-            # between 0.5 and 6 with the target image (both are conditioning-limited: 1e-4 .. 2e-3 of the largest entry for
-            # the field gradient of this loss), hence the absolute alternative
-            # (round 4, profiles/r04b_grad_diag.txt: float32 autograd itself is 1.0e-4 off for w1 and 5e-4 for wh on some
-            # mesh / draw combinations -- a ReLU pre-activation within rounding of 0 takes the other branch than in float64 --
-            # while on others it is 5e-7; the fused path flips different samples, so the absolute alternative is 3e-4.
-            # Round 5 SHOWS it: test_training_gradients_match_float64_under_the_saved_relu_masks below compares under the
-            # masks the fused forward saved -- every tensor within 5e-6 there, 1-5 flipped bits where this comparison is off)
-            assert ours < max(5.0 * torch32, 2e-3 if name == "field" else 3e-4), ((S, S_fine, biased), name, ours, torch32, errs)
-            # round 6: with the explanation in hand the ABSOLUTE alternative above is only admissible where bits flipped: on a
-            # batch on which the fused forward took every ReLU decision as float64 does, the fused gradient must be within 1e-5 --
-            # or within 5x of what float32 autograd reaches on the same batch (the composite's adjoint cancels in fp32 on both
-            # sides: first run of this assertion, (24, 24, biased, scaled): 0 flipped decisions, see the printed errors)
-            if flipped == 0:
-                assert ours < max(5.0 * torch32, 1e-5), ((S, S_fine, biased), name, ours, torch32, "no ReLU decision differs from float64", errs)
+            got = [field.grad.clone()] + [p.grad.clone() for p in render.mlp_weights(mlp)]
+            want_rgb, want = float64_statement(cap)
+            np.testing.assert_allclose(out["rgb"].detach().cpu().numpy(), want_rgb.cpu().numpy(), rtol=0, atol=1e-5)
+            n_s, flips = flipped_decisions(cap, fused)
+            errs = [(nm, _rel(a, w)) for nm, a, w in zip(names, got, want)]
+            print(f"config {(S, S_fine, biased, scaling)} {'fused' if fused else 'float32 autograd'}: {n_s} samples, ReLU decisions differing "
+                  f"from float64 per layer {flips}; " + " ".join(f"{nm} {e:.1e}" for nm, e in errs))
+            for nm, e in errs:
+                # within 1e-5 of float64 on every tensor -- unless a ReLU decision differs: a unit whose pre-activation is within an
+                # ulp of 0 contributes its whole (sample, unit) term or nothing, and one term can be 1e-3 of the largest entry
+                # of a gradient that is a sum over 25k samples (the masked test below shows that this is ALL that differs)
+                assert e < 1e-5 or sum(flips) > 0, ((S, S_fine, biased, scaling), "fused" if fused else "float32", nm, e, flips, errs)
+                assert e < (4e-3 if nm == "field" else 3e-3), ((S, S_fine, biased, scaling), nm, e, flips)
 
 
 def _decode_relu_masks(masks, n):
