@@ -186,7 +186,7 @@ def trace_breakdown(tracer, o, d, M):
 
 
 def cross_check(tracer):
-    """blind sample (every verify_stride-th certified ray: 1 in 1024 by default) + risk classes (every certified ray inside the
+    """blind sample (every verify_stride-th certified ray: 1 in 256 by default) + risk classes (every certified ray inside the
     wide band of a guard)"""
     return tracer.cross_check()
 

@@ -383,6 +383,15 @@ int tn_render_rays(tn_mlp_t mlp, uint32_t max_ray_triangles, const uint32_t *num
                    const float *u_table, float histogram_padding, float eps, const float *field_vm, const float *dirs,
                    const tn_rgb_background *background, float *out_rgb, float *out_acc, float *out_depth,
                    const float *ray_head_bias, void *stream);
+/* ... with the arithmetic of the MLP phases as a per-call argument like tn_mlp_forward's `mode` (round 6): 0 = fp32 MFMA (what
+ * tn_render_rays runs), 1 = bf16x3 (split-operand bf16 MFMA, csrc/tn_mlp_x3.hip; opt-in): then the frame is bit-identical to the
+ * kernel chain run with mode 1.  Same reference span (model.py:531-662). */
+int tn_render_rays_ex(tn_mlp_t mlp, uint32_t max_ray_triangles, const uint32_t *num_visited, const float *hit_distances,
+                   const float *barycentric, const uint32_t *vertex_indices, const uint32_t *ray_index, const uint32_t *count,
+                   size_t num_hit_rays_max, uint32_t num_samples, uint32_t num_fine, int biased, const float *linspace,
+                   const float *u_table, float histogram_padding, float eps, const float *field_vm, const float *dirs,
+                   const tn_rgb_background *background, float *out_rgb, float *out_acc, float *out_depth,
+                   const float *ray_head_bias, int mode, void *stream);
 
 /* ---- ray samplers between tn_trace_rays and the render passes (model.py:111-192, 549-557, 582-586; nerfstudio's
  * UniformSampler / PDFSampler for the parts the reference imports).  One wavefront per HITTING ray; the trace rows are

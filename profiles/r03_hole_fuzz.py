@@ -33,6 +33,7 @@ rng, MESHES, aimed_rays = lib.rng, lib.MESHES, lib.aimed_rays
 
 t0 = time.time(); total = 0; mism_rays = 0; oracle_rays = 0; oracle_bad = 0; reasons = {}; batches = 0
 B = 400_000; M = 256
+if lib.FAMILY == "big": B, M = 200_000, 1024   # rays of the 1M-point mesh cross 500-650 faces
 while total < target_rays:
     for name, make in MESHES:
         pts, cells = make()

@@ -28,6 +28,52 @@ MESHES = [(f"twins_{s:g}", (lambda s=s: scenes.near_duplicates_mesh(3000, s, see
     ("flat_hull_exact", lambda: flat_hull_mesh(3000, 0.0))]
 
 
+
+
+def planar_patches_mesh(n=6000, noise=1e-7, seed=11):
+    """COLMAP-like: most points on a few planar patches (two axis-aligned, two oblique) with `noise` of off-plane scatter (0 = exactly
+    coplanar in fp32 up to the rounding of the oblique ones), jittered copies as scripts/triangulate.py:36-55 adds them, a sparse
+    uniform cloud around: sheets of near-degenerate tets between coplanar points, the geometry VERDICT r05 asked the fuzzer for"""
+    r = np.random.default_rng(seed + 1000 * SEED)
+    k = n // 6
+    def patch(origin, e1, e2):
+        uv = r.random((k, 2))
+        nrm = np.cross(e1, e2); nrm = nrm / np.linalg.norm(nrm)
+        return origin + uv[:, :1] * e1 + uv[:, 1:] * e2 + (noise * r.normal(size=(k, 1)) if noise else 0.0) * nrm
+    pts = [patch(np.array([0.1, 0.1, 0.3]), np.array([0.8, 0, 0]), np.array([0, 0.8, 0])),
+           patch(np.array([0.1, 0.7, 0.1]), np.array([0.8, 0, 0]), np.array([0, 0, 0.8])),
+           patch(np.array([0.2, 0.2, 0.2]), np.array([0.6, 0.1, 0.3]), np.array([-0.1, 0.6, 0.2])),
+           patch(np.array([0.8, 0.2, 0.8]), np.array([-0.5, 0.3, -0.2]), np.array([0.1, 0.5, -0.4]))]
+    base = np.concatenate(pts, 0)
+    m = k
+    s_ = 1.0 / np.cbrt(n)
+    off = r.normal(size=(m, 3)); off /= np.linalg.norm(off, axis=-1, keepdims=True)
+    copies = base[r.choice(len(base), m, replace=True)] + off * np.abs(r.normal(s_, 0.5 * s_, size=(m, 1)))
+    return scenes._mesh_of(np.concatenate([base, copies, r.random((n - 4 * k - m, 3))], 0))
+
+
+def big_mesh(n_points=1_000_000, seed=7):
+    """the reference's upper size (scripts/triangulate.py:15): Delaunay of 1M uniform points, cached like the GPU suite's"""
+    rr = np.random.default_rng(seed)
+    pts = rr.random((n_points, 3)).astype(np.float32)
+    f = Path(os.environ.get("TETRANERF_TEST_CACHE", str(Path.home() / ".cache" / "tetranerf_tests"))) / f"delaunay_{n_points}_seed{seed}.npy"
+    if f.exists():
+        return pts, np.load(f)
+    cells = scenes.delaunay_cells(pts)
+    try:
+        f.parent.mkdir(parents=True, exist_ok=True); np.save(f, cells)
+    except OSError:
+        pass
+    return pts, cells
+
+
+# TETRANERF_FUZZ_FAMILY: "default" (rounds 3-5), "planar" (round 6: coplanar COLMAP-like patches), "big" (round 6: the 1M-point mesh)
+FAMILY = os.environ.get("TETRANERF_FUZZ_FAMILY", "default")
+if FAMILY == "planar":
+    MESHES = [(f"planar_{s:g}", (lambda s=s: planar_patches_mesh(6000, s, seed=11))) for s in (0.0, 1e-8, 1e-7, 1e-6, 1e-4)]
+elif FAMILY == "big":
+    MESHES = [("uniform_1M_points", big_mesh)]
+
 def ulp_perturb(p, k):
     if k == 0: return p
     p = p.astype(np.float32).copy()

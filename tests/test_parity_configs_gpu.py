@@ -72,7 +72,7 @@ def _trace(tr, device, o, d, M):
 
 def _cross_check_clean(tr, num_rays, ctx):
     """The always-on cross-check of the walk's certification (a count-only BVH all-hits traversal beside the writer and the
-    fill): the blind sample (tracer option verify_stride, default 1024) ran, and it never disagreed; and -- round 5 -- EVERY
+    fill): the blind sample (tracer option verify_stride, default 256) ran, and it never disagreed; and -- round 5 -- EVERY
     certified ray of the risk classes (inside the 16-delta band of a guard that hands over at 8 delta) was re-counted as well
     (all but those the blind sample already holds), without a disagreement."""
     why = tr.flag_reasons()

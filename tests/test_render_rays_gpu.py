@@ -94,6 +94,42 @@ def test_one_launch_render_is_bit_identical_to_the_kernel_chain(tn, device, scen
     assert bool((a["rgb"][~a["ray_mask"]] == torch.tensor([0.1, 0.5, 0.9], device=device)).all())
 
 
+@pytest.mark.parametrize("S,S_fine,biased,M", [(64, 0, False, 256), (100, 37, False, 256), (256, 256, False, 512), (128, 128, True, 512)])
+def test_one_launch_render_bf16x3_is_bit_identical_to_the_bf16x3_chain(tn, device, scenes, render, S, S_fine, biased, M):
+    """Round 6: the persistent launch also in the opt-in bf16x3 arithmetic (tn_render_rays_ex, mode 1: the MLP phases run
+    x3::forward_group, the loop body of k_mlp_forward_x3; ray phase 1 leaves the ray's 32-float direction encoding and its
+    appearance bias row in the tile's scratch, because that arithmetic's head layer takes the encoding as two k-steps of its GEMM)
+    -- bit-identical to the bf16x3 kernel chain on a frame with missing rays, a 137-ray batch, an all-miss batch, with a per-ray
+    head bias and a coloured background; and within 1e-5 of the fp32 launch (the bound the bf16x3 mode is tested to elsewhere)."""
+    import torch
+
+    tr, mlp, field = _setup(tn, scenes, render, device)
+    kw = dict(fused=True, num_fine_samples=S_fine, biased=biased, mlp_mode="bf16x3")
+    one = render.TetraRenderer(tr, field, mlp, S, M, fused_pass=True, **kw)
+    chain = render.TetraRenderer(tr, field, mlp, S, M, fused_pass=False, **kw)
+    fp32 = render.TetraRenderer(tr, field, mlp, S, M, fused=True, num_fine_samples=S_fine, biased=biased, fused_pass=True)
+    assert one._one_launch_ok("bf16x3") and not chain._one_launch_ok("bf16x3")
+    fo, fd = _frame(scenes, device, 120, 90)
+    so, sd = fo[4000:4137].contiguous(), fd[4000:4137].contiguous()
+    away = (fo + 10.0).contiguous()
+    for name, (o, d) in (("frame", (fo, fd)), ("137 rays", (so, sd)), ("all miss", (away, fd))):
+        a, b = one.render(o, d), chain.render(o, d)
+        assert torch.equal(a["ray_mask"], b["ray_mask"])
+        for k in ("rgb", "accumulation", "depth"):
+            assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), (name, k, float((a[k] - b[k]).abs().max()))
+        assert bool(torch.isfinite(a["rgb"]).all())
+        if name == "frame":
+            c = fp32.render(o, d)
+            assert float((a["rgb"] - c["rgb"]).abs().max()) < 1e-5 and float((a["accumulation"] - c["accumulation"]).abs().max()) < 1e-5
+            assert not torch.equal(a["rgb"].view(torch.int32), c["rgb"].view(torch.int32))      # it IS another arithmetic
+    bias = torch.randn(len(fo), 128, device=device) * 0.7
+    a, b = one.render(fo, fd, ray_head_bias=bias), chain.render(fo, fd, ray_head_bias=bias)
+    assert torch.equal(a["rgb"].view(torch.int32), b["rgb"].view(torch.int32))
+    assert float((a["rgb"] - one.render(fo, fd)["rgb"]).abs().max()) > 1e-2
+    a, b = one.render(fo, fd, background=(0.1, 0.5, 0.9)), chain.render(fo, fd, background=(0.1, 0.5, 0.9))
+    assert torch.equal(a["rgb"].view(torch.int32), b["rgb"].view(torch.int32))
+
+
 @pytest.mark.parametrize("M", [4, 8, 16])
 def test_one_launch_render_small_max_ray_triangles(tn, device, scenes, render, M):
     """max_ray_triangles of 4 / 8 (both accepted by trace_rays): 2 M < 28, so the 28 floats of the direction encoding at the start

@@ -25,7 +25,7 @@ SYMBOLS = (
     "tn_trace_stats", "tn_trace_flag_reasons", "tn_set_option", "tn_mlp_create", "tn_mlp_destroy", "tn_mlp_set_weights",
     "tn_mlp_forward", "tn_mlp_forward_gather", "tn_composite", "tn_gather_uint32", "tn_scatter_ema_uint32",
     "tn_mlp_forward_gather_train", "tn_mlp_backward", "tn_mlp_ray_head_grad", "tn_mlp_param_grads", "tn_composite_backward", "tn_sample_coarse", "tn_sample_pdf",
-    "tn_trace_timings", "tn_trace_cross_check", "tn_fill_rows", "tn_compact_hits", "tn_render_rays",
+    "tn_trace_timings", "tn_trace_cross_check", "tn_fill_rows", "tn_compact_hits", "tn_render_rays", "tn_render_rays_ex",
 )
 
 ABI_VERSION = 6          # include/tetranerf_hip.h: TN_ABI_VERSION this binding was written against
@@ -98,6 +98,7 @@ def load():
     lib.tn_sample_pdf.argtypes = [sz, u32, u32, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
     lib.tn_compact_hits.argtypes = [sz, vp, vp, vp, vp, vp, sz, vp]
     lib.tn_render_rays.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, sz, u32, u32, i32, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tn_render_rays_ex.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, sz, u32, u32, i32, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("tn_last_error", "tn_version", "tn_abi_version", "tn_num_faces"):

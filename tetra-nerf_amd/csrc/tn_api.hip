@@ -59,8 +59,11 @@ struct tn_tracer {
     // Measured interleaved in one process (profiles/r05e_risk_sweep.txt; C2 frame / C4 frame / C5 rays): round 4's blind sample
     // of 1 in 256 cost +0.8 / +0.9 / +0.0 % over no check at all; the risk classes at band 2 + a blind 1 in 1024 cost the same
     // (+0.8 / +1.3 / -0.0 %) while checking EVERY ray of the classes (1,850 / 2,705 / 5,176 rays) and 618 / 609 / 924 blind ones;
-    // band 4 costs +1.1 / +5.3 / +4.1 %, band 8 +5.5 / +13 / +15 % (three to seven times as many rays).  Hence 1024 and 2.
-    unsigned verify_stride = 1024;
+    // band 4 costs +1.1 / +5.3 / +4.1 %, band 8 +5.5 / +13 / +15 % (three to seven times as many rays).  Hence band 2.
+    // Round 6: the blind stride is back at 256 beside the risk classes (the residue of the certification is not proved, and the
+    // blind sample is all that looks beyond the band): in-process sweep, 1024 -> 256: +0.0 / +0.7 / +1.1 %, 64: +2.1 / +1.7 / +6.7 %
+    // (profiles/r06i_stride_sweep.txt) -- paid for by rules A-C of the order test (-0.1 / -1.9 / -3.5 % in the same sweep).
+    unsigned verify_stride = 256;
     unsigned literal_sort_passes = 8;    // odd-even passes over a literal ray's logged hits before the bitonic network (tests: 0, 1)
     bool verify_inject = false;          // tests: every cross-checked ray is treated as a mismatch (exercises the hand-over)
     tn::DevBuf<uint32_t> verify_list;    // certified rays whose count differed: re-traced by the BVH kernel at the end of the call
@@ -1042,8 +1045,20 @@ int tn_render_rays(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const 
                    float histogram_padding, float eps, const float *field_vm, const float *dirs,
                    const tn_rgb_background *background, float *out_rgb, float *out_acc, float *out_depth,
                    const float *ray_head_bias, void *stream_) {
+    return tn_render_rays_ex(mlp, M, num_visited, hit_distances, barycentric, vertex_indices, ray_index, count, num_hit_rays_max,
+                             num_samples, num_fine, biased, linspace, u_table, histogram_padding, eps, field_vm, dirs, background,
+                             out_rgb, out_acc, out_depth, ray_head_bias, 0, stream_);
+}
+
+int tn_render_rays_ex(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const float *hit_distances, const float *barycentric,
+                      const uint32_t *vertex_indices, const uint32_t *ray_index, const uint32_t *count, size_t num_hit_rays_max,
+                      uint32_t num_samples, uint32_t num_fine, int biased, const float *linspace, const float *u_table,
+                      float histogram_padding, float eps, const float *field_vm, const float *dirs,
+                      const tn_rgb_background *background, float *out_rgb, float *out_acc, float *out_depth,
+                      const float *ray_head_bias, int mode, void *stream_) {
     return guarded([&] {
         tn_mlp *m = checked_mlp(mlp);
+        check_mode(mode);
         if (num_hit_rays_max == 0) return;
         if (!num_visited || !hit_distances || !barycentric || !vertex_indices || !ray_index || !linspace || !field_vm || !dirs ||
             !out_rgb || !out_acc || !out_depth || (num_fine && !u_table))
@@ -1074,7 +1089,7 @@ int tn_render_rays(tn_mlp_t mlp, uint32_t M, const uint32_t *num_visited, const 
         tn::launch_render_rays(num_visited, hit_distances, barycentric, vertex_indices, M, ray_index, count, num_hit_rays_max, num_samples,
                                num_fine, biased != 0, linspace, u_table, histogram_padding, eps, field_vm, dirs, ray_head_bias, m->packs(0),
                                background_of(background), out_rgb, out_acc, out_depth, m->render_scratch.p, L, grid, (hipStream_t)stream_,
-                               profile ? m->render_prof.p : nullptr);
+                               profile ? m->render_prof.p : nullptr, mode);
         TN_HIP(hipGetLastError());
         if (profile) {
             unsigned long long h[8];

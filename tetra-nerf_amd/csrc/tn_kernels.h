@@ -209,14 +209,15 @@ void launch_transpose(const float *in, float *out, uint32_t rows, uint32_t cols,
 // MLP (density) -> weights -> PDF sampler -> match -> gather + MLP + heads -> composite, scattered into out_* (arrays over ALL rays)
 // at the hitting rays ray_index[0 .. *count) (count null: r_max); S_fine = 0: one pass.  dirs [R_all, 3], ray_bias [R_all, 128] or
 // null are indexed by ray.  scratch: render_rays_scratch_floats(...) floats, laid out by the RenderRaysLayout it fills.
-struct RenderRaysLayout { uint32_t T; size_t per_block, o_edges_f, o_hterm, o_vi, o_bc, o_sigma, o_rgb; };
+struct RenderRaysLayout { uint32_t T; size_t per_block, o_edges_f, o_hterm, o_vi, o_bc, o_sigma, o_rgb, o_enc; };
 size_t render_rays_scratch_floats(size_t r_max, uint32_t S, uint32_t S_fine, bool has_bias, unsigned grid, RenderRaysLayout &L);
 void launch_render_rays(const uint32_t *num_visited, const float *dist, const float *bary, const uint32_t *verts, uint32_t M,
                         const uint32_t *ray_index, const uint32_t *count, size_t r_max, uint32_t S, uint32_t S_fine, bool biased,
                         const float *lin, const float *u_table, float hist_pad, float eps, const float *fieldT, const float *dirs,
                         const float *ray_bias, const MlpPacks &w, Background background, float *out_rgb, float *out_acc, float *out_depth,
                         float *scratch, const RenderRaysLayout &L, unsigned grid, hipStream_t stream,
-                        unsigned long long *prof = nullptr /* [8] debug: 100 MHz ticks per phase kind, summed over blocks */);
+                        unsigned long long *prof = nullptr /* [8] debug: 100 MHz ticks per phase kind, summed over blocks */,
+                        int mode = 0 /* 0: fp32 MFMA, 1: bf16x3 (the MLP phases run x3::forward_group) */);
 // ray samplers (tn_samplers.hip): one wavefront per hitting ray, trace rows read in place through ray_index
 // count (nullable, every launcher below): the number of hitting rays lives on the device; r / R is the upper bound the grid is sized for
 void launch_sample_coarse(size_t r, uint32_t S, uint32_t M, const uint32_t *ray_index, const uint32_t *num_visited, const float *hit_dist,

@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "tn_mlp_fwd.h"
+#include "tn_mlp_x3_fwd.h"
 #include "tn_ray_ops.h"
 
 namespace tn {
@@ -66,13 +67,14 @@ struct RenderRaysParams {
     const float *ray_bias;         // [R_all, 128] or null
     const float *wenc;             // [128][28] the direction encoding's columns of mlp_head (head_ray_term)
     const float *pk;               // packed weights (gather order)
+    const uint4 *blob;             // bf16x3 mode (round 6): k_mlp_pack_x3's weight pieces
     Background bg;
     float *out_rgb, *out_acc, *out_depth;   // [R_all, 3], [R_all], [R_all]: written at the ray's own row
     // per-block scratch (global memory), offsets in floats
     float *scratch;
     size_t per_block;
     uint32_t T;                    // tile capacity in rays
-    size_t o_edges_f, o_hterm, o_vi, o_bc, o_sigma, o_rgb;   // (edges_c at 0)
+    size_t o_edges_f, o_hterm, o_vi, o_bc, o_sigma, o_rgb, o_enc;   // (edges_c at 0; o_enc: bf16x3 mode, [T][32] direction encodings)
     uint32_t region;               // floats of LDS per wave for the ray phases
     unsigned long long *prof;      // [8] DIAG builds only (TETRANERF_HIP_RENDER_PROFILE=1): 100 MHz ticks per phase kind, summed over blocks
 };
@@ -261,7 +263,10 @@ __device__ __forceinline__ void wave_global_sync() {
 // and barriers per sample) lost more than the overlap gained: 3.6 % behind the kernel chain instead of 1.3 %.
 constexpr int RR_BLOCK = MLP_BLOCK;
 
-template <bool FINE>
+// X3 (round 6): the MLP phases in the bf16x3 arithmetic (x3::forward_group, the loop body of k_mlp_forward_x3: same bits as the
+// bf16x3 kernel chain).  The head layer of that arithmetic takes the direction encoding as two k-steps of its GEMM, not as a
+// per-ray term, so ray phase 1 leaves the ray's 32-float encoding (and its appearance bias row, if any) in the tile's scratch.
+template <bool FINE, bool X3>
 __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
@@ -283,6 +288,7 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
     float *edges_c = sc, *edges_f = sc + p.o_edges_f, *hterm = sc + p.o_hterm;
     uint32_t *vi = reinterpret_cast<uint32_t *>(sc + p.o_vi);
     float *bc = sc + p.o_bc, *sigma = sc + p.o_sigma, *rgb = sc + p.o_rgb;
+    float *enc_t = sc + p.o_enc;                            // X3: [T][32]
     float *wl = lds + (size_t)wave * p.region;              // this wave's LDS for the ray phases (aliases the weight stage)
 
     const uint32_t nrays = (uint32_t)(q1 - q0);
@@ -330,12 +336,21 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
             // the head layer's per-ray term: Wh[:, :27] enc(dir) + the appearance embedding's bias (k_head_ray_term's expression)
             ray_dir_encoding(p.dirs + 3 * ray, wl, lane);   // (28 floats of the wave's LDS: the sampler is done with `cum`)
             lds_sync();
+            if constexpr (X3) {
+                // the encoding itself, padded to 32 (k_dir_encoding32's layout), and the ray's bias row
+                if (lane < 32) enc_t[(size_t)t * 32 + lane] = lane < 27 ? wl[lane] : 0.f;
+                if (p.ray_bias) {
+                    hterm[(size_t)t * HID + lane] = p.ray_bias[ray * HID + lane];
+                    hterm[(size_t)t * HID + 64 + lane] = p.ray_bias[ray * HID + 64 + lane];
+                }
+            } else {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int o = lane + 64 * half;
-                float tv = head_ray_term(p.wenc + o * ENC_PAD, wl);
-                if (p.ray_bias) tv += p.ray_bias[ray * HID + o];
-                hterm[(size_t)t * HID + o] = tv;
+                for (int half = 0; half < 2; ++half) {
+                    const int o = lane + 64 * half;
+                    float tv = head_ray_term(p.wenc + o * ENC_PAD, wl);
+                    if (p.ray_bias) tv += p.ray_bias[ray * HID + o];
+                    hterm[(size_t)t * HID + o] = tv;
+                }
             }
             lds_sync();
             if (S <= 256) ray_match<4>(S, M, ray, nv, p, el, vi + 4 * (size_t)t * S, bc + 3 * (size_t)t * S, wl, wl + M, lane, dv);
@@ -348,7 +363,8 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
             {
                 const size_t n = (size_t)nt * S, ngroups = (n + GROUP - 1) / GROUP;
                 for (size_t g = 0; g < ngroups; ++g)
-                    mlp_forward_group<true, true, RR_BLOCK, false>(lds, g, n, S, nullptr, vi, bc, p.fieldT, nullptr, p.pk, sigma, nullptr,
+if constexpr (X3) x3::forward_group<true, true>(reinterpret_cast<uint4 *>(lds), g, n, S, nullptr, vi, bc, p.fieldT, nullptr, p.blob, sigma, nullptr, nullptr);
+                    else                     mlp_forward_group<true, true, RR_BLOCK, false>(lds, g, n, S, nullptr, vi, bc, p.fieldT, nullptr, p.pk, sigma, nullptr,
                                                                    FwdSave{});
             }
             __syncthreads();
@@ -383,7 +399,9 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void k_render_rays(RenderRaysParams p)
         {
             const size_t n = (size_t)nt * Sf, ngroups = (n + GROUP - 1) / GROUP;
             for (size_t g = 0; g < ngroups; ++g)
-                mlp_forward_group<true, false, RR_BLOCK, false>(lds, g, n, Sf, nullptr, vi, bc, p.fieldT, hterm, p.pk, sigma, rgb, FwdSave{});
+                if constexpr (X3) x3::forward_group<true, false>(reinterpret_cast<uint4 *>(lds), g, n, Sf, nullptr, vi, bc, p.fieldT, enc_t, p.blob, sigma, rgb,
+                                                                 p.ray_bias ? hterm : nullptr);
+                else mlp_forward_group<true, false, RR_BLOCK, false>(lds, g, n, Sf, nullptr, vi, bc, p.fieldT, hterm, p.pk, sigma, rgb, FwdSave{});
         }
         __syncthreads();
         tick(3);
@@ -405,7 +423,7 @@ size_t render_rays_scratch_floats(size_t r_max, uint32_t S, uint32_t S_fine, boo
     auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };   // 256-byte aligned pieces (and blocks): a group's 4 KB of vertex ids start on a line
     const uint32_t nb = S_fine + 1;
     const uint32_t Sf = S_fine ? S + nb : S;
-    const size_t per_ray = (size_t)(S + 1) + (S_fine ? (size_t)(Sf + 1) : 0) + HID + (size_t)Sf * 11;
+    const size_t per_ray = (size_t)(S + 1) + (S_fine ? (size_t)(Sf + 1) : 0) + HID + 32 + (size_t)Sf * 11;
     const size_t rays_per_block = (r_max + grid - 1) / grid;
     // Scratch budget per block = tile size.  Measured (profiles/r05k_scratch_sweep.txt): a chip-wide working set of 256 x 4 MB
     // costs the coarse-only render 1.4 % against 256 x 0.5 MB (address translation: 256 private windows), but small tiles end in
@@ -427,6 +445,7 @@ size_t render_rays_scratch_floats(size_t r_max, uint32_t S, uint32_t S_fine, boo
     L.o_bc = o; o = al(o + T * Sf * 3);
     L.o_sigma = o; o = al(o + T * Sf);
     L.o_rgb = o; o = al(o + T * Sf * 3);
+    L.o_enc = o; o = al(o + T * 32);                      // (bf16x3 mode)
     L.per_block = o;
     return o * grid;
 }
@@ -435,7 +454,7 @@ void launch_render_rays(const uint32_t *num_visited, const float *dist, const fl
                         const uint32_t *ray_index, const uint32_t *count, size_t r_max, uint32_t S, uint32_t S_fine, bool biased,
                         const float *lin, const float *u_table, float hist_pad, float eps, const float *fieldT, const float *dirs,
                         const float *ray_bias, const MlpPacks &w, Background background, float *out_rgb, float *out_acc, float *out_depth,
-                        float *scratch, const RenderRaysLayout &L, unsigned grid, hipStream_t stream, unsigned long long *prof) {
+                        float *scratch, const RenderRaysLayout &L, unsigned grid, hipStream_t stream, unsigned long long *prof, int mode) {
     if (r_max == 0) return;
     const uint32_t nb = S_fine + 1;
     // per wave: phase 1 = [tin / pmax (or the biased sampler's cum): 2 M][coarse edges: S + 1]; phase 2 = [coarse weights |
@@ -443,7 +462,7 @@ void launch_render_rays(const uint32_t *num_visited, const float *dist, const fl
     const size_t w_fl = ((size_t)S + 3) & ~(size_t)3;
     const size_t region = (std::max<size_t>(phase1_edges_offset(M) + (S + 1), S_fine ? std::max<size_t>(2 * (size_t)M, w_fl + pdf_lds_floats(S, nb)) +
                                                                                   (size_t)S + nb + 1 : 0) + 3) & ~(size_t)3;
-    const size_t lds_floats = std::max<size_t>(MAX_STAGE_FLOATS, (RR_BLOCK / 64) * region);
+    const size_t lds_floats = std::max<size_t>(mode ? 4 * x3::MAX_STAGE_U4 : MAX_STAGE_FLOATS, (RR_BLOCK / 64) * region);
     const size_t smem = lds_floats * sizeof(float);
     if (smem > 160 * 1024) throw Error("render_rays: max_ray_triangles / samples per ray too large for the per-wave LDS regions");
     RenderRaysParams p{};
@@ -456,16 +475,24 @@ void launch_render_rays(const uint32_t *num_visited, const float *dist, const fl
     p.out_rgb = out_rgb; p.out_acc = out_acc; p.out_depth = out_depth;
     p.scratch = scratch; p.per_block = L.per_block; p.T = L.T;
     p.o_edges_f = L.o_edges_f; p.o_hterm = L.o_hterm; p.o_vi = L.o_vi; p.o_bc = L.o_bc;
-    p.o_sigma = L.o_sigma; p.o_rgb = L.o_rgb;
+    p.o_sigma = L.o_sigma; p.o_rgb = L.o_rgb; p.o_enc = L.o_enc;
+    p.blob = w.blob;
     p.region = (uint32_t)region;
     p.prof = DIAG ? prof : nullptr;
     static PerDeviceOnce lds_attr;
     lds_attr.run([&] {
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<false>), 160 * 1024);
-        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<true>), 160 * 1024);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<false, false>), 160 * 1024);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<true, false>), 160 * 1024);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<false, true>), 160 * 1024);
+        allow_dynamic_lds(reinterpret_cast<const void *>(k_render_rays<true, true>), 160 * 1024);
     });
-    if (S_fine) hipLaunchKernelGGL(k_render_rays<true>, dim3(grid), dim3(RR_BLOCK), smem, stream, p);
-    else hipLaunchKernelGGL(k_render_rays<false>, dim3(grid), dim3(RR_BLOCK), smem, stream, p);
+    if (mode) {
+        if (S_fine) hipLaunchKernelGGL((k_render_rays<true, true>), dim3(grid), dim3(RR_BLOCK), smem, stream, p);
+        else hipLaunchKernelGGL((k_render_rays<false, true>), dim3(grid), dim3(RR_BLOCK), smem, stream, p);
+        return;
+    }
+    if (S_fine) hipLaunchKernelGGL((k_render_rays<true, false>), dim3(grid), dim3(RR_BLOCK), smem, stream, p);
+    else hipLaunchKernelGGL((k_render_rays<false, false>), dim3(grid), dim3(RR_BLOCK), smem, stream, p);
 }
 
 }  // namespace tn

@@ -420,9 +420,10 @@ class TetraRenderer:
         return background if isinstance(background, (int, float)) else tuple(float(x) for x in background_tensor(background).tolist())
 
     def _one_launch_ok(self, mode):
-        """tn_render_rays' preconditions: fp32 arithmetic, device samplers, the per-wave LDS regions of its ray phases fit."""
-        region = max(2 * self.M + self.S + 1, (max(2 * self.M, 3 * self.S + self.S_fine + 6) + 2 * self.S + self.S_fine + 2) if self.S_fine else 0) + 4
-        return (self.fused_pass is not False and mode == "fp32" and self.device_samplers and 8 * 4 * region <= 160 * 1024
+        """tn_render_rays' preconditions: device samplers, the per-wave LDS regions of its ray phases fit (either arithmetic
+        since round 6: the bf16x3 mode runs x3::forward_group in the MLP phases)."""
+        region = max(max(2 * self.M, 28) + self.S + 1, (max(2 * self.M, 3 * self.S + self.S_fine + 6) + 2 * self.S + self.S_fine + 2) if self.S_fine else 0) + 4
+        return (self.fused_pass is not False and mode in ("fp32", "bf16x3") and self.device_samplers and 8 * 4 * region <= 160 * 1024
                 and self.S + self.S_fine + 2 <= 8192)
 
     @torch.no_grad()
@@ -464,7 +465,7 @@ class TetraRenderer:
         d = directions.contiguous()
         if self._one_launch_ok(mode):
             cpp.render_rays(lists, order, count, self.field, d, w, S, self.S_fine, self.biased, out=(rgb, acc, depth), background=bg,
-                            clamp=True, ray_head_bias=ray_head_bias)
+                            clamp=True, ray_head_bias=ray_head_bias, mode=mode)
             return res
         # the chain of separate kernels: each is launched over R rows and processes the first `count` of them
         order_l = order.long()

@@ -688,8 +688,8 @@ def _background(background, clamp=False):
 
 
 def render_rays(trace_lists, order, count, field, directions, weights, num_samples, num_fine=0, biased=False, out=None,
-                background=1.0, clamp=True, ray_head_bias=None, histogram_padding=0.01, eps=1e-5):
-    """Everything between trace_rays and the frame as ONE persistent launch (tn_render_rays): coarse sampler -> match -> gather
+                background=1.0, clamp=True, ray_head_bias=None, histogram_padding=0.01, eps=1e-5, mode="fp32"):
+    """Everything between trace_rays and the frame as ONE persistent launch (tn_render_rays_ex; mode "fp32" | "bf16x3"): coarse sampler -> match -> gather
     + MLP -> weights -> PDF sampler -> match -> gather + MLP + heads -> composite, for the hitting rays order[:count] (compact_hits)
     whose number stays on the device.  trace_lists as returned by trace_rays; directions f32 [R,3] and ray_head_bias f32 [R,128]
     over ALL rays; out = (rgb [R,3], accumulation [R,1] or [R], depth) pre-filled with the background values."""
@@ -714,10 +714,10 @@ def render_rays(trace_lists, order, count, field, directions, weights, num_sampl
     if ray_head_bias is not None:
         hb = _ray_bias(ray_head_bias, R, dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().tn_render_rays(
+        _lib.check(_lib.load().tn_render_rays_ex(
             m.handle, M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(order), _ptr(count), order.numel(), S, Sf, 1 if biased else 0,
             _ptr(_linspace_table(S, dev)), _ptr(_quantile_table(Sf + 1, True, dev)) if Sf else None, float(histogram_padding), float(eps),
-            _ptr(field_vm), _ptr(directions), _background(background, clamp), _ptr(rgb), _ptr(acc), _ptr(depth), _ptr(hb), _stream(dev)))
+            _ptr(field_vm), _ptr(directions), _background(background, clamp), _ptr(rgb), _ptr(acc), _ptr(depth), _ptr(hb), _mode(mode), _stream(dev)))
 
 
 _TABLES = {}    # (kind, n, device) -> small constant tables of the samplers (the values the PyTorch statements use)
