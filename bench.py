@@ -104,16 +104,19 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
     # the two shipped evaluation configs with the PDF fine pass (registration.py:55-57, model.py:78-80).  Per config:
     #   "fp32"               the DEFAULT renderer = everything after the trace as ONE persistent launch (tn_render_rays)
     #   "fp32_kernel_chain"  the same stages as separate kernels (sampler, matcher, gather + MLP, composite per pass): bit-identical frame
-    #   "bf16x3"             the kernel chain with the split-operand bf16 MFMA arithmetic (opt-in)
+    #   "bf16x3"             the one launch with the split-operand bf16 MFMA arithmetic in its MLP phases (opt-in; round 6)
+    #   "bf16x3_kernel_chain" the kernel chain in that arithmetic: bit-identical frame
     # none of them synchronises with the host (device-side compaction of the hitting rays)
     full = {}
     configs = (("coarse-256", (samples, 0, False)), ("tetra-nerf-original", (256, 256, False)), ("tetra-nerf", (128, 128, True)))
     for name, (s_c, s_f, biased) in configs:
         full[name] = {"samples_per_ray": f"{s_c} coarse" + (f" (density only) + {s_c + s_f + 1} fine" if s_f else "")}
-        for key, kw in (("fp32", {}), ("fp32_kernel_chain", dict(fused_pass=False)), ("bf16x3", dict(mlp_mode="bf16x3"))):
+        for key, kw in (("fp32", {}), ("fp32_kernel_chain", dict(fused_pass=False)), ("bf16x3", dict(mlp_mode="bf16x3")),
+                        ("bf16x3_kernel_chain", dict(mlp_mode="bf16x3", fused_pass=False))):
             dtf = timed(render.TetraRenderer(tracer, field, mlp, s_c, M, fused=True, num_fine_samples=s_f, biased=biased, **kw))
             full[name][key] = {"rendered_rays_per_s": R / dtf, "ms_per_frame": dtf * 1e3}
         full[name]["one_launch_over_chain"] = full[name]["fp32"]["ms_per_frame"] / full[name]["fp32_kernel_chain"]["ms_per_frame"]
+        full[name]["one_launch_over_chain_bf16x3"] = full[name]["bf16x3"]["ms_per_frame"] / full[name]["bf16x3_kernel_chain"]["ms_per_frame"]
     # MLP kernel alone on one chunk worth of samples of hitting rays (MFMA roofline)
     n = min(hit, chunk) * samples
     feats = torch.randn(64, n, device=dev)
@@ -661,7 +664,8 @@ def secondary_summary(line):
         sec["render"] = {"coarse_only_ms": _r(rn.get("ms_per_frame"), 2), "mlp_forward_frac": _r(_get(rn, "roofline_mlp", "frac"))}
         for k, v in (rn.get("eval_configs") or {}).items():
             sec["render"][k] = {"one_launch_ms": _r(_get(v, "fp32", "ms_per_frame"), 2), "chain_ms": _r(_get(v, "fp32_kernel_chain", "ms_per_frame"), 2),
-                                "bf16x3_ms": _r(_get(v, "bf16x3", "ms_per_frame"), 2), "one_launch_over_chain": _r(v.get("one_launch_over_chain"))}
+                                "bf16x3_ms": _r(_get(v, "bf16x3", "ms_per_frame"), 2), "bf16x3_chain_ms": _r(_get(v, "bf16x3_kernel_chain", "ms_per_frame"), 2),
+                                "one_launch_over_chain": _r(v.get("one_launch_over_chain")), "one_launch_over_chain_bf16x3": _r(v.get("one_launch_over_chain_bf16x3"))}
     if isinstance(line.get("sharded_render"), dict):
         sec["sharded_render"] = {"ms_per_frame": _r(line["sharded_render"].get("ms_per_frame"), 2),
                                  "all_gather_ms": _r(line["sharded_render"].get("all_gather_ms"))}

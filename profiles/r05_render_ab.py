@@ -29,7 +29,8 @@ field = ((torch.rand(64, len(pts), device=dev) * 2 - 1) * 1e-4)
 field[1:4] = torch.rand(3, len(pts), device=dev) * 2 - 1
 R, M = o.shape[0], 512
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 65536      # rays per render() call (nerfstudio's eval default: 4096)
-print(f"chunks of {chunk} rays")
+mode = sys.argv[3] if len(sys.argv) > 3 else "fp32"             # round 6: "bf16x3" runs both forms in that arithmetic
+print(f"chunks of {chunk} rays, mlp_mode {mode}")
 
 
 def frame(rd):
@@ -38,7 +39,7 @@ def frame(rd):
 
 
 for name, (s_c, s_f, biased) in (("coarse-256", (256, 0, False)), ("tetra-nerf-original", (256, 256, False)), ("tetra-nerf", (128, 128, True))):
-    rds = {k: render.TetraRenderer(tr, field, mlp, s_c, M, fused=True, num_fine_samples=s_f, biased=biased, fused_pass=fp)
+    rds = {k: render.TetraRenderer(tr, field, mlp, s_c, M, fused=True, num_fine_samples=s_f, biased=biased, fused_pass=fp, mlp_mode=mode)
            for k, fp in (("one_launch", True), ("chain", False))}
     for rd in rds.values():
         frame(rd)

@@ -16,10 +16,10 @@ lib = importlib.import_module("tetra-nerf_amd._lib").load()
 dev = torch.device("cuda:0")
 # (first run of the round, rules of round 5: gpurun_out/r06b_literal_reasons.txt had [2] = two short gaps at the entry face, [4] = short
 #  inverted as the first pair, [8] = inverted pair at the very end -- the three patterns rules A-C of round 6 certify)
-NAMES = ["literal rays", "short asc after an inverted pair", "short gap while an entry look-ahead is pending", "short inverted after a short gap",
-         "entry look-ahead unsettled at the end of the chain", "short inverted, face before within eps", "inverted by eps or more",
-         "long asc after an inverted pair, not clear", "inverted last pair of a 3-hit chain", "rays with exactly one violation",
-         "violations in total", "rays with an inversion >= eps", "hits of literal rays"]
+NAMES = ["literal rays", "joined a cluster while the entry look-ahead was pending", "eps or more below an earlier member of its cluster",
+         "inverted cluster of more than three hits", "inverted cluster within eps of the previous cluster", "inverted first cluster (beyond the pair of rule C)",
+         "entry look-ahead unsettled at the end of the chain", "inverted last cluster (not a pair / chain shorter than 4)", "(round 5 rules: any violation)",
+         "rays with exactly one violation", "violations in total", "-", "hits of literal rays"]
 for name, npts, seed in (("C2", 15000, 0), ("C4", 45000, 2), ("C5", 150000, 3)):
     pts, cells = scenes.random_mesh(npts, seed)
     tr = tn.TetrahedraTracer(dev)

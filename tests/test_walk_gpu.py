@@ -186,7 +186,7 @@ def test_literal_pairing_of_the_log_equals_bvh_fallback(tn, device, oracle, scen
 
 
 def test_end_of_chain_rules_agree_with_the_literal_kernel(tn, device, scenes, bottle):
-    """Round 6's rules A-C of the walk's order test (tn_trace_walk.hip header; tests/cert_model.py) certify rays that round 5
+    """Round 6's rules A-D of the walk's order test (tn_trace_walk.hip: struct OrderR6; tests/cert_model.py) certify rays that round 5
     handed to the literal pairing kernel: an inverted last pair, a run of short gaps at the entry face, an inverted first pair
     (whose second segment the reference loses: the writer's drop flag).  Option cert_ends = 0 restores round 5's rules, so the
     same rays come once from k_write_segments and once from k_postprocess_log -- two independent implementations -- and the

@@ -51,7 +51,15 @@
 //                    then finds no partner, so the reference emits NO segment for hit 2 although it is long: the ray is
 //                    certified with a flag that makes the segment writer drop that one segment (hit 2 clear of both by eps,
 //                    then two more long ascending gaps: the same look-ahead bound).
-//               Runs that contain an inversion are NOT certified: a face whose two chain neighbours both sort
+//                 D  (generalises the isolated inverted pair) a CLUSTER -- hits each less than eps above the largest t before
+//                    them -- that contains inversions is certified when it has at most THREE members, no member lies eps or
+//                    more below an earlier one and every member is at least eps above the previous cluster: for every sorted
+//                    order of such a triple the phases still emit exactly the chain pairs with a gap >= eps (exhaustive over the
+//                    orders + 350,000 random chains against the literal algorithm; the first counter-examples are 4-clusters in
+//                    which the first member sorts behind both of the last two -- the a-p-u-q-v-r-b example below is of that kind).
+//                 The device code is struct OrderR6 below (clusters); OrderR5 keeps round 5's pairwise statement for the
+//                 cross-check option cert_ends = 0.
+//               Larger clusters that contain an inversion are NOT certified: a face whose two chain neighbours both sort
 //               after it survives phase 1 inside the run, and the look-ahead of the run's last face can then
 //               stop short of its partner (worked example in DESIGN.md section 2).
 //   literal     the chain is sound but its order is not clean (an inversion inside a run of short gaps, an
@@ -175,10 +183,95 @@ __device__ __forceinline__ SV selsv(const SV &p0, const SV &p1, const SV &p2, co
 
 }  // namespace
 
+// ---- the ORDER TEST of the certification (header: "certified"), as a per-lane state machine over the recorded hits ----------
+// Two statements of it exist on purpose.  OrderR6 is the product (round 6: clusters; rules A-D); OrderR5 is round 5's pairwise
+// test (option cert_ends = 0): rays that R6 certifies and R5 does not come once from the segment writer and once from the literal
+// pairing kernel -- two independent implementations -- and must give identical rows (tests/test_walk_gpu.py).  Both are written as
+// selects: `vp` = this step recorded a hit and a previous one exists, `start` = this step recorded the ray's first hit.
+namespace {
+struct OrderR5 {
+    bool ok = true, have_pp = false, prev_short = false, prev_inv = false;
+    float ppt = 0.f;
+    __device__ __forceinline__ uint32_t step(bool valid, bool have_prev, float pt, float ct, bool tie_asc, uint32_t nhits) {
+        const bool vp = valid && have_prev;
+        const bool is_short = fabsf(pt - ct) < TN_EPS;
+        const bool asc = (ct > pt) || (ct == pt && tie_asc);
+        const bool clear2 = ct - ppt >= TN_EPS;
+        // short + ascending: any run of them is fine (header), except a run that starts at the entry hull face (pairs 1 and 2 both
+        // short: nhits == 2 here); short + inverted: isolated and clear of the face before; after an inverted pair: a long gap,
+        // clear of both of its members
+        const bool good = is_short ? (asc ? (!prev_inv && !(prev_short && nhits == 2u)) : (!prev_short && have_pp && clear2))
+                                   : (asc && (!prev_inv || clear2));
+        ok = ok && (!vp || good);
+        prev_inv = vp ? (is_short && !asc) : prev_inv;
+        prev_short = vp ? is_short : prev_short;
+        have_pp = valid ? have_prev : have_pp;
+        ppt = valid ? pt : ppt;
+        return (vp && !good) ? 1u : 0u;
+    }
+    __device__ __forceinline__ bool finish(uint32_t) const { return ok && !prev_inv; }   // a pair inverted at the very end: not certified
+    __device__ __forceinline__ bool drop2() const { return false; }
+    __device__ __forceinline__ uint32_t end_reason() const { return 8u; }
+};
+
+// Round 6: the same test on CLUSTERS.  A hit joins the current cluster iff it is less than eps above the cluster's largest t
+// (so a new cluster starts with a gap of at least eps above EVERY member of the old one).  tests/cert_model.py is this state
+// machine in Python, statement for statement; tests/test_certification_rules.py checks it against the literal algorithm.
+//   * a cluster WITHOUT an inversion is an ascending run of short gaps: any length (header proof);
+//   * a cluster WITH an inversion (adjacent hits in the wrong sorted order, exact ties by face id) is certified iff it has at most
+//     THREE members, no member lies eps or more below an earlier one, and every member is at least eps above the previous
+//     cluster (rule D; 2 members = round 2's isolated inverted pair).  Exhaustive over the sorted orders of isolated 3-clusters
+//     and Monte-Carlo over 350,000 chains: the reference's phases then still emit exactly the chain pairs with a gap >= eps; the
+//     first failures are 4-clusters in which the FIRST member sorts behind both of the last two;
+//   * the ENDS of the chain: A an inverted PAIR as the last cluster of a chain of >= 4 hits; B an ascending first cluster of >= 3
+//     hits when two long gaps follow; C the first cluster = an inverted pair: the reference loses the segment of hit 2 (drop2),
+//     three long gaps must follow.  `pend` is the entry face's look-ahead: 0 none | 1 inside B's run | 2 one more long gap needed |
+//     3 C: hit 2 pending | 4 two more long gaps needed; a hit that JOINS a cluster while pend >= 2 ends the certification.
+struct OrderR6 {
+    bool ok = true, cinv = false, cfirst = false, d2 = false;
+    uint32_t cn = 0, pend = 0;
+    float cmax = 0.f, prev_cmax = 0.f;
+    __device__ __forceinline__ uint32_t step(bool valid, bool have_prev, float pt, float ct, bool tie_asc, uint32_t) {
+        const bool vp = valid && have_prev, start = valid && !have_prev;
+        const bool joins = !(ct - cmax >= TN_EPS);
+        const bool asc = (ct > pt) || (ct == pt && tie_asc);
+        const bool vj = vp && joins, vn = vp && !joins;
+        const bool long_inv = cmax - ct >= TN_EPS;
+        const bool cinv_n = cinv || !asc;
+        const uint32_t cn_n = cn + 1u;
+        const bool inv_ok = !long_inv && (cfirst ? cn_n == 2u : (cn_n <= 3u && ct - prev_cmax >= TN_EPS));
+        const bool good = pend < 2u && (!cinv_n || inv_ok);
+        ok = ok && (!vj || good);
+        const bool rule_c = vj && cinv_n && cfirst && cn_n == 2u;
+        const bool rule_b = vj && !cinv_n && cfirst && cn_n == 3u;
+        d2 = d2 || rule_c;
+        const uint32_t pend_new_cluster = (0x2810u >> (3u * pend)) & 7u;        // 0 2 0 4 2
+        const uint32_t pend_old = pend;
+        pend = vj ? (rule_c ? 3u : (rule_b ? 1u : pend)) : (vn ? pend_new_cluster : pend);
+        const uint32_t why = (vj && !good) ? (pend_old >= 2u ? 1u : (long_inv ? 2u : (cfirst ? 5u : (cn_n > 3u ? 3u : 4u)))) : 0u;
+        const bool fresh = vn || start;
+        prev_cmax = vn ? cmax : prev_cmax;
+        cmax = vj ? fmaxf(cmax, ct) : (fresh ? ct : cmax);
+        cn = vj ? cn_n : (fresh ? 1u : cn);
+        cinv = vj ? cinv_n : (fresh ? false : cinv);
+        cfirst = start ? true : (vn ? false : cfirst);
+        // (`why`, diagnostic builds: 1 joined while the entry look-ahead was pending | 2 eps or more below an earlier member | 3
+        //  inverted cluster of more than three | 4 inverted cluster within eps of the previous one | 5 inverted first cluster)
+        return why;
+    }
+    __device__ __forceinline__ bool finish(uint32_t nhits) const {
+        return ok && pend == 0u && (!cinv || (!cfirst && cn == 2u && nhits >= 4u));
+    }
+    __device__ __forceinline__ bool drop2() const { return d2; }
+    __device__ __forceinline__ uint32_t end_reason() const { return pend ? 6u : 7u; }   // look-ahead unsettled | inverted last cluster
+};
+}  // namespace
+
 // The walk runs on entry-face-specialised records (WalkVar, tn_common.h): nothing of the entry face is permuted
 // or recomputed, one vertex is sheared per step, three edge functions against it decide the exit, and the exit
 // face's edge functions are evaluated directly in its stored order (E(P,Q) == -E(Q,P) bitwise, so they equal the
 // shared ones): bit-identical hits for 30 % fewer instructions than a per-tet record with dynamic selects.
+template <typename Order>
 __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     const TraceParams &t = p.t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -303,19 +396,13 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         if (fabsf(A.x) + fabsf(A.y) < pad || fabsf(B.x) + fabsf(B.y) < pad || fabsf(C.x) + fabsf(C.y) < pad) { flag = true; why = 4; alive = false; }
     }
     float Uc = edge_f(B, C), Vc = edge_f(C, A), Wc = edge_f(A, B);
-    bool have_prev = false, have_pp = false;  // one / two valid hits have been recorded
-    bool order_ok = true;     // the order of the hits so far is "clean" (header)
-    bool prev_short = false, prev_inv = false;  // the previous pair was closer than eps / and inverted
-    // round 6 (rules A-C of the header; tests/cert_model.py states them, tests/test_certification_rules.py checks them against
-    // the literal algorithm): look-ahead state of the ENTRY face -- 0 none | 1 inside a run of short gaps at the entry | 2 one more
-    // long gap needed | 3 first pair inverted, hit 2 pending | 4 two more long gaps needed -- and "the segment of hit 2 is lost"
-    uint32_t pend = 0;
-    bool drop2 = false;
-    float pt = 0.f, ppt = 0.f;  // t of the previous recorded hit and of the one before
+    bool have_prev = false;   // a valid hit has been recorded
+    Order ord;                // the order test (OrderR6; OrderR5 with option cert_ends = 0)
+    float pt = 0.f;           // t of the previous recorded hit
     uint32_t nhits = 0, nshort = 0;
     uint32_t steps = 0;
 #if TN_WALK_DIAG
-    uint32_t lit_why = 0, n_viol = 0, n_inv_long = 0;
+    uint32_t lit_why = 0, n_viol = 0;
 #endif
     Var cur = load_var(p.vars, c);
     if (alive && ((cur.code_hi >> 8) & 0xFFu) <= thin_exp) {
@@ -327,6 +414,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         // the entry hull face itself may be the first recorded hit (exit code 3 = "hull face id in the low bits")
         float tt, uu, vv;
         if (tri_finish(Uc, Vc, Wc, A.z, B.z, C.z, tt, uu, vv)) {
+            ord.step(true, false, 0.f, tt, false, 0u);
             have_prev = true; pt = tt; nhits = 1;
             mylog[0] = make_uint4(__float_as_uint(tt), __float_as_uint(uu), __float_as_uint(vv), f_in0 | (3u << 30));
         }
@@ -372,43 +460,18 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         float ct = 0.f, cu = 0.f, cv = 0.f;
         const bool valid = tri_finish(U, V, W, A2.z, B2.z, C2.z, ct, cu, cv);
 
-        // order of the pair (previous hit, this hit); see "certified" in the header
+        // order of the pair (previous hit, this hit); see "certified" in the header.  Sorted order of the two = chain order; an
+        // exact tie in t is ordered by face id: the previous recorded hit is this tet's entry face, and "id of exit x > id of the
+        // entry face" is bit 16 + x of the record's code_hi
         {
-            const bool vp = valid && have_prev;
-            const bool is_short = fabsf(pt - ct) < TN_EPS;
-            // sorted order of the two = chain order; an exact tie in t is ordered by face id: the previous recorded hit is
-            // this tet's entry face, and "id of exit x > id of the entry face" is bit 16 + x of the record's code_hi
-            const bool asc = (ct > pt) || (ct == pt && ((cur.code_hi >> (16u + x)) & 1u) != 0);
-            const bool clear2 = ct - ppt >= TN_EPS;
-            // short + ascending: any run of them is fine (header) -- a run that starts at the entry face (pairs 1 and 2 both
-            // short: nhits == 2 here) only if two long gaps follow it (rule B); short + inverted: isolated and clear of the face
-            // before -- as the FIRST pair: the segment of hit 2 is lost, three clear long gaps must follow (rule C); after an
-            // inverted pair: a long gap, clear of both of its members
-            const bool pend_wait = pend >= 2u;
-            const bool first_inv = is_short && !asc && !have_pp;
-            const bool entry_run = is_short && asc && prev_short && nhits == 2u;
-            const bool ok = (is_short ? (!pend_wait && (asc ? !prev_inv : (!have_pp || (!prev_short && clear2))))
-                                      : (asc && (!prev_inv || clear2))) &&
-                            (p.cert_ends || !(entry_run || first_inv));            // (cert_ends = 0: round 5's rules)
-            const uint32_t pend_long = (0x2810u >> (3u * pend)) & 7u;               // on a long gap: 0 2 0 4 2
-            const uint32_t pend_next = is_short ? (entry_run ? 1u : (first_inv ? 3u : pend)) : pend_long;
-            pend = vp ? pend_next : pend;
-            drop2 = drop2 || (vp && first_inv);
-            order_ok = order_ok && (!vp || ok);
+            const uint32_t viol = ord.step(valid, have_prev, pt, ct, ((cur.code_hi >> (16u + x)) & 1u) != 0, nhits);
 #if TN_WALK_DIAG
-            if (vp && !ok) {
-                // 1 short asc after an inverted pair | 2 short gap while an entry look-ahead is pending | 3 short inverted after a
-                // short gap | 5 short inverted, the face before within eps | 6 inverted by eps or more | 7 long asc after an
-                // inverted pair, not clear of it
-                const uint32_t r = is_short ? (pend_wait ? 2u : (asc ? 1u : (prev_short ? 3u : 5u))) : (asc ? 7u : 6u);
-                lit_why = lit_why ? lit_why : r;
-                n_viol++;
-                n_inv_long += r == 6u ? 1u : 0u;
-            }
+            lit_why = lit_why ? lit_why : viol;
+            n_viol += viol ? 1u : 0u;
+#else
+            (void)viol;
 #endif
-            nshort += (vp && is_short) ? 1u : 0u;
-            prev_inv = vp ? (is_short && !asc) : prev_inv;
-            prev_short = vp ? is_short : prev_short;
+            nshort += (valid && have_prev && fabsf(pt - ct) < TN_EPS) ? 1u : 0u;
         }
         bad = (!bad && !valid && have_prev) ? 10u : bad;        // the hit list is not a suffix of the chain
         bad = (!bad && valid && nhits >= M - 1) ? 9u : bad;     // more than M-1 faces
@@ -424,8 +487,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
             mylog[(size_t)slot_k * 64] = make_uint4(__float_as_uint(ct), __float_as_uint(cu), __float_as_uint(cv), c | (x << 30));
         }
         nhits += valid ? 1u : 0u;
-        have_pp = valid ? have_prev : have_pp;
-        ppt = valid ? pt : ppt;
         pt = valid ? ct : pt;
         have_prev = have_prev || valid;
         // the chain must end in the other crossed hull face: its t was computed by the hull search with the same expression
@@ -444,9 +505,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     }
 
     // ------------------------------------------------------------------ classes, hand-over lists, hit counts
-    // rule A: an isolated inverted pair at the very end of a chain of >= 4 hits needs no following face (with 3 hits the entry hull
-    // face would look ahead straight at the exit hull face); rules B / C: the entry face's look-ahead must have been settled
-    order_ok = order_ok && pend == 0u && !(prev_inv && (nhits < 4u || !p.cert_ends));
+    const bool order_ok = ord.finish(nhits);
+    const bool drop2 = ord.drop2();
     // every consecutive pair that is not short (rule C: minus the segment of hit 2, which the reference loses)
     const uint32_t nseg = nhits ? nhits - 1 - nshort - (drop2 ? 1u : 0u) : 0;
     const uint32_t wflag = drop2 ? 1u : 0u;
@@ -459,10 +519,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         } else if (!order_ok) {
 #if TN_WALK_DIAG
             atomicAdd(&g_walk_diag[0], 1ull);
-            atomicAdd(&g_walk_diag[lit_why ? lit_why : (pend ? 4u : 8u)], 1ull);   // 4: entry look-ahead unsettled at the end | 8: inverted last pair of a 3-hit chain
+            atomicAdd(&g_walk_diag[lit_why ? lit_why : ord.end_reason()], 1ull);
             atomicAdd(&g_walk_diag[9], n_viol == 1 ? 1ull : 0ull);                 // rays with exactly one violation
             atomicAdd(&g_walk_diag[10], (unsigned long long)n_viol);               // violations in total
-            atomicAdd(&g_walk_diag[11], n_inv_long ? 1ull : 0ull);                 // rays with an inversion by eps or more
             atomicAdd(&g_walk_diag[12], (unsigned long long)nhits);               // hits of literal rays
 #endif
             if (t.stats) atomicAdd(&t.stats[4 + 7], 1ull);
@@ -861,7 +920,8 @@ void launch_trace_walk(const WalkParams &p, hipStream_t stream, size_t lds_reser
     const uint32_t unit = 8 * XCD_GROUP;
     const uint32_t grid = (nblk + unit - 1) / unit * unit;
     if (lds_reserve > 64 * 1024) lds_reserve = 64 * 1024;
-    hipLaunchKernelGGL(k_trace_walk, dim3(grid), dim3(WALK_BLOCK), lds_reserve, stream, p);
+    if (p.cert_ends) hipLaunchKernelGGL(k_trace_walk<OrderR6>, dim3(grid), dim3(WALK_BLOCK), lds_reserve, stream, p);
+    else hipLaunchKernelGGL(k_trace_walk<OrderR5>, dim3(grid), dim3(WALK_BLOCK), lds_reserve, stream, p);
 }
 
 }  // namespace tn
