@@ -101,16 +101,20 @@ def _frame(scenes, width=800, height=800):
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs
-def test_c2_full_bench_frame_bit_exact(tn, device, oracle, scenes):
-    """configs[1]: the exact bench.py workload, all 640,000 rays, M = 512, default path selection."""
+@pytest.mark.parametrize("order_test", ["default", "clusters"])
+def test_c2_full_bench_frame_bit_exact(tn, device, oracle, scenes, order_test):
+    """configs[1]: the exact bench.py workload, all 640,000 rays, M = 512, default path selection -- with the order test the
+    tracer picks for this mesh size (round 5's pairwise test below 500k tets) and with round 6's cluster test forced (rules A-D:
+    2,500 more of the frame's rays come from the segment writer instead of the literal kernel)."""
     pts, cells = _mesh(scenes, 15000, 0, "C2")
     o, d = _frame(scenes)
-    tr = _tracer(tn, device, pts, cells, walk=1)
+    tr = _tracer(tn, device, pts, cells, walk=1, **({"cert_ends": 1} if order_test == "clusters" else {}))
     out = _trace(tr, device, o, d, 512)
-    st = tr.trace_stats()
+    st, why = tr.trace_stats(), tr.flag_reasons()
     assert st["walk"] > 0.97 * len(o), st
+    assert (why.get(13, 0) < 1000) == (order_test == "clusters"), why       # literal rays: ~500 with the cluster test, ~3,000 without
     _cross_check_clean(tr, len(o), "C2 frame")
-    total = _compare(out, _oracle(oracle, pts, cells), o, d, 512, ctx="C2 frame")
+    total = _compare(out, _oracle(oracle, pts, cells), o, d, 512, ctx=f"C2 frame ({order_test})")
     assert total == int(out["num_visited_cells"].sum()) and total > 25_000_000
 
 
@@ -122,12 +126,15 @@ def test_c4_frame_and_training_batches_bit_exact(tn, device, oracle, scenes):
     ot = _oracle(oracle, pts, cells)
     tr = _tracer(tn, device, pts, cells, walk=1)
     o, d = _frame(scenes)
-    out = _trace(tr, device, o, d, 512)
-    st = tr.trace_stats()
-    assert st["walk"] > 0.93 * len(o), st
-    _cross_check_clean(tr, len(o), "C4 frame")
-    _compare(out, ot, o, d, 512, ctx="C4 frame")
-    del out
+    for ends in (2, 1):                 # the order test picked by mesh size (pairwise here), then round 6's cluster test forced
+        tr.set_option("cert_ends", ends)
+        out = _trace(tr, device, o, d, 512)
+        st = tr.trace_stats()
+        assert st["walk"] > 0.93 * len(o), st
+        _cross_check_clean(tr, len(o), "C4 frame")
+        _compare(out, ot, o, d, 512, ctx=f"C4 frame cert_ends={ends}")
+        del out
+    tr.set_option("cert_ends", 2)
     for name, (bo, bd) in (("outside-in", scenes.outside_in_rays(4096, 1)), ("inside-out", scenes.inside_out_rays(4096, 2))):
         for walk in (1, 2):
             tr.set_option("walk", walk)
@@ -340,11 +347,11 @@ def test_speculative_fill_is_overwritten_by_every_ray_class(tn, device, oracle, 
     assert len(long_rays) > 10000
     # every class of the walk occurs among the rays that reach into the speculatively filled quarter
     tr = _tracer(tn, device, pts, cells, walk=2)
+    tr.set_option("cert_ends", 0)       # round 5's order rules: 200+ of these rays are literal (round 6's rules A-D leave a dozen)
     _trace(tr, device, np.ascontiguousarray(o[long_rays]), np.ascontiguousarray(d[long_rays]), M)
     st, why = tr.trace_stats(), tr.flag_reasons()
-    # (round 6: rules A-C of the order test certify most of what used to be literal here -- 45 rays are left; the second pass runs
-    #  round 5's rules, under which 200+ of these rays go through the literal kernel)
-    assert st["walk"] > 1000 and why.get(13, 0) > 20 and sum(v for k, v in why.items() if k in (1, 2, 3, 4, 5, 6, 9, 10, 11)) > 50, (st, why)
+    tr.set_option("cert_ends", 1)
+    assert st["walk"] > 1000 and why.get(13, 0) > 50 and sum(v for k, v in why.items() if k in (1, 2, 3, 4, 5, 6, 9, 10, 11)) > 50, (st, why)
     for k0, ends in ((0, 1), (64, 1), (32, 1), (0, 0), (32, 0)):
         tr.set_option("spec_k0", k0)
         tr.set_option("cert_ends", ends)

@@ -89,7 +89,13 @@ struct tn_tracer {
     // instructions over a walk-built list of non-empty groups.  Alone it equals the grouped-store writer below (0.62 ms on the C2
     // frame), in the schedule it costs +3..6 %: it leaves the padding [n, ceil32(n)) to the tail fill, and a line written in part
     // by two kernels costs the fill 12-18 % (partial-line writes).  The tail fill BESIDE that writer: +17 % / +3 % / +0..6 %.
-    int cert_ends = 1;                   // rules A-C of the walk's order test (tn_trace_walk.hip header); 0: round 5's rules
+    // The walk's order test (tn_trace_walk.hip): 1 = round 6's cluster test (OrderR6: rules A-D certify 73-87 % of the rays round 5
+    // handed to the literal pairing), 0 = round 5's pairwise test (OrderR5), 2 = by mesh size (default).  Same rows either way (the
+    // literal kernel writes what the writer does not).  In-process sweeps on three boxes (profiles/r06l_sweep.txt, r06m_sweep*.txt,
+    // r06p_place_sweep.txt): the cluster test's extra state costs the frames +1.1..3.8 % (100k / 300k tets: 0.1-0.5 % of the rays
+    // are literal there and the walk is VALU-bound beside the speculative fill) and buys C5 -1.8..-3.5 % (1M tets: 9 % literal, the
+    // walk waits for fetches); at 6.7 M tets 27 % of a frame's rays were literal.  Hence OrderR6 from WALK_TET_MIN_TETS tets on.
+    int cert_ends = 2;
 
     tn::DevBuf<uint32_t> risk_list;      // certified rays inside the wide band of a certification guard (all cross-checked)
     bool verify_risk = true;             // option "verify_risk"
@@ -477,7 +483,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 w.risk_list = verify_risk ? t->risk_list.p : nullptr;
                 w.risk_count = t->risk_count();
                 w.risk_band = (float)t->risk_band;
-                w.cert_ends = t->cert_ends ? 1u : 0u;
+                w.cert_ends = (t->cert_ends == 2 ? t->mesh.T >= tn::WALK_TET_MIN_TETS : t->cert_ends != 0) ? 1u : 0u;
                 tn::launch_trace_walk(w, stream, walk_reserve);
                 if (t->verify_stride && !single) {  // chunked call: serially, before anything that reads walk_n / the fallback list
                     tn::launch_verify_counts(w.t, t->verify_stride, w.walk_n, w.fallback_list, w.fallback_count, base, stream, false,
@@ -561,7 +567,9 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 tn::launch_trace_general(p, s_aux);
                 mark();                                                   // 3: BVH re-trace of the fallback rays
                 if (t->verify_stride) {
-                    // the count cross-check beside the writer and the fill (late form): mismatching rays -> verify_list
+                    // the count cross-check beside the writer and the fill (late form): mismatching rays -> verify_list.  (Round 6
+                    // measured two other places for it -- on the side stream behind the literal pairing, and on the aux stream but
+                    // not before the writer has finished: +1.2..1.8 % on the frames, +0.2..3.5 % on C5, profiles/r06p_place_sweep.txt)
                     tn::launch_verify_counts(chunk_params(0, R), t->verify_stride, t->walk_n.p, t->verify_list.p, t->verify_count(), 0,
                                              s_aux, true, t->verify_inject);
                     // ... and EVERY certified ray of the risk classes (inside the wide band of a guard: DESIGN.md section 2)
