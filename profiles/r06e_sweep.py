@@ -21,7 +21,7 @@ variants = []
 for a in sys.argv[3:]:
     n, _, spec = a.partition(":")
     variants.append((n, [kv.split("=") for kv in spec.split(",") if kv]))
-DEFAULTS = {"cert_ends": 1, "verify_stride": 256}
+DEFAULTS = {"cert_ends": 2, "verify_stride": 256}
 CFG = {"C2": (15000, 0, 512), "C4": (45000, 2, 512), "C5": (150000, 3, 512)}
 
 

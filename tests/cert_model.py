@@ -67,6 +67,50 @@ def certify(t, fid):
     return bool(fin), bool(d2), {k: bool(v and fin) for k, v in used.items()}
 
 
+PEND_NEXT_ON_LONG = PEND_NEW_CLUSTER
+
+
+def certify_pairwise(t, fid):
+    """struct OrderPair<true> (OrderR5e): round 5's pairwise test + rules A-C -- what the tracer runs below 500k tets.  Pairwise
+    notions: "short" = |t_k - t_(k-1)| < eps; an inverted pair must be isolated (the pair before long, the face before it at least
+    eps away, a long gap clear of both members behind it); no rule D."""
+    have_prev = have_pp = False
+    order_ok = True
+    prev_short = prev_inv = False
+    pt = ppt = np.float32(0)
+    nhits = 0
+    pend = 0
+    drop2 = used_b = False
+    for k in range(len(t)):
+        ct = np.float32(t[k])
+        if have_prev:
+            is_short = abs(np.float32(pt - ct)) < EPS
+            asc = bool(ct > pt or (ct == pt and fid[k] > fid[k - 1]))
+            clear2 = np.float32(ct - ppt) >= EPS
+            pend_wait = pend >= 2
+            first_inv = is_short and not asc and not have_pp                      # rule C
+            entry_run = is_short and asc and prev_short and nhits == 2            # rule B
+            if is_short:
+                ok = (not pend_wait) and ((not prev_inv) if asc else ((not have_pp) or (not prev_short and clear2)))
+                pend = 1 if entry_run else (3 if first_inv else pend)
+            else:
+                ok = asc and ((not prev_inv) or clear2)
+                pend = PEND_NEXT_ON_LONG[pend]
+            drop2 = drop2 or first_inv
+            used_b = used_b or entry_run
+            order_ok = order_ok and ok
+            prev_inv = is_short and not asc
+            prev_short = is_short
+        nhits += 1
+        have_pp = have_prev
+        ppt = pt
+        pt = ct
+        have_prev = True
+    order_ok = order_ok and pend == 0 and not (prev_inv and nhits < 4)            # rule A (+ B / C settled before the chain ends)
+    return bool(order_ok), bool(drop2), {"A": bool(order_ok and prev_inv), "B": bool(order_ok and used_b), "C": bool(order_ok and drop2),
+                                         "D": False}
+
+
 def plain_pairing(t, drop2):
     """What the segment writer emits for a certified chain: (tet index k, t_in, t_out) for every pair (k-1, k) that is not short."""
     segs = []

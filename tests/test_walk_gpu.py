@@ -210,7 +210,7 @@ def test_end_of_chain_rules_agree_with_the_literal_kernel(tn, device, scenes, bo
         to, td = torch.from_numpy(np.ascontiguousarray(o)).to(device), torch.from_numpy(np.ascontiguousarray(d)).to(device)
         for table in (1, 2):
             res = {}
-            for ends in (0, 1):
+            for ends in (0, 3, 1):                          # round 5's pairwise test | + rules A-C | round 6's cluster test (A-D)
                 tr = tn.TetrahedraTracer(device)
                 tr.set_option("walk", 2)
                 tr.set_option("writer_table", table)
@@ -219,18 +219,21 @@ def test_end_of_chain_rules_agree_with_the_literal_kernel(tn, device, scenes, bo
                 junk = torch.full((64 << 20,), 0x7FC12345, dtype=torch.int32, device=device)   # poison what the allocator hands out next
                 del junk
                 res[ends] = (tr.trace_rays(to, td, 256), tr.trace_rays(to, td, 256, compact_rows=True), tr.flag_reasons().get(13, 0))
-            (want, want_c, lit0), (got, got_c, lit1) = res[0], res[1]
-            assert lit1 <= lit0, (name, lit0, lit1)
-            moved += (lit0 - lit1) if table == 1 else 0
+            want, want_c, lit0 = res[0]
             n = want["num_visited_cells"]
             valid = torch.arange(256, device=device)[None] < n[:, None]
-            for k in KEYS:
-                assert torch.equal(got[k].view(torch.int32), want[k].view(torch.int32)), (name, table, k)
-            assert torch.equal(got_c["num_visited_cells"], n)
-            for k in KEYS[1:]:
-                a, b = got_c[k], want_c[k]
-                m = valid.reshape(valid.shape + (1,) * (a.dim() - 2)).expand_as(a)
-                assert torch.equal(a[m].view(torch.int32), b[m].view(torch.int32)), (name, table, k, "compact")
+            for ends in (3, 1):
+                got, got_c, lit1 = res[ends]
+                assert lit1 <= lit0, (name, ends, lit0, lit1)
+                for k in KEYS:
+                    assert torch.equal(got[k].view(torch.int32), want[k].view(torch.int32)), (name, table, ends, k)
+                assert torch.equal(got_c["num_visited_cells"], n)
+                for k in KEYS[1:]:
+                    a, b = got_c[k], want_c[k]
+                    m = valid.reshape(valid.shape + (1,) * (a.dim() - 2)).expand_as(a)
+                    assert torch.equal(a[m].view(torch.int32), b[m].view(torch.int32)), (name, table, ends, k, "compact")
+            assert res[1][2] <= res[3][2], (name, res[3][2], res[1][2])      # the cluster test certifies at least what A-C do
+            moved += (lit0 - res[1][2]) if table == 1 else 0
     assert moved > 200, moved                               # the rules really move rays from the literal kernel to the writer
 
 

@@ -89,12 +89,13 @@ struct tn_tracer {
     // instructions over a walk-built list of non-empty groups.  Alone it equals the grouped-store writer below (0.62 ms on the C2
     // frame), in the schedule it costs +3..6 %: it leaves the padding [n, ceil32(n)) to the tail fill, and a line written in part
     // by two kernels costs the fill 12-18 % (partial-line writes).  The tail fill BESIDE that writer: +17 % / +3 % / +0..6 %.
-    // The walk's order test (tn_trace_walk.hip): 1 = round 6's cluster test (OrderR6: rules A-D certify 73-87 % of the rays round 5
-    // handed to the literal pairing), 0 = round 5's pairwise test (OrderR5), 2 = by mesh size (default).  Same rows either way (the
-    // literal kernel writes what the writer does not).  In-process sweeps on three boxes (profiles/r06l_sweep.txt, r06m_sweep*.txt,
-    // r06p_place_sweep.txt): the cluster test's extra state costs the frames +1.1..3.8 % (100k / 300k tets: 0.1-0.5 % of the rays
-    // are literal there and the walk is VALU-bound beside the speculative fill) and buys C5 -1.8..-3.5 % (1M tets: 9 % literal, the
-    // walk waits for fetches); at 6.7 M tets 27 % of a frame's rays were literal.  Hence OrderR6 from WALK_TET_MIN_TETS tets on.
+    // The walk's order test (tn_trace_walk.hip): 0 = round 5's pairwise test (OrderR5), 3 = the same + the end-of-chain rules A-C
+    // (OrderR5e), 1 = round 6's cluster test (OrderR6: rules A-D), 2 = by mesh size (default).  Same rows whichever is used (the
+    // literal kernel writes what the writer does not).  In-process sweeps (profiles/r06f_sweep.txt, r06i_stride_sweep.txt: A-C
+    // against round 5: C2 +-0, C4 -1.9..-2.8 %, C5 -3.5..-3.9 %; r06l_sweep.txt, r06m_sweep*.txt, r06p_place_sweep.txt: the cluster
+    // test against round 5: C2 +2.5..3.8 %, C4 +1.1..2.6 %, C5 -1.8..-2.9 %, i.e. its extra state costs the frames ~4 % where the
+    // walk is VALU-bound beside the speculative fill and pays where 9-27 % of the rays would be literal): hence A-C below
+    // WALK_TET_MIN_TETS tets, the cluster test from there on.
     int cert_ends = 2;
 
     tn::DevBuf<uint32_t> risk_list;      // certified rays inside the wide band of a certification guard (all cross-checked)
@@ -483,7 +484,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 w.risk_list = verify_risk ? t->risk_list.p : nullptr;
                 w.risk_count = t->risk_count();
                 w.risk_band = (float)t->risk_band;
-                w.cert_ends = (t->cert_ends == 2 ? t->mesh.T >= tn::WALK_TET_MIN_TETS : t->cert_ends != 0) ? 1u : 0u;
+                w.cert_ends = t->cert_ends == 2 ? (t->mesh.T >= tn::WALK_TET_MIN_TETS ? 1u : 3u) : (uint32_t)t->cert_ends;
                 tn::launch_trace_walk(w, stream, walk_reserve);
                 if (t->verify_stride && !single) {  // chunked call: serially, before anything that reads walk_n / the fallback list
                     tn::launch_verify_counts(w.t, t->verify_stride, w.walk_n, w.fallback_list, w.fallback_count, base, stream, false,
@@ -839,7 +840,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
             t->lds_cap = (unsigned)value;
         }
         else if (k == "writer_table") t->writer_table = value;   // applies at the next load_tetrahedra
-        else if (k == "cert_ends") t->cert_ends = value;
+        else if (k == "cert_ends") { if (value < 0 || value > 3) throw tn::Error("cert_ends must be 0 .. 3"); t->cert_ends = value; }
         else if (k == "verify_inject") t->verify_inject = value != 0;
         else if (k == "literal_sort_passes") t->literal_sort_passes = value < 0 ? 0u : (unsigned)value;
         else if (k == "verify_stride") t->verify_stride = value < 0 ? 0u : (unsigned)value;

@@ -61,7 +61,7 @@ struct WalkParams {
     uint32_t *risk_list;       // [num_items] certified rays inside the WIDE band (risk_band x 8 delta: 16 delta by default) of a certification guard: every one of
     uint32_t *risk_count;      // [1]          them is cross-checked (k_verify_counts); null: not collected
     float risk_band;           // width of that band in units of the guards' own 8 delta (tn option "risk_band")
-    uint32_t cert_ends;        // 1: rules A-C of the order test (round 6: end-of-chain patterns certified); 0: round 5's rules (A/B, tests)
+    uint32_t cert_ends;        // the order test: 0 round 5's pairwise test, 3 the same + the end-of-chain rules A-C, 1 round 6's cluster test (A-D)
 };
 // lds_reserve: bytes of (unused) dynamic LDS per block = an occupancy limit (160 KB / lds_reserve blocks per CU), 0 = none
 void launch_trace_walk(const WalkParams &p, hipStream_t stream, size_t lds_reserve = 0);

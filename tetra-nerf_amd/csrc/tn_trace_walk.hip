@@ -189,19 +189,33 @@ __device__ __forceinline__ SV selsv(const SV &p0, const SV &p1, const SV &p2, co
 // pairing kernel -- two independent implementations -- and must give identical rows (tests/test_walk_gpu.py).  Both are written as
 // selects: `vp` = this step recorded a hit and a previous one exists, `start` = this step recorded the ray's first hit.
 namespace {
-struct OrderR5 {
-    bool ok = true, have_pp = false, prev_short = false, prev_inv = false;
+// OrderPair<false> = round 5's pairwise test; OrderPair<true> = the same with the end-of-chain rules A-C added (the form round 6
+// measured first: cheaper per step than the cluster test, and what the tracer uses below WALK_TET_MIN_TETS tets;
+// tests/cert_model.py: certify_pairwise).
+template <bool ENDS>
+struct OrderPair {
+    bool ok = true, have_pp = false, prev_short = false, prev_inv = false, d2 = false;
+    uint32_t pend = 0;
     float ppt = 0.f;
     __device__ __forceinline__ uint32_t step(bool valid, bool have_prev, float pt, float ct, bool tie_asc, uint32_t nhits) {
         const bool vp = valid && have_prev;
         const bool is_short = fabsf(pt - ct) < TN_EPS;
         const bool asc = (ct > pt) || (ct == pt && tie_asc);
         const bool clear2 = ct - ppt >= TN_EPS;
-        // short + ascending: any run of them is fine (header), except a run that starts at the entry hull face (pairs 1 and 2 both
-        // short: nhits == 2 here); short + inverted: isolated and clear of the face before; after an inverted pair: a long gap,
-        // clear of both of its members
-        const bool good = is_short ? (asc ? (!prev_inv && !(prev_short && nhits == 2u)) : (!prev_short && have_pp && clear2))
-                                   : (asc && (!prev_inv || clear2));
+        // short + ascending: any run of them is fine (header) -- a run that starts at the entry face (pairs 1 and 2 both short:
+        // nhits == 2 here) only if two long gaps follow it (rule B); short + inverted: isolated and clear of the face before -- as
+        // the FIRST pair: the segment of hit 2 is lost, three clear long gaps must follow (rule C); after an inverted pair: a long
+        // gap, clear of both of its members
+        const bool pend_wait = pend >= 2u;
+        const bool first_inv = is_short && !asc && !have_pp;
+        const bool entry_run = is_short && asc && prev_short && nhits == 2u;
+        const bool good = (is_short ? (!pend_wait && (asc ? !prev_inv : (!have_pp || (!prev_short && clear2))))
+                                    : (asc && (!prev_inv || clear2))) &&
+                          (ENDS || !(entry_run || first_inv));
+        const uint32_t pend_long = (0x2810u >> (3u * pend)) & 7u;               // on a long gap: 0 2 0 4 2
+        const uint32_t pend_next = is_short ? (entry_run ? 1u : (first_inv ? 3u : pend)) : pend_long;
+        pend = vp ? pend_next : pend;
+        d2 = d2 || (vp && first_inv);
         ok = ok && (!vp || good);
         prev_inv = vp ? (is_short && !asc) : prev_inv;
         prev_short = vp ? is_short : prev_short;
@@ -211,10 +225,13 @@ struct OrderR5 {
     }
     __device__ __forceinline__ bool needs_step(bool, bool, float) const { return true; }
     __device__ __forceinline__ void fast(bool, float) {}
-    __device__ __forceinline__ bool finish(uint32_t) const { return ok && !prev_inv; }   // a pair inverted at the very end: not certified
-    __device__ __forceinline__ bool drop2() const { return false; }
+    // rule A: an isolated inverted pair at the very end of a chain of >= 4 hits needs no following face; B / C: look-ahead settled
+    __device__ __forceinline__ bool finish(uint32_t nhits) const { return ok && pend == 0u && !(prev_inv && (nhits < 4u || !ENDS)); }
+    __device__ __forceinline__ bool drop2() const { return d2; }
     __device__ __forceinline__ uint32_t end_reason() const { return 8u; }
 };
+using OrderR5 = OrderPair<false>;
+using OrderR5e = OrderPair<true>;
 
 // Round 6: the same test on CLUSTERS.  A hit joins the current cluster iff it is less than eps above the cluster's largest t
 // (so a new cluster starts with a gap of at least eps above EVERY member of the old one).  tests/cert_model.py is this state
@@ -937,7 +954,8 @@ void launch_trace_walk(const WalkParams &p, hipStream_t stream, size_t lds_reser
     const uint32_t unit = 8 * XCD_GROUP;
     const uint32_t grid = (nblk + unit - 1) / unit * unit;
     if (lds_reserve > 64 * 1024) lds_reserve = 64 * 1024;
-    if (p.cert_ends) hipLaunchKernelGGL(k_trace_walk<OrderR6>, dim3(grid), dim3(WALK_BLOCK), lds_reserve, stream, p);
+    if (p.cert_ends == 1u) hipLaunchKernelGGL(k_trace_walk<OrderR6>, dim3(grid), dim3(WALK_BLOCK), lds_reserve, stream, p);
+    else if (p.cert_ends == 3u) hipLaunchKernelGGL(k_trace_walk<OrderR5e>, dim3(grid), dim3(WALK_BLOCK), lds_reserve, stream, p);
     else hipLaunchKernelGGL(k_trace_walk<OrderR5>, dim3(grid), dim3(WALK_BLOCK), lds_reserve, stream, p);
 }
 
