@@ -172,6 +172,7 @@ def test_literal_pairing_of_the_log_equals_bvh_fallback(tn, device, oracle, scen
     b = _trace(tr, device, o, d, 512)
     assert 13 not in tr.flag_reasons()
     tr.set_option("literal", 1)
+    tr.set_option("spec_fill", 1)
     tr.set_option("spec_k0", 32)     # speculative fill from slot 32 on: the literal rows overwrite it
     c = _trace(tr, device, o, d, 512)
     for k in KEYS:

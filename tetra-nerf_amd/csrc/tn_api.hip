@@ -38,7 +38,7 @@ struct tn_tracer {
     hipStream_t aux = nullptr;           // BVH re-trace of the fallback rays (forked right after the walk)
     hipStream_t pre = nullptr;           // speculative tail fill beside the walk
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_start = nullptr, ev_pre = nullptr, ev_seg = nullptr, ev_aux = nullptr;
-    int spec_fill = 1;                   // 1: the last quarter of every row is filled beside the walk where that is mesh-safe; 0 off
+    int spec_fill = 0;                   // 1: the last quarter of every row is filled beside the walk where that is mesh-safe; 0 off (default since round 6)
     unsigned spec_k0 = 0;                // override of the first speculatively filled slot (multiple of 32; tests)
     // Round 4: the speculative fill used to be launched with 2048 blocks = 32 waves per CU -- every wave slot of the chip --
     // in front of a walk that wants all 32 slots itself (64 VGPRs): the kernels shared the time instead of overlapping.  Now
@@ -47,6 +47,12 @@ struct tn_tracer {
     // duration: -3.1 % on the C2 frame, -4.9 % on the C4 frame (interleaved sweep on one box, profiles/r04f_overlap_sweep.txt;
     // 7 or 5 walk blocks, 1 or 4 fill blocks per CU are all worse).  Options for sweeps:
     unsigned spec_blocks = 512;          // grid of the speculative fill
+    unsigned writer_blocks = 0;          // grid of the segment writer (0: 2 blocks per CU, what is resident at once)
+    // Round 6: the tail fill is cut fine (one block per row, k_fill_rows_fine) and nothing is filled beside the walk any more:
+    // -5.9 / -6.6 / -1.3 % on the C2 / C4 frames / C5 rays, averaged over fresh allocations of the rows in one process
+    // (profiles/r06u_alloc_sweep.txt; persistent waves at 512 ... 160000 blocks: r06t_alloc_sweep*.txt).  With the round's
+    // faster writer the overlap of fill and walk had stopped paying (r06r_spec_sweep.txt: on / off +-0.4 %).
+    unsigned fill_blocks = tn::FILL_FINE; // grid of the tail fill (option "fill_blocks": -1 = one block per row, else persistent waves)
     unsigned walk_lds_kb = 26;           // dynamic LDS reserved per walk block beside a speculative fill (0: no limit)
     bool small_lds = true;               // small batches: LDS hit arrays sized for the mesh, overflow rays in a second launch
     unsigned lds_cap = 0;                // 0: from the mesh size; otherwise the entries of the small arrays (power of two; tests)
@@ -504,12 +510,12 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 q.out_bary = bary + base * M * 6;
                 q.out_dist = dist + base * M * 2;
                 q.out_verts = verts ? verts + base * M * 4 : nullptr;
-                tn::launch_write_segments(q, stream);
+                tn::launch_write_segments(q, stream, t->writer_blocks);
             };
             auto launch_fill = [&](size_t base, size_t n, uint32_t k_hi, hipStream_t st) {   // [ceil32(n_r), k_hi) of the certified rows
                 if (!dense_tails) return;
                 tn::launch_fill_range(n, M, false, t->walk_n.p + base, num_visited + base, visited + base * M, bary + base * M * 6,
-                                      dist + base * M * 2, verts ? verts + base * M * 4 : nullptr, st, k_hi, false);
+                                      dist + base * M * 2, verts ? verts + base * M * 4 : nullptr, st, k_hi, false, t->fill_blocks);
             };
             auto launch_literal = [&](size_t base, size_t n, hipStream_t st) {
                 if (!t->literal) return;
@@ -832,7 +838,9 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (k == "literal") t->literal = value != 0;
         else if (k == "spec_fill") t->spec_fill = value != 0;
         else if (k == "spec_k0") t->spec_k0 = (unsigned)value;
-        else if (k == "spec_blocks") t->spec_blocks = (unsigned)value;
+        else if (k == "spec_blocks") t->spec_blocks = value < 0 ? tn::FILL_FINE : (unsigned)value;
+        else if (k == "writer_blocks") t->writer_blocks = (unsigned)value;
+        else if (k == "fill_blocks") t->fill_blocks = value < 0 ? tn::FILL_FINE : (unsigned)value;    // -1: one block per row
         else if (k == "walk_lds_kb") t->walk_lds_kb = (unsigned)value;
         else if (k == "small_lds") t->small_lds = value != 0;
         else if (k == "lds_cap") {

@@ -873,10 +873,61 @@ __global__ __launch_bounds__(256) void k_fill_range(size_t num_rays, uint32_t M,
     }
 }
 
+// The same rows with the work cut FINE: one block per row, its four waves take 6-8 KB each (cells + distances | first half
+// of the barycentrics | second half | vertex ids), six to eight 1 KB store instructions per wave and the block is gone.
+// Rows in flight form one moving window per array and the dispatcher balances the channels: with long-lived waves that
+// own fixed spans of rows the same 17 GB took 2.40 ... 3.07 ms depending on WHERE the driver had put the pages (fresh
+// allocations of the same rows in one process, profiles/r06s_placement.txt), torch's own one-store-per-thread fill of the
+// same pages 2.43 ... 2.50 ms (profiles/r06s_torch_fill.txt).
+template <bool NT>
+__global__ __launch_bounds__(256) void k_fill_rows_fine(size_t num_rays, uint32_t M, uint32_t all_rows, uint32_t k_split,
+                                                        const uint32_t *__restrict__ walk_n, const uint32_t *__restrict__ out_num,
+                                                        uint32_t *__restrict__ out_cells,
+                                                        float *__restrict__ out_bary, float *__restrict__ out_dist,
+                                                        uint32_t *__restrict__ out_verts) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const size_t r = blockIdx.x;
+    uint32_t lo = k_split, hi = M;
+    if (!all_rows) {
+        if (walk_n[r] == TN_EMPTY) return;        // literal / fallback ray: those kernels write the whole row
+        lo = (out_num[r] + 31u) & ~31u;
+        if (lo > M) lo = M;
+        hi = k_split;
+    }
+    if (lo >= hi) return;
+    const uint32_t mid = 6u * lo + ((3u * (hi - lo) + 3u) & ~3u);   // 16-byte aligned when lo is
+    uint32_t *bary = reinterpret_cast<uint32_t *>(out_bary + r * M * 6);
+    if (wave == 0) {
+        fill_dwords<NT>(out_cells + r * M, lo, hi, TN_EMPTY, lane);
+        fill_dwords<NT>(reinterpret_cast<uint32_t *>(out_dist + r * M * 2), 2 * lo, 2 * hi, 0u, lane);
+    } else if (wave == 1) {
+        fill_dwords<NT>(bary, 6 * lo, mid < 6 * hi ? mid : 6 * hi, 0u, lane);
+    } else if (wave == 2) {
+        if (mid < 6 * hi) fill_dwords<NT>(bary, mid, 6 * hi, 0u, lane);
+    } else if (out_verts) {
+        fill_dwords<NT>(out_verts + r * M * 4, 4 * lo, 4 * hi, TN_EMPTY, lane);
+    }
+}
+
 void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *walk_n, const uint32_t *out_num,
                        uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
                        uint32_t k_split, bool nontemporal, unsigned max_blocks) {
     if (num_rays == 0) return;
+    if (max_blocks == FILL_FINE) {
+        for (size_t base = 0; base < num_rays; base += 0x40000000u) {     // grid.x limit
+            const size_t n = num_rays - base < 0x40000000u ? num_rays - base : 0x40000000u;
+            if (nontemporal)
+                hipLaunchKernelGGL(k_fill_rows_fine<true>, dim3((unsigned)n), dim3(256), 0, stream, n, M, all_rows ? 1u : 0u, k_split,
+                                   walk_n ? walk_n + base : nullptr, out_num ? out_num + base : nullptr, out_cells + base * M,
+                                   out_bary + base * M * 6, out_dist + base * M * 2, out_verts ? out_verts + base * M * 4 : nullptr);
+            else
+                hipLaunchKernelGGL(k_fill_rows_fine<false>, dim3((unsigned)n), dim3(256), 0, stream, n, M, all_rows ? 1u : 0u, k_split,
+                                   walk_n ? walk_n + base : nullptr, out_num ? out_num + base : nullptr, out_cells + base * M,
+                                   out_bary + base * M * 6, out_dist + base * M * 2, out_verts ? out_verts + base * M * 4 : nullptr);
+        }
+        return;
+    }
     size_t blocks = (num_rays + 3) / 4;           // >= one ray per wave
     // after the writer: 2 blocks (8 waves) per CU hold the write ceiling, and the latency-bound kernels running beside
     // the fill are less starved than with 8 per CU (profiles/r01_fill_grid.txt); beside the walk: 2048 blocks
