@@ -514,3 +514,64 @@ def test_find_visited_cells_ray_index(tn, device, scenes):
         assert torch.equal(a[k], b[k]), k
     assert bool(a["mask"].any())
 
+
+
+def _sphere_hull_mesh(scenes, n_hull_points, interior=3000, seed=11):
+    """`n_hull_points` points on a sphere (all of them hull vertices: 2 n - 4 hull faces) + interior points."""
+    rng = np.random.default_rng(seed)
+    v = rng.normal(size=(n_hull_points, 3))
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    pts = np.concatenate([0.5 + 0.49 * v, 0.5 + 0.5 * (rng.random((interior, 3)) - 0.5)], 0).astype(np.float32)
+    return np.ascontiguousarray(pts), scenes.delaunay_cells(np.ascontiguousarray(pts))
+
+
+def _hull_faces(cells):
+    f = np.concatenate([cells[:, [1, 2, 3]], cells[:, [0, 2, 3]], cells[:, [0, 1, 3]], cells[:, [0, 1, 2]]], 0)
+    f.sort(1)
+    return int((np.unique(f, axis=0, return_counts=True)[1] == 1).sum())
+
+
+@pytest.mark.parametrize("mesh", ["cube", "random", "colmap_like", "sphere_1020", "sphere_1024", "sphere_1028", "sphere_notched"])
+def test_flat_hull_search_equals_the_threaded_tree(tn, device, oracle, scenes, mesh):
+    """Round 6: k_hull_entry finds the two crossed hull faces through a flat two-level box table staged in LDS (hulls of at
+    most 1024 faces: 66 KB of dynamic LDS at the limit, above 64 KB only by opt-in) instead of the threaded tree; both must
+    give the same rows, bit for bit, and the oracle's on a sample.  Hull sizes around the limit (1020 / 1024 flat, 1028
+    tree), a notched (non-convex) hull and the 12-face cube (one group, six leaves)."""
+    if mesh == "cube":
+        pts, cells = scenes.cube_mesh()
+    elif mesh == "random":
+        pts, cells = scenes.random_mesh(6000, 3)
+    elif mesh == "colmap_like":
+        pts, cells = scenes.colmap_like_mesh()
+    elif mesh == "sphere_notched":
+        # a convex hull with tets removed at the boundary: lines through a notch cross the hull four times (-> BVH path)
+        pts, cells = _sphere_hull_mesh(scenes, 300)
+        f = np.concatenate([cells[:, [1, 2, 3]], cells[:, [0, 2, 3]], cells[:, [0, 1, 3]], cells[:, [0, 1, 2]]], 0)
+        f.sort(1)
+        _, inv, cnt = np.unique(f, axis=0, return_inverse=True, return_counts=True)
+        on_hull = (cnt[inv.reshape(-1)] == 1).reshape(4, -1).sum(0)
+        cells = np.ascontiguousarray(np.delete(cells, np.nonzero(on_hull == 1)[0][::7], axis=0))
+        assert _hull_faces(cells) > 596
+    else:
+        n = {"sphere_1020": 512, "sphere_1024": 514, "sphere_1028": 516}[mesh]
+        pts, cells = _sphere_hull_mesh(scenes, n)
+        assert _hull_faces(cells) == 2 * n - 4
+    rays = [scenes.outside_in_rays(30000, 5), scenes.inside_out_rays(20000, 6)]
+    o = np.ascontiguousarray(np.concatenate([r[0] for r in rays], 0))
+    d = np.ascontiguousarray(np.concatenate([r[1] for r in rays], 0))
+    M = 256
+    outs = {}
+    for flat in (1, 0):
+        tr = _tracer(tn, device, pts, cells, walk=True)
+        tr.set_option("hull_flat", flat)
+        outs[flat] = _trace(tr, device, o, d, M)
+        st = tr.trace_stats()
+        assert st["walk"] > 0.5 * len(o) or mesh in ("cube", "sphere_notched"), st
+    for k in KEYS:
+        assert _bits_equal(outs[1][k], outs[0][k]), k
+    ot = oracle.OracleTracer(use_bvh=True)
+    ot.load_tetrahedra(pts, cells)
+    sl = slice(0, len(o), 25)
+    want = ot.trace_rays(np.ascontiguousarray(o[sl]), np.ascontiguousarray(d[sl]), M)
+    for k in KEYS:
+        assert _bits_equal(outs[1][k][sl], want[k]), k

@@ -28,6 +28,7 @@ struct tn_tracer {
     uint32_t bvh_max_stack = 1;
     unsigned leaf_width = 16;            // faces per BVH leaf block (16 / 32 / 64; applies at the next load_tetrahedra)
     tn::DevBuf<uint32_t> faces, face_tets, fallback_list, walk_n;
+    tn::DevBuf<uint4> hull_entry;        // [R] k_hull_entry -> k_trace_walk
     tn::DevBuf<uint2> literal_list;      // rays whose logged hits go through the literal sort + pairing
     tn::DevBuf<uint4> hit_log;           // walk -> segment writer / literal pairing: 16 B per recorded hit, [rays / 64][M][64]
     size_t log_cap_bytes = 0;            // 0: a fraction of the free device memory (decided per call); larger calls are walked
@@ -47,6 +48,7 @@ struct tn_tracer {
     // duration: -3.1 % on the C2 frame, -4.9 % on the C4 frame (interleaved sweep on one box, profiles/r04f_overlap_sweep.txt;
     // 7 or 5 walk blocks, 1 or 4 fill blocks per CU are all worse).  Options for sweeps:
     unsigned spec_blocks = 512;          // grid of the speculative fill
+    bool hull_flat = true;               // the walk finds its hull faces through the flat box table in LDS (hulls of <= 1024 faces); false: threaded tree
     unsigned writer_blocks = 0;          // grid of the segment writer (0: 2 blocks per CU, what is resident at once)
     // Round 6: the tail fill is cut fine (one block per row, k_fill_rows_fine) and nothing is filled beside the walk any more:
     // -5.9 / -6.6 / -1.3 % on the C2 / C4 frames / C5 rays, averaged over fresh allocations of the rows in one process
@@ -289,7 +291,7 @@ int tn_load_tetrahedra(tn_tracer_t tracer, size_t V, size_t T, const float *xyz,
             tn::build_walk_variants(recs, vars);
             t->vars.upload(vars);
         }
-        t->hull_nodes.upload(hth.nodes);
+        t->hull_nodes.upload(hth.nodes_and_flat());
         t->hull_tris.upload(hth.tris);
         n_hull = hull_ids.size(); n_hull_nodes = hth.nodes.size() / 8;
         }
@@ -430,7 +432,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
         // M >= 4: the writer and the fills store 16-byte vectors into the rows; M is a power of two (checked above), so
         // from 4 on every row base is 16-byte aligned
         const bool walk = t->use_walk && (R >= t->walk_min_rays || t->use_walk == 2) && M >= 4 &&
-                          t->mesh.n_hull > 0;
+                          t->mesh.n_hull > 0 && t->mesh.n_hull < (1u << 24);   // (HullEntry keeps the face's slot in 24 bits)
         t->last_walk = walk;
         if (walk) {
             // main stream: walk (hits -> log; classes) -> segment writer -> tails [ceil32(n), K0) of the certified rows
@@ -440,7 +442,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
             // Everything that writes rows is ordered behind the speculative fill, so a ray with more than K0 segments
             // (or a literal / fallback row) simply overwrites its slots.  The log holds 16 B per hit slot; calls whose log
             // would exceed the cap are processed in ray chunks (multiples of 4096 rays, the walk's XCD run), serially.
-            if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); }
+            if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); t->hull_entry.alloc(R); }
             const bool verify_risk = t->verify_risk && t->verify_stride;
             if (t->verify_stride) {
                 // sized with the other scratch buffers, BEFORE the first launch of the call: an allocation in the middle of
@@ -480,6 +482,11 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 w.hull_nodes = t->mesh.hull_nodes;
                 w.hull_tris = t->mesh.hull_tris;
                 w.n_hull_nodes = t->mesh.n_hull_nodes;
+                w.hull_flat = t->mesh.hull_nodes + 2 * (size_t)t->mesh.n_hull_nodes;
+                w.n_hull_leaves = t->hull_flat ? tn::hull_flat_leaves(t->mesh.n_hull) : 0u;
+                w.n_hull_groups = t->hull_flat ? tn::hull_flat_groups(t->mesh.n_hull) : 0u;
+                w.n_hull = t->mesh.n_hull;
+                w.hull_entry = t->hull_entry.p + base;
                 w.fallback_list = t->fallback_list.p;
                 w.fallback_count = t->fallback_count();
                 w.literal_list = t->literal ? t->literal_list.p : nullptr;
@@ -594,6 +601,8 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 TN_HIP(hipStreamWaitEvent(s_side, t->ev_seg, 0));    // literal pairing beside the bandwidth-bound fill, not
                 launch_literal(0, R, s_side);                        // beside the latency-bound writer (r02f_sched_sweep.txt)
                 mark();                                                   // 6: literal pairing of the logged hits
+                // (round 6, once more: the tail fill needs only the walk's counts, but beside the writer it costs +3 ... 5 % whatever its
+                // grid and whichever is enqueued first, profiles/r06w_fill_beside.txt)
                 launch_fill(0, R, K0 ? K0 : M, stream);
                 mark();                                                   // 7: tail fill
                 TN_HIP(hipEventRecord(t->ev_join, s_side));
@@ -632,7 +641,7 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
             while (C < expect && C < M) C <<= 1;
             if (t->lds_cap) C = t->lds_cap;
             if (t->small_lds && C < M) {
-                if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); }
+                if (t->fallback_list.n < R) { t->fallback_list.alloc(R); t->walk_n.alloc(R); t->literal_list.alloc(R); t->hull_entry.alloc(R); }
                 tn::TraceParams p1 = p;
                 p1.lds_cap = C; p1.overflow_list = t->fallback_list.p; p1.overflow_count = t->fallback_count();
                 tn::launch_trace_general(p1, stream);
@@ -839,6 +848,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (k == "spec_fill") t->spec_fill = value != 0;
         else if (k == "spec_k0") t->spec_k0 = (unsigned)value;
         else if (k == "spec_blocks") t->spec_blocks = value < 0 ? tn::FILL_FINE : (unsigned)value;
+        else if (k == "hull_flat") t->hull_flat = value != 0;
         else if (k == "writer_blocks") t->writer_blocks = (unsigned)value;
         else if (k == "fill_blocks") t->fill_blocks = value < 0 ? tn::FILL_FINE : (unsigned)value;    // -1: one block per row
         else if (k == "walk_lds_kb") t->walk_lds_kb = (unsigned)value;

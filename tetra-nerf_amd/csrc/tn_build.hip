@@ -425,7 +425,7 @@ void device_build(size_t V, size_t T, const float *xyz, const uint32_t *cells, h
     const size_t nn = bn.size(), n_leaves = leaf_nodes.size();
     HostHullBvh hth;
     build_hull_from_info(hinfo, hth);
-    out.hull_nodes.upload(hth.nodes);
+    out.hull_nodes.upload(hth.nodes_and_flat());
     out.hull_tris.upload(hth.tris);
 
     DevBuf<core::BinNode> dbn;

@@ -193,7 +193,16 @@ struct HostWideBvh {
 struct HostHullBvh {
     std::vector<float> nodes;  // [n_nodes][8]: lo.xyz, skip | hi.xyz, leaf (first<<3|count, or ~0)
     std::vector<float> tris;   // [n_hull][12]: v0.xyz, face id | v1.xyz, tet record | v2.xyz, local face  (Morton order)
+    // Flat two-level box table over the same Morton-ordered faces (round 6, the walk's LDS hull search; only for hulls of at
+    // most HULL_FLAT_MAX faces, else empty): [G groups][8] then [L leaves][8], each lo.xyz, first | hi.xyz, count -- a leaf
+    // = 2 consecutive faces (first = face slot), a group = 8 consecutive leaves (first = leaf index)
+    std::vector<float> flat;
+    // what is uploaded as the device's hull_nodes array: the threaded tree, then the flat table
+    std::vector<float> nodes_and_flat() const { std::vector<float> v(nodes); v.insert(v.end(), flat.begin(), flat.end()); return v; }
 };
+constexpr uint32_t HULL_FLAT_MAX = 1024;   // faces: 512 leaves + 64 groups = 18 KB of LDS per walk block
+inline uint32_t hull_flat_leaves(uint32_t n_hull) { return n_hull && n_hull <= HULL_FLAT_MAX ? (n_hull + 1u) / 2u : 0u; }
+inline uint32_t hull_flat_groups(uint32_t n_hull) { return (hull_flat_leaves(n_hull) + 7u) / 8u; }
 // `recs` / `rec_of_tet` (record index of each original tet) from build_tet_records: every hull face carries
 // the record index of its tet and its local face index, so the walk starts without further lookups
 void build_hull_threaded(const float *xyz, const uint32_t *faces, const uint32_t *face_tets,

@@ -49,6 +49,10 @@ struct WalkParams {
     const float4 *hull_nodes;  // threaded per-lane hull tree
     const float4 *hull_tris;
     uint32_t n_hull_nodes;
+    const float4 *hull_flat;   // flat two-level box table of the hull (HostHullBvh::flat): groups, then leaves; staged in LDS
+    uint32_t n_hull_groups, n_hull_leaves;   // 0: use the threaded tree
+    uint32_t n_hull;           // hull faces
+    uint4 *hull_entry;         // [num_items] k_hull_entry -> k_trace_walk (layout: tn_trace_walk.hip)
     uint32_t *fallback_list;   // [R] rays for the BVH all-hits kernel (global ray ids)
     uint32_t *fallback_count;  // [1]
     uint2 *literal_list;       // [num_items] {ray index within this launch, hits in the log}: sound chains whose ORDER is

@@ -399,6 +399,7 @@ void build_hull_from_info(const std::vector<float> &info, HostHullBvh &out) {
     const size_t n = info.size() / 12;
     out.nodes.clear();
     out.tris.clear();
+    out.flat.clear();
     if (n == 0) return;
     // Morton order of the face centroids
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -446,6 +447,32 @@ void build_hull_from_info(const std::vector<float> &info, HostHullBvh &out) {
         nd[4] = bhi[0]; nd[5] = bhi[1]; nd[6] = bhi[2]; std::memcpy(&nd[7], &leaf, 4);
     };
     emit(0, n);
+    // flat two-level table over the same face slots (tn_common.h: HostHullBvh::flat)
+    const uint32_t L = hull_flat_leaves((uint32_t)n), G = hull_flat_groups((uint32_t)n);
+    if (L) {
+        out.flat.assign((size_t)(G + L) * 8, 0.f);
+        auto put = [&](size_t slot, const float *blo, const float *bhi, uint32_t first, uint32_t count) {
+            float *nd = out.flat.data() + slot * 8;
+            nd[0] = blo[0]; nd[1] = blo[1]; nd[2] = blo[2]; std::memcpy(&nd[3], &first, 4);
+            nd[4] = bhi[0]; nd[5] = bhi[1]; nd[6] = bhi[2]; std::memcpy(&nd[7], &count, 4);
+        };
+        auto box_of = [&](size_t a, size_t b, float *blo, float *bhi) {
+            for (int k = 0; k < 3; ++k) { blo[k] = INFINITY; bhi[k] = -INFINITY; }
+            for (size_t s = a; s < b; ++s)
+                for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], fb[6 * s + k]); bhi[k] = std::max(bhi[k], fb[6 * s + 3 + k]); }
+        };
+        float blo[3], bhi[3];
+        for (uint32_t l = 0; l < L; ++l) {
+            const size_t a = 2 * (size_t)l, b = std::min(a + 2, n);
+            box_of(a, b, blo, bhi);
+            put(G + l, blo, bhi, (uint32_t)a, (uint32_t)(b - a));
+        }
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t l0 = 8 * g, l1 = std::min(l0 + 8u, L);
+            box_of(2 * (size_t)l0, std::min(2 * (size_t)l1, n), blo, bhi);
+            put(g, blo, bhi, l0, l1 - l0);
+        }
+    }
 }
 
 // Shape of the median-split binary tree over n faces (core::BinNode): BFS order, level by level; a node of `count`

@@ -105,6 +105,12 @@
 #endif
 #if TN_WALK_DIAG
 __device__ unsigned long long g_walk_diag[16];
+__device__ unsigned long long g_walk_time[8];   // 100 MHz ticks: [0] waves, [1] sum hull search, [2] sum walk loop, [3] max hull, [4] max loop, [5] max steps, [6] sum of per-wave max steps
+extern "C" int tn_debug_walk_time(unsigned long long out[8], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_time), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_walk_time), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
 extern "C" int tn_debug_walk_diag(unsigned long long out[16], int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_diag), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
     if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_walk_diag), z, sizeof z) != hipSuccess) return 1; }
@@ -303,11 +309,13 @@ struct OrderR6 {
 // or recomputed, one vertex is sheared per step, three edge functions against it decide the exit, and the exit
 // face's edge functions are evaluated directly in its stored order (E(P,Q) == -E(Q,P) bitwise, so they equal the
 // shared ones): bit-identical hits for 30 % fewer instructions than a per-tet record with dynamic selects.
-template <typename Order>
-__global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
+// Entry search, a kernel of its own since round 6 (it was the first half of k_trace_walk: its registers -- six float4 of
+// face data in flight -- cost the walk loop an occupancy step, 82 instead of 69 VGPRs).  Per ray one 16-byte HullEntry:
+//   x = variant (record, entry face) the walk starts in, y = face id of the entry hull face,
+//   z = triangle slot of that face | first flag reason << 24 | hull near-miss risk << 28 | state << 29 (0 miss, 1 walk, 2 hand over),
+//   w = t of the OTHER crossed hull face (the chain must end there, bit for bit).
+__global__ __launch_bounds__(WALK_BLOCK) void k_hull_entry(WalkParams p) {
     const TraceParams &t = p.t;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t M = t.M;
 
     // XCD-aware block remap: hardware places block b on XCD b % 8; give each XCD a contiguous band
     // Consecutive blocks trace neighbouring rays that cross the same tets, so each XCD gets RUNS
@@ -340,7 +348,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     // of whose edges passes within 8 delta of the ray sends the ray to the BVH path.
     const float delta = 0.21875f * pad;               // 7/32 of the box padding
     const float kappa = 8.0f * delta;
-    const uint32_t thin_exp = (__float_as_uint(32.0f * delta) >> 23) & 0xFFu;
     // RISK classes of the certification (round 5): the two guards above hand a ray over when it passes
     // within 8 delta of a hull edge / of an edge of a thin-neighbourhood tet.  What is not proved is that the degenerate
     // feature always lies THAT close to a tested edge, so the same tests with a wider band (option "risk_band": twice as wide
@@ -376,11 +383,57 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         hf1 = s1 ? fid : hf1; ht1 = s1 ? tt : ht1; hc1 = s1 ? rec : hc1; he1 = s1 ? loc : he1; hs1 = s1 ? slot : hs1;
         nhull += mixed ? 0u : 1u;
     };
-    {
+    // Round 6: the search was HALF of this kernel (100 MHz clock around both parts, profiles/r06y_walk_time.txt: 141 us of
+    // hull search and 95 us of walk per wave on the C2 frame, 1.1 ms and 0.6 ms at 1M tets) although a hull has a few hundred
+    // faces: every node and every leaf triangle of the threaded tree is a dependent round trip to L2, ~90 of them per ray.
+    // For hulls of at most HULL_FLAT_MAX faces the boxes now live in LDS (flat two-level table, tn_common.h): a lane tests
+    // all G <= 64 group boxes, the 8 leaf boxes of each group it hits and the 2 faces of each leaf it hits -- faces staged in
+    // LDS as well (66 KB at 1024 faces): no dependent round trip to memory is left in the search.  The order in which
+    // crossings are found is free (first0 = ht0 < ht1 sorts the two).
+    const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+    if (p.n_hull_leaves) {
+        extern __shared__ float4 s_hull[];
+        const uint32_t nbox2 = 2u * (p.n_hull_groups + p.n_hull_leaves);
+        for (uint32_t i = threadIdx.x; i < nbox2; i += WALK_BLOCK) s_hull[i] = p.hull_flat[i];
+        float4 *s_tri = s_hull + nbox2;                         // the faces themselves: 48 bytes each
+        for (uint32_t i = threadIdx.x; i < 3u * p.n_hull; i += WALK_BLOCK) s_tri[i] = p.hull_tris[i];
+        __syncthreads();
+        const float4 *s_leaf = s_hull + 2u * p.n_hull_groups;
+        unsigned long long gm = 0ull;
+        if (active)
+            for (uint32_t g = 0; g < p.n_hull_groups; ++g) {     // uniform addresses: LDS broadcasts
+                const float4 a = s_hull[2 * g], b = s_hull[2 * g + 1];
+                gm |= line_box(ox, oy, oz, ix, iy, iz, a.x, a.y, a.z, b.x, b.y, b.z, pad) ? 1ull << g : 0ull;
+            }
+        while (gm) {
+            const uint32_t g = (uint32_t)__ffsll((long long)gm) - 1u;
+            gm &= gm - 1ull;
+            const uint32_t l0 = 8u * g;
+            uint32_t lm = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                const uint32_t l = l0 + j < p.n_hull_leaves ? l0 + j : p.n_hull_leaves - 1u;
+                const float4 a = s_leaf[2 * l], b = s_leaf[2 * l + 1];
+                lm |= (l0 + j < p.n_hull_leaves && line_box(ox, oy, oz, ix, iy, iz, a.x, a.y, a.z, b.x, b.y, b.z, pad)) ? 1u << j : 0u;
+            }
+            while (lm) {
+                const uint32_t l = l0 + (uint32_t)__ffs((int)lm) - 1u;
+                lm &= lm - 1u;
+                const uint32_t first = __float_as_uint(s_leaf[2 * l].w), cnt = __float_as_uint(s_leaf[2 * l + 1].w);
+                const float4 *tp = s_tri + 3u * first;
+                const float4 *tq = tp + (cnt > 1u ? 3 : 0);
+                const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2], w0 = tq[0], w1 = tq[1], w2 = tq[2];
+                hull_face(shear(rp, v0.x, v0.y, v0.z), shear(rp, v1.x, v1.y, v1.z), shear(rp, v2.x, v2.y, v2.z),
+                          __float_as_uint(v0.w), __float_as_uint(v1.w), __float_as_uint(v2.w), first);
+                if (cnt > 1u)
+                    hull_face(shear(rp, w0.x, w0.y, w0.z), shear(rp, w1.x, w1.y, w1.z), shear(rp, w2.x, w2.y, w2.z),
+                              __float_as_uint(w0.w), __float_as_uint(w1.w), __float_as_uint(w2.w), first + 1u);
+            }
+        }
+    } else {
         // Per-lane stackless traversal of the threaded hull tree (DFS pre-order, skip links):
         // ray-independent visiting order, every crossing of the ray's LINE is found.  Works for
         // incoherent batches (random training rays) as well as for camera frames.
-        const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
         uint32_t i = active ? 0u : p.n_hull_nodes;
         while (i < p.n_hull_nodes) {
             const float4 a = p.hull_nodes[2 * (size_t)i], b = p.hull_nodes[2 * (size_t)i + 1];
@@ -402,6 +455,75 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     if (nhull == 2 && !(ht0 < ht1 || ht1 < ht0)) { flag = true; why = 3; }  // equal or NaN
     if (!active) { flag = false; nhull = 0; }
 
+    if (active) {
+        const bool alive = nhull == 2 && !flag;
+        const bool first0 = ht0 < ht1;
+        uint4 e;
+        e.x = alive ? 4u * (first0 ? hc0 : hc1) + (first0 ? he0 : he1) : 0u;   // variant = (tet record, entry face)
+        e.y = first0 ? hf0 : hf1;
+        e.z = (first0 ? hs0 : hs1) | (why << 24) | ((risk & 1u) << 28) | ((flag ? 2u : alive ? 1u : 0u) << 29);
+        e.w = __float_as_uint(first0 ? ht1 : ht0);
+        p.hull_entry[ray] = e;
+    }
+}
+
+template <typename Order>
+__global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
+    const TraceParams &t = p.t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t M = t.M;
+
+    // XCD-aware block remap: hardware places block b on XCD b % 8; give each XCD a contiguous band
+    // Consecutive blocks trace neighbouring rays that cross the same tets, so each XCD gets RUNS
+    // of XCD_GROUP consecutive blocks (its L2 keeps their tets) while the runs still interleave
+    // across the frame (an XCD owning one contiguous band would own all the misses or all the
+    // long rays).
+    const uint32_t nblk = (uint32_t)((t.num_items + WALK_BLOCK - 1) / WALK_BLOCK);
+    const uint32_t super = blockIdx.x / (8 * XCD_GROUP), rem = blockIdx.x % (8 * XCD_GROUP);
+    const uint32_t lb = super * 8 * XCD_GROUP + (rem & 7) * XCD_GROUP + (rem >> 3);
+    if (lb >= nblk) return;
+    const size_t ray = (size_t)lb * WALK_BLOCK + threadIdx.x;
+    const bool active = ray < t.num_items;
+    const size_t rr = active ? ray : 0;
+
+    const float ox = t.origins[3 * rr], oy = t.origins[3 * rr + 1], oz = t.origins[3 * rr + 2];
+    const float dx = t.dirs[3 * rr], dy = t.dirs[3 * rr + 1], dz = t.dirs[3 * rr + 2];
+    const RayPre rp = ray_pre(ox, oy, oz, dx, dy, dz);
+
+    bool flag = false;  // ray must be re-traced by the general path
+    uint32_t why = 0;   // first reason (1..12), counted in stats[4 + why]
+#if TN_WALK_DIAG
+    const unsigned long long tick0 = wall_clock64();
+#endif
+
+    // ------------------------------------------------------------------ hull crossing search
+    // Wave-uniform traversal of the (small) hull BVH: a node is visited if ANY lane's line hits
+    // its padded box; box / triangle data are read through uniform (scalar) loads, every lane
+    // tests its own ray.  No stack: the tree has a fixed depth (<= 3 internal levels).
+    // rounding distance of a projected vertex: the box padding of the BVH path (tn_device.h: line_box)
+    const float pad = 16.0f * 1.1920929e-7f * (fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))) + p.scene_max);
+    // Rule 8 (fold guard, see the header): delta = 7 * 2^-24 * (|o| + scene) bounds the error of a sheared 2-D vertex
+    // position; a tet whose neighbourhood holds a tet thinner than 32 delta (exponent compare, conservative) AND one
+    // of whose edges passes within 8 delta of the ray sends the ray to the BVH path.
+    const float delta = 0.21875f * pad;               // 7/32 of the box padding
+    const float kappa = 8.0f * delta;
+    const uint32_t thin_exp = (__float_as_uint(32.0f * delta) >> 23) & 0xFFu;
+    // RISK classes of the certification (round 5): the two guards above hand a ray over when it passes
+    // within 8 delta of a hull edge / of an edge of a thin-neighbourhood tet.  What is not proved is that the degenerate
+    // feature always lies THAT close to a tested edge, so the same tests with a wider band (option "risk_band": twice as wide
+    // = 16 delta by default) mark a certified ray as "at risk": every such ray -- not one in 256 -- is re-counted by the BVH
+    // cross-check (k_verify_counts).  bit 0: within 8 delta (hand over), bit 1: within the wide band (verify)
+    const float kappa2 = p.risk_band * kappa;
+    auto edge_band = [&](float e, const SV &X, const SV &Y) -> uint32_t {
+        const float len = fabsf(X.x - Y.x) + fabsf(X.y - Y.y), ae = fabsf(e);
+        return (ae <= kappa * len ? 1u : 0u) | (ae <= kappa2 * len ? 2u : 0u);
+    };
+    uint32_t risk = 0;   // bit 0: hull near-miss, bit 1: thin-neighbourhood near-miss
+    // the entry found by k_hull_entry
+    const uint4 ent = active ? p.hull_entry[ray] : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t ent_state = ent.z >> 29;
+    if (ent_state == 2u) { flag = true; why = (ent.z >> 24) & 15u; }
+    risk = (ent.z >> 28) & 1u;
     // ------------------------------------------------------------------ the walk
     // Every recorded (valid) hit k of this ray is one 16-byte entry of the hit log, at
     // log[(wave of 64 rays) * M + k][lane]: the lanes of a wave store consecutive bytes.
@@ -409,19 +531,17 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
     const size_t logoff = gw * (size_t)M * 64 + (size_t)lane;
     uint4 *mylog = p.hit_log + logoff;
 
-    bool alive = nhull == 2 && !flag;
-    const bool first0 = ht0 < ht1;
-    const uint32_t f_in0 = first0 ? hf0 : hf1;
-    const float t_out = first0 ? ht1 : ht0;
-    uint32_t c = 4u * (first0 ? hc0 : hc1) + (first0 ? he0 : he1);  // variant = (tet record, entry face)
-    if (!alive) c = 0;
+    bool alive = ent_state == 1u;
+    const uint32_t f_in0 = ent.y;
+    const float t_out = __uint_as_float(ent.w);
+    uint32_t c = alive ? ent.x : 0u;                                 // variant = (tet record, entry face)
     // The entry face in its STORED order: sheared vertices A,B,C and edge functions U=E(B,C), V=E(C,A), W=E(A,B).
     // From here on they are carried: the exit face of a step, evaluated in its stored order, is the entry face of
     // the next (same face-table entry), so per step only ONE vertex is sheared and three edge functions against
     // it decide the exit.
     SV A = {0.f, 0.f, 0.f}, B = A, C = A;
     if (alive) {
-        const float4 *tp = p.hull_tris + 3 * (size_t)(first0 ? hs0 : hs1);
+        const float4 *tp = p.hull_tris + 3 * (size_t)(ent.z & 0xFFFFFFu);
         const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
         A = shear(rp, v0.x, v0.y, v0.z); B = shear(rp, v1.x, v1.y, v1.z); C = shear(rp, v2.x, v2.y, v2.z);
         // a vertex of the entry face within rounding distance of the ray (reason 4, see the header)
@@ -452,6 +572,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         }
     }
 
+#if TN_WALK_DIAG
+    const unsigned long long tick1 = wall_clock64();
+#endif
     while (alive) {
         // All checks of a step accumulate into `bad` (first reason kept), straight-line: as nested ifs the checks
         // became a dozen exec-masked branches per step.
@@ -538,6 +661,19 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         Uc = U; Vc = V; Wc = W;
     }
 
+#if TN_WALK_DIAG
+    {
+        const unsigned long long tick2 = wall_clock64();
+        uint32_t ms = steps;
+        for (int off = 32; off; off >>= 1) { const uint32_t o2 = __shfl_xor(ms, off); ms = o2 > ms ? o2 : ms; }
+        if (lane == 0) {
+            atomicAdd(&g_walk_time[0], 1ull);
+            atomicAdd(&g_walk_time[1], tick1 - tick0); atomicAdd(&g_walk_time[2], tick2 - tick1);
+            atomicMax(&g_walk_time[3], tick1 - tick0); atomicMax(&g_walk_time[4], tick2 - tick1);
+            atomicMax(&g_walk_time[5], (unsigned long long)ms); atomicAdd(&g_walk_time[6], (unsigned long long)ms);
+        }
+    }
+#endif
     // ------------------------------------------------------------------ classes, hand-over lists, hit counts
     const bool order_ok = ord.finish(nhits);
     const bool drop2 = ord.drop2();
@@ -1004,6 +1140,12 @@ void launch_trace_walk(const WalkParams &p, hipStream_t stream, size_t lds_reser
     // grid padded so that the remap (runs of XCD_GROUP blocks per XCD) is a bijection
     const uint32_t unit = 8 * XCD_GROUP;
     const uint32_t grid = (nblk + unit - 1) / unit * unit;
+    // entry search: the flat hull table + the faces in LDS (up to 18 + 48 KB at HULL_FLAT_MAX faces)
+    const size_t need = p.n_hull_leaves ? (size_t)(p.n_hull_groups + p.n_hull_leaves) * 32 + (size_t)p.n_hull * 48 : 0;
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hull_entry), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)((HULL_FLAT_MAX / 2 + HULL_FLAT_MAX / 16) * 32 + HULL_FLAT_MAX * 48)) == hipSuccess;
+    if (need > 64 * 1024 && !big_lds) throw Error("k_hull_entry: the device refused " + std::to_string(need) + " bytes of dynamic LDS");
+    hipLaunchKernelGGL(k_hull_entry, dim3(grid), dim3(WALK_BLOCK), need, stream, p);
     if (lds_reserve > 64 * 1024) lds_reserve = 64 * 1024;
     if (p.cert_ends == 1u) hipLaunchKernelGGL(k_trace_walk<OrderR6>, dim3(grid), dim3(WALK_BLOCK), lds_reserve, stream, p);
     else if (p.cert_ends == 3u) hipLaunchKernelGGL(k_trace_walk<OrderR5e>, dim3(grid), dim3(WALK_BLOCK), lds_reserve, stream, p);
