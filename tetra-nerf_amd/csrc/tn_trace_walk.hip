@@ -399,11 +399,14 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_hull_entry(WalkParams p) {
         for (uint32_t i = threadIdx.x; i < 3u * p.n_hull; i += WALK_BLOCK) s_tri[i] = p.hull_tris[i];
         __syncthreads();
         const float4 *s_leaf = s_hull + 2u * p.n_hull_groups;
+        // boxes padded by TWICE the rounding distance: the graze guard of hull_face reaches 8 delta = 1.75 pad from an edge, and
+        // every face that close to the line must be looked at (the 2-face leaves are tighter than the tree's 4-face ones)
+        const float pad2 = 2.0f * pad;
         unsigned long long gm = 0ull;
         if (active)
             for (uint32_t g = 0; g < p.n_hull_groups; ++g) {     // uniform addresses: LDS broadcasts
                 const float4 a = s_hull[2 * g], b = s_hull[2 * g + 1];
-                gm |= line_box(ox, oy, oz, ix, iy, iz, a.x, a.y, a.z, b.x, b.y, b.z, pad) ? 1ull << g : 0ull;
+                gm |= line_box(ox, oy, oz, ix, iy, iz, a.x, a.y, a.z, b.x, b.y, b.z, pad2) ? 1ull << g : 0ull;
             }
         while (gm) {
             const uint32_t g = (uint32_t)__ffsll((long long)gm) - 1u;
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_hull_entry(WalkParams p) {
             for (uint32_t j = 0; j < 8; ++j) {
                 const uint32_t l = l0 + j < p.n_hull_leaves ? l0 + j : p.n_hull_leaves - 1u;
                 const float4 a = s_leaf[2 * l], b = s_leaf[2 * l + 1];
-                lm |= (l0 + j < p.n_hull_leaves && line_box(ox, oy, oz, ix, iy, iz, a.x, a.y, a.z, b.x, b.y, b.z, pad)) ? 1u << j : 0u;
+                lm |= (l0 + j < p.n_hull_leaves && line_box(ox, oy, oz, ix, iy, iz, a.x, a.y, a.z, b.x, b.y, b.z, pad2)) ? 1u << j : 0u;
             }
             while (lm) {
                 const uint32_t l = l0 + (uint32_t)__ffs((int)lm) - 1u;
@@ -572,6 +575,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_trace_walk(WalkParams p) {
         }
     }
 
+    // (round 6: issue priority by chord length -- s_setprio 3..0 by quarters of the hull diagonal, so that the longest rays of
+    // a frame go first -- changed nothing: +-0.2 %, profiles/r06aa_prio_sweep.txt)
 #if TN_WALK_DIAG
     const unsigned long long tick1 = wall_clock64();
 #endif
