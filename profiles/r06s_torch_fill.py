@@ -6,6 +6,8 @@ from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 cpp = importlib.import_module("tetra-nerf_amd.tetranerf_cpp_extension")
+import ctypes as _C
+lib = _C.CDLL(str(importlib.import_module("tetra-nerf_amd._lib").LIB_PATH))
 dev = torch.device("cuda:0")
 R, M = 640000, 512
 streams = [torch.cuda.Stream(dev) for _ in range(4)]
@@ -44,8 +46,16 @@ for t in range(int(sys.argv[1])):
             cur.wait_stream(s)
 
     a = nbytes / timed(lambda: cpp.fill_rows(vc, bc, hd, vi, 0)) / 1e6
+    flat = ""
+    if hasattr(lib, "tn_debug_fill_flat"):
+        import ctypes as C
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for mode in (1, 2):
+            f = lambda: lib.tn_debug_fill_flat(C.c_size_t(R), C.c_uint32(M), C.c_int(mode), C.c_void_p(vc.data_ptr()), C.c_void_p(bc.data_ptr()),
+                                               C.c_void_p(hd.data_ptr()), C.c_void_p(vi.data_ptr()), st)
+            flat += f"  flat mode {mode}: {nbytes / timed(f) / 1e6:5.0f}"
     each = [x.numel() * 4 / timed(lambda: x.zero_()) / 1e6 for x in arrs]
     b = nbytes / timed(seq) / 1e6
     c = nbytes / timed(par) / 1e6
-    print(f"alloc {t}: tn_fill_rows {a:5.0f}   torch fill each array " + " ".join(f"{e:5.0f}" for e in each) + f"   four in sequence {b:5.0f}   four streams at once {c:5.0f} GB/s", flush=True)
+    print(f"alloc {t}: tn_fill_rows {a:5.0f}{flat}   torch fill each array " + " ".join(f"{e:5.0f}" for e in each) + f"   four in sequence {b:5.0f}   four streams at once {c:5.0f} GB/s", flush=True)
     del vc, bc, hd, vi, arrs

@@ -14,7 +14,7 @@ variants = []
 for a in sys.argv[3:]:
     n, _, spec = a.partition(":")
     variants.append((n, [kv.split("=") for kv in spec.split(",") if kv]))
-DEFAULTS = {"cert_ends": 2, "verify_stride": 256, "fill_blocks": -1, "spec_blocks": 512, "spec_fill": 0, "writer_blocks": 0, "hull_flat": 1}
+DEFAULTS = {"cert_ends": 2, "verify_stride": 256, "fill_blocks": -1, "spec_blocks": 512, "spec_fill": 0, "spec_k0": 0, "writer_blocks": 0, "hull_flat": 1}
 CFG = {"C2": (15000, 0, 512), "C4": (45000, 2, 512), "C5": (150000, 3, 512)}
 npts, seed, M = CFG[name]
 pts, cells = scenes.random_mesh(npts, seed)

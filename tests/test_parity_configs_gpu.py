@@ -254,7 +254,7 @@ def test_adversarial_meshes_bit_exact(tn, device, oracle, scenes, name):
     flagged = {}
     # default schedule; speculative tail fill beside the walk, forced down to slot 64; persistent-wave tail fill; BVH path
     # (+ the count-only BVH cross-check of EVERY certified ray: it must never disagree with the walk)
-    for walk, extra in ((2, {"verify_stride": 1}), (2, {"spec_fill": 1, "spec_k0": 64}), (2, {"fill_blocks": 512}), (0, {})):
+    for walk, extra in ((2, {"verify_stride": 1}), (2, {"spec_fill": 1, "spec_k0": 64}), (2, {"fill_blocks": 512}), (2, {"fill_blocks": -1}), (0, {})):
         tr = _tracer(tn, device, pts, cells, walk=walk, **extra)
         for sname, (o, d) in _ray_sets(scenes, pts, 20000, 40, pts.min(0), pts.max(0)).items():
             out = _trace(tr, device, o, d, 512)
@@ -317,7 +317,7 @@ def test_randomised_stress_sample(tn, device, oracle, scenes):
             w = int(np.sqrt(R))
             o, d = scenes.pinhole_rays(w, w, eye=(0.5 + 1.7 * np.cos(seed), 0.5 + 1.7 * np.sin(seed), 0.6), lookat=(0.5, 0.5, 0.5))
         tr = _tracer(tn, device, pts, cells, walk=2, spec_fill=int(rng.choice([0, 1])), spec_k0=int(rng.choice([0, 32, 96])),
-                     fill_blocks=int(rng.choice([-1, -1, 512, 100000])), literal=int(rng.choice([0, 1, 1])))
+                     fill_blocks=int(rng.choice([-2, -2, -1, 512, 100000])), spec_blocks=int(rng.choice([512, -1, -2])), literal=int(rng.choice([0, 1, 1])))
         _compare(_trace(tr, device, o, d, M), _oracle(oracle, pts, cells), o, d, M,
                  ctx=f"stress case {case}: npts={npts} seed={seed} M={M} kind={kind}")
 
@@ -352,7 +352,7 @@ def test_speculative_fill_is_overwritten_by_every_ray_class(tn, device, oracle, 
     tr.set_option("cert_ends", 1)
     tr.set_option("spec_fill", 1)       # off by default since round 6
     assert st["walk"] > 1000 and why.get(13, 0) > 50 and sum(v for k, v in why.items() if k in (1, 2, 3, 4, 5, 6, 9, 10, 11)) > 50, (st, why)
-    for k0, ends, grid in ((0, 1, -1), (64, 1, 512), (32, 1, -1), (0, 0, -1), (32, 0, 2048), (0, 3, 512), (64, 3, -1)):
+    for k0, ends, grid in ((0, 1, -2), (64, 1, 512), (32, 1, -1), (0, 0, -2), (32, 0, 2048), (0, 3, 512), (64, 3, -2)):
         tr.set_option("spec_k0", k0)
         tr.set_option("cert_ends", ends)
         tr.set_option("fill_blocks", grid)
@@ -361,7 +361,7 @@ def test_speculative_fill_is_overwritten_by_every_ray_class(tn, device, oracle, 
             g = out[k].cpu().numpy()
             assert np.array_equal(g.view(np.uint32), np.ascontiguousarray(want[k]).view(np.uint32)), f"spec_k0={k0}: {k}"
     # the same with the fill switched off and through the BVH path alone
-    for opts in ({"spec_fill": 0}, {"spec_fill": 0, "fill_blocks": 512}, {"walk": 0}):
+    for opts in ({"spec_fill": 0}, {"spec_fill": 0, "fill_blocks": 512}, {"spec_fill": 0, "fill_blocks": -1}, {"spec_fill": 1, "spec_blocks": -2}, {"walk": 0}):
         tr2 = _tracer(tn, device, pts, cells, **{"walk": 2, **opts})
         out = _trace(tr2, device, o, d, M)
         for k in KEYS:

@@ -54,7 +54,7 @@ struct tn_tracer {
     // -5.9 / -6.6 / -1.3 % on the C2 / C4 frames / C5 rays, averaged over fresh allocations of the rows in one process
     // (profiles/r06u_alloc_sweep.txt; persistent waves at 512 ... 160000 blocks: r06t_alloc_sweep*.txt).  With the round's
     // faster writer the overlap of fill and walk had stopped paying (r06r_spec_sweep.txt: on / off +-0.4 %).
-    unsigned fill_blocks = tn::FILL_FINE; // grid of the tail fill (option "fill_blocks": -1 = one block per row, else persistent waves)
+    unsigned fill_blocks = tn::FILL_FINE; // grid of the tail fill (option "fill_blocks": -2 = one linear stream per array, -1 = one block per row, else persistent waves)
     unsigned walk_lds_kb = 26;           // dynamic LDS reserved per walk block beside a speculative fill (0: no limit)
     bool small_lds = true;               // small batches: LDS hit arrays sized for the mesh, overflow rays in a second launch
     unsigned lds_cap = 0;                // 0: from the mesh size; otherwise the entries of the small arrays (power of two; tests)
@@ -562,6 +562,8 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 int mark_i = 0;
                 auto mark = [&] { if (timing) TN_HIP(hipEventRecord(t->tev[mark_i++], stream)); };
                 mark();                                                   // 0: start
+                // (round 6: [K0, M) of every row through k_fill_linear BEFORE the walk, the short [ceil32(n), K0) pieces after the
+                // writer: +6 ... 15 % on the frames for K0 = 32 ... 192, +2 ... 8 % at 1M tets, profiles/r06ad_bulk_sweep*.txt)
                 if (K0) {
                     TN_HIP(hipEventRecord(t->ev_start, stream));
                     TN_HIP(hipStreamWaitEvent(s_pre, t->ev_start, 0));
@@ -825,7 +827,7 @@ int tn_fill_rows(size_t R, uint32_t M, uint32_t first_slot, uint32_t *visited, f
         // rows are written from a 128-byte line boundary of all four arrays on (multiples of 32 slots), like the tracer's own fill;
         // any other first slot is refused rather than rounded: rounding down would overwrite up to 31 written segments
         if (first_slot & 31u) throw tn::Error("tn_fill_rows: first_slot must be a multiple of 32");
-        tn::launch_fill_range(R, M, true, nullptr, nullptr, visited, bary, dist, verts, (hipStream_t)stream_, first_slot, false, 512);
+        tn::launch_fill_range(R, M, true, nullptr, nullptr, visited, bary, dist, verts, (hipStream_t)stream_, first_slot, false, tn::FILL_LINEAR);   // no per-row lookups here: one linear stream per array
         TN_HIP(hipGetLastError());
     });
 }
@@ -847,10 +849,10 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
         else if (k == "literal") t->literal = value != 0;
         else if (k == "spec_fill") t->spec_fill = value != 0;
         else if (k == "spec_k0") t->spec_k0 = (unsigned)value;
-        else if (k == "spec_blocks") t->spec_blocks = value < 0 ? tn::FILL_FINE : (unsigned)value;
+        else if (k == "spec_blocks") t->spec_blocks = value == -2 ? tn::FILL_LINEAR : value < 0 ? tn::FILL_FINE : (unsigned)value;
         else if (k == "hull_flat") t->hull_flat = value != 0;
         else if (k == "writer_blocks") t->writer_blocks = (unsigned)value;
-        else if (k == "fill_blocks") t->fill_blocks = value < 0 ? tn::FILL_FINE : (unsigned)value;    // -1: one block per row
+        else if (k == "fill_blocks") t->fill_blocks = value == -2 ? tn::FILL_LINEAR : value < 0 ? tn::FILL_FINE : (unsigned)value;    // -1: one block per row
         else if (k == "walk_lds_kb") t->walk_lds_kb = (unsigned)value;
         else if (k == "small_lds") t->small_lds = value != 0;
         else if (k == "lds_cap") {

@@ -102,6 +102,7 @@ struct WriteParams {
 void launch_write_segments(const WriteParams &q, hipStream_t stream, unsigned max_blocks = 0);
 // all_rows: slots [k_split, M) of every row; otherwise slots [ceil32(out_num[r]), k_split) of the certified rows
 constexpr unsigned FILL_FINE = 0xFFFFFFFFu;   // max_blocks value: one block per row (k_fill_rows_fine)
+constexpr unsigned FILL_LINEAR = 0xFFFFFFFEu; // max_blocks value: one linear stream per array, one store per thread (k_fill_linear)
 void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *walk_n, const uint32_t *out_num,
                        uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
                        uint32_t k_split, bool nontemporal, unsigned max_blocks = 0);

@@ -1051,10 +1051,76 @@ __global__ __launch_bounds__(256) void k_fill_rows_fine(size_t num_rays, uint32_
     }
 }
 
+// The same rows as ONE LINEAR STREAM PER ARRAY, the arrays one after the other, one 16-byte store per thread and the thread
+// is gone (round 6, the last of the fill experiments and the first to explain them).  Fresh allocations of the same rows
+// in one process (same virtual addresses, new physical pages) moved every fill that writes the four arrays IN STEP -- rows
+// dealt to persistent waves, a block per row, even torch-style one-store blocks interleaved 1 : 2 : 6 : 4 -- between 5.6 and
+// 7.1 TB/s, while a single linear stream (this order; torch's own fill) stays at 7.0 - 7.15 TB/s wherever the pages lie
+// (profiles/r06s_flat_fill.txt, r06s_torch_fill.txt, r06s_placement.txt).
+//   block -> (array, 256 consecutive 16-byte units of it); a row holds M/4, M/2, 3M/2, M units (cells, distances,
+//   barycentrics, vertex ids): powers of two and 3 x a power of two, so the row of a unit costs a shift (and a division by 3).
+template <bool NT>
+__global__ __launch_bounds__(256) void k_fill_linear(size_t num_rays, uint32_t M, uint32_t all_rows, uint32_t k_split, uint32_t log2_m4,
+                                                     unsigned long long n_bary, unsigned long long n_verts, unsigned long long n_dist,
+                                                     const uint32_t *__restrict__ walk_n, const uint32_t *__restrict__ out_num,
+                                                     uint32_t *__restrict__ out_cells, float *__restrict__ out_bary,
+                                                     float *__restrict__ out_dist, uint32_t *__restrict__ out_verts) {
+    // n_bary / n_verts / n_dist: first block of the NEXT array (blocks are dealt bary, verts, dist, cells: largest first)
+    unsigned long long b = blockIdx.x;
+    u32x4 *base; uint32_t w4, sh; uint32_t val; bool three = false;     // w4 = 16-byte units per 4 slots; units per row = (M/4 << sh) (x3)
+    if (b < n_bary) { base = reinterpret_cast<u32x4 *>(out_bary); w4 = 6; sh = 1; three = true; val = 0u; }
+    else if (b < n_verts) { b -= n_bary; base = reinterpret_cast<u32x4 *>(out_verts); w4 = 4; sh = 2; val = TN_EMPTY; }
+    else if (b < n_dist) { b -= n_verts; base = reinterpret_cast<u32x4 *>(out_dist); w4 = 2; sh = 1; val = 0u; }
+    else { b -= n_dist; base = reinterpret_cast<u32x4 *>(out_cells); w4 = 1; sh = 0; val = TN_EMPTY; }
+    const unsigned long long g = b * 256ull + threadIdx.x;             // unit of the array
+    const uint32_t q = (uint32_t)(g >> (log2_m4 + sh));                // (x3 arrays: the row's third; else the row)
+    const uint32_t row = three ? q / 3u : q;
+    if (row >= num_rays) return;
+    const uint32_t upr = (three ? 3u : 1u) << (log2_m4 + sh);          // units per row
+    const uint32_t off = (uint32_t)(g - (unsigned long long)row * upr);
+    uint32_t lo = k_split, hi = M;
+    if (!all_rows) {
+        // (a per-row lookup in front of the one store: the wave then lives for a load latency per KB and the fill is bound by
+        // THAT -- 6.0 instead of 3.3 ms per C2 frame; four chunks per block with the lookups up front: 4.2 ms and the pure
+        // fill falls to 6.0 - 6.5 TB/s, profiles/r06ac_linear_sweep*.txt.  So the tracer's tail fill, which needs the
+        // lookup, stays with k_fill_rows_fine, and this kernel serves tn_fill_rows and option fill_blocks = -2)
+        if (walk_n[row] == TN_EMPTY) return;      // literal / fallback ray: those kernels write the whole row
+        lo = (out_num[row] + 31u) & ~31u;
+        if (lo > M) lo = M;
+        hi = k_split;
+    }
+    // lo, hi are multiples of 4 slots: [lo, hi) slots = [lo / 4 * w4, hi / 4 * w4) units
+    if (off < (lo >> 2) * w4 || off >= (hi >> 2) * w4) return;
+    const u32x4 v4 = {val, val, val, val};
+    if constexpr (NT) __builtin_nontemporal_store(v4, base + g);
+    else base[g] = v4;
+}
+
 void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_t *walk_n, const uint32_t *out_num,
                        uint32_t *out_cells, float *out_bary, float *out_dist, uint32_t *out_verts, hipStream_t stream,
                        uint32_t k_split, bool nontemporal, unsigned max_blocks) {
     if (num_rays == 0) return;
+    if (max_blocks == FILL_LINEAR) {
+        if (M < 4 || (M & (M - 1)) != 0) throw Error("k_fill_linear: M must be a power of two >= 4");
+        uint32_t log2_m4 = 0;
+        while ((4u << log2_m4) < M) ++log2_m4;
+        const size_t cap_rows = 0x200000u;          // rows per launch: 2^21 rows x 13 M / 1024 blocks (1.1e8 at M = 4096) stays below 2^31
+        for (size_t base = 0; base < num_rays; base += cap_rows) {
+            const size_t n = num_rays - base < cap_rows ? num_rays - base : cap_rows;
+            const unsigned long long u_cells = (unsigned long long)n * (M / 4);
+            auto blocks_of = [](unsigned long long units) { return (units + 255ull) / 256ull; };
+            const unsigned long long nb = blocks_of(6 * u_cells), nv = nb + (out_verts ? blocks_of(4 * u_cells) : 0ull),
+                                     nd = nv + blocks_of(2 * u_cells), total = nd + blocks_of(u_cells);
+            if (total > 0x7FFFFFFFull) throw Error("k_fill_linear: grid too large");
+            auto args = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), 0, stream, n, M, all_rows ? 1u : 0u, k_split, log2_m4, nb, nv, nd,
+                                   walk_n ? walk_n + base : nullptr, out_num ? out_num + base : nullptr, out_cells + base * M,
+                                   out_bary + base * M * 6, out_dist + base * M * 2, out_verts ? out_verts + base * M * 4 : nullptr);
+            };
+            if (nontemporal) args(k_fill_linear<true>); else args(k_fill_linear<false>);
+        }
+        return;
+    }
     if (max_blocks == FILL_FINE) {
         for (size_t base = 0; base < num_rays; base += 0x40000000u) {     // grid.x limit
             const size_t n = num_rays - base < 0x40000000u ? num_rays - base : 0x40000000u;
