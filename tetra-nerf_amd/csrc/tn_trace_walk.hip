@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_fill_rows_fine(size_t num_rays, uint32_
 // (profiles/r06s_flat_fill.txt, r06s_torch_fill.txt, r06s_placement.txt).
 //   block -> (array, 256 consecutive 16-byte units of it); a row holds M/4, M/2, 3M/2, M units (cells, distances,
 //   barycentrics, vertex ids): powers of two and 3 x a power of two, so the row of a unit costs a shift (and a division by 3).
-template <bool NT>
+template <bool NT, bool UNI>
 __global__ __launch_bounds__(256) void k_fill_linear(size_t num_rays, uint32_t M, uint32_t all_rows, uint32_t k_split, uint32_t log2_m4,
                                                      unsigned long long n_bary, unsigned long long n_verts, unsigned long long n_dist,
                                                      const uint32_t *__restrict__ walk_n, const uint32_t *__restrict__ out_num,
@@ -1082,10 +1082,19 @@ __global__ __launch_bounds__(256) void k_fill_linear(size_t num_rays, uint32_t M
     if (!all_rows) {
         // (a per-row lookup in front of the one store: the wave then lives for a load latency per KB and the fill is bound by
         // THAT -- 6.0 instead of 3.3 ms per C2 frame; four chunks per block with the lookups up front: 4.2 ms and the pure
-        // fill falls to 6.0 - 6.5 TB/s, profiles/r06ac_linear_sweep*.txt.  So the tracer's tail fill, which needs the
-        // lookup, stays with k_fill_rows_fine, and this kernel serves tn_fill_rows and option fill_blocks = -2)
-        if (walk_n[row] == TN_EMPTY) return;      // literal / fallback ray: those kernels write the whole row
-        lo = (out_num[row] + 31u) & ~31u;
+        // fill falls to 6.0 - 6.5 TB/s; the lookup through the scalar cache (this code): 5.4 ms; a block per row with the
+        // arrays one after the other: 4.1 ms, steadier (3.97 - 4.21) but never below the block-per-row fill of all four
+        // arrays (3.24 - 4.02); profiles/r06ac_linear_sweep*.txt, r06ae_*.txt.  So the tracer's tail fill, which needs
+        // the lookup, stays with k_fill_rows_fine, and this kernel serves tn_fill_rows and option fill_blocks = -2)
+        uint32_t wn, n;
+        if constexpr (UNI) {   // M >= 256: a wave's 64 units lie in one row -> the lookup goes through the scalar cache
+            const uint32_t rs = (uint32_t)__builtin_amdgcn_readfirstlane((int)row);
+            wn = walk_n[rs]; n = out_num[rs];
+        } else {
+            wn = walk_n[row]; n = out_num[row];
+        }
+        if (wn == TN_EMPTY) return;               // literal / fallback ray: those kernels write the whole row
+        lo = (n + 31u) & ~31u;
         if (lo > M) lo = M;
         hi = k_split;
     }
@@ -1117,7 +1126,8 @@ void launch_fill_range(size_t num_rays, uint32_t M, bool all_rows, const uint32_
                                    walk_n ? walk_n + base : nullptr, out_num ? out_num + base : nullptr, out_cells + base * M,
                                    out_bary + base * M * 6, out_dist + base * M * 2, out_verts ? out_verts + base * M * 4 : nullptr);
             };
-            if (nontemporal) args(k_fill_linear<true>); else args(k_fill_linear<false>);
+            if (M >= 256) { if (nontemporal) args(k_fill_linear<true, true>); else args(k_fill_linear<false, true>); }
+            else { if (nontemporal) args(k_fill_linear<true, false>); else args(k_fill_linear<false, false>); }
         }
         return;
     }
