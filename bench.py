@@ -153,10 +153,10 @@ def render_leg(tn, tracer, num_vertices, o, d, M, dev, samples=256, chunk=65536,
 
 
 def box_write_ceiling(tn, out, reps=5):
-    """The write rate THIS box sustains, measured in this process: the product's own tail-fill kernel (k_fill_range,
-    tn_fill_rows) ALONE over every slot of the dense rows of one bench launch.  88 % of a trace_rays call's bytes are
-    these constant tails, so this is the ceiling of the call on this box (boxes of this pool differ by +-12 %: the
-    same kernel writes 5.1 TB/s on some and 6.6 TB/s on others)."""
+    """The write rate THIS box sustains, measured in this process: tn_fill_rows (k_fill_linear: one linear stream per array,
+    one 16-byte store per thread -- since round 6 the one fill whose rate does not depend on where the driver put the
+    pages, 7.0 - 7.15 TB/s, profiles/r06s_flat_fill.txt) ALONE over every slot of the dense rows of one bench launch.
+    88 % of a trace_rays call's bytes are these constant tails, so this is the ceiling of the call on this box."""
     cpp = tn.cpp
     args = (out["visited_cells"], out["barycentric_coordinates"], out["hit_distances"], out["vertex_indices"])
     R, M = out["visited_cells"].shape
@@ -171,7 +171,7 @@ def box_write_ceiling(tn, out, reps=5):
     ms = e0.elapsed_time(e1) / reps
     nbytes = R * M * 52
     return {"GBps": nbytes / (ms * 1e-3) / 1e9, "bytes": nbytes, "ms": ms,
-            "kernel": "k_fill_range (tn_fill_rows) alone, all slots of the bench launch's rows, same process"}
+            "kernel": "k_fill_linear (tn_fill_rows) alone, all slots of the bench launch's rows, same process"}
 
 
 def trace_breakdown(tracer, o, d, M):
@@ -845,10 +845,10 @@ def main():
                 "traffic_source": "committed rocprofv3 PMC passes of this command (profiles/traffic.json), not read in this run",
                 # `achieved` / `frac` are LAUNCH figures (conservative): the whole trace_rays call -- walk, segment writer, tail
                 # fills, literal pairing, BVH fallback, cross-check -- over the HIP-event duration of the call.  The dominant
-                # kernel by time and bytes is k_fill_range (the constant tails, 88 % of the bytes): its own rate is
-                # `box_write_ceiling_GBps`, measured in this process on this box
-                "kernel": "trace_rays launch: k_trace_walk, k_write_segments, 2 x k_fill_range (dominant), k_postprocess_log, "
-                          "k_trace_general, k_verify_counts",
+                # kernel by time and bytes is k_fill_rows_fine (the constant tails, 88 % of the bytes); what a pure fill
+                # of the same rows reaches on this box, in this process, is `box_write_ceiling_GBps`
+                "kernel": "trace_rays launch: k_hull_entry, k_trace_walk, k_write_segments, k_fill_rows_fine (dominant), "
+                          "k_postprocess_log, k_trace_general, k_verify_counts",
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                 "box_write_ceiling_GBps": ceiling["GBps"], "box_write_ceiling": ceiling,
                 "frac_of_box_write_ceiling": achieved / ceiling["GBps"],

@@ -10,7 +10,8 @@ import json
 import sys
 from pathlib import Path
 
-KERNELS = {"k_trace_walk": 1, "k_write_segments": 1, "k_fill_range<false>": 1, "k_fill_range<true>": 1, "k_postprocess_log": 1,
+KERNELS = {"k_hull_entry": 1, "k_trace_walk": 1, "k_write_segments": 1, "k_fill_range<false>": 1, "k_fill_range<true>": 1,
+           "k_fill_rows_fine": 1, "k_fill_linear": 1, "k_postprocess_log": 1,
            "k_trace_general": 2, "k_verify_counts": 2}
 
 
@@ -46,7 +47,7 @@ doc = {"workload": {"mesh_points": 15000, "mesh_seed": 0, "rays": R, "M": M},
        "write_bytes": int(w), "fetch_bytes_counter": int(f), "ratio": (w + 2 * f) / alg,
        "write_bytes_per_kernel": {k: int(v) for k, v in wp.items()}, "fetch_bytes_per_kernel": {k: int(v) for k, v in fp.items()},
        "how": "rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE in separate passes of `python bench.py --steps 3 --warmup 1 "
-              "--no-cpu-baseline --no-render --no-configs --no-calibration` (profiles/r05end_call.sh -> " + Path(sys.argv[1]).name +
+              "--no-cpu-baseline --no-render --no-configs --no-calibration` (profiles/r06zz_call.sh -> " + Path(sys.argv[1]).name +
               ", " + Path(sys.argv[2]).name + "); profiles/make_traffic.py: per dense launch = max over dispatches of every kernel of "
               "the call (the min is the compact-rows leg), WRITE_SIZE + 2 x FETCH_SIZE (gfx950 wide-read correction)",
        "round": sys.argv[3]}
