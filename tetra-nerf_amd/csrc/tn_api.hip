@@ -563,7 +563,8 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
                 auto mark = [&] { if (timing) TN_HIP(hipEventRecord(t->tev[mark_i++], stream)); };
                 mark();                                                   // 0: start
                 // (round 6: [K0, M) of every row through k_fill_linear BEFORE the walk, the short [ceil32(n), K0) pieces after the
-                // writer: +6 ... 15 % on the frames for K0 = 32 ... 192, +2 ... 8 % at 1M tets, profiles/r06ad_bulk_sweep*.txt)
+                // writer: +6 ... 15 % on the frames for K0 = 32 ... 192, +2 ... 8 % at 1M tets, profiles/r06ad_bulk_sweep*.txt; the same
+                // with a block per (array, row): +11 ... 20 %, r06af_bulk_rows_sweep.txt)
                 if (K0) {
                     TN_HIP(hipEventRecord(t->ev_start, stream));
                     TN_HIP(hipStreamWaitEvent(s_pre, t->ev_start, 0));
