@@ -271,12 +271,19 @@ int tn_fill_rows(size_t num_rays, uint32_t max_ray_triangles, uint32_t first_slo
  *             Tracer-wide; prefer the per-call flag TN_TRACE_COMPACT_ROWS of tn_trace_rays_ex
  *   "literal" 1 (default) = rays whose order the walk cannot certify have their logged hits sorted and paired
  *             literally; 0 = they are re-traced through the BVH all-hits path (cross-check of the two paths)
- *   "spec_fill"  1 (default) = the last quarter / half of every row (slots no ray, or hardly any ray, of this mesh reaches)
- *             is filled beside the walk on a stream of its own; 0 = the whole tail fill after the segment writer.
- *             "spec_k0" = first speculatively filled slot (multiple of 32; 0 = the rule of tn_api.hip) -- tests force it
- *             low so that rays of every class overwrite speculatively filled slots; "spec_blocks" (512) = grid of that
- *             fill, "walk_lds_kb" (26) = dynamic LDS reserved per walk block beside it (an occupancy limit that keeps both
- *             kernels resident): sweeps
+ *   "spec_fill"  1 = the last quarter / half of every row (slots no ray, or hardly any ray, of this mesh reaches) is filled
+ *             beside the walk on a stream of its own (the schedule of rounds 2-5); 0 (default since round 6) = the whole
+ *             tail fill after the segment writer.  "spec_k0" = first speculatively filled slot (multiple of 32; 0 = the
+ *             rule of tn_api.hip) -- tests force it low so that rays of every class overwrite speculatively filled slots;
+ *             "spec_blocks" (512) = grid of that fill, "walk_lds_kb" (26) = dynamic LDS reserved per walk block beside it
+ *   "fill_blocks"  grid of the tail fill: -1 (default) = one block per row (k_fill_rows_fine), -2 = one linear stream per
+ *             array with one store per thread (k_fill_linear: what tn_fill_rows uses), n > 0 = n blocks of persistent waves
+ *   "writer_blocks"  grid of the segment writer (0 = default: 2 blocks per CU, what is resident at once)
+ *   "hull_flat"  1 (default) = the walk's entry search (k_hull_entry) goes through the flat box table staged in LDS when the
+ *             hull has at most 1024 faces; 0 = the threaded hull tree for every hull size (tests, A/B)
+ *   "cert_ends"  statement of the walk's order test: 0 round 5's pairwise test, 3 the same + the end-of-chain rules A-C,
+ *             1 the cluster test with rules A-D, 2 (default) = by mesh size.  Moves rays between the segment writer and the
+ *             literal pairing kernel, never a byte of a row
  *   "log_cap_mb"  cap of the hit log in MiB (0 = default: a quarter of the free device memory, at most 24 GiB);
  *             larger calls are processed in ray chunks
  *   "gpu_build"  1 (default) = load_tetrahedra builds its structures on the device; 0 = single-threaded host build
@@ -284,7 +291,7 @@ int tn_fill_rows(size_t num_rays, uint32_t max_ray_triangles, uint32_t first_slo
  *             path tests 64 / leaf_width crossed leaves per wave instruction
  *   "small_lds"  1 (default) = batches below walk_min_rays use LDS hit arrays sized for the mesh (every ray resident at
  *             once) and re-trace the rays with more hits in a second launch; "lds_cap" forces their size (tests)
- *   "verify_stride"  k > 0 (default 1024; 256 until round 5, when the risk classes below took over most of the work): every k-th ray
+ *   "verify_stride"  k > 0 (default 256): every k-th ray
  *             the walk certified is cross-checked: a count-only BVH all-hits
  *             traversal must find exactly the faces the walk logged, otherwise the ray is re-traced through the BVH path and
  *             counted in tn_trace_flag_reasons()[14].  A one-chunk call runs the check beside the row writers (< 1 % of the
