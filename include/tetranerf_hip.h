@@ -262,7 +262,8 @@ int tn_fill_rows(size_t num_rays, uint32_t max_ray_triangles, uint32_t first_slo
 /* knobs ("walk" and "gpu_build" also through the environment: TETRANERF_HIP_WALK, TETRANERF_HIP_GPU_BUILD):
  *   "walk"    1 = adjacency-walk fast path with general-path fallback (default),
  *             0 = general all-hits path for every ray, 2 = walk for any batch size
- *   "walk_min_rays"  smallest batch the walk is used for (default 12288; below it one wavefront per
+ *   "walk_min_rays"  smallest batch the walk is used for (default 12288; 8192 from 2M tets, 6144 from 4M tets on until
+ *             the option is set; below it one wavefront per
  *             ray through the wide BVH has the lower latency).  Whatever the options say, the walk path needs
  *             max_ray_triangles >= 4 (16-byte stores into the rows); 1 and 2 take the BVH path
  *   "dense_tails"  1 (default) = every slot of the [R,M] rows is written, as the reference does;

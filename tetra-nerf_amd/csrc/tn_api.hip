@@ -111,7 +111,10 @@ struct tn_tracer {
     unsigned risk_band = 2;              // option "risk_band": width of the risk classes' band, in units of the guards' 8 delta
     size_t last_num_rays = 0;
     int use_walk = 1;                    // 0 never, 1 from walk_min_rays rays on, 2 always
-    size_t walk_min_rays = 12288;        // measured crossover on the 300k-tet mesh after round 2b's faster BVH path
+    size_t walk_min_rays = 12288;        // measured crossover on the 100k ... 1M-tet meshes (round 6 again: profiles/r06y_batch_crossover.txt)
+    bool walk_min_auto = true;           // ... and by mesh size above that (until option "walk_min_rays" is set): the BVH path's LDS hit arrays grow
+                                         // with the mesh, a batch then needs several rounds of waves: 8192 from 2M tets, 6144 from 4M tets on
+                                         // (2.7 M / 6.7 M tets at 8192 rays: BVH 2.11 / 3.37 ms, walk 2.02 / 2.68; profiles/r06al_big_mesh_batches.txt)
                                          // (profiles/r02t_crossover.txt: 8192 rays 0.46-0.49 vs 0.61-0.71 ms, 12288 rays 0.68-0.90 vs
                                          //  0.67-0.82 ms, 16384 rays 0.89-1.16 vs 0.67-0.84 ms; round 2a: 6144)
     bool last_walk = false;
@@ -431,7 +434,9 @@ static int trace_rays_common(tn_tracer_t tracer, size_t R, uint32_t M, const flo
         // so the walk is used from `walk_min_rays` on (use_walk == 2 forces it for any size).
         // M >= 4: the writer and the fills store 16-byte vectors into the rows; M is a power of two (checked above), so
         // from 4 on every row base is 16-byte aligned
-        const bool walk = t->use_walk && (R >= t->walk_min_rays || t->use_walk == 2) && M >= 4 &&
+        const size_t walk_min = !t->walk_min_auto ? t->walk_min_rays
+                              : t->mesh.T >= 4000000u ? (size_t)6144 : t->mesh.T >= 2000000u ? (size_t)8192 : t->walk_min_rays;
+        const bool walk = t->use_walk && (R >= walk_min || t->use_walk == 2) && M >= 4 &&
                           t->mesh.n_hull > 0 && t->mesh.n_hull < (1u << 24);   // (HullEntry keeps the face's slot in 24 bits)
         t->last_walk = walk;
         if (walk) {
@@ -845,7 +850,7 @@ int tn_set_option(tn_tracer_t tracer, const char *name, int value) {
             t->leaf_width = (unsigned)value;
         }
         else if (k == "walk") t->use_walk = value < 0 ? 0 : (value > 2 ? 2 : value);
-        else if (k == "walk_min_rays") t->walk_min_rays = value < 0 ? 0 : (size_t)value;
+        else if (k == "walk_min_rays") { t->walk_min_rays = value < 0 ? 0 : (size_t)value; t->walk_min_auto = false; }
         else if (k == "dense_tails") t->dense_tails = value != 0;
         else if (k == "literal") t->literal = value != 0;
         else if (k == "spec_fill") t->spec_fill = value != 0;
