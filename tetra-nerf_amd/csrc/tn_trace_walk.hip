@@ -4,7 +4,7 @@
 // f0 < f1 < ... < fn in which consecutive faces bound the tetrahedron between them.  Instead
 // of collecting all hits through a BVH and sorting them (the reference's structure,
 // src/optix/optix_trace_rays.cu:268-331 + :78-108), a lane walks the chain: find the two hull
-// faces the ray's line crosses, then step tet -> neighbour tet through 64-byte records specialised
+// faces the ray's line crosses (k_hull_entry), then step tet -> neighbour tet through 64-byte records specialised
 // by entry face (WalkVar, tn_common.h), producing the faces already in order.  Per step: one
 // dependent record load, ONE vertex shear, three edge functions against the carried entry face to
 // pick the exit, the exit face's three edge functions in its stored order, one (t,u,v).
@@ -90,9 +90,10 @@
 // {t, u, v, variant | exit << 30} at log[wave of 64 rays][hit index][lane] -- the 64 lanes of a wave store 1 KB of
 // consecutive bytes per step, and the log is 16 B per hit instead of 52 B per segment.  k_write_segments turns
 // the log of the certified rays into segment records (whole 128-byte lines, one wave per 8 rays, staged through LDS so
-// that every store instruction writes contiguous runs), k_fill_range streams the constant tails: the last quarter of
-// every row BESIDE the walk (slots no ray of the mesh is expected to reach need nothing from it; the walk is bound by
-// VALU issue, the fill by HBM writes), slots [ceil32(n), 3M/4) of the certified rows after the segment writer.
+// that every store instruction writes contiguous runs), k_fill_rows_fine -- one short-lived block per row -- streams the
+// constant tails [ceil32(n), M) of the certified rows after the segment writer (rounds 2-5 filled the last quarter of every
+// row BESIDE the walk with persistent waves: option spec_fill = 1 / k_fill_range; since round 6's faster writer that overlap
+// no longer pays).  The entry search is a kernel of its own (k_hull_entry: the hull's boxes and faces in LDS).
 // blockIdx is remapped so each XCD owns runs of 16 consecutive blocks (4096 neighbouring rays) and its L2 keeps
 // the tets they cross.
 #include "tn_device.h"
