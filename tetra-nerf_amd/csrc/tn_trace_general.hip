@@ -501,6 +501,14 @@ __device__ uint32_t collect_hits(const WideBvh &bvh, WaveSmem &s, uint32_t M, ui
         return nh;
 }
 
+#if TN_WALK_DIAG
+__device__ unsigned long long g_gen_time[8];   // 100 MHz ticks: [0] rays, [1] traversal + leaf tests, [2] sort, [3] pairing + row write, [4] nodes, [5] leaves, [6] hits
+extern "C" int tn_debug_general_time(unsigned long long out[8], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gen_time), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_gen_time), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
@@ -517,10 +525,16 @@ __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
     for (size_t it = blockIdx.x; it < n_items; it += gridDim.x) {
         const size_t ray = p.ray_list ? (size_t)p.ray_list[it] : it;
         bool overflow = false;
+#if TN_WALK_DIAG
+        const unsigned long long tk0 = wall_clock64();
+#endif
         uint32_t nh = collect_hits(p.bvh, s, C, cap, p.origins[3 * ray], p.origins[3 * ray + 1], p.origins[3 * ray + 2],
                                    p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2],
                                    nullptr,
                                    lane, overflow, defer);
+#if TN_WALK_DIAG
+        const unsigned long long tk1 = wall_clock64();
+#endif
         if (overflow && defer) {
             if (lane == 0) p.overflow_list[atomicAdd(p.overflow_count, 1u)] = (uint32_t)ray;
             continue;
@@ -528,10 +542,20 @@ __global__ __launch_bounds__(64) void k_trace_general(TraceParams p) {
         if (overflow && lane == 0 && p.stats) atomicAdd(&p.stats[3], 1ull);
 
         sort_hits(s, nh, lane);
+#if TN_WALK_DIAG
+        const unsigned long long tk2 = wall_clock64();
+#endif
         postprocess_and_write(s, nh, M, p.faces, p.face_tets, p.out_num + ray, p.out_cells + ray * M,
                               p.out_bary + ray * M * 6, p.out_dist + ray * M * 2,
                               p.out_verts ? p.out_verts + ray * M * 4 : nullptr, p.stats, lane, p.compact_rows != 0);
         wave_sync();
+#if TN_WALK_DIAG
+        if (lane == 0) {
+            const unsigned long long tk3 = wall_clock64();
+            atomicAdd(&g_gen_time[0], 1ull); atomicAdd(&g_gen_time[1], tk1 - tk0); atomicAdd(&g_gen_time[2], tk2 - tk1);
+            atomicAdd(&g_gen_time[3], tk3 - tk2); atomicAdd(&g_gen_time[6], (unsigned long long)nh);
+        }
+#endif
     }
 }
 
