@@ -57,12 +57,39 @@ def _check_input(x, name):
     _check(x.is_contiguous(), f"{name} must be contiguous")
 
 
+# The wrappers below are on the path of every op call: at 4096 x 513 samples find_visited_cells is an 18 us kernel behind what
+# used to be 21-27 us of Python per call (profiles/r06av_ops_host.txt), so the helpers avoid object construction: the raw
+# stream handle instead of a torch Stream object, plain ints for pointers (every entry point has ctypes argtypes, which
+# convert an int to a void pointer), and a device context only when the tracer's device is not the current one.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device) -> int:
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream
 
 
 def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(device):
+    """`with _on(dev):` = torch.cuda.device(dev) when another device is current, nothing otherwise."""
+    if device.index is None or torch.cuda.current_device() == device.index:
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 class TetrahedraTracer:
@@ -191,12 +218,14 @@ class TetrahedraTracer:
         """py_binding.cpp:163-216.  Addition: `ray_index` (int32 [r]) matches a SUBSET of the traced rays without
         compacting their rows first -- `distances` and the results are [r, S...], the trace tensors stay [R, M...];
         `count` (int32 [1] device tensor, with ray_index): only the first count[0] rows are matched (compact_hits)."""
+        sdev = self._device
         for x, name in ((num_visited_cells, "num_visited_cells"), (visited_cells, "visited_cells"),
                         (barycentric_coordinates, "barycentric_coordinates"),
                         (hit_distances, "hit_distances"), (distances, "distances"),
                         (vertex_indices, "vertex_indices")):
-            _check_input(x, name)
-            _check(x.device == self._device, f"{name} must be on the same device")
+            if not (isinstance(x, torch.Tensor) and x.is_cuda and x.is_contiguous() and x.device == sdev):
+                _check_input(x, name)                                   # (raises with the reference's messages)
+                _check(x.device == sdev, f"{name} must be on the same device")
         _check(distances.dtype == torch.float32, "distances must have float32 type")
         R = num_visited_cells.size(0)
         _check(count is None or ray_index is not None, "find_visited_cells: `count` needs `ray_index` (it counts rows of that list)")
@@ -221,7 +250,7 @@ class TetrahedraTracer:
         barycentric_coordinates_out = _empty((R, S, 3), dtype=torch.float32, device=dev)
         vertex_indices_out = _empty((R, S, 4), dtype=torch.int32, device=dev)
         # the C entry points take no device argument: launch with the tracer's device current (its stream, its pointers)
-        with torch.cuda.device(dev):
+        with _on(dev):
             if ray_index is None:
                 _lib.check(self._lib.tn_find_matched_cells(
                     R, S, M, _ptr(num_visited_cells), _ptr(visited_cells), _ptr(hit_distances),
@@ -331,7 +360,7 @@ def fill_rows(visited_cells, barycentric_coordinates, hit_distances, vertex_indi
         _check_input(x, name)
     R, M = visited_cells.shape
     dev = visited_cells.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.load().tn_fill_rows(R, M, int(first_slot), _ptr(visited_cells), _ptr(barycentric_coordinates),
                                             _ptr(hit_distances), _ptr(vertex_indices), _stream(dev)))
 
@@ -387,7 +416,7 @@ def invalidate_field_cache(field=None):
 def _transpose_field(field):
     Fd, V = field.shape
     ft = _empty((V, Fd), dtype=torch.float32, device=field.device)
-    with torch.cuda.device(field.device):
+    with _on(field.device):
         _lib.check(_lib.load().tn_transpose_f32(Fd, V, _ptr(field), _ptr(ft), _stream(field.device)))
     return ft
 
@@ -435,7 +464,7 @@ def interpolate_values(vertex_indices, barycentric_coordinates, field):
     Fd = field.size(0)
     result = _empty((Fd,) + tuple(vertex_indices.shape[:-1]), dtype=field.dtype, device=field.device)
     ft = field_vertex_major(field)
-    with torch.cuda.device(field.device):
+    with _on(field.device):
         _lib.check(_lib.load().tn_interpolate_values_vm(
             D, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates), _ptr(ft), _ptr(result), _stream(field.device)))
     return result.moveaxis(0, -1)
@@ -478,7 +507,7 @@ def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, 
     lib = _lib.load()
     if grad_in.moveaxis(-1, 0).is_contiguous() and Fd > 1 and not deterministic_gradients():
         # the reference's layout: a [Fd, n] buffer viewed as [..., Fd] (what py_binding.cpp:369 produces)
-        with torch.cuda.device(field.device):
+        with _on(field.device):
             _lib.check(lib.tn_interpolate_values_backward(D, V, n, Fd, _ptr(vertex_indices), _ptr(barycentric_coordinates),
                                                           _ptr(grad_in.moveaxis(-1, 0)), _ptr(grad_field_out),
                                                           _stream(field.device)))
@@ -486,7 +515,7 @@ def interpolate_values_backward(vertex_indices, barycentric_coordinates, field, 
     # sample-major rows, the usual autograd gradient: consumed as is, accumulated vertex-major, transposed back once
     g = grad_in.contiguous()
     grad_vm = torch.zeros((V, Fd), dtype=torch.float32, device=grad_in.device)
-    with torch.cuda.device(field.device):
+    with _on(field.device):
         _gather_adjoint_vm(lib, D, V, n, Fd, vertex_indices, barycentric_coordinates, g, grad_vm, _stream(field.device))
         _lib.check(lib.tn_transpose_f32(V, Fd, _ptr(grad_vm), _ptr(grad_field_out), _stream(field.device)))
     return grad_field_out
@@ -559,7 +588,7 @@ class FusedMLP:
             _check(w.dtype == torch.float32 and tuple(w.shape) == shp, f"{name} must be f32 {shp}")
             keep.append(w)
             setattr(st, name, w.data_ptr())
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(self._lib.tn_mlp_set_weights(self._h, C.byref(st), _stream(self.device)))
         del keep
         self._packed = torch.cuda.Event()
@@ -624,7 +653,7 @@ def mlp_forward(feats_fm, dirs, weights, samples_per_ray, mode="fp32"):
     dev = feats_fm.device
     sigma = _empty((n,), dtype=torch.float32, device=dev)
     rgb = _empty((n, 3), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.load().tn_mlp_forward(m.handle, n, S, _ptr(feats_fm), _ptr(dirs), _mode(mode), _ptr(sigma), _ptr(rgb),
                                               _stream(dev)))
     return sigma, rgb
@@ -664,7 +693,7 @@ def mlp_forward_gather(vertex_indices, barycentric_coordinates, field, dirs, wei
     field_vm = field_vertex_major(field)
     sigma = _empty((n,), dtype=torch.float32, device=dev)
     rgb = None if density_only else _empty((n, 3), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.load().tn_mlp_forward_gather(m.handle, n, S, _ptr(vertex_indices), _ptr(barycentric_coordinates),
                                                      _ptr(field_vm), _ptr(dirs), _mode(mode), _ptr(sigma), _ptr(rgb),
                                                      _ptr(None if density_only else _ray_bias(ray_head_bias, n // S, dev)),
@@ -713,7 +742,7 @@ def render_rays(trace_lists, order, count, field, directions, weights, num_sampl
     hb = None
     if ray_head_bias is not None:
         hb = _ray_bias(ray_head_bias, R, dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.load().tn_render_rays_ex(
             m.handle, M, _ptr(nv), _ptr(dist), _ptr(bary), _ptr(verts), _ptr(order), _ptr(count), order.numel(), S, Sf, 1 if biased else 0,
             _ptr(_linspace_table(S, dev)), _ptr(_quantile_table(Sf + 1, True, dev)) if Sf else None, float(histogram_padding), float(eps),
@@ -751,7 +780,7 @@ def compact_hits(num_visited_cells, want_padded=False):
     padded = _empty((R,), dtype=torch.int32, device=dev) if want_padded else None
     n_scratch = 2 * ((R + 2047) // 2048)
     scratch = _empty((max(n_scratch, 1),), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.load().tn_compact_hits(R, _ptr(num_visited_cells), _ptr(order), _ptr(count), _ptr(padded), _ptr(scratch),
                                                scratch.numel(), _stream(dev)))
     return (order, count, padded) if want_padded else (order, count)
@@ -773,7 +802,7 @@ def sample_coarse(num_visited_cells, hit_distances, ray_index, num_samples, bias
         _check(t_rand.dtype == torch.float32 and tuple(t_rand.shape) == (r, S + 1), "t_rand must be f32 [r, S+1]")
     edges = _empty((r, S + 1), dtype=torch.float32, device=dev)
     near_far = _empty((r, 2), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.load().tn_sample_coarse(r, S, M, _ptr(ray_index), _ptr(num_visited_cells), _ptr(hit_distances),
                                                 _ptr(_linspace_table(S, dev)), _ptr(t_rand), 1 if biased else 0, _ptr(edges),
                                                 _ptr(near_far), _ptr(count), _stream(dev)))
@@ -795,7 +824,7 @@ def sample_pdf(edges, weights, near_far, num_fine, u_rand=None, histogram_paddin
         _check_input(u_rand, "u_rand")
         _check(u_rand.dtype == torch.float32 and tuple(u_rand.shape) == (r, nb), "u_rand must be f32 [r, num_fine+1]")
     out = _empty((r, S + 1 + nb), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.load().tn_sample_pdf(r, S, int(num_fine), _ptr(edges), _ptr(weights), _ptr(near_far),
                                              _ptr(_quantile_table(nb, u_rand is None, dev)), _ptr(u_rand), float(histogram_padding),
                                              float(eps), _ptr(out), _ptr(count), _stream(dev)))
@@ -816,7 +845,7 @@ def composite(sigma, rgb, edges, background=1.0, return_weights=False, clamp=Fal
     dev = sigma.device
     if rgb is None:
         weights = _empty((R, S), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), None, _ptr(edges), None, None, None, None,
                                                 _ptr(weights), None, _ptr(count), _stream(dev)))
         return weights
@@ -826,7 +855,7 @@ def composite(sigma, rgb, edges, background=1.0, return_weights=False, clamp=Fal
         for x, name in ((o_rgb, "rgb"), (o_acc, "accumulation"), (o_depth, "depth")):
             _check_input(x, name)
             _check(x.dtype == torch.float32, f"{name} must have float32 type")
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), _ptr(rgb), _ptr(edges), _background(background, clamp), _ptr(o_rgb),
                                                 _ptr(o_acc), _ptr(o_depth), None, _ptr(ray_index), _ptr(count), _stream(dev)))
         return None
@@ -834,7 +863,7 @@ def composite(sigma, rgb, edges, background=1.0, return_weights=False, clamp=Fal
     acc = _empty((R, 1), dtype=torch.float32, device=dev)
     depth = _empty((R, 1), dtype=torch.float32, device=dev)
     weights = _empty((R, S), dtype=torch.float32, device=dev) if return_weights else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.load().tn_composite(R, S, _ptr(sigma), _ptr(rgb), _ptr(edges), _background(background, clamp), _ptr(out_rgb),
                                             _ptr(acc), _ptr(depth), _ptr(weights), None, _ptr(count), _stream(dev)))
     return (out_rgb, acc, depth, weights) if return_weights else (out_rgb, acc, depth)
@@ -877,7 +906,7 @@ def mlp_forward_gather_train(vertex_indices, barycentric_coordinates, field, dir
     a = sv.acts
     bs = _MlpBackwardBuffers(a[0:64].data_ptr(), a[64:192].data_ptr(), a[192:320].data_ptr(), a[320:448].data_ptr(),
                              a[448:576].data_ptr(), sv.masks.data_ptr(), None, None, None, None, None, None)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.load().tn_mlp_forward_gather_train(m.handle, n, S, _ptr(vertex_indices), _ptr(barycentric_coordinates),
                                                            _ptr(field_vm), _ptr(dirs.contiguous()), _ptr(sv.sigma), _ptr(sv.rgb),
                                                            C.byref(bs), _ptr(_ray_bias(ray_head_bias, n // S, dev)), _stream(dev)))
@@ -921,7 +950,7 @@ def mlp_backward(saved, vertex_indices, barycentric_coordinates, field, dirs, we
                              a[448:576].data_ptr(), saved.masks.data_ptr(), buf[0:128].data_ptr(), buf[128:256].data_ptr(),
                              buf[256:384].data_ptr(), buf[384:512].data_ptr(), buf[512:516].data_ptr(), rows.data_ptr())
     stream = _stream(dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.tn_mlp_backward(mh.handle, n, _ptr(sigma.contiguous()), _ptr(rgb.contiguous()), _ptr(d_sigma), _ptr(d_rgb),
                                        C.byref(bs), stream))
         _lib.check(lib.tn_mlp_param_grads(mh.handle, n, S, _ptr(dirs), C.byref(bs), C.byref(gs), stream))
@@ -946,7 +975,7 @@ def composite_backward(sigma, rgb, edges, d_out_rgb, d_out_acc, background=1.0):
     d_rgb = _empty((R, S, 3), dtype=torch.float32, device=dev)
     g_rgb = None if d_out_rgb is None else d_out_rgb.contiguous().float()
     g_acc = None if d_out_acc is None else d_out_acc.contiguous().float()
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.load().tn_composite_backward(R, S, _ptr(sigma.contiguous()), _ptr(rgb.contiguous()), _ptr(edges.contiguous()),
                                                      _background(background), _ptr(g_rgb), _ptr(g_acc), _ptr(d_sigma), _ptr(d_rgb),
                                                      _stream(dev)))
@@ -991,7 +1020,7 @@ def gather_uint32(self, dim, index):
     _check(dim == 0, "dim must be 0")
     _check(self.dtype in (torch.float32, torch.float64), "self must be float32 or float64")
     result = _empty(index.shape, dtype=self.dtype, device=self.device)
-    with torch.cuda.device(self.device):
+    with _on(self.device):
         _lib.check(_lib.load().tn_gather_uint32(self.element_size(), self.numel(), index.numel(), _ptr(index), _ptr(self),
                                                 _ptr(result), _stream(self.device)))
     return result
@@ -1014,6 +1043,6 @@ def scatter_ema_uint32(self, dim, index, decay, values):
     _check(index.dim() == self.dim(), "self and index must have the same number of dimensions")
     _check(values.shape == index.shape, "values and index must have the same shape")
     _check(self.dtype in (torch.float32, torch.float64), "self must be float32 or float64")
-    with torch.cuda.device(self.device):
+    with _on(self.device):
         _lib.check(_lib.load().tn_scatter_ema_uint32(self.element_size(), self.numel(), index.numel(), _ptr(index),
                                                      float(decay), _ptr(values), _ptr(self), _stream(self.device)))
