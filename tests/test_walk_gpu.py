@@ -575,3 +575,53 @@ def test_flat_hull_search_equals_the_threaded_tree(tn, device, oracle, scenes, m
     want = ot.trace_rays(np.ascontiguousarray(o[sl]), np.ascontiguousarray(d[sl]), M)
     for k in KEYS:
         assert _bits_equal(outs[1][k][sl], want[k]), k
+
+
+@pytest.mark.parametrize("M", [4, 16, 32, 64, 128, 256, 512, 2048])
+def test_fill_rows_writes_the_tail_constants_and_nothing_else(tn, device, M):
+    """tn_fill_rows (k_fill_linear: one linear stream per array, one 16-byte store per thread): slots >= first_slot of every
+    row get the tail constants (cells / vertex ids 0xFFFFFFFF, distances / barycentrics 0), slots below keep their bytes;
+    with and without the vertex-id array; a first slot that is not a multiple of 32 is refused; first_slot >= M is a no-op."""
+    import torch
+
+    cpp = tn.cpp
+    R = 1237 if M <= 512 else 301
+    for first in sorted({0, 32, 64, max(M - 32, 0)} & set(range(0, M + 1, 32))) + ([M] if M % 32 == 0 else []):
+        for with_verts in (True, False):
+            vc = torch.full((R, M), 7, dtype=torch.int32, device=device)
+            bc = torch.full((R, M, 2, 3), 3.5, dtype=torch.float32, device=device)
+            hd = torch.full((R, M, 2), 2.5, dtype=torch.float32, device=device)
+            vi = torch.full((R, M, 4), 9, dtype=torch.int32, device=device) if with_verts else None
+            cpp.fill_rows(vc, bc, hd, vi, first)
+            torch.cuda.synchronize()
+            f = min(first, M)
+            assert bool((vc[:, :f] == 7).all()) and bool((vc[:, f:] == -1).all()), (M, first)
+            assert bool((bc[:, :f] == 3.5).all()) and bool((bc[:, f:] == 0).all()), (M, first)
+            assert bool((hd[:, :f] == 2.5).all()) and bool((hd[:, f:] == 0).all()), (M, first)
+            if with_verts:
+                assert bool((vi[:, :f] == 9).all()) and bool((vi[:, f:] == -1).all()), (M, first)
+    if M >= 64:
+        vc = torch.zeros((4, M), dtype=torch.int32, device=device)
+        with pytest.raises(RuntimeError):
+            cpp.fill_rows(vc, torch.zeros((4, M, 2, 3), device=device), torch.zeros((4, M, 2), device=device), None, 16)
+
+
+@pytest.mark.parametrize("M", [16, 64, 128])
+def test_tail_fill_variants_agree_at_small_max_ray_triangles(tn, device, scenes, M):
+    """The three tail fills (a block per row: default; one linear stream per array: -2, whose row lookup is per lane below
+    M = 256; persistent waves: 512) and the BVH path write identical rows at M = 16 / 64 / 128 (rays with more than M - 1
+    faces included: their rows come from the BVH path's overflow rule)."""
+    pts, cells = scenes.random_mesh(4000, 9)
+    o, d = scenes.outside_in_rays(30000, 10)
+    ref = None
+    for opts in ({"walk": 0}, {"fill_blocks": -1}, {"fill_blocks": -2}, {"fill_blocks": 512}, {"fill_blocks": -2, "spec_fill": 1, "spec_k0": 32}):
+        tr = _tracer(tn, device, pts, cells, walk=opts.get("walk", 2) != 0)
+        for k, v in opts.items():
+            if k != "walk":
+                tr.set_option(k, v)
+        out = _trace(tr, device, o, d, M)
+        if ref is None:
+            ref = out
+            continue
+        for k in KEYS:
+            assert _bits_equal(out[k], ref[k]), (opts, k)
