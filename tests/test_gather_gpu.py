@@ -214,3 +214,38 @@ def test_stale_field_cache_is_caught_by_the_debug_check(tn, device):
             cpp._CHECK_CACHES = old
     finally:
         cpp.unregister_field(field)
+
+
+@pytest.mark.parametrize("D,Fd", [(4, 64), (3, 7), (2, 1)])
+def test_backward_rows_entry_point_equals_the_feature_major_one(tn, device, D, Fd):
+    """tn_interpolate_values_backward_rows (the gradient in autograd's own [n, F] layout, straight through the C-ABI: no Python
+    wrapper routes to it) against tn_interpolate_values_backward on the transposed copy the reference makes
+    (py_binding.cpp:369): the same sums up to the order of the atomic additions."""
+    import ctypes as C
+    import importlib
+
+    import torch
+
+    lib = importlib.import_module("tetra-nerf_amd._lib").load()
+    torch.manual_seed(D * 100 + Fd)
+    V, n = 500, 6000
+    vi = torch.randint(0, V, (n, D), dtype=torch.int32, device=device)
+    vi[::17, 0] = -1                                   # empty slots (0xFFFFFFFF) are skipped
+    bc = torch.rand(n, D - 1, device=device) / D
+    g_rows = torch.randn(n, Fd, device=device)
+    g_fm = g_rows.t().contiguous()
+    out_rows = torch.full((Fd, V), float("nan"), device=device)
+    out_fm = torch.full((Fd, V), float("nan"), device=device)
+    st = torch.cuda.current_stream(device).cuda_stream
+    assert lib.tn_interpolate_values_backward_rows(D, V, n, Fd, vi.data_ptr(), bc.data_ptr(), g_rows.data_ptr(), out_rows.data_ptr(), st) == 0
+    assert lib.tn_interpolate_values_backward(D, V, n, Fd, vi.data_ptr(), bc.data_ptr(), g_fm.data_ptr(), out_fm.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out_rows).all()) and bool(torch.isfinite(out_fm).all())      # fully written
+    assert float((out_rows - out_fm).abs().max()) <= 2e-5 * max(1.0, float(out_fm.abs().max()))
+    # and the definition: scatter-add of w_k * g over the vertices
+    w = torch.cat([1.0 - bc.sum(-1, keepdim=True), bc], -1).double()
+    want = torch.zeros(V, Fd, dtype=torch.float64, device=device)
+    for k in range(D):
+        ok = vi[:, k] >= 0
+        want.index_add_(0, vi[ok, k].long(), w[ok, k:k + 1] * g_rows[ok].double())
+    assert float((out_rows.double() - want.t()).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))

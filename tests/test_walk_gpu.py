@@ -625,3 +625,29 @@ def test_tail_fill_variants_agree_at_small_max_ray_triangles(tn, device, scenes,
             continue
         for k in KEYS:
             assert _bits_equal(out[k], ref[k]), (opts, k)
+
+
+def test_timing_option_serialises_the_same_kernels(tn, device, scenes):
+    """set_option("timing", 1) runs the kernels of a one-chunk walk call serialised on the caller's stream with an event after
+    each (tn_trace_timings): same rows, every stage that ran has a positive time, the stages add up to no more than the call."""
+    import torch
+
+    pts, cells = scenes.random_mesh(6000, 3)
+    o, d = scenes.outside_in_rays(60000, 5)
+    tr = _tracer(tn, device, pts, cells, walk=True)
+    a = _trace(tr, device, o, d, 256)
+    tr.set_option("timing", 1)
+    oo, dd = torch.from_numpy(o).to(device), torch.from_numpy(d).to(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = tr.trace_rays(oo, dd, 256)
+    e1.record()
+    torch.cuda.synchronize()
+    t = tr.trace_timings()
+    tr.set_option("timing", 0)
+    for k in KEYS:
+        assert _bits_equal(out[k].cpu().numpy(), a[k]), k
+    assert set(t) == set(tr.TIMING_KEYS)
+    assert t["walk"] > 0 and t["segment_writer"] > 0 and t["tail_fill"] > 0, t
+    assert all(v >= 0 for v in t.values()), t
+    assert sum(t.values()) <= e0.elapsed_time(e1) * 1.05 + 0.05, (t, e0.elapsed_time(e1))
