@@ -219,6 +219,15 @@ def test_reference_scale_mesh_one_million_points(tn, device, oracle, scenes):
     ref = _trace(tb, device, o, d, M)
     for k in KEYS:
         assert torch.equal(out[k].view(torch.int32), ref[k].view(torch.int32)), f"1M points, walk vs BVH path: {k}"
+    # round 6: from 4M tets on the walk takes batches of 6144 rays and more (the BVH path's LDS hit arrays grow with the mesh):
+    # an 8192-ray batch goes through the walk, a 4096-ray batch through the BVH, both equal the BVH path's rows
+    for nb, walked in ((8192, True), (4096, False)):
+        bo, bd = np.ascontiguousarray(ro[:nb]), np.ascontiguousarray(rd[:nb])
+        got = _trace(tr, device, bo, bd, M)
+        assert (tr.trace_stats()["walk"] > 0) == walked, (nb, tr.trace_stats())
+        want = _trace(tb, device, bo, bd, M)
+        for k in KEYS:
+            assert torch.equal(got[k].view(torch.int32), want[k].view(torch.int32)), f"1M points, {nb}-ray batch: {k}"
     del ref, tb
     rows = np.sort(np.concatenate([np.random.default_rng(3).choice(len(fo), 6144, replace=False), len(fo) + np.arange(2048)]))
     _compare(out, _oracle(oracle, pts, cells), o, d, M, rows=rows, chunk=8192, ctx="1M points")
