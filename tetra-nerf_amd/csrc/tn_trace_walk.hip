@@ -1224,9 +1224,11 @@ void launch_trace_walk(const WalkParams &p, hipStream_t stream, size_t lds_reser
     const uint32_t grid = (nblk + unit - 1) / unit * unit;
     // entry search: the flat hull table + the faces in LDS (up to 18 + 48 KB at HULL_FLAT_MAX faces)
     const size_t need = p.n_hull_leaves ? (size_t)(p.n_hull_groups + p.n_hull_leaves) * 32 + (size_t)p.n_hull * 48 : 0;
-    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hull_entry), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    (int)((HULL_FLAT_MAX / 2 + HULL_FLAT_MAX / 16) * 32 + HULL_FLAT_MAX * 48)) == hipSuccess;
-    if (need > 64 * 1024 && !big_lds) throw Error("k_hull_entry: the device refused " + std::to_string(need) + " bytes of dynamic LDS");
+    // above 64 KB of dynamic LDS only by opt-in, per device (a process may hold tracers on several): set whenever it is needed
+    if (need > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hull_entry), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((HULL_FLAT_MAX / 2 + HULL_FLAT_MAX / 16) * 32 + HULL_FLAT_MAX * 48)) != hipSuccess)
+        throw Error("k_hull_entry: the device refused " + std::to_string(need) + " bytes of dynamic LDS");
     hipLaunchKernelGGL(k_hull_entry, dim3(grid), dim3(WALK_BLOCK), need, stream, p);
     if (lds_reserve > 64 * 1024) lds_reserve = 64 * 1024;
     if (p.cert_ends == 1u) hipLaunchKernelGGL(k_trace_walk<OrderR6>, dim3(grid), dim3(WALK_BLOCK), lds_reserve, stream, p);
